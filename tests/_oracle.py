@@ -1,0 +1,155 @@
+"""ctypes binding of the ORACLE (oracle/libdexref.so) and fixture helpers -- tests only."""
+import ctypes as C
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF_BIN = os.path.join(ORACLE_DIR, "_ref")
+
+REF_DEL, REF_INS, REF_MRG, REF_SUB, REF_DRUN, REF_SRUN = range(6)
+
+
+class QVStats(C.Structure):
+    _fields_ = [("hist", (C.c_uint64 * 256) * 6), ("totChar", C.c_uint64),
+                ("delChar", C.c_int32), ("subChar", C.c_int32),
+                ("del_first", C.c_int64), ("sub_first", C.c_int64), ("nentries", C.c_int64)]
+
+
+class Scheme(C.Structure):
+    _fields_ = [("type", C.c_int32), ("bits", C.c_uint32 * 256), ("lens", C.c_int32 * 256)]
+
+
+class Coding(C.Structure):
+    _fields_ = [("s", Scheme * 6), ("delChar", C.c_int32), ("subChar", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "libdexref.so")
+        src = os.path.join(ORACLE_DIR, "dexref.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "libdexref.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        u8p = C.c_char_p
+        for name in ("ref_dexta", "ref_dexar"):
+            getattr(L, name).restype = C.c_long
+            getattr(L, name).argtypes = [u8p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ref_undexta.restype = C.c_long
+        L.ref_undexta.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.ref_undexar.restype = C.c_long
+        L.ref_undexar.argtypes = [u8p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.ref_dexqv.restype = C.c_long
+        L.ref_dexqv.argtypes = [u8p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.ref_undexqv.restype = C.c_long
+        L.ref_undexqv.argtypes = [u8p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t]
+        L.ref_qv_scan.restype = C.c_int
+        L.ref_qv_scan.argtypes = [u8p, C.c_size_t, C.POINTER(QVStats)]
+        L.ref_qv_create.restype = C.c_int
+        L.ref_qv_create.argtypes = [C.POINTER(QVStats), C.c_int, C.POINTER(Coding)]
+        L.ref_huffman.restype = C.c_int
+        L.ref_huffman.argtypes = [C.POINTER(C.c_uint64), C.POINTER(Scheme), C.POINTER(Scheme)]
+        L.ref_qv_write_coding.restype = C.c_long
+        L.ref_qv_write_coding.argtypes = [C.POINTER(Coding), C.c_char_p, C.c_void_p, C.c_size_t]
+        L.ref_qv_encode_entry.restype = C.c_long
+        L.ref_qv_encode_entry.argtypes = [C.POINTER(Coding), C.c_int, C.c_int] + [C.c_void_p] * 5 + \
+                                         [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def _call(fn, data, cap, *mid):
+    buf = C.create_string_buffer(cap)
+    n = fn(data, len(data), *mid, buf, cap)
+    if n < 0:
+        raise ValueError(f"{fn.__name__} -> {n}")
+    return buf.raw[:n]
+
+
+def dexta(txt):   return _call(lib().ref_dexta, txt, len(txt) // 3 + 4096)
+def dexar(txt):   return _call(lib().ref_dexar, txt, len(txt) // 3 + 4096)
+def undexta(img, upper=False, width=80): return _call(lib().ref_undexta, img, 6 * len(img) + 4096, int(upper), width)
+def undexar(img, width=80):              return _call(lib().ref_undexar, img, 6 * len(img) + 4096, width)
+def dexqv(txt, lossy=False):             return _call(lib().ref_dexqv, txt, 2 * len(txt) + 65536, int(lossy))
+def undexqv(img, upper=False):           return _call(lib().ref_undexqv, img, 12 * len(img) + 65536, int(upper))
+
+
+def qv_scan(txt):
+    st = QVStats()
+    r = lib().ref_qv_scan(txt, len(txt), C.byref(st))
+    if r < 0:
+        raise ValueError(f"ref_qv_scan -> {r}")
+    return st
+
+
+def qv_create(st, lossy=False):
+    c = Coding()
+    r = lib().ref_qv_create(C.byref(st), int(lossy), C.byref(c))
+    if r < 0:
+        raise ValueError(f"ref_qv_create -> {r}")
+    return c
+
+
+def qv_encode_entry(coding, lossy, lines):
+    """lines: uint8 [5, L] -> (bytes, seg[5])"""
+    lines = np.ascontiguousarray(lines, dtype=np.uint8)
+    L = lines.shape[1]
+    cap = 8 * L + 64
+    buf = C.create_string_buffer(cap)
+    seg = (C.c_uint32 * 5)()
+    ptr = [lines[r].ctypes.data for r in range(5)]
+    n = lib().ref_qv_encode_entry(C.byref(coding), int(lossy), L, *ptr, buf, cap, seg)
+    if n < 0:
+        raise ValueError(f"ref_qv_encode_entry -> {n}")
+    return buf.raw[:n], list(seg)
+
+
+def hist_array(st):
+    return np.ctypeslib.as_array(st.hist).reshape(6, 256).copy()
+
+
+# ---- fixtures ------------------------------------------------------------------------------
+
+def golden(name):
+    p = os.path.join(GOLDEN, name)
+    if os.path.exists(p):
+        with open(p, "rb") as f:
+            return f.read()
+    with gzip.open(p + ".gz", "rb") as f:
+        return f.read()
+
+
+def cases(kind=None):
+    with open(os.path.join(GOLDEN, "cases.json")) as f:
+        cs = json.load(f)
+    return [c for c in cs if kind is None or c["kind"] == kind]
+
+
+def hashes():
+    with open(os.path.join(GOLDEN, "hashes.json")) as f:
+        return json.load(f)
+
+
+def have_ref():
+    return os.path.isfile(os.path.join(REF_BIN, "dexqv"))
+
+
+def run_ref(tool, flags, src_bytes, src_ext, dst_ext, tmpdir):
+    """Run a real reference tool (oracle/_ref) on bytes; returns the produced file's bytes."""
+    src = os.path.join(str(tmpdir), "x" + src_ext)
+    with open(src, "wb") as f:
+        f.write(src_bytes)
+    r = subprocess.run([os.path.join(REF_BIN, tool), "-k", *flags, src], capture_output=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{tool}: exit {r.returncode}: {r.stderr.decode()}")
+    with open(os.path.join(str(tmpdir), "x" + dst_ext), "rb") as f:
+        return f.read()
