@@ -1,0 +1,47 @@
+# Build of the MI355X-native DEXTRACTOR codecs.
+#   make lib      dextractor_amd/libdexgpu.so   (HIP kernels + C-ABI, gfx950)
+#   make cli      dextractor_amd/bin/{dexta,undexta,dexar,undexar,dexqv,undexqv}
+#   make oracle   oracle/libdexref.so (+ oracle/_ref/* when /root/reference is present)  [tests only]
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+CSRC     = dextractor_amd/csrc
+BUILD    = build
+LIB      = dextractor_amd/libdexgpu.so
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+CFLAGS   = -O2 -fPIC -Iinclude -Wall -Wextra
+
+HIP_SRC  = dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth
+HIP_OBJ  = $(HIP_SRC:%=$(BUILD)/%.o)
+C_OBJ    = $(BUILD)/dx_host.o $(BUILD)/dx_files.o
+TOOLS    = dexta undexta dexar undexar dexqv undexqv
+
+all: lib cli
+
+lib: $(LIB)
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/dx_internal.hpp $(CSRC)/dx_device.hpp include/dexgpu.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(BUILD)/%.o: $(CSRC)/%.c include/dexgpu.h
+	@mkdir -p $(BUILD)
+	$(CC) $(CFLAGS) -c $< -o $@
+
+$(LIB): $(HIP_OBJ) $(C_OBJ)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -Wl,-rpath,/opt/rocm/lib -Wl,-soname,libdexgpu.so
+
+cli: $(LIB) $(TOOLS:%=dextractor_amd/bin/%)
+
+dextractor_amd/bin/%: $(CSRC)/cli/%.c $(CSRC)/cli/cli_common.c $(CSRC)/cli/cli_common.h $(LIB)
+	@mkdir -p dextractor_amd/bin
+	$(CC) -O2 -Wall -Wextra -Iinclude -I$(CSRC)/cli -o $@ $< $(CSRC)/cli/cli_common.c \
+	      -Ldextractor_amd -ldexgpu -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,/opt/rocm/lib -lm
+
+oracle:
+	$(MAKE) -C oracle all
+
+clean:
+	rm -rf $(BUILD) $(LIB) dextractor_amd/bin
+
+.PHONY: all lib cli oracle clean

@@ -1,0 +1,118 @@
+"""ctypes binding of libdexgpu.so (the C-ABI of include/dexgpu.h).
+
+The HIP library is the product: there is no CPU fallback.  Loading fails loudly when the shared
+object has not been built (`make lib` or `python -c 'import __graft_entry__ as g; g.build()'`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdexgpu.so")
+
+DX_OK = 0
+ERR_NAMES = {-1: "DX_E_ARG", -2: "DX_E_HIP", -3: "DX_E_FORMAT", -4: "DX_E_DEGENERATE",
+             -5: "DX_E_UNSUPPORTED", -6: "DX_E_NOMEM", -7: "DX_E_MISMATCH", -8: "DX_E_SPACE"}
+
+DX_ALPHA_BASES, DX_ALPHA_ARROW = 0, 1
+DX_LETTERS_LOWER, DX_LETTERS_UPPER, DX_LETTERS_ARROW = 0, 1, 2
+DX_DEL, DX_INS, DX_MRG, DX_SUB, DX_DRUN, DX_SRUN = range(6)
+KERNELS = ["k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
+           "k_qv_encode", "k_qv_decode", "k_synth"]
+
+
+class QVBatch(C.Structure):
+    _fields_ = [("d_text", C.c_void_p), ("d_off", C.c_void_p), ("d_len", C.c_void_p),
+                ("n", C.c_uint64), ("line_pad", C.c_uint32)]
+
+
+class QVParams(C.Structure):
+    _fields_ = [("delChar", C.c_int32), ("subChar", C.c_int32),
+                ("del_first", C.c_int64), ("sub_first", C.c_int64)]
+
+
+class Scheme(C.Structure):
+    _fields_ = [("type", C.c_int32), ("bits", C.c_uint32 * 256), ("lens", C.c_int32 * 256)]
+
+
+class QVCoding(C.Structure):
+    _fields_ = [("s", Scheme * 6), ("delChar", C.c_int32), ("subChar", C.c_int32)]
+
+
+HIST = (C.c_uint64 * 256) * 6
+
+# name -> (restype, argtypes); every symbol include/dexgpu.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "dx_device_count": (C.c_int, []),
+    "dx_open": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "dx_close": (None, [_P]),
+    "dx_last_error": (C.c_char_p, [_P]),
+    "dx_set_stream": (C.c_int, [_P, _P]),
+    "dx_sync": (C.c_int, [_P]),
+    "dx_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "dx_free": (C.c_int, [_P, _P]),
+    "dx_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "dx_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "dx_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
+    "dx_profile": (C.c_int, [_P, C.c_int]),
+    "dx_profile_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "dx_kernel_name": (C.c_char_p, [C.c_int]),
+    "dx_pack2_encode": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_uint64, _P, _P, _P, _P]),
+    "dx_pack2_decode": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_uint64, C.c_uint32, _P, _P]),
+    "dx_frame_bound": (C.c_size_t, [_P, C.c_uint64, C.c_int32, C.c_int]),
+    "dx_frame_headers": (C.c_int, [_P, _P, C.c_uint64, C.c_int, C.POINTER(C.c_int32), _P, _P]),
+    "dx_snr_to_cnr": (C.c_uint16, [C.c_float]),
+    "dx_index_quiva": (C.c_int, [_P, C.c_size_t, C.c_uint64, _P, _P, _P, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "dx_index_seq": (C.c_int, [C.c_int, _P, C.c_size_t, C.c_uint64, _P, _P, _P, _P, _P,
+                               C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64),
+                               C.POINTER(C.c_int)]),
+    "dx_qv_prescan": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams)]),
+    "dx_qv_hist": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams), C.POINTER(HIST),
+                             C.POINTER(C.c_uint64)]),
+    "dx_qv_build": (C.c_int, [C.POINTER(HIST), C.c_uint64, C.POINTER(QVParams), C.c_int, C.POINTER(QVCoding)]),
+    "dx_qv_write_coding": (C.c_int, [C.POINTER(QVCoding), C.c_char_p, C.c_size_t, _P, C.c_size_t,
+                                     C.POINTER(C.c_size_t)]),
+    "dx_qv_read_coding": (C.c_int, [_P, C.c_size_t, C.POINTER(QVCoding), C.POINTER(C.c_int), _P, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]),
+    "dx_qv_set_coding": (C.c_int, [_P, C.POINTER(QVCoding), C.c_int]),
+    "dx_qv_sizes": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, C.POINTER(C.c_uint64)]),
+    "dx_qv_encode": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, _P, _P]),
+    "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
+    "dx_file_pack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),
+                                C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "dx_file_unpack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "dx_file_dexqv": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t),
+                                C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "dx_file_free": (None, [_P]),
+    "dx_synth_quiva": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.c_uint64, _P, _P, _P, _P, C.c_int,
+                                 C.c_char_p, _P]),
+}
+
+_lib = None
+
+
+class DexGPUError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def load() -> C.CDLL:
+    """Load libdexgpu.so and bind every C-ABI symbol; raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library is the product and there is no CPU fallback. "
+            "Build it with `make lib` (hipcc --offload-arch=gfx950) or __graft_entry__.build().")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,264 @@
+"""Python mirror of the libdexgpu C-ABI (thin: device buffers, numpy in/out, errors -> exceptions).
+
+Names follow the reference's tools and functions: `dexta/undexta/dexar/undexar/dexqv` are the
+whole-file drivers (dexta.c ... dexqv.c); `Context.qv_*` are the batch forms of QVcoding_Scan,
+Create_QVcoding and Compress_Next_QVentry (QV.h:48-97).  All compute happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class DevBuf:
+    """A device allocation owned by a Context."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx._chk(ctx.lib.dx_malloc(ctx.h, self.nbytes + 64, C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.dx_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def upload(self, arr) -> "DevBuf":
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        if a.nbytes:
+            self.ctx._chk(self.ctx.lib.dx_h2d(self.ctx.h, self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, dtype=np.uint8, count=None, offset=0) -> np.ndarray:
+        dt = np.dtype(dtype)
+        count = (self.nbytes - offset) // dt.itemsize if count is None else count
+        out = np.empty(count, dtype=dt)
+        if out.nbytes:
+            self.ctx._chk(self.ctx.lib.dx_d2h(self.ctx.h, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def zero(self):
+        self.ctx._chk(self.ctx.lib.dx_memset(self.ctx.h, self.ptr, 0, self.nbytes))
+        return self
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.dx_open(device, C.byref(h))
+        if rc != 0:
+            raise L.DexGPUError(rc, (self.lib.dx_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.dx_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise L.DexGPUError(rc, (self.lib.dx_last_error(self.h) or b"").decode())
+
+    # ---- memory ------------------------------------------------------------------------------
+    def alloc(self, nbytes) -> DevBuf:
+        return DevBuf(self, nbytes)
+
+    def to_device(self, arr) -> DevBuf:
+        a = np.ascontiguousarray(arr)
+        return DevBuf(self, a.nbytes).upload(a)
+
+    def sync(self):
+        self._chk(self.lib.dx_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.dx_set_stream(self.h, stream_ptr))
+
+    # ---- profiling ---------------------------------------------------------------------------
+    def profile(self, enable=True):
+        self._chk(self.lib.dx_profile(self.h, int(enable)))
+
+    def kernel_times(self) -> dict:
+        out = {}
+        for k, name in enumerate(L.KERNELS):
+            ms, cnt = C.c_double(), C.c_uint64()
+            self._chk(self.lib.dx_profile_get(self.h, k, C.byref(ms), C.byref(cnt)))
+            if cnt.value:
+                out[name] = (ms.value, cnt.value)
+        return out
+
+    # ---- 2-bit packers -----------------------------------------------------------------------
+    def pack2_encode(self, alphabet, d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off):
+        self._chk(self.lib.dx_pack2_encode(self.h, alphabet, d_text.ptr, d_off.ptr, d_tlen.ptr, d_nsym.ptr, n,
+                                           d_hdr.ptr if d_hdr else None, d_hdr_off.ptr if d_hdr_off else None,
+                                           d_out.ptr, d_out_off.ptr))
+
+    def pack2_decode(self, letters, d_in, d_in_off, d_nsym, n, width, d_out, d_out_off):
+        self._chk(self.lib.dx_pack2_decode(self.h, letters, d_in.ptr, d_in_off.ptr, d_nsym.ptr, n, width,
+                                           d_out.ptr, d_out_off.ptr))
+
+    # ---- QV coder ----------------------------------------------------------------------------
+    @staticmethod
+    def qv_batch(d_text, d_off, d_len, n, line_pad=1) -> L.QVBatch:
+        return L.QVBatch(d_text.ptr, d_off.ptr, d_len.ptr, n, line_pad)
+
+    def qv_prescan(self, batch, entry0=0, params=None) -> L.QVParams:
+        p = params or L.QVParams(-1, -1, -1, -1)
+        self._chk(self.lib.dx_qv_prescan(self.h, C.byref(batch), entry0, C.byref(p)))
+        return p
+
+    def qv_hist(self, batch, params, entry0=0, hist=None, tot=0):
+        """Returns (hist uint64 [6,256], totChar); adds into `hist`/`tot` when given (shards)."""
+        h = L.HIST()
+        if hist is not None:
+            np.ctypeslib.as_array(h)[:] = hist
+        t = C.c_uint64(tot)
+        self._chk(self.lib.dx_qv_hist(self.h, C.byref(batch), entry0, C.byref(params), C.byref(h), C.byref(t)))
+        return np.ctypeslib.as_array(h).reshape(6, 256).copy(), t.value
+
+    def qv_set_coding(self, coding, lossy=False):
+        self._chk(self.lib.dx_qv_set_coding(self.h, C.byref(coding), int(lossy)))
+
+    def qv_sizes(self, batch, d_hdr_off, d_rec_off) -> int:
+        tot = C.c_uint64()
+        self._chk(self.lib.dx_qv_sizes(self.h, C.byref(batch), d_hdr_off.ptr if d_hdr_off else None,
+                                       d_rec_off.ptr, C.byref(tot)))
+        return tot.value
+
+    def qv_encode(self, batch, d_hdr, d_hdr_off, d_rec_off, d_out, d_seg=None):
+        self._chk(self.lib.dx_qv_encode(self.h, C.byref(batch), d_hdr.ptr if d_hdr else None,
+                                        d_hdr_off.ptr if d_hdr_off else None, d_rec_off.ptr, d_out.ptr,
+                                        d_seg.ptr if d_seg else None))
+
+    def synth_quiva(self, seed, entry0, n, d_off, d_len, d_hdr4, d_lut, del_run, movie, d_text):
+        self._chk(self.lib.dx_synth_quiva(self.h, seed & 0xFFFFFFFF, entry0, n, d_off.ptr, d_len.ptr, d_hdr4.ptr,
+                                          d_lut.ptr, del_run, movie.encode(), d_text.ptr))
+
+    # ---- whole-file drivers (what the CLI tools call) -------------------------------------------
+    def _file_call(self, fn, *args):
+        out, n = C.c_void_p(), C.c_size_t()
+        line, code = C.c_uint64(), C.c_int()
+        extra = (C.byref(line), C.byref(code)) if fn is not self.lib.dx_file_unpack2 else ()
+        rc = fn(self.h, *args, C.byref(out), C.byref(n), *extra)
+        if rc != 0:
+            msg = (self.lib.dx_last_error(self.h) or b"").decode()
+            if rc == -3 and extra:
+                msg = f"line {line.value}: input rejected (DX_IDX code {code.value}) {msg}"
+            raise L.DexGPUError(rc, msg)
+        try:
+            return C.string_at(out.value, n.value)
+        finally:
+            self.lib.dx_file_free(out)
+
+    def dexta(self, fasta: bytes) -> bytes:
+        return self._file_call(self.lib.dx_file_pack2, 0, fasta, len(fasta))
+
+    def dexar(self, arrow: bytes) -> bytes:
+        return self._file_call(self.lib.dx_file_pack2, 1, arrow, len(arrow))
+
+    def undexta(self, img: bytes, upper=False, width=80) -> bytes:
+        return self._file_call(self.lib.dx_file_unpack2, L.DX_LETTERS_UPPER if upper else L.DX_LETTERS_LOWER,
+                               img, len(img), width)
+
+    def undexar(self, img: bytes, width=80) -> bytes:
+        return self._file_call(self.lib.dx_file_unpack2, L.DX_LETTERS_ARROW, img, len(img), width)
+
+    def dexqv(self, quiva: bytes, lossy=False) -> bytes:
+        return self._file_call(self.lib.dx_file_dexqv, quiva, len(quiva), int(lossy))
+
+
+# ---- host-only helpers (no GPU needed) ---------------------------------------------------------
+
+def qv_build(hist, tot, params, lossy=False) -> L.QVCoding:
+    """Create_QVcoding (QV.c:1029-1169) on the host."""
+    lib = L.load()
+    h = L.HIST()
+    np.ctypeslib.as_array(h)[:] = np.asarray(hist, dtype=np.uint64).reshape(6, 256)
+    c = L.QVCoding()
+    rc = lib.dx_qv_build(C.byref(h), int(tot), C.byref(params), int(lossy), C.byref(c))
+    if rc != 0:
+        raise L.DexGPUError(rc, "dx_qv_build")
+    return c
+
+
+def qv_write_coding(coding, prefix: bytes) -> bytes:
+    lib = L.load()
+    n = C.c_size_t()
+    lib.dx_qv_write_coding(C.byref(coding), prefix, len(prefix), None, 0, C.byref(n))
+    buf = C.create_string_buffer(n.value)
+    rc = lib.dx_qv_write_coding(C.byref(coding), prefix, len(prefix), buf, n.value, C.byref(n))
+    if rc != 0:
+        raise L.DexGPUError(rc, "dx_qv_write_coding")
+    return buf.raw[:n.value]
+
+
+def qv_read_coding(img: bytes):
+    """-> (coding, flip, prefix, consumed)"""
+    lib = L.load()
+    c, flip, used = L.QVCoding(), C.c_int(), C.c_size_t()
+    pre = C.create_string_buffer(len(img) + 1)
+    rc = lib.dx_qv_read_coding(img, len(img), C.byref(c), C.byref(flip), pre, len(img) + 1, C.byref(used))
+    if rc != 0:
+        raise L.DexGPUError(rc, "dx_qv_read_coding")
+    return c, flip.value, pre.value, used.value
+
+
+def frame_headers(hdr4, cnr4=None, lwell=0):
+    """-> (blob uint8, off uint64 [n+1], last well)"""
+    lib = L.load()
+    hdr4 = np.ascontiguousarray(hdr4, dtype=np.int32)
+    n = len(hdr4)
+    kind = 0 if cnr4 is None else 1
+    if cnr4 is not None:
+        cnr4 = np.ascontiguousarray(cnr4, dtype=np.uint16)
+    bound = lib.dx_frame_bound(hdr4.ctypes.data, n, lwell, kind)
+    blob = np.zeros(bound + 16, np.uint8)
+    off = np.zeros(n + 1, np.uint64)
+    lw = C.c_int32(lwell)
+    rc = lib.dx_frame_headers(hdr4.ctypes.data, cnr4.ctypes.data if kind else None, n, kind, C.byref(lw),
+                              blob.ctypes.data, off.ctypes.data)
+    if rc != 0:
+        raise L.DexGPUError(rc, "dx_frame_headers")
+    return blob[: int(off[n])], off, lw.value
+
+
+def index_quiva(text: bytes):
+    """-> (off uint64, len uint32, hdr4 int32 [n,4], prefix_len)"""
+    lib = L.load()
+    cnt, pl, line, code = C.c_uint64(), C.c_size_t(), C.c_uint64(), C.c_int()
+    rc = lib.dx_index_quiva(text, len(text), 0, None, None, None, C.byref(cnt), C.byref(pl), C.byref(line), C.byref(code))
+    if rc != 0:
+        raise L.DexGPUError(rc, f"line {line.value}: DX_IDX code {code.value}")
+    n = cnt.value
+    off, ln, hdr = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, 4), np.int32)
+    lib.dx_index_quiva(text, len(text), n, off.ctypes.data, ln.ctypes.data, hdr.ctypes.data, C.byref(cnt),
+                       C.byref(pl), C.byref(line), C.byref(code))
+    return off, ln, hdr, pl.value
+
+
+def index_seq(text: bytes, arrow=False):
+    """-> (off, tlen, nsym, hdr4, cnr4, prefix_len)"""
+    lib = L.load()
+    cnt, pl, line, code = C.c_uint64(), C.c_size_t(), C.c_uint64(), C.c_int()
+    rc = lib.dx_index_seq(int(arrow), text, len(text), 0, None, None, None, None, None, C.byref(cnt), C.byref(pl),
+                          C.byref(line), C.byref(code))
+    if rc != 0:
+        raise L.DexGPUError(rc, f"line {line.value}: DX_IDX code {code.value}")
+    n = cnt.value
+    off, tl, ns = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    hdr, cnr = np.zeros((n, 4), np.int32), np.zeros((n, 4), np.uint16)
+    lib.dx_index_seq(int(arrow), text, len(text), n, off.ctypes.data, tl.ctypes.data, ns.ctypes.data,
+                     hdr.ctypes.data, cnr.ctypes.data, C.byref(cnt), C.byref(pl), C.byref(line), C.byref(code))
+    return off, tl, ns, hdr, cnr, pl.value

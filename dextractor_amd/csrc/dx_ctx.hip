@@ -1,0 +1,226 @@
+// dx_ctx.hip -- context, device memory and per-kernel timing plumbing of libdexgpu.
+#include "dx_internal.hpp"
+
+#include <stdlib.h>
+
+static char g_open_err[512] = "";
+
+int dx_fail(dx_ctx *ctx, int code, const char *fmt, ...)
+{ char *dst = ctx ? ctx->err : g_open_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char *dx_last_error(const dx_ctx *ctx) { return ctx ? ctx->err : g_open_err; }
+
+extern "C" int dx_device_count(void)
+{ int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+extern "C" int dx_open(int device, dx_ctx **out)
+{ if (out == NULL)
+    return dx_fail(NULL, DX_E_ARG, "dx_open: NULL result pointer");
+  *out = NULL;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return dx_fail(NULL, DX_E_HIP, "dx_open: no HIP device available (%s)",
+                   e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n)
+    return dx_fail(NULL, DX_E_ARG, "dx_open: device %d out of range (0..%d)", device, n - 1);
+
+  dx_ctx *ctx = new dx_ctx();
+  ctx->device = device;
+  ctx->err[0] = '\0';
+  ctx->profiling = false;
+  memset(ctx->ms, 0, sizeof(ctx->ms));
+  memset(ctx->launches, 0, sizeof(ctx->launches));
+  ctx->d_tok = NULL;
+  ctx->coding_set = 0;
+  ctx->d_scratch = NULL;
+  ctx->scratch_bytes = 0;
+
+#define OPEN_HIP(call)                                                                       \
+  do { hipError_t e_ = (call);                                                               \
+       if (e_ != hipSuccess)                                                                 \
+         { dx_fail(NULL, DX_E_HIP, "dx_open: %s: %s", #call, hipGetErrorString(e_));         \
+           delete ctx;                                                                       \
+           return DX_E_HIP;                                                                  \
+         }                                                                                   \
+     } while (0)
+
+  OPEN_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  OPEN_HIP(hipGetDeviceProperties(&prop, device));
+  ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  OPEN_HIP(hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking));
+  ctx->stream = ctx->own;
+  OPEN_HIP(hipMalloc((void **) &ctx->d_tok, DX_TOK_WORDS * sizeof(uint32_t)));
+  OPEN_HIP(hipMalloc((void **) &ctx->d_status, 64));
+  OPEN_HIP(hipMalloc((void **) &ctx->d_u64, 64 * sizeof(uint64_t)));
+  OPEN_HIP(hipMemset(ctx->d_status, 0, 64));
+#undef OPEN_HIP
+  *out = ctx;
+  return DX_OK;
+}
+
+extern "C" void dx_close(dx_ctx *ctx)
+{ if (ctx == NULL)
+    return;
+  (void) hipSetDevice(ctx->device);
+  (void) hipStreamSynchronize(ctx->stream);
+  for (auto &p : ctx->pend)
+    { (void) hipEventDestroy(p.a);
+      (void) hipEventDestroy(p.b);
+    }
+  (void) hipFree(ctx->d_tok);
+  (void) hipFree(ctx->d_status);
+  (void) hipFree(ctx->d_u64);
+  (void) hipFree(ctx->d_scratch);
+  (void) hipStreamDestroy(ctx->own);
+  delete ctx;
+}
+
+extern "C" int dx_set_stream(dx_ctx *ctx, void *hip_stream)
+{ if (ctx == NULL) return DX_E_ARG;
+  ctx->stream = hip_stream ? (hipStream_t) hip_stream : ctx->own;
+  return DX_OK;
+}
+
+extern "C" int dx_sync(dx_ctx *ctx)
+{ if (ctx == NULL) return DX_E_ARG;
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DX_OK;
+}
+
+extern "C" int dx_malloc(dx_ctx *ctx, size_t bytes, void **d_ptr)
+{ if (ctx == NULL || d_ptr == NULL) return DX_E_ARG;
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+  if (e != hipSuccess)
+    return dx_fail(ctx, DX_E_NOMEM, "dx_malloc(%zu): %s", bytes, hipGetErrorString(e));
+  return DX_OK;
+}
+
+extern "C" int dx_free(dx_ctx *ctx, void *d_ptr)
+{ if (ctx == NULL) return DX_E_ARG;
+  DX_HIP(ctx, hipFree(d_ptr));
+  return DX_OK;
+}
+
+extern "C" int dx_h2d(dx_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (bytes == 0) return DX_OK;
+  DX_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DX_OK;
+}
+
+extern "C" int dx_d2h(dx_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (bytes == 0) return DX_OK;
+  DX_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return DX_OK;
+}
+
+extern "C" int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (bytes == 0) return DX_OK;
+  DX_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+  return DX_OK;
+}
+
+int dx_scratch(dx_ctx *ctx, size_t bytes, void **p)
+{ if (bytes > ctx->scratch_bytes)
+    { DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_scratch)
+        DX_HIP(ctx, hipFree(ctx->d_scratch));
+      ctx->d_scratch = NULL;
+      ctx->scratch_bytes = 0;
+      size_t want = bytes + bytes / 4 + 4096;
+      hipError_t e = hipMalloc(&ctx->d_scratch, want);
+      if (e != hipSuccess)
+        return dx_fail(ctx, DX_E_NOMEM, "scratch allocation of %zu bytes failed: %s", want,
+                       hipGetErrorString(e));
+      ctx->scratch_bytes = want;
+    }
+  *p = ctx->d_scratch;
+  return DX_OK;
+}
+
+// Number of workgroups for a one-wave-per-unit grid-stride kernel: enough waves to fill the
+// chip (waves_per_cu resident waves on each of the CUs) but never more than the units.
+int dx_grid_waves(dx_ctx *ctx, uint64_t n_units, int waves_per_cu)
+{ uint64_t waves = (uint64_t) ctx->num_cu * (uint64_t) waves_per_cu;
+  if (waves > n_units) waves = n_units;
+  uint64_t blocks = (waves + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK;
+  return blocks ? (int) blocks : 1;
+}
+
+// ---- per-kernel timing --------------------------------------------------------------------
+
+static const char *k_names[DX_K_COUNT] =
+  { "k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
+    "k_qv_encode", "k_qv_decode", "k_synth" };
+
+extern "C" const char *dx_kernel_name(int kernel)
+{ return (kernel >= 0 && kernel < DX_K_COUNT) ? k_names[kernel] : "?"; }
+
+void dx_prof_begin(dx_ctx *ctx, int kernel)
+{ if (!ctx->profiling) return;
+  dx_pending p;
+  p.kernel = kernel;
+  if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)
+    return;
+  (void) hipEventRecord(p.a, ctx->stream);
+  ctx->pend.push_back(p);
+}
+
+void dx_prof_end(dx_ctx *ctx)
+{ if (!ctx->profiling || ctx->pend.empty()) return;
+  (void) hipEventRecord(ctx->pend.back().b, ctx->stream);
+}
+
+static int prof_collect(dx_ctx *ctx)
+{ if (ctx->pend.empty()) return DX_OK;
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto &p : ctx->pend)
+    { float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+        { ctx->ms[p.kernel] += ms;
+          ctx->launches[p.kernel] += 1;
+        }
+      (void) hipEventDestroy(p.a);
+      (void) hipEventDestroy(p.b);
+    }
+  ctx->pend.clear();
+  return DX_OK;
+}
+
+extern "C" int dx_profile(dx_ctx *ctx, int enable)
+{ if (ctx == NULL) return DX_E_ARG;
+  int r = prof_collect(ctx);
+  if (r) return r;
+  if (enable)
+    { memset(ctx->ms, 0, sizeof(ctx->ms));
+      memset(ctx->launches, 0, sizeof(ctx->launches));
+    }
+  ctx->profiling = enable != 0;
+  return DX_OK;
+}
+
+extern "C" int dx_profile_get(dx_ctx *ctx, int kernel, double *ms_total, uint64_t *launches)
+{ if (ctx == NULL || kernel < 0 || kernel >= DX_K_COUNT) return DX_E_ARG;
+  int r = prof_collect(ctx);
+  if (r) return r;
+  if (ms_total) *ms_total = ctx->ms[kernel];
+  if (launches) *launches = ctx->launches[kernel];
+  return DX_OK;
+}

@@ -1,0 +1,92 @@
+// dx_device.hpp -- wave-level device helpers for gfx950 (wave64).
+//
+// All kernels in libdexgpu give one 64-lane wavefront one unit of work (a read, a .quiva entry)
+// and step over its byte streams 1 KiB at a time: 16 consecutive bytes per lane, loaded with a
+// single (possibly unaligned) global_load_dwordx4.  gfx950 runs with unaligned access mode
+// enabled, so byte-aligned 16-byte loads and 4-byte stores are single instructions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4    u32x4_u __attribute__((aligned(1)));
+typedef uint32_t u32_u   __attribute__((aligned(1)));
+typedef uint64_t u64_u   __attribute__((aligned(1)));
+
+#define DX_STEP 1024            // bytes of one stream a wave consumes per step (16 per lane)
+
+__device__ __forceinline__ int      lane_id()  { return (int) (threadIdx.x & 63); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{ uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) v);
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (v >> 32));
+  return ((uint64_t) hi << 32) | lo;
+}
+
+// Orders this wave's LDS traffic: everything before is complete and visible to the other lanes
+// of the wave before anything after starts.  (LDS instructions of one wave execute in order;
+// this pins the compiler and waits for outstanding returns.)
+__device__ __forceinline__ void wave_sync()
+{ __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Inclusive prefix sum over the 64 lanes, in registers (DPP row shifts + row broadcasts).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{ v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_total(uint32_t incl)
+{ return __builtin_amdgcn_readlane(incl, 63); }
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{ return wave_total(wave_incl_scan(v)); }
+
+// 16 bytes of a stream for this lane: bytes [0,valid) are real, the rest read as zero.  A full
+// chunk is one unaligned 16-byte load; a partial one (only in the last step of a stream) is
+// assembled from byte loads so that nothing past the stream's end is ever touched.
+__device__ __forceinline__ u32x4 load_chunk(const uint8_t *p, int valid)
+{ u32x4 v = { 0u, 0u, 0u, 0u };
+  if (valid >= 16)
+    v = *(const u32x4_u *) p;
+  else if (valid > 0)
+    { uint32_t w[4] = { 0u, 0u, 0u, 0u };
+      for (int b = 0; b < valid; b++)
+        w[b >> 2] |= (uint32_t) p[b] << (8 * (b & 3));
+      v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t chunk_word(const u32x4 &v, int i)
+{ return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// byte b (0..15, dynamic) of a chunk
+__device__ __forceinline__ uint32_t chunk_byte(const u32x4 &v, int b)
+{ uint32_t w = (b & 8) ? ((b & 4) ? v.w : v.z) : ((b & 4) ? v.y : v.x);
+  return (w >> (8 * (b & 3))) & 0xffu;
+}
+
+// 16-bit mask: bit b set iff byte b of the chunk equals c
+__device__ __forceinline__ uint32_t chunk_eq_mask(const u32x4 &v, uint32_t c)
+{ uint32_t m = 0;
+  #pragma unroll
+  for (int i = 0; i < 4; i++)
+    { uint32_t w = chunk_word(v, i) ^ (c * 0x01010101u);
+      // zero-byte detector: exact per byte (no cross-byte borrow)
+      uint32_t z = ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu);   // 0x80 where byte == 0
+      m |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * i);
+    }
+  return m;
+}
+
+__device__ __forceinline__ void store32_u(uint8_t *p, uint32_t v) { *(u32_u *) p = v; }

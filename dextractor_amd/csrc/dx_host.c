@@ -1,0 +1,545 @@
+/*
+ * dx_host.c -- host-only parts of libdexgpu (plain C, as the reference's host code is C):
+ *   record framing of the three formats, the Huffman scheme builder and the (de)serialisation
+ *   of the .dexqv coding header.  O(records) / O(256 log 256) work: it stays on the CPU.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "dexgpu.h"
+
+/* ==========================================================================================
+ *  record framing (dexta.c:187-198, dexar.c:159-163 + 193-204, dexqv.c:128-139)
+ * ========================================================================================== */
+
+uint16_t dx_snr_to_cnr(float snr)                         /* dexar.c:159-163 */
+{ if (snr > 99.99)
+    return 9999;
+  return (uint16_t) ((uint32_t) (snr * 100.));
+}
+
+/* bytes of the well-delta chain: one 0xff per whole 255 of a non-negative delta, then one byte */
+static size_t well_chain(int32_t well, int32_t lwell)
+{ int64_t d = (int64_t) well - (int64_t) lwell;
+  return (d >= 255) ? (size_t) (d / 255) + 1 : 1;
+}
+
+size_t dx_frame_bound(const int32_t *hdr4, uint64_t n, int32_t lwell, int kind)
+{ size_t tot = 0;
+  uint64_t i;
+  for (i = 0; i < n; i++)
+    { tot  += well_chain(hdr4[4*i], lwell) + 8 + (kind ? 8 : 4);
+      lwell = hdr4[4*i];
+    }
+  return tot;
+}
+
+int dx_frame_headers(const int32_t *hdr4, const uint16_t *cnr4, uint64_t n, int kind,
+                     int32_t *lwell, uint8_t *blob, uint64_t *off)
+{ uint64_t i, at = 0;
+  int32_t  last;
+  if (hdr4 == NULL || lwell == NULL || blob == NULL || off == NULL || (kind && cnr4 == NULL))
+    return DX_E_ARG;
+  last = *lwell;
+  for (i = 0; i < n; i++)
+    { const int32_t *h = hdr4 + 4*i;
+      int32_t well = h[0];
+      off[i] = at;
+      while (well - last >= 255)                          /* dexta.c:187-191 */
+        { blob[at++] = 0xff;
+          last += 255;
+        }
+      blob[at++] = (uint8_t) (well - last);
+      last = well;
+      memcpy(blob + at, h + 1, 4); at += 4;               /* beg */
+      memcpy(blob + at, h + 2, 4); at += 4;               /* end */
+      if (kind)
+        { memcpy(blob + at, cnr4 + 4*i, 8); at += 8; }    /* dexar.c:204 */
+      else
+        { memcpy(blob + at, h + 3, 4); at += 4; }         /* qv, dexta.c:198 */
+    }
+  off[n] = at;
+  *lwell = last;
+  return DX_OK;
+}
+
+/* ==========================================================================================
+ *  Huffman schemes (QV.c:91-220, 1029-1169)
+ *
+ *  The tree shape is part of the file format (the .dexqv header stores the code bits), so the
+ *  construction order is reproduced exactly: leaves enter the heap in ascending symbol order
+ *  (the escape pseudo-leaf first), the heap is built bottom-up, and the sift-down breaks count
+ *  ties towards the RIGHT child while moving a child up only if it is strictly smaller.
+ * ========================================================================================== */
+
+typedef struct
+  { uint64_t cnt[512];
+    int16_t  kid[512][2];      /* kid[v][0] < 0: leaf, symbol in kid[v][1] */
+    int      heap[260];
+    int      hsize;
+  } hwork;
+
+static void sift(hwork *w, int s)
+{ int held = w->heap[s], at = s;
+  for (;;)
+    { int l = 2*at, pick;
+      if (l > w->hsize)
+        break;
+      pick = l;
+      if (l + 1 <= w->hsize && !(w->cnt[w->heap[l+1]] > w->cnt[w->heap[l]]))
+        pick = l + 1;                                     /* right child unless it is larger */
+      if (!(w->cnt[held] > w->cnt[w->heap[pick]]))
+        break;
+      w->heap[at] = w->heap[pick];
+      at = pick;
+    }
+  w->heap[at] = held;
+}
+
+static int huffman(const uint64_t *hist, const dx_scheme *prev, dx_scheme *out)
+{ hwork w;
+  int   nleaf = 0, nnode, i;
+
+  w.hsize = 0;
+  if (prev != NULL)                                       /* QV.c:162-167 */
+    { w.cnt[0] = 0;
+      w.kid[0][0] = -1;
+      w.kid[0][1] = 255;
+      w.heap[++w.hsize] = nleaf++;
+    }
+  for (i = 0; i < 256; i++)                               /* QV.c:168-178 */
+    { if (hist[i] == 0)
+        continue;
+      if (prev != NULL && (prev->lens[i] > 16 || i == 255))
+        w.cnt[0] += hist[i];
+      else
+        { w.cnt[nleaf] = hist[i];
+          w.kid[nleaf][0] = -1;
+          w.kid[nleaf][1] = (int16_t) i;
+          w.heap[++w.hsize] = nleaf++;
+        }
+    }
+  if (nleaf == 0)
+    return DX_E_DEGENERATE;
+
+  for (i = w.hsize / 2; i >= 1; i--)                      /* QV.c:180-181 */
+    sift(&w, i);
+
+  nnode = nleaf;
+  for (i = 1; i < nleaf; i++)                             /* QV.c:183-194 */
+    { int a = w.heap[1], b;
+      w.heap[1] = w.heap[w.hsize--];
+      sift(&w, 1);
+      b = w.heap[1];
+      w.cnt[nnode]    = w.cnt[a] + w.cnt[b];
+      w.kid[nnode][0] = (int16_t) a;
+      w.kid[nnode][1] = (int16_t) b;
+      w.heap[1] = nnode++;
+      sift(&w, 1);
+    }
+
+  memset(out->bits, 0, sizeof(out->bits));
+  memset(out->lens, 0, sizeof(out->lens));
+  { /* QV.c:125-137, iteratively: (node, code, len) stack; left edge 0, right edge 1 */
+    int      sn[512], sl[512], sp = 0;
+    uint32_t sc[512];
+    sn[0] = nnode - 1; sc[0] = 0; sl[0] = 0; sp = 1;
+    while (sp > 0)
+      { int v = sn[--sp], len = sl[sp];
+        uint32_t code = sc[sp];
+        if (w.kid[v][0] < 0)
+          { out->bits[w.kid[v][1]] = code;
+            out->lens[w.kid[v][1]] = len;
+          }
+        else
+          { sn[sp] = w.kid[v][1]; sc[sp] = (code << 1) | 1u; sl[sp] = len + 1; sp++;
+            sn[sp] = w.kid[v][0]; sc[sp] = (code << 1);      sl[sp] = len + 1; sp++;
+          }
+      }
+  }
+
+  if (prev != NULL)                                       /* QV.c:203-210 */
+    { out->type = 2;
+      for (i = 0; i < 255; i++)
+        if (prev->lens[i] > 16 || out->lens[i] > 16)
+          { out->lens[i] = out->lens[255];
+            out->bits[i] = out->bits[255];
+          }
+    }
+  else                                                    /* QV.c:211-217 */
+    { out->type = 0;
+      for (i = 0; i < 256; i++)
+        if (out->lens[i] > 16)
+          out->type = 1;
+    }
+  return DX_OK;
+}
+
+static int scheme_for(const uint64_t *hist, dx_scheme *out)          /* QV.c:1069-1078 */
+{ dx_scheme first;
+  int e = huffman(hist, NULL, &first), i;
+  if (e) return e;
+  if (first.type)
+    { e = huffman(hist, &first, out);
+      if (e) return e;
+    }
+  else
+    *out = first;
+  for (i = 0; i < 256; i++)
+    if (out->lens[i] > 16)
+      return DX_E_UNSUPPORTED;
+  return DX_OK;
+}
+
+int dx_qv_build(const uint64_t hist[6][256], uint64_t totChar, const dx_qv_params *p, int lossy,
+                dx_qv_coding *out)
+{ uint64_t h[6][256];
+  int      k, e, delChar, subChar;
+
+  if (hist == NULL || p == NULL || out == NULL)
+    return DX_E_ARG;
+  memcpy(h, hist, sizeof(h));
+  memset(out, 0, sizeof(*out));
+  delChar = p->delChar;
+  subChar = p->subChar;
+  if (delChar > 255 || subChar > 255)
+    return DX_E_ARG;
+
+  for (k = 0; k < 256; k++)                               /* run bins start at 1, QV.c:934-935 */
+    { h[DX_DRUN][k] += 1;
+      h[DX_SRUN][k] += 1;
+    }
+
+  if (totChar < 200000 || (subChar >= 0 && (double) h[DX_SUB][subChar] < .5 * (double) totChar))
+    subChar = -1;                                         /* QV.c:1044-1045 */
+
+  if (lossy)                                              /* QV.c:1049-1065 */
+    { for (k = 0; k < 256; k += 2)
+        { h[DX_INS][k]  += h[DX_INS][k+1];
+          h[DX_INS][k+1] = 0;
+        }
+      for (k = 0; k < 256; k += 4)
+        { h[DX_MRG][k]  += h[DX_MRG][k+1] + h[DX_MRG][k+2] + h[DX_MRG][k+3];
+          h[DX_MRG][k+1] = h[DX_MRG][k+2] = h[DX_MRG][k+3] = 0;
+        }
+    }
+
+  if (delChar >= 0)                                       /* QV.c:1097-1108 */
+    { h[DX_DEL][delChar] = 0;
+      if ((e = scheme_for(h[DX_DRUN], &out->s[DX_DRUN]))) return e;
+    }
+  if ((e = scheme_for(h[DX_DEL], &out->s[DX_DEL]))) return e;
+  if ((e = scheme_for(h[DX_INS], &out->s[DX_INS]))) return e;   /* QV.c:1121-1122 */
+  if ((e = scheme_for(h[DX_MRG], &out->s[DX_MRG]))) return e;
+  if (subChar >= 0)                                       /* QV.c:1124-1135 */
+    { h[DX_SUB][subChar] = 0;
+      if ((e = scheme_for(h[DX_SRUN], &out->s[DX_SRUN]))) return e;
+    }
+  if ((e = scheme_for(h[DX_SUB], &out->s[DX_SUB]))) return e;
+
+  out->delChar = delChar;
+  out->subChar = subChar;
+  return DX_OK;
+}
+
+/* ==========================================================================================
+ *  coding header image (QV.c:300-375, 1173-1320)
+ * ========================================================================================== */
+
+typedef struct { uint8_t *p; size_t at, cap; } wbuf;
+
+static void wput(wbuf *b, const void *src, size_t n)
+{ if (b->at + n <= b->cap)
+    memcpy(b->p + b->at, src, n);
+  b->at += n;
+}
+
+static void put_scheme(wbuf *b, const dx_scheme *s)       /* QV.c:300-318 */
+{ int i;
+  uint8_t x = (uint8_t) s->type;
+  wput(b, &x, 1);
+  for (i = 0; i < 256; i++)
+    { x = (uint8_t) s->lens[i];
+      wput(b, &x, 1);
+      if (x > 0)
+        wput(b, &s->bits[i], 4);
+    }
+}
+
+int dx_qv_write_coding(const dx_qv_coding *c, const char *prefix, size_t plen,
+                       uint8_t *buf, size_t cap, size_t *written)
+{ wbuf     b;
+  uint16_t half;
+  int32_t  len = (int32_t) plen;
+
+  if (c == NULL || (plen && prefix == NULL) || written == NULL)
+    return DX_E_ARG;
+  b.p = buf; b.at = 0; b.cap = buf ? cap : 0;
+
+  half = 0x33cc;                                           wput(&b, &half, 2);   /* QV.c:1180 */
+  half = c->delChar < 0 ? 256 : (uint16_t) c->delChar;     wput(&b, &half, 2);
+  half = c->subChar < 0 ? 256 : (uint16_t) c->subChar;     wput(&b, &half, 2);
+  wput(&b, &len, 4);
+  wput(&b, prefix, plen);
+  put_scheme(&b, &c->s[DX_DEL]);                                                 /* QV.c:1202-1209 */
+  if (c->delChar >= 0) put_scheme(&b, &c->s[DX_DRUN]);
+  put_scheme(&b, &c->s[DX_INS]);
+  put_scheme(&b, &c->s[DX_MRG]);
+  put_scheme(&b, &c->s[DX_SUB]);
+  if (c->subChar >= 0) put_scheme(&b, &c->s[DX_SRUN]);
+
+  *written = b.at;
+  return (b.at <= b.cap) ? DX_OK : DX_E_SPACE;
+}
+
+typedef struct { const uint8_t *p; size_t at, n; int bad; } rbuf;
+
+static void rget(rbuf *b, void *dst, size_t k)
+{ if (b->at + k > b->n) { b->bad = 1; memset(dst, 0, k); b->at = b->n; return; }
+  memcpy(dst, b->p + b->at, k);
+  b->at += k;
+}
+
+static uint16_t flip16(uint16_t v) { return (uint16_t) ((v << 8) | (v >> 8)); }
+static uint32_t flip32(uint32_t v)
+{ return (v << 24) | ((v & 0xff00u) << 8) | ((v >> 8) & 0xff00u) | (v >> 24); }
+
+static int get_scheme(rbuf *b, int flip, dx_scheme *s)    /* QV.c:322-363 */
+{ int i;
+  uint8_t x;
+  rget(b, &x, 1);
+  s->type = x;
+  for (i = 0; i < 256; i++)
+    { rget(b, &x, 1);
+      s->lens[i] = x;
+      s->bits[i] = 0;
+      if (x > 0)
+        { uint32_t v;
+          rget(b, &v, 4);
+          s->bits[i] = flip ? flip32(v) : v;
+        }
+      if (x > 16)
+        return DX_E_UNSUPPORTED;
+    }
+  return b->bad ? DX_E_FORMAT : DX_OK;
+}
+
+int dx_qv_read_coding(const uint8_t *buf, size_t n, dx_qv_coding *c, int *flip,
+                      char *prefix, size_t pcap, size_t *consumed)
+{ rbuf     b;
+  uint16_t half;
+  uint32_t len;
+  int      fl, e;
+
+  if (buf == NULL || c == NULL)
+    return DX_E_ARG;
+  b.p = buf; b.at = 0; b.n = n; b.bad = 0;
+  memset(c, 0, sizeof(*c));
+
+  rget(&b, &half, 2);                                      /* QV.c:1222-1226 */
+  fl = (half != 0x33cc);
+  rget(&b, &half, 2); if (fl) half = flip16(half);
+  c->delChar = half >= 256 ? -1 : half;
+  rget(&b, &half, 2); if (fl) half = flip16(half);
+  c->subChar = half >= 256 ? -1 : half;
+  rget(&b, &len, 4);  if (fl) len = flip32(len);
+  if (b.bad || len > n)
+    return DX_E_FORMAT;
+  if (prefix != NULL)
+    { if ((size_t) len + 1 > pcap)
+        return DX_E_SPACE;
+      rget(&b, prefix, len);
+      prefix[len] = '\0';
+    }
+  else
+    b.at += len;
+
+  if ((e = get_scheme(&b, fl, &c->s[DX_DEL]))) return e;                          /* QV.c:1281-1302 */
+  if (c->delChar >= 0 && (e = get_scheme(&b, fl, &c->s[DX_DRUN]))) return e;
+  if ((e = get_scheme(&b, fl, &c->s[DX_INS]))) return e;
+  if ((e = get_scheme(&b, fl, &c->s[DX_MRG]))) return e;
+  if ((e = get_scheme(&b, fl, &c->s[DX_SUB]))) return e;
+  if (c->subChar >= 0 && (e = get_scheme(&b, fl, &c->s[DX_SRUN]))) return e;
+  if (b.bad)
+    return DX_E_FORMAT;
+  if (flip) *flip = fl;
+  if (consumed) *consumed = b.at;
+  return DX_OK;
+}
+
+/* ==========================================================================================
+ *  text front end: index .quiva / .fasta / .arrow images (host, O(file) memchr work)
+ *
+ *  Replaces the fgets loops of QV.c:751-798 + the header checks of QV.c:954-968 (quiva) and
+ *  dexta.c:104-183 / dexar.c:103-188 (fasta/arrow).  The kernels then read the streams straight
+ *  from the file image through the offsets produced here.
+ * ========================================================================================== */
+#include <stdio.h>
+
+#define DX_LINE_LIMIT 100000            /* MAX_BUFFER, dexta.c:21 */
+
+typedef struct { const uint8_t *p; size_t n, at; uint64_t line; } tsrc;
+
+/* 1 = line read, 0 = end of input, -1 = last line has no newline */
+static int get_line(tsrc *t, const uint8_t **s, size_t *len)
+{ const uint8_t *nl;
+  if (t->at >= t->n)
+    return 0;
+  t->line += 1;
+  nl = memchr(t->p + t->at, '\n', t->n - t->at);
+  if (nl == NULL)
+    return -1;
+  *s   = t->p + t->at;
+  *len = (size_t) (nl - *s);
+  t->at += *len + 1;
+  return 1;
+}
+
+/* sscanf needs a terminated string: copy the (bounded) header tail */
+static int scan_tail(const uint8_t *s, size_t n, const char *fmt, int32_t *f, float *snr)
+{ char tmp[400];
+  int  w, b, e, q, k;
+  if (n > sizeof(tmp) - 2) n = sizeof(tmp) - 2;
+  memcpy(tmp, s, n);
+  tmp[n] = '\n';
+  tmp[n+1] = '\0';
+  if (snr != NULL)
+    { k = sscanf(tmp, fmt, &w, &b, &e, snr, snr+1, snr+2, snr+3);
+      q = 0;
+    }
+  else
+    { q = 0;
+      k = sscanf(tmp, fmt, &w, &b, &e, &q);
+    }
+  if (k >= 1) f[0] = w;
+  if (k >= 2) f[1] = b;
+  if (k >= 3) f[2] = e;
+  f[3] = (snr == NULL && k >= 4) ? q : 0;
+  return k;
+}
+
+static int idx_fail(uint64_t line, int code, uint64_t *errline, int *errcode)
+{ if (errline) *errline = line;
+  if (errcode) *errcode = code;
+  return DX_E_FORMAT;
+}
+
+int dx_index_quiva(const uint8_t *text, size_t n, uint64_t cap,
+                   uint64_t *off, uint32_t *len, int32_t *hdr4,
+                   uint64_t *count, size_t *prefix_len, uint64_t *errline, int *errcode)
+{ tsrc     t;
+  uint64_t k = 0;
+  if (text == NULL && n) return DX_E_ARG;
+  t.p = text; t.n = n; t.at = 0; t.line = 0;
+  if (prefix_len) *prefix_len = 0;
+  for (;;)
+    { const uint8_t *h, *s, *slash;
+      size_t  hl, sl = 0, first = 0;
+      int32_t f[4];
+      int     r, j;
+
+      r = get_line(&t, &h, &hl);                          /* QV.c:948-952 */
+      if (r == 0) break;
+      if (r < 0) return idx_fail(t.line, DX_IDX_NO_NEWLINE, errline, errcode);
+      if (hl == 0 || h[0] != '@')                         /* QV.c:954-957 */
+        return idx_fail(t.line, DX_IDX_NO_HEADER, errline, errcode);
+      slash = hl > 1 ? memchr(h + 1, '/', hl - 1) : NULL; /* QV.c:958 */
+      if (slash == NULL)
+        return idx_fail(t.line, DX_IDX_BAD_HEADER, errline, errcode);
+      if (scan_tail(slash + 1, hl - (size_t) (slash + 1 - h), "%d/%d_%d RQ=0.%d\n", f, NULL) != 4)
+        return idx_fail(t.line, DX_IDX_BAD_HEADER, errline, errcode);     /* QV.c:964-968 */
+      if (k == 0 && prefix_len) *prefix_len = (size_t) (slash - h);      /* dexqv.c:94-102 */
+
+      for (j = 0; j < 5; j++)                             /* QV.c:973-978, 785-796 */
+        { r = get_line(&t, &s, &sl);
+          if (r == 0) return idx_fail(t.line + 1, DX_IDX_INCOMPLETE, errline, errcode);
+          if (r < 0) return idx_fail(t.line, DX_IDX_NO_NEWLINE, errline, errcode);
+          if (j == 0)
+            { first = sl;
+              if (off != NULL && k < cap) off[k] = (uint64_t) (s - text);
+            }
+          else if (sl != first)
+            return idx_fail(t.line, DX_IDX_RAGGED, errline, errcode);
+        }
+      if (first > 0x7fffffffu)
+        return idx_fail(t.line, DX_IDX_TOO_LONG, errline, errcode);
+      if (k < cap)
+        { if (len  != NULL) len[k] = (uint32_t) first;
+          if (hdr4 != NULL) memcpy(hdr4 + 4*k, f, sizeof(f));
+        }
+      k += 1;
+    }
+  if (count) *count = k;
+  return DX_OK;
+}
+
+int dx_index_seq(int arrow, const uint8_t *text, size_t n, uint64_t cap,
+                 uint64_t *off, uint32_t *tlen, uint32_t *nsym, int32_t *hdr4, uint16_t *cnr4,
+                 uint64_t *count, size_t *prefix_len, uint64_t *errline, int *errcode)
+{ tsrc     t;
+  uint64_t k = 0;
+  const uint8_t *h, *slash;
+  size_t   hl;
+  int      r;
+
+  if (text == NULL && n) return DX_E_ARG;
+  t.p = text; t.n = n; t.at = 0; t.line = 0;
+  if (count) *count = 0;
+  if (prefix_len) *prefix_len = 0;
+
+  r = get_line(&t, &h, &hl);                              /* dexta.c:108-122 */
+  if (r == 0) return idx_fail(1, DX_IDX_EMPTY, errline, errcode);
+  if (r < 0 || hl + 1 >= DX_LINE_LIMIT) return idx_fail(1, DX_IDX_TOO_LONG, errline, errcode);
+  if (hl == 0 || h[0] != '>') return idx_fail(1, DX_IDX_NO_HEADER, errline, errcode);
+  slash = memchr(h, '/', hl);
+  if (slash == NULL) return idx_fail(1, DX_IDX_BAD_HEADER, errline, errcode);
+  if (prefix_len) *prefix_len = (size_t) (slash - h);
+
+  for (;;)                                                /* dexta.c:139-205 */
+    { int32_t  f[4];
+      float    snr[4];
+      const uint8_t *s;
+      size_t   sl, start, end, lines = 0;
+      int      more = 0, x;
+
+      slash = hl > 1 ? memchr(h + 1, '/', hl - 1) : NULL; /* dexta.c:146 */
+      if (slash == NULL) return idx_fail(t.line, DX_IDX_BAD_HEADER, errline, errcode);
+      if (arrow)
+        { x = scan_tail(slash + 1, hl - (size_t) (slash + 1 - h), "%d/%d_%d SN=%f,%f,%f,%f\n", f, snr);
+          if (x != 7) return idx_fail(t.line, DX_IDX_BAD_HEADER, errline, errcode);   /* dexar.c:152-157 */
+        }
+      else
+        { x = scan_tail(slash + 1, hl - (size_t) (slash + 1 - h), "%d/%d_%d RQ=0.%d\n", f, NULL);
+          if (x < 3) return idx_fail(t.line, DX_IDX_BAD_HEADER, errline, errcode);    /* dexta.c:151-157 */
+        }
+
+      start = t.at;                                       /* dexta.c:161-183: lines up to the next '>' */
+      end   = t.at;
+      for (;;)
+        { r = get_line(&t, &s, &sl);
+          if (r == 0) break;
+          if (r < 0 || sl + 1 >= DX_LINE_LIMIT) return idx_fail(t.line, DX_IDX_TOO_LONG, errline, errcode);
+          if (sl > 0 && s[0] == '>')
+            { h = s; hl = sl; more = 1;
+              break;
+            }
+          lines += 1;
+          end = t.at;
+        }
+      if (end - start - lines > 0x7fffffffu) return idx_fail(t.line, DX_IDX_TOO_LONG, errline, errcode);
+      if (k < cap)
+        { if (off  != NULL) off[k]  = (uint64_t) start;
+          if (tlen != NULL) tlen[k] = (uint32_t) (end - start);
+          if (nsym != NULL) nsym[k] = (uint32_t) (end - start - lines);
+          if (hdr4 != NULL) memcpy(hdr4 + 4*k, f, sizeof(f));
+          if (arrow && cnr4 != NULL)
+            { int j;
+              for (j = 0; j < 4; j++) cnr4[4*k + j] = dx_snr_to_cnr(snr[j]);
+            }
+        }
+      k += 1;
+      if (!more) break;
+    }
+  if (count) *count = k;
+  return DX_OK;
+}

@@ -1,0 +1,65 @@
+// dx_internal.hpp -- shared host-side definitions of libdexgpu (not part of the C-ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "dexgpu.h"
+
+#define DX_WAVE          64
+#define DX_BLOCK         256                 // 4 waves per workgroup
+#define DX_WAVES_PER_BLK (DX_BLOCK / DX_WAVE)
+#define DX_TOK_WORDS     (6 * 256)           // device token table: 6 schemes x 256 entries
+
+struct dx_pending { hipEvent_t a, b; int kernel; };
+
+struct dx_ctx
+{ int          device;
+  hipStream_t  own, stream;
+  int          num_cu;
+  char         err[512];
+
+  // profiling
+  bool                    profiling;
+  std::vector<dx_pending> pend;
+  double                  ms[DX_K_COUNT];
+  uint64_t                launches[DX_K_COUNT];
+
+  // QV coder state (dx_qv_set_coding)
+  uint32_t *d_tok;             // DX_TOK_WORDS packed tokens (see dx_qv.hip)
+  int       coding_set;
+  int       lossy;
+  int       delChar, subChar;
+
+  // scratch owned by the context
+  uint32_t *d_status;          // device error flags (bit 0: symbol count mismatch)
+  uint64_t *d_u64;             // small device scalars (prescan keys, totals, ...)
+  void     *d_scratch;         // grow-only scratch (scan partials, histograms, sizes)
+  size_t    scratch_bytes;
+};
+
+int  dx_fail(dx_ctx *ctx, int code, const char *fmt, ...);
+int  dx_scratch(dx_ctx *ctx, size_t bytes, void **p);
+void dx_prof_begin(dx_ctx *ctx, int kernel);
+void dx_prof_end(dx_ctx *ctx);
+int  dx_grid_waves(dx_ctx *ctx, uint64_t n_units, int waves_per_cu);
+
+#define DX_HIP(ctx, call)                                                                   \
+  do { hipError_t e_ = (call);                                                              \
+       if (e_ != hipSuccess)                                                                \
+         return dx_fail(ctx, DX_E_HIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                        __FILE__, __LINE__);                                                \
+     } while (0)
+
+// Launch `kern<<<grid, block, 0, ctx->stream>>>(...)` bracketed by profiling events.
+#define DX_LAUNCH(ctx, id, kern, grid, block, ...)                                          \
+  do { dx_prof_begin(ctx, id);                                                              \
+       hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);    \
+       dx_prof_end(ctx);                                                                    \
+       DX_HIP(ctx, hipGetLastError());                                                      \
+     } while (0)

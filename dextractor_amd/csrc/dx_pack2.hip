@@ -1,0 +1,255 @@
+// dx_pack2.hip -- 2-bit packers behind dexta/undexta and dexar/undexar.
+//
+// Reference behaviour reproduced (bit-exact):
+//   Number_Read / Number_Arrow   DB.c:393-441   ASCII -> 0..3
+//   Compress_Read                DB.c:319-338   4 symbols per byte, first in the top two bits
+//   Uncompress_Read              DB.c:342-363
+//   Lower_Read/Upper_Read/Letter_Arrow DB.c:367-389
+//   sequence-line gathering      dexta.c:161-183   (newlines dropped on the device)
+//   line wrapping                undexta.c:263-270
+//
+// Roofline: HBM.  Algorithmic bytes per symbol: encode 1 (+1/80 for the newlines of 80-column
+// text) read + 0.25 written; decode 0.25 read + 1 (+1/80) written.
+//
+// Layout: one 64-lane wavefront per read, grid-stride over reads.  A wave walks the read's text
+// 1 KiB per step (16 bytes per lane, one unaligned global_load_dwordx4), drops the '\n' bytes by
+// a lane-local compaction + wave prefix sum of the kept counts, ORs each lane's <=32 code bits
+// into a small LDS word window at the bit position the prefix sum gives, and flushes the
+// completed 32-bit words with coalesced (unaligned) dword stores.
+#include "dx_internal.hpp"
+#include "dx_device.hpp"
+
+#define P2_WIN 72        // LDS words per wave: 64 words/step + carried partial word + slack
+
+// ---------------------------------------------------------------------------------------------
+//  alphabet maps (computed, not tabulated)
+// ---------------------------------------------------------------------------------------------
+template <int ALPHA>
+__device__ __forceinline__ uint32_t sym_code(uint32_t x)
+{ if (ALPHA == DX_ALPHA_BASES)
+    { uint32_t u = x & 0xdfu;                        // fold case; bytes >= 128 keep bit 7 and miss
+      return (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 0u;
+    }
+  else
+    return (x == '1') ? 0u : (x == '2') ? 1u : (x == '3' || x == 'G') ? 2u : 3u;
+}
+
+template <int ALPHA>
+__global__ __launch_bounds__(DX_BLOCK)
+void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict__ off,
+                    const uint32_t *__restrict__ tlen, const uint32_t *__restrict__ nsym, uint64_t n,
+                    const uint8_t *__restrict__ hdr, const uint64_t *__restrict__ hdr_off,
+                    uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
+                    uint32_t *__restrict__ status)
+{ __shared__ uint32_t s_win[DX_WAVES_PER_BLK][P2_WIN];
+  const int       lane  = lane_id();
+  const int       wid   = threadIdx.x >> 6;
+  uint32_t       *win   = s_win[wid];
+  const uint64_t  wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + wid;
+  const uint64_t  nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+
+  for (int j = lane; j < P2_WIN; j += 64)
+    win[j] = 0;
+  wave_sync();
+
+  for (uint64_t r = wave0; r < n; r += nwave)
+    { const uint8_t *src = text + off[r];
+      const uint32_t T   = tlen[r];
+      uint8_t       *dst = out + out_off[r];
+
+      if (hdr != NULL)                                   // record framing bytes (dexta.c:187-198)
+        { const uint64_t h0 = hdr_off[r];
+          const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
+          for (uint32_t k = lane; k < hl; k += 64)
+            dst[k] = hdr[h0 + k];
+          dst += hl;
+        }
+
+      uint32_t G     = 0;        // symbols consumed so far
+      uint32_t wbase = 0;        // index of the 32-bit output word held in win[0]
+
+      for (uint32_t base = 0; base < T; base += DX_STEP)
+        { const uint32_t pos   = base + 16u * lane;
+          const int      valid = pos >= T ? 0 : (T - pos >= 16u ? 16 : (int) (T - pos));
+          const u32x4    c     = load_chunk(src + pos, valid);
+
+          uint32_t keep = ~chunk_eq_mask(c, '\n') & ((1u << valid) - 1u);
+          uint32_t cnt  = __popc(keep);
+          uint32_t acc  = 0;                             // kept codes, first one in the top bits
+          int      sh   = 30;
+          #pragma unroll
+          for (int b = 0; b < 16; b++)
+            if ((keep >> b) & 1u)
+              { acc |= sym_code<ALPHA>((chunk_word(c, b >> 2) >> (8 * (b & 3))) & 0xffu) << sh;
+                sh  -= 2;
+              }
+
+          const uint32_t incl  = wave_incl_scan(cnt);
+          const uint32_t total = wave_total(incl);
+          const uint32_t bit   = 2u * (G + incl - cnt) - 32u * wbase;   // bit offset in the window
+          if (cnt)
+            { const uint32_t w = bit >> 5, s = bit & 31u;
+              atomicOr(&win[w], acc >> s);
+              if (s && 2u * cnt + s > 32u)
+                atomicOr(&win[w + 1], acc << (32u - s));
+            }
+          G += total;
+          wave_sync();
+
+          const uint32_t nfull = (G >> 4) - wbase;       // completed words (16 symbols each), <= 65
+          for (uint32_t j = lane; j < nfull; j += 64)
+            store32_u(dst + 4ull * (wbase + j), __builtin_bswap32(win[j]));
+          const uint32_t part = win[nfull];              // carried partial word (uniform address)
+          wave_sync();
+          for (uint32_t j = lane; j <= nfull; j += 64)
+            win[j] = (j == 0) ? part : 0u;
+          wbase += nfull;
+          wave_sync();
+        }
+
+      { const uint32_t clen = (G + 3u) >> 2;             // COMPRESSED_LEN, DB.h:255
+        const uint32_t done = 4u * wbase;
+        if (lane == 0)
+          { const uint32_t w = __builtin_bswap32(win[0]);
+            for (uint32_t k = done; k < clen; k++)
+              dst[k] = (uint8_t) (w >> (8 * (k - done)));
+            win[0] = 0;
+            if (G != nsym[r])
+              atomicOr(status, 1u);
+          }
+        wave_sync();
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  decode: output driven, 16 text bytes per lane
+// ---------------------------------------------------------------------------------------------
+template <int LETTERS>
+__device__ __forceinline__ uint32_t sym_letter(uint32_t code)
+{ if (LETTERS == DX_LETTERS_LOWER) return (0x74676361u >> (8 * code)) & 0xffu;       // "acgt"
+  if (LETTERS == DX_LETTERS_UPPER) return (0x54474341u >> (8 * code)) & 0xffu;       // "ACGT"
+  return '1' + code;
+}
+
+template <int LETTERS>
+__global__ __launch_bounds__(DX_BLOCK)
+void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
+                    const uint32_t *__restrict__ nsym, uint64_t n, uint32_t width,
+                    uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off)
+{ const int      lane  = lane_id();
+  const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
+  const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+
+  for (uint64_t r = wave0; r < n; r += nwave)
+    { const uint8_t *src  = in + in_off[r];
+      uint8_t       *dst  = out + out_off[r];
+      const uint32_t L    = nsym[r];
+      const uint32_t clen = (L + 3u) >> 2;
+      const uint32_t T    = L + (L + width - 1u) / width;        // letters + newlines
+      const uint32_t W1   = width + 1u;
+
+      for (uint32_t base = 0; base < T; base += DX_STEP)
+        { const uint32_t q0 = base + 16u * lane;
+          if (q0 >= T) continue;
+          const int valid = (T - q0 >= 16u) ? 16 : (int) (T - q0);
+          uint32_t  line  = q0 / W1;
+          uint32_t  col   = q0 - line * W1;
+          const uint32_t i0 = q0 - line;                         // symbol index of text byte q0 (if a letter)
+          const uint32_t b0 = i0 >> 2;                           // first packed byte needed
+          uint64_t  bits = 0;                                    // packed bytes b0.., first in the low byte
+          if (b0 + 8u <= clen)
+            bits = *(const u64_u *) (src + b0);
+          else
+            for (uint32_t k = b0; k < clen; k++)
+              bits |= (uint64_t) src[k] << (8 * (k - b0));
+
+          uint32_t w[4] = { 0u, 0u, 0u, 0u };
+          uint32_t idx  = i0;
+          #pragma unroll
+          for (int b = 0; b < 16; b++)
+            { uint32_t ch;
+              if (col == width || q0 + b == T - 1u)
+                { ch = '\n'; col = 0; }
+              else
+                { const uint32_t rel = idx - 4u * b0;            // 0 .. 18
+                  const uint32_t code = (uint32_t) (bits >> (8u * (rel >> 2) + 6u - 2u * (rel & 3u))) & 3u;
+                  ch = sym_letter<LETTERS>(code);
+                  idx += 1; col += 1;
+                }
+              w[b >> 2] |= ch << (8 * (b & 3));
+            }
+          if (valid == 16)
+            { u32x4 v = { w[0], w[1], w[2], w[3] };
+              *(u32x4_u *) (dst + q0) = v;
+            }
+          else
+            for (int b = 0; b < valid; b++)
+              dst[q0 + b] = (uint8_t) (w[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  C-ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int dx_pack2_encode(dx_ctx *ctx, int alphabet,
+                               const uint8_t *d_text, const uint64_t *d_off, const uint32_t *d_tlen,
+                               const uint32_t *d_nsym, uint64_t n,
+                               const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                               uint8_t *d_out, const uint64_t *d_out_off)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (alphabet != DX_ALPHA_BASES && alphabet != DX_ALPHA_ARROW)
+    return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: unknown alphabet %d", alphabet);
+  if ((d_hdr == NULL) != (d_hdr_off == NULL))
+    return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: d_hdr and d_hdr_off must be given together");
+  if (n == 0) return DX_OK;
+  if (!d_text || !d_off || !d_tlen || !d_nsym || !d_out || !d_out_off)
+    return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: NULL device pointer");
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+  const int grid = dx_grid_waves(ctx, n, 16);
+  if (alphabet == DX_ALPHA_BASES)
+    DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_BASES>, grid, DX_BLOCK,
+              d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status);
+  else
+    DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_ARROW>, grid, DX_BLOCK,
+              d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status);
+  uint32_t st = 0;
+  DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (st & 1u)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_pack2_encode: a read's symbol count differs from d_nsym");
+  return DX_OK;
+}
+
+extern "C" int dx_pack2_decode(dx_ctx *ctx, int letters,
+                               const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_nsym,
+                               uint64_t n, uint32_t width, uint8_t *d_out, const uint64_t *d_out_off)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (letters < DX_LETTERS_LOWER || letters > DX_LETTERS_ARROW)
+    return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: unknown letter set %d", letters);
+  if (width == 0)
+    return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: line width must be >= 1 "
+                                  "(the reference loops forever on -w0, undexta.c:265)");
+  if (n == 0) return DX_OK;
+  if (!d_in || !d_in_off || !d_nsym || !d_out || !d_out_off)
+    return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: NULL device pointer");
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  const int grid = dx_grid_waves(ctx, n, 16);
+  switch (letters)
+    { case DX_LETTERS_LOWER:
+        DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_LOWER>, grid, DX_BLOCK,
+                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off);
+        break;
+      case DX_LETTERS_UPPER:
+        DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_UPPER>, grid, DX_BLOCK,
+                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off);
+        break;
+      default:
+        DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_ARROW>, grid, DX_BLOCK,
+                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off);
+        break;
+    }
+  return DX_OK;
+}

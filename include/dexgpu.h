@@ -1,0 +1,257 @@
+/*
+ * dexgpu.h -- C-ABI of libdexgpu: MI355X (gfx950) kernels for DEXTRACTOR's three codecs.
+ *
+ * The reference (thegenemyers/DEXTRACTOR) has no plugin/FFI interface; its boundary is the C API
+ * of QV.h:48-97 + DB.h:255-267 (per-entry, FILE*-streaming, static state) under six CLI tools.
+ * A GPU cannot be fed one entry at a time through FILE*, so this library exposes the SAME
+ * operations batch-wise over device-resident buffers.  Each entry point names the reference
+ * function(s) it replaces.  Plain pointers and sizes only; no HIP or torch types.
+ *
+ * Conventions
+ *   - `d_` pointers are DEVICE pointers (from dx_malloc, hipMalloc, or a torch tensor's
+ *     data_ptr()); everything else is host memory.
+ *   - every function returns DX_OK (0) or a negative DX_E_* code; dx_last_error() gives a
+ *     message.  Nothing here ever calls exit() (the reference's batch error model, DB.h:45-47,
+ *     is reproduced by the CLI front-ends, not the library).
+ *   - one dx_ctx per GPU and per host thread; all work of a context is issued on one HIP
+ *     stream (dx_set_stream lets a caller supply its own, e.g. torch's current stream).
+ *   - multi-byte integers in all produced file images are little-endian, as the reference
+ *     writes them on x86-64 hosts (endian key 0x55aa / 0x33cc).
+ */
+#ifndef DEXGPU_H
+#define DEXGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DX_OK              0
+#define DX_E_ARG         (-1)   /* bad argument */
+#define DX_E_HIP         (-2)   /* HIP runtime error (message has hipGetErrorString) */
+#define DX_E_FORMAT      (-3)   /* malformed input image */
+#define DX_E_DEGENERATE  (-4)   /* a stream that needs a scheme has an empty histogram (reference: UB, QV.c:201) */
+#define DX_E_UNSUPPORTED (-5)   /* a final code longer than 16 bits (the reference's own decoder cannot read it) */
+#define DX_E_NOMEM       (-6)
+#define DX_E_MISMATCH    (-7)   /* device-side consistency check failed (e.g. symbol count != expected) */
+#define DX_E_SPACE       (-8)   /* output buffer too small */
+
+typedef struct dx_ctx dx_ctx;
+
+/* ------------------------------------------------------------------------------------------
+ *  context, memory, profiling
+ * ------------------------------------------------------------------------------------------ */
+int         dx_device_count(void);
+int         dx_open(int device, dx_ctx **ctx);
+void        dx_close(dx_ctx *ctx);
+const char *dx_last_error(const dx_ctx *ctx);      /* ctx may be NULL: last error of dx_open */
+int         dx_set_stream(dx_ctx *ctx, void *hip_stream);   /* NULL restores the context's own stream */
+int         dx_sync(dx_ctx *ctx);
+
+int dx_malloc(dx_ctx *ctx, size_t bytes, void **d_ptr);
+int dx_free  (dx_ctx *ctx, void *d_ptr);
+int dx_h2d   (dx_ctx *ctx, void *d_dst, const void *src, size_t bytes);   /* synchronous */
+int dx_d2h   (dx_ctx *ctx, void *dst, const void *d_src, size_t bytes);   /* synchronous */
+int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes);
+
+/* Per-kernel device time, measured with HIP events on the context's stream around every launch
+ * while profiling is enabled.  Kernel ids: */
+enum { DX_K_PACK2_ENC = 0, DX_K_PACK2_DEC, DX_K_QV_PRESCAN, DX_K_QV_HIST, DX_K_QV_SIZES, DX_K_SCAN,
+       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_COUNT };
+int         dx_profile(dx_ctx *ctx, int enable);                  /* enabling resets the counters */
+int         dx_profile_get(dx_ctx *ctx, int kernel, double *ms_total, uint64_t *launches);  /* syncs */
+const char *dx_kernel_name(int kernel);
+
+/* ------------------------------------------------------------------------------------------
+ *  2-bit packers: dexta/undexta, dexar/undexar
+ * ------------------------------------------------------------------------------------------ */
+enum { DX_ALPHA_BASES = 0,    /* Number_Read  DB.c:393: c/C->1 g/G->2 t/T->3, everything else 0   */
+       DX_ALPHA_ARROW = 1 };  /* Number_Arrow DB.c:418: '1'->0 '2'->1 '3','G'->2, everything else 3 */
+enum { DX_LETTERS_LOWER = 0,  /* Lower_Read  DB.c:367 acgt */
+       DX_LETTERS_UPPER = 1,  /* Upper_Read  DB.c:375 ACGT */
+       DX_LETTERS_ARROW = 2 };/* Letter_Arrow DB.c:383 1234 */
+
+/* Replaces, for n reads at once: the line-gathering loop dexta.c:161-183 (newlines are skipped on
+ * the device), Number_Read/Number_Arrow (DB.c:393-441), Compress_Read (DB.c:319-338) and the
+ * record writes dexta.c:187-204 / dexar.c:193-210.
+ *   read i's sequence text = d_text[d_off[i] .. d_off[i]+d_tlen[i]) : any number of lines, '\n'
+ *   bytes are dropped, all other bytes are symbols; it must hold exactly d_nsym[i] symbols.
+ *   Output record i is written at d_out + d_out_off[i]: first the framing bytes
+ *   d_hdr[d_hdr_off[i] .. d_hdr_off[i+1]) (may be NULL: no framing), then (nsym+3)>>2 packed
+ *   bytes, first symbol in the top two bits, missing symbols 0.
+ * Returns DX_E_MISMATCH if some read's symbol count differs from d_nsym[i].                     */
+int dx_pack2_encode(dx_ctx *ctx, int alphabet,
+                    const uint8_t *d_text, const uint64_t *d_off, const uint32_t *d_tlen,
+                    const uint32_t *d_nsym, uint64_t n,
+                    const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                    uint8_t *d_out, const uint64_t *d_out_off);
+
+/* Replaces Uncompress_Read (DB.c:342-363) + Lower_Read/Upper_Read/Letter_Arrow (DB.c:367-389)
+ * + the line wrapping of undexta.c:263-270 / undexar.c:221-228.
+ *   read i's packed bytes start at d_in + d_in_off[i]; its text (d_nsym[i] letters, a '\n'
+ *   after every `width` letters and after the last partial line; nothing for an empty read) is
+ *   written at d_out + d_out_off[i].  width >= 1.                                               */
+int dx_pack2_decode(dx_ctx *ctx, int letters,
+                    const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_nsym, uint64_t n,
+                    uint32_t width, uint8_t *d_out, const uint64_t *d_out_off);
+
+/* Host helpers for the record framing of all three formats (dexta.c:187-198, dexar.c:159-163 +
+ * 193-204, dexqv.c:128-139): well-delta chain, int32 beg, end, then int32 qv (kind 0) or four
+ * uint16 cnr (kind 1, values already converted with dx_snr_to_cnr).  `field[i]` points at the
+ * 4 int32 {well,beg,end,qv} (kind 0) or {well,beg,end,-} followed in `cnr` by 4 uint16 (kind 1).
+ * blob must hold dx_frame_bound(...) bytes; off gets n+1 entries.  *lwell carries the previous
+ * well across calls (starts at 0, dexta.c:137).                                                 */
+size_t   dx_frame_bound(const int32_t *hdr4, uint64_t n, int32_t lwell, int kind);
+int      dx_frame_headers(const int32_t *hdr4, const uint16_t *cnr4, uint64_t n, int kind,
+                          int32_t *lwell, uint8_t *blob, uint64_t *off);
+uint16_t dx_snr_to_cnr(float snr);                 /* dexar.c:159-163 */
+
+/* ------------------------------------------------------------------------------------------
+ *  text front end (host): index a file image so the kernels can read it in place
+ * ------------------------------------------------------------------------------------------ */
+/* why an image was rejected (*errcode), with the 1-based line number in *errline */
+enum { DX_IDX_NO_NEWLINE = 1,   /* last line does not end with a newline   (QV.c:779) */
+       DX_IDX_NO_HEADER  = 2,   /* header line missing                     (QV.c:954, dexta.c:113) */
+       DX_IDX_BAD_HEADER = 3,   /* header line incorrectly formatted       (QV.c:958-968, dexta.c:146-155) */
+       DX_IDX_INCOMPLETE = 4,   /* incomplete last entry of .quiva file    (QV.c:789) */
+       DX_IDX_RAGGED     = 5,   /* lines for an entry are not the same length (QV.c:793) */
+       DX_IDX_TOO_LONG   = 6,   /* fasta/arrow line longer than 99998 chars (dexta.c:165-172) */
+       DX_IDX_EMPTY      = 7 }; /* empty input (the reference reads an uninitialised buffer, dexta.c:108) */
+
+/* .quiva: replaces the Read_Lines loops and header validation of QVcoding_Scan (QV.c:751-798,
+ * 948-978).  Fills (up to cap entries of) off[i] = offset of entry i's first data line, len[i] =
+ * symbols per line, hdr4[4i..] = well, beg, end, qv; *count = entries found (call with cap 0 to
+ * count); *prefix_len = bytes of the first header before its first '/' after position 0.      */
+int dx_index_quiva(const uint8_t *text, size_t n, uint64_t cap,
+                   uint64_t *off, uint32_t *len, int32_t *hdr4,
+                   uint64_t *count, size_t *prefix_len, uint64_t *errline, int *errcode);
+
+/* .fasta (arrow = 0) / .arrow (arrow = 1): replaces dexta.c:104-183 / dexar.c:103-188.  off[i] =
+ * offset of read i's first sequence line, tlen[i] = its text bytes up to the next header or the
+ * end (newlines included), nsym[i] = symbols (tlen - lines), hdr4 = well, beg, end, qv (qv = 0
+ * when "RQ=" is missing), cnr4 (arrow) = the four SN values converted by dx_snr_to_cnr.        */
+int dx_index_seq(int arrow, const uint8_t *text, size_t n, uint64_t cap,
+                 uint64_t *off, uint32_t *tlen, uint32_t *nsym, int32_t *hdr4, uint16_t *cnr4,
+                 uint64_t *count, size_t *prefix_len, uint64_t *errline, int *errcode);
+
+/* ------------------------------------------------------------------------------------------
+ *  5-stream QV coder: dexqv/undexqv (QV.c)
+ * ------------------------------------------------------------------------------------------ */
+enum { DX_DEL = 0, DX_INS = 1, DX_MRG = 2, DX_SUB = 3, DX_DRUN = 4, DX_SRUN = 5 };
+
+/* A batch of .quiva entries resident on the device.  Entry i's five streams (deletion QV,
+ * deletion tag, insertion QV, merge QV, substitution QV -- the line order of QV.c:973-991) are
+ * d_len[i] bytes each; stream k starts at d_text + d_off[i] + k*(d_len[i] + line_pad).  For a
+ * .quiva file image line_pad = 1 (the '\n').                                                    */
+typedef struct
+  { const uint8_t  *d_text;
+    const uint64_t *d_off;
+    const uint32_t *d_len;
+    uint64_t        n;
+    uint32_t        line_pad;
+  } dx_qv_batch;
+
+/* The order-dependent scan state of QVcoding_Scan (QV.c:993-1017): run characters (-1 none) and
+ * the GLOBAL entry index from which each run-length histogram starts counting.                  */
+typedef struct
+  { int32_t delChar, subChar;
+    int64_t del_first, sub_first;
+  } dx_qv_params;
+
+/* Finds delChar (deletion QV under the first 'n'/'N' tag, QV.c:993-1002) and the provisional
+ * subChar (argmax of the substitution histogram of the entries up to the one where the running
+ * symbol count first reaches 100000, ties to the smallest value, QV.c:1006-1015), on the device.
+ * entry0 = global index of the batch's first entry.  Fields of *p that are already set (>= 0)
+ * are kept; initialise *p to {-1,-1,-1,-1}.  The subChar search needs the file's first entries,
+ * so it only runs for the batch with entry0 == 0 (a shard holding the first 100000 symbols).   */
+int dx_qv_prescan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx_qv_params *p);
+
+/* Histogram_Seqs x4 + Histogram_Runs x2 (QV.c:702-724, 988-1017) over the batch: ADDS the
+ * batch's counts into hist (host, 6x256, order DX_DEL..DX_SRUN) and its symbol count into
+ * *totChar.  Run histograms are raw counts: the reference's start value of 1 per bin
+ * (QV.c:934-935) is added once by dx_qv_build.  Shards of one file: call per shard (any GPU),
+ * add the arrays on the host.                                                                   */
+int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, const dx_qv_params *p,
+               uint64_t hist[6][256], uint64_t *totChar);
+
+typedef struct
+  { int32_t  type;              /* 0 normal, 2 truncated with escape code (QV.c:76-81) */
+    uint32_t bits[256];
+    int32_t  lens[256];
+  } dx_scheme;
+
+typedef struct
+  { dx_scheme s[6];             /* DX_DEL..DX_SRUN; run schemes valid iff the run char is >= 0 */
+    int32_t   delChar, subChar; /* final values (subChar may have been dropped, QV.c:1044-1045) */
+  } dx_qv_coding;
+
+/* Create_QVcoding (QV.c:1029-1169) incl. Huffman/Reheap/Build_Table (QV.c:91-220): host only. */
+int dx_qv_build(const uint64_t hist[6][256], uint64_t totChar, const dx_qv_params *p, int lossy,
+                dx_qv_coding *out);
+
+/* Write_QVcoding (QV.c:1173-1210) / Read_QVcoding (QV.c:1214-1320) on memory images.  The
+ * image starts at the 0x33cc key (dexqv's own 0x55aa key, dexqv.c:105, is not included).       */
+int dx_qv_write_coding(const dx_qv_coding *c, const char *prefix, size_t plen,
+                       uint8_t *buf, size_t cap, size_t *written);
+int dx_qv_read_coding(const uint8_t *buf, size_t n, dx_qv_coding *c, int *flip,
+                      char *prefix, size_t pcap, size_t *consumed);
+
+/* Uploads the code tables for the kernels below (and remembers `lossy`, QV.c:1406-1415). */
+int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy);
+
+/* Record sizes: for each entry the bytes Compress_Next_QVentry (QV.c:1381-1426) would write
+ * (bit totals, pad rule QV.c:436-442 / 499-505, Pack_Tag length) plus its framing bytes
+ * d_hdr_off[i+1]-d_hdr_off[i] (NULL: none), then an exclusive scan in file order:
+ * d_rec_off[0..n] (device, n+1 entries), *total = d_rec_off[n].                                 */
+int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_hdr_off,
+                uint64_t *d_rec_off, uint64_t *total);
+
+/* Compress_Next_QVentry for the whole batch: record i = framing bytes, then the del words, tag
+ * bytes, ins words, mrg words, sub words (Encode / Encode_Run / Pack_Tag+Number_Read+
+ * Compress_Read, QV.c:386-506, 810-819, 1393-1423) at d_out + d_rec_off[i].  d_seg (optional,
+ * n x 5 uint32) receives the byte size of each segment -- the index the format itself does not
+ * store and a parallel decoder needs.                                                           */
+int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                 const uint64_t *d_rec_off, uint8_t *d_out, uint32_t *d_seg);
+
+/* Uncompress_Next_QVentry (QV.c:1428-1481: Decode, Decode_Run, Unpack_Tag) for n records whose
+ * segment starts are known: entry i's five segments start at d_in + d_seg_off[5*i+k]; the five
+ * decoded lines (d_len[i] symbols each, every line followed by '\n') are written at
+ * d_out + d_out_off[i].  upper != 0 applies undexqv's -U (undexqv.c:198-204).                  */
+int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_seg_off, const uint32_t *d_len,
+                 uint64_t n, int upper, uint8_t *d_out, const uint64_t *d_out_off);
+
+/* ------------------------------------------------------------------------------------------
+ *  whole-file drivers (host images in, host images out): what the six CLI tools call
+ * ------------------------------------------------------------------------------------------ */
+/* Each takes a complete input file image and returns the complete output image (malloc'd, free
+ * with dx_file_free), byte-identical to the file the reference tool writes.  On DX_E_FORMAT from
+ * the text front end, *errline / *errcode say where and why (DX_IDX_*).
+ *   dx_file_pack2    dexta.c:104-205 (arrow = 0) / dexar.c:103-211 (arrow = 1)
+ *   dx_file_unpack2  undexta.c:131-271 (mode DX_LETTERS_LOWER / _UPPER) / undexar.c:129-229 (_ARROW)
+ *   dx_file_dexqv    dexqv.c:79-143                                                             */
+int  dx_file_pack2  (dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
+                     uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
+int  dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
+                     uint8_t **out, size_t *out_len);
+int  dx_file_dexqv  (dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
+                     uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
+void dx_file_free(void *p);
+
+/* ------------------------------------------------------------------------------------------
+ *  seeded synthetic corpora on the device (benchmark/test plumbing; mirrors dextractor_amd/synth.py)
+ * ------------------------------------------------------------------------------------------ */
+/* Writes entries [entry0, entry0+n) of the .quiva corpus `seed`: for each entry the header line
+ * "@<movie>/WWWWWWWW/BBBBBBB_EEEEEEE RQ=0.QQQ\n" (fixed width, from d_hdr4 = well,beg,end,qv)
+ * ending right before d_off[i], then the five lines.  d_lut = 5 x 4096 symbol tables (del, tag,
+ * ins, mrg, sub); del_run = value under which the tag is 'N' (-1 never).                        */
+int dx_synth_quiva(dx_ctx *ctx, uint32_t seed, uint64_t entry0, uint64_t n,
+                   const uint64_t *d_off, const uint32_t *d_len, const int32_t *d_hdr4,
+                   const uint8_t *d_lut, int del_run, const char *movie, uint8_t *d_text);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

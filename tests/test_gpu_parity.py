@@ -1,0 +1,271 @@
+"""Parity of the HIP path against the oracle and the reference's golden bytes (needs an MI355X).
+
+Everything goes through the C-ABI of libdexgpu.so (ctypes).  Bar: bit-exact."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from dextractor_amd import _lib as L
+from dextractor_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _undex_args(flags):
+    upper = "-U" in flags
+    width = 80
+    for f in flags:
+        if f.startswith("-w"):
+            width = int(f[2:])
+    return upper, width
+
+
+# ---- golden fixtures: outputs of the compiled reference ----------------------------------------
+
+@pytest.mark.parametrize("case", O.cases("fasta"), ids=lambda c: c["name"])
+def test_dexta_golden(ctx, case):
+    txt, dx = O.golden(case["name"] + ".fasta"), O.golden(case["name"] + ".dexta")
+    assert ctx.dexta(txt) == dx
+    upper, width = _undex_args(case["undex_flags"])
+    rt = txt if case["rt_is_input"] else O.golden(case["name"] + ".rt.fasta")
+    assert ctx.undexta(dx, upper, width) == rt
+
+
+@pytest.mark.parametrize("case", O.cases("arrow"), ids=lambda c: c["name"])
+def test_dexar_golden(ctx, case):
+    txt, dx = O.golden(case["name"] + ".arrow"), O.golden(case["name"] + ".dexar")
+    assert ctx.dexar(txt) == dx
+    _, width = _undex_args(case["undex_flags"])
+    rt = txt if case["rt_is_input"] else O.golden(case["name"] + ".rt.arrow")
+    assert ctx.undexar(dx, width) == rt
+
+
+@pytest.mark.parametrize("case", O.cases("quiva"), ids=lambda c: c["name"])
+def test_dexqv_golden(ctx, case):
+    txt, dx = O.golden(case["input"] + ".quiva"), O.golden(case["name"] + ".dexqv")
+    got = ctx.dexqv(txt, "-l" in case["flags"])
+    assert len(got) == len(dx)
+    assert got == dx
+
+
+def test_config1_hash(ctx):
+    h = O.hashes()["config1_fasta"]
+    c = synth.make_seqfile("fasta", h["n"], seed=h["seed"], mean=h["mean"])
+    dx = ctx.dexta(c.text)
+    assert hashlib.sha256(dx).hexdigest() == h["dexta_sha256"]
+    assert ctx.undexta(dx, upper=True) == c.text                      # round trip byte-identical
+
+
+@pytest.mark.parametrize("lossy", [0, 1])
+def test_config4_sample_hash(ctx, lossy):
+    h = O.hashes()["config4s_quiva" + ("_lossy" if lossy else "")]
+    c = synth.make_quiva(h["n"], seed=h["seed"], mean=h["mean"])
+    dx = ctx.dexqv(c.text, lossy)
+    assert len(dx) == h["dexqv_bytes"]
+    assert hashlib.sha256(dx).hexdigest() == h["dexqv_sha256"]
+
+
+# ---- differential against the oracle on seeded corpora -----------------------------------------
+
+@pytest.mark.parametrize("kind", ["fasta", "arrow"])
+@pytest.mark.parametrize("seed,n,mean,width", [(1, 40, 50, 80), (2, 300, 1500, 80), (3, 64, 5000, 61), (4, 5, 70000, 80)])
+def test_pack2_vs_oracle(ctx, kind, seed, n, mean, width):
+    c = synth.make_seqfile(kind, n, seed=seed, mean=mean, width=width)
+    if kind == "fasta":
+        want = O.dexta(c.text)
+        assert ctx.dexta(c.text) == want
+        for upper, w in ((True, width), (False, 1), (False, 7), (True, 100000)):
+            assert ctx.undexta(want, upper, w) == O.undexta(want, upper, w)
+    else:
+        want = O.dexar(c.text)
+        assert ctx.dexar(c.text) == want
+        for w in (width, 3, 1024):
+            assert ctx.undexar(want, w) == O.undexar(want, w)
+
+
+def test_pack2_every_small_length(ctx):
+    """Reads of every length 0..200 and around the 1 KiB step / 16-byte lane boundaries."""
+    lens = np.array(list(range(0, 200)) + [1008, 1023, 1024, 1025, 1039, 1040, 2047, 2048, 2049, 4096 + 17],
+                    dtype=np.uint32)
+    for kind in ("fasta", "arrow"):
+        c = synth.make_seqfile(kind, len(lens), seed=11, lens=lens)
+        want = O.dexta(c.text) if kind == "fasta" else O.dexar(c.text)
+        got = ctx.dexta(c.text) if kind == "fasta" else ctx.dexar(c.text)
+        assert got == want
+        if kind == "fasta":
+            assert ctx.undexta(want, True, 80) == c.text
+        else:
+            assert ctx.undexar(want, 80) == c.text
+
+
+def test_pack2_arbitrary_bytes(ctx):
+    """Every byte value as a 'base': the maps of DB.c:393-441 (bytes >= 128 -> 0 / 3)."""
+    body = bytes(b for b in range(256) if b not in (10, 62)) * 3
+    fa = b">mv/1/0_%d RQ=0.8\n" % len(body) + body + b"\n"
+    assert ctx.dexta(fa)[-(len(body) + 3) // 4:] == O.dexta(fa)[-(len(body) + 3) // 4:]
+    ar = b">mv/1/0_%d SN=1.00,2.00,3.00,4.00\n" % len(body) + body + b"\n"
+    assert ctx.dexar(ar) == O.dexar(ar)
+
+
+def _upload_quiva(ctx, c):
+    d_text = ctx.to_device(np.frombuffer(c.text, np.uint8))
+    d_off, d_len = ctx.to_device(c.off), ctx.to_device(c.len)
+    return ctx.qv_batch(d_text, d_off, d_len, len(c.len)), (d_text, d_off, d_len)
+
+
+@pytest.mark.parametrize("seed,n,mean", [(1, 3, 300), (2, 13, 9000), (3, 40, 8000), (4, 700, 900), (5, 3000, 120)])
+def test_qv_scan_vs_oracle(ctx, seed, n, mean):
+    """k_qv_prescan + k_qv_hist == QVcoding_Scan (order-dependent start points included)."""
+    c = synth.make_quiva(n, seed=seed, mean=mean)
+    st = O.qv_scan(c.text)
+    b, keep = _upload_quiva(ctx, c)
+    p = ctx.qv_prescan(b)
+    assert (p.delChar, p.subChar) == (st.delChar, st.subChar)
+    assert (p.del_first, p.sub_first) == (st.del_first, st.sub_first)
+    hist, tot = ctx.qv_hist(b, p)
+    want = O.hist_array(st)
+    want[4:6] -= 1
+    assert tot == st.totChar
+    for s in range(6):
+        assert (hist[s] == want[s]).all(), f"histogram {s}"
+
+
+def test_qv_scan_late_delchar_and_none(ctx):
+    txt = O.golden("qv_runs.quiva")
+    off, ln, hdr, _ = api.index_quiva(txt)
+    st = O.qv_scan(txt)
+    assert st.del_first == 2
+    c = synth.Corpus(txt, off, ln, hdr)
+    b, keep = _upload_quiva(ctx, c)
+    p = ctx.qv_prescan(b)
+    assert (p.delChar, p.del_first, p.subChar) == (st.delChar, 2, st.subChar)
+    hist, tot = ctx.qv_hist(b, p)
+    want = O.hist_array(st); want[4:6] -= 1
+    assert (hist == want).all()
+    txt = O.golden("qv_nodel.quiva")
+    off, ln, hdr, _ = api.index_quiva(txt)
+    b, keep = _upload_quiva(ctx, synth.Corpus(txt, off, ln, hdr))
+    p = ctx.qv_prescan(b)
+    assert p.delChar == -1 and p.del_first == -1
+
+
+@pytest.mark.parametrize("lossy", [0, 1])
+@pytest.mark.parametrize("seed,n,mean", [(1, 3, 300), (2, 13, 9000), (3, 40, 8000), (4, 700, 900), (6, 24, 30000)])
+def test_dexqv_vs_oracle(ctx, seed, n, mean, lossy):
+    c = synth.make_quiva(n, seed=seed, mean=mean)
+    assert ctx.dexqv(c.text, lossy) == O.dexqv(c.text, lossy)
+
+
+@pytest.mark.parametrize("run_p", [0.02, 0.3, 0.6, 0.97, 0.999])
+def test_dexqv_run_densities(ctx, run_p):
+    prof = synth.pacbio_profile(del_run_p=run_p, sub_run_p=run_p)
+    c = synth.make_quiva(30, seed=77, mean=9000, prof=prof)
+    assert ctx.dexqv(c.text) == O.dexqv(c.text)
+
+
+def test_dexqv_every_small_length(ctx):
+    """Entries of every length 1..130 and around the step/lane boundaries; sizes and segments."""
+    lens = np.array(list(range(1, 131)) + [1007, 1008, 1009, 1023, 1024, 1025, 1040, 2048, 2049, 3000, 5000,
+                                           16384, 16385] + [9000] * 24, dtype=np.uint32)
+    c = synth.make_quiva(len(lens), seed=31, lens=lens)
+    want = O.dexqv(c.text)
+    assert ctx.dexqv(c.text) == want
+
+
+def test_qv_sizes_and_segments_vs_oracle(ctx):
+    """k_qv_sizes record offsets and the k_qv_encode segment index against per-entry oracle calls."""
+    c = synth.make_quiva(60, seed=8, mean=4000)
+    st = O.qv_scan(c.text)
+    ref_coding = O.qv_create(st)
+    b, keep = _upload_quiva(ctx, c)
+    p = ctx.qv_prescan(b)
+    hist, tot = ctx.qv_hist(b, p)
+    coding = api.qv_build(hist, tot, p)
+    ctx.qv_set_coding(coding)
+    blob, hoff, _ = api.frame_headers(c.hdr)
+    d_hdr, d_hoff = ctx.to_device(blob), ctx.to_device(hoff)
+    n = len(c.len)
+    d_rec = ctx.alloc(8 * (n + 1))
+    total = ctx.qv_sizes(b, d_hoff, d_rec)
+    rec = d_rec.download(np.uint64)
+    d_out, d_seg = ctx.alloc(total), ctx.alloc(4 * 5 * n)
+    ctx.qv_encode(b, d_hdr, d_hoff, d_rec, d_out, d_seg)
+    out = d_out.download(np.uint8, total).tobytes()
+    seg = d_seg.download(np.uint32, 5 * n).reshape(n, 5)
+    text = np.frombuffer(c.text, np.uint8)
+    at = 0
+    for i in range(n):
+        L = int(c.len[i]); o = int(c.off[i])
+        lines = np.stack([text[o + k * (L + 1): o + k * (L + 1) + L] for k in range(5)])
+        body, want_seg = O.qv_encode_entry(ref_coding, False, lines)
+        hl = int(hoff[i + 1] - hoff[i])
+        assert int(rec[i]) == at
+        assert list(seg[i]) == want_seg
+        assert out[at + hl: at + hl + len(body)] == body
+        at += hl + len(body)
+    assert int(rec[n]) == at == total
+
+
+def test_qv_type2_and_pad_rule(ctx):
+    """Fibonacci-weighted symbols (8-bit escapes) in every stream position + all pad-rule branches."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    f = [1, 1]
+    while len(f) < 23:
+        f.append(f[-1] + f[-2])
+    pool = np.concatenate([np.full(cn, 40 + i, np.uint8) for i, cn in enumerate(f)])
+    ents = []
+    prof = synth.pacbio_profile()
+    for e in range(30):
+        L = int(rng.integers(1, 4000))
+        b = synth.qv_lines(5, e, L, prof)
+        b[2] = rng.choice(pool, L)
+        b[3] = rng.choice(pool, L)
+        ents.append((10 + e * 7, 0, 800, [b[r].tobytes() for r in range(5)]))
+    out = []
+    for well, beg, qv, lines in ents:
+        L = len(lines[0])
+        out.append(b"@m9/%d/%d_%d RQ=0.%d\n" % (well, beg, beg + L, qv))
+        out += [x + b"\n" for x in lines]
+    txt = b"".join(out)
+    want = O.dexqv(txt)
+    assert ctx.dexqv(txt) == want
+
+
+def test_device_generator_matches_numpy(ctx):
+    n = 37
+    lens = synth.lengths(n, 5, mean=700)
+    lens[3] = 1; lens[4] = 16; lens[5] = 1024; lens[6] = 1025
+    hdr = synth.headers(n, 5, lens)
+    prof = synth.pacbio_profile()
+    c = synth.make_quiva(n, seed=5, lens=lens, fixed_width=True, prof=prof)
+    d_off, d_len, d_hdr = ctx.to_device(c.off), ctx.to_device(c.len), ctx.to_device(hdr)
+    d_lut = ctx.to_device(prof.table())
+    d_text = ctx.alloc(len(c.text)).zero()
+    ctx.synth_quiva(5, 0, n, d_off, d_len, d_hdr, d_lut, prof.del_run, "m000_000", d_text)
+    assert d_text.download(np.uint8, len(c.text)).tobytes() == c.text
+    # a slice generated on its own equals the same entries of the whole corpus
+    d_text2 = ctx.alloc(len(c.text)).zero()
+    ctx.synth_quiva(5, 20, n - 20, ctx.to_device(c.off[20:]), ctx.to_device(c.len[20:]), ctx.to_device(hdr[20:]),
+                    d_lut, prof.del_run, "m000_000", d_text2)
+    lo = int(c.off[20]) - 43
+    assert d_text2.download(np.uint8, len(c.text)).tobytes()[lo:] == c.text[lo:]
+
+
+def test_errors_are_loud(ctx):
+    with pytest.raises(L.DexGPUError) as e:
+        ctx.dexqv(b"@m/1/0_3 RQ=0.8\nabc\nabc\nab\nabc\nabc\n")
+    assert e.value.code == -3
+    with pytest.raises(L.DexGPUError):
+        ctx.undexta(b"\x00\x01garbage")
+    with pytest.raises(L.DexGPUError):
+        ctx.undexta(O.golden("ta_edge.dexta"), False, 0)

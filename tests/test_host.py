@@ -1,0 +1,170 @@
+"""CPU-side tests of the product's host logic (no GPU): the C-ABI library loads and exports every
+declared symbol; Huffman/coding-header builder, record framing and the text front end agree with
+the oracle and with the reference's golden bytes."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from dextractor_amd import _lib as L
+from dextractor_amd import api, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "dexgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dx_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 30
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in dexgpu.h but not exported"
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+
+
+def _params(st):
+    return L.QVParams(st.delChar, st.subChar, st.del_first, st.sub_first)
+
+
+def _raw_hist(st):
+    h = O.hist_array(st)
+    h[4:6] -= 1                       # dx_qv_build adds the reference's start value of 1 itself
+    return h
+
+
+@pytest.mark.parametrize("case", O.cases("quiva"), ids=lambda c: c["name"])
+def test_build_matches_oracle_and_golden_header(case):
+    txt = O.golden(case["input"] + ".quiva")
+    lossy = "-l" in case["flags"]
+    st = O.qv_scan(txt)
+    want = O.qv_create(st, lossy)
+    got = api.qv_build(_raw_hist(st), st.totChar, _params(st), lossy)
+    assert (got.delChar, got.subChar) == (want.delChar, want.subChar)
+    for s in range(6):
+        if (s == 4 and got.delChar < 0) or (s == 5 and got.subChar < 0):
+            continue
+        assert got.s[s].type == want.s[s].type
+        assert list(got.s[s].bits) == list(want.s[s].bits)
+        assert list(got.s[s].lens) == list(want.s[s].lens)
+    # Write_QVcoding bytes == the golden file's header (after dexqv's own 0x55aa key)
+    dx = O.golden(case["name"] + ".dexqv")
+    prefix = txt[: txt.index(b"/", 1)]
+    img = api.qv_write_coding(got, prefix)
+    assert dx[:2] == b"\xaa\x55" and dx[2: 2 + len(img)] == img
+    back, flip, pre, used = api.qv_read_coding(dx[2:])
+    assert flip == 0 and pre == prefix and used == len(img)
+    assert (back.delChar, back.subChar) == (got.delChar, got.subChar)
+    assert list(back.s[1].bits) == list(got.s[1].bits) and list(back.s[1].lens) == list(got.s[1].lens)
+
+
+def test_build_random_histograms_match_oracle():
+    rng = np.random.Generator(np.random.PCG64(5))
+    lib = O.lib()
+    for trial in range(300):
+        nsym = int(rng.integers(1, 257))
+        kind = trial % 4
+        h = np.zeros(256, np.uint64)
+        idx = rng.choice(256, nsym, replace=False)
+        if kind == 0:
+            h[idx] = rng.integers(1, 1000, nsym)
+        elif kind == 1:
+            h[idx] = rng.integers(1, 4, nsym)                       # many ties
+        elif kind == 2:
+            h[idx] = (1.6 ** np.minimum(rng.permutation(nsym), 80)).astype(np.uint64) + 1   # deep tree -> truncated
+        else:
+            h[idx] = 1 << rng.integers(0, 40, nsym).astype(np.uint64)
+        hist = np.zeros((6, 256), np.uint64)
+        hist[:4] = h
+        hist[4:] = rng.integers(0, 5, (2, 256))
+        p = L.QVParams(-1, -1, -1, -1)
+        try:
+            got = api.qv_build(hist, 10, p, False)
+        except L.DexGPUError as e:
+            assert e.code == -5                                    # a >16-bit escape code: unsupported
+            continue
+        first, want = O.Scheme(), O.Scheme()
+        hh = (C.c_uint64 * 256)(*[int(x) for x in h])
+        assert lib.ref_huffman(hh, None, C.byref(first)) == 0
+        if first.type:
+            assert lib.ref_huffman(hh, C.byref(first), C.byref(want)) == 0
+        else:
+            want = first
+        assert got.s[0].type == want.type
+        assert list(got.s[0].bits) == list(want.bits) and list(got.s[0].lens) == list(want.lens)
+
+
+def test_build_degenerate_and_errors():
+    hist = np.zeros((6, 256), np.uint64)
+    with pytest.raises(L.DexGPUError) as e:
+        api.qv_build(hist, 0, L.QVParams(-1, -1, -1, -1), False)
+    assert e.value.code == -4                                      # empty histogram
+
+
+def test_frame_headers_known_bytes():
+    hdr = np.array([[5, 0, 5, 851], [5, 10, 10, 800], [260, 3, 10, 0], [770, 0, 2, 85]], np.int32)
+    blob, off, last = api.frame_headers(hdr)
+    want = bytes.fromhex("05" "00000000" "05000000" "53030000"
+                         "00" "0a000000" "0a000000" "20030000"
+                         "ff00" "03000000" "0a000000" "00000000"
+                         "ffff00" "00000000" "02000000" "55000000")
+    assert blob.tobytes() == want and list(off) == [0, 13, 26, 40, 55] and last == 770
+    # negative delta wraps the byte like the reference's (uint8) cast, dexta.c:192
+    blob, off, _ = api.frame_headers(np.array([[10, 0, 0, 0], [7, 0, 0, 0]], np.int32))
+    assert blob[13] == (7 - 10) & 0xff
+    # arrow framing + SNR conversion (dexar.c:159-163)
+    lib = L.load()
+    assert [lib.dx_snr_to_cnr(np.float32(v)) for v in (6.81, 99.99, 100.5, 0.0)] == [680, 9998, 9999, 0]
+    cnr = np.array([[680, 9998, 9999, 0]], np.uint16)
+    blob, off, _ = api.frame_headers(np.array([[5, 0, 6, 0]], np.int32), cnr)
+    assert blob.tobytes() == bytes.fromhex("05" "00000000" "06000000" "a8020e270f270000")
+
+
+def test_index_quiva_matches_generator():
+    c = synth.make_quiva(9, seed=5, mean=700)
+    off, ln, hdr, pl = api.index_quiva(c.text)
+    assert (off == c.off).all() and (ln == c.len).all() and (hdr == c.hdr).all()
+    assert c.text[:pl] == b"@m000_000"
+
+
+@pytest.mark.parametrize("bad,code", [
+    (b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc", 1),            # no final newline
+    (b"m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n", 2),           # header missing
+    (b"@m 1 0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n", 3),          # no slash
+    (b"@m/1/0_3\nabc\nabc\nabc\nabc\nabc\n", 3),                 # RQ field required (QV.c:964)
+    (b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\n", 4),                    # incomplete entry
+    (b"@m/1/0_3 RQ=0.8\nabc\nabc\nab\nabc\nabc\n", 5),           # ragged
+])
+def test_index_quiva_rejects(bad, code):
+    lib = L.load()
+    cnt, pl, line, ec = C.c_uint64(), C.c_size_t(), C.c_uint64(), C.c_int()
+    rc = lib.dx_index_quiva(bad, len(bad), 0, None, None, None, C.byref(cnt), C.byref(pl), C.byref(line), C.byref(ec))
+    assert rc == -3 and ec.value == code
+    with pytest.raises(ValueError):
+        O.dexqv(bad)                                               # the oracle rejects it too
+
+
+@pytest.mark.parametrize("kind", ["fasta", "arrow"])
+def test_index_seq_matches_generator(kind):
+    c = synth.make_seqfile(kind, 7, seed=3, mean=300, width=70)
+    off, tl, ns, hdr, cnr, pl = api.index_seq(c.text, arrow=(kind == "arrow"))
+    assert (off == c.off).all() and (tl == c.tlen).all() and (ns == c.len).all()
+    assert (hdr[:, :3] == c.hdr[:, :3]).all()
+    if kind == "fasta":
+        assert (hdr[:, 3] == c.hdr[:, 3]).all()
+    else:
+        want = (np.array(c.snr, dtype=np.float64) * 100 + 0.5).astype(np.int64)
+        assert (cnr == want).all()
+
+
+def test_index_seq_edge_file():
+    txt = O.golden("ta_edge.fasta")
+    off, tl, ns, hdr, cnr, pl = api.index_seq(txt)
+    assert list(ns) == [5, 0, 7, 2, 4, 1, 6, 173, 80]
+    assert list(tl) == [6, 0, 8, 3, 5, 2, 7, 176, 81]
+    assert list(hdr[:, 0]) == [5, 5, 260, 770, 771, 1025, 1281, 1881, 1881]
+    assert list(hdr[:, 3]) == [851, 800, 0, 85, 9, 75, 123456, 77, 5]
+    assert txt[:pl] == b">mv"
