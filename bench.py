@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""dexqv-encode throughput on MI355X (BASELINE.json metric: input GB/s, round-trip bit-exact).
+
+One "step" = one complete dexqv encode of the resident synthetic .quiva batch:
+    k_qv_prescan -> k_qv_hist -> (12 KB to host, Huffman tables, ~6 KB back) -> k_qv_sizes ->
+    k_scan -> k_qv_encode
+with the input image already in HBM when the timed region starts and the .dexqv record stream
+left in HBM.  Workload at N=1: BASELINE.json configs[3] -- 1 M entries x 10 kb (5e10 stream
+bytes); weak scaling for N>1 (every rank holds its own 1 M-entry slice of one corpus; the only
+exchange is the 12 KB histogram sum + 32 B of scan state on the host side, via gloo -- no RCCL
+on the data path).
+
+Prints ONE JSON line (rank 0).  `value` = 5 * bases * steps / wall over all ranks, in GB/s.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--entries", type=int, default=1_000_000, help="entries per GPU")
+    ap.add_argument("--mean", type=int, default=10_000)
+    ap.add_argument("--dist", default="fixed", choices=["fixed", "lognormal"])
+    ap.add_argument("--lossy", action="store_true")
+    ap.add_argument("--seed", type=int, default=20261003)
+    ap.add_argument("--cpu-sample-entries", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+
+    from dextractor_amd import _lib as L
+    from dextractor_amd import api, synth
+
+    ctx = api.Context(local)
+    n = args.entries
+    entry0 = rank * n
+    movie = "m000_000"
+    hlen = 1 + len(movie) + 1 + 8 + 1 + 7 + 1 + 7 + 6 + 3 + 1
+
+    # ---- corpus slice of this rank, generated straight into HBM -----------------------------------
+    lens = synth.lengths(entry0 + n, args.seed, args.dist, args.mean)[entry0:]
+    hdr4 = synth.headers(n, args.seed, lens, entry0)
+    rec_bytes = hlen + 5 * (lens.astype(np.uint64) + 1)
+    off = (np.concatenate([[0], np.cumsum(rec_bytes)[:-1]]) + hlen).astype(np.uint64)
+    text_bytes = int(rec_bytes.sum())
+    bases = int(lens.astype(np.uint64).sum())
+    prof = synth.pacbio_profile()
+
+    d_text = torch.empty(text_bytes + 64, dtype=torch.uint8, device="cuda")
+    t_off, t_len = torch.from_numpy(off.view(np.int64)).cuda(), torch.from_numpy(lens.view(np.int32)).cuda()
+    t_hdr4 = torch.from_numpy(hdr4.reshape(-1)).cuda()
+    t_lut = torch.from_numpy(prof.table().reshape(-1)).cuda()
+
+    class Ptr:                                   # torch-owned device memory seen through the C-ABI
+        def __init__(self, t): self.t, self.ptr = t, t.data_ptr()
+
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    p_text, p_off, p_len = Ptr(d_text), Ptr(t_off), Ptr(t_len)
+    ctx.synth_quiva(args.seed, entry0, n, p_off, p_len, Ptr(t_hdr4), Ptr(t_lut), prof.del_run, movie, p_text)
+    ctx.sync()
+    batch = ctx.qv_batch(p_text, p_off, p_len, n)
+
+    # record framing bytes (host, O(records)): well deltas need the previous slice's last well
+    lwell0 = 0 if entry0 == 0 else int(synth.headers(1, args.seed, lens[:1] * 0, entry0 - 1)[0, 0])
+    blob, hoff, _ = api.frame_headers(hdr4, None, lwell0)
+    p_hdr = Ptr(torch.from_numpy(blob.copy()).cuda())
+    p_hoff = Ptr(torch.from_numpy(hoff.view(np.int64)).cuda())
+    p_rec = Ptr(torch.empty(n + 1, dtype=torch.int64, device="cuda"))
+    out_cap = int(2.2 * bases) + int(hoff[-1]) + 4096
+    p_out = Ptr(torch.empty(out_cap, dtype=torch.uint8, device="cuda"))
+
+    state = {}
+
+    def step():
+        p = ctx.qv_prescan(batch, entry0)
+        if world > 1:                        # one file sharded over the ranks: agree on the scan state
+            mine = torch.tensor([p.delChar, p.del_first, p.subChar, p.sub_first], dtype=torch.int64)
+            every = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(every, mine)
+            found = [e for e in every if e[0] >= 0]
+            d = found[0] if found else every[0]
+            p = L.QVParams(int(d[0]), int(every[0][2]), int(d[1]), int(every[0][3]))
+        hist, tot = ctx.qv_hist(batch, p, entry0)
+        if world > 1:                        # host-side sum of the 12 KB histograms (no RCCL)
+            h = torch.from_numpy(np.concatenate([hist.reshape(-1), [tot]]).astype(np.int64))
+            dist.all_reduce(h)
+            hist, tot = h[:-1].numpy().astype(np.uint64).reshape(6, 256), int(h[-1])
+        coding = api.qv_build(hist, tot, p, args.lossy)
+        ctx.qv_set_coding(coding, args.lossy)
+        total = ctx.qv_sizes(batch, p_hoff, p_rec)
+        assert total <= out_cap, (total, out_cap)
+        ctx.qv_encode(batch, p_hdr, p_hoff, p_rec, p_out)
+        state.update(total=total, coding=coding, params=p)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    times = ctx.kernel_times()
+    ctx.profile(False)
+
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+        bb = torch.tensor([bases, state["total"]], dtype=torch.int64)
+        dist.all_reduce(bb)
+        all_bases, all_out = int(bb[0]), int(bb[1])
+    else:
+        all_bases, all_out = bases, state["total"]
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = 5.0 * all_bases * args.steps / dt / 1e9
+
+    # ---- roofline of the dominant kernel (per-launch algorithmic bytes / measured launch time) -----
+    algo = {"k_qv_hist": 4.0 * bases, "k_qv_sizes": 4.0 * bases,
+            "k_qv_encode": 5.0 * bases + state["total"]}
+    kern = {k: {"ms_avg": ms / cnt, "launches": cnt} for k, (ms, cnt) in times.items()}
+    for k, b in algo.items():
+        if k in kern:
+            kern[k]["algo_bytes"] = b
+            kern[k]["GBps"] = b / (kern[k]["ms_avg"] * 1e-3) / 1e9
+    dom = max(algo, key=lambda k: kern.get(k, {}).get("ms_avg", 0.0))
+    traffic = None
+    if os.path.exists(args.traffic_file):
+        try:
+            tf = json.load(open(args.traffic_file))
+            if tf.get("entries") == n and tf.get("mean") == args.mean and tf.get("dist") == args.dist:
+                traffic = tf["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(kern[dom]["GBps"], 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algo_bytes_per_launch": algo[dom]}
+    # whole pipeline against the same roofline: (4 + 5) B/base read + output written, over kernel time
+    ktime = sum(kern[k]["ms_avg"] for k in kern if k != "k_synth") * 1e-3
+    pipe = {"algo_bytes": 9.0 * bases + state["total"], "kernel_ms": round(ktime * 1e3, 3),
+            "GBps": round((9.0 * bases + state["total"]) / ktime / 1e9, 1)}
+    pipe["frac"] = round(pipe["GBps"] / HBM_PEAK_GBS, 4)
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state)
+
+    line = {
+        "metric": "dexqv encode input GB/s (5 QV/tag stream bytes per base; .dexqv bit-exact vs reference)",
+        "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"dexqv 5-stream Huffman encode, {n} x {args.mean} .quiva per GPU "
+                               f"({args.dist} lengths, BASELINE.json configs[3]), HBM-resident",
+                   "entries_per_gpu": n, "mean_len": args.mean, "lossy": bool(args.lossy),
+                   "input_bytes_per_gpu": 5 * bases, "text_image_bytes_per_gpu": text_bytes,
+                   "output_bytes": all_out, "ratio": round(5.0 * all_bases / all_out, 3),
+                   "sharding": "contiguous entry ranges, one file (host-side 12 KB histogram sum)" if world > 1 else "single GPU"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "pipeline": pipe,
+        "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                    for k, v in kern.items()},
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state):
+    """Time the CPU path on a bounded sample of the same corpus (first S entries), on this host.
+    kind "reference": the real reference `dexqv` (oracle/_ref, compiled from the reference's own
+    sources); kind "port": the oracle's C restatement.  Also checks the GPU output for the same
+    sample against it (bit-exact)."""
+    S = min(args.cpu_sample_entries, len(lens))
+    end = int(off[S - 1] + 5 * (int(lens[S - 1]) + 1)) if S else 0
+    sample = d_text[:end].cpu().numpy().tobytes()
+    sbases = int(lens[:S].astype(np.uint64).sum())
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "dexqv")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    res = {"unit": "GB/s", "cores": 1,
+           "sample": f"first {S} entries of the bench corpus ({5 * sbases / 1e9:.2f} GB of stream bytes)"}
+    want = None
+    if os.path.isfile(ref_bin):
+        with tempfile.TemporaryDirectory(dir=shm) as d:
+            src = os.path.join(d, "s.quiva")
+            with open(src, "wb") as f:
+                f.write(sample)
+            t0 = time.perf_counter()
+            subprocess.check_call([ref_bin, "-k"] + (["-l"] if args.lossy else []) + [src])
+            dt = time.perf_counter() - t0
+            with open(os.path.join(d, "s.dexqv"), "rb") as f:
+                want = f.read()
+        res.update(kind="reference", value=round(5 * sbases / dt / 1e9, 4), seconds=round(dt, 2))
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        t0 = time.perf_counter()
+        want = O.dexqv(sample, args.lossy)
+        dt = time.perf_counter() - t0
+        res.update(kind="port", value=round(5 * sbases / dt / 1e9, 4), seconds=round(dt, 2))
+    got = ctx.dexqv(sample, args.lossy)          # same sample through the GPU path (file driver)
+    res["gpu_output_identical"] = bool(got == want)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,288 @@
+/*
+ * cli_common.c -- command-line surface of the reference's six codec tools, on top of libdexgpu.
+ *
+ * Same flags, usage text, file naming (<dir>/<root><.ext>), -i pipe mode, -v messages, source
+ * removal unless -k, error messages and exit codes as dexta.c / undexta.c / dexar.c / undexar.c /
+ * dexqv.c / undexqv.c (argument macros DB.h:79-123, path helpers DB.c:112-181).  The file is
+ * read whole, handed to the GPU through the whole-file drivers of libdexgpu, and the result is
+ * written whole.  There is no CPU codec here: without a HIP device the tools fail loudly.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <unistd.h>
+
+#include "cli_common.h"
+#include "dexgpu.h"
+
+typedef struct
+  { const char *name, *flags, *src_ext, *dst_ext, *what, *usage;
+    int         pipe_ok;
+    const char *help[4];
+  } tool_t;
+
+static const tool_t TOOLS[6] =
+  { { "dexta",   "vki",  ".fasta", ".dexta", "Fasta", "[-vk] ( -i | <path:fasta> ... )", 1,
+      { "      -i: source is on standard input.\n",
+        "      -k: do *not* remove the .fasta file on completion.\n",
+        "      -w: line width for sequence lines.\n", NULL } },
+    { "undexta", "vkiU", ".dexta", ".fasta", "dexta", "[-vkU] [-w<int(80)>] ( -i | <path:dexta> ... )", 1,
+      { "      -i: source is on standard input.\n",
+        "      -k: do *not* remove the .dexta file on completion.\n",
+        "      -U: use uppercase letters (default is lower case).\n",
+        "      -w: line width for sequence lines.\n" } },
+    { "dexar",   "vki",  ".arrow", ".dexar", "Arrow", "[-vk] ( -i | <path:arrow> ... )", 1,
+      { "      -i: source is on standard input.\n",
+        "      -k: do *not* remove the .arrow file on completion.\n", NULL, NULL } },
+    { "undexar", "vki",  ".dexar", ".arrow", "dexar", "[-vk] [-w<int(80)>] ( -i | <path:dexar> ... )", 1,
+      { "      -i: source is on standard input.\n",
+        "      -k: do *not* remove the .dexar file on completion.\n",
+        "      -w: line width for arrow lines.\n", NULL } },
+    { "dexqv",   "vkl",  ".quiva", ".dexqv", "quiva", "[-vkl] <path:quiva> ...", 0,
+      { "      -k: do *not* remove the .quiva file on completion.\n",
+        "      -l: use lossy compression (not recommended).\n", NULL, NULL } },
+    { "undexqv", "vkU",  ".dexqv", ".quiva", "dexqv", "[-vkU] <path:dexqv> ...", 0,
+      { "      -k: do *not* remove the .dexqv file on completion.\n",
+        "      -U: use uppercase letters (default is lower case).\n", NULL, NULL } } };
+
+static const char *Prog;
+
+/* ---- whole-file I/O ---------------------------------------------------------------------- */
+
+static uint8_t *slurp(FILE *f, size_t *n)
+{ size_t cap = 1 << 20, len = 0, k;
+  uint8_t *buf = malloc(cap);
+  if (buf == NULL) return NULL;
+  while ((k = fread(buf + len, 1, cap - len, f)) > 0)
+    { len += k;
+      if (len == cap)
+        { uint8_t *nb = realloc(buf, cap *= 2);
+          if (nb == NULL) { free(buf); return NULL; }
+          buf = nb;
+        }
+    }
+  *n = len;
+  return buf;
+}
+
+/* directory part / root name, as PathTo and Root do (DB.c:112-160) */
+static char *path_to(const char *name)
+{ const char *s = strrchr(name, '/');
+  char *p;
+  if (s == NULL) return strdup(".");
+  p = malloc((size_t) (s - name) + 1);
+  memcpy(p, name, (size_t) (s - name));
+  p[s - name] = '\0';
+  return p;
+}
+
+static char *root_of(const char *name, const char *suffix)
+{ const char *f = strrchr(name, '/');
+  size_t fl, sl = strlen(suffix);
+  char  *r;
+  f  = f ? f + 1 : name;
+  fl = strlen(f);
+  r  = strdup(f);
+  if (fl > sl && strcasecmp(f + (fl - sl), suffix) == 0)
+    r[fl - sl] = '\0';
+  return r;
+}
+
+static char *catenate(const char *dir, const char *root, const char *ext)
+{ char *p = malloc(strlen(dir) + strlen(root) + strlen(ext) + 2);
+  sprintf(p, "%s/%s%s", dir, root, ext);
+  return p;
+}
+
+/* ---- error reporting in the reference's words ------------------------------------------------ */
+
+static void report_text_error(int tool, uint64_t line, int code)
+{ const tool_t *t = &TOOLS[tool];
+  if (tool == TOOL_DEXQV)
+    switch (code)
+      { case DX_IDX_NO_NEWLINE: fprintf(stderr, "Line %llu: Last line does not end with a newline !\n", (unsigned long long) line); break;   /* QV.c:779 */
+        case DX_IDX_NO_HEADER:  fprintf(stderr, "Line %llu: Header in quiva file is missing\n", (unsigned long long) line); break;          /* QV.c:955 */
+        case DX_IDX_INCOMPLETE: fprintf(stderr, "Line %llu: incomplete last entry of .quiv file\n", (unsigned long long) line); break;      /* QV.c:789 */
+        case DX_IDX_RAGGED:     fprintf(stderr, "Line %llu: Lines for an entry are not the same length\n", (unsigned long long) line); break; /* QV.c:793 */
+        default:                fprintf(stderr, "%s: Line %llu: Header line incorrectly formatted ?\n", Prog, (unsigned long long) line); break; /* QV.c:960 */
+      }
+  else
+    switch (code)
+      { case DX_IDX_TOO_LONG:
+        case DX_IDX_NO_NEWLINE:
+        case DX_IDX_EMPTY:     fprintf(stderr, "Line %llu: %s line is too long (> %d chars)\n", (unsigned long long) line, t->what, 99998); break;   /* dexta.c:110,168 */
+        case DX_IDX_NO_HEADER: fprintf(stderr, "Line 1: First header in %s file is missing\n", tool == TOOL_DEXTA ? "fasta" : "arrow"); break;   /* dexta.c:114 */
+        default:               fprintf(stderr, "%s: Header line incorrectly formatted ?\n", Prog); break;                                        /* dexta.c:120,148,154 */
+      }
+}
+
+/* ---- one file --------------------------------------------------------------------------------- */
+
+static int convert(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, int opt_U, int opt_l, int width,
+                   uint8_t **out, size_t *out_len)
+{ uint64_t line = 0;
+  int      code = 0, rc;
+  switch (tool)
+    { case TOOL_DEXTA:   rc = dx_file_pack2(ctx, 0, in, n, out, out_len, &line, &code); break;
+      case TOOL_DEXAR:   rc = dx_file_pack2(ctx, 1, in, n, out, out_len, &line, &code); break;
+      case TOOL_UNDEXTA: rc = dx_file_unpack2(ctx, opt_U ? DX_LETTERS_UPPER : DX_LETTERS_LOWER, in, n, (uint32_t) width, out, out_len); break;
+      case TOOL_UNDEXAR: rc = dx_file_unpack2(ctx, DX_LETTERS_ARROW, in, n, (uint32_t) width, out, out_len); break;
+      case TOOL_DEXQV:   rc = dx_file_dexqv(ctx, in, n, opt_l, out, out_len, &line, &code); break;
+      default:           rc = dx_file_undexqv(ctx, in, n, opt_U, out, out_len); break;
+    }
+  if (rc == DX_OK)
+    return 0;
+  if (rc == DX_E_FORMAT && (tool == TOOL_DEXTA || tool == TOOL_DEXAR || tool == TOOL_DEXQV))
+    { report_text_error(tool, line, code);
+      return 1;
+    }
+  if (rc == DX_E_FORMAT && n >= 2 && (tool == TOOL_UNDEXTA || tool == TOOL_UNDEXAR))
+    { uint16_t key;
+      memcpy(&key, in, 2);
+      if (key != 0x55aa && key != 0xaa55 && !(tool == TOOL_UNDEXTA && (key == 0x33cc || key == 0xcc33)))
+        { fprintf(stderr, "%s: Not a .%s file, endian key invalid\n", Prog, TOOLS[tool].what);   /* undexta.c:156 */
+          return 1;
+        }
+    }
+  if (rc == DX_E_FORMAT)
+    { fprintf(stderr, "%s: System error, read failed!\n", Prog);                                 /* DB.h:136-139 */
+      return 2;
+    }
+  fprintf(stderr, "%s: %s (libdexgpu error %d)\n", Prog, dx_last_error(ctx), rc);
+  return 1;
+}
+
+int dex_tool_main(int tool, int argc, char *argv[])
+{ const tool_t *t = &TOOLS[tool];
+  int     flags[128], i, j, k, width = 80;
+  int     VERBOSE, KEEP, PIPE, UPPER, LOSSY;
+  dx_ctx *ctx = NULL;
+
+  Prog = t->name;
+  memset(flags, 0, sizeof(flags));
+
+  j = 1;                                                   /* ARG_INIT / ARG_FLAGS, DB.h:79-91 */
+  for (i = 1; i < argc; i++)
+    if (argv[i][0] == '-')
+      { if (argv[i][1] == 'w' && (tool == TOOL_UNDEXTA || tool == TOOL_UNDEXAR))
+          { char *eptr;                                    /* ARG_NON_NEGATIVE, DB.h:105-115 */
+            width = (int) strtol(argv[i] + 2, &eptr, 10);
+            if (*eptr != '\0' || argv[i][2] == '\0')
+              { fprintf(stderr, "%s: -%c '%s' argument is not an integer\n", Prog, argv[i][1], argv[i] + 2);
+                exit(1);
+              }
+            if (width < 0)
+              { fprintf(stderr, "%s: %s must be non-negative (%d)\n", Prog, "Line width", width);
+                exit(1);
+              }
+            continue;
+          }
+        for (k = 1; argv[i][k] != '\0'; k++)
+          { if (strchr(t->flags, argv[i][k]) == NULL)
+              { fprintf(stderr, "%s: -%c is an illegal option\n", Prog, argv[i][k]);
+                exit(1);
+              }
+            flags[(int) argv[i][k]] = 1;
+          }
+      }
+    else
+      argv[j++] = argv[i];
+  argc = j;
+
+  VERBOSE = flags['v'];
+  KEEP    = flags['k'];
+  PIPE    = flags['i'];
+  UPPER   = flags['U'];
+  LOSSY   = flags['l'];
+
+  if ((t->pipe_ok && ((PIPE && argc > 1) || (!PIPE && argc <= 1))) || (!t->pipe_ok && argc == 1))
+    { fprintf(stderr, "Usage: %s %s\n", Prog, t->usage);   /* e.g. dexta.c:47-54 */
+      fprintf(stderr, "\n");
+      for (k = 0; k < 4; k++)
+        if (t->help[k] != NULL)
+          fprintf(stderr, "%s", t->help[k]);
+      exit(1);
+    }
+  if (PIPE)
+    { KEEP = 1;
+      argc = 2;
+    }
+  if (width == 0)
+    { fprintf(stderr, "%s: Line width must be positive (the reference never terminates on -w0)\n", Prog);
+      exit(1);
+    }
+
+  { const char *dev = getenv("DEXGPU_DEVICE");
+    if (dx_open(dev ? atoi(dev) : 0, &ctx) != DX_OK)
+      { fprintf(stderr, "%s: cannot open a GPU: %s\n", Prog, dx_last_error(NULL));
+        exit(1);
+      }
+  }
+
+  for (i = 1; i < argc; i++)
+    { char    *pwd = NULL, *root, *src = NULL, *dst = NULL;
+      FILE    *input, *output;
+      uint8_t *in, *out = NULL;
+      size_t   n = 0, out_len = 0;
+      int      st;
+
+      if (PIPE)
+        { input  = stdin;
+          output = stdout;
+          root   = strdup("Standard Input");
+        }
+      else
+        { pwd  = path_to(argv[i]);                         /* dexta.c:87-94 */
+          root = root_of(argv[i], t->src_ext);
+          src  = catenate(pwd, root, t->src_ext);
+          dst  = catenate(pwd, root, t->dst_ext);
+          if ((input = fopen(src, "r")) == NULL)
+            { fprintf(stderr, "%s: Cannot open %s for 'r'\n", Prog, src);   /* Fopen, DB.c:103-110 */
+              exit(1);
+            }
+          if ((output = fopen(dst, "w")) == NULL)
+            { fprintf(stderr, "%s: Cannot open %s for 'w'\n", Prog, dst);
+              exit(1);
+            }
+        }
+
+      if (VERBOSE)
+        { fprintf(stderr, "Processing '%s' ...\n", root);
+          fflush(stderr);
+        }
+
+      in = slurp(input, &n);
+      if (in == NULL)
+        { fprintf(stderr, "%s: Out of memory (Allocating read buffer)\n", Prog);
+          exit(1);
+        }
+      st = convert(ctx, tool, in, n, UPPER, LOSSY, width, &out, &out_len);
+      if (st != 0)
+        exit(st);
+      if (out_len > 0 && fwrite(out, 1, out_len, output) != out_len)
+        { fprintf(stderr, "%s: System error, write failed!\n", Prog);
+          exit(2);
+        }
+      dx_file_free(out);
+      free(in);
+
+      if (!PIPE)
+        { fclose(input);
+          fclose(output);
+          if (!KEEP)
+            unlink(src);
+        }
+      else
+        fflush(output);
+      free(root); free(pwd); free(src); free(dst);
+
+      if (VERBOSE)
+        { fprintf(stderr, "Done\n");
+          fflush(stderr);
+        }
+    }
+
+  dx_close(ctx);
+  exit(0);
+}

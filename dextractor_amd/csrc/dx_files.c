@@ -333,3 +333,13 @@ done:
   free(off); free(hoff); free(len); free(hdr4); free(blob); free(cd); free(hist); free(img);
   return rc;
 }
+
+/* ==========================================================================================
+ *  undexqv  (round-1: pending the device decoder)
+ * ========================================================================================== */
+int dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper, uint8_t **out, size_t *out_len)
+{ (void) img; (void) n; (void) upper;
+  if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
+  *out = NULL; *out_len = 0;
+  return DX_E_UNSUPPORTED;
+}

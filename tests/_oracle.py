@@ -77,8 +77,8 @@ def _call(fn, data, cap, *mid):
 
 def dexta(txt):   return _call(lib().ref_dexta, txt, len(txt) // 3 + 4096)
 def dexar(txt):   return _call(lib().ref_dexar, txt, len(txt) // 3 + 4096)
-def undexta(img, upper=False, width=80): return _call(lib().ref_undexta, img, 6 * len(img) + 4096, int(upper), width)
-def undexar(img, width=80):              return _call(lib().ref_undexar, img, 6 * len(img) + 4096, width)
+def undexta(img, upper=False, width=80): return _call(lib().ref_undexta, img, 9 * len(img) + 65536, int(upper), width)
+def undexar(img, width=80):              return _call(lib().ref_undexar, img, 9 * len(img) + 65536, width)
 def dexqv(txt, lossy=False):             return _call(lib().ref_dexqv, txt, 2 * len(txt) + 65536, int(lossy))
 def undexqv(img, upper=False):           return _call(lib().ref_undexqv, img, 12 * len(img) + 65536, int(upper))
 
