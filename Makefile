@@ -8,7 +8,8 @@ ARCH    ?= gfx950
 CSRC     = dextractor_amd/csrc
 BUILD    = build
 LIB      = dextractor_amd/libdexgpu.so
-HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+EXTRA   ?=
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(EXTRA)
 CFLAGS   = -O2 -fPIC -Iinclude -Wall -Wextra
 
 HIP_SRC  = dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth

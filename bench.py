@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--cpu-sample-entries", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="timing experiments with ablated kernels")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
     return ap.parse_args()
 
@@ -87,7 +88,7 @@ def main():
     p_text, p_off, p_len = Ptr(d_text), Ptr(t_off), Ptr(t_len)
     ctx.synth_quiva(args.seed, entry0, n, p_off, p_len, Ptr(t_hdr4), Ptr(t_lut), prof.del_run, movie, p_text)
     ctx.sync()
-    batch = ctx.qv_batch(p_text, p_off, p_len, n)
+    batch = ctx.qv_batch(p_text, p_off, p_len, n, text_bytes=text_bytes + 64)
 
     # record framing bytes (host, O(records)): well deltas need the previous slice's last well
     lwell0 = 0 if entry0 == 0 else int(synth.headers(1, args.seed, lens[:1] * 0, entry0 - 1)[0, 0])
@@ -95,6 +96,7 @@ def main():
     p_hdr = Ptr(torch.from_numpy(blob.copy()).cuda())
     p_hoff = Ptr(torch.from_numpy(hoff.view(np.int64)).cuda())
     p_rec = Ptr(torch.empty(n + 1, dtype=torch.int64, device="cuda"))
+    p_seg = Ptr(torch.empty(5 * n, dtype=torch.int32, device="cuda"))
     out_cap = int(2.2 * bases) + int(hoff[-1]) + 4096
     p_out = Ptr(torch.empty(out_cap, dtype=torch.uint8, device="cuda"))
 
@@ -116,9 +118,13 @@ def main():
             hist, tot = h[:-1].numpy().astype(np.uint64).reshape(6, 256), int(h[-1])
         coding = api.qv_build(hist, tot, p, args.lossy)
         ctx.qv_set_coding(coding, args.lossy)
-        total = ctx.qv_sizes(batch, p_hoff, p_rec)
+        total = ctx.qv_sizes(batch, p_hoff, p_seg, p_rec)
         assert total <= out_cap, (total, out_cap)
-        ctx.qv_encode(batch, p_hdr, p_hoff, p_rec, p_out)
+        try:
+            ctx.qv_encode(batch, p_hdr, p_hoff, p_rec, p_seg, p_out)
+        except L.DexGPUError:
+            if not args.no_check:
+                raise
         state.update(total=total, coding=coding, params=p)
 
     def fence():

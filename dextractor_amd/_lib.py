@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdexgpu.so")
+LIB_PATH = os.environ.get("DEXGPU_LIB") or os.path.join(HERE, "libdexgpu.so")   # DEXGPU_LIB: A/B builds
 
 DX_OK = 0
 ERR_NAMES = {-1: "DX_E_ARG", -2: "DX_E_HIP", -3: "DX_E_FORMAT", -4: "DX_E_DEGENERATE",
@@ -24,7 +24,7 @@ KERNELS = ["k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_q
 
 class QVBatch(C.Structure):
     _fields_ = [("d_text", C.c_void_p), ("d_off", C.c_void_p), ("d_len", C.c_void_p),
-                ("n", C.c_uint64), ("line_pad", C.c_uint32)]
+                ("n", C.c_uint64), ("text_bytes", C.c_uint64), ("line_pad", C.c_uint32)]
 
 
 class QVParams(C.Structure):
@@ -78,7 +78,7 @@ SIGNATURES = {
     "dx_qv_read_coding": (C.c_int, [_P, C.c_size_t, C.POINTER(QVCoding), C.POINTER(C.c_int), _P, C.c_size_t,
                                     C.POINTER(C.c_size_t)]),
     "dx_qv_set_coding": (C.c_int, [_P, C.POINTER(QVCoding), C.c_int]),
-    "dx_qv_sizes": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, C.POINTER(C.c_uint64)]),
+    "dx_qv_sizes": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, C.POINTER(C.c_uint64)]),
     "dx_qv_encode": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, _P, _P]),
     "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
     "dx_file_pack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),

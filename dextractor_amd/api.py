@@ -111,8 +111,8 @@ class Context:
 
     # ---- QV coder ----------------------------------------------------------------------------
     @staticmethod
-    def qv_batch(d_text, d_off, d_len, n, line_pad=1) -> L.QVBatch:
-        return L.QVBatch(d_text.ptr, d_off.ptr, d_len.ptr, n, line_pad)
+    def qv_batch(d_text, d_off, d_len, n, line_pad=1, text_bytes=0) -> L.QVBatch:
+        return L.QVBatch(d_text.ptr, d_off.ptr, d_len.ptr, n, text_bytes, line_pad)
 
     def qv_prescan(self, batch, entry0=0, params=None) -> L.QVParams:
         p = params or L.QVParams(-1, -1, -1, -1)
@@ -131,16 +131,16 @@ class Context:
     def qv_set_coding(self, coding, lossy=False):
         self._chk(self.lib.dx_qv_set_coding(self.h, C.byref(coding), int(lossy)))
 
-    def qv_sizes(self, batch, d_hdr_off, d_rec_off) -> int:
+    def qv_sizes(self, batch, d_hdr_off, d_seg, d_rec_off) -> int:
         tot = C.c_uint64()
         self._chk(self.lib.dx_qv_sizes(self.h, C.byref(batch), d_hdr_off.ptr if d_hdr_off else None,
-                                       d_rec_off.ptr, C.byref(tot)))
+                                       d_seg.ptr, d_rec_off.ptr, C.byref(tot)))
         return tot.value
 
-    def qv_encode(self, batch, d_hdr, d_hdr_off, d_rec_off, d_out, d_seg=None):
+    def qv_encode(self, batch, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out):
         self._chk(self.lib.dx_qv_encode(self.h, C.byref(batch), d_hdr.ptr if d_hdr else None,
-                                        d_hdr_off.ptr if d_hdr_off else None, d_rec_off.ptr, d_out.ptr,
-                                        d_seg.ptr if d_seg else None))
+                                        d_hdr_off.ptr if d_hdr_off else None, d_rec_off.ptr, d_seg.ptr,
+                                        d_out.ptr))
 
     def synth_quiva(self, seed, entry0, n, d_off, d_len, d_hdr4, d_lut, del_run, movie, d_text):
         self._chk(self.lib.dx_synth_quiva(self.h, seed & 0xFFFFFFFF, entry0, n, d_off.ptr, d_len.ptr, d_hdr4.ptr,

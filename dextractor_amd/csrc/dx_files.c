@@ -272,7 +272,7 @@ int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
   dx_qv_params p = { -1, -1, -1, -1 };
   dx_qv_coding *cd = NULL;
   uint64_t   (*hist)[256] = NULL;
-  void        *d_text, *d_off, *d_len, *d_hdr, *d_hoff, *d_rec, *d_out;
+  void        *d_text, *d_off, *d_len, *d_hdr, *d_hoff, *d_rec, *d_seg, *d_out;
   int          rc;
 
   if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
@@ -303,7 +303,9 @@ int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
   TRY(dupload(&pool, blob, (size_t) hoff[cnt], &d_hdr));
   TRY(dupload(&pool, hoff, (cnt + 1) * 8, &d_hoff));
   TRY(dalloc(&pool, (cnt + 1) * 8, &d_rec));
+  TRY(dalloc(&pool, cnt * 5 * 4, &d_seg));
   b.d_text = d_text; b.d_off = d_off; b.d_len = d_len; b.n = cnt; b.line_pad = 1;
+  b.text_bytes = n;
 
   /* ... and histogram on the device (QV.c:988-1017) */
   TRY(dx_qv_prescan(ctx, &b, 0, &p));
@@ -315,7 +317,7 @@ int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
   if (rc != DX_OK && rc != DX_E_SPACE) goto done;
   head = 2 + clen;
 
-  TRY(dx_qv_sizes(ctx, &b, d_hoff, d_rec, &total));
+  TRY(dx_qv_sizes(ctx, &b, d_hoff, d_seg, d_rec, &total));
   img = malloc(head + total + 16);
   if (!img) { rc = DX_E_NOMEM; goto done; }
   { uint16_t key = 0x55aa;                                                 /* dexqv.c:105-108 */
@@ -323,7 +325,7 @@ int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
     TRY(dx_qv_write_coding(cd, (const char *) text, plen, img + 2, clen, &clen));
   }
   TRY(dalloc(&pool, total, &d_out));
-  TRY(dx_qv_encode(ctx, &b, d_hdr, d_hoff, d_rec, d_out, NULL));          /* pass 2, dexqv.c:112-143 */
+  TRY(dx_qv_encode(ctx, &b, d_hdr, d_hoff, d_rec, d_seg, d_out));          /* pass 2, dexqv.c:112-143 */
   TRY(dx_d2h(ctx, img + head, d_out, total));
   *out = img; *out_len = head + total; img = NULL;
   rc = DX_OK;

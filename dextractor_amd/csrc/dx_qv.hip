@@ -8,14 +8,15 @@
 //   Compress_Next_QVentry   QV.c:1381-1426 (segment order del, tag, ins, mrg, sub; lossy mask)
 //
 // Roofline: HBM.  Algorithmic bytes per base: histogram pass 4 read; encode pass 5 read + C
-// written (C = output bytes per base, ~1.44).  The size pass re-reads 4 and the tag segment
-// re-reads the deletion line (both counted against `achieved`, not as algorithmic bytes).
+// written (C = output bytes per base, ~1.44).  The size pass re-reads 4 B/base (counted against
+// `achieved`, not as algorithmic bytes).
 //
-// Layout: one 64-lane wavefront per .quiva entry, grid-stride over entries.  A wave walks each
-// stream 1 KiB per step (16 bytes per lane, one unaligned global_load_dwordx4).  Code tables
-// live in LDS as packed tokens; a DPP inclusive prefix sum over the lanes' bit counts places
-// every lane's bits in a per-wave LDS word window (ds_or_b32); completed 32-bit words leave
-// with coalesced dword stores at the segment's (byte-granular) file offset.
+// Layout: one 64-lane wavefront per .quiva entry, grid-stride over entries.  A wave walks the
+// streams 1 KiB per step (16 bytes per lane, one unaligned global_load_dwordx4 each), with the
+// next step's chunks already in flight (register prefetch) while the current ones are processed.
+// Code tables live in LDS as packed tokens; a DPP inclusive prefix sum over the lanes' bit counts
+// places every lane's bits in a per-wave LDS word window (ds_or_b32); completed 32-bit words
+// leave with coalesced dword stores at the segment's (byte-granular) file offset.
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 
@@ -26,14 +27,31 @@
 #define TOK_BITS(e) ((e) & 0xffffffu)
 #define TOK_ESC(e)  ((e) >> 31)
 
-#define QV_WIN_WORDS 512                     // per-wave LDS window (2 KiB)
-#define QV_WIN_BITS  (32u * (QV_WIN_WORDS - 32))   // usable bits: leaves room for one lane's worst case (896 bits)
+#define QV_WIN_WORDS  512                          // per-wave LDS bit window (2 KiB)
+#define QV_WIN_BITS   (32u * (QV_WIN_WORDS - 32))  // usable: one lane's worst case (896 bits) always fits
+#define QV_FLUSH_BITS 8192u                        // drain the window once it holds this much
+#define TAG_WIN_WORDS 128                          // per-wave window of the tag segment
+#define TAG_FLUSH_BITS 1024u
+
+#define HREP 4                                     // replication of the LDS symbol histograms
+
+// minimum waves per SIMD the register allocator must leave room for (caps VGPRs: 512 / waves)
+#ifndef HIST_WAVES
+#define HIST_WAVES 4
+#endif
+#ifndef SIZES_WAVES
+#define SIZES_WAVES 4
+#endif
+#ifndef ENC_WAVES
+#define ENC_WAVES 4
+#endif
 
 struct qv_args
 { const uint8_t  *text;
   const uint64_t *off;
   const uint32_t *len;
   uint64_t        n;
+  uint64_t        text_bytes;   // readable bytes at text (0: unknown -> never read past a line)
   uint32_t        pad;          // line_pad
   int             delChar, subChar;
   int             lossy;
@@ -42,30 +60,74 @@ struct qv_args
 __device__ __forceinline__ const uint8_t *line_ptr(const qv_args &a, uint64_t r, uint32_t L, int k)
 { return a.text + a.off[r] + (uint64_t) k * ((uint64_t) L + a.pad); }
 
-// ---------------------------------------------------------------------------------------------
-//  run-length bookkeeping shared by the histogram, size and encode kernels
-// ---------------------------------------------------------------------------------------------
-// For one 1-KiB step of a run-coded stream: `nr` is the lane's 16-bit mask of NON-run symbols.
-// Returns the number of run characters immediately preceding this lane's first byte (runs
-// continue across lanes and across steps through C) and updates C for the next step.
-__device__ __forceinline__ uint32_t run_carry(uint32_t nr, int valid, uint32_t step_valid, uint32_t &C)
-{ const int      lane  = lane_id();
-  const uint32_t trail = nr ? (uint32_t) valid - 1u - (31u - (uint32_t) __clz(nr)) : 0u;
-  const uint64_t Z     = __ballot(nr != 0);
-  const uint64_t lower = Z & ((1ull << lane) - 1ull);
-  const int      j     = lower ? 63 - __clzll(lower) : 0;
-  const uint32_t tj    = __shfl(trail, j);
-  const uint32_t carry = lower ? 16u * (uint32_t) (lane - j - 1) + tj : C + 16u * (uint32_t) lane;
-  if (Z == 0)
-    C += step_valid;
-  else
-    { const int      jl = 63 - __clzll(Z);                       // wave-uniform
-      const uint32_t tl = __builtin_amdgcn_readlane(trail, jl);
-      const uint32_t vl = step_valid - 16u * jl >= 16u ? 16u : step_valid - 16u * jl;
-      C = tl + step_valid - 16u * jl - vl;
+// may the last (partial) lane of this line be read with a full 16-byte load?
+__device__ __forceinline__ bool can_overread(const qv_args &a, const uint8_t *p, uint32_t L)
+{ return (uint64_t) (p - a.text) + L + 16u <= a.text_bytes; }
+
+// this lane's 16 bytes of a stream at p+pos: bytes [0,valid) real, the rest zero
+__device__ __forceinline__ u32x4 fetch(const uint8_t *p, uint32_t pos, uint32_t L, bool over)
+{ u32x4 v = { 0u, 0u, 0u, 0u };
+  if (pos < L)
+    { const uint32_t left = L - pos;
+      if (left >= 16u)
+        v = *(const u32x4_u *) (p + pos);
+      else if (over)
+        { v = *(const u32x4_u *) (p + pos);
+          const uint32_t m0 = left >= 4u  ? ~0u : ~(~0u << (8u * left));
+          const uint32_t m1 = left >= 8u  ? ~0u : (left > 4u  ? ~(~0u << (8u * (left - 4u)))  : 0u);
+          const uint32_t m2 = left >= 12u ? ~0u : (left > 8u  ? ~(~0u << (8u * (left - 8u)))  : 0u);
+          const uint32_t m3 =                     (left > 12u ? ~(~0u << (8u * (left - 12u))) : 0u);
+          v.x &= m0; v.y &= m1; v.z &= m2; v.w &= m3;
+        }
+      else
+        v = load_chunk(p + pos, (int) left);
     }
-  return carry;
+  return v;
 }
+
+__device__ __forceinline__ int valid_of(uint32_t pos, uint32_t L)
+{ return pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos)); }
+
+#define BYTE_OF(c, b) ((chunk_word(c, (b) >> 2) >> (8 * ((b) & 3))) & 0xffu)
+
+// ---------------------------------------------------------------------------------------------
+//  run-coded streams: dense token processing (shared by the histogram, size and encode kernels)
+// ---------------------------------------------------------------------------------------------
+// Only the non-run symbols of a run-coded stream (15-20 % of it) produce tokens.  Letting every
+// lane loop over the non-run symbols of its own 16 bytes runs to the worst lane's count with a
+// third of the lanes busy.  Instead each step first compacts the positions of its non-run symbols
+// into an LDS list (wave prefix sum of the per-lane counts) next to a copy of the 1-KiB chunk;
+// the tokens are then processed 64 at a time, one per lane: the run before token i is simply
+// list[i] - list[i-1] - 1, and C carries the run that is open at the step's start.
+struct run_lds
+{ uint8_t  *chunk;        // this wave's 1 KiB copy of the step's bytes (16-byte aligned)
+  uint16_t *list;         // ascending step-relative positions of the non-run symbols
+};
+
+__device__ __forceinline__ uint32_t run_collect(const run_lds &R, const u32x4 &c, int valid, uint32_t rc)
+{ const int lane = lane_id();
+  uint32_t       nr   = ~chunk_eq_mask(c, rc) & ((1u << valid) - 1u);
+  const uint32_t cnt  = __popc(nr);
+  const uint32_t incl = wave_incl_scan(cnt);
+  uint32_t       idx  = incl - cnt;
+  *(u32x4 *) (R.chunk + 16 * lane) = c;
+  while (nr)
+    { R.list[idx++] = (uint16_t) (16 * lane + __ffs(nr) - 1);
+      nr &= nr - 1u;
+    }
+  wave_sync();
+  return wave_total(incl);
+}
+
+// token i of the step (i < total): symbol and preceding run length
+#define RUN_TOKEN(R, i, C, pos, x, run)                                                         \
+  const uint32_t pos = (R).list[i];                                                             \
+  const uint32_t x   = (R).chunk[pos];                                                          \
+  const uint32_t run = (i) ? pos - (uint32_t) (R).list[(i) - 1] - 1u : (C) + pos;
+
+// run open at the end of a step of sv bytes with `total` tokens
+__device__ __forceinline__ uint32_t run_after(const run_lds &R, uint32_t total, uint32_t sv, uint32_t C)
+{ return total ? sv - 1u - (uint32_t) R.list[total - 1] : C + sv; }
 
 // =============================================================================================
 //  prescan: delChar / subChar discovery (QV.c:993-1015)
@@ -90,7 +152,7 @@ void k_qv_prescan_del(qv_args a, uint64_t entry0, unsigned long long *key)
       bool found = false, done = false;
       for (uint32_t base = 0; base < L && !done; base += DX_STEP)
         { const uint32_t pos   = base + 16u * lane;
-          const int      valid = pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos));
+          const int      valid = valid_of(pos, L);
           const u32x4    c     = load_chunk(tag + pos, valid);
           const uint32_t m     = (chunk_eq_mask(c, 'n') | chunk_eq_mask(c, 'N')) & ((1u << valid) - 1u);
           const uint64_t any   = __ballot(m != 0);
@@ -166,91 +228,104 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 // =============================================================================================
 //  histogram pass (QV.c:702-724, 988-1017)
 // =============================================================================================
+// Symbol histograms live in LDS with every bin replicated HREP times (copy = lane & (HREP-1)),
+// which divides the same-address serialisation of ds_add_u32 on the dominant symbols by HREP.
 
-__device__ __forceinline__ void hist_plain(const uint8_t *p, uint32_t L, uint32_t *h)
-{ const int lane = lane_id();
-  for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const uint32_t pos = base + 16u * lane;
-      if (L - base >= DX_STEP)                         // full step: no lane is partial
-        { const u32x4 c = *(const u32x4_u *) (p + pos);
-          #pragma unroll
-          for (int b = 0; b < 16; b++)
-            atomicAdd(&h[(chunk_word(c, b >> 2) >> (8 * (b & 3))) & 0xffu], 1u);
-        }
-      else
-        { const int   valid = pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos));
-          const u32x4 c     = load_chunk(p + pos, valid);
-          for (int b = 0; b < valid; b++)
-            atomicAdd(&h[chunk_byte(c, b)], 1u);
-        }
+__device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool full, uint32_t *h)
+{ const uint32_t k = (uint32_t) lane_id() & (HREP - 1);
+  if (full)
+    {
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        atomicAdd(&h[BYTE_OF(c, b) * HREP + k], 1u);
     }
+  else
+    for (int b = 0; b < valid; b++)
+      atomicAdd(&h[chunk_byte(c, b) * HREP + k], 1u);
 }
 
-// symbol histogram + run-length histogram of a run-coded stream; the run character itself is
-// counted with popcounts instead of LDS atomics (it is 80-85 % of the stream)
-__device__ __forceinline__ void hist_runs(const uint8_t *p, uint32_t L, uint32_t rc, uint32_t *hs, uint32_t *hr)
-{ const int lane = lane_id();
-  uint32_t  C = 0, nrun = 0;
-  for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const uint32_t pos   = base + 16u * lane;
-      const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
-      const int      valid = pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos));
-      const u32x4    c     = load_chunk(p + pos, valid);
-      const uint32_t vm    = (1u << valid) - 1u;
-      uint32_t       nr    = ~chunk_eq_mask(c, rc) & vm;
-      nrun += (uint32_t) valid - __popc(nr);
-      uint32_t run  = run_carry(nr, valid, sv, C);
-      int      prev = -1;
-      while (nr)
-        { const int b = __ffs(nr) - 1;
-          run += (uint32_t) (b - prev - 1);
-          atomicAdd(&hr[run > 255u ? 255u : run], 1u);             // QV.c:717-720
-          atomicAdd(&hs[chunk_byte(c, b)], 1u);
-          run  = 0;
-          prev = b;
-          nr  &= nr - 1u;
-        }
+// one step of a run-coded stream: non-run symbols and the run before each (QV.c:709-724); the run
+// character itself is counted with popcounts instead of LDS atomics (it is 80-85 % of the stream)
+__device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c, int valid, uint32_t sv, uint32_t rc,
+                                               uint32_t &C, uint32_t &nrun, uint32_t *hs, uint32_t *hr)
+{ const int      lane  = lane_id();
+  const uint32_t k     = (uint32_t) lane & (HREP - 1);
+  const uint32_t total = run_collect(R, c, valid, rc);
+  nrun += sv - total;                                            // wave-uniform
+  for (uint32_t i = lane; i < total; i += 64)
+    { RUN_TOKEN(R, i, C, pos, x, run)
+      atomicAdd(&hr[run > 255u ? 255u : run], 1u);               // QV.c:717-720
+      atomicAdd(&hs[x * HREP + k], 1u);
     }
-  if (C > 0 && lane == 0)                                          // stream ends in the run char
-    atomicAdd(&hr[C > 255u ? 255u : C], 1u);
-  const uint32_t tot = wave_sum(nrun);
-  if (lane == 0 && tot)
-    atomicAdd(&hs[rc], tot);
+  C = run_after(R, total, sv, C);
+  wave_sync();
 }
 
-__global__ __launch_bounds__(DX_BLOCK)
+__global__ __launch_bounds__(DX_BLOCK, HIST_WAVES)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
                unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot)
-{ __shared__ uint32_t s_hist[6][256];
+{ __shared__ uint32_t s_sym[4][256 * HREP];
+  __shared__ uint32_t s_run[2][256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_chunk[DX_WAVES_PER_BLK][DX_STEP];
+  __shared__ uint16_t s_list[DX_WAVES_PER_BLK][DX_STEP];
   const int      lane  = lane_id();
   const int      tid   = threadIdx.x;
   const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (tid >> 6);
   const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  const run_lds  R     = { s_chunk[tid >> 6], s_list[tid >> 6] };
 
-  for (int k = tid; k < 6 * 256; k += DX_BLOCK)
-    (&s_hist[0][0])[k] = 0;
+  for (int k = tid; k < 4 * 256 * HREP; k += DX_BLOCK) (&s_sym[0][0])[k] = 0;
+  for (int k = tid; k < 2 * 256; k += DX_BLOCK)        (&s_run[0][0])[k] = 0;
   __syncthreads();
 
   uint64_t tot = 0, since = 0;
   for (uint64_t r = wave0; r < a.n; r += nwave)
     { const uint32_t  L = a.len[r];
       const long long g = (long long) (entry0 + r);
-      if (a.delChar >= 0 && g >= del_first)
-        hist_runs(line_ptr(a, r, L, 0), L, (uint32_t) a.delChar, s_hist[DX_DEL], s_hist[DX_DRUN]);
-      else
-        hist_plain(line_ptr(a, r, L, 0), L, s_hist[DX_DEL]);
-      hist_plain(line_ptr(a, r, L, 2), L, s_hist[DX_INS]);
-      hist_plain(line_ptr(a, r, L, 3), L, s_hist[DX_MRG]);
-      if (a.subChar >= 0 && g >= sub_first)
-        hist_runs(line_ptr(a, r, L, 4), L, (uint32_t) a.subChar, s_hist[DX_SUB], s_hist[DX_SRUN]);
-      else
-        hist_plain(line_ptr(a, r, L, 4), L, s_hist[DX_SUB]);
+      const bool drun = a.delChar >= 0 && g >= del_first;
+      const bool srun = a.subChar >= 0 && g >= sub_first;
+      const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2);
+      const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
+      const bool over = can_overread(a, p4, L);       // p4 is the last line of the entry
+      uint32_t C0 = 0, C4 = 0, n0 = 0, n4 = 0;
+
+      uint32_t pos = 16u * lane;
+      u32x4 c0 = fetch(p0, pos, L, over), c2 = fetch(p2, pos, L, over);
+      u32x4 c3 = fetch(p3, pos, L, over), c4 = fetch(p4, pos, L, over);
+      for (uint32_t base = 0; base < L; base += DX_STEP)
+        { const uint32_t np = pos + DX_STEP;           // next step's chunks go in flight first
+          const u32x4 d0 = fetch(p0, np, L, over), d2 = fetch(p2, np, L, over);
+          const u32x4 d3 = fetch(p3, np, L, over), d4 = fetch(p4, np, L, over);
+          const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
+          const bool     full  = sv == DX_STEP;
+          const int      valid = valid_of(pos, L);
+          if (drun) hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, s_sym[DX_DEL], s_run[0]);
+          else      hist_plain_step(c0, valid, full, s_sym[DX_DEL]);
+          hist_plain_step(c2, valid, full, s_sym[DX_INS]);
+          hist_plain_step(c3, valid, full, s_sym[DX_MRG]);
+          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, s_sym[DX_SUB], s_run[1]);
+          else      hist_plain_step(c4, valid, full, s_sym[DX_SUB]);
+          c0 = d0; c2 = d2; c3 = d3; c4 = d4;
+          pos = np;
+        }
+      if (drun)                                        // trailing run + the run character's own count
+        { if (C0 > 0 && lane == 0) atomicAdd(&s_run[0][C0 > 255u ? 255u : C0], 1u);
+          if (lane == 0 && n0) atomicAdd(&s_sym[DX_DEL][(uint32_t) a.delChar * HREP], n0);
+        }
+      if (srun)
+        { if (C4 > 0 && lane == 0) atomicAdd(&s_run[1][C4 > 255u ? 255u : C4], 1u);
+          if (lane == 0 && n4) atomicAdd(&s_sym[DX_SUB][(uint32_t) a.subChar * HREP], n4);
+        }
       tot   += L;
       since += L;
-      if (since >= (1ull << 26))                   // keep the 32-bit LDS bins far from overflow
-        { for (int k = lane; k < 6 * 256; k += 64)
-            { const uint32_t v = atomicExch(&(&s_hist[0][0])[k], 0u);
-              if (v) atomicAdd(&g_hist[k], (unsigned long long) v);
+      if (since >= (1ull << 26))                       // keep the 32-bit LDS bins far from overflow
+        { for (int k = lane; k < 4 * 256 * HREP; k += 64)
+            { const uint32_t v = atomicExch(&(&s_sym[0][0])[k], 0u);
+              if (v) atomicAdd(&g_hist[k / HREP], (unsigned long long) v);
+            }
+          for (int k = lane; k < 2 * 256; k += 64)
+            { const uint32_t v = atomicExch(&(&s_run[0][0])[k], 0u);
+              if (v) atomicAdd(&g_hist[4 * 256 + k], (unsigned long long) v);
             }
           since = 0;
         }
@@ -258,9 +333,14 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   if (lane == 0 && tot)
     atomicAdd(g_tot, (unsigned long long) tot);
   __syncthreads();
-  for (int k = tid; k < 6 * 256; k += DX_BLOCK)
-    { const uint32_t v = (&s_hist[0][0])[k];
+  for (int k = tid; k < 4 * 256; k += DX_BLOCK)
+    { uint32_t v = 0;
+      for (int j = 0; j < HREP; j++) v += (&s_sym[0][0])[k * HREP + j];
       if (v) atomicAdd(&g_hist[k], (unsigned long long) v);
+    }
+  for (int k = tid; k < 2 * 256; k += DX_BLOCK)
+    { const uint32_t v = (&s_run[0][0])[k];
+      if (v) atomicAdd(&g_hist[4 * 256 + k], (unsigned long long) v);
     }
 }
 
@@ -273,9 +353,9 @@ __device__ __forceinline__ void load_tables(uint32_t (*s_tok)[256], const uint32
   __syncthreads();
 }
 
-// words Encode/Encode_Run write for T bits whose final OCODE piece had `last` bits
-// (QV.c:436-442): the partial word, plus one more when the decoder's 16-bit look-ahead would
-// otherwise run past it.
+// words Encode/Encode_Run write beyond the data for T bits whose final OCODE piece had `last`
+// bits (QV.c:436-442): one more word when the decoder's 16-bit look-ahead would otherwise run
+// past the stream.
 __device__ __forceinline__ uint32_t pad_extra(uint64_t T, uint32_t last)
 { const uint32_t olen = (uint32_t) T & 31u;
   const uint32_t llen = (uint32_t) (T - last) & 31u;
@@ -290,131 +370,131 @@ __device__ __forceinline__ uint32_t last_piece_plain(const uint32_t *tab, const 
   return TOK_ESC(e) ? 8u : TOK_LEN(e);
 }
 
-// =============================================================================================
-//  size pass: bit totals only
-// =============================================================================================
-__device__ __forceinline__ uint64_t bits_plain(const uint8_t *p, uint32_t L, const uint32_t *tab, uint32_t mask)
-{ const int lane = lane_id();
-  uint32_t  acc  = 0;
-  uint64_t  tot  = 0;
-  const uint32_t m4 = mask * 0x01010101u;
-  for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const uint32_t pos = base + 16u * lane;
-      if (L - base >= DX_STEP)
-        { const u32x4 c = *(const u32x4_u *) (p + pos);
-          #pragma unroll
-          for (int b = 0; b < 16; b++)
-            acc += TOK_LEN(tab[((chunk_word(c, b >> 2) & m4) >> (8 * (b & 3))) & 0xffu]);
-        }
-      else
-        { const int   valid = pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos));
-          const u32x4 c     = load_chunk(p + pos, valid);
-          for (int b = 0; b < valid; b++)
-            acc += TOK_LEN(tab[chunk_byte(c, b) & mask]);
-        }
-      if ((base & 0x3ffffffu) == 0x3fffc00u)           // fold long before a 32-bit lane sum can wrap
-        { tot += wave_sum(acc);
-          acc  = 0;
-        }
-    }
-  return tot + wave_sum(acc);
-}
+__device__ __forceinline__ uint32_t seg_bytes(uint64_t T, uint32_t last)
+{ return 4u * ((uint32_t) (T >> 5) + (((uint32_t) T & 31u) ? 1u : 0u) + pad_extra(T, last)); }
 
 __device__ __forceinline__ uint32_t run_token_len(const uint32_t *rtab, uint32_t run)
 { const uint32_t e = rtab[run > 255u ? 255u : run];               // QV.c:479-487
   return TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
 }
 
-// bit total of Encode_Run; also returns the number of non-run symbols (Pack_Tag's clen) and the
-// length of the final piece
-__device__ __forceinline__ uint64_t bits_runs(const uint8_t *p, uint32_t L, uint32_t rc,
-                                              const uint32_t *ntab, const uint32_t *rtab,
-                                              uint32_t &nonrun, uint32_t &last)
-{ const int lane = lane_id();
-  uint32_t  C = 0, acc = 0, nn = 0;
-  uint64_t  tot = 0;
-  for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const uint32_t pos   = base + 16u * lane;
-      const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
-      const int      valid = pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos));
-      const u32x4    c     = load_chunk(p + pos, valid);
-      uint32_t       nr    = ~chunk_eq_mask(c, rc) & ((1u << valid) - 1u);
-      nn += __popc(nr);
-      uint32_t run  = run_carry(nr, valid, sv, C);
-      int      prev = -1;
-      while (nr)
-        { const int b = __ffs(nr) - 1;
-          run += (uint32_t) (b - prev - 1);
-          acc += run_token_len(rtab, run) + TOK_LEN(ntab[chunk_byte(c, b)]);
-          run  = 0;
-          prev = b;
-          nr  &= nr - 1u;
-        }
-      if ((base & 0x3ffffffu) == 0x3fffc00u)
-        { tot += wave_sum(acc);
-          acc  = 0;
-        }
-    }
-  tot   += wave_sum(acc);
-  nonrun = wave_sum(nn);
-  if (C > 0)                                                      // trailing run token
-    { const uint32_t e = rtab[C > 255u ? 255u : C];
-      tot += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
-      last = TOK_ESC(e) ? 16u : TOK_LEN(e);
+// =============================================================================================
+//  size pass: bit totals only (4 streams in one sweep)
+// =============================================================================================
+__device__ __forceinline__ uint32_t bits_plain_step(const u32x4 &c, int valid, bool full, const uint32_t *tab, uint32_t m4)
+{ uint32_t acc = 0;
+  if (full)
+    {
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        acc += TOK_LEN(tab[((chunk_word(c, b >> 2) & m4) >> (8 * (b & 3))) & 0xffu]);
     }
   else
-    last = last_piece_plain(ntab, p, L, 0xffu);
-  return tot;
+    for (int b = 0; b < valid; b++)
+      acc += TOK_LEN(tab[chunk_byte(c, b) & (m4 & 0xffu)]);
+  return acc;
 }
 
-__device__ __forceinline__ uint32_t seg_bytes(uint64_t T, uint32_t last)
-{ return 4u * ((uint32_t) (T >> 5) + (((uint32_t) T & 31u) ? 1u : 0u) + pad_extra(T, last)); }
+__device__ __forceinline__ uint32_t bits_runs_step(const run_lds &R, const u32x4 &c, int valid, uint32_t sv, uint32_t rc,
+                                                   uint32_t &C, uint32_t &nonrun, const uint32_t *ntab, const uint32_t *rtab)
+{ const int      lane  = lane_id();
+  const uint32_t total = run_collect(R, c, valid, rc);
+  uint32_t acc = 0;
+  nonrun += total;                                               // wave-uniform
+  for (uint32_t i = lane; i < total; i += 64)
+    { RUN_TOKEN(R, i, C, pos, x, run)
+      acc += run_token_len(rtab, run) + TOK_LEN(ntab[x]);
+    }
+  C = run_after(R, total, sv, C);
+  wave_sync();
+  return acc;
+}
 
-__global__ __launch_bounds__(DX_BLOCK)
-void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *rec_size)
+__global__ __launch_bounds__(DX_BLOCK, SIZES_WAVES)
+void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *seg /* n x 5 */,
+                uint32_t *rec_size)
 { __shared__ uint32_t s_tok[6][256];
+  __shared__ __attribute__((aligned(16))) uint8_t s_chunk[DX_WAVES_PER_BLK][DX_STEP];
+  __shared__ uint16_t s_list[DX_WAVES_PER_BLK][DX_STEP];
   load_tables(s_tok, g_tok);
   const int      lane  = lane_id();
   const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
   const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  const run_lds  R     = { s_chunk[threadIdx.x >> 6], s_list[threadIdx.x >> 6] };
   const uint32_t imask = a.lossy ? 0xfeu : 0xffu, mmask = a.lossy ? 0xfcu : 0xffu;
+  const uint32_t im4 = imask * 0x01010101u, mm4 = mmask * 0x01010101u;
+  const bool drun = a.delChar >= 0, srun = a.subChar >= 0;
 
   for (uint64_t r = wave0; r < a.n; r += nwave)
     { const uint32_t L = a.len[r];
-      uint32_t sz = hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u;
-      uint32_t clen = L, last;
-      uint64_t T;
+      const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2);
+      const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
+      const bool over = can_overread(a, p4, L);
+      uint32_t C0 = 0, C4 = 0, nn0 = 0, nn4 = 0;
+      uint32_t a0 = 0, a2 = 0, a3 = 0, a4 = 0;          // per-lane bit sums of the four streams
+      uint64_t T0 = 0, T2 = 0, T3 = 0, T4 = 0;
 
-      const uint8_t *del = line_ptr(a, r, L, 0);
-      if (a.delChar >= 0)
-        T = bits_runs(del, L, (uint32_t) a.delChar, s_tok[DX_DEL], s_tok[DX_DRUN], clen, last);
+      uint32_t pos = 16u * lane;
+      u32x4 c0 = fetch(p0, pos, L, over), c2 = fetch(p2, pos, L, over);
+      u32x4 c3 = fetch(p3, pos, L, over), c4 = fetch(p4, pos, L, over);
+      for (uint32_t base = 0; base < L; base += DX_STEP)
+        { const uint32_t np = pos + DX_STEP;
+          const u32x4 d0 = fetch(p0, np, L, over), d2 = fetch(p2, np, L, over);
+          const u32x4 d3 = fetch(p3, np, L, over), d4 = fetch(p4, np, L, over);
+          const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
+          const bool     full  = sv == DX_STEP;
+          const int      valid = valid_of(pos, L);
+          a0 += drun ? bits_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, nn0, s_tok[DX_DEL], s_tok[DX_DRUN])
+                     : bits_plain_step(c0, valid, full, s_tok[DX_DEL], ~0u);
+          a2 += bits_plain_step(c2, valid, full, s_tok[DX_INS], im4);
+          a3 += bits_plain_step(c3, valid, full, s_tok[DX_MRG], mm4);
+          a4 += srun ? bits_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, nn4, s_tok[DX_SUB], s_tok[DX_SRUN])
+                     : bits_plain_step(c4, valid, full, s_tok[DX_SUB], ~0u);
+          c0 = d0; c2 = d2; c3 = d3; c4 = d4;
+          pos = np;
+          if ((base & 0x3ffffffu) == 0x3fffc00u)       // fold long before a 32-bit lane sum can wrap
+            { T0 += wave_sum(a0); T2 += wave_sum(a2); T3 += wave_sum(a3); T4 += wave_sum(a4);
+              a0 = a2 = a3 = a4 = 0;
+            }
+        }
+      T0 += wave_sum(a0); T2 += wave_sum(a2); T3 += wave_sum(a3); T4 += wave_sum(a4);
+
+      uint32_t last0, last4, clen = L;
+      if (drun)
+        { clen = nn0;                                    // Pack_Tag's count, QV.c:810-819
+          if (C0 > 0)                                    // trailing run token
+            { const uint32_t e = s_tok[DX_DRUN][C0 > 255u ? 255u : C0];
+              T0   += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
+              last0 = TOK_ESC(e) ? 16u : TOK_LEN(e);
+            }
+          else
+            last0 = last_piece_plain(s_tok[DX_DEL], p0, L, 0xffu);
+        }
       else
-        { T = bits_plain(del, L, s_tok[DX_DEL], 0xffu);
-          last = last_piece_plain(s_tok[DX_DEL], del, L, 0xffu);
-        }
-      sz += seg_bytes(T, last) + ((clen + 3u) >> 2);
-
-      const uint8_t *ins = line_ptr(a, r, L, 2);
-      T   = bits_plain(ins, L, s_tok[DX_INS], imask);
-      sz += seg_bytes(T, last_piece_plain(s_tok[DX_INS], ins, L, imask));
-
-      const uint8_t *mrg = line_ptr(a, r, L, 3);
-      T   = bits_plain(mrg, L, s_tok[DX_MRG], mmask);
-      sz += seg_bytes(T, last_piece_plain(s_tok[DX_MRG], mrg, L, mmask));
-
-      const uint8_t *sub = line_ptr(a, r, L, 4);
-      if (a.subChar >= 0)
-        { uint32_t nn;
-          T = bits_runs(sub, L, (uint32_t) a.subChar, s_tok[DX_SUB], s_tok[DX_SRUN], nn, last);
+        last0 = last_piece_plain(s_tok[DX_DEL], p0, L, 0xffu);
+      if (srun)
+        { if (C4 > 0)
+            { const uint32_t e = s_tok[DX_SRUN][C4 > 255u ? 255u : C4];
+              T4   += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
+              last4 = TOK_ESC(e) ? 16u : TOK_LEN(e);
+            }
+          else
+            last4 = last_piece_plain(s_tok[DX_SUB], p4, L, 0xffu);
         }
       else
-        { T = bits_plain(sub, L, s_tok[DX_SUB], 0xffu);
-          last = last_piece_plain(s_tok[DX_SUB], sub, L, 0xffu);
-        }
-      sz += seg_bytes(T, last);
+        last4 = last_piece_plain(s_tok[DX_SUB], p4, L, 0xffu);
 
+      const uint32_t s0 = seg_bytes(T0, last0);
+      const uint32_t s1 = (clen + 3u) >> 2;
+      const uint32_t s2 = seg_bytes(T2, last_piece_plain(s_tok[DX_INS], p2, L, imask));
+      const uint32_t s3 = seg_bytes(T3, last_piece_plain(s_tok[DX_MRG], p3, L, mmask));
+      const uint32_t s4 = seg_bytes(T4, last4);
       if (lane == 0)
-        rec_size[r] = sz;
+        { const uint32_t hl = hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u;
+          uint32_t *sg = seg + 5 * r;
+          sg[0] = s0; sg[1] = s1; sg[2] = s2; sg[3] = s3; sg[4] = s4;
+          rec_size[r] = hl + s0 + s1 + s2 + s3 + s4;
+        }
     }
 }
 
@@ -425,8 +505,7 @@ void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint3
 #define SCAN_TILE  (DX_BLOCK * SCAN_ITEMS)
 
 __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t *s_wave, uint64_t &total)
-{ // inclusive scan of 64-bit values within the wave via two 32-bit halves with carry
-  const int lane = lane_id(), wid = threadIdx.x >> 6;
+{ const int lane = lane_id(), wid = threadIdx.x >> 6;
   uint64_t x = v;
   for (int d = 1; d < 64; d <<= 1)
     { const uint64_t y = __shfl_up(x, d);
@@ -521,7 +600,7 @@ __device__ __forceinline__ void flush_words(wave_out &o, bool swap)
   wave_sync();
 }
 
-// lane-local MSB-first bit accumulator feeding the window
+// lane-local MSB-first bit accumulator feeding the window (generic path: any token lengths)
 struct bit_acc { uint64_t acc; uint32_t fill, w; };
 
 __device__ __forceinline__ void acc_begin(bit_acc &s, uint32_t bit) { s.acc = 0; s.fill = bit & 31u; s.w = bit >> 5; }
@@ -542,17 +621,24 @@ __device__ __forceinline__ void acc_end(bit_acc &s, uint32_t *win)
     atomicOr(&win[s.w], (uint32_t) (s.acc >> 32));
 }
 
-// The lanes' bit strings of one step go into the window in lane order; when the step does not
-// fit (only with pathological code tables) it is split at lane boundaries into several rounds.
-// `incl` is the inclusive prefix sum of the lanes' bit counts `nb`.  EMIT(lane_bit_offset) writes
-// one lane's bits.
+// funnel: low 32 bits of (hi:lo) >> s, 1 <= s <= 32
+__device__ __forceinline__ uint32_t fsr(uint32_t hi, uint32_t lo, uint32_t s)
+{ return (uint32_t) ((((uint64_t) hi << 32) | lo) >> s); }
+
+// The lanes' bit strings of one step go into the window in lane order.  Normally the whole step
+// fits (one round); if the window is too full it is drained first, and with pathological code
+// tables a step is split at lane boundaries into several rounds.  `incl` = inclusive prefix sum
+// of the lanes' bit counts `nb`; the statement block receives `bit_`, this lane's bit offset.
 #define FOR_EACH_ROUND(o, incl, nb, ...)                                                         \
   { uint32_t done_ = 0, lo_ = 0;                                                                \
     const int lane_ = lane_id();                                                                \
     while (lo_ < 64u)                                                                           \
       { const uint32_t cap_ = QV_WIN_BITS - (o).winbits;                                        \
-        uint32_t hi_        = (uint32_t) __popcll(__ballot((incl) <= done_ + cap_));            \
-        if (hi_ <= lo_) hi_ = 64u;   /* cannot happen (one lane's bits always fit); never spin */ \
+        uint32_t hi_ = (uint32_t) __popcll(__ballot((incl) <= done_ + cap_));                   \
+        if (hi_ <= lo_)                                                                         \
+          { if ((o).winbits >= 32u) { flush_words((o), false); continue; }                      \
+            hi_ = 64u;              /* cannot happen (one lane always fits); never spin */      \
+          }                                                                                     \
         if ((uint32_t) lane_ >= lo_ && (uint32_t) lane_ < hi_ && (nb))                          \
           { const uint32_t bit_ = (o).winbits + ((incl) - (nb)) - done_;                        \
             __VA_ARGS__                                                                         \
@@ -561,30 +647,67 @@ __device__ __forceinline__ void acc_end(bit_acc &s, uint32_t *win)
         (o).winbits += upto_ - done_;                                                           \
         done_ = upto_;                                                                          \
         lo_   = hi_;                                                                            \
-        flush_words((o), false);                                                                \
       }                                                                                         \
+    if ((o).winbits >= QV_FLUSH_BITS)                                                           \
+      flush_words((o), false);                                                                  \
   }
 
-// Encode (QV.c:386-443) of one stream into the segment at o.seg; returns the segment's bytes
-__device__ __forceinline__ uint32_t encode_plain(wave_out &o, const uint8_t *p, uint32_t L,
-                                                 const uint32_t *tab, uint32_t mask)
-{ const int lane = lane_id();
-  o.wordbase = 0;
-  o.winbits  = 0;
-  for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const uint32_t pos   = base + 16u * lane;
-      const int      valid = pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos));
-      const u32x4    c     = load_chunk(p + pos, valid);
-      uint32_t tok[16];
-      uint32_t nb = 0;
-      #pragma unroll
-      for (int b = 0; b < 16; b++)
-        { const uint32_t x = (chunk_word(c, b >> 2) >> (8 * (b & 3))) & mask;
-          tok[b] = b < valid ? tab[x] : 0u;
-          nb    += TOK_LEN(tok[b]);
-        }
-      const uint32_t incl = wave_incl_scan(nb);
+// write the partial word and the pad word (QV.c:436-442); returns the segment's byte size
+__device__ __forceinline__ uint32_t finish_words(wave_out &o, uint32_t last)
+{ flush_words(o, false);
+  const uint64_t T     = 32ull * o.wordbase + o.winbits;
+  const uint32_t tailw = (o.winbits ? 1u : 0u) + pad_extra(T, last);
+  if (lane_id() == 0)
+    { const uint32_t w = o.win[0];
+      for (uint32_t k = 0; k < tailw; k++)
+        store32_u(o.seg + 4ull * (o.wordbase + k), w);
+      o.win[0] = 0;
+    }
+  wave_sync();
+  return 4u * (o.wordbase + tailw);
+}
+
+// one step of Encode (QV.c:427-434): 16 table look-ups per lane, prefix sum, bits into the window
+__device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, int valid, bool full,
+                                                  const uint32_t *tab, uint32_t m4)
+{ uint32_t tok[16];
+  uint32_t nb = 0, z = 0;
+  #pragma unroll
+  for (int b = 0; b < 16; b++)
+    { const uint32_t x = ((chunk_word(c, b >> 2) & m4) >> (8 * (b & 3))) & 0xffu;
+      tok[b] = (full || b < valid) ? tab[x] : 0u;
+      const uint32_t l = TOK_LEN(tok[b]);
+      nb += l;
+      z  |= l - 1u;                                   // sign bit set iff some token has length 0
+    }
+  const uint32_t incl = wave_incl_scan(nb);
+  const bool fast = full && !__any((int) ((z >> 31) | (nb > 128u)));
+  if (fast)
+    { // all 16 tokens have 1..24 bits and the lane's string fits 128 bits: branch-free packing
       FOR_EACH_ROUND(o, incl, nb,
+        { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+          _Pragma("unroll")
+          for (int b = 0; b < 16; b++)
+            { const uint32_t l = TOK_LEN(tok[b]), s = 32u - l;        // s in 8..31
+              w3 = __builtin_amdgcn_alignbit(w3, w2, s);
+              w2 = __builtin_amdgcn_alignbit(w2, w1, s);
+              w1 = __builtin_amdgcn_alignbit(w1, w0, s);
+              w0 = (w0 << l) | TOK_BITS(tok[b]);
+            }
+          const uint32_t e  = bit_ + nb;                               // end bit (exclusive)
+          const uint32_t sl = (32u - (e & 31u)) & 31u, sr = 32u - sl;  // left-align to the last word
+          const uint32_t we = (e - 1u) >> 5;
+          const uint32_t x0 = w0 << sl;
+          const uint32_t x1 = fsr(w1, w0, sr), x2 = fsr(w2, w1, sr), x3 = fsr(w3, w2, sr), x4 = fsr(0u, w3, sr);
+          atomicOr(&o.win[we], x0);
+          if (x1) atomicOr(&o.win[we - 1], x1);
+          if (x2) atomicOr(&o.win[we - 2], x2);
+          if (x3) atomicOr(&o.win[we - 3], x3);
+          if (x4) atomicOr(&o.win[we - 4], x4);
+        })
+    }
+  else
+    { FOR_EACH_ROUND(o, incl, nb,
         { bit_acc s;
           acc_begin(s, bit_);
           _Pragma("unroll")
@@ -593,156 +716,165 @@ __device__ __forceinline__ uint32_t encode_plain(wave_out &o, const uint8_t *p, 
           acc_end(s, o.win);
         })
     }
-  // tail: partial word and the pad word of QV.c:436-442
-  const uint64_t T     = 32ull * o.wordbase + o.winbits;
-  const uint32_t last  = last_piece_plain(tab, p, L, mask);
-  const uint32_t extra = pad_extra(T, last);
-  const uint32_t tailw = (o.winbits ? 1u : 0u) + extra;
-  if (lane == 0)
-    { const uint32_t w = o.win[0];
-      for (uint32_t k = 0; k < tailw; k++)
-        store32_u(o.seg + 4ull * (o.wordbase + k), w);
+}
+
+// a token of 1..56 bits (right-aligned in tok) at bit offset q of the window
+__device__ __forceinline__ void place_token(uint32_t *win, uint32_t q, uint64_t tok, uint32_t len)
+{ const uint64_t V = tok << (64u - len);                         // left-aligned
+  const uint32_t s = q & 31u, w = q >> 5;
+  const uint64_t A = V >> s;
+  const uint32_t W2 = (uint32_t) (V << (32u - s));               // s == 0: shifts everything out
+  atomicOr(&win[w], (uint32_t) (A >> 32));
+  if ((uint32_t) A) atomicOr(&win[w + 1], (uint32_t) A);
+  if (W2)           atomicOr(&win[w + 2], W2);
+}
+
+// one step of Encode_Run (QV.c:475-497): the step's non-run symbols are processed 64 at a time,
+// one (run token + symbol token) per lane.  With TAGS the same lanes also emit the 2-bit code of
+// the deletion tag under each non-run symbol (Pack_Tag + Number_Read + Compress_Read,
+// QV.c:810-819, 1402-1404) into the tag window.
+template <bool TAGS>
+__device__ __forceinline__ void encode_runs_step(wave_out &o, wave_out &ot, const run_lds &R, uint8_t *tagchunk,
+                                                 const u32x4 &c, const u32x4 &t, int valid, uint32_t sv,
+                                                 uint32_t rc, uint32_t &C, const uint32_t *ntab, const uint32_t *rtab)
+{ const int lane = lane_id();
+  if (TAGS)
+    *(u32x4 *) (tagchunk + 16 * lane) = t;
+  const uint32_t total = run_collect(R, c, valid, rc);
+  for (uint32_t k = 0; k < total; k += 64)
+    { const uint32_t i = k + lane;
+      uint64_t tok = 0;
+      uint32_t len = 0;
+      if (i < total)
+        { RUN_TOKEN(R, i, C, pos, x, run)
+          const uint32_t re = rtab[run > 255u ? 255u : run];     // QV.c:479-487
+          const uint32_t se = ntab[x];
+          const uint32_t rb = TOK_ESC(re) ? ((TOK_BITS(re) << 16) | run) : TOK_BITS(re);
+          const uint32_t sl = TOK_LEN(se);
+          tok = ((uint64_t) rb << sl) | TOK_BITS(se);
+          len = TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u) + sl;
+          if (TAGS)
+            { const uint32_t u    = (uint32_t) tagchunk[pos] & 0xdfu;
+              const uint32_t code = (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 0u;
+              const uint32_t p    = (ot.winbits >> 1) + (uint32_t) lane;
+              if (code) atomicOr(&ot.win[p >> 4], code << (30u - 2u * (p & 15u)));
+            }
+        }
+      const uint32_t incl = wave_incl_scan(len);
+      FOR_EACH_ROUND(o, incl, len,
+        { place_token(o.win, bit_, tok, len); })
+      if (TAGS)
+        { ot.winbits += 2u * (total - k >= 64u ? 64u : total - k);
+          if (ot.winbits >= TAG_FLUSH_BITS)
+            flush_words(ot, true);
+        }
+    }
+  C = run_after(R, total, sv, C);
+  wave_sync();
+}
+
+// the run-only token that ends a stream whose last symbol is the run character (QV.c:476-487);
+// returns the length of the final piece for the pad rule
+__device__ __forceinline__ uint32_t encode_trailing_run(wave_out &o, uint32_t C, const uint32_t *rtab)
+{ const uint32_t re = rtab[C > 255u ? 255u : C];
+  const uint32_t tl = TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u);
+  if (o.winbits + tl > QV_WIN_BITS)
+    flush_words(o, false);
+  if (lane_id() == 0 && tl)
+    { bit_acc s;
+      acc_begin(s, o.winbits);
+      acc_put(s, o.win, TOK_ESC(re) ? ((TOK_BITS(re) << 16) | C) : TOK_BITS(re), tl);
+      acc_end(s, o.win);
+    }
+  o.winbits += tl;
+  return TOK_ESC(re) ? 16u : TOK_LEN(re);
+}
+
+// one step of Pack_Tag + Number_Read + Compress_Read (QV.c:810-819, 1402-1404): the tags at the
+// positions in `keep`, 2 bits each, into the tag window
+__device__ __forceinline__ void encode_tags_step(wave_out &o, const u32x4 &t, uint32_t keep)
+{ const uint32_t cnt = __popc(keep);
+  uint32_t acc = 0;
+  int      sh  = 30;
+  #pragma unroll
+  for (int b = 0; b < 16; b++)
+    if ((keep >> b) & 1u)
+      { const uint32_t u = BYTE_OF(t, b) & 0xdfu;
+        acc |= ((u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 0u) << sh;
+        sh  -= 2;
+      }
+  const uint32_t incl = wave_incl_scan(cnt);
+  if (cnt)
+    { const uint32_t bit = o.winbits + 2u * (incl - cnt);
+      const uint32_t w = bit >> 5, s = bit & 31u;
+      atomicOr(&o.win[w], acc >> s);
+      if (s && 2u * cnt + s > 32u)
+        atomicOr(&o.win[w + 1], acc << (32u - s));
+    }
+  o.winbits += 2u * wave_total(incl);
+  if (o.winbits >= TAG_FLUSH_BITS)
+    flush_words(o, true);
+}
+
+__device__ __forceinline__ uint32_t finish_tags(wave_out &o)
+{ flush_words(o, true);
+  const uint32_t clen_bytes = 4u * o.wordbase + ((o.winbits + 7u) >> 3);      // (clen + 3) >> 2
+  if (lane_id() == 0)
+    { const uint32_t w = __builtin_bswap32(o.win[0]);
+      for (uint32_t k = 0; 8u * k < o.winbits; k++)
+        o.seg[4ull * o.wordbase + k] = (uint8_t) (w >> (8 * k));
       o.win[0] = 0;
     }
   wave_sync();
-  return 4u * (o.wordbase + tailw);
+  return clen_bytes;
 }
 
-// Encode_Run (QV.c:448-506)
-__device__ __forceinline__ uint32_t encode_runs(wave_out &o, const uint8_t *p, uint32_t L, uint32_t rc,
-                                                const uint32_t *ntab, const uint32_t *rtab)
+// a plain-coded stream into its segment; returns the segment's bytes
+__device__ __forceinline__ uint32_t encode_plain_stream(wave_out &o, const uint8_t *p, uint32_t L,
+                                                        bool over, const uint32_t *tab, uint32_t mask)
+{ const int lane = lane_id();
+  const uint32_t m4 = mask * 0x01010101u;
+  o.wordbase = 0;
+  o.winbits  = 0;
+  uint32_t pos = 16u * lane;
+  u32x4 c = fetch(p, pos, L, over);
+  for (uint32_t base = 0; base < L; base += DX_STEP)
+    { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
+      encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, m4);
+      c = d;
+      pos += DX_STEP;
+    }
+  return finish_words(o, last_piece_plain(tab, p, L, mask));
+}
+
+__device__ __forceinline__ uint32_t encode_runs_stream(wave_out &o, const run_lds &R, const uint8_t *p, uint32_t L,
+                                                       bool over, uint32_t rc, const uint32_t *ntab, const uint32_t *rtab)
 { const int lane = lane_id();
   uint32_t  C = 0;
   o.wordbase = 0;
   o.winbits  = 0;
+  uint32_t pos = 16u * lane;
+  u32x4 c = fetch(p, pos, L, over);
   for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const uint32_t pos   = base + 16u * lane;
-      const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
-      const int      valid = pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos));
-      const u32x4    c     = load_chunk(p + pos, valid);
-      const uint32_t nr0   = ~chunk_eq_mask(c, rc) & ((1u << valid) - 1u);
-      const uint32_t carry = run_carry(nr0, valid, sv, C);
-
-      uint32_t nb = 0;
-      { uint32_t nr = nr0, run = carry;
-        int      prev = -1;
-        while (nr)
-          { const int b = __ffs(nr) - 1;
-            run += (uint32_t) (b - prev - 1);
-            nb  += run_token_len(rtab, run) + TOK_LEN(ntab[chunk_byte(c, b)]);
-            run  = 0;
-            prev = b;
-            nr  &= nr - 1u;
-          }
-      }
-      const uint32_t incl = wave_incl_scan(nb);
-      FOR_EACH_ROUND(o, incl, nb,
-        { bit_acc  s;
-          uint32_t nr = nr0, run = carry;
-          int      prev = -1;
-          acc_begin(s, bit_);
-          while (nr)
-            { const int b = __ffs(nr) - 1;
-              run += (uint32_t) (b - prev - 1);
-              const uint32_t re = rtab[run > 255u ? 255u : run];
-              if (TOK_ESC(re))
-                acc_put(s, o.win, (TOK_BITS(re) << 16) | run, TOK_LEN(re) + 16u);   // QV.c:486-487
-              else
-                acc_put(s, o.win, TOK_BITS(re), TOK_LEN(re));
-              const uint32_t se = ntab[chunk_byte(c, b)];
-              acc_put(s, o.win, TOK_BITS(se), TOK_LEN(se));
-              run  = 0;
-              prev = b;
-              nr  &= nr - 1u;
-            }
-          acc_end(s, o.win);
-        })
+    { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
+      const uint32_t sv = L - base >= DX_STEP ? DX_STEP : L - base;
+      encode_runs_step<false>(o, o, R, NULL, c, c, valid_of(pos, L), sv, rc, C, ntab, rtab);
+      c = d;
+      pos += DX_STEP;
     }
-  uint32_t last;
-  if (C > 0)                                                       // trailing run: one run-only token
-    { const uint32_t re = rtab[C > 255u ? 255u : C];
-      const uint32_t tl = TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u);
-      if (lane == 0 && tl)
-        { bit_acc s;
-          acc_begin(s, o.winbits);
-          acc_put(s, o.win, TOK_ESC(re) ? ((TOK_BITS(re) << 16) | C) : TOK_BITS(re), tl);
-          acc_end(s, o.win);
-        }
-      o.winbits += tl;
-      flush_words(o, false);
-      last = TOK_ESC(re) ? 16u : TOK_LEN(re);
-    }
-  else
-    last = last_piece_plain(ntab, p, L, 0xffu);
-
-  const uint64_t T     = 32ull * o.wordbase + o.winbits;
-  const uint32_t extra = pad_extra(T, last);
-  const uint32_t tailw = (o.winbits ? 1u : 0u) + extra;
-  if (lane == 0)
-    { const uint32_t w = o.win[0];
-      for (uint32_t k = 0; k < tailw; k++)
-        store32_u(o.seg + 4ull * (o.wordbase + k), w);
-      o.win[0] = 0;
-    }
-  wave_sync();
-  return 4u * (o.wordbase + tailw);
+  const uint32_t last = C > 0 ? encode_trailing_run(o, C, rtab) : last_piece_plain(ntab, p, L, 0xffu);
+  return finish_words(o, last);
 }
 
-// Pack_Tag + Number_Read + Compress_Read (QV.c:810-819, 1402-1404): tags at positions where
-// del != delChar (all positions when rc < 0), 2 bits each
-__device__ __forceinline__ uint32_t encode_tags(wave_out &o, const uint8_t *del, const uint8_t *tag,
-                                                uint32_t L, int rc)
-{ const int lane = lane_id();
-  uint32_t  G = 0;
-  o.wordbase = 0;
-  o.winbits  = 0;
-  for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const uint32_t pos   = base + 16u * lane;
-      const int      valid = pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos));
-      const u32x4    t     = load_chunk(tag + pos, valid);
-      uint32_t keep = (1u << valid) - 1u;
-      if (rc >= 0)
-        keep &= ~chunk_eq_mask(load_chunk(del + pos, valid), (uint32_t) rc);
-      const uint32_t cnt = __popc(keep);
-      uint32_t acc = 0;
-      int      sh  = 30;
-      #pragma unroll
-      for (int b = 0; b < 16; b++)
-        if ((keep >> b) & 1u)
-          { const uint32_t u = ((chunk_word(t, b >> 2) >> (8 * (b & 3))) & 0xffu) & 0xdfu;
-            acc |= ((u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 0u) << sh;
-            sh  -= 2;
-          }
-      const uint32_t incl = wave_incl_scan(cnt);
-      if (cnt)
-        { const uint32_t bit = o.winbits + 2u * (incl - cnt);
-          const uint32_t w = bit >> 5, s = bit & 31u;
-          atomicOr(&o.win[w], acc >> s);
-          if (s && 2u * cnt + s > 32u)
-            atomicOr(&o.win[w + 1], acc << (32u - s));
-        }
-      const uint32_t total = wave_total(incl);
-      o.winbits += 2u * total;
-      G         += total;
-      flush_words(o, true);
-    }
-  const uint32_t clen = (G + 3u) >> 2;
-  const uint32_t done = 4u * o.wordbase;
-  if (lane == 0)
-    { const uint32_t w = __builtin_bswap32(o.win[0]);
-      for (uint32_t k = done; k < clen; k++)
-        o.seg[k] = (uint8_t) (w >> (8 * (k - done)));
-      o.win[0] = 0;
-    }
-  wave_sync();
-  return clen;
-}
-
-__global__ __launch_bounds__(DX_BLOCK)
+__global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
-                 const uint64_t *rec_off, uint8_t *out, uint32_t *seg_out)
+                 const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_win[DX_WAVES_PER_BLK][QV_WIN_WORDS];
+  __shared__ uint32_t s_tag[DX_WAVES_PER_BLK][TAG_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint8_t s_chunk[DX_WAVES_PER_BLK][DX_STEP];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tchunk[DX_WAVES_PER_BLK][DX_STEP];
+  __shared__ uint16_t s_list[DX_WAVES_PER_BLK][DX_STEP];
   load_tables(s_tok, g_tok);
   const int      lane  = lane_id();
   const int      wid   = threadIdx.x >> 6;
@@ -750,15 +882,18 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
   const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
   const uint32_t imask = a.lossy ? 0xfeu : 0xffu, mmask = a.lossy ? 0xfcu : 0xffu;
 
-  wave_out o;
-  o.win = s_win[wid];
-  for (int j = lane; j < QV_WIN_WORDS; j += 64)
-    o.win[j] = 0;
+  const run_lds R = { s_chunk[wid], s_list[wid] };
+  wave_out o, ot;
+  o.win  = s_win[wid];
+  ot.win = s_tag[wid];
+  for (int j = lane; j < QV_WIN_WORDS; j += 64)  o.win[j]  = 0;
+  for (int j = lane; j < TAG_WIN_WORDS; j += 64) ot.win[j] = 0;
   wave_sync();
 
   for (uint64_t r = wave0; r < a.n; r += nwave)
-    { const uint32_t L   = a.len[r];
-      uint8_t       *dst = out + rec_off[r];
+    { const uint32_t  L   = a.len[r];
+      const uint32_t *sg  = seg + 5 * r;
+      uint8_t        *dst = out + rec_off[r];
       if (hdr != NULL)                                   // record framing (dexqv.c:128-139)
         { const uint64_t h0 = hdr_off[r];
           const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
@@ -766,26 +901,62 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
             dst[k] = hdr[h0 + k];
           dst += hl;
         }
-      const uint8_t *del = line_ptr(a, r, L, 0);
-      uint32_t sz[5];
+      const uint8_t *p0 = line_ptr(a, r, L, 0), *p1 = line_ptr(a, r, L, 1);
+      const bool over = can_overread(a, line_ptr(a, r, L, 4), L);
+      const uint32_t want0 = sg[0], want1 = sg[1], want2 = sg[2], want3 = sg[3], want4 = sg[4];
+      uint32_t bad = 0;
 
-      o.seg = dst;                                       // QV.c:1393-1401
-      sz[0] = (a.delChar >= 0)
-                ? encode_runs(o, del, L, (uint32_t) a.delChar, s_tok[DX_DEL], s_tok[DX_DRUN])
-                : encode_plain(o, del, L, s_tok[DX_DEL], 0xffu);
-      o.seg += sz[0];                                    // QV.c:1400-1404
-      sz[1]  = encode_tags(o, del, line_ptr(a, r, L, 1), L, a.delChar);
-      o.seg += sz[1];                                    // QV.c:1406-1418
-      sz[2]  = encode_plain(o, line_ptr(a, r, L, 2), L, s_tok[DX_INS], imask);
-      o.seg += sz[2];
-      sz[3]  = encode_plain(o, line_ptr(a, r, L, 3), L, s_tok[DX_MRG], mmask);
-      o.seg += sz[3];                                    // QV.c:1419-1423
-      sz[4]  = (a.subChar >= 0)
-                ? encode_runs(o, line_ptr(a, r, L, 4), L, (uint32_t) a.subChar, s_tok[DX_SUB], s_tok[DX_SRUN])
-                : encode_plain(o, line_ptr(a, r, L, 4), L, s_tok[DX_SUB], 0xffu);
+#ifndef ABL_NO_DEL
+      // ---- deletion QVs and deletion tags in one sweep (QV.c:1393-1404): the tag segment starts
+      //      want0 bytes after the deletion segment (sizes come from k_qv_sizes)
+      { o.seg  = dst;         o.wordbase  = 0; o.winbits  = 0;
+        ot.seg = dst + want0; ot.wordbase = 0; ot.winbits = 0;
+        const bool     drun = a.delChar >= 0;
+        const uint32_t rc   = (uint32_t) a.delChar;
+        uint32_t C = 0, pos = 16u * lane;
+        u32x4 c = fetch(p0, pos, L, over), t = fetch(p1, pos, L, over);
+        for (uint32_t base = 0; base < L; base += DX_STEP)
+          { const u32x4 d = fetch(p0, pos + DX_STEP, L, over), u = fetch(p1, pos + DX_STEP, L, over);
+            const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
+            const int      valid = valid_of(pos, L);
+            const uint32_t vm    = (1u << valid) - 1u;
+            if (drun)
+#ifndef ABL_NO_TAG
+              encode_runs_step<true>(o, ot, R, s_tchunk[wid], c, t, valid, sv, rc, C, s_tok[DX_DEL], s_tok[DX_DRUN]);
+#else
+              encode_runs_step<false>(o, ot, R, s_tchunk[wid], c, t, valid, sv, rc, C, s_tok[DX_DEL], s_tok[DX_DRUN]);
+#endif
+            else
+              { encode_plain_step(o, c, valid, sv == DX_STEP, s_tok[DX_DEL], ~0u);
+                encode_tags_step(ot, t, vm);
+              }
+            c = d; t = u;
+            pos += DX_STEP;
+          }
+        const uint32_t last = (drun && C > 0) ? encode_trailing_run(o, C, s_tok[DX_DRUN])
+                                              : last_piece_plain(s_tok[DX_DEL], p0, L, 0xffu);
+        bad |= finish_words(o, last) ^ want0;
+        bad |= finish_tags(ot) ^ want1;
+      }
+#endif
 
-      if (seg_out != NULL && lane < 5)
-        seg_out[5 * r + lane] = sz[lane == 0 ? 0 : lane == 1 ? 1 : lane == 2 ? 2 : lane == 3 ? 3 : 4];
+      // ---- insertion, merge, substitution QVs (QV.c:1406-1423)
+      o.seg = dst + want0 + want1;
+#ifndef ABL_NO_INS
+      bad  |= encode_plain_stream(o, line_ptr(a, r, L, 2), L, over, s_tok[DX_INS], imask) ^ want2;
+#endif
+      o.seg += want2;
+#ifndef ABL_NO_MRG
+      bad  |= encode_plain_stream(o, line_ptr(a, r, L, 3), L, over, s_tok[DX_MRG], mmask) ^ want3;
+#endif
+      o.seg += want3;
+#ifndef ABL_NO_SUB
+      bad  |= ((a.subChar >= 0)
+                 ? encode_runs_stream(o, R, line_ptr(a, r, L, 4), L, over, (uint32_t) a.subChar, s_tok[DX_SUB], s_tok[DX_SRUN])
+                 : encode_plain_stream(o, line_ptr(a, r, L, 4), L, over, s_tok[DX_SUB], 0xffu)) ^ want4;
+#endif
+      if (bad && lane == 0)
+        atomicOr(status, 2u);                            // sizes disagree with k_qv_sizes
     }
 }
 
@@ -803,6 +974,7 @@ static int check_batch(dx_ctx *ctx, const dx_qv_batch *b, const char *who)
 static qv_args make_args(const dx_qv_batch *b, int delChar, int subChar, int lossy)
 { qv_args a;
   a.text = b->d_text; a.off = b->d_off; a.len = b->d_len; a.n = b->n; a.pad = b->line_pad;
+  a.text_bytes = b->text_bytes;
   a.delChar = delChar; a.subChar = subChar; a.lossy = lossy;
   return a;
 }
@@ -855,9 +1027,8 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   if ((e = dx_scratch(ctx, (6 * 256 + 1) * 8, (void **) &d_hist))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 1) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
-  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, dx_grid_waves(ctx, b->n, 16), DX_BLOCK,
+  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, dx_grid_waves(ctx, b->n, 32), DX_BLOCK,
             a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256);
-  static_assert(sizeof(unsigned long long) == 8, "u64");
   uint64_t host[6 * 256 + 1];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -909,11 +1080,12 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
 }
 
 extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_hdr_off,
-                           uint64_t *d_rec_off, uint64_t *total)
+                           uint32_t *d_seg, uint64_t *d_rec_off, uint64_t *total)
 { int e = check_batch(ctx, b, "dx_qv_sizes");
   if (e) return e;
   if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_sizes: call dx_qv_set_coding first");
-  if (d_rec_off == NULL) return dx_fail(ctx, DX_E_ARG, "dx_qv_sizes: NULL d_rec_off");
+  if (d_rec_off == NULL || (b->n && d_seg == NULL))
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_sizes: NULL d_seg / d_rec_off");
   DX_HIP(ctx, hipSetDevice(ctx->device));
   const uint64_t n      = b->n;
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -930,8 +1102,8 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
       return DX_OK;
     }
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
-  DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, n, 16), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_size);
+  DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, n, 32), DX_BLOCK,
+            a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_seg, d_size);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) ntiles, DX_BLOCK, (const uint32_t *) d_size, n, d_tile);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, ntiles, d_gran);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, (const uint32_t *) d_size, n,
@@ -944,17 +1116,24 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
 }
 
 extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
-                            const uint64_t *d_rec_off, uint8_t *d_out, uint32_t *d_seg)
+                            const uint64_t *d_rec_off, const uint32_t *d_seg, uint8_t *d_out)
 { int e = check_batch(ctx, b, "dx_qv_encode");
   if (e) return e;
   if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: call dx_qv_set_coding first");
   if ((d_hdr == NULL) != (d_hdr_off == NULL))
     return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: d_hdr and d_hdr_off must be given together");
   if (b->n == 0) return DX_OK;
-  if (!d_rec_off || !d_out) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: NULL device pointer");
+  if (!d_rec_off || !d_seg || !d_out) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
+  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 16), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_out, d_seg);
+            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status);
+  uint32_t st = 0;
+  DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (st & 2u)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode: a segment's size differs from what dx_qv_sizes "
+                                       "computed (d_seg / coding do not belong to this batch?)");
   return DX_OK;
 }

@@ -150,6 +150,9 @@ typedef struct
     const uint64_t *d_off;
     const uint32_t *d_len;
     uint64_t        n;
+    uint64_t        text_bytes;   /* readable bytes at d_text (the whole image).  With it the kernels
+                                     may load a line's last, partial 16-byte chunk in one piece;
+                                     0 = unknown: nothing beyond a line's end is ever read        */
     uint32_t        line_pad;
   } dx_qv_batch;
 
@@ -202,19 +205,22 @@ int dx_qv_read_coding(const uint8_t *buf, size_t n, dx_qv_coding *c, int *flip,
 int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy);
 
 /* Record sizes: for each entry the bytes Compress_Next_QVentry (QV.c:1381-1426) would write
- * (bit totals, pad rule QV.c:436-442 / 499-505, Pack_Tag length) plus its framing bytes
- * d_hdr_off[i+1]-d_hdr_off[i] (NULL: none), then an exclusive scan in file order:
- * d_rec_off[0..n] (device, n+1 entries), *total = d_rec_off[n].                                 */
+ * (bit totals, pad rule QV.c:436-442 / 499-505, Pack_Tag length): d_seg[5*i+k] = bytes of entry
+ * i's del / tag / ins / mrg / sub segment -- the index the format itself does not store and a
+ * parallel decoder needs.  Adding the framing bytes d_hdr_off[i+1]-d_hdr_off[i] (NULL: none) and
+ * an exclusive scan in file order gives d_rec_off[0..n] (device, n+1 entries); *total =
+ * d_rec_off[n].                                                                                */
 int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_hdr_off,
-                uint64_t *d_rec_off, uint64_t *total);
+                uint32_t *d_seg, uint64_t *d_rec_off, uint64_t *total);
 
 /* Compress_Next_QVentry for the whole batch: record i = framing bytes, then the del words, tag
  * bytes, ins words, mrg words, sub words (Encode / Encode_Run / Pack_Tag+Number_Read+
- * Compress_Read, QV.c:386-506, 810-819, 1393-1423) at d_out + d_rec_off[i].  d_seg (optional,
- * n x 5 uint32) receives the byte size of each segment -- the index the format itself does not
- * store and a parallel decoder needs.                                                           */
+ * Compress_Read, QV.c:386-506, 810-819, 1393-1423) at d_out + d_rec_off[i].  d_seg and
+ * d_rec_off are the outputs of dx_qv_sizes for the same batch and coding (the deletion QVs and
+ * their tags are written in one sweep, which needs the deletion segment's size up front); the
+ * kernel re-derives every segment size and returns DX_E_MISMATCH if one disagrees.              */
 int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
-                 const uint64_t *d_rec_off, uint8_t *d_out, uint32_t *d_seg);
+                 const uint64_t *d_rec_off, const uint32_t *d_seg, uint8_t *d_out);
 
 /* Uncompress_Next_QVentry (QV.c:1428-1481: Decode, Decode_Run, Unpack_Tag) for n records whose
  * segment starts are known: entry i's five segments start at d_in + d_seg_off[5*i+k]; the five

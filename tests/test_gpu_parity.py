@@ -120,7 +120,7 @@ def test_pack2_arbitrary_bytes(ctx):
 def _upload_quiva(ctx, c):
     d_text = ctx.to_device(np.frombuffer(c.text, np.uint8))
     d_off, d_len = ctx.to_device(c.off), ctx.to_device(c.len)
-    return ctx.qv_batch(d_text, d_off, d_len, len(c.len)), (d_text, d_off, d_len)
+    return ctx.qv_batch(d_text, d_off, d_len, len(c.len), text_bytes=len(c.text)), (d_text, d_off, d_len)
 
 
 @pytest.mark.parametrize("seed,n,mean", [(1, 3, 300), (2, 13, 9000), (3, 40, 8000), (4, 700, 900), (5, 3000, 120)])
@@ -195,11 +195,11 @@ def test_qv_sizes_and_segments_vs_oracle(ctx):
     blob, hoff, _ = api.frame_headers(c.hdr)
     d_hdr, d_hoff = ctx.to_device(blob), ctx.to_device(hoff)
     n = len(c.len)
-    d_rec = ctx.alloc(8 * (n + 1))
-    total = ctx.qv_sizes(b, d_hoff, d_rec)
+    d_rec, d_seg = ctx.alloc(8 * (n + 1)), ctx.alloc(4 * 5 * n)
+    total = ctx.qv_sizes(b, d_hoff, d_seg, d_rec)
     rec = d_rec.download(np.uint64)
-    d_out, d_seg = ctx.alloc(total), ctx.alloc(4 * 5 * n)
-    ctx.qv_encode(b, d_hdr, d_hoff, d_rec, d_out, d_seg)
+    d_out = ctx.alloc(total)
+    ctx.qv_encode(b, d_hdr, d_hoff, d_rec, d_seg, d_out)
     out = d_out.download(np.uint8, total).tobytes()
     seg = d_seg.download(np.uint32, 5 * n).reshape(n, 5)
     text = np.frombuffer(c.text, np.uint8)
