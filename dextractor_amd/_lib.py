@@ -42,6 +42,12 @@ class QVCoding(C.Structure):
 
 HIST = (C.c_uint64 * 256) * 6
 
+
+class QVIndex(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("rec_off", C.POINTER(C.c_uint64)), ("hdr_off", C.POINTER(C.c_uint64)),
+                ("seg", C.POINTER(C.c_uint32)), ("len", C.POINTER(C.c_uint32)), ("hdr4", C.POINTER(C.c_int32)),
+                ("coding", QVCoding), ("prefix", C.c_char_p), ("newv", C.c_int), ("flip", C.c_int)]
+
 # name -> (restype, argtypes); every symbol include/dexgpu.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -80,7 +86,9 @@ SIGNATURES = {
     "dx_qv_set_coding": (C.c_int, [_P, C.POINTER(QVCoding), C.c_int]),
     "dx_qv_sizes": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, C.POINTER(C.c_uint64)]),
     "dx_qv_encode": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, _P, _P]),
-    "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
+    "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
+    "dx_qv_walk": (C.c_int, [_P, C.c_size_t, _P]),
+    "dx_qv_index_free": (None, [_P]),
     "dx_file_pack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),
                                 C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dx_file_unpack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_size_t)]),

@@ -142,6 +142,10 @@ class Context:
                                         d_hdr_off.ptr if d_hdr_off else None, d_rec_off.ptr, d_seg.ptr,
                                         d_out.ptr))
 
+    def qv_decode(self, d_in, d_rec_off, d_hdr_off, d_seg, d_len, n, upper, d_out, d_out_off):
+        self._chk(self.lib.dx_qv_decode(self.h, d_in.ptr, d_rec_off.ptr, d_hdr_off.ptr if d_hdr_off else None,
+                                        d_seg.ptr, d_len.ptr, n, int(upper), d_out.ptr, d_out_off.ptr))
+
     def synth_quiva(self, seed, entry0, n, d_off, d_len, d_hdr4, d_lut, del_run, movie, d_text):
         self._chk(self.lib.dx_synth_quiva(self.h, seed & 0xFFFFFFFF, entry0, n, d_off.ptr, d_len.ptr, d_hdr4.ptr,
                                           d_lut.ptr, del_run, movie.encode(), d_text.ptr))
@@ -150,7 +154,7 @@ class Context:
     def _file_call(self, fn, *args):
         out, n = C.c_void_p(), C.c_size_t()
         line, code = C.c_uint64(), C.c_int()
-        extra = (C.byref(line), C.byref(code)) if fn is not self.lib.dx_file_unpack2 else ()
+        extra = () if fn in (self.lib.dx_file_unpack2, self.lib.dx_file_undexqv) else (C.byref(line), C.byref(code))
         rc = fn(self.h, *args, C.byref(out), C.byref(n), *extra)
         if rc != 0:
             msg = (self.lib.dx_last_error(self.h) or b"").decode()
@@ -177,6 +181,9 @@ class Context:
 
     def dexqv(self, quiva: bytes, lossy=False) -> bytes:
         return self._file_call(self.lib.dx_file_dexqv, quiva, len(quiva), int(lossy))
+
+    def undexqv(self, img: bytes, upper=False) -> bytes:
+        return self._file_call(self.lib.dx_file_undexqv, img, len(img), int(upper))
 
 
 # ---- host-only helpers (no GPU needed) ---------------------------------------------------------
@@ -213,6 +220,27 @@ def qv_read_coding(img: bytes):
     if rc != 0:
         raise L.DexGPUError(rc, "dx_qv_read_coding")
     return c, flip.value, pre.value, used.value
+
+
+def qv_walk(img: bytes):
+    """Host boundary walk of a bare .dexqv image -> dict of numpy arrays + coding (QVIndex copy)."""
+    lib = L.load()
+    x = L.QVIndex()
+    rc = lib.dx_qv_walk(img, len(img), C.byref(x))
+    if rc != 0:
+        raise L.DexGPUError(rc, "dx_qv_walk")
+    try:
+        n = x.n
+        return {"n": n,
+                "rec_off": np.ctypeslib.as_array(x.rec_off, (n + 1,)).copy(),
+                "hdr_off": np.ctypeslib.as_array(x.hdr_off, (n + 1,)).copy(),
+                "seg": np.ctypeslib.as_array(x.seg, (max(n, 1), 5))[:n].copy(),
+                "len": np.ctypeslib.as_array(x.len, (max(n, 1),))[:n].copy(),
+                "hdr4": np.ctypeslib.as_array(x.hdr4, (max(n, 1), 4))[:n].copy(),
+                "prefix": bytes(x.prefix), "newv": x.newv, "flip": x.flip,
+                "delChar": x.coding.delChar, "subChar": x.coding.subChar}
+    finally:
+        lib.dx_qv_index_free(C.byref(x))
 
 
 def frame_headers(hdr4, cnr4=None, lwell=0):

@@ -42,6 +42,8 @@ extern "C" int dx_open(int device, dx_ctx **out)
   memset(ctx->ms, 0, sizeof(ctx->ms));
   memset(ctx->launches, 0, sizeof(ctx->launches));
   ctx->d_tok = NULL;
+  ctx->d_dec = NULL;
+  ctx->d_long = NULL;
   ctx->coding_set = 0;
   ctx->d_scratch = NULL;
   ctx->scratch_bytes = 0;
@@ -62,6 +64,8 @@ extern "C" int dx_open(int device, dx_ctx **out)
   OPEN_HIP(hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking));
   ctx->stream = ctx->own;
   OPEN_HIP(hipMalloc((void **) &ctx->d_tok, DX_TOK_WORDS * sizeof(uint32_t)));
+  OPEN_HIP(hipMalloc((void **) &ctx->d_dec, 6 * DX_DEC_SIZE * sizeof(uint16_t)));
+  OPEN_HIP(hipMalloc((void **) &ctx->d_long, 6 * (1 + DX_LONG_MAX) * sizeof(uint32_t)));
   OPEN_HIP(hipMalloc((void **) &ctx->d_status, 64));
   OPEN_HIP(hipMalloc((void **) &ctx->d_u64, 64 * sizeof(uint64_t)));
   OPEN_HIP(hipMemset(ctx->d_status, 0, 64));
@@ -80,6 +84,8 @@ extern "C" void dx_close(dx_ctx *ctx)
       (void) hipEventDestroy(p.b);
     }
   (void) hipFree(ctx->d_tok);
+  (void) hipFree(ctx->d_dec);
+  (void) hipFree(ctx->d_long);
   (void) hipFree(ctx->d_status);
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);

@@ -337,11 +337,60 @@ done:
 }
 
 /* ==========================================================================================
- *  undexqv  (round-1: pending the device decoder)
+ *  undexqv
  * ========================================================================================== */
 int dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper, uint8_t **out, size_t *out_len)
-{ (void) img; (void) n; (void) upper;
-  if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
+{ dpool       pool = { {0}, 0, ctx };
+  dx_qv_index x;
+  tbuf        hd = { NULL, 0, 0 };
+  uint64_t   *ooff = NULL, *hat = NULL, i;
+  uint8_t    *res = NULL;
+  size_t      total = 0, plen;
+  void       *d_in, *d_rec, *d_hoff, *d_seg, *d_len, *d_out, *d_ooff;
+  int         rc;
+
+  if (ctx == NULL || out == NULL || out_len == NULL || img == NULL) return DX_E_ARG;
   *out = NULL; *out_len = 0;
-  return DX_E_UNSUPPORTED;
+  rc = dx_qv_walk(img, n, &x);                            /* sequential boundary walk (host) */
+  if (rc != DX_OK) return rc;
+  plen = strlen(x.prefix);
+
+  ooff = malloc((x.n + 1) * sizeof(*ooff));
+  hat  = malloc((x.n + 1) * sizeof(*hat));
+  if (!ooff || !hat) { rc = DX_E_NOMEM; goto done; }
+  for (i = 0; i < x.n; i++)                               /* header lines, undexqv.c:182 */
+    { const int32_t *h = x.hdr4 + 4*i;
+      if ((rc = tb_room(&hd, plen + 80)) != DX_OK) goto done;
+      hat[i]  = hd.len;
+      hd.len += (size_t) sprintf(hd.p + hd.len, "%s/%d/%d_%d RQ=0.%d\n", x.prefix, h[0], h[1], h[2], h[3]);
+      total  += hd.len - (size_t) hat[i];
+      ooff[i] = total;
+      total  += 5 * ((size_t) x.len[i] + 1);              /* undexqv.c:206-207 */
+    }
+  hat[x.n] = hd.len;
+  res = malloc(total + 16);
+  if (!res) { rc = DX_E_NOMEM; goto done; }
+
+  if (x.n > 0)
+    { TRY(dx_qv_set_coding(ctx, &x.coding, 0));
+      TRY(dupload(&pool, img, n, &d_in));
+      TRY(dupload(&pool, x.rec_off, (x.n + 1) * 8, &d_rec));
+      TRY(dupload(&pool, x.hdr_off, (x.n + 1) * 8, &d_hoff));
+      TRY(dupload(&pool, x.seg, x.n * 5 * 4, &d_seg));
+      TRY(dupload(&pool, x.len, x.n * 4, &d_len));
+      TRY(dupload(&pool, ooff, x.n * 8, &d_ooff));
+      TRY(dalloc(&pool, total, &d_out));
+      TRY(dx_qv_decode(ctx, d_in, d_rec, d_hoff, d_seg, d_len, x.n, upper, d_out, d_ooff));
+      TRY(dx_d2h(ctx, res, d_out, total));
+      for (i = 0; i < x.n; i++)
+        memcpy(res + ooff[i] - (hat[i+1] - hat[i]), hd.p + hat[i], (size_t) (hat[i+1] - hat[i]));
+    }
+  *out = res; *out_len = total; res = NULL;
+  rc = DX_OK;
+
+done:
+  dfree_all(&pool);
+  dx_qv_index_free(&x);
+  free(ooff); free(hat); free(hd.p); free(res);
+  return rc;
 }

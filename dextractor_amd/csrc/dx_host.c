@@ -543,3 +543,206 @@ int dx_index_seq(int arrow, const uint8_t *text, size_t n, uint64_t cap,
   if (count) *count = k;
   return DX_OK;
 }
+
+/* ==========================================================================================
+ *  bare-file index: walk a .dexqv image front to back (host)
+ *
+ *  The format stores no record or segment lengths (QV.c:1428-1481; undexqv.c:119-208), so the
+ *  start of every segment is known only after the previous one has been walked code by code.
+ *  This is that walk: it decodes code LENGTHS only (plus what it needs to count symbols) and
+ *  yields the index dx_qv_decode takes.  Inherently sequential; everything that produces
+ *  symbols runs on the GPU afterwards.
+ * ========================================================================================== */
+
+typedef struct { uint16_t e[0x10000]; } wlut;          /* len << 8 | symbol, by 16-bit window (QV.c:365-372) */
+
+static void build_wlut(const dx_scheme *s, wlut *t)
+{ int i;
+  memset(t->e, 0, sizeof(t->e));
+  for (i = 0; i < 256; i++)                             /* ascending: 255 wins shared escape codes */
+    if (s->lens[i] > 0 && s->lens[i] <= 16)
+      { uint32_t base = (s->bits[i] << (16 - s->lens[i])) & 0xffffu, cnt = 1u << (16 - s->lens[i]), j;
+        for (j = 0; j < cnt; j++)
+          t->e[(base + j) & 0xffffu] = (uint16_t) ((s->lens[i] << 8) | i);
+      }
+}
+
+typedef struct { const uint8_t *p, *end; uint64_t buf; int nb; uint64_t T; } wrd;
+
+static void w_fill(wrd *r)
+{ while (r->nb <= 32 && r->p + 4 <= r->end)
+    { uint32_t w;
+      memcpy(&w, r->p, 4);
+      r->buf |= (uint64_t) w << (32 - r->nb);
+      r->nb  += 32;
+      r->p   += 4;
+    }
+}
+static uint32_t w_peek(wrd *r) { w_fill(r); return (uint32_t) (r->buf >> 48); }
+static void w_skip(wrd *r, int n) { r->buf <<= n; r->nb -= n; r->T += (uint64_t) n; }
+
+static uint32_t pad_words(uint64_t T, uint32_t last)    /* QV.c:436-442 */
+{ uint32_t olen = (uint32_t) T & 31u, llen = (uint32_t) (T - last) & 31u;
+  uint32_t w = (uint32_t) (T >> 5) + (olen ? 1u : 0u);
+  if (olen > 0) return w + ((llen > 16u && olen > llen) ? 1u : 0u);
+  return w + ((T > 0 && llen > 16u) ? 1u : 0u);
+}
+
+/* bytes of a plain-coded segment of rlen symbols starting at p (QV.c:510-599) */
+static int64_t walk_plain(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *t, int esc)
+{ wrd r = { p, end, 0, 0, 0 };
+  uint32_t j, last = 0;
+  int64_t bytes;
+  for (j = 0; j < rlen; j++)
+    { uint32_t e = t->e[w_peek(&r)];
+      last = e >> 8;
+      w_skip(&r, (int) last);
+      if (esc && (e & 0xff) == 255)
+        { w_peek(&r); w_skip(&r, 8); last = 8; }
+    }
+  bytes = 4 * (int64_t) pad_words(r.T, last);
+  return (p + bytes <= end) ? bytes : -1;
+}
+
+/* run-coded segment (QV.c:604-691); *nonrun receives the number of non-run symbols */
+static int64_t walk_runs(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *nt, int esc,
+                         const wlut *rt, uint32_t *nonrun)
+{ wrd r = { p, end, 0, 0, 0 };
+  uint32_t j = 0, last = 0, nn = 0;
+  int64_t bytes;
+  while (j < rlen)
+    { uint32_t e = rt->e[w_peek(&r)], c = e & 0xff;
+      last = e >> 8;
+      w_skip(&r, (int) last);
+      if (c == 255)
+        { c = w_peek(&r); w_skip(&r, 16); last = 16; }
+      if (c > rlen - j) return -1;
+      j += c;
+      if (j < rlen)
+        { e = nt->e[w_peek(&r)];
+          last = e >> 8;
+          w_skip(&r, (int) last);
+          if (esc && (e & 0xff) == 255)
+            { w_peek(&r); w_skip(&r, 8); last = 8; }
+          j  += 1;
+          nn += 1;
+        }
+    }
+  *nonrun = nn;
+  bytes = 4 * (int64_t) pad_words(r.T, last);
+  return (p + bytes <= end) ? bytes : -1;
+}
+
+void dx_qv_index_free(dx_qv_index *x)
+{ if (x == NULL) return;
+  free(x->rec_off); free(x->hdr_off); free(x->seg); free(x->len); free(x->hdr4); free(x->prefix);
+  memset(x, 0, sizeof(*x));
+}
+
+int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
+{ wlut    *lut[6] = { NULL, NULL, NULL, NULL, NULL, NULL };
+  size_t   at = 0, used = 0;
+  uint64_t cap = 0, hat = 0;
+  uint16_t key;
+  int      rc = DX_OK, well = 0, s;
+
+  if (img == NULL || x == NULL) return DX_E_ARG;
+  memset(x, 0, sizeof(*x));
+  if (n < 2) return DX_E_FORMAT;
+  memcpy(&key, img, 2);                                   /* undexqv.c:103-110 */
+  if (key == 0x55aa || key == 0xaa55) { x->newv = 1; at = 2; }
+  x->prefix = malloc(n < 4096 ? 4096 : 4096);
+  if (x->prefix == NULL) return DX_E_NOMEM;
+  rc = dx_qv_read_coding(img + at, n - at, &x->coding, &x->flip, x->prefix, 4096, &used);
+  if (rc != DX_OK) goto fail;
+  if (x->flip) { rc = DX_E_UNSUPPORTED; goto fail; }      /* byte-swapped archives: SURVEY 8(f) rank 4 */
+  at += used;
+
+  for (s = 0; s < 6; s++)
+    { if ((s == DX_DRUN && x->coding.delChar < 0) || (s == DX_SRUN && x->coding.subChar < 0)) continue;
+      lut[s] = malloc(sizeof(wlut));
+      if (lut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
+      build_wlut(&x->coding.s[s], lut[s]);
+    }
+
+  while (at < n)                                          /* undexqv.c:119-208 */
+    { const uint8_t *end = img + n;
+      size_t   h0 = at;
+      int32_t  beg, end_, qv;
+      uint32_t rlen, clen, *sg;
+      int64_t  b;
+
+      while (at < n && img[at] == 255) { well += 255; at += 1; }
+      if (at >= n) { rc = DX_E_FORMAT; goto fail; }
+      well += img[at++];
+      if (x->newv)
+        { if (at + 12 > n) { rc = DX_E_FORMAT; goto fail; }
+          memcpy(&beg, img + at, 4); memcpy(&end_, img + at + 4, 4); memcpy(&qv, img + at + 8, 4);
+          at += 12;
+        }
+      else
+        { uint16_t h[3];
+          if (at + 6 > n) { rc = DX_E_FORMAT; goto fail; }
+          memcpy(h, img + at, 6);
+          beg = h[0]; end_ = h[1]; qv = h[2];
+          at += 6;
+        }
+      if (end_ < beg) { rc = DX_E_FORMAT; goto fail; }
+      rlen = (uint32_t) (end_ - beg);
+
+      if (x->n == cap)
+        { cap = cap ? 2 * cap : 1024;
+          x->rec_off = realloc(x->rec_off, (cap + 1) * sizeof(uint64_t));
+          x->hdr_off = realloc(x->hdr_off, (cap + 1) * sizeof(uint64_t));
+          x->seg     = realloc(x->seg, cap * 5 * sizeof(uint32_t));
+          x->len     = realloc(x->len, cap * sizeof(uint32_t));
+          x->hdr4    = realloc(x->hdr4, cap * 4 * sizeof(int32_t));
+          if (!x->rec_off || !x->hdr_off || !x->seg || !x->len || !x->hdr4) { rc = DX_E_NOMEM; goto fail; }
+        }
+      x->rec_off[x->n] = h0;
+      x->hdr_off[x->n] = hat;
+      hat += at - h0;
+      x->len[x->n] = rlen;
+      x->hdr4[4*x->n] = well; x->hdr4[4*x->n+1] = beg; x->hdr4[4*x->n+2] = end_; x->hdr4[4*x->n+3] = qv;
+      sg = x->seg + 5 * x->n;
+
+      clen = rlen;                                        /* QV.c:1433-1462 */
+      if (x->coding.delChar < 0)
+        b = walk_plain(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2);
+      else
+        b = walk_runs(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2, lut[DX_DRUN], &clen);
+      if (b < 0) { rc = DX_E_FORMAT; goto fail; }
+      sg[0] = (uint32_t) b; at += (size_t) b;
+      sg[1] = (clen + 3) >> 2;
+      if (at + sg[1] > n) { rc = DX_E_FORMAT; goto fail; }
+      at += sg[1];
+      b = walk_plain(img + at, end, rlen, lut[DX_INS], x->coding.s[DX_INS].type == 2);   /* QV.c:1464 */
+      if (b < 0) { rc = DX_E_FORMAT; goto fail; }
+      sg[2] = (uint32_t) b; at += (size_t) b;
+      b = walk_plain(img + at, end, rlen, lut[DX_MRG], x->coding.s[DX_MRG].type == 2);   /* QV.c:1467 */
+      if (b < 0) { rc = DX_E_FORMAT; goto fail; }
+      sg[3] = (uint32_t) b; at += (size_t) b;
+      if (x->coding.subChar < 0)                                                          /* QV.c:1470-1478 */
+        b = walk_plain(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2);
+      else
+        { uint32_t nn;
+          b = walk_runs(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2, lut[DX_SRUN], &nn);
+        }
+      if (b < 0) { rc = DX_E_FORMAT; goto fail; }
+      sg[4] = (uint32_t) b; at += (size_t) b;
+      x->n += 1;
+    }
+  if (x->rec_off == NULL)
+    { x->rec_off = calloc(1, sizeof(uint64_t));
+      x->hdr_off = calloc(1, sizeof(uint64_t));
+    }
+  x->rec_off[x->n] = at;
+  x->hdr_off[x->n] = hat;
+  for (s = 0; s < 6; s++) free(lut[s]);
+  return DX_OK;
+
+fail:
+  for (s = 0; s < 6; s++) free(lut[s]);
+  dx_qv_index_free(x);
+  return rc;
+}

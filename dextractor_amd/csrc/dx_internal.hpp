@@ -15,6 +15,9 @@
 #define DX_BLOCK         256                 // 4 waves per workgroup
 #define DX_WAVES_PER_BLK (DX_BLOCK / DX_WAVE)
 #define DX_TOK_WORDS     (6 * 256)           // device token table: 6 schemes x 256 entries
+#define DX_DEC_BITS      11                  // primary decode table: indexed by the next 11 bits
+#define DX_DEC_SIZE      (1 << DX_DEC_BITS)
+#define DX_LONG_MAX      256                 // codes longer than DX_DEC_BITS, per scheme
 
 struct dx_pending { hipEvent_t a, b; int kernel; };
 
@@ -32,6 +35,9 @@ struct dx_ctx
 
   // QV coder state (dx_qv_set_coding)
   uint32_t *d_tok;             // DX_TOK_WORDS packed tokens (see dx_qv.hip)
+  uint16_t *d_dec;             // 6 x DX_DEC_SIZE primary decode entries (len << 8 | symbol; 0: long code)
+  uint32_t *d_long;            // 6 x (1 + DX_LONG_MAX): count, then prefix16 << 16 | len << 8 | symbol
+  int       sym_type[4];       // scheme types of del/ins/mrg/sub (2: escape code present)
   int       coding_set;
   int       lossy;
   int       delChar, subChar;

@@ -1069,9 +1069,43 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
           tok[s * 256 + x] = run ? pack_run(&c->s[s], x) : pack_sym(&c->s[s], x);
         }
     }
+  // decode side (Read_Scheme's look-up table, QV.c:365-372, in two levels): ascending symbol order
+  // so that for codes shared through the escape the last writer, 255, wins
+  static uint16_t dec[6 * DX_DEC_SIZE];
+  static uint32_t lng[6 * (1 + DX_LONG_MAX)];
+  memset(dec, 0, sizeof(dec));
+  memset(lng, 0, sizeof(lng));
+  for (int s = 0; s < 6; s++)
+    { if ((s == DX_DRUN && c->delChar < 0) || (s == DX_SRUN && c->subChar < 0))
+        continue;
+      uint32_t *L = lng + s * (1 + DX_LONG_MAX);
+      for (int x = 0; x < 256; x++)
+        { const int len = c->s[s].lens[x];
+          const uint32_t bits = c->s[s].bits[x];
+          if (len <= 0) continue;
+          if (len <= DX_DEC_BITS)
+            { const uint32_t base = bits << (DX_DEC_BITS - len), cnt = 1u << (DX_DEC_BITS - len);
+              for (uint32_t j = 0; j < cnt; j++)
+                dec[s * DX_DEC_SIZE + ((base + j) & (DX_DEC_SIZE - 1))] = (uint16_t) ((len << 8) | x);
+            }
+          else
+            { const uint32_t pre = (bits << (16 - len)) & 0xffffu;
+              uint32_t k;
+              for (k = 1; k <= L[0]; k++)                        // same code again: later symbol wins
+                if ((L[k] >> 16) == pre && ((L[k] >> 8) & 0xff) == (uint32_t) len)
+                  break;
+              if (k > L[0]) L[0] = k;
+              L[k] = (pre << 16) | ((uint32_t) len << 8) | (uint32_t) x;
+            }
+        }
+    }
   DX_HIP(ctx, hipSetDevice(ctx->device));
   DX_HIP(ctx, hipMemcpyAsync(ctx->d_tok, tok, sizeof(tok), hipMemcpyHostToDevice, ctx->stream));
+  DX_HIP(ctx, hipMemcpyAsync(ctx->d_dec, dec, sizeof(dec), hipMemcpyHostToDevice, ctx->stream));
+  DX_HIP(ctx, hipMemcpyAsync(ctx->d_long, lng, sizeof(lng), hipMemcpyHostToDevice, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < 4; s++)
+    ctx->sym_type[s] = c->s[s].type;
   ctx->coding_set = 1;
   ctx->lossy   = lossy != 0;
   ctx->delChar = c->delChar;

@@ -223,11 +223,32 @@ int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const 
                  const uint64_t *d_rec_off, const uint32_t *d_seg, uint8_t *d_out);
 
 /* Uncompress_Next_QVentry (QV.c:1428-1481: Decode, Decode_Run, Unpack_Tag) for n records whose
- * segment starts are known: entry i's five segments start at d_in + d_seg_off[5*i+k]; the five
- * decoded lines (d_len[i] symbols each, every line followed by '\n') are written at
- * d_out + d_out_off[i].  upper != 0 applies undexqv's -U (undexqv.c:198-204).                  */
-int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_seg_off, const uint32_t *d_len,
-                 uint64_t n, int upper, uint8_t *d_out, const uint64_t *d_out_off);
+ * segment starts are known: record i starts at d_in + d_rec_off[i] with d_hdr_off[i+1] -
+ * d_hdr_off[i] framing bytes (NULL: none) followed by segments of d_seg[5*i+k] bytes -- exactly
+ * the arrays dx_qv_sizes produces, or dx_qv_walk for a bare file.  The five decoded lines
+ * (d_len[i] symbols each, every line followed by '\n') are written at d_out + d_out_off[i].
+ * upper != 0 applies undexqv's -U (undexqv.c:198-204).  Uses the tables of dx_qv_set_coding.     */
+int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_rec_off, const uint64_t *d_hdr_off,
+                 const uint32_t *d_seg, const uint32_t *d_len, uint64_t n, int upper,
+                 uint8_t *d_out, const uint64_t *d_out_off);
+
+/* Host walk of a bare .dexqv image (undexqv.c:101-208 and the bit-level structure of QV.c:510-691):
+ * the format stores no lengths, so the start of every segment is only known after walking the one
+ * before it, code by code.  Fills the index dx_qv_decode needs (arrays are malloc'd; release with
+ * dx_qv_index_free).  Sequential by nature of the format.                                        */
+typedef struct
+  { uint64_t      n;            /* records */
+    uint64_t     *rec_off;      /* n+1: offset of each record in the image */
+    uint64_t     *hdr_off;      /* n+1: running sum of the records' framing bytes */
+    uint32_t     *seg;          /* n x 5 segment byte sizes */
+    uint32_t     *len;          /* n: symbols per entry (end - beg, undexqv.c:186) */
+    int32_t      *hdr4;         /* n x 4: well, beg, end, qv */
+    dx_qv_coding  coding;
+    char         *prefix;       /* header prefix (QV.c:1256-1265) */
+    int           newv, flip;   /* 0x55aa-keyed file (int32 fields) / byte-swapped writer */
+  } dx_qv_index;
+int  dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *idx);
+void dx_qv_index_free(dx_qv_index *idx);
 
 /* ------------------------------------------------------------------------------------------
  *  whole-file drivers (host images in, host images out): what the six CLI tools call

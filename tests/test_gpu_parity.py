@@ -269,3 +269,56 @@ def test_errors_are_loud(ctx):
         ctx.undexta(b"\x00\x01garbage")
     with pytest.raises(L.DexGPUError):
         ctx.undexta(O.golden("ta_edge.dexta"), False, 0)
+
+
+# ---- decode (undexqv) --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", O.cases("quiva"), ids=lambda c: c["name"])
+def test_undexqv_golden(ctx, case):
+    txt, dx = O.golden(case["input"] + ".quiva"), O.golden(case["name"] + ".dexqv")
+    rt = txt if case["rt_is_input"] else O.golden(case["name"] + ".rt.quiva")
+    assert ctx.undexqv(dx, upper=True) == rt                     # reference `undexqv -U` output
+    assert ctx.undexqv(dx, upper=False) == O.undexqv(dx, upper=False)
+
+
+@pytest.mark.parametrize("lossy", [0, 1])
+@pytest.mark.parametrize("seed,n,mean", [(1, 3, 300), (3, 40, 8000), (4, 700, 900), (6, 24, 30000)])
+def test_undexqv_vs_oracle(ctx, seed, n, mean, lossy):
+    c = synth.make_quiva(n, seed=seed, mean=mean)
+    dx = O.dexqv(c.text, lossy)
+    got = ctx.undexqv(dx, upper=True)
+    assert got == O.undexqv(dx, upper=True)
+    if not lossy:
+        assert got == c.text                                     # round trip byte-identical
+
+
+def test_device_round_trip_with_encoder_index(ctx):
+    """encode -> decode entirely on the device, the decoder fed by the encoder's own index."""
+    lens = np.array(list(range(1, 80)) + [1023, 1024, 1025, 4097] + [7000] * 40, dtype=np.uint32)
+    c = synth.make_quiva(len(lens), seed=21, lens=lens)
+    n = len(lens)
+    b, keep = _upload_quiva(ctx, c)
+    p = ctx.qv_prescan(b)
+    hist, tot = ctx.qv_hist(b, p)
+    coding = api.qv_build(hist, tot, p)
+    ctx.qv_set_coding(coding)
+    blob, hoff, _ = api.frame_headers(c.hdr)
+    d_hdr, d_hoff = ctx.to_device(blob), ctx.to_device(hoff)
+    d_rec, d_seg = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n)
+    total = ctx.qv_sizes(b, d_hoff, d_seg, d_rec)
+    d_out = ctx.alloc(total)
+    ctx.qv_encode(b, d_hdr, d_hoff, d_rec, d_seg, d_out)
+    d_txt2 = ctx.to_device(np.frombuffer(c.text, np.uint8).copy())
+    # wipe the data lines, keep the header lines, then decode in place
+    img = np.frombuffer(c.text, np.uint8).copy()
+    for i in range(n):
+        img[int(c.off[i]): int(c.off[i]) + 5 * (int(c.len[i]) + 1)] = 0
+    d_txt2.upload(img)
+    ctx.qv_decode(d_out, d_rec, d_hoff, d_seg, keep[2], n, True, d_txt2, keep[1])
+    assert d_txt2.download(np.uint8, len(c.text)).tobytes() == c.text
+
+
+def test_undexqv_no_delchar_and_type2(ctx):
+    for name in ("qv_nodel", "qv_type2", "qv_runs"):
+        dx = O.golden(name + ".dexqv")
+        assert ctx.undexqv(dx, upper=False) == O.undexqv(dx, upper=False)

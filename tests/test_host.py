@@ -168,3 +168,33 @@ def test_index_seq_edge_file():
     assert list(hdr[:, 0]) == [5, 5, 260, 770, 771, 1025, 1281, 1881, 1881]
     assert list(hdr[:, 3]) == [851, 800, 0, 85, 9, 75, 123456, 77, 5]
     assert txt[:pl] == b">mv"
+
+
+@pytest.mark.parametrize("case", O.cases("quiva"), ids=lambda c: c["name"])
+def test_walk_bare_file_index(case):
+    """dx_qv_walk (host boundary walk of a bare .dexqv) against per-entry oracle encodes."""
+    txt = O.golden(case["input"] + ".quiva")
+    dx = O.golden(case["name"] + ".dexqv")
+    lossy = "-l" in case["flags"]
+    w = api.qv_walk(dx)
+    off, ln, hdr, pl = api.index_quiva(txt)
+    assert w["n"] == len(ln) and (w["len"] == ln).all() and (w["hdr4"] == hdr).all()
+    assert w["prefix"] == txt[:pl] and w["newv"] == 1 and w["flip"] == 0
+    assert int(w["rec_off"][-1]) == len(dx)
+    coding = O.qv_create(O.qv_scan(txt), lossy)
+    text = np.frombuffer(txt, np.uint8)
+    for i in range(w["n"]):
+        L, o = int(ln[i]), int(off[i])
+        lines = np.stack([text[o + k * (L + 1): o + k * (L + 1) + L] for k in range(5)])
+        body, seg = O.qv_encode_entry(coding, lossy, lines)
+        assert list(w["seg"][i]) == seg
+        hl = int(w["hdr_off"][i + 1] - w["hdr_off"][i])
+        assert dx[int(w["rec_off"][i]) + hl: int(w["rec_off"][i + 1])] == body
+
+
+def test_walk_rejects_garbage():
+    with pytest.raises(L.DexGPUError):
+        api.qv_walk(b"\xaa\x55\xcc\x33" + bytes(40))
+    dx = O.golden("qv_tiny.dexqv")
+    with pytest.raises(L.DexGPUError):
+        api.qv_walk(dx[:-7])
