@@ -1,0 +1,123 @@
+"""The six drop-in tools: same command-line surface, files, messages and exit codes as the
+reference's (compared live against oracle/_ref where present)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import _oracle as O
+from dextractor_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "dextractor_amd", "bin")
+TOOLS = ["dexta", "undexta", "dexar", "undexar", "dexqv", "undexqv"]
+
+needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (compiled reference) not present")
+
+
+def run(tool, args, cwd, ref=False, stdin=None):
+    exe = os.path.join(O.REF_BIN if ref else BIN, tool)
+    return subprocess.run([exe, *args], cwd=str(cwd), capture_output=True, input=stdin)
+
+
+def test_tools_are_built():
+    for t in TOOLS:
+        assert os.access(os.path.join(BIN, t), os.X_OK), f"{t} missing: run `make cli`"
+
+
+@needs_ref
+@pytest.mark.parametrize("tool", TOOLS)
+def test_usage_and_illegal_option_match_reference(tool, tmp_path):
+    """Argument errors are reported before any GPU is touched, in the reference's words."""
+    for args in ([], ["-Z"], ["-vZ", "x"]):
+        a, b = run(tool, args, tmp_path), run(tool, args, tmp_path, ref=True)
+        assert (a.returncode, a.stderr) == (b.returncode, b.stderr), (tool, args)
+    if tool in ("undexta", "undexar"):
+        for args in (["-wabc", "x"], ["-w-3", "x"], ["-w", "x"]):
+            a, b = run(tool, args, tmp_path), run(tool, args, tmp_path, ref=True)
+            assert (a.returncode, a.stderr) == (b.returncode, b.stderr), (tool, args)
+
+
+def _write(path, data):
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def _read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_cli_round_trips_equal_reference(tmp_path):
+    fa = synth.make_seqfile("fasta", 30, seed=4, mean=1500).text
+    ar = synth.make_seqfile("arrow", 30, seed=4, mean=1500).text
+    qv = synth.make_quiva(40, seed=4, mean=7000).text
+    mine, ref = tmp_path / "mine", tmp_path / "ref"
+    for d, isref in ((mine, False), (ref, True)):
+        d.mkdir()
+        _write(d / "a.fasta", fa); _write(d / "b.arrow", ar); _write(d / "c.quiva", qv)
+        _write(d / "c2.quiva", qv)
+        assert run("dexta", ["-v", "a"], d, isref).returncode == 0
+        assert not (d / "a.fasta").exists()                         # source removed without -k
+        assert run("dexar", ["-k", "b.arrow"], d, isref).returncode == 0
+        assert (d / "b.arrow").exists()
+        assert run("dexqv", ["c"], d, isref).returncode == 0
+        assert run("dexqv", ["-kl", "c2"], d, isref).returncode == 0
+        shutil.copy(d / "a.dexta", d / "a2.dexta")
+        assert run("undexta", ["-kU", "-w70", "a2"], d, isref).returncode == 0
+        assert run("undexta", ["a"], d, isref).returncode == 0
+        shutil.copy(d / "b.dexar", d / "b2.dexar")
+        os.remove(d / "b.arrow")
+        assert run("undexar", ["-k", "b"], d, isref).returncode == 0
+        shutil.copy(d / "c.dexqv", d / "c3.dexqv")
+        assert run("undexqv", ["-U", "c"], d, isref).returncode == 0
+        assert run("undexqv", ["-k", "c3"], d, isref).returncode == 0
+    names = sorted(os.listdir(ref))
+    assert names == sorted(os.listdir(mine))
+    for nme in names:
+        assert _read(mine / nme) == _read(ref / nme), nme
+    assert _read(mine / "c.quiva") == qv                            # dexqv | undexqv -U round trip
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_cli_pipe_mode_and_verbose(tmp_path):
+    fa = synth.make_seqfile("fasta", 5, seed=6, mean=400).text
+    a, b = run("dexta", ["-i"], tmp_path, stdin=fa), run("dexta", ["-i"], tmp_path, ref=True, stdin=fa)
+    assert a.returncode == 0 and a.stdout == b.stdout
+    a2, b2 = run("undexta", ["-i", "-U"], tmp_path, stdin=a.stdout), run("undexta", ["-i", "-U"], tmp_path, ref=True, stdin=b.stdout)
+    assert a2.stdout == b2.stdout == fa
+    _write(tmp_path / "v.fasta", fa)
+    a3 = run("dexta", ["-vk", "v.fasta"], tmp_path)
+    assert a3.stderr == b"Processing 'v' ...\nDone\n"
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("tool,ext,data", [
+    ("dexqv", ".quiva", b"@m/1/0_3 RQ=0.8\nabc\nabc\nab\nabc\nabc\n"),
+    ("dexqv", ".quiva", b"m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n"),
+    ("dexqv", ".quiva", b"@m/1/0_3\nabc\nabc\nabc\nabc\nabc\n"),
+    ("dexqv", ".quiva", b"@m/1/0_3 RQ=0.8\nabc\nabc\n"),
+    ("dexta", ".fasta", b"m/1/0_3 RQ=0.8\nACG\n"),
+    ("dexta", ".fasta", b">m 1 0_3 RQ=0.8\nACG\n"),
+    ("dexar", ".arrow", b">m/1/0_3 SN=1.0,2.0\n123\n"),
+    ("undexta", ".dexta", b"\x01\x02\x03\x04\x05\x06"),
+    ("undexar", ".dexar", b"\xcc\x33\x03\x04\x05\x06"),
+])
+def test_cli_error_messages_match_reference(tmp_path, tool, ext, data):
+    mine, ref = tmp_path / "mine", tmp_path / "ref"
+    for d in (mine, ref):
+        d.mkdir()
+        _write(d / ("x" + ext), data)
+    a, b = run(tool, ["-k", "x"], mine), run(tool, ["-k", "x"], ref, ref=True)
+    assert (a.returncode, a.stderr) == (b.returncode, b.stderr)
+
+
+@pytest.mark.gpu
+def test_cli_missing_file(tmp_path):
+    a = run("dexta", ["nothere"], tmp_path)
+    assert a.returncode == 1 and a.stderr == b"dexta: Cannot open ./nothere.fasta for 'r'\n"
