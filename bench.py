@@ -42,11 +42,18 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="timing experiments with ablated kernels")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--workload", default="dexqv", choices=["dexqv", "dexta", "dexar"],
+                    help="dexqv = BASELINE metric (default); dexta/dexar = configs[1]/[2] (2-bit pack + unpack)")
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU for dexta/dexar")
+    ap.add_argument("--verify-roundtrip", action="store_true",
+                    help="dexqv: decode the encoded batch on the device and compare with the input image")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    if args.workload != "dexqv":
+        return pack2_main(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,6 +152,29 @@ def main():
     times = ctx.kernel_times()
     ctx.profile(False)
 
+    roundtrip = None
+    if args.verify_roundtrip:
+        # size-independent property at full size: decode(encode(x)) == x, entirely on the device
+        # (the decoder is fed by the encoder's own index); headers are copied, data lines rebuilt
+        d_back = torch.zeros_like(d_text)
+        torch.cuda.synchronize()
+        ctx.qv_decode(p_out, p_rec, p_hoff, p_seg, p_len, n, True, Ptr(d_back), p_off)
+        ctx.sync(); torch.cuda.synchronize()
+        # compare only the 5 data lines of every entry (fixed-length corpora: one strided view)
+        if args.dist == "fixed":
+            rec = hlen + 5 * (args.mean + 1)
+            a = d_text[: n * rec].view(n, rec)[:, hlen:]
+            b = d_back[: n * rec].view(n, rec)[:, hlen:]
+            roundtrip = bool(torch.equal(a, b))
+        else:
+            idx = torch.from_numpy(np.concatenate([[0], np.cumsum(rec_bytes)]).astype(np.int64)).cuda()
+            ok = True
+            for i in range(0, n, max(1, n // 64)):           # sampled entries for ragged corpora
+                lo, hi = int(off[i]), int(off[i]) + 5 * (int(lens[i]) + 1)
+                ok = ok and bool(torch.equal(d_text[lo:hi], d_back[lo:hi]))
+            roundtrip = ok
+        del d_back
+
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -205,6 +235,7 @@ def main():
                    "sharding": "contiguous entry ranges, one file (host-side 12 KB histogram sum)" if world > 1 else "single GPU"},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "roundtrip_bit_exact": roundtrip,
         "pipeline": pipe,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                     for k, v in kern.items()},
@@ -249,6 +280,91 @@ def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state):
     got = ctx.dexqv(sample, args.lossy)          # same sample through the GPU path (file driver)
     res["gpu_output_identical"] = bool(got == want)
     return res
+
+
+def pack2_main(args):
+    """BASELINE configs[1]/[2]: 2-bit pack + unpack of `--reads` x `--mean` reads (80-column text).
+    A host-generated tile of 20000 reads is replicated on the device to the full size."""
+    import torch
+    from dextractor_amd import _lib as L
+    from dextractor_amd import api, synth
+    torch.cuda.set_device(0)
+    ctx = api.Context(0)
+    arrow = args.workload == "dexar"
+    n0 = min(20000, args.reads)
+    tile = synth.make_seqfile("arrow" if arrow else "fasta", n0, seed=args.seed, dist="fixed", mean=args.mean)
+    reps = max(1, args.reads // n0)
+    n = n0 * reps
+    tb = len(tile.text)
+    t_tile = torch.from_numpy(np.frombuffer(tile.text, np.uint8).copy()).cuda()
+    d_text = t_tile.repeat(reps)
+    rep_off = (np.arange(reps, dtype=np.uint64) * np.uint64(tb))[:, None]
+    off = (rep_off + tile.off[None, :]).reshape(-1)
+    tlen, nsym = np.tile(tile.tlen, reps), np.tile(tile.len, reps)
+    hdr4 = np.tile(tile.hdr, (reps, 1)).astype(np.int32)
+    hdr4[:, 0] = np.arange(1, n + 1)                              # wells keep increasing across the tiles
+    cnr = None
+    if arrow:
+        cnr = np.tile((np.array(tile.snr, dtype=np.float64) * 100 + 0.5).astype(np.uint16), (reps, 1))
+    blob, hoff, _ = api.frame_headers(hdr4, cnr)
+    clen = (nsym.astype(np.uint64) + 3) >> 2
+    rec = (hoff[1:] - hoff[:-1]) + clen
+    ooff = np.concatenate([[0], np.cumsum(rec)[:-1]]).astype(np.uint64)
+    out_bytes = int(rec.sum())
+
+    class Ptr:
+        def __init__(self, t): self.t, self.ptr = t, t.data_ptr()
+    up = lambda a, dt: Ptr(torch.from_numpy(np.ascontiguousarray(a).view(dt)).cuda())
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    p_text, p_off, p_tlen, p_nsym = Ptr(d_text), up(off, np.int64), up(tlen, np.int32), up(nsym, np.int32)
+    p_hdr, p_hoff, p_ooff = up(blob, np.uint8), up(hoff, np.int64), up(ooff, np.int64)
+    p_out = Ptr(torch.empty(out_bytes + 64, dtype=torch.uint8, device="cuda"))
+    # decode side: packed bytes sit after each record's framing; text goes back in 80-column lines
+    ioff = (ooff + (hoff[1:] - hoff[:-1])).astype(np.uint64)
+    p_ioff = up(ioff, np.int64)
+    p_back = Ptr(torch.zeros(n * tb // n0 + 64, dtype=torch.uint8, device="cuda"))
+    alpha = L.DX_ALPHA_ARROW if arrow else L.DX_ALPHA_BASES
+    letters = L.DX_LETTERS_ARROW if arrow else L.DX_LETTERS_UPPER
+
+    def step():
+        ctx.pack2_encode(alpha, p_text, p_off, p_tlen, p_nsym, n, p_hdr, p_hoff, p_out, p_ooff)
+        ctx.pack2_decode(letters, p_out, p_ioff, p_nsym, n, 80, p_back, p_off)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync(); torch.cuda.synchronize()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    times = ctx.kernel_times()
+    ctx.profile(False)
+    # round trip: sequence text regions identical (header lines are not rewritten by the decoder)
+    rec_t = tb // n0 if n0 and all(tile.tlen == tile.tlen[0]) else None
+    same = None
+    if rec_t and tb % n0 == 0:
+        hl = int(tile.off[0])
+        same = bool(torch.equal(d_text.view(n, tb // n0)[:, hl:], p_back.t[: n * (tb // n0)].view(n, tb // n0)[:, hl:]))
+    bases = int(nsym.astype(np.uint64).sum())
+    text_in = int(tlen.astype(np.uint64).sum())
+    enc_ms, dec_ms = times["k_pack2_encode"][0] / args.steps, times["k_pack2_decode"][0] / args.steps
+    algo_enc, algo_dec = text_in + out_bytes, (out_bytes + text_in)
+    line = {"metric": f"{args.workload} 2-bit pack input GB/s (+ unpack); round-trip bit-exact",
+            "value": round(text_in / (enc_ms * 1e-3) / 1e9, 2), "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload} + un{args.workload}, {n} x {args.mean} reads, 80-column text, HBM-resident "
+                                   f"(BASELINE.json configs[{2 if arrow else 1}])", "reads": n, "bases": bases,
+                       "text_bytes": text_in, "packed_bytes": out_bytes},
+            "roofline": {"kernel": "k_pack2_encode", "bound": "hbm", "achieved": round(algo_enc / (enc_ms * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_enc / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "algo_bytes_per_launch": algo_enc},
+            "decode": {"kernel": "k_pack2_decode", "ms": round(dec_ms, 3), "GBps": round(algo_dec / (dec_ms * 1e-3) / 1e9, 1),
+                       "frac": round(algo_dec / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "encode_ms": round(enc_ms, 3), "roundtrip_bit_exact": same, "cpu_baseline": None}
+    print(json.dumps(line))
 
 
 if __name__ == "__main__":

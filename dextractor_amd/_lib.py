@@ -56,6 +56,7 @@ SIGNATURES = {
     "dx_close": (None, [_P]),
     "dx_last_error": (C.c_char_p, [_P]),
     "dx_set_stream": (C.c_int, [_P, _P]),
+    "dx_reset_stream": (C.c_int, [_P]),
     "dx_sync": (C.c_int, [_P]),
     "dx_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "dx_free": (C.c_int, [_P, _P]),

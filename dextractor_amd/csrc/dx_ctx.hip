@@ -95,7 +95,13 @@ extern "C" void dx_close(dx_ctx *ctx)
 
 extern "C" int dx_set_stream(dx_ctx *ctx, void *hip_stream)
 { if (ctx == NULL) return DX_E_ARG;
-  ctx->stream = hip_stream ? (hipStream_t) hip_stream : ctx->own;
+  ctx->stream = (hipStream_t) hip_stream;
+  return DX_OK;
+}
+
+extern "C" int dx_reset_stream(dx_ctx *ctx)
+{ if (ctx == NULL) return DX_E_ARG;
+  ctx->stream = ctx->own;
   return DX_OK;
 }
 

@@ -47,7 +47,9 @@ int         dx_device_count(void);
 int         dx_open(int device, dx_ctx **ctx);
 void        dx_close(dx_ctx *ctx);
 const char *dx_last_error(const dx_ctx *ctx);      /* ctx may be NULL: last error of dx_open */
-int         dx_set_stream(dx_ctx *ctx, void *hip_stream);   /* NULL restores the context's own stream */
+int         dx_set_stream(dx_ctx *ctx, void *hip_stream);   /* issue on this hipStream_t; NULL = the default (null) stream,
+                                                               e.g. torch's current stream when it is the default one */
+int         dx_reset_stream(dx_ctx *ctx);                   /* back to the context's own non-blocking stream */
 int         dx_sync(dx_ctx *ctx);
 
 int dx_malloc(dx_ctx *ctx, size_t bytes, void **d_ptr);
