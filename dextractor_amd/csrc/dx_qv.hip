@@ -20,12 +20,14 @@
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 
-// Packed token: bits [0,24) code bits (for an escaped symbol: code<<8 | literal), [24,30) length
-// in bits, bit 31 = escape flag.  For run schemes the entry holds the bare run code; the 16-bit
-// literal of an escaped run is appended at emission time (QV.c:486-487).
-#define TOK_LEN(e)  (((e) >> 24) & 0x3fu)
+// Packed token: bits [0,24) code bits (for an escaped symbol: code<<8 | literal), bit 25 = escape
+// flag, [26,32) length in bits (a single shift extracts it; a symbol without a code is entry 0).
+// For run schemes the entry holds the bare run code; the 16-bit literal of an escaped run is
+// appended at emission time (QV.c:486-487).
+#define TOK_LEN(e)  ((e) >> 26)
 #define TOK_BITS(e) ((e) & 0xffffffu)
-#define TOK_ESC(e)  ((e) >> 31)
+#define TOK_ESC(e)  (((e) >> 25) & 1u)
+#define TOK_PACK(bits, len, esc) (((bits) & 0xffffffu) | ((uint32_t) (len) << 26) | ((esc) ? 0x2000000u : 0u))
 
 #define QV_WIN_WORDS  512                          // per-wave LDS bit window (2 KiB)
 #define QV_WIN_BITS   (32u * (QV_WIN_WORDS - 32))  // usable: one lane's worst case (896 bits) always fits
@@ -733,9 +735,8 @@ __device__ __forceinline__ void place_token(uint32_t *win, uint32_t q, uint64_t 
 // one (run token + symbol token) per lane.  With TAGS the same lanes also emit the 2-bit code of
 // the deletion tag under each non-run symbol (Pack_Tag + Number_Read + Compress_Read,
 // QV.c:810-819, 1402-1404) into the tag window.
-template <bool TAGS>
 __device__ __forceinline__ void encode_runs_step(wave_out &o, wave_out &ot, const run_lds &R, uint8_t *tagchunk,
-                                                 const u32x4 &c, const u32x4 &t, int valid, uint32_t sv,
+                                                 const bool TAGS, const u32x4 &c, const u32x4 &t, int valid, uint32_t sv,
                                                  uint32_t rc, uint32_t &C, const uint32_t *ntab, const uint32_t *rtab)
 { const int lane = lane_id();
   if (TAGS)
@@ -829,41 +830,18 @@ __device__ __forceinline__ uint32_t finish_tags(wave_out &o)
   return clen_bytes;
 }
 
-// a plain-coded stream into its segment; returns the segment's bytes
-__device__ __forceinline__ uint32_t encode_plain_stream(wave_out &o, const uint8_t *p, uint32_t L,
-                                                        bool over, const uint32_t *tab, uint32_t mask)
+// tags of an entry whose deletion stream is NOT run coded (no delChar): every position is kept
+__device__ __forceinline__ uint32_t encode_all_tags(wave_out &ot, const uint8_t *p1, uint32_t L, bool over)
 { const int lane = lane_id();
-  const uint32_t m4 = mask * 0x01010101u;
-  o.wordbase = 0;
-  o.winbits  = 0;
   uint32_t pos = 16u * lane;
-  u32x4 c = fetch(p, pos, L, over);
+  u32x4 t = fetch(p1, pos, L, over);
   for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
-      encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, m4);
-      c = d;
+    { const u32x4 u = fetch(p1, pos + DX_STEP, L, over);
+      encode_tags_step(ot, t, (1u << valid_of(pos, L)) - 1u);
+      t = u;
       pos += DX_STEP;
     }
-  return finish_words(o, last_piece_plain(tab, p, L, mask));
-}
-
-__device__ __forceinline__ uint32_t encode_runs_stream(wave_out &o, const run_lds &R, const uint8_t *p, uint32_t L,
-                                                       bool over, uint32_t rc, const uint32_t *ntab, const uint32_t *rtab)
-{ const int lane = lane_id();
-  uint32_t  C = 0;
-  o.wordbase = 0;
-  o.winbits  = 0;
-  uint32_t pos = 16u * lane;
-  u32x4 c = fetch(p, pos, L, over);
-  for (uint32_t base = 0; base < L; base += DX_STEP)
-    { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
-      const uint32_t sv = L - base >= DX_STEP ? DX_STEP : L - base;
-      encode_runs_step<false>(o, o, R, NULL, c, c, valid_of(pos, L), sv, rc, C, ntab, rtab);
-      c = d;
-      pos += DX_STEP;
-    }
-  const uint32_t last = C > 0 ? encode_trailing_run(o, C, rtab) : last_piece_plain(ntab, p, L, 0xffu);
-  return finish_words(o, last);
+  return finish_tags(ot);
 }
 
 __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
@@ -880,7 +858,6 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
   const int      wid   = threadIdx.x >> 6;
   const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + wid;
   const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
-  const uint32_t imask = a.lossy ? 0xfeu : 0xffu, mmask = a.lossy ? 0xfcu : 0xffu;
 
   const run_lds R = { s_chunk[wid], s_list[wid] };
   wave_out o, ot;
@@ -901,60 +878,69 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
             dst[k] = hdr[h0 + k];
           dst += hl;
         }
-      const uint8_t *p0 = line_ptr(a, r, L, 0), *p1 = line_ptr(a, r, L, 1);
-      const bool over = can_overread(a, line_ptr(a, r, L, 4), L);
-      const uint32_t want0 = sg[0], want1 = sg[1], want2 = sg[2], want3 = sg[3], want4 = sg[4];
+      const uint8_t *p1   = line_ptr(a, r, L, 1);
+      const bool     over = can_overread(a, line_ptr(a, r, L, 4), L);
       uint32_t bad = 0;
 
-#ifndef ABL_NO_DEL
-      // ---- deletion QVs and deletion tags in one sweep (QV.c:1393-1404): the tag segment starts
-      //      want0 bytes after the deletion segment (sizes come from k_qv_sizes)
-      { o.seg  = dst;         o.wordbase  = 0; o.winbits  = 0;
-        ot.seg = dst + want0; ot.wordbase = 0; ot.winbits = 0;
-        const bool     drun = a.delChar >= 0;
-        const uint32_t rc   = (uint32_t) a.delChar;
-        uint32_t C = 0, pos = 16u * lane;
-        u32x4 c = fetch(p0, pos, L, over), t = fetch(p1, pos, L, over);
-        for (uint32_t base = 0; base < L; base += DX_STEP)
-          { const u32x4 d = fetch(p0, pos + DX_STEP, L, over), u = fetch(p1, pos + DX_STEP, L, over);
-            const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
-            const int      valid = valid_of(pos, L);
-            const uint32_t vm    = (1u << valid) - 1u;
-            if (drun)
-#ifndef ABL_NO_TAG
-              encode_runs_step<true>(o, ot, R, s_tchunk[wid], c, t, valid, sv, rc, C, s_tok[DX_DEL], s_tok[DX_DRUN]);
-#else
-              encode_runs_step<false>(o, ot, R, s_tchunk[wid], c, t, valid, sv, rc, C, s_tok[DX_DEL], s_tok[DX_DRUN]);
+      // The four QV streams in file order: del (with its tag segment right behind it), ins, mrg,
+      // sub (QV.c:1393-1423).  One loop, so that each step body exists once in the code.
+      #pragma unroll 1
+      for (int q = 0; q < 4; q++)
+        {
+#ifdef ABL_SKIP_Q
+          if ((ABL_SKIP_Q >> q) & 1) { dst += sg[q ? q + 1 : 0] + (q == 0 ? sg[1] : 0); continue; }
 #endif
-            else
-              { encode_plain_step(o, c, valid, sv == DX_STEP, s_tok[DX_DEL], ~0u);
-                encode_tags_step(ot, t, vm);
-              }
-            c = d; t = u;
-            pos += DX_STEP;
-          }
-        const uint32_t last = (drun && C > 0) ? encode_trailing_run(o, C, s_tok[DX_DRUN])
-                                              : last_piece_plain(s_tok[DX_DEL], p0, L, 0xffu);
-        bad |= finish_words(o, last) ^ want0;
-        bad |= finish_tags(ot) ^ want1;
-      }
-#endif
+          const int       line = q ? q + 1 : 0;
+          const uint8_t  *p    = line_ptr(a, r, L, line);
+          const int       rci  = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
+          const uint32_t *tab  = s_tok[q];
+          const uint32_t  want = sg[line];
+          const uint32_t  mask = !a.lossy ? 0xffu : (q == 1 ? 0xfeu : (q == 2 ? 0xfcu : 0xffu));   // QV.c:1406-1415
+          o.seg = dst; o.wordbase = 0; o.winbits = 0;
+          uint32_t got, pos = 16u * lane;
 
-      // ---- insertion, merge, substitution QVs (QV.c:1406-1423)
-      o.seg = dst + want0 + want1;
-#ifndef ABL_NO_INS
-      bad  |= encode_plain_stream(o, line_ptr(a, r, L, 2), L, over, s_tok[DX_INS], imask) ^ want2;
-#endif
-      o.seg += want2;
-#ifndef ABL_NO_MRG
-      bad  |= encode_plain_stream(o, line_ptr(a, r, L, 3), L, over, s_tok[DX_MRG], mmask) ^ want3;
-#endif
-      o.seg += want3;
-#ifndef ABL_NO_SUB
-      bad  |= ((a.subChar >= 0)
-                 ? encode_runs_stream(o, R, line_ptr(a, r, L, 4), L, over, (uint32_t) a.subChar, s_tok[DX_SUB], s_tok[DX_SRUN])
-                 : encode_plain_stream(o, line_ptr(a, r, L, 4), L, over, s_tok[DX_SUB], 0xffu)) ^ want4;
-#endif
+          if (rci >= 0)                                  // Encode_Run; for del also Pack_Tag & co.
+            { const uint32_t *rtab = s_tok[q == 0 ? DX_DRUN : DX_SRUN];
+              const bool      tags = q == 0;
+              uint32_t C = 0;
+              ot.seg = dst + want; ot.wordbase = 0; ot.winbits = 0;
+              u32x4 c = fetch(p, pos, L, over), t = c;
+              if (tags) t = fetch(p1, pos, L, over);
+              for (uint32_t base = 0; base < L; base += DX_STEP)
+                { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
+                  u32x4 u = d;
+                  if (tags) u = fetch(p1, pos + DX_STEP, L, over);
+                  const uint32_t sv = L - base >= DX_STEP ? DX_STEP : L - base;
+                  encode_runs_step(o, ot, R, s_tchunk[wid], tags, c, t, valid_of(pos, L), sv, (uint32_t) rci, C, tab, rtab);
+                  c = d; t = u;
+                  pos += DX_STEP;
+                }
+              const uint32_t last = C > 0 ? encode_trailing_run(o, C, rtab) : last_piece_plain(tab, p, L, 0xffu);
+              got = finish_words(o, last);
+              if (tags)
+                { bad |= finish_tags(ot) ^ sg[1];
+                  dst += sg[1];
+                }
+            }
+          else                                           // Encode
+            { const uint32_t m4 = mask * 0x01010101u;
+              u32x4 c = fetch(p, pos, L, over);
+              for (uint32_t base = 0; base < L; base += DX_STEP)
+                { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
+                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, m4);
+                  c = d;
+                  pos += DX_STEP;
+                }
+              got = finish_words(o, last_piece_plain(tab, p, L, mask));
+              if (q == 0)                                // no delChar: the whole tag line is packed
+                { ot.seg = dst + want; ot.wordbase = 0; ot.winbits = 0;
+                  bad |= encode_all_tags(ot, p1, L, over) ^ sg[1];
+                  dst += sg[1];
+                }
+            }
+          bad |= got ^ want;
+          dst += want;
+        }
       if (bad && lane == 0)
         atomicOr(status, 2u);                            // sizes disagree with k_qv_sizes
     }
@@ -1043,14 +1029,13 @@ static uint32_t pack_sym(const dx_scheme *s, int x)
 { const uint32_t len = (uint32_t) s->lens[x], bits = s->bits[x];
   if (len == 0) return 0;
   const bool esc = s->type == 2 && bits == s->bits[255] && s->lens[x] == s->lens[255];   // QV.c:432
-  return esc ? (((bits << 8) | (uint32_t) x) & 0xffffffu) | ((len + 8u) << 24) | 0x80000000u
-             : (bits & 0xffffffu) | (len << 24);
+  return esc ? TOK_PACK((bits << 8) | (uint32_t) x, len + 8u, true) : TOK_PACK(bits, len, false);
 }
 
 static uint32_t pack_run(const dx_scheme *s, int x)
 { const uint32_t len = (uint32_t) s->lens[x], bits = s->bits[x];
   const bool esc = bits == s->bits[255] && s->lens[x] == s->lens[255];                   // QV.c:468-469, 486
-  return (bits & 0xffffffu) | (len << 24) | (esc ? 0x80000000u : 0u);
+  return TOK_PACK(bits, len, esc);
 }
 
 extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
