@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--workload", default="dexqv", choices=["dexqv", "dexta", "dexar"],
                     help="dexqv = BASELINE metric (default); dexta/dexar = configs[1]/[2] (2-bit pack + unpack)")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU for dexta/dexar")
-    ap.add_argument("--verify-roundtrip", action="store_true",
-                    help="dexqv: decode the encoded batch on the device and compare with the input image")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="dexqv: skip the (untimed) full-size on-device decode + compare after the timed steps")
     return ap.parse_args()
 
 
@@ -153,7 +153,7 @@ def main():
     ctx.profile(False)
 
     roundtrip = None
-    if args.verify_roundtrip:
+    if not args.no_verify:
         # size-independent property at full size: decode(encode(x)) == x, entirely on the device
         # (the decoder is fed by the encoder's own index); headers are copied, data lines rebuilt
         d_back = torch.zeros_like(d_text)
@@ -220,7 +220,8 @@ def main():
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state)
+        cpu = cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state,
+                           dict(p_out=p_out, p_rec=p_rec, n=n, movie=movie))
 
     line = {
         "metric": "dexqv encode input GB/s (5 QV/tag stream bytes per base; .dexqv bit-exact vs reference)",
@@ -245,7 +246,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state):
+def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state, big):
     """Time the CPU path on a bounded sample of the same corpus (first S entries), on this host.
     kind "reference": the real reference `dexqv` (oracle/_ref, compiled from the reference's own
     sources); kind "port": the oracle's C restatement.  Also checks the GPU output for the same
@@ -279,6 +280,46 @@ def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state):
         res.update(kind="port", value=round(5 * sbases / dt / 1e9, 4), seconds=round(dt, 2))
     got = ctx.dexqv(sample, args.lossy)          # same sample through the GPU path (file driver)
     res["gpu_output_identical"] = bool(got == want)
+
+    # how the single-threaded reference would be deployed: one independent copy per host core
+    cores = os.cpu_count() or 1
+    if os.path.isfile(ref_bin) and cores > 1:
+        S2 = min(4000, S)
+        end2 = int(off[S2 - 1] + 5 * (int(lens[S2 - 1]) + 1))
+        b2 = int(lens[:S2].astype(np.uint64).sum())
+        with tempfile.TemporaryDirectory(dir=shm) as d:
+            src = os.path.join(d, "s.quiva")
+            with open(src, "wb") as f:
+                f.write(sample[:end2])
+            paths = []
+            for k in range(cores):
+                os.mkdir(os.path.join(d, f"c{k}"))
+                os.symlink(src, os.path.join(d, f"c{k}", "s.quiva"))
+                paths.append(os.path.join(d, f"c{k}", "s.quiva"))
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([ref_bin, "-k"] + (["-l"] if args.lossy else []) + [q]) for q in paths]
+            rcs = [q.wait() for q in procs]
+            dt = time.perf_counter() - t0
+        if all(r == 0 for r in rcs):
+            res["all_cores"] = {"cores": cores, "value": round(cores * 5 * b2 / dt / 1e9, 3), "unit": "GB/s",
+                                "sample": f"{cores} concurrent copies of the reference, {S2} entries each"}
+
+    # the big batch's LAST records (file offsets beyond 4 GiB) decoded by the oracle with the
+    # batch's own tables must reproduce the last entries of the input image
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        T, n = min(64, big["n"]), big["n"]
+        rec = big["p_rec"].t[n - T: n + 1].cpu().numpy().astype(np.uint64)
+        body = big["p_out"].t[int(rec[0]): int(rec[-1])].cpu().numpy().tobytes()
+        img = b"\xaa\x55" + api.qv_write_coding(state["coding"], ("@" + big["movie"]).encode()) + body
+        txt = O.undexqv(img, upper=True)
+        lo = int(off[n - T])
+        want_txt = d_text[lo - hlen: int(off[n - 1]) + 5 * (int(lens[n - 1]) + 1)].cpu().numpy().tobytes()
+        strip = lambda b_: [ln for ln in b_.split(b"\n") if not ln.startswith(b"@")]
+        res["tail_records_decode_ok"] = bool(strip(txt) == strip(want_txt)) if not args.lossy else None
+    except Exception as e:                                   # the checker is optional plumbing
+        res["tail_records_decode_ok"] = f"check failed to run: {e}"
     return res
 
 

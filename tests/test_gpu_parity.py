@@ -322,3 +322,39 @@ def test_undexqv_no_delchar_and_type2(ctx):
     for name in ("qv_nodel", "qv_type2", "qv_runs"):
         dx = O.golden(name + ".dexqv")
         assert ctx.undexqv(dx, upper=False) == O.undexqv(dx, upper=False)
+
+
+def _quiva(ents, movie=b"m7"):
+    out = []
+    for well, lines in ents:
+        L = len(lines[0])
+        out.append(b"@%s/%d/%d_%d RQ=0.%d\n" % (movie, well, 3, 3 + L, 801))
+        out += [bytes(x) + b"\n" for x in lines]
+    return b"".join(out)
+
+
+def test_dexqv_zero_length_entries(ctx):
+    """Entries with no symbols at all (five empty lines) between normal ones."""
+    prof = synth.pacbio_profile()
+    ents = []
+    for e, L in enumerate([0, 700, 0, 0, 15, 1024, 0]):
+        b = synth.qv_lines(3, e, L, prof)
+        ents.append((5 + 3 * e, [b[r].tobytes() for r in range(5)]))
+    txt = _quiva(ents)
+    want = O.dexqv(txt)
+    assert ctx.dexqv(txt) == want
+    assert ctx.undexqv(want, upper=True) == O.undexqv(want, upper=True)
+
+
+def test_dexqv_run_longer_than_16_bits(ctx):
+    """A deletion run of 70000 does not fit the 16-bit run literal (QV.c:487): the reference ORs the
+    overflowing bit into the preceding code.  The device path reproduces those bytes."""
+    prof = synth.pacbio_profile()
+    L = 70000 + 50
+    b = synth.qv_lines(9, 0, L, prof)
+    b[0, :] = ord("2"); b[1, :] = ord("N")
+    b[0, 70000:] = np.arange(50) % 16 + 34
+    b[1, 70000:] = ord("A")
+    b2 = synth.qv_lines(9, 1, 3000, prof)
+    txt = _quiva([(4, [b[r].tobytes() for r in range(5)]), (9, [b2[r].tobytes() for r in range(5)])])
+    assert ctx.dexqv(txt) == O.dexqv(txt)
