@@ -90,3 +90,33 @@ __device__ __forceinline__ uint32_t chunk_eq_mask(const u32x4 &v, uint32_t c)
 }
 
 __device__ __forceinline__ void store32_u(uint8_t *p, uint32_t v) { *(u32_u *) p = v; }
+
+// ---------------------------------------------------------------------------------------------
+//  per-wave output window: bits are ORed into a zeroed LDS word window (MSB-first within 32-bit
+//  words) and leave as coalesced, possibly unaligned, dword stores at the segment's byte address
+// ---------------------------------------------------------------------------------------------
+struct wave_out
+{ uint32_t *win;          // this wave's LDS window (zero outside [0, winbits))
+  uint8_t  *seg;          // byte address of the current segment's first word
+  uint32_t  wordbase;     // words of this segment already stored
+  uint32_t  winbits;      // bits in the window
+};
+
+// store the window's completed words and slide the partial word to win[0]
+__device__ __forceinline__ void flush_words(wave_out &o, bool swap)
+{ const int      lane  = lane_id();
+  const uint32_t nfull = o.winbits >> 5;
+  wave_sync();
+  for (uint32_t j = lane; j < nfull; j += 64)
+    { const uint32_t w = o.win[j];
+      store32_u(o.seg + 4ull * (o.wordbase + j), swap ? __builtin_bswap32(w) : w);
+    }
+  const uint32_t part = o.win[nfull];
+  wave_sync();
+  for (uint32_t j = lane; j <= nfull; j += 64)
+    o.win[j] = (j == 0) ? part : 0u;
+  o.wordbase += nfull;
+  o.winbits  &= 31u;
+  wave_sync();
+}
+

@@ -19,7 +19,8 @@
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 
-#define P2_WIN 72        // LDS words per wave: 64 words/step + carried partial word + slack
+#define P2_WIN_WORDS  320                // per-wave LDS window: flush threshold + one step (64 words) + slack
+#define P2_FLUSH_BITS 8192u
 
 // ---------------------------------------------------------------------------------------------
 //  alphabet maps (computed, not tabulated)
@@ -34,6 +35,9 @@ __device__ __forceinline__ uint32_t sym_code(uint32_t x)
     return (x == '1') ? 0u : (x == '2') ? 1u : (x == '3' || x == 'G') ? 2u : 3u;
 }
 
+__device__ __forceinline__ u32x4 p2_fetch(const uint8_t *p, uint32_t pos, uint32_t T)
+{ return load_chunk(p + pos, pos >= T ? 0 : (T - pos >= 16u ? 16 : (int) (T - pos))); }
+
 template <int ALPHA>
 __global__ __launch_bounds__(DX_BLOCK)
 void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict__ off,
@@ -41,15 +45,16 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
                     const uint8_t *__restrict__ hdr, const uint64_t *__restrict__ hdr_off,
                     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
                     uint32_t *__restrict__ status)
-{ __shared__ uint32_t s_win[DX_WAVES_PER_BLK][P2_WIN];
+{ __shared__ uint32_t s_win[DX_WAVES_PER_BLK][P2_WIN_WORDS];
   const int       lane  = lane_id();
   const int       wid   = threadIdx.x >> 6;
-  uint32_t       *win   = s_win[wid];
   const uint64_t  wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + wid;
   const uint64_t  nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
 
-  for (int j = lane; j < P2_WIN; j += 64)
-    win[j] = 0;
+  wave_out o;
+  o.win = s_win[wid];
+  for (int j = lane; j < P2_WIN_WORDS; j += 64)
+    o.win[j] = 0;
   wave_sync();
 
   for (uint64_t r = wave0; r < n; r += nwave)
@@ -64,61 +69,50 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
             dst[k] = hdr[h0 + k];
           dst += hl;
         }
+      o.seg = dst; o.wordbase = 0; o.winbits = 0;
 
-      uint32_t G     = 0;        // symbols consumed so far
-      uint32_t wbase = 0;        // index of the 32-bit output word held in win[0]
-
+      uint32_t pos = 16u * lane;
+      u32x4 c = p2_fetch(src, pos, T);
       for (uint32_t base = 0; base < T; base += DX_STEP)
-        { const uint32_t pos   = base + 16u * lane;
-          const int      valid = pos >= T ? 0 : (T - pos >= 16u ? 16 : (int) (T - pos));
-          const u32x4    c     = load_chunk(src + pos, valid);
-
-          uint32_t keep = ~chunk_eq_mask(c, '\n') & ((1u << valid) - 1u);
-          uint32_t cnt  = __popc(keep);
-          uint32_t acc  = 0;                             // kept codes, first one in the top bits
-          int      sh   = 30;
+        { const u32x4 d = p2_fetch(src, pos + DX_STEP, T);       // next step already in flight
+          const int valid = pos >= T ? 0 : (T - pos >= 16u ? 16 : (int) (T - pos));
+          const uint32_t keep = ~chunk_eq_mask(c, '\n') & ((1u << valid) - 1u);
+          const uint32_t cnt  = __popc(keep);
+          uint32_t acc = 0;                              // kept codes, first one in the top bits
+          int      sh  = 30;
           #pragma unroll
           for (int b = 0; b < 16; b++)
             if ((keep >> b) & 1u)
               { acc |= sym_code<ALPHA>((chunk_word(c, b >> 2) >> (8 * (b & 3))) & 0xffu) << sh;
                 sh  -= 2;
               }
-
-          const uint32_t incl  = wave_incl_scan(cnt);
-          const uint32_t total = wave_total(incl);
-          const uint32_t bit   = 2u * (G + incl - cnt) - 32u * wbase;   // bit offset in the window
+          const uint32_t incl = wave_incl_scan(cnt);
           if (cnt)
-            { const uint32_t w = bit >> 5, s = bit & 31u;
-              atomicOr(&win[w], acc >> s);
+            { const uint32_t bit = o.winbits + 2u * (incl - cnt);
+              const uint32_t w = bit >> 5, s = bit & 31u;
+              atomicOr(&o.win[w], acc >> s);
               if (s && 2u * cnt + s > 32u)
-                atomicOr(&win[w + 1], acc << (32u - s));
+                atomicOr(&o.win[w + 1], acc << (32u - s));
             }
-          G += total;
-          wave_sync();
-
-          const uint32_t nfull = (G >> 4) - wbase;       // completed words (16 symbols each), <= 65
-          for (uint32_t j = lane; j < nfull; j += 64)
-            store32_u(dst + 4ull * (wbase + j), __builtin_bswap32(win[j]));
-          const uint32_t part = win[nfull];              // carried partial word (uniform address)
-          wave_sync();
-          for (uint32_t j = lane; j <= nfull; j += 64)
-            win[j] = (j == 0) ? part : 0u;
-          wbase += nfull;
-          wave_sync();
+          o.winbits += 2u * wave_total(incl);
+          if (o.winbits >= P2_FLUSH_BITS)
+            flush_words(o, true);
+          c = d;
+          pos += DX_STEP;
         }
 
-      { const uint32_t clen = (G + 3u) >> 2;             // COMPRESSED_LEN, DB.h:255
-        const uint32_t done = 4u * wbase;
-        if (lane == 0)
-          { const uint32_t w = __builtin_bswap32(win[0]);
-            for (uint32_t k = done; k < clen; k++)
-              dst[k] = (uint8_t) (w >> (8 * (k - done)));
-            win[0] = 0;
-            if (G != nsym[r])
-              atomicOr(status, 1u);
-          }
-        wave_sync();
-      }
+      flush_words(o, true);
+      const uint32_t G    = 16u * o.wordbase + (o.winbits >> 1);  // symbols seen
+      const uint32_t clen = (G + 3u) >> 2;                        // COMPRESSED_LEN, DB.h:255
+      if (lane == 0)
+        { const uint32_t w = __builtin_bswap32(o.win[0]);
+          for (uint32_t k = 4u * o.wordbase; k < clen; k++)
+            dst[k] = (uint8_t) (w >> (8 * (k - 4u * o.wordbase)));
+          o.win[0] = 0;
+          if (G != nsym[r])
+            atomicOr(status, 1u);
+        }
+      wave_sync();
     }
 }
 
@@ -208,7 +202,7 @@ extern "C" int dx_pack2_encode(dx_ctx *ctx, int alphabet,
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
-  const int grid = dx_grid_waves(ctx, n, 16);
+  const int grid = dx_grid_waves(ctx, n, 32);
   if (alphabet == DX_ALPHA_BASES)
     DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_BASES>, grid, DX_BLOCK,
               d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status);
@@ -236,7 +230,7 @@ extern "C" int dx_pack2_decode(dx_ctx *ctx, int letters,
   if (!d_in || !d_in_off || !d_nsym || !d_out || !d_out_off)
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
-  const int grid = dx_grid_waves(ctx, n, 16);
+  const int grid = dx_grid_waves(ctx, n, 32);
   switch (letters)
     { case DX_LETTERS_LOWER:
         DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_LOWER>, grid, DX_BLOCK,

@@ -577,31 +577,6 @@ void k_scan_apply(const uint32_t *in, uint64_t n, const uint64_t *tile_sum, uint
 // =============================================================================================
 //  encode pass
 // =============================================================================================
-struct wave_out
-{ uint32_t *win;          // this wave's LDS window (zero outside [0, winbits))
-  uint8_t  *seg;          // byte address of the current segment's first word
-  uint32_t  wordbase;     // words of this segment already stored
-  uint32_t  winbits;      // bits in the window
-};
-
-// store the window's completed words and slide the partial word to win[0]
-__device__ __forceinline__ void flush_words(wave_out &o, bool swap)
-{ const int      lane  = lane_id();
-  const uint32_t nfull = o.winbits >> 5;
-  wave_sync();
-  for (uint32_t j = lane; j < nfull; j += 64)
-    { const uint32_t w = o.win[j];
-      store32_u(o.seg + 4ull * (o.wordbase + j), swap ? __builtin_bswap32(w) : w);
-    }
-  const uint32_t part = o.win[nfull];
-  wave_sync();
-  for (uint32_t j = lane; j <= nfull; j += 64)
-    o.win[j] = (j == 0) ? part : 0u;
-  o.wordbase += nfull;
-  o.winbits  &= 31u;
-  wave_sync();
-}
-
 // lane-local MSB-first bit accumulator feeding the window (generic path: any token lengths)
 struct bit_acc { uint64_t acc; uint32_t fill, w; };
 
