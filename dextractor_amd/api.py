@@ -142,9 +142,10 @@ class Context:
                                         d_hdr_off.ptr if d_hdr_off else None, d_rec_off.ptr, d_seg.ptr,
                                         d_out.ptr))
 
-    def qv_decode(self, d_in, d_rec_off, d_hdr_off, d_seg, d_len, n, upper, d_out, d_out_off):
+    def qv_decode(self, d_in, d_rec_off, d_hdr_off, d_seg, d_len, n, upper, d_out, d_out_off, flip=False):
+        flags = (1 if upper else 0) | (2 if flip else 0)          # DX_DECODE_UPPER | DX_DECODE_FLIP
         self._chk(self.lib.dx_qv_decode(self.h, d_in.ptr, d_rec_off.ptr, d_hdr_off.ptr if d_hdr_off else None,
-                                        d_seg.ptr, d_len.ptr, n, int(upper), d_out.ptr, d_out_off.ptr))
+                                        d_seg.ptr, d_len.ptr, n, flags, d_out.ptr, d_out_off.ptr))
 
     def synth_quiva(self, seed, entry0, n, d_off, d_len, d_hdr4, d_lut, del_run, movie, d_text):
         self._chk(self.lib.dx_synth_quiva(self.h, seed & 0xFFFFFFFF, entry0, n, d_off.ptr, d_len.ptr, d_hdr4.ptr,

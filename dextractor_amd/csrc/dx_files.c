@@ -380,7 +380,8 @@ int dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper, uint8_
       TRY(dupload(&pool, x.len, x.n * 4, &d_len));
       TRY(dupload(&pool, ooff, x.n * 8, &d_ooff));
       TRY(dalloc(&pool, total, &d_out));
-      TRY(dx_qv_decode(ctx, d_in, d_rec, d_hoff, d_seg, d_len, x.n, upper, d_out, d_ooff));
+      TRY(dx_qv_decode(ctx, d_in, d_rec, d_hoff, d_seg, d_len, x.n,
+                       (upper ? DX_DECODE_UPPER : 0) | (x.flip ? DX_DECODE_FLIP : 0), d_out, d_ooff));
       TRY(dx_d2h(ctx, res, d_out, total));
       for (i = 0; i < x.n; i++)
         memcpy(res + ooff[i] - (hat[i+1] - hat[i]), hd.p + hat[i], (size_t) (hat[i+1] - hat[i]));

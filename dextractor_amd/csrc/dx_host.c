@@ -567,12 +567,13 @@ static void build_wlut(const dx_scheme *s, wlut *t)
       }
 }
 
-typedef struct { const uint8_t *p, *end; uint64_t buf; int nb; uint64_t T; } wrd;
+typedef struct { const uint8_t *p, *end; uint64_t buf; int nb; uint64_t T; int flip; } wrd;
 
 static void w_fill(wrd *r)
 { while (r->nb <= 32 && r->p + 4 <= r->end)
     { uint32_t w;
       memcpy(&w, r->p, 4);
+      if (r->flip) w = flip32(w);
       r->buf |= (uint64_t) w << (32 - r->nb);
       r->nb  += 32;
       r->p   += 4;
@@ -589,8 +590,8 @@ static uint32_t pad_words(uint64_t T, uint32_t last)    /* QV.c:436-442 */
 }
 
 /* bytes of a plain-coded segment of rlen symbols starting at p (QV.c:510-599) */
-static int64_t walk_plain(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *t, int esc)
-{ wrd r = { p, end, 0, 0, 0 };
+static int64_t walk_plain(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *t, int esc, int flip)
+{ wrd r = { p, end, 0, 0, 0, flip };
   uint32_t j, last = 0;
   int64_t bytes;
   for (j = 0; j < rlen; j++)
@@ -606,8 +607,8 @@ static int64_t walk_plain(const uint8_t *p, const uint8_t *end, uint32_t rlen, c
 
 /* run-coded segment (QV.c:604-691); *nonrun receives the number of non-run symbols */
 static int64_t walk_runs(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *nt, int esc,
-                         const wlut *rt, uint32_t *nonrun)
-{ wrd r = { p, end, 0, 0, 0 };
+                         const wlut *rt, uint32_t *nonrun, int flip)
+{ wrd r = { p, end, 0, 0, 0, flip };
   uint32_t j = 0, last = 0, nn = 0;
   int64_t bytes;
   while (j < rlen)
@@ -655,7 +656,6 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   if (x->prefix == NULL) return DX_E_NOMEM;
   rc = dx_qv_read_coding(img + at, n - at, &x->coding, &x->flip, x->prefix, 4096, &used);
   if (rc != DX_OK) goto fail;
-  if (x->flip) { rc = DX_E_UNSUPPORTED; goto fail; }      /* byte-swapped archives: SURVEY 8(f) rank 4 */
   at += used;
 
   for (s = 0; s < 6; s++)
@@ -678,12 +678,15 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
       if (x->newv)
         { if (at + 12 > n) { rc = DX_E_FORMAT; goto fail; }
           memcpy(&beg, img + at, 4); memcpy(&end_, img + at + 4, 4); memcpy(&qv, img + at + 8, 4);
+          if (x->flip)                                    /* undexqv.c:140-148 */
+            { beg = (int32_t) flip32((uint32_t) beg); end_ = (int32_t) flip32((uint32_t) end_); qv = (int32_t) flip32((uint32_t) qv); }
           at += 12;
         }
       else
         { uint16_t h[3];
           if (at + 6 > n) { rc = DX_E_FORMAT; goto fail; }
           memcpy(h, img + at, 6);
+          if (x->flip) { h[0] = flip16(h[0]); h[1] = flip16(h[1]); h[2] = flip16(h[2]); }
           beg = h[0]; end_ = h[1]; qv = h[2];
           at += 6;
         }
@@ -708,25 +711,25 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
 
       clen = rlen;                                        /* QV.c:1433-1462 */
       if (x->coding.delChar < 0)
-        b = walk_plain(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2);
+        b = walk_plain(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2, x->flip);
       else
-        b = walk_runs(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2, lut[DX_DRUN], &clen);
+        b = walk_runs(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2, lut[DX_DRUN], &clen, x->flip);
       if (b < 0) { rc = DX_E_FORMAT; goto fail; }
       sg[0] = (uint32_t) b; at += (size_t) b;
       sg[1] = (clen + 3) >> 2;
       if (at + sg[1] > n) { rc = DX_E_FORMAT; goto fail; }
       at += sg[1];
-      b = walk_plain(img + at, end, rlen, lut[DX_INS], x->coding.s[DX_INS].type == 2);   /* QV.c:1464 */
+      b = walk_plain(img + at, end, rlen, lut[DX_INS], x->coding.s[DX_INS].type == 2, x->flip);   /* QV.c:1464 */
       if (b < 0) { rc = DX_E_FORMAT; goto fail; }
       sg[2] = (uint32_t) b; at += (size_t) b;
-      b = walk_plain(img + at, end, rlen, lut[DX_MRG], x->coding.s[DX_MRG].type == 2);   /* QV.c:1467 */
+      b = walk_plain(img + at, end, rlen, lut[DX_MRG], x->coding.s[DX_MRG].type == 2, x->flip);   /* QV.c:1467 */
       if (b < 0) { rc = DX_E_FORMAT; goto fail; }
       sg[3] = (uint32_t) b; at += (size_t) b;
       if (x->coding.subChar < 0)                                                          /* QV.c:1470-1478 */
-        b = walk_plain(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2);
+        b = walk_plain(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2, x->flip);
       else
         { uint32_t nn;
-          b = walk_runs(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2, lut[DX_SRUN], &nn);
+          b = walk_runs(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2, lut[DX_SRUN], &nn, x->flip);
         }
       if (b < 0) { rc = DX_E_FORMAT; goto fail; }
       sg[4] = (uint32_t) b; at += (size_t) b;

@@ -31,14 +31,16 @@ struct dec_args
   int             delChar, subChar;
   int             type[4];      // scheme type of del/ins/mrg/sub
   int             upper;
+  int             flip;         // words were written by a host of the other endianness (GETFLIP, QV.c:553-568)
 };
 
 // MSB-first bit reader over little-endian 32-bit words; never reads past `end`
-struct bitrd { const uint8_t *p, *end; uint64_t buf; int nb; };
+struct bitrd { const uint8_t *p, *end; uint64_t buf; int nb; bool flip; };
 
 __device__ __forceinline__ void br_fill(bitrd &r)
 { while (r.nb <= 32 && r.p < r.end)
-    { r.buf |= (uint64_t) (*(const u32_u *) r.p) << (32 - r.nb);
+    { const uint32_t w = *(const u32_u *) r.p;
+      r.buf |= (uint64_t) (r.flip ? __builtin_bswap32(w) : w) << (32 - r.nb);
       r.nb  += 32;
       r.p   += 4;
     }
@@ -116,7 +118,7 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       for (int k = 0; k < line; k++)
         at += sg[k];
 
-      bitrd rd = { a.in + at, a.in + at + sg[line], 0, 0 };
+      bitrd rd = { a.in + at, a.in + at + sg[line], 0, 0, a.flip != 0 };
       bsink o  = { a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u), 0, 0 };
       const int rc = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
       const uint16_t *prim = s_dec[q];
@@ -226,7 +228,7 @@ void k_qv_decode_tags(dec_args a)
 }
 
 extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_rec_off, const uint64_t *d_hdr_off,
-                            const uint32_t *d_seg, const uint32_t *d_len, uint64_t n, int upper,
+                            const uint32_t *d_seg, const uint32_t *d_len, uint64_t n, int flags,
                             uint8_t *d_out, const uint64_t *d_out_off)
 { if (ctx == NULL) return DX_E_ARG;
   if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_decode: call dx_qv_set_coding first");
@@ -237,7 +239,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   dec_args a;
   a.in = d_in; a.rec_off = d_rec_off; a.hdr_off = d_hdr_off; a.seg = d_seg; a.len = d_len; a.n = n;
-  a.out = d_out; a.out_off = d_out_off; a.delChar = ctx->delChar; a.subChar = ctx->subChar; a.upper = upper != 0;
+  a.out = d_out; a.out_off = d_out_off; a.delChar = ctx->delChar; a.subChar = ctx->subChar; a.upper = (flags & DX_DECODE_UPPER) != 0; a.flip = (flags & DX_DECODE_FLIP) != 0;
   for (int s = 0; s < 4; s++) a.type[s] = ctx->sym_type[s];
   uint64_t blocks = (4 * n + DX_BLOCK - 1) / DX_BLOCK;
   const uint64_t cap = (uint64_t) ctx->num_cu * 8;

@@ -229,9 +229,13 @@ int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const 
  * d_hdr_off[i] framing bytes (NULL: none) followed by segments of d_seg[5*i+k] bytes -- exactly
  * the arrays dx_qv_sizes produces, or dx_qv_walk for a bare file.  The five decoded lines
  * (d_len[i] symbols each, every line followed by '\n') are written at d_out + d_out_off[i].
- * upper != 0 applies undexqv's -U (undexqv.c:198-204).  Uses the tables of dx_qv_set_coding.     */
+ * flags: DX_DECODE_UPPER applies undexqv's -U (undexqv.c:198-204); DX_DECODE_FLIP reads the code
+ * words byte-swapped (a file written on a host of the other endianness: GETFLIP, QV.c:553-568).
+ * Uses the tables of dx_qv_set_coding.                                                          */
+#define DX_DECODE_UPPER 1
+#define DX_DECODE_FLIP  2
 int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_rec_off, const uint64_t *d_hdr_off,
-                 const uint32_t *d_seg, const uint32_t *d_len, uint64_t n, int upper,
+                 const uint32_t *d_seg, const uint32_t *d_len, uint64_t n, int flags,
                  uint8_t *d_out, const uint64_t *d_out_off);
 
 /* Host walk of a bare .dexqv image (undexqv.c:101-208 and the bit-level structure of QV.c:510-691):

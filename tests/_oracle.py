@@ -153,3 +153,40 @@ def run_ref(tool, flags, src_bytes, src_ext, dst_ext, tmpdir):
         raise RuntimeError(f"{tool}: exit {r.returncode}: {r.stderr.decode()}")
     with open(os.path.join(str(tmpdir), "x" + dst_ext), "rb") as f:
         return f.read()
+
+
+def byteswap_dexqv(dx, walk):
+    """The same .dexqv as a host of the other endianness would have written it (every uint16 /
+    int32 / uint32 field and code word byte-swapped; tag bytes and well bytes unchanged).
+    `walk` = api.qv_walk(dx)."""
+    b = bytearray(dx)
+
+    def sw(at, n):
+        b[at:at + n] = b[at:at + n][::-1]
+    at = 0
+    sw(at, 2); at += 2                       # 0x55aa
+    sw(at, 2); at += 2                       # 0x33cc
+    sw(at, 2); at += 2                       # delChar
+    sw(at, 2); at += 2                       # subChar
+    plen = int.from_bytes(dx[at:at + 4], "little")
+    sw(at, 4); at += 4 + plen
+    nschemes = 4 + (walk["delChar"] >= 0) + (walk["subChar"] >= 0)
+    for _ in range(nschemes):
+        at += 1                              # type
+        for _ in range(256):
+            ln = dx[at]; at += 1
+            if ln:
+                sw(at, 4); at += 4
+    assert at == int(walk["rec_off"][0])
+    for i in range(walk["n"]):
+        r0 = int(walk["rec_off"][i]); hl = int(walk["hdr_off"][i + 1] - walk["hdr_off"][i])
+        for k in range(3):
+            sw(r0 + hl - 12 + 4 * k, 4)      # beg, end, qv
+        p = r0 + hl
+        for k in range(5):
+            n = int(walk["seg"][i][k])
+            if k != 1:
+                for w in range(0, n, 4):
+                    sw(p + w, 4)
+            p += n
+    return bytes(b)

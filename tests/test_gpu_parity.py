@@ -358,3 +358,32 @@ def test_dexqv_run_longer_than_16_bits(ctx):
     b2 = synth.qv_lines(9, 1, 3000, prof)
     txt = _quiva([(4, [b[r].tobytes() for r in range(5)]), (9, [b2[r].tobytes() for r in range(5)])])
     assert ctx.dexqv(txt) == O.dexqv(txt)
+
+
+@pytest.mark.parametrize("name", ["qv_full", "qv_type2", "qv_runs", "qv_nodel"])
+def test_undexqv_byteswapped_file(ctx, name):
+    """GETFLIP path (QV.c:553-568): a .dexqv written on a host of the other endianness."""
+    dx = O.golden(name + ".dexqv")
+    fl = O.byteswap_dexqv(dx, api.qv_walk(dx))
+    assert ctx.undexqv(fl, upper=True) == ctx.undexqv(dx, upper=True) == O.undexqv(fl, upper=True)
+
+
+def test_undexta_legacy_and_byteswapped_keys(ctx):
+    """undexta accepts 0x33cc (uint16 fields) and byte-swapped files (undexta.c:140-159, 211-240)."""
+    import struct
+    name = b">mv"
+    recs = [(5, 0, 7, 851, b"\x1b\x18"), (300, 3, 5, 7, b"\xb0")]      # ACGTACG, GT
+    def build(key, flip, newv):
+        e = ">" if flip else "<"
+        out = struct.pack(e + "H", key) + struct.pack(e + "i", len(name)) + name
+        last = 0
+        for well, beg, end, qv, body in recs:
+            d = well - last
+            out += b"\xff" * (d // 255) + bytes([d % 255]); last = well
+            out += struct.pack(e + ("iii" if newv else "HHH"), beg, end, qv) + body
+        return out
+    imgs = [build(0x55aa, False, True), build(0x55aa, True, True), build(0x33cc, False, False), build(0x33cc, True, False)]
+    want = b">mv/5/0_7 RQ=0.851\nacgtacg\n>mv/300/3_5 RQ=0.7\ngt\n"
+    for img in imgs:
+        assert O.undexta(img) == want
+        assert ctx.undexta(img) == want

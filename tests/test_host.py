@@ -198,3 +198,14 @@ def test_walk_rejects_garbage():
     dx = O.golden("qv_tiny.dexqv")
     with pytest.raises(L.DexGPUError):
         api.qv_walk(dx[:-7])
+
+
+def test_walk_byteswapped_file():
+    """A file written on a host of the other endianness (keys 0xaa55 / 0xcc33): same index."""
+    dx = O.golden("qv_full.dexqv")
+    w = api.qv_walk(dx)
+    fl = O.byteswap_dexqv(dx, w)
+    assert O.undexqv(fl, upper=True) == O.undexqv(dx, upper=True)      # the oracle's flip path agrees
+    w2 = api.qv_walk(fl)
+    assert w2["flip"] == 1 and w2["n"] == w["n"]
+    assert (w2["seg"] == w["seg"]).all() and (w2["hdr4"] == w["hdr4"]).all() and (w2["rec_off"] == w["rec_off"]).all()
