@@ -652,9 +652,9 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   if (n < 2) return DX_E_FORMAT;
   memcpy(&key, img, 2);                                   /* undexqv.c:103-110 */
   if (key == 0x55aa || key == 0xaa55) { x->newv = 1; at = 2; }
-  x->prefix = malloc(n < 4096 ? 4096 : 4096);
+  x->prefix = malloc(n + 1);                              /* the prefix cannot be longer than the image */
   if (x->prefix == NULL) return DX_E_NOMEM;
-  rc = dx_qv_read_coding(img + at, n - at, &x->coding, &x->flip, x->prefix, 4096, &used);
+  rc = dx_qv_read_coding(img + at, n - at, &x->coding, &x->flip, x->prefix, n + 1, &used);
   if (rc != DX_OK) goto fail;
   at += used;
 

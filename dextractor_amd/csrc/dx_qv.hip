@@ -864,9 +864,6 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
       #pragma unroll 1
       for (int q = 0; q < 4; q++)
         {
-#ifdef ABL_SKIP_Q
-          if ((ABL_SKIP_Q >> q) & 1) { dst += sg[q ? q + 1 : 0] + (q == 0 ? sg[1] : 0); continue; }
-#endif
           const int       line = q ? q + 1 : 0;
           const uint8_t  *p    = line_ptr(a, r, L, line);
           const int       rci  = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
