@@ -387,3 +387,43 @@ def test_undexta_legacy_and_byteswapped_keys(ctx):
     for img in imgs:
         assert O.undexta(img) == want
         assert ctx.undexta(img) == want
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_encode_concatenates_to_whole_file(ctx, world):
+    """One .quiva cut into contiguous entry ranges ("ranks"), each shard scanned and encoded on its own
+    with the host-summed histograms / merged scan state: shard streams concatenate to the whole file."""
+    from dextractor_amd import shard
+    c = synth.make_quiva(37, seed=61, mean=8000)
+    want = ctx.dexqv(c.text)
+    assert want == O.dexqv(c.text)
+    n = len(c.len)
+    text = np.frombuffer(c.text, np.uint8)
+    d_text = ctx.to_device(text)
+    parts, params, hists, tots = [], [], [], []
+    for r in range(world):                                   # pass 1 per shard
+        lo, hi = shard.entry_range(n, r, world)
+        b = ctx.qv_batch(d_text, ctx.to_device(c.off[lo:hi]), ctx.to_device(c.len[lo:hi]), hi - lo, text_bytes=len(c.text))
+        p = ctx.qv_prescan(b, entry0=lo)
+        params.append((p.delChar, p.del_first, p.subChar, p.sub_first))
+        parts.append((lo, hi, b))
+    dC, dF, sC, sF = shard.merge_params(params)
+    gp = L.QVParams(dC, sC, dF, sF)
+    for lo, hi, b in parts:
+        h, t = ctx.qv_hist(b, gp, entry0=lo)
+        hists.append(h); tots.append(t)
+    hist, tot = shard.merge_hist(hists, tots)
+    coding = api.qv_build(hist, tot, gp)
+    ctx.qv_set_coding(coding)
+    streams = []
+    for lo, hi, b in parts:                                  # pass 2 per shard
+        m = hi - lo
+        blob, hoff, _ = api.frame_headers(c.hdr[lo:hi], None, shard.previous_well(c.hdr, lo))
+        d_hdr, d_hoff = ctx.to_device(blob), ctx.to_device(hoff)
+        d_rec, d_seg = ctx.alloc(8 * (m + 1)), ctx.alloc(20 * m)
+        total = ctx.qv_sizes(b, d_hoff, d_seg, d_rec)
+        d_out = ctx.alloc(total)
+        ctx.qv_encode(b, d_hdr, d_hoff, d_rec, d_seg, d_out)
+        streams.append(d_out.download(np.uint8, total).tobytes())
+    head = b"\xaa\x55" + api.qv_write_coding(coding, c.text[: c.text.index(b"/", 1)])
+    assert shard.concat(head, streams) == want
