@@ -12,7 +12,7 @@ EXTRA   ?=
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(EXTRA)
 CFLAGS   = -O2 -fPIC -Iinclude -Wall -Wextra
 
-HIP_SRC  = dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth
+HIP_SRC  = dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth dx_index
 HIP_OBJ  = $(HIP_SRC:%=$(BUILD)/%.o)
 C_OBJ    = $(BUILD)/dx_host.o $(BUILD)/dx_files.o
 TOOLS    = dexta undexta dexar undexar dexqv undexqv

@@ -177,6 +177,20 @@ def main():
             roundtrip = ok
         del d_back
 
+    # GPU text front end on the same resident image (untimed extra): newline scan -> entry index
+    front = None
+    if not args.no_verify:
+        torch.cuda.synchronize()
+        ctx.profile(True)
+        t1 = time.perf_counter()
+        o2, l2, h2, pl2 = ctx.index_quiva_device(p_text, text_bytes)
+        t2 = time.perf_counter()
+        kt = ctx.kernel_times().get("k_index", (0.0, 0))
+        ctx.profile(False)
+        front = {"entries": int(len(l2)), "wall_ms": round((t2 - t1) * 1e3, 2), "kernel_ms": round(kt[0], 3),
+                 "text_GBps_kernels": round(text_bytes / (kt[0] * 1e-3) / 1e9, 1) if kt[0] else None,
+                 "index_identical": bool((o2 == off).all() and (l2 == lens).all() and (h2 == hdr4).all())}
+
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -239,6 +253,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "roundtrip_bit_exact": roundtrip,
+        "text_front_end": front,
         "pipeline": pipe,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                     for k, v in kern.items()},

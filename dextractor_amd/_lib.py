@@ -19,7 +19,7 @@ DX_ALPHA_BASES, DX_ALPHA_ARROW = 0, 1
 DX_LETTERS_LOWER, DX_LETTERS_UPPER, DX_LETTERS_ARROW = 0, 1, 2
 DX_DEL, DX_INS, DX_MRG, DX_SUB, DX_DRUN, DX_SRUN = range(6)
 KERNELS = ["k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
-           "k_qv_encode", "k_qv_decode", "k_synth"]
+           "k_qv_encode", "k_qv_decode", "k_synth", "k_index"]
 
 
 class QVBatch(C.Structure):
@@ -76,6 +76,9 @@ SIGNATURES = {
     "dx_index_seq": (C.c_int, [C.c_int, _P, C.c_size_t, C.c_uint64, _P, _P, _P, _P, _P,
                                C.POINTER(C.c_uint64), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64),
                                C.POINTER(C.c_int)]),
+    "dx_index_quiva_device": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint64),
+                                        C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "dx_parse_quiva_headers": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "dx_qv_prescan": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams)]),
     "dx_qv_hist": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams), C.POINTER(HIST),
                              C.POINTER(C.c_uint64)]),

@@ -147,6 +147,29 @@ class Context:
         self._chk(self.lib.dx_qv_decode(self.h, d_in.ptr, d_rec_off.ptr, d_hdr_off.ptr if d_hdr_off else None,
                                         d_seg.ptr, d_len.ptr, n, flags, d_out.ptr, d_out_off.ptr))
 
+    def index_quiva_device(self, d_text, nbytes):
+        """GPU text front end -> (off uint64, len uint32, hdr4 int32 [n,4], prefix_len); raises
+        DexGPUError(DX_E_FORMAT) with .line / .idx_code on a malformed image."""
+        d_off, d_len, hdr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cnt, pl, line, code = C.c_uint64(), C.c_size_t(), C.c_uint64(), C.c_int()
+        rc = self.lib.dx_index_quiva_device(self.h, d_text.ptr, nbytes, C.byref(d_off), C.byref(d_len), C.byref(cnt),
+                                            C.byref(hdr), C.byref(pl), C.byref(line), C.byref(code))
+        if rc != 0:
+            e = L.DexGPUError(rc, f"line {line.value}: DX_IDX code {code.value}")
+            e.line, e.idx_code = line.value, code.value
+            raise e
+        n = cnt.value
+        off, ln = np.empty(n, np.uint64), np.empty(n, np.uint32)
+        if n:
+            self._chk(self.lib.dx_d2h(self.h, off.ctypes.data, d_off, n * 8))
+            self._chk(self.lib.dx_d2h(self.h, ln.ctypes.data, d_len, n * 4))
+            h4 = np.ctypeslib.as_array(C.cast(hdr, C.POINTER(C.c_int32)), (n, 4)).copy()
+            self.lib.dx_free(self.h, d_off); self.lib.dx_free(self.h, d_len)
+            C.CDLL(None).free(hdr)
+        else:
+            h4 = np.empty((0, 4), np.int32)
+        return off, ln, h4, pl.value
+
     def synth_quiva(self, seed, entry0, n, d_off, d_len, d_hdr4, d_lut, del_run, movie, d_text):
         self._chk(self.lib.dx_synth_quiva(self.h, seed & 0xFFFFFFFF, entry0, n, d_off.ptr, d_len.ptr, d_hdr4.ptr,
                                           d_lut.ptr, del_run, movie.encode(), d_text.ptr))

@@ -24,6 +24,8 @@ void dx_file_free(void *p) { free(p); }
 
 #define TRY(x) do { rc = (x); if (rc != DX_OK) goto done; } while (0)
 
+#define DX_GPU_INDEX_MIN (1u << 20)      /* .quiva images from 1 MiB on are indexed on the GPU */
+
 typedef struct { void *p[16]; int n; dx_ctx *ctx; } dpool;
 
 static int dalloc(dpool *pool, size_t bytes, void **out)
@@ -272,34 +274,55 @@ int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
   dx_qv_params p = { -1, -1, -1, -1 };
   dx_qv_coding *cd = NULL;
   uint64_t   (*hist)[256] = NULL;
-  void        *d_text, *d_off, *d_len, *d_hdr, *d_hoff, *d_rec, *d_seg, *d_out;
+  void        *d_text, *d_off = NULL, *d_len = NULL, *d_hdr, *d_hoff, *d_rec, *d_seg, *d_out;
   int          rc;
 
   if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
   *out = NULL; *out_len = 0;
 
-  /* pass 1 of the reference (QVcoding_Scan, dexqv.c:81-82): validate + index on the host ... */
-  TRY(dx_index_quiva(text, n, 0, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
-  off  = malloc((cnt + 1) * sizeof(*off));
-  hoff = malloc((cnt + 1) * sizeof(*hoff));
-  len  = malloc((cnt + 1) * sizeof(*len));
-  hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+  /* pass 1 of the reference (QVcoding_Scan, dexqv.c:81-82): validate + index.  Large images are
+   * indexed on the GPU (newline scan + structure checks there, only the header lines come back);
+   * small ones, and any image the GPU front end rejects (so that the message is exactly the
+   * reference's first one), by the host indexer.                                               */
   cd   = malloc(sizeof(*cd));
   hist = calloc(6, sizeof(*hist));
-  if (!off || !hoff || !len || !hdr4 || !cd || !hist) { rc = DX_E_NOMEM; goto done; }
-  TRY(dx_index_quiva(text, n, cnt, off, len, hdr4, &cnt, &plen, errline, errcode));
+  if (!cd || !hist) { rc = DX_E_NOMEM; goto done; }
+  TRY(dupload(&pool, text, n, &d_text));
+  if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL)
+    { uint64_t *go = NULL; uint32_t *gl = NULL;
+      rc = dx_index_quiva_device(ctx, d_text, n, &go, &gl, &cnt, &hdr4, &plen, errline, errcode);
+      if (rc == DX_OK && cnt > 0)
+        { d_off = go; d_len = gl;
+          pool.p[pool.n++] = go; pool.p[pool.n++] = gl;
+        }
+      else if (rc != DX_OK && rc != DX_E_FORMAT)
+        goto done;
+      rc = DX_OK;
+    }
+  if (d_off == NULL)
+    { TRY(dx_index_quiva(text, n, 0, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
+      off  = malloc((cnt + 1) * sizeof(*off));
+      len  = malloc((cnt + 1) * sizeof(*len));
+      free(hdr4);
+      hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+      if (!off || !len || !hdr4) { rc = DX_E_NOMEM; goto done; }
+      TRY(dx_index_quiva(text, n, cnt, off, len, hdr4, &cnt, &plen, errline, errcode));
+      if (cnt > 0)
+        { TRY(dupload(&pool, off, cnt * 8, &d_off));
+          TRY(dupload(&pool, len, cnt * 4, &d_len));
+        }
+    }
   if (cnt == 0)
     { rc = DX_E_DEGENERATE;     /* empty file: the reference dereferences a NULL header (dexqv.c:94) */
       goto done;
     }
+  hoff = malloc((cnt + 1) * sizeof(*hoff));
+  if (!hoff) { rc = DX_E_NOMEM; goto done; }
 
   blob = malloc(dx_frame_bound(hdr4, cnt, 0, 0) + 16);
   if (!blob) { rc = DX_E_NOMEM; goto done; }
   TRY(dx_frame_headers(hdr4, NULL, cnt, 0, &lwell, blob, hoff));
 
-  TRY(dupload(&pool, text, n, &d_text));
-  TRY(dupload(&pool, off, cnt * 8, &d_off));
-  TRY(dupload(&pool, len, cnt * 4, &d_len));
   TRY(dupload(&pool, blob, (size_t) hoff[cnt], &d_hdr));
   TRY(dupload(&pool, hoff, (cnt + 1) * 8, &d_hoff));
   TRY(dalloc(&pool, (cnt + 1) * 8, &d_rec));

@@ -749,3 +749,23 @@ fail:
   dx_qv_index_free(x);
   return rc;
 }
+
+/* Header lines gathered by the GPU text front end (dx_index_quiva_device): blob holds line i at
+ * [pos[i], pos[i+1]) including its newline.  The same checks as dx_index_quiva / QV.c:958-968. */
+int dx_parse_quiva_headers(const uint8_t *blob, const uint64_t *pos, uint64_t n, int32_t *hdr4,
+                           size_t *prefix_len, uint64_t *bad_entry)
+{ uint64_t i;
+  for (i = 0; i < n; i++)
+    { const uint8_t *h = blob + pos[i], *slash;
+      size_t hl = (size_t) (pos[i+1] - pos[i]) - 1;
+      int32_t f[4];
+      slash = hl > 1 ? memchr(h + 1, '/', hl - 1) : NULL;
+      if (slash == NULL || scan_tail(slash + 1, hl - (size_t) (slash + 1 - h), "%d/%d_%d RQ=0.%d\n", f, NULL) != 4)
+        { if (bad_entry) *bad_entry = i;
+          return DX_E_FORMAT;
+        }
+      memcpy(hdr4 + 4*i, f, sizeof(f));
+      if (i == 0 && prefix_len) *prefix_len = (size_t) (slash - h);
+    }
+  return DX_OK;
+}

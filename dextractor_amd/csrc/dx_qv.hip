@@ -1072,6 +1072,31 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
   return DX_OK;
 }
 
+// exclusive scan of n uint32 values into n+1 uint64 offsets (d_out[n] = total)
+int dx_scan_u32(dx_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *total)
+{ if (n == 0)
+    { uint64_t z = 0;
+      DX_HIP(ctx, hipMemcpyAsync(d_out, &z, 8, hipMemcpyHostToDevice, ctx->stream));
+      DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (total) *total = 0;
+      return DX_OK;
+    }
+  const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  uint64_t *d_tile;
+  DX_HIP(ctx, hipMalloc((void **) &d_tile, (ntiles + 2) * 8));
+  uint64_t *d_gran = d_tile + ntiles;
+  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) ntiles, DX_BLOCK, d_in, n, d_tile);
+  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, ntiles, d_gran);
+  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, d_in, n, (const uint64_t *) d_tile, d_out,
+            (const uint64_t *) d_gran);
+  uint64_t t = 0;
+  DX_HIP(ctx, hipMemcpyAsync(&t, d_gran, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  DX_HIP(ctx, hipFree(d_tile));
+  if (total) *total = t;
+  return DX_OK;
+}
+
 extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_hdr_off,
                            uint32_t *d_seg, uint64_t *d_rec_off, uint64_t *total)
 { int e = check_batch(ctx, b, "dx_qv_sizes");

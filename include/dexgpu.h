@@ -61,7 +61,7 @@ int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes);
 /* Per-kernel device time, measured with HIP events on the context's stream around every launch
  * while profiling is enabled.  Kernel ids: */
 enum { DX_K_PACK2_ENC = 0, DX_K_PACK2_DEC, DX_K_QV_PRESCAN, DX_K_QV_HIST, DX_K_QV_SIZES, DX_K_SCAN,
-       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_COUNT };
+       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_INDEX, DX_K_COUNT };
 int         dx_profile(dx_ctx *ctx, int enable);                  /* enabling resets the counters */
 int         dx_profile_get(dx_ctx *ctx, int kernel, double *ms_total, uint64_t *launches);  /* syncs */
 const char *dx_kernel_name(int kernel);
@@ -137,6 +137,18 @@ int dx_index_quiva(const uint8_t *text, size_t n, uint64_t cap,
 int dx_index_seq(int arrow, const uint8_t *text, size_t n, uint64_t cap,
                  uint64_t *off, uint32_t *tlen, uint32_t *nsym, int32_t *hdr4, uint16_t *cnr4,
                  uint64_t *count, size_t *prefix_len, uint64_t *errline, int *errcode);
+
+/* GPU text front end for a .quiva image already in device memory: newline scan, structure checks
+ * and entry index on the device; only the header lines come back to the host, where sscanf parses
+ * them as QV.c:964 does.  Same results as dx_index_quiva.  *d_off / *d_len are device arrays
+ * (release with dx_free), *hdr4 a host array (free()).  On DX_E_FORMAT *errline / *errcode name an
+ * offending line; callers that need the reference's exact first message re-run dx_index_quiva
+ * on the host copy (the error path is not performance relevant).                               */
+int dx_index_quiva_device(dx_ctx *ctx, const uint8_t *d_text, uint64_t nbytes,
+                          uint64_t **d_off, uint32_t **d_len, uint64_t *count,
+                          int32_t **hdr4, size_t *prefix_len, uint64_t *errline, int *errcode);
+int dx_parse_quiva_headers(const uint8_t *blob, const uint64_t *pos, uint64_t n, int32_t *hdr4,
+                           size_t *prefix_len, uint64_t *bad_entry);
 
 /* ------------------------------------------------------------------------------------------
  *  5-stream QV coder: dexqv/undexqv (QV.c)

@@ -427,3 +427,53 @@ def test_sharded_encode_concatenates_to_whole_file(ctx, world):
         streams.append(d_out.download(np.uint8, total).tobytes())
     head = b"\xaa\x55" + api.qv_write_coding(coding, c.text[: c.text.index(b"/", 1)])
     assert shard.concat(head, streams) == want
+
+
+# ---- GPU text front end ------------------------------------------------------------------------
+
+@pytest.mark.parametrize("src", ["qv_tiny", "qv_full", "qv_runs", "synth"])
+def test_gpu_index_matches_host_index(ctx, src):
+    txt = synth.make_quiva(300, seed=12, mean=2500).text if src == "synth" else O.golden(src + ".quiva")
+    d = ctx.to_device(np.frombuffer(txt, np.uint8))
+    off, ln, hdr, pl = ctx.index_quiva_device(d, len(txt))
+    off2, ln2, hdr2, pl2 = api.index_quiva(txt)
+    assert (off == off2).all() and (ln == ln2).all() and (hdr == hdr2).all() and pl == pl2
+
+
+@pytest.mark.parametrize("bad", [
+    b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc",                 # no final newline
+    b"m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n",                # header missing
+    b"@m 1 0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n",               # no slash
+    b"@m/1/0_3\nabc\nabc\nabc\nabc\nabc\n",                      # RQ field required
+    b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\n",                         # incomplete entry
+    b"@m/1/0_3 RQ=0.8\nabc\nabc\nab\nabc\nabc\n",                # ragged
+    b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n\n",             # blank header line
+    b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n@m/2/0_1 RQ=0.8\na\nb\n",
+])
+def test_gpu_index_rejects_like_host(ctx, bad):
+    """Every image the host indexer rejects is rejected by the GPU front end too (the drivers then
+    re-run the host indexer for the reference's exact first message)."""
+    lib = L.load()
+    cnt, pl, line, ec = C.c_uint64(), C.c_size_t(), C.c_uint64(), C.c_int()
+    assert lib.dx_index_quiva(bad, len(bad), 0, None, None, None, C.byref(cnt), C.byref(pl), C.byref(line), C.byref(ec)) == -3
+    d = ctx.to_device(np.frombuffer(bad, np.uint8))
+    with pytest.raises(L.DexGPUError) as e:
+        ctx.index_quiva_device(d, len(bad))
+    assert e.value.code == -3
+    assert (e.value.line, e.value.idx_code) == (line.value, ec.value)
+
+
+def test_dexqv_large_file_uses_gpu_index_and_still_matches(ctx, monkeypatch):
+    c = synth.make_quiva(120, seed=17, mean=9000)                  # > 1 MiB: GPU-indexed in dx_file_dexqv
+    assert len(c.text) > (1 << 20)
+    a = ctx.dexqv(c.text)
+    monkeypatch.setenv("DEXGPU_HOST_INDEX", "1")
+    b = ctx.dexqv(c.text)
+    assert a == b == O.dexqv(c.text)
+    bad = c.text[:-5]                                              # truncated last line: same error either way
+    with pytest.raises(L.DexGPUError) as e1:
+        ctx.dexqv(bad)
+    monkeypatch.delenv("DEXGPU_HOST_INDEX")
+    with pytest.raises(L.DexGPUError) as e2:
+        ctx.dexqv(bad)
+    assert str(e1.value) == str(e2.value)
