@@ -30,7 +30,7 @@ $(BUILD)/%.o: $(CSRC)/%.c include/dexgpu.h
 	$(CC) $(CFLAGS) -c $< -o $@
 
 $(LIB): $(HIP_OBJ) $(C_OBJ)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -Wl,-rpath,/opt/rocm/lib -Wl,-soname,libdexgpu.so
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -Wl,-rpath,/opt/rocm/lib -Wl,-soname,libdexgpu.so -lpthread
 
 cli: $(LIB) $(TOOLS:%=dextractor_amd/bin/%)
 

@@ -98,6 +98,8 @@ SIGNATURES = {
     "dx_file_unpack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "dx_file_dexqv": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t),
                                 C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "dx_file_dexqv_sharded": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dx_file_undexqv": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "dx_file_free": (None, [_P]),
     "dx_synth_quiva": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.c_uint64, _P, _P, _P, _P, C.c_int,

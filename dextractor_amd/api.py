@@ -210,6 +210,21 @@ class Context:
         return self._file_call(self.lib.dx_file_undexqv, img, len(img), int(upper))
 
 
+def dexqv_sharded(contexts, quiva: bytes, lossy=False) -> bytes:
+    """One .quiva file over several contexts/GPUs (dx_file_dexqv_sharded)."""
+    lib = contexts[0].lib
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    out, n, line, code = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_int()
+    rc = lib.dx_file_dexqv_sharded(arr, len(contexts), quiva, len(quiva), int(lossy), C.byref(out), C.byref(n),
+                                   C.byref(line), C.byref(code))
+    if rc != 0:
+        raise L.DexGPUError(rc, f"line {line.value} (DX_IDX code {code.value})")
+    try:
+        return C.string_at(out.value, n.value)
+    finally:
+        lib.dx_file_free(out)
+
+
 # ---- host-only helpers (no GPU needed) ---------------------------------------------------------
 
 def qv_build(hist, tot, params, lossy=False) -> L.QVCoding:

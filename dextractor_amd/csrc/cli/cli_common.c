@@ -119,10 +119,16 @@ static void report_text_error(int tool, uint64_t line, int code)
 
 /* ---- one file --------------------------------------------------------------------------------- */
 
+static dx_ctx *Ctxs[64];     /* DEXGPU_DEVICES: one context per listed GPU; a file's entries are sharded over them */
+static int     Nctx = 0;
+
 static int convert(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, int opt_U, int opt_l, int width,
                    uint8_t **out, size_t *out_len)
 { uint64_t line = 0;
   int      code = 0, rc;
+  if (tool == TOOL_DEXQV && Nctx > 1)
+    rc = dx_file_dexqv_sharded(Ctxs, Nctx, in, n, opt_l, out, out_len, &line, &code);
+  else
   switch (tool)
     { case TOOL_DEXTA:   rc = dx_file_pack2(ctx, 0, in, n, out, out_len, &line, &code); break;
       case TOOL_DEXAR:   rc = dx_file_pack2(ctx, 1, in, n, out, out_len, &line, &code); break;
@@ -213,8 +219,30 @@ int dex_tool_main(int tool, int argc, char *argv[])
       exit(1);
     }
 
-  { const char *dev = getenv("DEXGPU_DEVICE");
-    if (dx_open(dev ? atoi(dev) : 0, &ctx) != DX_OK)
+  { const char *dev = getenv("DEXGPU_DEVICE"), *devs = getenv("DEXGPU_DEVICES");
+    if (devs != NULL && *devs != '\0')              /* "all" or a comma list, e.g. 0,1,2,3 */
+      { if (strcmp(devs, "all") == 0)
+          { int nd = dx_device_count();
+            for (k = 0; k < nd && k < 64; k++)
+              if (dx_open(k, &Ctxs[Nctx]) == DX_OK) Nctx += 1;
+          }
+        else
+          { const char *q = devs;
+            while (*q != '\0' && Nctx < 64)
+              { char *e;
+                long  d = strtol(q, &e, 10);
+                if (e == q) break;
+                if (dx_open((int) d, &Ctxs[Nctx]) != DX_OK)
+                  { fprintf(stderr, "%s: cannot open GPU %ld: %s\n", Prog, d, dx_last_error(NULL));
+                    exit(1);
+                  }
+                Nctx += 1;
+                q = (*e == ',') ? e + 1 : e;
+              }
+          }
+        if (Nctx > 0) ctx = Ctxs[0];
+      }
+    if (ctx == NULL && dx_open(dev ? atoi(dev) : 0, &ctx) != DX_OK)
       { fprintf(stderr, "%s: cannot open a GPU: %s\n", Prog, dx_last_error(NULL));
         exit(1);
       }
@@ -283,6 +311,9 @@ int dex_tool_main(int tool, int argc, char *argv[])
         }
     }
 
-  dx_close(ctx);
+  if (Nctx > 0)
+    for (k = 0; k < Nctx; k++) dx_close(Ctxs[k]);
+  else
+    dx_close(ctx);
   exit(0);
 }

@@ -418,3 +418,237 @@ done:
   free(ooff); free(hat); free(hd.p); free(res);
   return rc;
 }
+
+/* ==========================================================================================
+ *  dexqv of one file on several GPUs: contiguous entry ranges, one host thread
+ *  per context; the only exchange is on the host -- the merged scan state (32 bytes) and the sum
+ *  of the 12 KB histograms -- after which every shard is encoded with identical tables and the
+ *  record streams are concatenated in order.  No RCCL.
+ * ========================================================================================== */
+#include <pthread.h>
+
+typedef struct shard_job shard_job;
+
+typedef struct
+  { int               nsh, lossy, rc;
+    pthread_barrier_t bar;
+    const uint8_t    *text;
+    const uint64_t   *off;
+    const uint32_t   *len;
+    const int32_t    *hdr4;
+    uint64_t          cnt, cut;              /* cut: entry at which the running symbol count reaches 100000 */
+    dx_qv_params      p;
+    dx_qv_coding      cd;
+    uint64_t          hist[6][256], tot;
+    uint8_t          *img;
+    size_t            head, total;
+    shard_job        *jobs;
+  } shard_all;
+
+struct shard_job
+  { shard_all   *all;
+    dx_ctx      *ctx;
+    int          id, rc;
+    uint64_t     lo, hi;                      /* entries [lo, hi) */
+    dx_qv_params p;
+    uint64_t     hist[6][256], tot, bytes, at;
+  };
+
+static int all_ok(shard_all *a)
+{ int k;
+  for (k = 0; k < a->nsh; k++)
+    if (a->jobs[k].rc != DX_OK) return 0;
+  return a->rc == DX_OK;
+}
+
+static void *shard_main(void *arg)
+{ shard_job  *j = arg;
+  shard_all  *a = j->all;
+  dpool       pool = { {0}, 0, j->ctx };
+  uint64_t    m = j->hi - j->lo, i, *roff = NULL, *hoff = NULL, base = 0, span = 0, total = 0;
+  uint8_t    *blob = NULL;
+  void       *d_text = NULL, *d_off = NULL, *d_len = NULL, *d_hdr = NULL, *d_hoff = NULL, *d_rec = NULL, *d_seg = NULL, *d_out = NULL;
+  dx_qv_batch b;
+  int         rc = DX_OK, k;
+
+  memset(&b, 0, sizeof(b));
+  j->p.delChar = j->p.subChar = -1; j->p.del_first = j->p.sub_first = -1;
+  memset(j->hist, 0, sizeof(j->hist)); j->tot = 0; j->bytes = 0;
+
+  if (m > 0)                                             /* this shard's slice of the text image */
+    { int32_t lwell = j->lo ? a->hdr4[4*(j->lo-1)] : 0;
+      base = a->off[j->lo];
+      span = a->off[j->hi-1] + 5 * ((uint64_t) a->len[j->hi-1] + 1) - base;
+      roff = malloc(m * sizeof(*roff));
+      hoff = malloc((m + 1) * sizeof(*hoff));
+      blob = malloc(dx_frame_bound(a->hdr4 + 4*j->lo, m, lwell, 0) + 16);
+      if (!roff || !hoff || !blob) rc = DX_E_NOMEM;
+      for (i = 0; rc == DX_OK && i < m; i++) roff[i] = a->off[j->lo + i] - base;
+      if (rc == DX_OK) rc = dx_frame_headers(a->hdr4 + 4*j->lo, NULL, m, 0, &lwell, blob, hoff);
+      if (rc == DX_OK) rc = dupload(&pool, a->text + base, span, &d_text);
+      if (rc == DX_OK) rc = dupload(&pool, roff, m * 8, &d_off);
+      if (rc == DX_OK) rc = dupload(&pool, a->len + j->lo, m * 4, &d_len);
+      if (rc == DX_OK) rc = dupload(&pool, blob, (size_t) hoff[m], &d_hdr);
+      if (rc == DX_OK) rc = dupload(&pool, hoff, (m + 1) * 8, &d_hoff);
+      if (rc == DX_OK) rc = dalloc(&pool, (m + 1) * 8, &d_rec);
+      if (rc == DX_OK) rc = dalloc(&pool, m * 20, &d_seg);
+      b.d_text = d_text; b.d_off = d_off; b.d_len = d_len; b.n = m; b.line_pad = 1; b.text_bytes = span;
+      if (rc == DX_OK) rc = dx_qv_prescan(j->ctx, &b, j->lo, &j->p);       /* QV.c:993-1015, per shard */
+    }
+  if (rc == DX_OK && j->id == 0 && a->cut >= j->hi)
+    { /* the file's first 100000 symbols (QV.c:1006-1015) reach beyond shard 0: find the provisional
+         subChar on a prefix batch of entries [0, cut] instead */
+      uint64_t     mp = a->cut + 1, sp = a->off[a->cut] + 5 * ((uint64_t) a->len[a->cut] + 1) - a->off[0];
+      uint64_t    *po = malloc(mp * sizeof(*po));
+      void        *pt = NULL, *pd_off = NULL, *pd_len = NULL;
+      dx_qv_batch  pb;
+      dx_qv_params pp = { 0, -1, 0, -1 };                 /* delChar "set": only the sub search runs */
+      if (po == NULL) rc = DX_E_NOMEM;
+      for (i = 0; rc == DX_OK && i < mp; i++) po[i] = a->off[i] - a->off[0];
+      if (rc == DX_OK) rc = dupload(&pool, a->text + a->off[0], sp, &pt);
+      if (rc == DX_OK) rc = dupload(&pool, po, mp * 8, &pd_off);
+      if (rc == DX_OK) rc = dupload(&pool, a->len, mp * 4, &pd_len);
+      pb.d_text = pt; pb.d_off = pd_off; pb.d_len = pd_len; pb.n = mp; pb.line_pad = 1; pb.text_bytes = sp;
+      if (rc == DX_OK) rc = dx_qv_prescan(j->ctx, &pb, 0, &pp);
+      j->p.subChar = pp.subChar; j->p.sub_first = pp.sub_first;
+      free(po);
+    }
+  j->rc = rc;
+  pthread_barrier_wait(&a->bar);
+
+  if (j->id == 0 && all_ok(a))                           /* merge the scan state (lowest entry wins) */
+    { a->p.delChar = a->p.subChar = -1; a->p.del_first = a->p.sub_first = -1;
+      for (k = 0; k < a->nsh; k++)
+        if (a->jobs[k].p.delChar >= 0 && (a->p.delChar < 0 || a->jobs[k].p.del_first < a->p.del_first))
+          { a->p.delChar = a->jobs[k].p.delChar; a->p.del_first = a->jobs[k].p.del_first; }
+      for (k = 0; k < a->nsh; k++)
+        if (a->jobs[k].lo == 0 && a->jobs[k].hi > 0)
+          { a->p.subChar = a->jobs[k].p.subChar; a->p.sub_first = a->jobs[k].p.sub_first; }
+    }
+  pthread_barrier_wait(&a->bar);
+
+  if (all_ok(a) && m > 0)
+    j->rc = dx_qv_hist(j->ctx, &b, j->lo, &a->p, j->hist, &j->tot);        /* QV.c:988-1017, per shard */
+  pthread_barrier_wait(&a->bar);
+
+  if (j->id == 0 && all_ok(a))                           /* host-side sum + Create_QVcoding */
+    { int s, x;
+      memset(a->hist, 0, sizeof(a->hist)); a->tot = 0;
+      for (k = 0; k < a->nsh; k++)
+        { for (s = 0; s < 6; s++)
+            for (x = 0; x < 256; x++)
+              a->hist[s][x] += a->jobs[k].hist[s][x];
+          a->tot += a->jobs[k].tot;
+        }
+      a->rc = dx_qv_build((const uint64_t (*)[256]) a->hist, a->tot, &a->p, a->lossy, &a->cd);
+    }
+  pthread_barrier_wait(&a->bar);
+
+  if (all_ok(a) && m > 0)
+    { rc = dx_qv_set_coding(j->ctx, &a->cd, a->lossy);
+      if (rc == DX_OK) rc = dx_qv_sizes(j->ctx, &b, d_hoff, d_seg, d_rec, &total);
+      j->bytes = total;
+      j->rc = rc;
+    }
+  pthread_barrier_wait(&a->bar);
+
+  if (j->id == 0 && all_ok(a))                           /* layout of the final image */
+    { size_t clen = 0, plen = 0;
+      const uint8_t *h = a->text, *slash = memchr(h + 1, '/', (size_t) (a->off[0] - 1));
+      plen = slash ? (size_t) (slash - h) : 0;
+      dx_qv_write_coding(&a->cd, (const char *) a->text, plen, NULL, 0, &clen);
+      a->head = 2 + clen;
+      a->total = a->head;
+      for (k = 0; k < a->nsh; k++)
+        { a->jobs[k].at = a->total;
+          a->total += a->jobs[k].bytes;
+        }
+      a->img = malloc(a->total + 16);
+      if (a->img == NULL) a->rc = DX_E_NOMEM;
+      else
+        { uint16_t key = 0x55aa;
+          memcpy(a->img, &key, 2);
+          a->rc = dx_qv_write_coding(&a->cd, (const char *) a->text, plen, a->img + 2, clen, &clen);
+        }
+    }
+  pthread_barrier_wait(&a->bar);
+
+  if (all_ok(a) && m > 0)
+    { rc = dalloc(&pool, total, &d_out);
+      if (rc == DX_OK) rc = dx_qv_encode(j->ctx, &b, d_hdr, d_hoff, d_rec, d_seg, d_out);
+      if (rc == DX_OK) rc = dx_d2h(j->ctx, a->img + j->at, d_out, total);
+      j->rc = rc;
+    }
+  dfree_all(&pool);
+  free(roff); free(hoff); free(blob);
+  return NULL;
+}
+
+int dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n, int lossy,
+                          uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
+{ shard_all  a;
+  pthread_t *th = NULL;
+  uint64_t   cnt = 0, *off = NULL;
+  uint32_t  *len = NULL;
+  int32_t   *hdr4 = NULL;
+  size_t     plen = 0;
+  int        rc, k, started = 0;
+
+  if (ctxs == NULL || nctx < 1 || out == NULL || out_len == NULL) return DX_E_ARG;
+  if (nctx == 1) return dx_file_dexqv(ctxs[0], text, n, lossy, out, out_len, errline, errcode);
+  *out = NULL; *out_len = 0;
+  memset(&a, 0, sizeof(a));
+
+  rc = dx_index_quiva(text, n, 0, NULL, NULL, NULL, &cnt, &plen, errline, errcode);
+  if (rc != DX_OK) return rc;
+  if (cnt == 0) return DX_E_DEGENERATE;
+  off  = malloc((cnt + 1) * sizeof(*off));
+  len  = malloc((cnt + 1) * sizeof(*len));
+  hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+  a.jobs = calloc((size_t) nctx, sizeof(*a.jobs));
+  th = calloc((size_t) nctx, sizeof(*th));
+  if (!off || !len || !hdr4 || !a.jobs || !th) { rc = DX_E_NOMEM; goto done; }
+  TRY(dx_index_quiva(text, n, cnt, off, len, hdr4, &cnt, &plen, errline, errcode));
+
+  a.nsh = nctx; a.lossy = lossy; a.text = text; a.off = off; a.len = len; a.hdr4 = hdr4; a.cnt = cnt;
+  a.rc = DX_OK;
+  { uint64_t run = 0, e;
+    a.cut = 0;
+    for (e = 0; e < cnt; e++)
+      { run += len[e];
+        if (run >= 100000) break;
+      }
+    a.cut = e < cnt ? e : 0;                 /* never reached: no subChar at all, shard 0 finds that too */
+  }
+  pthread_barrier_init(&a.bar, NULL, (unsigned) nctx);
+  { uint64_t per = cnt / (uint64_t) nctx, extra = cnt % (uint64_t) nctx, lo = 0;
+    for (k = 0; k < nctx; k++)
+      { uint64_t m = per + ((uint64_t) k < extra ? 1 : 0);
+        a.jobs[k].all = &a; a.jobs[k].ctx = ctxs[k]; a.jobs[k].id = k;
+        a.jobs[k].lo = lo; a.jobs[k].hi = lo + m; a.jobs[k].rc = DX_OK;
+        lo += m;
+      }
+  }
+  for (k = 0; k < nctx; k++)
+    { if (pthread_create(&th[k], NULL, shard_main, &a.jobs[k]) != 0)
+        { /* cannot run short-handed: the barriers count nctx threads */
+          rc = DX_E_NOMEM;
+          for (; started > 0; started--) pthread_cancel(th[started-1]);
+          goto done_bar;
+        }
+      started += 1;
+    }
+  for (k = 0; k < nctx; k++)
+    pthread_join(th[k], NULL);
+  rc = a.rc;
+  for (k = 0; k < nctx && rc == DX_OK; k++)
+    rc = a.jobs[k].rc;
+  if (rc == DX_OK)
+    { *out = a.img; *out_len = a.total; a.img = NULL; }
+
+done_bar:
+  pthread_barrier_destroy(&a.bar);
+done:
+  free(off); free(len); free(hdr4); free(a.jobs); free(th); free(a.img);
+  return rc;
+}

@@ -283,6 +283,11 @@ int  dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32
                      uint8_t **out, size_t *out_len);
 int  dx_file_dexqv  (dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
                      uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
+/* dexqv of ONE file on several GPUs (one context each; contiguous entry ranges, one host thread per
+ * context, scan state and 12 KB histograms merged on the host, outputs concatenated): identical
+ * bytes to dx_file_dexqv.  nctx == 1 is dx_file_dexqv.                                          */
+int  dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n, int lossy,
+                           uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
 int  dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper,
                      uint8_t **out, size_t *out_len);                       /* undexqv.c:101-208 */
 void dx_file_free(void *p);

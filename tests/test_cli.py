@@ -121,3 +121,14 @@ def test_cli_error_messages_match_reference(tmp_path, tool, ext, data):
 def test_cli_missing_file(tmp_path):
     a = run("dexta", ["nothere"], tmp_path)
     assert a.returncode == 1 and a.stderr == b"dexta: Cannot open ./nothere.fasta for 'r'\n"
+
+
+@pytest.mark.gpu
+def test_cli_dexqv_on_several_contexts(tmp_path):
+    """DEXGPU_DEVICES shards one file over the listed GPUs (here: the same GPU three times)."""
+    qv = synth.make_quiva(25, seed=8, mean=5000).text
+    _write(tmp_path / "m.quiva", qv)
+    env = dict(os.environ, DEXGPU_DEVICES="0,0,0")
+    r = subprocess.run([os.path.join(BIN, "dexqv"), "-k", "m"], cwd=str(tmp_path), capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert _read(tmp_path / "m.dexqv") == O.dexqv(qv)

@@ -477,3 +477,24 @@ def test_dexqv_large_file_uses_gpu_index_and_still_matches(ctx, monkeypatch):
     with pytest.raises(L.DexGPUError) as e2:
         ctx.dexqv(bad)
     assert str(e1.value) == str(e2.value)
+
+
+@pytest.mark.parametrize("nctx", [2, 5])
+@pytest.mark.parametrize("lossy", [0, 1])
+def test_file_dexqv_sharded_over_contexts(ctx, nctx, lossy):
+    """dx_file_dexqv_sharded: host threads + host-side merge; here all contexts sit on device 0."""
+    c = synth.make_quiva(43, seed=71, mean=7000)
+    cs = [api.Context(0) for _ in range(nctx)]
+    try:
+        got = api.dexqv_sharded(cs, c.text, lossy)
+    finally:
+        for x in cs:
+            x.close()
+    assert got == O.dexqv(c.text, lossy)
+    tiny = synth.make_quiva(3, seed=72, mean=100)                 # fewer entries than contexts
+    cs = [api.Context(0) for _ in range(nctx)]
+    try:
+        assert api.dexqv_sharded(cs, tiny.text, lossy) == O.dexqv(tiny.text, lossy)
+    finally:
+        for x in cs:
+            x.close()
