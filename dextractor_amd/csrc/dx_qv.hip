@@ -1030,10 +1030,10 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
     }
   // decode side (Read_Scheme's look-up table, QV.c:365-372, in two levels): ascending symbol order
   // so that for codes shared through the escape the last writer, 255, wins
-  static uint16_t dec[6 * DX_DEC_SIZE];
-  static uint32_t lng[6 * (1 + DX_LONG_MAX)];
-  memset(dec, 0, sizeof(dec));
-  memset(lng, 0, sizeof(lng));
+  std::vector<uint16_t> dec_v(6 * DX_DEC_SIZE, 0);                // per call: contexts run on their own threads
+  std::vector<uint32_t> lng_v(6 * (1 + DX_LONG_MAX), 0);
+  uint16_t *dec = dec_v.data();
+  uint32_t *lng = lng_v.data();
   for (int s = 0; s < 6; s++)
     { if ((s == DX_DRUN && c->delChar < 0) || (s == DX_SRUN && c->subChar < 0))
         continue;
@@ -1060,8 +1060,8 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
     }
   DX_HIP(ctx, hipSetDevice(ctx->device));
   DX_HIP(ctx, hipMemcpyAsync(ctx->d_tok, tok, sizeof(tok), hipMemcpyHostToDevice, ctx->stream));
-  DX_HIP(ctx, hipMemcpyAsync(ctx->d_dec, dec, sizeof(dec), hipMemcpyHostToDevice, ctx->stream));
-  DX_HIP(ctx, hipMemcpyAsync(ctx->d_long, lng, sizeof(lng), hipMemcpyHostToDevice, ctx->stream));
+  DX_HIP(ctx, hipMemcpyAsync(ctx->d_dec, dec, dec_v.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+  DX_HIP(ctx, hipMemcpyAsync(ctx->d_long, lng, lng_v.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int s = 0; s < 4; s++)
     ctx->sym_type[s] = c->s[s].type;
