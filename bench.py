@@ -160,8 +160,13 @@ def main():
         # (the decoder is fed by the encoder's own index); headers are copied, data lines rebuilt
         d_back = torch.zeros_like(d_text)
         torch.cuda.synchronize()
+        ctx.profile(True)
         ctx.qv_decode(p_out, p_rec, p_hoff, p_seg, p_len, n, True, Ptr(d_back), p_off)
         ctx.sync(); torch.cuda.synchronize()
+        dec_ms = ctx.kernel_times().get("k_qv_decode", (0.0, 0))[0]
+        ctx.profile(False)
+        state["decode"] = {"kernel": "k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),
+                           "output_GBps": round(5.0 * bases / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None}
         # compare only the 5 data lines of every entry (fixed-length corpora: one strided view)
         if args.dist == "fixed":
             rec = hlen + 5 * (args.mean + 1)
@@ -253,6 +258,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "roundtrip_bit_exact": roundtrip,
+        "decode": state.get("decode"),
         "text_front_end": front,
         "pipeline": pipe,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}

@@ -209,3 +209,19 @@ def test_walk_byteswapped_file():
     w2 = api.qv_walk(fl)
     assert w2["flip"] == 1 and w2["n"] == w["n"]
     assert (w2["seg"] == w["seg"]).all() and (w2["hdr4"] == w["hdr4"]).all() and (w2["rec_off"] == w["rec_off"]).all()
+
+
+def test_no_gpu_means_loud_failure(tmp_path):
+    """There is no CPU fallback: without a HIP device the library and the tools refuse to work."""
+    import subprocess
+    lib = L.load()
+    if lib.dx_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(L.DexGPUError) as e:
+        api.Context(0)
+    assert e.value.code == -2 and "no HIP device" in str(e.value)
+    fa = tmp_path / "x.fasta"
+    fa.write_bytes(b">m/1/0_4 RQ=0.8\nACGT\n")
+    r = subprocess.run([os.path.join(ROOT, "dextractor_amd", "bin", "dexta"), "-k", str(fa)], capture_output=True)
+    assert r.returncode == 1 and b"cannot open a GPU" in r.stderr
+    assert not (tmp_path / "x.dexta").exists() or (tmp_path / "x.dexta").stat().st_size == 0
