@@ -7,8 +7,8 @@
 //   undexqv -U   undexqv.c:198-204
 //
 // A Huffman bit stream can only be decoded front to back, and the .dexqv format stores no index,
-// so the parallelism is across (entry, stream) pairs: k_qv_decode gives every LANE one of the four
-// QV streams of one entry (4 consecutive lanes = one entry) and walks it sequentially through a
+// so the parallelism is across (entry, stream) pairs: k_qv_decode gives every LANE one QV stream of
+// one entry (a wavefront = the same stream kind of 64 entries) and walks it sequentially through a
 // two-level table (11-bit primary look-up in LDS, linear list for the rare longer codes).  The
 // segment starts come from the index k_qv_sizes produces (or, for a bare file, from the host
 // walk dx_qv_walk).  k_qv_decode_tags then rebuilds the tag line of each entry from the decoded
@@ -107,10 +107,14 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
   for (int k = threadIdx.x; k < 6 * (1 + DX_LONG_MAX); k += DX_BLOCK)     (&s_long[0][0])[k] = g_long[k];
   __syncthreads();
 
-  const uint64_t nthr = (uint64_t) gridDim.x * DX_BLOCK;
-  for (uint64_t g = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x; g < 4 * a.n; g += nthr)
-    { const uint64_t r = g >> 2;
-      const int      q = (int) (g & 3);                    // 0 del, 1 ins, 2 mrg, 3 sub
+  // A wavefront decodes ONE stream kind (q) of 64 consecutive entries, one entry per lane: all its
+  // lanes then run the same loop (plain or run-coded) and only the trip counts differ.
+  const uint64_t nwave  = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  const uint64_t ngroup = (a.n + 63) / 64;                 // groups of 64 entries
+  for (uint64_t w = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6); w < 4 * ngroup; w += nwave)
+    { const int      q = (int) (w & 3);                    // 0 del, 1 ins, 2 mrg, 3 sub
+      const uint64_t r = (w >> 2) * 64 + (uint64_t) lane_id();
+      if (r >= a.n) continue;
       const int      line = q == 0 ? 0 : q + 1;            // output line / segment index
       const uint32_t L  = a.len[r];
       const uint32_t *sg = a.seg + 5 * r;
@@ -241,7 +245,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   a.in = d_in; a.rec_off = d_rec_off; a.hdr_off = d_hdr_off; a.seg = d_seg; a.len = d_len; a.n = n;
   a.out = d_out; a.out_off = d_out_off; a.delChar = ctx->delChar; a.subChar = ctx->subChar; a.upper = (flags & DX_DECODE_UPPER) != 0; a.flip = (flags & DX_DECODE_FLIP) != 0;
   for (int s = 0; s < 4; s++) a.type[s] = ctx->sym_type[s];
-  uint64_t blocks = (4 * n + DX_BLOCK - 1) / DX_BLOCK;
+  uint64_t blocks = (4 * ((n + 63) / 64) + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK;
   const uint64_t cap = (uint64_t) ctx->num_cu * 8;
   if (blocks > cap) blocks = cap;
   DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DX_BLOCK, a, (const uint16_t *) ctx->d_dec,
