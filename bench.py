@@ -125,7 +125,9 @@ def main():
             h = torch.from_numpy(np.concatenate([hist.reshape(-1), [tot]]).astype(np.int64))
             dist.all_reduce(h)
             hist, tot = h[:-1].numpy().astype(np.uint64).reshape(6, 256), int(h[-1])
+        th = time.perf_counter()
         coding = api.qv_build(hist, tot, p, args.lossy)
+        state["host_build_us"] = round((time.perf_counter() - th) * 1e6, 1)      # Huffman tables on the host
         ctx.qv_set_coding(coding, args.lossy)
         total = ctx.qv_sizes(batch, p_hoff, p_seg, p_rec)
         assert total <= out_cap, (total, out_cap)
@@ -258,6 +260,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "roundtrip_bit_exact": roundtrip,
+        "host_table_build_us": state.get("host_build_us"),
         "decode": state.get("decode"),
         "text_front_end": front,
         "pipeline": pipe,
@@ -303,6 +306,24 @@ def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state, bi
         res.update(kind="port", value=round(5 * sbases / dt / 1e9, 4), seconds=round(dt, 2))
     got = ctx.dexqv(sample, args.lossy)          # same sample through the GPU path (file driver)
     res["gpu_output_identical"] = bool(got == want)
+
+    # secondary number: end-to-end wall time of the drop-in CLI on the same sample file (tmpfs -> tmpfs,
+    # includes process start, HIP init, PCIe both ways and the host parse) -- never the headline value
+    cli = os.path.join(ROOT, "dextractor_amd", "bin", "dexqv")
+    if os.path.isfile(cli):
+        with tempfile.TemporaryDirectory(dir=shm) as d:
+            src = os.path.join(d, "s.quiva")
+            with open(src, "wb") as f:
+                f.write(sample)
+            t0 = time.perf_counter()
+            rc_ = subprocess.call([cli, "-k"] + (["-l"] if args.lossy else []) + [src])
+            dtc = time.perf_counter() - t0
+            same = False
+            if rc_ == 0:
+                with open(os.path.join(d, "s.dexqv"), "rb") as f:
+                    same = f.read() == want
+        res["cli_end_to_end"] = {"seconds": round(dtc, 2), "GBps": round(5 * sbases / dtc / 1e9, 3),
+                                 "output_identical": bool(same)}
 
     # how the single-threaded reference would be deployed: one independent copy per host core
     cores = os.cpu_count() or 1

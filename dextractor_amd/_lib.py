@@ -102,6 +102,11 @@ SIGNATURES = {
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dx_file_undexqv": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "dx_file_free": (None, [_P]),
+    "dx_entries_new": (_P, []),
+    "dx_entries_free": (None, [_P]),
+    "dx_entries_add": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
+    "dx_entries_compress": (C.c_int, [_P, _P, C.c_int, C.POINTER(QVCoding), C.POINTER(_P), C.POINTER(C.c_size_t),
+                                      C.POINTER(_P)]),
     "dx_synth_quiva": (C.c_int, [_P, C.c_uint32, C.c_uint64, C.c_uint64, _P, _P, _P, _P, C.c_int,
                                  C.c_char_p, _P]),
 }

@@ -652,3 +652,100 @@ done:
   free(off); free(len); free(hdr4); free(a.jobs); free(th); free(a.img);
   return rc;
 }
+
+/* ==========================================================================================
+ *  in-memory entry API: the shape of QVcoding_Scan1 /
+ *  Compress_Next_QVentry1 (QV.c:866-920, 1343-1379), i.e. what dex2DB.c:511-643 calls per entry
+ *  to write a .qvs track -- as a batch: entries are gathered on the host, then scanned and
+ *  compressed together on the GPU.  The output is the bare record stream (no framing bytes) and
+ *  the offset of every entry in it (DAZZ_READ.coff, dex2DB.c:617-621).
+ * ========================================================================================== */
+struct dx_entries
+  { uint8_t  *text;  size_t tlen, tcap;      /* five lines back to back per entry (line_pad 0) */
+    uint64_t *off;   uint32_t *len;
+    uint64_t  n, cap;
+  };
+
+dx_entries *dx_entries_new(void) { return calloc(1, sizeof(dx_entries)); }
+
+void dx_entries_free(dx_entries *e)
+{ if (e == NULL) return;
+  free(e->text); free(e->off); free(e->len); free(e);
+}
+
+/* QVcoding_Scan1's / Compress_Next_QVentry1's argument list: one entry, five streams of rlen bytes */
+int dx_entries_add(dx_entries *e, int rlen, const char *del, const char *tag, const char *ins,
+                   const char *mrg, const char *sub)
+{ const char *s[5];
+  int k;
+  if (e == NULL || rlen < 0 || (rlen > 0 && (!del || !tag || !ins || !mrg || !sub))) return DX_E_ARG;
+  s[0] = del; s[1] = tag; s[2] = ins; s[3] = mrg; s[4] = sub;
+  if (e->n == e->cap)
+    { uint64_t nc = e->cap ? 2 * e->cap : 1024;
+      uint64_t *no = realloc(e->off, nc * sizeof(*no));
+      uint32_t *nl = realloc(e->len, nc * sizeof(*nl));
+      if (no) e->off = no;
+      if (nl) e->len = nl;
+      if (!no || !nl) return DX_E_NOMEM;
+      e->cap = nc;
+    }
+  if (e->tlen + 5 * (size_t) rlen + 16 > e->tcap)
+    { size_t nc = 2 * e->tcap + 5 * (size_t) rlen + 4096;
+      uint8_t *nt = realloc(e->text, nc);
+      if (!nt) return DX_E_NOMEM;
+      e->text = nt; e->tcap = nc;
+    }
+  e->off[e->n] = e->tlen;
+  e->len[e->n] = (uint32_t) rlen;
+  for (k = 0; k < 5; k++)
+    { memcpy(e->text + e->tlen, s[k], (size_t) rlen);
+      e->tlen += (size_t) rlen;
+    }
+  e->n += 1;
+  return DX_OK;
+}
+
+int dx_entries_compress(dx_ctx *ctx, const dx_entries *e, int lossy, dx_qv_coding *coding,
+                        uint8_t **records, size_t *nbytes, uint64_t **coff)
+{ dpool        pool = { {0}, 0, ctx };
+  dx_qv_batch  b;
+  dx_qv_params p = { -1, -1, -1, -1 };
+  uint64_t   (*hist)[256] = NULL, tot = 0, total = 0;
+  void        *d_text, *d_off, *d_len, *d_rec, *d_seg, *d_out;
+  uint8_t     *res = NULL;
+  uint64_t    *ro = NULL;
+  int          rc;
+
+  if (ctx == NULL || e == NULL || coding == NULL || records == NULL || nbytes == NULL) return DX_E_ARG;
+  *records = NULL; *nbytes = 0;
+  if (coff) *coff = NULL;
+  if (e->n == 0) return DX_E_DEGENERATE;
+  hist = calloc(6, sizeof(*hist));
+  if (!hist) return DX_E_NOMEM;
+  TRY(dupload(&pool, e->text, e->tlen, &d_text));
+  TRY(dupload(&pool, e->off, e->n * 8, &d_off));
+  TRY(dupload(&pool, e->len, e->n * 4, &d_len));
+  TRY(dalloc(&pool, (e->n + 1) * 8, &d_rec));
+  TRY(dalloc(&pool, e->n * 20, &d_seg));
+  b.d_text = d_text; b.d_off = d_off; b.d_len = d_len; b.n = e->n; b.line_pad = 0; b.text_bytes = e->tlen;
+  TRY(dx_qv_prescan(ctx, &b, 0, &p));                      /* QVcoding_Scan1 over all entries */
+  TRY(dx_qv_hist(ctx, &b, 0, &p, hist, &tot));
+  TRY(dx_qv_build((const uint64_t (*)[256]) hist, tot, &p, lossy, coding));   /* Create_QVcoding */
+  TRY(dx_qv_set_coding(ctx, coding, lossy));
+  TRY(dx_qv_sizes(ctx, &b, NULL, d_seg, d_rec, &total));
+  TRY(dalloc(&pool, total, &d_out));
+  TRY(dx_qv_encode(ctx, &b, NULL, NULL, d_rec, d_seg, d_out));   /* Compress_Next_QVentry1 x n */
+  res = malloc(total + 16);
+  ro  = malloc((e->n + 1) * sizeof(*ro));
+  if (!res || !ro) { rc = DX_E_NOMEM; goto done; }
+  TRY(dx_d2h(ctx, res, d_out, total));
+  TRY(dx_d2h(ctx, ro, d_rec, (e->n + 1) * 8));
+  *records = res; *nbytes = total; res = NULL;
+  if (coff) { *coff = ro; ro = NULL; }
+  rc = DX_OK;
+
+done:
+  dfree_all(&pool);
+  free(hist); free(res); free(ro);
+  return rc;
+}

@@ -293,6 +293,24 @@ int  dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper,
 void dx_file_free(void *p);
 
 /* ------------------------------------------------------------------------------------------
+ *  in-memory entry API: QVcoding_Scan1 / Compress_Next_QVentry1 (QV.c:866-920, 1343-1379) as a batch
+ * ------------------------------------------------------------------------------------------ */
+/* dex2DB.c:511-643 feeds entries one at a time through the *1 functions and writes the compressed
+ * bytes of each to a .qvs file, remembering its offset (DAZZ_READ.coff).  Here the entries are
+ * gathered first (dx_entries_add has the *1 functions' argument list), then scanned and compressed
+ * together on the GPU: *records = the bare record stream (no framing bytes), coff[i] = offset of
+ * entry i in it (n+1 values), *coding = the tables to write with dx_qv_write_coding.  records / coff
+ * are malloc'd (dx_file_free).  The streams are copied; the caller's buffers are not modified
+ * (the reference mutates them in place).                                                        */
+typedef struct dx_entries dx_entries;
+dx_entries *dx_entries_new(void);
+void        dx_entries_free(dx_entries *e);
+int         dx_entries_add(dx_entries *e, int rlen, const char *del, const char *tag, const char *ins,
+                           const char *mrg, const char *sub);
+int         dx_entries_compress(dx_ctx *ctx, const dx_entries *e, int lossy, dx_qv_coding *coding,
+                                uint8_t **records, size_t *nbytes, uint64_t **coff);
+
+/* ------------------------------------------------------------------------------------------
  *  seeded synthetic corpora on the device (benchmark/test plumbing; mirrors dextractor_amd/synth.py)
  * ------------------------------------------------------------------------------------------ */
 /* Writes entries [entry0, entry0+n) of the .quiva corpus `seed`: for each entry the header line

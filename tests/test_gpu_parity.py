@@ -498,3 +498,32 @@ def test_file_dexqv_sharded_over_contexts(ctx, nctx, lossy):
     finally:
         for x in cs:
             x.close()
+
+
+def test_in_memory_entry_api(ctx):
+    """dx_entries_* (QVcoding_Scan1 / Compress_Next_QVentry1 shape): bare records + per-entry offsets
+    equal the oracle's per-entry encodes with the tables of the same scan."""
+    c = synth.make_quiva(33, seed=88, mean=7000)
+    text = np.frombuffer(c.text, np.uint8)
+    lib = L.load()
+    e = lib.dx_entries_new()
+    lines_of = []
+    for i in range(len(c.len)):
+        Ln, o = int(c.len[i]), int(c.off[i])
+        lines = [text[o + k * (Ln + 1): o + k * (Ln + 1) + Ln].tobytes() for k in range(5)]
+        lines_of.append(lines)
+        assert lib.dx_entries_add(e, Ln, *lines) == 0
+    coding, rec, nb, coff = L.QVCoding(), C.c_void_p(), C.c_size_t(), C.c_void_p()
+    rc = lib.dx_entries_compress(ctx.h, e, 0, C.byref(coding), C.byref(rec), C.byref(nb), C.byref(coff))
+    assert rc == 0
+    got = C.string_at(rec.value, nb.value)
+    offs = np.ctypeslib.as_array(C.cast(coff, C.POINTER(C.c_uint64)), (len(c.len) + 1,)).copy()
+    lib.dx_file_free(rec); lib.dx_file_free(coff); lib.dx_entries_free(e)
+    ref = O.qv_create(O.qv_scan(c.text))
+    assert (coding.delChar, coding.subChar) == (ref.delChar, ref.subChar)
+    at = 0
+    for i, lines in enumerate(lines_of):
+        body, _ = O.qv_encode_entry(ref, False, np.stack([np.frombuffer(x, np.uint8) for x in lines]))
+        assert int(offs[i]) == at and got[at: at + len(body)] == body
+        at += len(body)
+    assert at == len(got) == int(offs[-1])
