@@ -79,6 +79,10 @@ SIGNATURES = {
     "dx_index_quiva_device": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_uint64),
                                         C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dx_parse_quiva_headers": (C.c_int, [_P, _P, C.c_uint64, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
+    "dx_index_seq_device": (C.c_int, [_P, C.c_int, _P, C.c_uint64, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                      C.POINTER(C.c_uint64), C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "dx_parse_seq_headers": (C.c_int, [C.c_int, _P, _P, C.c_uint64, _P, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "dx_qv_prescan": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams)]),
     "dx_qv_hist": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams), C.POINTER(HIST),
                              C.POINTER(C.c_uint64)]),

@@ -170,6 +170,29 @@ class Context:
             h4 = np.empty((0, 4), np.int32)
         return off, ln, h4, pl.value
 
+    def index_seq_device(self, d_text, nbytes, arrow=False):
+        """GPU text front end for .fasta/.arrow -> (off, tlen, nsym, hdr4, cnr4, prefix_len)."""
+        d_off, d_tl, d_ns, hdr, cnr = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cnt, pl, line, code = C.c_uint64(), C.c_size_t(), C.c_uint64(), C.c_int()
+        rc = self.lib.dx_index_seq_device(self.h, int(arrow), d_text.ptr, nbytes, C.byref(d_off), C.byref(d_tl),
+                                          C.byref(d_ns), C.byref(cnt), C.byref(hdr), C.byref(cnr), C.byref(pl),
+                                          C.byref(line), C.byref(code))
+        if rc != 0:
+            e = L.DexGPUError(rc, f"line {line.value}: DX_IDX code {code.value}")
+            e.line, e.idx_code = line.value, code.value
+            raise e
+        n = cnt.value
+        off, tl, ns = np.empty(n, np.uint64), np.empty(n, np.uint32), np.empty(n, np.uint32)
+        self._chk(self.lib.dx_d2h(self.h, off.ctypes.data, d_off, n * 8))
+        self._chk(self.lib.dx_d2h(self.h, tl.ctypes.data, d_tl, n * 4))
+        self._chk(self.lib.dx_d2h(self.h, ns.ctypes.data, d_ns, n * 4))
+        h4 = np.ctypeslib.as_array(C.cast(hdr, C.POINTER(C.c_int32)), (n, 4)).copy()
+        c4 = np.ctypeslib.as_array(C.cast(cnr, C.POINTER(C.c_uint16)), (n, 4)).copy()
+        for p_ in (d_off, d_tl, d_ns):
+            self.lib.dx_free(self.h, p_)
+        C.CDLL(None).free(hdr); C.CDLL(None).free(cnr)
+        return off, tl, ns, h4, c4, pl.value
+
     def synth_quiva(self, seed, entry0, n, d_off, d_len, d_hdr4, d_lut, del_run, movie, d_text):
         self._chk(self.lib.dx_synth_quiva(self.h, seed & 0xFFFFFFFF, entry0, n, d_off.ptr, d_len.ptr, d_hdr4.ptr,
                                           d_lut.ptr, del_run, movie.encode(), d_text.ptr))

@@ -26,10 +26,12 @@ void dx_file_free(void *p) { free(p); }
 
 #define DX_GPU_INDEX_MIN (1u << 20)      /* .quiva images from 1 MiB on are indexed on the GPU */
 
-typedef struct { void *p[16]; int n; dx_ctx *ctx; } dpool;
+typedef struct { void *p[24]; int n; dx_ctx *ctx; } dpool;
 
 static int dalloc(dpool *pool, size_t bytes, void **out)
-{ int rc = dx_malloc(pool->ctx, bytes + 64, out);
+{ int rc;
+  if (pool->n >= (int) (sizeof(pool->p) / sizeof(pool->p[0])) - 2) return DX_E_NOMEM;   /* pool slots exhausted */
+  rc = dx_malloc(pool->ctx, bytes + 64, out);
   if (rc == DX_OK) pool->p[pool->n++] = *out;
   return rc;
 }
@@ -59,22 +61,45 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
   uint16_t *cnr4 = NULL;
   uint8_t  *blob = NULL, *img = NULL;
   size_t    plen = 0, at, total;
-  void     *d_text, *d_off, *d_tlen, *d_nsym, *d_hdr, *d_hoff, *d_out, *d_ooff;
+  void     *d_text = NULL, *d_off = NULL, *d_tlen = NULL, *d_nsym = NULL, *d_hdr, *d_hoff, *d_out, *d_ooff;
   int       rc;
 
   if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
   *out = NULL; *out_len = 0;
 
-  TRY(dx_index_seq(arrow, text, n, 0, NULL, NULL, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
-  off  = malloc((cnt + 1) * sizeof(*off));
+  /* index: on the GPU for large images (newline scan, record extents there; only header lines come
+     back), on the host for small ones and for anything the GPU front end rejects (exact message) */
+  if (n > 0) TRY(dupload(&pool, text, n, &d_text));
+  if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL)
+    { uint64_t *go = NULL; uint32_t *gt = NULL, *gs = NULL;
+      rc = dx_index_seq_device(ctx, arrow, d_text, n, &go, &gt, &gs, &cnt, &hdr4, &cnr4, &plen, errline, errcode);
+      if (rc == DX_OK)
+        { d_off = go; d_tlen = gt; d_nsym = gs;
+          pool.p[pool.n++] = go; pool.p[pool.n++] = gt; pool.p[pool.n++] = gs;
+          nsym = malloc((cnt + 1) * sizeof(*nsym));
+          if (!nsym) { rc = DX_E_NOMEM; goto done; }
+          TRY(dx_d2h(ctx, nsym, d_nsym, cnt * 4));
+        }
+      else if (rc != DX_E_FORMAT)
+        goto done;
+      rc = DX_OK;
+    }
+  if (d_off == NULL)
+    { TRY(dx_index_seq(arrow, text, n, 0, NULL, NULL, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
+      off  = malloc((cnt + 1) * sizeof(*off));
+      tlen = malloc((cnt + 1) * sizeof(*tlen));
+      nsym = malloc((cnt + 1) * sizeof(*nsym));
+      hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+      cnr4 = malloc((cnt + 1) * 4 * sizeof(*cnr4));
+      if (!off || !tlen || !nsym || !hdr4 || !cnr4) { rc = DX_E_NOMEM; goto done; }
+      TRY(dx_index_seq(arrow, text, n, cnt, off, tlen, nsym, hdr4, cnr4, &cnt, &plen, errline, errcode));
+      TRY(dupload(&pool, off,  cnt * 8, &d_off));
+      TRY(dupload(&pool, tlen, cnt * 4, &d_tlen));
+      TRY(dupload(&pool, nsym, cnt * 4, &d_nsym));
+    }
   hoff = malloc((cnt + 1) * sizeof(*hoff));
   ooff = malloc((cnt + 1) * sizeof(*ooff));
-  tlen = malloc((cnt + 1) * sizeof(*tlen));
-  nsym = malloc((cnt + 1) * sizeof(*nsym));
-  hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
-  cnr4 = malloc((cnt + 1) * 4 * sizeof(*cnr4));
-  if (!off || !hoff || !ooff || !tlen || !nsym || !hdr4 || !cnr4) { rc = DX_E_NOMEM; goto done; }
-  TRY(dx_index_seq(arrow, text, n, cnt, off, tlen, nsym, hdr4, cnr4, &cnt, &plen, errline, errcode));
+  if (!hoff || !ooff) { rc = DX_E_NOMEM; goto done; }
 
   blob = malloc(dx_frame_bound(hdr4, cnt, 0, arrow) + 16);
   if (!blob) { rc = DX_E_NOMEM; goto done; }
@@ -97,11 +122,7 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
   }
 
   if (cnt > 0)
-    { TRY(dupload(&pool, text, n, &d_text));
-      TRY(dupload(&pool, off,  cnt * 8, &d_off));
-      TRY(dupload(&pool, tlen, cnt * 4, &d_tlen));
-      TRY(dupload(&pool, nsym, cnt * 4, &d_nsym));
-      TRY(dupload(&pool, blob, (size_t) hoff[cnt], &d_hdr));
+    { TRY(dupload(&pool, blob, (size_t) hoff[cnt], &d_hdr));
       TRY(dupload(&pool, hoff, (cnt + 1) * 8, &d_hoff));
       TRY(dupload(&pool, ooff, cnt * 8, &d_ooff));
       TRY(dalloc(&pool, total, &d_out));

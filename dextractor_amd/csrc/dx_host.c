@@ -769,3 +769,40 @@ int dx_parse_quiva_headers(const uint8_t *blob, const uint64_t *pos, uint64_t n,
     }
   return DX_OK;
 }
+
+/* Header lines of .fasta / .arrow records gathered by dx_index_seq_device: the checks and field
+ * conversions of dexta.c:118-157 / dexar.c:118-163.                                            */
+int dx_parse_seq_headers(int arrow, const uint8_t *blob, const uint64_t *pos, uint64_t n,
+                         int32_t *hdr4, uint16_t *cnr4, size_t *prefix_len, uint64_t *bad_entry)
+{ uint64_t i;
+  for (i = 0; i < n; i++)
+    { const uint8_t *h = blob + pos[i], *slash;
+      size_t  hl = (size_t) (pos[i+1] - pos[i]) - 1;
+      int32_t f[4];
+      float   snr[4];
+      int     x, j;
+      if (i == 0)
+        { slash = memchr(h, '/', hl);                           /* dexta.c:118 */
+          if (slash == NULL) goto bad;
+          if (prefix_len) *prefix_len = (size_t) (slash - h);
+        }
+      slash = hl > 1 ? memchr(h + 1, '/', hl - 1) : NULL;       /* dexta.c:146 */
+      if (slash == NULL) goto bad;
+      if (arrow)
+        { x = scan_tail(slash + 1, hl - (size_t) (slash + 1 - h), "%d/%d_%d SN=%f,%f,%f,%f\n", f, snr);
+          if (x != 7) goto bad;
+          for (j = 0; j < 4; j++) cnr4[4*i + j] = dx_snr_to_cnr(snr[j]);
+        }
+      else
+        { x = scan_tail(slash + 1, hl - (size_t) (slash + 1 - h), "%d/%d_%d RQ=0.%d\n", f, NULL);
+          if (x < 3) goto bad;
+          for (j = 0; j < 4; j++) cnr4[4*i + j] = 0;
+        }
+      memcpy(hdr4 + 4*i, f, sizeof(f));
+      continue;
+    bad:
+      if (bad_entry) *bad_entry = i;
+      return DX_E_FORMAT;
+    }
+  return DX_OK;
+}

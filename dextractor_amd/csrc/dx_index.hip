@@ -213,3 +213,181 @@ done:
   #undef FMT
   return rc;
 }
+
+// =============================================================================================
+//  .fasta / .arrow: records are delimited by header lines (first byte '>'), dexta.c:139-183
+// =============================================================================================
+
+// per line: 1 if it is a header line (non-empty, starts with '>'), else 0; also the longest line
+__global__ __launch_bounds__(DX_BLOCK)
+void k_seq_lines(const uint8_t *text, const uint64_t *line_start, uint64_t nlines, uint32_t *is_hdr,
+                 unsigned long long *err)
+{ const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
+  if (i >= nlines) return;
+  const uint64_t s = line_start[i], e = line_start[i + 1] - 1;
+  const bool h = e > s && text[s] == '>';
+  is_hdr[i] = h ? 1u : 0u;
+  if (e - s + 1 >= 100000ull)                                      // dexta.c:165-172: fgets limit
+    atomicMin(err, ((unsigned long long) (i + 1) << 8) | DX_IDX_TOO_LONG);
+  if (i == 0 && !h)
+    atomicMin(err, (1ull << 8) | DX_IDX_NO_HEADER);                // dexta.c:113
+}
+
+// one thread per header line k-th record: needs rank of the header among headers
+__global__ __launch_bounds__(DX_BLOCK)
+void k_seq_records(const uint8_t *text, const uint64_t *line_start, uint64_t nlines, const uint32_t *is_hdr,
+                   const uint64_t *hdr_rank /* exclusive scan of is_hdr, nlines+1 */, uint64_t nbytes,
+                   uint64_t *hline /* line index of record r's header */)
+{ const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
+  if (i >= nlines || !is_hdr[i]) return;
+  hline[hdr_rank[i]] = i;
+  (void) text; (void) line_start; (void) nbytes;
+}
+
+__global__ __launch_bounds__(DX_BLOCK)
+void k_seq_extent(const uint64_t *line_start, uint64_t nlines, const uint64_t *hline, uint64_t nrec,
+                  uint64_t *off, uint32_t *tlen, uint32_t *nsym, uint32_t *hdr_len, unsigned long long *err)
+{ const uint64_t r = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
+  if (r >= nrec) return;
+  const uint64_t h  = hline[r];
+  const uint64_t nx = r + 1 < nrec ? hline[r + 1] : nlines;        // first line after this record
+  const uint64_t s  = line_start[h + 1], e = line_start[nx];
+  const uint64_t tl = e - s, lines = nx - h - 1;
+  off[r] = s;
+  hdr_len[r] = (uint32_t) (line_start[h + 1] - 1 - line_start[h]);
+  if (tl - lines > 0x7fffffffull)
+    { atomicMin(err, ((unsigned long long) nx << 8) | DX_IDX_TOO_LONG);
+      tlen[r] = nsym[r] = 0;
+      return;
+    }
+  tlen[r] = (uint32_t) tl;
+  nsym[r] = (uint32_t) (tl - lines);
+}
+
+__global__ __launch_bounds__(DX_BLOCK)
+void k_gather_lines(const uint8_t *text, const uint64_t *line_start, const uint64_t *hline, uint64_t nrec,
+                    const uint64_t *hdr_pos, uint8_t *blob)
+{ const int      lane  = lane_id();
+  const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
+  const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  for (uint64_t i = wave0; i < nrec; i += nwave)
+    { const uint8_t *src = text + line_start[hline[i]];
+      const uint64_t n   = hdr_pos[i + 1] - hdr_pos[i];
+      uint8_t       *dst = blob + hdr_pos[i];
+      for (uint64_t k = lane; k + 1 < n; k += 64)
+        dst[k] = src[k];
+      if (lane == 0) dst[n - 1] = '\n';
+    }
+}
+
+extern "C" int dx_parse_seq_headers(int arrow, const uint8_t *blob, const uint64_t *pos, uint64_t n,
+                                    int32_t *hdr4, uint16_t *cnr4, size_t *prefix_len, uint64_t *bad_entry);
+
+extern "C" int dx_index_seq_device(dx_ctx *ctx, int arrow, const uint8_t *d_text, uint64_t nbytes,
+                                   uint64_t **d_off, uint32_t **d_tlen, uint32_t **d_nsym, uint64_t *count,
+                                   int32_t **hdr4, uint16_t **cnr4, size_t *prefix_len,
+                                   uint64_t *errline, int *errcode)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (!d_off || !d_tlen || !d_nsym || !count || !hdr4 || !cnr4)
+    return dx_fail(ctx, DX_E_ARG, "dx_index_seq_device: NULL result pointer");
+  *d_off = NULL; *d_tlen = NULL; *d_nsym = NULL; *count = 0; *hdr4 = NULL; *cnr4 = NULL;
+  if (prefix_len) *prefix_len = 0;
+  if (nbytes == 0)
+    { if (errline) *errline = 1;
+      if (errcode) *errcode = DX_IDX_EMPTY;
+      return DX_E_FORMAT;
+    }
+  if (d_text == NULL) return dx_fail(ctx, DX_E_ARG, "dx_index_seq_device: NULL text");
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+
+  const uint64_t ntiles = (nbytes + IDX_TILE - 1) / IDX_TILE;
+  uint32_t *d_cnt = NULL, *d_ish = NULL, *d_hlen = NULL, *d_tl = NULL, *d_ns = NULL;
+  uint64_t *d_toff = NULL, *d_line = NULL, *d_rank = NULL, *d_hline = NULL, *d_hpos = NULL, *d_o = NULL, *pos = NULL;
+  uint8_t  *d_blob = NULL, *blob = NULL, last = 0;
+  uint64_t  nl = 0, nrec = 0, hbytes = 0, bad = 0;
+  unsigned long long *d_err = (unsigned long long *) (ctx->d_u64 + 8), err = ~0ull;
+  int rc = DX_OK;
+  #define CK(x)  do { rc = (x); if (rc != DX_OK) goto done; } while (0)
+  #define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = dx_fail(ctx, DX_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+  #define FMT(line, code) do { if (errline) *errline = (line); if (errcode) *errcode = (code); rc = DX_E_FORMAT; goto done; } while (0)
+  #define GRID(n_) dim3((unsigned) (((n_) + DX_BLOCK - 1) / DX_BLOCK))
+
+  CKH(hipMalloc((void **) &d_cnt, ntiles * 4));
+  CKH(hipMalloc((void **) &d_toff, (ntiles + 1) * 8));
+  dx_prof_begin(ctx, DX_K_INDEX);
+  hipLaunchKernelGGL(k_nl_count, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, d_text, nbytes, d_cnt);
+  dx_prof_end(ctx);
+  CK(dx_scan_u32(ctx, d_cnt, ntiles, d_toff, &nl));
+  CKH(hipMemcpyAsync(&last, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
+  CKH(hipStreamSynchronize(ctx->stream));
+  if (last != '\n') FMT(nl + 1, DX_IDX_TOO_LONG);                   // dexta.c:165-172 (no newline = "too long")
+  CKH(hipMalloc((void **) &d_line, (nl + 2) * 8));
+  dx_prof_begin(ctx, DX_K_INDEX);
+  hipLaunchKernelGGL(k_nl_fill, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream,
+                     d_text, nbytes, (const uint64_t *) d_toff, d_line);
+  dx_prof_end(ctx);
+
+  CKH(hipMalloc((void **) &d_ish, nl * 4 + 4));
+  CKH(hipMalloc((void **) &d_rank, (nl + 1) * 8));
+  CKH(hipMemsetAsync(d_err, 0xff, 8, ctx->stream));
+  dx_prof_begin(ctx, DX_K_INDEX);
+  hipLaunchKernelGGL(k_seq_lines, GRID(nl), dim3(DX_BLOCK), 0, ctx->stream, d_text, (const uint64_t *) d_line, nl, d_ish, d_err);
+  dx_prof_end(ctx);
+  CK(dx_scan_u32(ctx, d_ish, nl, d_rank, &nrec));
+  CKH(hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+  CKH(hipStreamSynchronize(ctx->stream));
+  if (err != ~0ull) FMT(err >> 8, (int) (err & 0xff));
+  if (nrec == 0) FMT(1, DX_IDX_NO_HEADER);
+
+  CKH(hipMalloc((void **) &d_hline, nrec * 8));
+  CKH(hipMalloc((void **) &d_o, nrec * 8 + 64));
+  CKH(hipMalloc((void **) &d_tl, nrec * 4 + 64));
+  CKH(hipMalloc((void **) &d_ns, nrec * 4 + 64));
+  CKH(hipMalloc((void **) &d_hlen, nrec * 4));
+  dx_prof_begin(ctx, DX_K_INDEX);
+  hipLaunchKernelGGL(k_seq_records, GRID(nl), dim3(DX_BLOCK), 0, ctx->stream, d_text, (const uint64_t *) d_line, nl,
+                     (const uint32_t *) d_ish, (const uint64_t *) d_rank, nbytes, d_hline);
+  hipLaunchKernelGGL(k_seq_extent, GRID(nrec), dim3(DX_BLOCK), 0, ctx->stream, (const uint64_t *) d_line, nl,
+                     (const uint64_t *) d_hline, nrec, d_o, d_tl, d_ns, d_hlen, d_err);
+  dx_prof_end(ctx);
+  CKH(hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, ctx->stream));
+  CKH(hipStreamSynchronize(ctx->stream));
+  if (err != ~0ull) FMT(err >> 8, (int) (err & 0xff));
+
+  hipLaunchKernelGGL(k_add_one, GRID(nrec), dim3(DX_BLOCK), 0, ctx->stream, d_hlen, nrec);
+  CKH(hipMalloc((void **) &d_hpos, (nrec + 1) * 8));
+  CK(dx_scan_u32(ctx, d_hlen, nrec, d_hpos, &hbytes));
+  CKH(hipMalloc((void **) &d_blob, hbytes + 16));
+  dx_prof_begin(ctx, DX_K_INDEX);
+  hipLaunchKernelGGL(k_gather_lines, dim3((unsigned) dx_grid_waves(ctx, nrec, 32)), dim3(DX_BLOCK), 0, ctx->stream,
+                     d_text, (const uint64_t *) d_line, (const uint64_t *) d_hline, nrec, (const uint64_t *) d_hpos, d_blob);
+  dx_prof_end(ctx);
+  blob  = (uint8_t *) malloc(hbytes + 16);
+  pos   = (uint64_t *) malloc((nrec + 1) * 8);
+  *hdr4 = (int32_t *) malloc(nrec * 4 * sizeof(int32_t));
+  *cnr4 = (uint16_t *) malloc(nrec * 4 * sizeof(uint16_t));
+  if (!blob || !pos || !*hdr4 || !*cnr4) { rc = DX_E_NOMEM; goto done; }
+  CKH(hipMemcpyAsync(blob, d_blob, hbytes, hipMemcpyDeviceToHost, ctx->stream));
+  CKH(hipMemcpyAsync(pos, d_hpos, (nrec + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  CKH(hipStreamSynchronize(ctx->stream));
+  if (dx_parse_seq_headers(arrow, blob, pos, nrec, *hdr4, *cnr4, prefix_len, &bad) != DX_OK)
+    FMT(0, DX_IDX_BAD_HEADER);                                      // exact line: the host indexer reports it
+  *d_off = d_o; *d_tlen = d_tl; *d_nsym = d_ns; *count = nrec;
+  d_o = NULL; d_tl = NULL; d_ns = NULL;
+
+done:
+  (void) hipStreamSynchronize(ctx->stream);
+  (void) hipFree(d_cnt); (void) hipFree(d_toff); (void) hipFree(d_line); (void) hipFree(d_ish); (void) hipFree(d_rank);
+  (void) hipFree(d_hline); (void) hipFree(d_hlen); (void) hipFree(d_hpos); (void) hipFree(d_blob);
+  (void) hipFree(d_o); (void) hipFree(d_tl); (void) hipFree(d_ns);
+  free(blob); free(pos);
+  if (rc != DX_OK)
+    { if (*hdr4) { free(*hdr4); *hdr4 = NULL; }
+      if (*cnr4) { free(*cnr4); *cnr4 = NULL; }
+    }
+  #undef CK
+  #undef CKH
+  #undef FMT
+  #undef GRID
+  return rc;
+}

@@ -150,6 +150,16 @@ int dx_index_quiva_device(dx_ctx *ctx, const uint8_t *d_text, uint64_t nbytes,
 int dx_parse_quiva_headers(const uint8_t *blob, const uint64_t *pos, uint64_t n, int32_t *hdr4,
                            size_t *prefix_len, uint64_t *bad_entry);
 
+/* The same for a .fasta (arrow = 0) / .arrow (arrow = 1) image: records are delimited on the device by
+ * their header lines ('>' first); results as dx_index_seq.  On DX_E_FORMAT re-run dx_index_seq on the
+ * host copy for the reference's exact first message.                                             */
+int dx_index_seq_device(dx_ctx *ctx, int arrow, const uint8_t *d_text, uint64_t nbytes,
+                        uint64_t **d_off, uint32_t **d_tlen, uint32_t **d_nsym, uint64_t *count,
+                        int32_t **hdr4, uint16_t **cnr4, size_t *prefix_len,
+                        uint64_t *errline, int *errcode);
+int dx_parse_seq_headers(int arrow, const uint8_t *blob, const uint64_t *pos, uint64_t n,
+                         int32_t *hdr4, uint16_t *cnr4, size_t *prefix_len, uint64_t *bad_entry);
+
 /* ------------------------------------------------------------------------------------------
  *  5-stream QV coder: dexqv/undexqv (QV.c)
  * ------------------------------------------------------------------------------------------ */

@@ -527,3 +527,40 @@ def test_in_memory_entry_api(ctx):
         assert int(offs[i]) == at and got[at: at + len(body)] == body
         at += len(body)
     assert at == len(got) == int(offs[-1])
+
+
+@pytest.mark.parametrize("kind", ["fasta", "arrow"])
+def test_gpu_seq_index_matches_host_index(ctx, kind):
+    for txt in (O.golden("ta_edge.fasta") if kind == "fasta" else O.golden("ar_edge.arrow"),
+                synth.make_seqfile(kind, 200, seed=13, mean=3000, width=70).text):
+        d = ctx.to_device(np.frombuffer(txt, np.uint8))
+        got = ctx.index_seq_device(d, len(txt), arrow=(kind == "arrow"))
+        want = api.index_seq(txt, arrow=(kind == "arrow"))
+        for a, b in zip(got[:4], want[:4]):
+            assert (np.asarray(a) == np.asarray(b)).all()
+        if kind == "arrow":
+            assert (got[4] == want[4]).all()
+        assert got[5] == want[5]
+
+
+@pytest.mark.parametrize("kind,bad", [
+    ("fasta", b"m/1/0_3 RQ=0.8\nACG\n"), ("fasta", b">m 1 0_3 RQ=0.8\nACG\n"), ("fasta", b">m/1/0_3 RQ=0.8\nACG"),
+    ("fasta", b">m/1/0_3 RQ=0.8\nACG\n>m/x\nAC\n"), ("arrow", b">m/1/0_3 SN=1.0,2.0\n123\n"), ("fasta", b""),
+])
+def test_gpu_seq_index_rejects_like_host(ctx, kind, bad):
+    with pytest.raises(L.DexGPUError):
+        api.index_seq(bad, arrow=(kind == "arrow"))
+    d = ctx.to_device(np.frombuffer(bad + b" ", np.uint8))
+    with pytest.raises(L.DexGPUError) as e:
+        ctx.index_seq_device(d, len(bad), arrow=(kind == "arrow"))
+    assert e.value.code == -3
+
+
+@pytest.mark.parametrize("kind", ["fasta", "arrow"])
+def test_pack2_large_file_uses_gpu_index(ctx, kind, monkeypatch):
+    c = synth.make_seqfile(kind, 150, seed=19, mean=9000)
+    assert len(c.text) > (1 << 20)
+    f = ctx.dexta if kind == "fasta" else ctx.dexar
+    a = f(c.text)
+    monkeypatch.setenv("DEXGPU_HOST_INDEX", "1")
+    assert a == f(c.text) == (O.dexta(c.text) if kind == "fasta" else O.dexar(c.text))
