@@ -646,52 +646,105 @@ __device__ __forceinline__ uint32_t finish_words(wave_out &o, uint32_t last)
   return 4u * (o.wordbase + tailw);
 }
 
+// Shift tokens for the plain streams' packing chain: code bits left-aligned in the word, low byte
+// s = 32 - length (8..31; 32 for a symbol without a code).  v_alignbit_b32 takes its shift from
+// the low 5 bits of an operand, so the token itself is both the shift and the low word of every
+// funnel shift of the chain, and the low byte sums to 32*16 - bits.
+#define STOK_DUMMY 31u                                  // one zero bit; stands in for a missing byte
+__device__ __forceinline__ uint32_t shift_token(uint32_t t)
+{ const uint32_t l = TOK_LEN(t);
+  return l ? ((TOK_BITS(t) << (32u - l)) | (32u - l)) : 32u;
+}
+
+// tables 0..3: symbol schemes; 4, 5: run schemes, bare run code with bit 7 = escape (the 16-bit
+// literal follows, QV.c:486-487); tagcode: Number_Read's letter -> 2-bit code (DB.c:319-338)
+__device__ __forceinline__ void load_shift_tables(uint32_t (*s_stok)[256], uint8_t *s_tagcode, const uint32_t *g_tok)
+{ for (int k = threadIdx.x; k < 6 * 256; k += DX_BLOCK)
+    { const uint32_t t = g_tok[k];
+      (&s_stok[0][0])[k] = shift_token(t) | ((k >= 4 * 256 && TOK_ESC(t)) ? 0x80u : 0u);
+    }
+  for (int k = threadIdx.x; k < 256; k += DX_BLOCK)
+    { const int u = k & 0xdf;
+      s_tagcode[k] = (uint8_t) (u == 'C' ? 1 : (u == 'G' ? 2 : (u == 'T' ? 3 : 0)));
+    }
+  __syncthreads();
+}
+
+// append the token's bits to the 128-bit string w3:w0
+#define STOK_APPEND(t)                                                                          \
+  { w3 = __builtin_amdgcn_alignbit(w3, w2, (t));                                                \
+    w2 = __builtin_amdgcn_alignbit(w2, w1, (t));                                                \
+    w1 = __builtin_amdgcn_alignbit(w1, w0, (t));                                                \
+    w0 = __builtin_amdgcn_alignbit(w0, (t), (t));                                               \
+  }
+
+// OR the nb (1..128) bits right-aligned in w3:w0 into the window at bit offset `bit`
+__device__ __forceinline__ void place_bits128(uint32_t *win, uint32_t bit, uint32_t nb,
+                                              uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{ const uint32_t e  = bit + nb;                                // end bit (exclusive)
+  const uint32_t sl = (32u - (e & 31u)) & 31u, sr = 32u - sl;   // left-align to the last word
+  const uint32_t we = (e - 1u) >> 5;
+  const uint32_t x0 = w0 << sl;
+  const uint32_t x1 = fsr(w1, w0, sr), x2 = fsr(w2, w1, sr), x3 = fsr(w3, w2, sr), x4 = fsr(0u, w3, sr);
+  atomicOr(&win[we], x0);
+  if (x1) atomicOr(&win[we - 1], x1);
+  if (x2) atomicOr(&win[we - 2], x2);
+  if (x3) atomicOr(&win[we - 3], x3);
+  if (x4) atomicOr(&win[we - 4], x4);
+}
+
 // one step of Encode (QV.c:427-434): 16 table look-ups per lane, prefix sum, bits into the window
 __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, int valid, bool full,
-                                                  const uint32_t *tab, uint32_t m4)
+                                                  const uint32_t *tab, const uint32_t *stab, uint32_t m4)
 { uint32_t tok[16];
-  uint32_t nb = 0, z = 0;
-  #pragma unroll
-  for (int b = 0; b < 16; b++)
-    { const uint32_t x = ((chunk_word(c, b >> 2) & m4) >> (8 * (b & 3))) & 0xffu;
-      tok[b] = (full || b < valid) ? tab[x] : 0u;
-      const uint32_t l = TOK_LEN(tok[b]);
-      nb += l;
-      z  |= l - 1u;                                   // sign bit set iff some token has length 0
+  uint32_t ssum = 0, zor = 0;
+  if (full)
+    {
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        { tok[b] = stab[((chunk_word(c, b >> 2) & m4) >> (8 * (b & 3))) & 0xffu];
+          ssum += tok[b] & 0xffu;
+          zor  |= tok[b];
+        }
     }
+  else
+    {
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        { const uint32_t t = stab[((chunk_word(c, b >> 2) & m4) >> (8 * (b & 3))) & 0xffu];
+          tok[b] = b < valid ? t : STOK_DUMMY;
+          ssum  += b < valid ? (t & 0xffu) : 32u;
+          zor   |= tok[b];
+        }
+    }
+  const uint32_t nb   = 512u - ssum;
+  const uint32_t k    = 16u - (uint32_t) valid;                        // dummies (0 unless ragged)
   const uint32_t incl = wave_incl_scan(nb);
-  const bool fast = full && !__any((int) ((z >> 31) | (nb > 128u)));
+  const bool fast = !__any((int) ((zor & 32u) | (nb + k > 128u)));
   if (fast)
-    { // all 16 tokens have 1..24 bits and the lane's string fits 128 bits: branch-free packing
+    { // every token has 1..24 bits and the lane's string fits 128 bits: branch-free packing.  The
+      // dummies of a ragged last chunk append one zero bit each, shifted out again at the end.
       FOR_EACH_ROUND(o, incl, nb,
         { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
           _Pragma("unroll")
           for (int b = 0; b < 16; b++)
-            { const uint32_t l = TOK_LEN(tok[b]), s = 32u - l;        // s in 8..31
-              w3 = __builtin_amdgcn_alignbit(w3, w2, s);
-              w2 = __builtin_amdgcn_alignbit(w2, w1, s);
-              w1 = __builtin_amdgcn_alignbit(w1, w0, s);
-              w0 = (w0 << l) | TOK_BITS(tok[b]);
-            }
-          const uint32_t e  = bit_ + nb;                               // end bit (exclusive)
-          const uint32_t sl = (32u - (e & 31u)) & 31u, sr = 32u - sl;  // left-align to the last word
-          const uint32_t we = (e - 1u) >> 5;
-          const uint32_t x0 = w0 << sl;
-          const uint32_t x1 = fsr(w1, w0, sr), x2 = fsr(w2, w1, sr), x3 = fsr(w3, w2, sr), x4 = fsr(0u, w3, sr);
-          atomicOr(&o.win[we], x0);
-          if (x1) atomicOr(&o.win[we - 1], x1);
-          if (x2) atomicOr(&o.win[we - 2], x2);
-          if (x3) atomicOr(&o.win[we - 3], x3);
-          if (x4) atomicOr(&o.win[we - 4], x4);
+            STOK_APPEND(tok[b])
+          w0 = __builtin_amdgcn_alignbit(w1, w0, k);
+          w1 = __builtin_amdgcn_alignbit(w2, w1, k);
+          w2 = __builtin_amdgcn_alignbit(w3, w2, k);
+          w3 >>= k;
+          place_bits128(o.win, bit_, nb, w0, w1, w2, w3);
         })
     }
   else
     { FOR_EACH_ROUND(o, incl, nb,
         { bit_acc s;
           acc_begin(s, bit_);
-          _Pragma("unroll")
-          for (int b = 0; b < 16; b++)
-            acc_put(s, o.win, TOK_BITS(tok[b]), TOK_LEN(tok[b]));
+          _Pragma("unroll 1")
+          for (int b = 0; b < valid; b++)
+            { const uint32_t t = tab[chunk_byte(c, b) & (m4 & 0xffu)];
+              acc_put(s, o.win, TOK_BITS(t), TOK_LEN(t));
+            }
           acc_end(s, o.win);
         })
     }
@@ -708,41 +761,89 @@ __device__ __forceinline__ void place_token(uint32_t *win, uint32_t q, uint64_t 
   if (W2)           atomicOr(&win[w + 2], W2);
 }
 
-// one step of Encode_Run (QV.c:475-497): the step's non-run symbols are processed 64 at a time,
-// one (run token + symbol token) per lane.  With TAGS the same lanes also emit the 2-bit code of
-// the deletion tag under each non-run symbol (Pack_Tag + Number_Read + Compress_Read,
-// QV.c:810-819, 1402-1404) into the tag window.
+// one step of Encode_Run (QV.c:475-497).  The step's non-run symbols (dense list from run_collect)
+// are handled in passes of up to 64*RUN_TP tokens: every lane takes T <= RUN_TP consecutive tokens,
+// chains their (run code [+ 16-bit literal] + symbol code) pieces into one string of <= 128 bits,
+// and a single prefix sum + placement per pass puts the strings into the window.  With TAGS the
+// same lanes also emit the 2-bit codes of the deletion tags under their symbols (Pack_Tag +
+// Number_Read + Compress_Read, QV.c:810-819, 1402-1404) into the tag window.
+#define RUN_TP 6u
 __device__ __forceinline__ void encode_runs_step(wave_out &o, wave_out &ot, const run_lds &R, uint8_t *tagchunk,
-                                                 const bool TAGS, const u32x4 &c, const u32x4 &t, int valid, uint32_t sv,
-                                                 uint32_t rc, uint32_t &C, const uint32_t *ntab, const uint32_t *rtab)
+                                                 const uint8_t *tagcode, const bool TAGS, const u32x4 &c, const u32x4 &t,
+                                                 int valid, uint32_t sv, uint32_t rc, uint32_t &C,
+                                                 const uint32_t *ntab, const uint32_t *rtab,
+                                                 const uint32_t *nstab, const uint32_t *rstab)
 { const int lane = lane_id();
   if (TAGS)
     *(u32x4 *) (tagchunk + 16 * lane) = t;
   const uint32_t total = run_collect(R, c, valid, rc);
-  for (uint32_t k = 0; k < total; k += 64)
-    { const uint32_t i = k + lane;
-      uint64_t tok = 0;
-      uint32_t len = 0;
-      if (i < total)
-        { RUN_TOKEN(R, i, C, pos, x, run)
-          const uint32_t re = rtab[run > 255u ? 255u : run];     // QV.c:479-487
-          const uint32_t se = ntab[x];
-          const uint32_t rb = TOK_ESC(re) ? ((TOK_BITS(re) << 16) | run) : TOK_BITS(re);
-          const uint32_t sl = TOK_LEN(se);
-          tok = ((uint64_t) rb << sl) | TOK_BITS(se);
-          len = TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u) + sl;
-          if (TAGS)
-            { const uint32_t u    = (uint32_t) tagchunk[pos] & 0xdfu;
-              const uint32_t code = (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 0u;
-              const uint32_t p    = (ot.winbits >> 1) + (uint32_t) lane;
-              if (code) atomicOr(&ot.win[p >> 4], code << (30u - 2u * (p & 15u)));
-            }
+  for (uint32_t k0 = 0; k0 < total; k0 += 64u * RUN_TP)
+    { const uint32_t m     = total - k0 < 64u * RUN_TP ? total - k0 : 64u * RUN_TP;
+      const uint32_t T     = (m + 63u) >> 6;
+      const uint32_t first = k0 + (uint32_t) lane * T;
+      const uint32_t cnt   = first < k0 + m ? (k0 + m - first < T ? k0 + m - first : T) : 0u;
+      // run before a token = its position - base; base = previous non-run position + 1, or -C
+      // (the run open at the step's start) for the step's first token
+      uint32_t base0 = 0;
+      if (cnt)
+        base0 = first ? (uint32_t) R.list[first - 1] + 1u : 0u - C;
+      uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, nb = 0, zor = 0, tacc = 0, base = base0;
+      #pragma unroll 1
+      for (uint32_t j = 0; j < T; j++)
+        if (j < cnt)
+          { const uint32_t pos = R.list[first + j];
+            const uint32_t x   = R.chunk[pos];
+            const uint32_t run = pos - base;
+            base = pos + 1u;
+            const uint32_t rt = rstab[run > 255u ? 255u : run];       // QV.c:479-487
+            const uint32_t st = nstab[x];
+            STOK_APPEND(rt)
+            if (rt & 0x80u)
+              { const uint32_t lit = (run << 16) | 16u;
+                STOK_APPEND(lit)
+                w0 |= run & 0xffff0000u;                              // OCODE(16,run) with run >= 2^16 (QV.c:411,420)
+                nb += 16u;
+              }
+            STOK_APPEND(st)
+            nb  += 64u - (rt & 0x3fu) - (st & 0xffu);
+            zor |= rt | st;
+            if (TAGS)
+              tacc = (tacc << 2) | (uint32_t) tagcode[tagchunk[pos]];
+          }
+      const uint32_t incl = wave_incl_scan(nb);
+      if (!__any((int) ((zor & 32u) | (nb > 128u))))
+        { FOR_EACH_ROUND(o, incl, nb,
+            { place_bits128(o.win, bit_, nb, w0, w1, w2, w3); })
         }
-      const uint32_t incl = wave_incl_scan(len);
-      FOR_EACH_ROUND(o, incl, len,
-        { place_token(o.win, bit_, tok, len); })
+      else                                    // a symbol or run without a code, or a string > 128 bits
+        { FOR_EACH_ROUND(o, incl, nb,
+            { bit_acc s;
+              acc_begin(s, bit_);
+              uint32_t b2 = base0;
+              _Pragma("unroll 1")
+              for (uint32_t j = 0; j < cnt; j++)
+                { const uint32_t pos = R.list[first + j];
+                  const uint32_t run = pos - b2;
+                  b2 = pos + 1u;
+                  const uint32_t re = rtab[run > 255u ? 255u : run];
+                  const uint32_t se = ntab[R.chunk[pos]];
+                  acc_put(s, o.win, TOK_ESC(re) ? ((TOK_BITS(re) << 16) | run) : TOK_BITS(re),
+                          TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u));
+                  acc_put(s, o.win, TOK_BITS(se), TOK_LEN(se));
+                }
+              acc_end(s, o.win);
+            })
+        }
       if (TAGS)
-        { ot.winbits += 2u * (total - k >= 64u ? 64u : total - k);
+        { if (cnt)
+            { const uint32_t bit = ot.winbits + 2u * (first - k0);
+              const uint32_t w = bit >> 5, sh = bit & 31u;
+              const uint32_t v = tacc << (32u - 2u * cnt);
+              atomicOr(&ot.win[w], v >> sh);
+              if (sh + 2u * cnt > 32u)
+                atomicOr(&ot.win[w + 1], v << (32u - sh));
+            }
+          ot.winbits += 2u * m;
           if (ot.winbits >= TAG_FLUSH_BITS)
             flush_words(ot, true);
         }
@@ -825,12 +926,15 @@ __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
                  const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status)
 { __shared__ uint32_t s_tok[6][256];
+  __shared__ uint32_t s_stok[6][256];
+  __shared__ uint8_t  s_tagcode[256];
   __shared__ uint32_t s_win[DX_WAVES_PER_BLK][QV_WIN_WORDS];
   __shared__ uint32_t s_tag[DX_WAVES_PER_BLK][TAG_WIN_WORDS];
   __shared__ __attribute__((aligned(16))) uint8_t s_chunk[DX_WAVES_PER_BLK][DX_STEP];
   __shared__ __attribute__((aligned(16))) uint8_t s_tchunk[DX_WAVES_PER_BLK][DX_STEP];
   __shared__ uint16_t s_list[DX_WAVES_PER_BLK][DX_STEP];
   load_tables(s_tok, g_tok);
+  load_shift_tables(s_stok, s_tagcode, g_tok);
   const int      lane  = lane_id();
   const int      wid   = threadIdx.x >> 6;
   const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + wid;
@@ -885,7 +989,8 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
                   u32x4 u = d;
                   if (tags) u = fetch(p1, pos + DX_STEP, L, over);
                   const uint32_t sv = L - base >= DX_STEP ? DX_STEP : L - base;
-                  encode_runs_step(o, ot, R, s_tchunk[wid], tags, c, t, valid_of(pos, L), sv, (uint32_t) rci, C, tab, rtab);
+                  encode_runs_step(o, ot, R, s_tchunk[wid], s_tagcode, tags, c, t, valid_of(pos, L), sv, (uint32_t) rci, C, tab, rtab,
+                                   s_stok[q], s_stok[q == 0 ? DX_DRUN : DX_SRUN]);
                   c = d; t = u;
                   pos += DX_STEP;
                 }
@@ -901,7 +1006,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
               u32x4 c = fetch(p, pos, L, over);
               for (uint32_t base = 0; base < L; base += DX_STEP)
                 { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
-                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, m4);
+                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, s_stok[q], m4);
                   c = d;
                   pos += DX_STEP;
                 }

@@ -103,7 +103,7 @@ def qv_encode_entry(coding, lossy, lines):
     """lines: uint8 [5, L] -> (bytes, seg[5])"""
     lines = np.ascontiguousarray(lines, dtype=np.uint8)
     L = lines.shape[1]
-    cap = 8 * L + 64
+    cap = 16 * L + 64
     buf = C.create_string_buffer(cap)
     seg = (C.c_uint32 * 5)()
     ptr = [lines[r].ctypes.data for r in range(5)]

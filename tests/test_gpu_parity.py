@@ -564,3 +564,92 @@ def test_pack2_large_file_uses_gpu_index(ctx, kind, monkeypatch):
     a = f(c.text)
     monkeypatch.setenv("DEXGPU_HOST_INDEX", "1")
     assert a == f(c.text) == (O.dexta(c.text) if kind == "fasta" else O.dexar(c.text))
+
+
+def _fixed_coding(sym_len, run_len, run_esc, del_char, sub_char):
+    """A hand-made prefix code: every symbol sym_len bits, every run run_len bits; run 255 is the
+    escape of a type-2 run scheme when run_esc."""
+    cd = L.QVCoding()
+    for k in range(6):
+        sc = cd.s[k]
+        ln = sym_len if k < 4 else run_len
+        sc.type = 2 if (k >= 4 and run_esc) else 0
+        for x in range(256):
+            sc.lens[x] = ln
+            sc.bits[x] = (x * 73 + k) & 0xff if ln == 8 else ((x * 257 + 3 * k) & ((1 << ln) - 1))
+    cd.delChar, cd.subChar = del_char, sub_char
+    return cd
+
+
+@pytest.mark.parametrize("sym_len,run_len,run_esc", [(16, 16, True), (8, 13, False), (8, 14, False), (9, 9, True),
+                                                     (3, 9, False)])
+@pytest.mark.parametrize("run_p", [0.05, 0.7])
+def test_qv_encode_with_given_coding(ctx, sym_len, run_len, run_esc, run_p):
+    """dx_qv_set_coding with a caller's tables (the Read_QVcoding situation): fixed-length codes put
+    a lane's string exactly at, below and above the 128 bits of the packing fast path, in plain and
+    run-coded streams; long runs take the 16-bit literal."""
+    prof = synth.pacbio_profile(del_run_p=run_p, sub_run_p=run_p)
+    lens = np.array([1, 15, 16, 17, 63, 64, 1023, 1024, 1025, 2500, 6000, 6001, 9000, 400, 3, 0, 7777], np.uint32)
+    c = synth.make_quiva(len(lens), seed=5, lens=lens, prof=prof)
+    st = O.qv_scan(c.text)
+    del_char = st.delChar
+    sub_char = st.subChar if st.subChar >= 0 else int(np.argmax(O.hist_array(st)[3]))   # too few symbols for a scan to keep it
+    assert del_char >= 0
+    txt, o = bytearray(c.text), int(c.off[12])                    # runs of 600: the 16-bit literal
+    txt[o + 100: o + 700] = bytes([del_char]) * 600
+    txt[o + 9001 + 100: o + 9001 + 700] = b"N" * 600
+    txt[o + 4 * 9001 + 2000: o + 4 * 9001 + 2600] = bytes([sub_char]) * 600
+    c.text = bytes(txt)
+    cd = _fixed_coding(sym_len, run_len, run_esc, del_char, sub_char)
+    ref_cd = O.Coding()
+    C.memmove(C.byref(ref_cd), C.byref(cd), C.sizeof(cd))
+    b, keep = _upload_quiva(ctx, c)
+    ctx.qv_set_coding(cd)
+    n = len(lens)
+    d_rec, d_seg = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n)
+    total = ctx.qv_sizes(b, None, d_seg, d_rec)
+    rec = d_rec.download(np.uint64)
+    d_out = ctx.alloc(max(total, 4))
+    ctx.qv_encode(b, None, None, d_rec, d_seg, d_out)
+    out = d_out.download(np.uint8, total).tobytes()
+    seg = d_seg.download(np.uint32, 5 * n).reshape(n, 5)
+    text = np.frombuffer(c.text, np.uint8)
+    for i in range(n):
+        Ln, o = int(c.len[i]), int(c.off[i])
+        lines = np.stack([text[o + k * (Ln + 1): o + k * (Ln + 1) + Ln] for k in range(5)])
+        body, want_seg = O.qv_encode_entry(ref_cd, False, lines)
+        assert list(seg[i]) == want_seg
+        assert out[int(rec[i]): int(rec[i + 1])] == body
+
+
+def test_dexqv_dense_token_stretches(ctx):
+    """Skewed (Fibonacci-weighted) alphabets with type-2 run schemes, and 900-symbol stretches without
+    a single run character: steps whose run streams need several full passes of 6 tokens per lane,
+    next to ordinary steps."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    f = [1, 1]
+    while len(f) < 21:
+        f.append(f[-1] + f[-2])
+    pool = np.concatenate([np.full(cn, 40 + i, np.uint8) for i, cn in enumerate(f)])
+    rare = np.array([40, 41, 42, 43], np.uint8)
+    prof = synth.pacbio_profile()
+    ents = []
+    for e in range(60):
+        L = int(rng.integers(2500, 6000))
+        b = synth.qv_lines(5, e, L, prof)
+        run = rng.random(L) < 0.55
+        b[0] = np.where(run, ord("2"), rng.choice(pool, L))
+        b[1] = np.where(run, ord("N"), rng.choice(np.frombuffer(b"ACGT", np.uint8), L))
+        b[2] = rng.choice(pool, L)
+        b[3] = rng.choice(pool, L)
+        b[4] = np.where(rng.random(L) < 0.6, ord("z"), rng.choice(pool, L))
+        if e % 3 == 1:                                   # dense rare stretches, no run characters inside
+            s0 = int(rng.integers(0, L - 900))
+            for r in (0, 2, 3, 4):
+                b[r, s0:s0 + 900] = rng.choice(rare, 900)
+            b[1, s0:s0 + 900] = rng.choice(np.frombuffer(b"acgt", np.uint8), 900)
+        ents.append((10 + e * 7, [b[r].tobytes() for r in range(5)]))
+    txt = _quiva(ents)
+    want = O.dexqv(txt)
+    assert ctx.dexqv(txt) == want
+    assert ctx.undexqv(want, upper=False) == O.undexqv(want, upper=False)
