@@ -235,13 +235,24 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 // Symbol histograms live in LDS with every bin replicated HREP times (copy = lane & (HREP-1)),
 // which divides the same-address serialisation of ds_add_u32 on the dominant symbols by HREP.
 
+#ifdef HIST_EXP
+__device__ uint32_t g_sink;
+#endif
 __device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool full, uint32_t *h)
 { const uint32_t k = (uint32_t) lane_id() & (HREP - 1);
   if (full)
     {
+#ifdef HIST_EXP
+      uint32_t sink = 0;
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        sink ^= (BYTE_OF(c, b) * HREP + k) << b;
+      if (sink == 0x12345678u) g_sink = sink;
+#else
       #pragma unroll
       for (int b = 0; b < 16; b++)
         atomicAdd(&h[BYTE_OF(c, b) * HREP + k], 1u);
+#endif
     }
   else
     for (int b = 0; b < valid; b++)
@@ -385,46 +396,97 @@ __device__ __forceinline__ uint32_t run_token_len(const uint32_t *rtab, uint32_t
 // =============================================================================================
 //  size pass: bit totals only (4 streams in one sweep)
 // =============================================================================================
-__device__ __forceinline__ uint32_t bits_plain_step(const u32x4 &c, int valid, bool full, const uint32_t *tab, uint32_t m4)
-{ uint32_t acc = 0;
-  if (full)
-    {
-      #pragma unroll
-      for (int b = 0; b < 16; b++)
-        acc += TOK_LEN(tab[((chunk_word(c, b >> 2) & m4) >> (8 * (b & 3))) & 0xffu]);
+// No tokens are formed here, only their lengths are summed, which needs far less than the dense
+// token list of the other two passes:
+//  * symbol codes: a byte-wide length table per stream (256 B: one LDS bank per dword, no bank
+//    conflicts); for a run-coded stream the run character's entry is 0, so all 16 bytes of a lane
+//    are simply looked up and added;
+//  * run codes (Encode_Run, QV.c:475-487): the non-run mask of a lane's 16 bytes is split into two
+//    bytes; the runs strictly inside a mask byte are summed by a 256-entry table built from the
+//    run scheme at kernel start; what remains per lane is the run in front of its first token
+//    (which needs the end of the previous token: a max-scan over the lanes, carried over steps in
+//    C) and the run across the middle of the mask.
+struct size_tabs
+{ uint8_t  len[6][256];     // token length per symbol / per run value (run: + 16 if escaped)
+  uint16_t inner[2][256];   // per 8-bit non-run mask: sum of run-token lengths of the runs inside it
+};
+
+__device__ __forceinline__ void load_size_tables(size_tabs &t, const uint32_t *g_tok, int delChar, int subChar)
+{ for (int k = threadIdx.x; k < 6 * 256; k += DX_BLOCK)
+    { const uint32_t e = g_tok[k];
+      uint32_t l = TOK_LEN(e) + ((k >= 4 * 256 && TOK_ESC(e)) ? 16u : 0u);
+      if ((delChar >= 0 && k == DX_DEL * 256 + delChar) || (subChar >= 0 && k == DX_SUB * 256 + subChar))
+        l = 0;
+      (&t.len[0][0])[k] = (uint8_t) l;
     }
-  else
-    for (int b = 0; b < valid; b++)
-      acc += TOK_LEN(tab[chunk_byte(c, b) & (m4 & 0xffu)]);
-  return acc;
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * 256; k += DX_BLOCK)
+    { const uint8_t *rl = t.len[4 + (k >> 8)];
+      uint32_t m = (uint32_t) k & 0xffu, sum = 0;
+      int prev = -1;
+      for (int b = 0; b < 8; b++)
+        if ((m >> b) & 1u)
+          { if (prev >= 0) sum += rl[b - prev - 1];
+            prev = b;
+          }
+      (&t.inner[0][0])[k] = (uint16_t) sum;
+    }
+  __syncthreads();
 }
 
-__device__ __forceinline__ uint32_t bits_runs_step(const run_lds &R, const u32x4 &c, int valid, uint32_t sv, uint32_t rc,
-                                                   uint32_t &C, uint32_t &nonrun, const uint32_t *ntab, const uint32_t *rtab)
-{ const int      lane  = lane_id();
-  const uint32_t total = run_collect(R, c, valid, rc);
-  uint32_t acc = 0;
-  nonrun += total;                                               // wave-uniform
-  for (uint32_t i = lane; i < total; i += 64)
-    { RUN_TOKEN(R, i, C, pos, x, run)
-      acc += run_token_len(rtab, run) + TOK_LEN(ntab[x]);
+// inclusive running maximum over the 64 lanes (values >= 0)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{ v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false));
+  return v;
+}
+
+// sum of the symbol-code lengths of a lane's bytes [0, valid)
+__device__ __forceinline__ uint32_t bits_syms_step(const u32x4 &c, int valid, const uint8_t *len, uint32_t m4)
+{ uint32_t acc = 0;
+  #pragma unroll
+  for (int b = 0; b < 16; b++)
+    acc += len[((chunk_word(c, b >> 2) & m4) >> (8 * (b & 3))) & 0xffu];
+  return acc - (16u - (uint32_t) valid) * len[0];                // missing bytes were read as 0
+}
+
+// sum of the run-code lengths of the tokens that start in this lane's bytes; C = run open at the
+// step's start (in), at its end (out); nonrun += this lane's token count
+__device__ __forceinline__ uint32_t bits_runs_step(const u32x4 &c, int valid, uint32_t sv, uint32_t rc, uint32_t &C,
+                                                   uint32_t &nonrun, const uint8_t *rlen, const uint16_t *inner)
+{ const uint32_t nr = ~chunk_eq_mask(c, rc) & ((1u << valid) - 1u);
+  const uint32_t lo = nr & 0xffu, hi = nr >> 8;
+  const uint32_t p0 = 16u * (uint32_t) lane_id();
+  // end (position + 1) of the last token at or before each lane; 0: none yet in this step
+  const uint32_t incl = wave_incl_max(nr ? p0 + 32u - (uint32_t) __clz(nr) : 0u);
+  const uint32_t prev = __builtin_amdgcn_update_dpp(0u, incl, 0x138, 0xf, 0xf, true);   // wave_shr:1
+  uint32_t acc = (uint32_t) inner[lo] + (uint32_t) inner[hi];
+  if (lo && hi)
+    acc += rlen[(uint32_t) __clz(lo) - 24u + (uint32_t) __ffs(hi) - 1u];      // zeros above lo's top bit + below hi's lowest
+  if (nr)
+    { const uint32_t run = p0 + (uint32_t) __ffs(nr) - 1u - (prev ? prev : 0u - C);
+      acc += rlen[run > 255u ? 255u : run];                                    // QV.c:479-482
     }
-  C = run_after(R, total, sv, C);
-  wave_sync();
+  nonrun += __popc(nr);
+  const uint32_t end = __builtin_amdgcn_readlane(incl, 63);
+  C = end ? sv - end : C + sv;
   return acc;
 }
 
 __global__ __launch_bounds__(DX_BLOCK, SIZES_WAVES)
 void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *seg /* n x 5 */,
                 uint32_t *rec_size)
-{ __shared__ uint32_t s_tok[6][256];
-  __shared__ __attribute__((aligned(16))) uint8_t s_chunk[DX_WAVES_PER_BLK][DX_STEP];
-  __shared__ uint16_t s_list[DX_WAVES_PER_BLK][DX_STEP];
+{ __shared__ uint32_t  s_tok[6][256];
+  __shared__ size_tabs s_t;
   load_tables(s_tok, g_tok);
+  load_size_tables(s_t, g_tok, a.delChar, a.subChar);
   const int      lane  = lane_id();
   const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
   const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
-  const run_lds  R     = { s_chunk[threadIdx.x >> 6], s_list[threadIdx.x >> 6] };
   const uint32_t imask = a.lossy ? 0xfeu : 0xffu, mmask = a.lossy ? 0xfcu : 0xffu;
   const uint32_t im4 = imask * 0x01010101u, mm4 = mmask * 0x01010101u;
   const bool drun = a.delChar >= 0, srun = a.subChar >= 0;
@@ -446,14 +508,13 @@ void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint3
           const u32x4 d0 = fetch(p0, np, L, over), d2 = fetch(p2, np, L, over);
           const u32x4 d3 = fetch(p3, np, L, over), d4 = fetch(p4, np, L, over);
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
-          const bool     full  = sv == DX_STEP;
           const int      valid = valid_of(pos, L);
-          a0 += drun ? bits_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, nn0, s_tok[DX_DEL], s_tok[DX_DRUN])
-                     : bits_plain_step(c0, valid, full, s_tok[DX_DEL], ~0u);
-          a2 += bits_plain_step(c2, valid, full, s_tok[DX_INS], im4);
-          a3 += bits_plain_step(c3, valid, full, s_tok[DX_MRG], mm4);
-          a4 += srun ? bits_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, nn4, s_tok[DX_SUB], s_tok[DX_SRUN])
-                     : bits_plain_step(c4, valid, full, s_tok[DX_SUB], ~0u);
+          a0 += bits_syms_step(c0, valid, s_t.len[DX_DEL], ~0u);
+          a2 += bits_syms_step(c2, valid, s_t.len[DX_INS], im4);
+          a3 += bits_syms_step(c3, valid, s_t.len[DX_MRG], mm4);
+          a4 += bits_syms_step(c4, valid, s_t.len[DX_SUB], ~0u);
+          if (drun) a0 += bits_runs_step(c0, valid, sv, (uint32_t) a.delChar, C0, nn0, s_t.len[DX_DRUN], s_t.inner[0]);
+          if (srun) a4 += bits_runs_step(c4, valid, sv, (uint32_t) a.subChar, C4, nn4, s_t.len[DX_SRUN], s_t.inner[1]);
           c0 = d0; c2 = d2; c3 = d3; c4 = d4;
           pos = np;
           if ((base & 0x3ffffffu) == 0x3fffc00u)       // fold long before a 32-bit lane sum can wrap
@@ -465,7 +526,7 @@ void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint3
 
       uint32_t last0, last4, clen = L;
       if (drun)
-        { clen = nn0;                                    // Pack_Tag's count, QV.c:810-819
+        { clen = wave_sum(nn0);                          // Pack_Tag's count, QV.c:810-819
           if (C0 > 0)                                    // trailing run token
             { const uint32_t e = s_tok[DX_DRUN][C0 > 255u ? 255u : C0];
               T0   += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
