@@ -235,24 +235,13 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 // Symbol histograms live in LDS with every bin replicated HREP times (copy = lane & (HREP-1)),
 // which divides the same-address serialisation of ds_add_u32 on the dominant symbols by HREP.
 
-#ifdef HIST_EXP
-__device__ uint32_t g_sink;
-#endif
 __device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool full, uint32_t *h)
 { const uint32_t k = (uint32_t) lane_id() & (HREP - 1);
   if (full)
     {
-#ifdef HIST_EXP
-      uint32_t sink = 0;
-      #pragma unroll
-      for (int b = 0; b < 16; b++)
-        sink ^= (BYTE_OF(c, b) * HREP + k) << b;
-      if (sink == 0x12345678u) g_sink = sink;
-#else
       #pragma unroll
       for (int b = 0; b < 16; b++)
         atomicAdd(&h[BYTE_OF(c, b) * HREP + k], 1u);
-#endif
     }
   else
     for (int b = 0; b < valid; b++)
@@ -811,17 +800,6 @@ __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, i
     }
 }
 
-// a token of 1..56 bits (right-aligned in tok) at bit offset q of the window
-__device__ __forceinline__ void place_token(uint32_t *win, uint32_t q, uint64_t tok, uint32_t len)
-{ const uint64_t V = tok << (64u - len);                         // left-aligned
-  const uint32_t s = q & 31u, w = q >> 5;
-  const uint64_t A = V >> s;
-  const uint32_t W2 = (uint32_t) (V << (32u - s));               // s == 0: shifts everything out
-  atomicOr(&win[w], (uint32_t) (A >> 32));
-  if ((uint32_t) A) atomicOr(&win[w + 1], (uint32_t) A);
-  if (W2)           atomicOr(&win[w + 2], W2);
-}
-
 // one step of Encode_Run (QV.c:475-497).  The step's non-run symbols (dense list from run_collect)
 // are handled in passes of up to 64*RUN_TP tokens: every lane takes T <= RUN_TP consecutive tokens,
 // chains their (run code [+ 16-bit literal] + symbol code) pieces into one string of <= 128 bits,
@@ -1311,7 +1289,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   DX_HIP(ctx, hipSetDevice(ctx->device));
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
-  DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 16), DX_BLOCK,
+  DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
             a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
