@@ -35,14 +35,7 @@
 #define TAG_WIN_WORDS 128                          // per-wave window of the tag segment
 #define TAG_FLUSH_BITS 1024u
 
-#ifndef HREP
-#define HREP 4                                     // replication of the LDS symbol histograms (1: 4.05 ms, 2: 3.14, 4: 2.70, 8: 2.79 per 200k entries)
-#endif
-
 // minimum waves per SIMD the register allocator must leave room for (caps VGPRs: 512 / waves)
-#ifndef HIST_WAVES
-#define HIST_WAVES 4
-#endif
 #ifndef SIZES_WAVES
 #define SIZES_WAVES 4
 #endif
@@ -232,54 +225,88 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 // =============================================================================================
 //  histogram pass (QV.c:702-724, 988-1017)
 // =============================================================================================
-// Symbol histograms live in LDS with every bin replicated HREP times (copy = lane & (HREP-1)),
-// which divides the same-address serialisation of ds_add_u32 on the dominant symbols by HREP.
+// ds_add_u32 is serviced in two groups of 32 lanes over 32 banks of 4 bytes, and lanes that hit
+// one bank (same bin or not) take one cycle each.  So every bin is kept 32 times, copy = lane & 31
+// in consecutive dwords: within a group every lane then owns a bank and no histogram update ever
+// conflicts, whatever the symbol distribution.  That costs 32 x 4 B per bin, affordable for the
+// symbols 0..127 (all of a .quiva file's printable QVs) and run lengths 0..63 of the six
+// histograms with ONE workgroup of 16 waves per CU (80 KB); bytes >= 128 and runs >= 64 go to
+// ordinary 256-bin tables.
+#define HIST_BLOCK   1024
+#define HIST_NWAVE   (HIST_BLOCK / 64)
+#define HCOLS        32
+#define HSYM_FAST    128
+#define HRUN_FAST    64
 
-__device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool full, uint32_t *h)
-{ const uint32_t k = (uint32_t) lane_id() & (HREP - 1);
-  if (full)
+struct hist_lds
+{ uint32_t sym[4][HSYM_FAST][HCOLS];     // 64 KB
+  uint32_t run[2][HRUN_FAST][HCOLS];     // 16 KB
+  uint32_t slow[6][256];                 //  6 KB
+};
+#define HIST_FAST_WORDS (4 * HSYM_FAST * HCOLS + 2 * HRUN_FAST * HCOLS)
+
+__device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool full, uint32_t (*h)[HCOLS], uint32_t *slow)
+{ const uint32_t col = (uint32_t) lane_id() & (HCOLS - 1);
+  const bool wide = __any((int) ((c.x | c.y | c.z | c.w) & 0x80808080u));
+  if (full && !wide)
     {
       #pragma unroll
       for (int b = 0; b < 16; b++)
-        atomicAdd(&h[BYTE_OF(c, b) * HREP + k], 1u);
+        atomicAdd(&h[BYTE_OF(c, b)][col], 1u);
     }
   else
     for (int b = 0; b < valid; b++)
-      atomicAdd(&h[chunk_byte(c, b) * HREP + k], 1u);
+      { const uint32_t x = chunk_byte(c, b);
+        if (x < HSYM_FAST) atomicAdd(&h[x][col], 1u);
+        else               atomicAdd(&slow[x], 1u);
+      }
 }
 
 // one step of a run-coded stream: non-run symbols and the run before each (QV.c:709-724); the run
 // character itself is counted with popcounts instead of LDS atomics (it is 80-85 % of the stream)
 __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c, int valid, uint32_t sv, uint32_t rc,
-                                               uint32_t &C, uint32_t &nrun, uint32_t *hs, uint32_t *hr)
+                                               uint32_t &C, uint32_t &nrun, uint32_t (*hs)[HCOLS], uint32_t *slow_s,
+                                               uint32_t (*hr)[HCOLS], uint32_t *slow_r)
 { const int      lane  = lane_id();
-  const uint32_t k     = (uint32_t) lane & (HREP - 1);
+  const uint32_t col   = (uint32_t) lane & (HCOLS - 1);
   const uint32_t total = run_collect(R, c, valid, rc);
   nrun += sv - total;                                            // wave-uniform
   for (uint32_t i = lane; i < total; i += 64)
     { RUN_TOKEN(R, i, C, pos, x, run)
-      atomicAdd(&hr[run > 255u ? 255u : run], 1u);               // QV.c:717-720
-      atomicAdd(&hs[x * HREP + k], 1u);
+      if (run < HRUN_FAST) atomicAdd(&hr[run][col], 1u);
+      else                 atomicAdd(&slow_r[run > 255u ? 255u : run], 1u);       // QV.c:717-720
+      if (x < HSYM_FAST)   atomicAdd(&hs[x][col], 1u);
+      else                 atomicAdd(&slow_s[x], 1u);
     }
   C = run_after(R, total, sv, C);
   wave_sync();
 }
 
-__global__ __launch_bounds__(DX_BLOCK, HIST_WAVES)
+// bin of the histogram g_hist[6*256] that LDS word k (of the fast tables, then the slow ones) counts
+__device__ __forceinline__ uint32_t hist_bin_of(uint32_t k)
+{ if (k < 4 * HSYM_FAST * HCOLS)
+    return (k / (HSYM_FAST * HCOLS)) * 256u + (k / HCOLS) % HSYM_FAST;
+  k -= 4 * HSYM_FAST * HCOLS;
+  if (k < 2 * HRUN_FAST * HCOLS)
+    return (4u + k / (HRUN_FAST * HCOLS)) * 256u + (k / HCOLS) % HRUN_FAST;
+  return k - 2 * HRUN_FAST * HCOLS;
+}
+
+__global__ __launch_bounds__(HIST_BLOCK)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
                unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot)
-{ __shared__ uint32_t s_sym[4][256 * HREP];
-  __shared__ uint32_t s_run[2][256];
-  __shared__ __attribute__((aligned(16))) uint8_t s_chunk[DX_WAVES_PER_BLK][DX_STEP];
-  __shared__ uint16_t s_list[DX_WAVES_PER_BLK][DX_STEP];
+{ __shared__ hist_lds H;
+  __shared__ __attribute__((aligned(16))) uint8_t s_chunk[HIST_NWAVE][DX_STEP];
+  __shared__ uint16_t s_list[HIST_NWAVE][DX_STEP];
   const int      lane  = lane_id();
   const int      tid   = threadIdx.x;
-  const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (tid >> 6);
-  const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  const uint64_t wave0 = (uint64_t) blockIdx.x * HIST_NWAVE + (tid >> 6);
+  const uint64_t nwave = (uint64_t) gridDim.x * HIST_NWAVE;
   const run_lds  R     = { s_chunk[tid >> 6], s_list[tid >> 6] };
+  uint32_t *const words = &H.sym[0][0][0];                      // the whole of H as words
+  const uint32_t  nwords = sizeof(hist_lds) / 4;
 
-  for (int k = tid; k < 4 * 256 * HREP; k += DX_BLOCK) (&s_sym[0][0])[k] = 0;
-  for (int k = tid; k < 2 * 256; k += DX_BLOCK)        (&s_run[0][0])[k] = 0;
+  for (uint32_t k = tid; k < nwords; k += HIST_BLOCK) words[k] = 0;
   __syncthreads();
 
   uint64_t tot = 0, since = 0;
@@ -303,33 +330,29 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
           const bool     full  = sv == DX_STEP;
           const int      valid = valid_of(pos, L);
-          if (drun) hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, s_sym[DX_DEL], s_run[0]);
-          else      hist_plain_step(c0, valid, full, s_sym[DX_DEL]);
-          hist_plain_step(c2, valid, full, s_sym[DX_INS]);
-          hist_plain_step(c3, valid, full, s_sym[DX_MRG]);
-          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, s_sym[DX_SUB], s_run[1]);
-          else      hist_plain_step(c4, valid, full, s_sym[DX_SUB]);
+          if (drun) hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.sym[DX_DEL], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN]);
+          else      hist_plain_step(c0, valid, full, H.sym[DX_DEL], H.slow[DX_DEL]);
+          hist_plain_step(c2, valid, full, H.sym[DX_INS], H.slow[DX_INS]);
+          hist_plain_step(c3, valid, full, H.sym[DX_MRG], H.slow[DX_MRG]);
+          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.sym[DX_SUB], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN]);
+          else      hist_plain_step(c4, valid, full, H.sym[DX_SUB], H.slow[DX_SUB]);
           c0 = d0; c2 = d2; c3 = d3; c4 = d4;
           pos = np;
         }
       if (drun)                                        // trailing run + the run character's own count
-        { if (C0 > 0 && lane == 0) atomicAdd(&s_run[0][C0 > 255u ? 255u : C0], 1u);
-          if (lane == 0 && n0) atomicAdd(&s_sym[DX_DEL][(uint32_t) a.delChar * HREP], n0);
+        { if (C0 > 0 && lane == 0) atomicAdd(&H.slow[DX_DRUN][C0 > 255u ? 255u : C0], 1u);
+          if (lane == 0 && n0) atomicAdd(&H.slow[DX_DEL][a.delChar], n0);
         }
       if (srun)
-        { if (C4 > 0 && lane == 0) atomicAdd(&s_run[1][C4 > 255u ? 255u : C4], 1u);
-          if (lane == 0 && n4) atomicAdd(&s_sym[DX_SUB][(uint32_t) a.subChar * HREP], n4);
+        { if (C4 > 0 && lane == 0) atomicAdd(&H.slow[DX_SRUN][C4 > 255u ? 255u : C4], 1u);
+          if (lane == 0 && n4) atomicAdd(&H.slow[DX_SUB][a.subChar], n4);
         }
       tot   += L;
       since += L;
       if (since >= (1ull << 26))                       // keep the 32-bit LDS bins far from overflow
-        { for (int k = lane; k < 4 * 256 * HREP; k += 64)
-            { const uint32_t v = atomicExch(&(&s_sym[0][0])[k], 0u);
-              if (v) atomicAdd(&g_hist[k / HREP], (unsigned long long) v);
-            }
-          for (int k = lane; k < 2 * 256; k += 64)
-            { const uint32_t v = atomicExch(&(&s_run[0][0])[k], 0u);
-              if (v) atomicAdd(&g_hist[4 * 256 + k], (unsigned long long) v);
+        { for (uint32_t k = lane; k < nwords; k += 64)
+            { const uint32_t v = atomicExch(&words[k], 0u);
+              if (v) atomicAdd(&g_hist[hist_bin_of(k)], (unsigned long long) v);
             }
           since = 0;
         }
@@ -337,14 +360,16 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   if (lane == 0 && tot)
     atomicAdd(g_tot, (unsigned long long) tot);
   __syncthreads();
-  for (int k = tid; k < 4 * 256; k += DX_BLOCK)
+  // fold the 32 copies of every fast bin (rotated start: the lanes of a wave read distinct banks)
+  for (uint32_t bin = tid; bin < HIST_FAST_WORDS / HCOLS; bin += HIST_BLOCK)
     { uint32_t v = 0;
-      for (int j = 0; j < HREP; j++) v += (&s_sym[0][0])[k * HREP + j];
-      if (v) atomicAdd(&g_hist[k], (unsigned long long) v);
+      for (uint32_t j = 0; j < HCOLS; j++)
+        v += words[bin * HCOLS + ((j + (uint32_t) lane) & (HCOLS - 1))];
+      if (v) atomicAdd(&g_hist[hist_bin_of(bin * HCOLS)], (unsigned long long) v);
     }
-  for (int k = tid; k < 2 * 256; k += DX_BLOCK)
-    { const uint32_t v = (&s_run[0][0])[k];
-      if (v) atomicAdd(&g_hist[4 * 256 + k], (unsigned long long) v);
+  for (uint32_t k = tid; k < 6 * 256; k += HIST_BLOCK)
+    { const uint32_t v = (&H.slow[0][0])[k];
+      if (v) atomicAdd(&g_hist[k], (unsigned long long) v);
     }
 }
 
@@ -1131,7 +1156,8 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   if ((e = dx_scratch(ctx, (6 * 256 + 1) * 8, (void **) &d_hist))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 1) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
-  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, dx_grid_waves(ctx, b->n, 32), DX_BLOCK,
+  const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE;       // one 16-wave workgroup per CU
+  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, (int) (hist_blocks < (uint64_t) ctx->num_cu ? hist_blocks : (uint64_t) ctx->num_cu), HIST_BLOCK,
             a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256);
   uint64_t host[6 * 256 + 1];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));

@@ -140,6 +140,39 @@ def test_qv_scan_vs_oracle(ctx, seed, n, mean):
         assert (hist[s] == want[s]).all(), f"histogram {s}"
 
 
+def test_qv_scan_wide_bytes_and_long_runs(ctx):
+    """Bytes >= 128 and runs >= 64 leave the conflict-free 32-copy bins of k_qv_hist for its plain
+    tables; the file still encodes byte-identically."""
+    rng = np.random.Generator(np.random.PCG64(17))
+    c = synth.make_quiva(60, seed=9, mean=5000)
+    st0 = O.qv_scan(c.text)
+    txt = bytearray(c.text)
+    for i in range(60):
+        L, o = int(c.len[i]), int(c.off[i])
+        for line in (0, 2, 3, 4):
+            at = o + line * (L + 1)
+            for pos in rng.integers(0, L, max(1, L // 40)):
+                v = int(rng.integers(128, 256))
+                if line != 0 or txt[o + (L + 1) + int(pos)] not in b"nN":       # keep the N-tag <-> delChar pairing
+                    txt[at + int(pos)] = v
+        if i % 7 == 3 and L > 700:                                # long runs of both run characters
+            txt[o + 100: o + 600] = bytes([st0.delChar]) * 500
+            txt[o + (L + 1) + 100: o + (L + 1) + 600] = b"N" * 500
+            if st0.subChar >= 0:
+                txt[o + 4 * (L + 1) + 50: o + 4 * (L + 1) + 450] = bytes([st0.subChar]) * 400
+    c.text = bytes(txt)
+    st = O.qv_scan(c.text)
+    b, keep = _upload_quiva(ctx, c)
+    p = ctx.qv_prescan(b)
+    assert (p.delChar, p.subChar, p.del_first, p.sub_first) == (st.delChar, st.subChar, st.del_first, st.sub_first)
+    hist, tot = ctx.qv_hist(b, p)
+    want = O.hist_array(st)
+    want[4:6] -= 1
+    assert tot == st.totChar and (hist == want).all()
+    assert hist[:4, 128:].sum() > 1000 and hist[4:, 64:].sum() > 10
+    assert ctx.dexqv(c.text) == O.dexqv(c.text)
+
+
 def test_qv_scan_late_delchar_and_none(ctx):
     txt = O.golden("qv_runs.quiva")
     off, ln, hdr, _ = api.index_quiva(txt)
