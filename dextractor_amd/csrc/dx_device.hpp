@@ -80,11 +80,14 @@ __device__ __forceinline__ uint32_t chunk_byte(const u32x4 &v, int b)
 __device__ __forceinline__ uint32_t chunk_eq_mask(const u32x4 &v, uint32_t c)
 { uint32_t m = 0;
   #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 3; i >= 0; i--)
     { uint32_t w = chunk_word(v, i) ^ (c * 0x01010101u);
       // zero-byte detector: exact per byte (no cross-byte borrow)
       uint32_t z = ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu);   // 0x80 where byte == 0
-      m |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * i);
+      // flags of bytes 0..2 sit at bits 7, 15, 23: a 24-bit multiply by 1 + 2^7 + 2^14 lines them
+      // up at bits 14..16 (all partial products fall on distinct bits, so nothing carries)
+      const uint32_t low3 = (__umul24(z >> 7, 0x4081u) >> 14) & 7u;
+      m = (m << 4) | ((z >> 31) << 3) | low3;
     }
   return m;
 }
