@@ -108,8 +108,9 @@ __device__ __forceinline__ uint32_t run_collect(const run_lds &R, const u32x4 &c
   const uint32_t incl = wave_incl_scan(cnt);
   uint32_t       idx  = incl - cnt;
   *(u32x4 *) (R.chunk + 16 * lane) = c;
+  const uint32_t p16 = 16u * (uint32_t) lane;
   while (nr)
-    { R.list[idx++] = (uint16_t) (16 * lane + __ffs(nr) - 1);
+    { R.list[idx++] = (uint16_t) (p16 + (uint32_t) __builtin_ctz(nr));
       nr &= nr - 1u;
     }
   wave_sync();
