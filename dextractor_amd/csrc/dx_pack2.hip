@@ -35,6 +35,8 @@ __device__ __forceinline__ uint32_t sym_code(uint32_t x)
     return (x == '1') ? 0u : (x == '2') ? 1u : (x == '3' || x == 'G') ? 2u : 3u;
 }
 
+#define BYTE_AT(c, b) ((chunk_word(c, (b) >> 2) >> (8 * ((b) & 3))) & 0xffu)
+
 __device__ __forceinline__ u32x4 p2_fetch(const uint8_t *p, uint32_t pos, uint32_t T)
 { return load_chunk(p + pos, pos >= T ? 0 : (T - pos >= 16u ? 16 : (int) (T - pos))); }
 
@@ -46,16 +48,20 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
                     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
                     uint32_t *__restrict__ status)
 { __shared__ uint32_t s_win[DX_WAVES_PER_BLK][P2_WIN_WORDS];
+  __shared__ uint8_t  s_code[256];       // Number_Read / Number_Arrow as a table: 256 B = one LDS
+                                         // bank per dword, so the 64 look-ups of a wave never conflict
   const int       lane  = lane_id();
   const int       wid   = threadIdx.x >> 6;
   const uint64_t  wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + wid;
   const uint64_t  nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
 
+  for (int k = threadIdx.x; k < 256; k += DX_BLOCK)
+    s_code[k] = (uint8_t) sym_code<ALPHA>((uint32_t) k);
   wave_out o;
   o.win = s_win[wid];
   for (int j = lane; j < P2_WIN_WORDS; j += 64)
     o.win[j] = 0;
-  wave_sync();
+  __syncthreads();
 
   for (uint64_t r = wave0; r < n; r += nwave)
     { const uint8_t *src = text + off[r];
@@ -75,17 +81,23 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
       u32x4 c = p2_fetch(src, pos, T);
       for (uint32_t base = 0; base < T; base += DX_STEP)
         { const u32x4 d = p2_fetch(src, pos + DX_STEP, T);       // next step already in flight
-          const int valid = pos >= T ? 0 : (T - pos >= 16u ? 16 : (int) (T - pos));
-          const uint32_t keep = ~chunk_eq_mask(c, '\n') & ((1u << valid) - 1u);
-          const uint32_t cnt  = __popc(keep);
-          uint32_t acc = 0;                              // kept codes, first one in the top bits
-          int      sh  = 30;
+          const uint32_t valid = pos >= T ? 0u : (T - pos >= 16u ? 16u : T - pos);
+          // the 16 bytes' codes, first one in the top bits, as if there were no line ends
+          uint32_t acc = 0;
           #pragma unroll
           for (int b = 0; b < 16; b++)
-            if ((keep >> b) & 1u)
-              { acc |= sym_code<ALPHA>((chunk_word(c, b >> 2) >> (8 * (b & 3))) & 0xffu) << sh;
-                sh  -= 2;
-              }
+            acc = (acc << 2) | (uint32_t) s_code[BYTE_AT(c, b)];
+          // drop the slots of the line ends, last one first so that the earlier slots stay put
+          uint32_t nl = chunk_eq_mask(c, '\n');                  // missing bytes read as 0: never set
+          const uint32_t cnt = valid - __popc(nl);
+          while (nl)
+            { const uint32_t p = 31u - (uint32_t) __clz(nl);      // byte position; its slot: bits 31-2p, 30-2p
+              const uint32_t K = 30u - 2u * p;
+              const uint32_t below = (1u << K) - 1u, upto = (4u << K) - 1u;
+              acc = (acc & ~upto) | ((acc & below) << 2);
+              nl ^= 1u << p;
+            }
+          acc = cnt ? acc & (~0u << (32u - 2u * cnt)) : 0u;      // slots past the kept symbols (missing bytes)
           const uint32_t incl = wave_incl_scan(cnt);
           if (cnt)
             { const uint32_t bit = o.winbits + 2u * (incl - cnt);
