@@ -138,14 +138,66 @@ __device__ __forceinline__ uint32_t sym_letter(uint32_t code)
   return '1' + code;
 }
 
+// 16 text bytes of the generic case: any width, chunks at the end of the text
+template <int LETTERS>
+__device__ __forceinline__ void decode_chunk_generic(const uint8_t *src, uint8_t *dst, uint32_t q0, uint32_t T,
+                                                     uint32_t clen, uint32_t width)
+{ const uint32_t W1    = width + 1u;
+  const int      valid = (T - q0 >= 16u) ? 16 : (int) (T - q0);
+  const uint32_t line  = q0 / W1;
+  uint32_t       col   = q0 - line * W1;
+  const uint32_t i0    = q0 - line;                              // symbol index of text byte q0 (if a letter)
+  const uint32_t b0    = i0 >> 2;                                // first packed byte needed
+  uint64_t bits = 0;                                             // packed bytes b0.., first in the low byte
+  if (b0 + 8u <= clen)
+    bits = *(const u64_u *) (src + b0);
+  else
+    for (uint32_t k = b0; k < clen; k++)
+      bits |= (uint64_t) src[k] << (8 * (k - b0));
+
+  uint32_t w[4] = { 0u, 0u, 0u, 0u };
+  uint32_t idx  = i0;
+  #pragma unroll
+  for (int b = 0; b < 16; b++)
+    { uint32_t ch;
+      if (col == width || q0 + b == T - 1u)
+        { ch = '\n'; col = 0; }
+      else
+        { const uint32_t rel = idx - 4u * b0;                    // 0 .. 18
+          const uint32_t code = (uint32_t) (bits >> (8u * (rel >> 2) + 6u - 2u * (rel & 3u))) & 3u;
+          ch = sym_letter<LETTERS>(code);
+          idx += 1; col += 1;
+        }
+      w[b >> 2] |= ch << (8 * (b & 3));
+    }
+  if (valid == 16)
+    { u32x4 v = { w[0], w[1], w[2], w[3] };
+      *(u32x4_u *) (dst + q0) = v;
+    }
+  else
+    for (int b = 0; b < valid; b++)
+      dst[q0 + b] = (uint8_t) (w[b >> 2] >> (8 * (b & 3)));
+}
+
 template <int LETTERS>
 __global__ __launch_bounds__(DX_BLOCK)
 void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
                     const uint32_t *__restrict__ nsym, uint64_t n, uint32_t width,
                     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off)
-{ const int      lane  = lane_id();
+{ __shared__ uint32_t s_quad[256];       // packed byte -> its four letters (Lower_Read & co., DB.c:367-389)
+  const int      lane  = lane_id();
   const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
   const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  for (uint32_t k = threadIdx.x; k < 256u; k += DX_BLOCK)
+    s_quad[k] = sym_letter<LETTERS>(k >> 6) | (sym_letter<LETTERS>((k >> 4) & 3u) << 8)
+              | (sym_letter<LETTERS>((k >> 2) & 3u) << 16) | (sym_letter<LETTERS>(k & 3u) << 24);
+  __syncthreads();
+
+  // text position 16*lane + 1024*step as (line, column): advanced incrementally, no division per step
+  const uint32_t W1     = width + 1u;
+  const uint32_t line0  = (16u * (uint32_t) lane) / W1, col0 = 16u * (uint32_t) lane - line0 * W1;
+  const uint32_t dline  = DX_STEP / W1, dcol = DX_STEP - dline * W1;
+  const bool     narrow = width < 16u;   // several line ends may fall into 16 bytes: generic path only
 
   for (uint64_t r = wave0; r < n; r += nwave)
     { const uint8_t *src  = in + in_off[r];
@@ -153,45 +205,42 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
       const uint32_t L    = nsym[r];
       const uint32_t clen = (L + 3u) >> 2;
       const uint32_t T    = L + (L + width - 1u) / width;        // letters + newlines
-      const uint32_t W1   = width + 1u;
+      uint32_t line = line0, col = col0;
 
       for (uint32_t base = 0; base < T; base += DX_STEP)
         { const uint32_t q0 = base + 16u * lane;
-          if (q0 >= T) continue;
-          const int valid = (T - q0 >= 16u) ? 16 : (int) (T - q0);
-          uint32_t  line  = q0 / W1;
-          uint32_t  col   = q0 - line * W1;
-          const uint32_t i0 = q0 - line;                         // symbol index of text byte q0 (if a letter)
-          const uint32_t b0 = i0 >> 2;                           // first packed byte needed
-          uint64_t  bits = 0;                                    // packed bytes b0.., first in the low byte
-          if (b0 + 8u <= clen)
-            bits = *(const u64_u *) (src + b0);
-          else
-            for (uint32_t k = b0; k < clen; k++)
-              bits |= (uint64_t) src[k] << (8 * (k - b0));
-
-          uint32_t w[4] = { 0u, 0u, 0u, 0u };
-          uint32_t idx  = i0;
-          #pragma unroll
-          for (int b = 0; b < 16; b++)
-            { uint32_t ch;
-              if (col == width || q0 + b == T - 1u)
-                { ch = '\n'; col = 0; }
-              else
-                { const uint32_t rel = idx - 4u * b0;            // 0 .. 18
-                  const uint32_t code = (uint32_t) (bits >> (8u * (rel >> 2) + 6u - 2u * (rel & 3u))) & 3u;
-                  ch = sym_letter<LETTERS>(code);
-                  idx += 1; col += 1;
+          const uint32_t i0 = q0 - line;                         // symbols before text byte q0
+          const uint32_t b0 = i0 >> 2;
+          if (q0 + 16u < T && b0 + 8u <= clen && !narrow)
+            { // 16 (or 15 + line end) letters from 8 packed bytes: symbol k of the chunk in bits 31-2k, 30-2k
+              const uint64_t raw = *(const u64_u *) (src + b0);
+              const uint64_t be  = ((uint64_t) __builtin_bswap32((uint32_t) raw) << 32) | __builtin_bswap32((uint32_t) (raw >> 32));
+              uint32_t cw = (uint32_t) ((be << (2u * (i0 & 3u))) >> 32);
+              const uint32_t nlpos = width - col;                // offset of the line end in this chunk (>= 16: none)
+              if (nlpos < 16u)
+                { const uint32_t K = 30u - 2u * nlpos;           // open a 2-bit hole at slot nlpos
+                  const uint32_t keep = ~((4u << K) - 1u);       // slots before it
+                  cw = (cw & keep) | ((cw & ~keep) >> 2);
                 }
-              w[b >> 2] |= ch << (8 * (b & 3));
-            }
-          if (valid == 16)
-            { u32x4 v = { w[0], w[1], w[2], w[3] };
+              u32x4 v;
+              v.x = s_quad[cw >> 24];
+              v.y = s_quad[(cw >> 16) & 0xffu];
+              v.z = s_quad[(cw >> 8) & 0xffu];
+              v.w = s_quad[cw & 0xffu];
+              if (nlpos < 16u)
+                { const uint32_t m = 0xffu << (8u * (nlpos & 3u)), j = nlpos >> 2;
+                  const uint32_t nl4 = 0x0a0a0a0au;
+                  v.x = j == 0u ? (v.x & ~m) | (nl4 & m) : v.x;
+                  v.y = j == 1u ? (v.y & ~m) | (nl4 & m) : v.y;
+                  v.z = j == 2u ? (v.z & ~m) | (nl4 & m) : v.z;
+                  v.w = j == 3u ? (v.w & ~m) | (nl4 & m) : v.w;
+                }
               *(u32x4_u *) (dst + q0) = v;
             }
-          else
-            for (int b = 0; b < valid; b++)
-              dst[q0 + b] = (uint8_t) (w[b >> 2] >> (8 * (b & 3)));
+          else if (q0 < T)
+            decode_chunk_generic<LETTERS>(src, dst, q0, T, clen, width);
+          line += dline; col += dcol;
+          if (col >= W1) { col -= W1; line += 1u; }
         }
     }
 }

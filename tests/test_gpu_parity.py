@@ -108,6 +108,21 @@ def test_pack2_every_small_length(ctx):
             assert ctx.undexar(want, 80) == c.text
 
 
+@pytest.mark.parametrize("width", [1, 2, 14, 15, 16, 17, 18, 31, 63, 64, 65, 127, 1023, 1024, 1025, 4000])
+def test_unpack2_line_widths(ctx, width):
+    """undexta/undexar -w: widths around the 16-byte lane (several line ends per lane below 16, the
+    one-line-end fast path from 16 up) and around the 1 KiB step; reads whose last line is full,
+    one short, and empty reads (undexta.c:263-270)."""
+    lens = np.array([0, 1, 15, 16, 17, 33, width, width + 1, 2 * width, 2 * width - 1, 3 * width + 5, 1024, 5000, 12345],
+                    dtype=np.uint32)
+    c = synth.make_seqfile("fasta", len(lens), seed=23, lens=lens)
+    img = O.dexta(c.text)
+    assert ctx.undexta(img, False, width) == O.undexta(img, False, width)
+    c = synth.make_seqfile("arrow", len(lens), seed=24, lens=lens)
+    img = O.dexar(c.text)
+    assert ctx.undexar(img, width) == O.undexar(img, width)
+
+
 def test_pack2_arbitrary_bytes(ctx):
     """Every byte value as a 'base': the maps of DB.c:393-441 (bytes >= 128 -> 0 / 3)."""
     body = bytes(b for b in range(256) if b not in (10, 62)) * 3
