@@ -14,8 +14,11 @@
 // walk dx_qv_walk).  k_qv_decode_tags then rebuilds the tag line of each entry from the decoded
 // deletion line, one wavefront per entry, coalesced.
 //
-// Roofline: HBM (reads C, writes 5 bytes per base); in practice the lane-serial decode is
-// latency/VALU bound -- it exists to close the on-device round trip, not as the headline path.
+// Roofline: HBM (reads C, writes 5 bytes per base).  With a lane per stream the 64 lanes of a wave
+// touch 64 different cache lines per access, so what matters is bytes moved per request: each lane
+// reads its stream 16 bytes at a time into registers and stages its output in a private 64-byte LDS
+// row that leaves as one contiguous burst (4-byte reads / 8-byte stores moved 13x / 4.8x the
+// algorithmic bytes: 75 GB of HBM traffic per 10 GB decoded).
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 
@@ -34,15 +37,33 @@ struct dec_args
   int             flip;         // words were written by a host of the other endianness (GETFLIP, QV.c:553-568)
 };
 
-// MSB-first bit reader over little-endian 32-bit words; never reads past `end`
-struct bitrd { const uint8_t *p, *end; uint64_t buf; int nb; bool flip; };
+// MSB-first bit reader over little-endian 32-bit words; never reads past `end`.  Words come from a
+// 16-byte register cache refilled with one global_load_dwordx4.
+struct bitrd { const uint8_t *p, *end; uint64_t buf; int nb; bool flip; u32x4 cache; int ci; };
+
+__device__ __forceinline__ void br_init(bitrd &r, const uint8_t *p, const uint8_t *end, bool flip)
+{ r.p = p; r.end = end; r.buf = 0; r.nb = 0; r.flip = flip; r.ci = 4;
+  r.cache.x = r.cache.y = r.cache.z = r.cache.w = 0u;
+}
 
 __device__ __forceinline__ void br_fill(bitrd &r)
 { while (r.nb <= 32 && r.p < r.end)
-    { const uint32_t w = *(const u32_u *) r.p;
+    { if (r.ci == 4)
+        { if (r.p + 16 <= r.end)
+            r.cache = *(const u32x4_u *) r.p;
+          else                                             // segments are whole words (QV.c:436-442)
+            { r.cache.x = *(const u32_u *) r.p;
+              r.cache.y = r.p + 8  <= r.end ? *(const u32_u *) (r.p + 4) : 0u;
+              r.cache.z = r.p + 12 <= r.end ? *(const u32_u *) (r.p + 8) : 0u;
+              r.cache.w = 0u;
+            }
+          r.ci = 0;
+        }
+      const uint32_t w = r.ci == 0 ? r.cache.x : (r.ci == 1 ? r.cache.y : (r.ci == 2 ? r.cache.z : r.cache.w));
       r.buf |= (uint64_t) (r.flip ? __builtin_bswap32(w) : w) << (32 - r.nb);
       r.nb  += 32;
       r.p   += 4;
+      r.ci  += 1;
     }
 }
 __device__ __forceinline__ uint32_t br_peek16(const bitrd &r) { return (uint32_t) (r.buf >> 48); }
@@ -67,15 +88,29 @@ __device__ __forceinline__ uint32_t dec_symbol(bitrd &r, const uint16_t *prim, c
   return e & 0xffu;
 }
 
-// byte sink: 8 bytes gathered in a register, stored with one (unaligned) 8-byte store
-struct bsink { uint8_t *p; uint64_t acc; int cnt; };
+// byte sink: 8 bytes gathered in a register go to the lane's LDS row (4 slots); a full row leaves
+// as 32 contiguous bytes (two unaligned 16-byte stores back to back)
+#define DEC_ROW_SLOTS 4
+#define DEC_ROW_BYTES 40                                   // 32 used; a 10-dword stride spreads the rows over the banks
+struct bsink { uint8_t *p; uint64_t acc; int cnt; uint64_t *row; int slot; };
+
+__device__ __forceinline__ void bs_push8(bsink &o)
+{ o.row[o.slot] = o.acc;
+  o.acc = 0; o.cnt = 0;
+  if (++o.slot == DEC_ROW_SLOTS)
+    { const uint64_t a0 = o.row[0], a1 = o.row[1], a2 = o.row[2], a3 = o.row[3];
+      const u32x4 v0 = { (uint32_t) a0, (uint32_t) (a0 >> 32), (uint32_t) a1, (uint32_t) (a1 >> 32) };
+      const u32x4 v1 = { (uint32_t) a2, (uint32_t) (a2 >> 32), (uint32_t) a3, (uint32_t) (a3 >> 32) };
+      u32x4_u *g = (u32x4_u *) o.p;
+      g[0] = v0; g[1] = v1;
+      o.p += 8 * DEC_ROW_SLOTS; o.slot = 0;
+    }
+}
 
 __device__ __forceinline__ void bs_put(bsink &o, uint32_t b)
 { o.acc |= (uint64_t) b << (8 * o.cnt);
   if (++o.cnt == 8)
-    { *(u64_u *) o.p = o.acc;
-      o.p += 8; o.acc = 0; o.cnt = 0;
-    }
+    bs_push8(o);
 }
 
 __device__ __forceinline__ void bs_fill(bsink &o, uint32_t b, uint32_t count)
@@ -87,34 +122,50 @@ __device__ __forceinline__ void bs_fill(bsink &o, uint32_t b, uint32_t count)
       o.cnt += (int) take;
       count -= take;
       if (o.cnt == 8)
-        { *(u64_u *) o.p = o.acc;
-          o.p += 8; o.acc = 0; o.cnt = 0;
-        }
+        bs_push8(o);
     }
 }
 
 __device__ __forceinline__ void bs_end(bsink &o)
-{ for (int k = 0; k < o.cnt; k++)
+{ for (int k = 0; k < o.slot; k++)
+    { *(u64_u *) o.p = o.row[k];
+      o.p += 8;
+    }
+  for (int k = 0; k < o.cnt; k++)
     o.p[k] = (uint8_t) (o.acc >> (8 * k));
   o.p += o.cnt;
+  o.slot = 0;
 }
 
-__global__ __launch_bounds__(DX_BLOCK)
-void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *status)
+#define DEC_BLOCK 1024                                     // two 16-wave workgroups per CU, each with its own tables
+#define DEC_NWAVE (DEC_BLOCK / 64)
+
+__global__ __launch_bounds__(DEC_BLOCK, 2)
+void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *status, uint32_t *next_task)
 { __shared__ uint16_t s_dec[6][DX_DEC_SIZE];               // 24 KB
   __shared__ uint32_t s_long[6][1 + DX_LONG_MAX];          // 6 KB
-  for (int k = threadIdx.x; k < 6 * DX_DEC_SIZE; k += DX_BLOCK)           (&s_dec[0][0])[k]  = g_dec[k];
-  for (int k = threadIdx.x; k < 6 * (1 + DX_LONG_MAX); k += DX_BLOCK)     (&s_long[0][0])[k] = g_long[k];
+  __shared__ __attribute__((aligned(8))) uint8_t s_row[DEC_BLOCK][DEC_ROW_BYTES];    // 40 KB
+  for (int k = threadIdx.x; k < 6 * DX_DEC_SIZE; k += DEC_BLOCK)          (&s_dec[0][0])[k]  = g_dec[k];
+  for (int k = threadIdx.x; k < 6 * (1 + DX_LONG_MAX); k += DEC_BLOCK)    (&s_long[0][0])[k] = g_long[k];
   __syncthreads();
 
-  // A wavefront decodes ONE stream kind (q) of 64 consecutive entries, one entry per lane: all its
-  // lanes then run the same loop (plain or run-coded) and only the trip counts differ.
-  const uint64_t nwave  = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  // A task = ONE stream kind (q) of 64 consecutive entries, one entry per lane: all lanes of the
+  // wavefront then run the same loop (plain or run-coded) and only the trip counts differ.  Tasks
+  // cost very different amounts (a run-coded line has a fifth of the tokens of a plain one), so
+  // the waves draw them from a counter, the expensive plain lines first.
   const uint64_t ngroup = (a.n + 63) / 64;                 // groups of 64 entries
-  for (uint64_t w = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6); w < 4 * ngroup; w += nwave)
-    { const int      q = (int) (w & 3);                    // 0 del, 1 ins, 2 mrg, 3 sub
-      const uint64_t r = (w >> 2) * 64 + (uint64_t) lane_id();
-      if (r >= a.n) continue;
+  for (;;)
+    { uint32_t t = 0;
+      if (lane_id() == 0)
+        t = atomicAdd(next_task, 1u);
+      t = uniform(t);
+      if ((uint64_t) t >= 4 * ngroup) break;               // every wave gets here: the counter only grows
+      // order: ins and mrg of every group, then del and sub
+      const uint64_t g = (uint64_t) t < 2 * ngroup ? t >> 1 : ((uint64_t) t - 2 * ngroup) >> 1;
+      const int      q = (uint64_t) t < 2 * ngroup ? 1 + (int) (t & 1u) : ((t & 1u) ? 3 : 0);
+      const uint64_t r = g * 64 + (uint64_t) lane_id();
+      if (r < a.n)                                         // lanes past the last entry idle through this task
+      {
       const int      line = q == 0 ? 0 : q + 1;            // output line / segment index
       const uint32_t L  = a.len[r];
       const uint32_t *sg = a.seg + 5 * r;
@@ -122,8 +173,9 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       for (int k = 0; k < line; k++)
         at += sg[k];
 
-      bitrd rd = { a.in + at, a.in + at + sg[line], 0, 0, a.flip != 0 };
-      bsink o  = { a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u), 0, 0 };
+      bitrd rd;
+      br_init(rd, a.in + at, a.in + at + sg[line], a.flip != 0);
+      bsink o  = { a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u), 0, 0, (uint64_t *) s_row[threadIdx.x], 0 };
       const int rc = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
       const uint16_t *prim = s_dec[q];
       const uint32_t *lng  = s_long[q];
@@ -169,6 +221,7 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       bs_put(o, '\n');
       bs_end(o);
       if (bad) atomicOr(status, 4u);
+      }
     }
 }
 
@@ -245,11 +298,13 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   a.in = d_in; a.rec_off = d_rec_off; a.hdr_off = d_hdr_off; a.seg = d_seg; a.len = d_len; a.n = n;
   a.out = d_out; a.out_off = d_out_off; a.delChar = ctx->delChar; a.subChar = ctx->subChar; a.upper = (flags & DX_DECODE_UPPER) != 0; a.flip = (flags & DX_DECODE_FLIP) != 0;
   for (int s = 0; s < 4; s++) a.type[s] = ctx->sym_type[s];
-  uint64_t blocks = (4 * ((n + 63) / 64) + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK;
-  const uint64_t cap = (uint64_t) ctx->num_cu * 8;
+  uint64_t blocks = (4 * ((n + 63) / 64) + DEC_NWAVE - 1) / DEC_NWAVE;
+  const uint64_t cap = (uint64_t) ctx->num_cu * 2;
   if (blocks > cap) blocks = cap;
-  DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DX_BLOCK, a, (const uint16_t *) ctx->d_dec,
-            (const uint32_t *) ctx->d_long, ctx->d_status);
+  uint32_t *d_next = (uint32_t *) (ctx->d_u64 + 16);       // task counter of k_qv_decode
+  DX_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
+  DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,
+            (const uint32_t *) ctx->d_long, ctx->d_status, d_next);
   DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
