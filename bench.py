@@ -50,6 +50,12 @@ def parse():
     return ap.parse_args()
 
 
+def trace(msg):
+    """BENCH_TRACE=1: stage markers on stderr (to localise a stall on the GPU box)."""
+    if os.environ.get("BENCH_TRACE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     if args.workload != "dexqv":
@@ -160,11 +166,14 @@ def main():
     if not args.no_verify:
         # size-independent property at full size: decode(encode(x)) == x, entirely on the device
         # (the decoder is fed by the encoder's own index); headers are copied, data lines rebuilt
+        trace("verify: allocate")
         d_back = torch.zeros_like(d_text)
         torch.cuda.synchronize()
         ctx.profile(True)
+        trace("verify: decode")
         ctx.qv_decode(p_out, p_rec, p_hoff, p_seg, p_len, n, True, Ptr(d_back), p_off)
         ctx.sync(); torch.cuda.synchronize()
+        trace("verify: compare")
         dec_ms = ctx.kernel_times().get("k_qv_decode", (0.0, 0))[0]
         ctx.profile(False)
         state["decode"] = {"kernel": "k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),
@@ -189,8 +198,10 @@ def main():
     if not args.no_verify:
         torch.cuda.synchronize()
         ctx.profile(True)
+        trace("front end: index")
         t1 = time.perf_counter()
         o2, l2, h2, pl2 = ctx.index_quiva_device(p_text, text_bytes)
+        trace("front end: done")
         t2 = time.perf_counter()
         kt = ctx.kernel_times().get("k_index", (0.0, 0))
         ctx.profile(False)
@@ -304,7 +315,9 @@ def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state, bi
         want = O.dexqv(sample, args.lossy)
         dt = time.perf_counter() - t0
         res.update(kind="port", value=round(5 * sbases / dt / 1e9, 4), seconds=round(dt, 2))
+    trace("cpu_baseline: reference done; GPU file driver on the sample")
     got = ctx.dexqv(sample, args.lossy)          # same sample through the GPU path (file driver)
+    trace("cpu_baseline: CLI end to end")
     res["gpu_output_identical"] = bool(got == want)
 
     # secondary number: end-to-end wall time of the drop-in CLI on the same sample file (tmpfs -> tmpfs,
@@ -326,6 +339,7 @@ def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state, bi
                                  "output_identical": bool(same)}
 
     # how the single-threaded reference would be deployed: one independent copy per host core
+    trace("cpu_baseline: all cores")
     cores = os.cpu_count() or 1
     if os.path.isfile(ref_bin) and cores > 1:
         S2 = min(4000, S)
@@ -350,6 +364,7 @@ def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state, bi
 
     # the big batch's LAST records (file offsets beyond 4 GiB) decoded by the oracle with the
     # batch's own tables must reproduce the last entries of the input image
+    trace("cpu_baseline: tail records")
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle as O

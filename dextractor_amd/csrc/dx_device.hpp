@@ -25,6 +25,16 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
   return ((uint64_t) hi << 32) | lo;
 }
 
+// Work distribution: the waves of a kernel draw their units (entries, reads) from a counter, so
+// units of very different length spread evenly.  The counter only grows, so every wave sees a
+// value >= n and leaves; the host zeroes it before the launch.
+__device__ __forceinline__ uint64_t next_unit(uint32_t *counter, uint32_t batch = 1u)
+{ uint32_t t = 0;
+  if (lane_id() == 0)
+    t = atomicAdd(counter, batch);
+  return (uint64_t) uniform(t);
+}
+
 // Orders this wave's LDS traffic: everything before is complete and visible to the other lanes
 // of the wave before anything after starts.  (LDS instructions of one wave execute in order;
 // this pins the compiler and waits for outstanding returns.)

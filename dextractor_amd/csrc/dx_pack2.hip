@@ -21,6 +21,7 @@
 
 #define P2_WIN_WORDS  320                // per-wave LDS window: flush threshold + one step (64 words) + slack
 #define P2_FLUSH_BITS 8192u
+#define P2_BATCH      16u                // reads a wave draws at a time (one same-address atomic costs ~11 ns chip-wide)
 
 // ---------------------------------------------------------------------------------------------
 //  alphabet maps (computed, not tabulated)
@@ -46,14 +47,12 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
                     const uint32_t *__restrict__ tlen, const uint32_t *__restrict__ nsym, uint64_t n,
                     const uint8_t *__restrict__ hdr, const uint64_t *__restrict__ hdr_off,
                     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
-                    uint32_t *__restrict__ status)
+                    uint32_t *__restrict__ status, uint32_t *__restrict__ ticket)
 { __shared__ uint32_t s_win[DX_WAVES_PER_BLK][P2_WIN_WORDS];
   __shared__ uint8_t  s_code[256];       // Number_Read / Number_Arrow as a table: 256 B = one LDS
                                          // bank per dword, so the 64 look-ups of a wave never conflict
   const int       lane  = lane_id();
   const int       wid   = threadIdx.x >> 6;
-  const uint64_t  wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + wid;
-  const uint64_t  nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
 
   for (int k = threadIdx.x; k < 256; k += DX_BLOCK)
     s_code[k] = (uint8_t) sym_code<ALPHA>((uint32_t) k);
@@ -63,7 +62,9 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
     o.win[j] = 0;
   __syncthreads();
 
-  for (uint64_t r = wave0; r < n; r += nwave)
+  for (uint64_t r0 = next_unit(ticket, P2_BATCH), nxt; r0 < n; r0 = nxt)
+  { nxt = next_unit(ticket, P2_BATCH);                   // drawn early: hidden behind these reads
+    for (uint64_t r = r0; r < r0 + P2_BATCH && r < n; r++)
     { const uint8_t *src = text + off[r];
       const uint32_t T   = tlen[r];
       uint8_t       *dst = out + out_off[r];
@@ -126,6 +127,7 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
         }
       wave_sync();
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -183,11 +185,9 @@ template <int LETTERS>
 __global__ __launch_bounds__(DX_BLOCK)
 void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__ in_off,
                     const uint32_t *__restrict__ nsym, uint64_t n, uint32_t width,
-                    uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off)
+                    uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off, uint32_t *__restrict__ ticket)
 { __shared__ uint32_t s_quad[256];       // packed byte -> its four letters (Lower_Read & co., DB.c:367-389)
   const int      lane  = lane_id();
-  const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
-  const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
   for (uint32_t k = threadIdx.x; k < 256u; k += DX_BLOCK)
     s_quad[k] = sym_letter<LETTERS>(k >> 6) | (sym_letter<LETTERS>((k >> 4) & 3u) << 8)
               | (sym_letter<LETTERS>((k >> 2) & 3u) << 16) | (sym_letter<LETTERS>(k & 3u) << 24);
@@ -199,7 +199,9 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
   const uint32_t dline  = DX_STEP / W1, dcol = DX_STEP - dline * W1;
   const bool     narrow = width < 16u;   // several line ends may fall into 16 bytes: generic path only
 
-  for (uint64_t r = wave0; r < n; r += nwave)
+  for (uint64_t r0 = next_unit(ticket, P2_BATCH), nxt; r0 < n; r0 = nxt)
+  { nxt = next_unit(ticket, P2_BATCH);
+    for (uint64_t r = r0; r < r0 + P2_BATCH && r < n; r++)
     { const uint8_t *src  = in + in_off[r];
       uint8_t       *dst  = out + out_off[r];
       const uint32_t L    = nsym[r];
@@ -243,6 +245,7 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
           if (col >= W1) { col -= W1; line += 1u; }
         }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,13 +266,15 @@ extern "C" int dx_pack2_encode(dx_ctx *ctx, int alphabet,
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 20);
+  DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   const int grid = dx_grid_waves(ctx, n, 32);
   if (alphabet == DX_ALPHA_BASES)
     DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_BASES>, grid, DX_BLOCK,
-              d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status);
+              d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status, d_ticket);
   else
     DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_ARROW>, grid, DX_BLOCK,
-              d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status);
+              d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status, d_ticket);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -291,19 +296,21 @@ extern "C" int dx_pack2_decode(dx_ctx *ctx, int letters,
   if (!d_in || !d_in_off || !d_nsym || !d_out || !d_out_off)
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 21);
+  DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   const int grid = dx_grid_waves(ctx, n, 32);
   switch (letters)
     { case DX_LETTERS_LOWER:
         DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_LOWER>, grid, DX_BLOCK,
-                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off);
+                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off, d_ticket);
         break;
       case DX_LETTERS_UPPER:
         DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_UPPER>, grid, DX_BLOCK,
-                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off);
+                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off, d_ticket);
         break;
       default:
         DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_ARROW>, grid, DX_BLOCK,
-                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off);
+                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off, d_ticket);
         break;
     }
   return DX_OK;

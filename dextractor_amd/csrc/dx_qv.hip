@@ -233,6 +233,9 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 // symbols 0..127 (all of a .quiva file's printable QVs) and run lengths 0..63 of the six
 // histograms with ONE workgroup of 16 waves per CU (80 KB); bytes >= 128 and runs >= 64 go to
 // ordinary 256-bin tables.
+#ifndef TICKET_BATCH
+#define TICKET_BATCH 2u                  // entries a wave of the histogram / size pass draws at a time
+#endif
 #define HIST_BLOCK   1024
 #define HIST_NWAVE   (HIST_BLOCK / 64)
 #define HCOLS        32
@@ -295,14 +298,12 @@ __device__ __forceinline__ uint32_t hist_bin_of(uint32_t k)
 
 __global__ __launch_bounds__(HIST_BLOCK)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
-               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot)
+               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket)
 { __shared__ hist_lds H;
   __shared__ __attribute__((aligned(16))) uint8_t s_chunk[HIST_NWAVE][DX_STEP];
   __shared__ uint16_t s_list[HIST_NWAVE][DX_STEP];
   const int      lane  = lane_id();
   const int      tid   = threadIdx.x;
-  const uint64_t wave0 = (uint64_t) blockIdx.x * HIST_NWAVE + (tid >> 6);
-  const uint64_t nwave = (uint64_t) gridDim.x * HIST_NWAVE;
   const run_lds  R     = { s_chunk[tid >> 6], s_list[tid >> 6] };
   uint32_t *const words = &H.sym[0][0][0];                      // the whole of H as words
   const uint32_t  nwords = sizeof(hist_lds) / 4;
@@ -311,7 +312,9 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   __syncthreads();
 
   uint64_t tot = 0, since = 0;
-  for (uint64_t r = wave0; r < a.n; r += nwave)
+  for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
+  { nxt = next_unit(ticket, TICKET_BATCH);             // drawn early: the atomic's latency hides behind these entries
+    for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
     { const uint32_t  L = a.len[r];
       const long long g = (long long) (entry0 + r);
       const bool drun = a.delChar >= 0 && g >= del_first;
@@ -358,6 +361,7 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           since = 0;
         }
     }
+  }
   if (lane == 0 && tot)
     atomicAdd(g_tot, (unsigned long long) tot);
   __syncthreads();
@@ -494,19 +498,19 @@ __device__ __forceinline__ uint32_t bits_runs_step(const u32x4 &c, int valid, ui
 
 __global__ __launch_bounds__(DX_BLOCK, SIZES_WAVES)
 void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *seg /* n x 5 */,
-                uint32_t *rec_size)
+                uint32_t *rec_size, uint32_t *ticket)
 { __shared__ uint32_t  s_tok[6][256];
   __shared__ size_tabs s_t;
   load_tables(s_tok, g_tok);
   load_size_tables(s_t, g_tok, a.delChar, a.subChar);
   const int      lane  = lane_id();
-  const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
-  const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
   const uint32_t imask = a.lossy ? 0xfeu : 0xffu, mmask = a.lossy ? 0xfcu : 0xffu;
   const uint32_t im4 = imask * 0x01010101u, mm4 = mmask * 0x01010101u;
   const bool drun = a.delChar >= 0, srun = a.subChar >= 0;
 
-  for (uint64_t r = wave0; r < a.n; r += nwave)
+  for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
+  { nxt = next_unit(ticket, TICKET_BATCH);
+    for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
     { const uint32_t L = a.len[r];
       const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2);
       const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
@@ -576,6 +580,7 @@ void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint3
           rec_size[r] = hl + s0 + s1 + s2 + s3 + s4;
         }
     }
+  }
 }
 
 // =============================================================================================
@@ -989,7 +994,7 @@ __device__ __forceinline__ uint32_t encode_all_tags(wave_out &ot, const uint8_t 
 
 __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
-                 const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status)
+                 const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status, uint32_t *ticket)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint8_t  s_tagcode[256];
@@ -1002,8 +1007,6 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
   load_shift_tables(s_stok, s_tagcode, g_tok);
   const int      lane  = lane_id();
   const int      wid   = threadIdx.x >> 6;
-  const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + wid;
-  const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
 
   const run_lds R = { s_chunk[wid], s_list[wid] };
   wave_out o, ot;
@@ -1013,8 +1016,9 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
   for (int j = lane; j < TAG_WIN_WORDS; j += 64) ot.win[j] = 0;
   wave_sync();
 
-  for (uint64_t r = wave0; r < a.n; r += nwave)
-    { const uint32_t  L   = a.len[r];
+  for (uint64_t r = next_unit(ticket), nxt; r < a.n; r = nxt)
+    { nxt = next_unit(ticket);
+      const uint32_t  L   = a.len[r];
       const uint32_t *sg  = seg + 5 * r;
       uint8_t        *dst = out + rec_off[r];
       if (hdr != NULL)                                   // record framing (dexqv.c:128-139)
@@ -1157,9 +1161,11 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   if ((e = dx_scratch(ctx, (6 * 256 + 1) * 8, (void **) &d_hist))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 1) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
+  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
+  DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE;       // one 16-wave workgroup per CU
   DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, (int) (hist_blocks < (uint64_t) ctx->num_cu ? hist_blocks : (uint64_t) ctx->num_cu), HIST_BLOCK,
-            a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256);
+            a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket);
   uint64_t host[6 * 256 + 1];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1291,8 +1297,10 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
       return DX_OK;
     }
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
-  DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, n, 32), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_seg, d_size);
+  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 18);
+  DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
+  DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, n, 4 * SIZES_WAVES), DX_BLOCK,
+            a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_seg, d_size, d_ticket);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) ntiles, DX_BLOCK, (const uint32_t *) d_size, n, d_tile);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, ntiles, d_gran);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, (const uint32_t *) d_size, n,
@@ -1316,8 +1324,10 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   DX_HIP(ctx, hipSetDevice(ctx->device));
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
+  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
+  DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status);
+            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
