@@ -248,6 +248,21 @@ def dexqv_sharded(contexts, quiva: bytes, lossy=False) -> bytes:
         lib.dx_file_free(out)
 
 
+def pack2_sharded(contexts, text: bytes, arrow=False) -> bytes:
+    """One .fasta/.arrow file over several contexts/GPUs (dx_file_pack2_sharded)."""
+    lib = contexts[0].lib
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    out, n, line, code = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_int()
+    rc = lib.dx_file_pack2_sharded(arr, len(contexts), int(arrow), text, len(text), C.byref(out), C.byref(n),
+                                   C.byref(line), C.byref(code))
+    if rc != 0:
+        raise L.DexGPUError(rc, f"line {line.value} (DX_IDX code {code.value})")
+    try:
+        return C.string_at(out.value, n.value)
+    finally:
+        lib.dx_file_free(out)
+
+
 # ---- host-only helpers (no GPU needed) ---------------------------------------------------------
 
 def qv_build(hist, tot, params, lossy=False) -> L.QVCoding:

@@ -128,6 +128,8 @@ static int convert(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, int opt_U
   int      code = 0, rc;
   if (tool == TOOL_DEXQV && Nctx > 1)
     rc = dx_file_dexqv_sharded(Ctxs, Nctx, in, n, opt_l, out, out_len, &line, &code);
+  else if ((tool == TOOL_DEXTA || tool == TOOL_DEXAR) && Nctx > 1)
+    rc = dx_file_pack2_sharded(Ctxs, Nctx, tool == TOOL_DEXAR, in, n, out, out_len, &line, &code);
   else
   switch (tool)
     { case TOOL_DEXTA:   rc = dx_file_pack2(ctx, 0, in, n, out, out_len, &line, &code); break;

@@ -14,6 +14,7 @@
  * fields, sprintf of decoded headers, Huffman table construction); every per-symbol loop runs on
  * the GPU through the kernels of libdexgpu.  Plain C: only the public C-ABI is used.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -47,6 +48,141 @@ static void dfree_all(dpool *pool)
   for (i = 0; i < pool->n; i++)
     dx_free(pool->ctx, pool->p[i]);
   pool->n = 0;
+}
+
+/* ==========================================================================================
+ *  dexta / dexar of one file on several GPUs: reads are independent, so contiguous read ranges
+ *  (balanced by text bytes) go to one host thread per context; nothing is exchanged -- the only
+ *  cross-record datum, the previous well of a range's first read, is known from the host index.
+ * ========================================================================================== */
+typedef struct
+  { dx_ctx         *ctx;
+    int             arrow, rc;
+    const uint8_t  *text;
+    const uint64_t *off, *ooff, *hoff;       /* per read: text offset, output offset, header-blob offset */
+    const uint32_t *tlen, *nsym;
+    const uint8_t  *blob;
+    uint8_t        *img;
+    uint64_t        lo, hi;                   /* reads [lo, hi) */
+  } p2_job;
+
+static void *p2_main(void *arg)
+{ p2_job   *j = (p2_job *) arg;
+  dpool     pool = { {0}, 0, j->ctx };
+  uint64_t  m = j->hi - j->lo, i, *roff = NULL, *rhoff = NULL, *rooff = NULL;
+  void     *d_text, *d_off, *d_tlen, *d_nsym, *d_hdr, *d_hoff, *d_out, *d_ooff;
+  int       rc = DX_OK;
+  if (m == 0) { j->rc = DX_OK; return NULL; }
+  { const uint64_t t0 = j->off[j->lo], t1 = j->off[j->hi - 1] + j->tlen[j->hi - 1];
+    const uint64_t h0 = j->hoff[j->lo], o0 = j->ooff[j->lo];
+    const uint64_t obytes = j->ooff[j->hi] - o0;
+    roff  = malloc(m * sizeof(*roff));
+    rhoff = malloc((m + 1) * sizeof(*rhoff));
+    rooff = malloc(m * sizeof(*rooff));
+    if (!roff || !rhoff || !rooff) { rc = DX_E_NOMEM; goto done; }
+    for (i = 0; i < m; i++)
+      { roff[i]  = j->off[j->lo + i] - t0;
+        rhoff[i] = j->hoff[j->lo + i] - h0;
+        rooff[i] = j->ooff[j->lo + i] - o0;
+      }
+    rhoff[m] = j->hoff[j->hi] - h0;
+    TRY(dupload(&pool, j->text + t0, (size_t) (t1 - t0), &d_text));
+    TRY(dupload(&pool, roff, m * 8, &d_off));
+    TRY(dupload(&pool, j->tlen + j->lo, m * 4, &d_tlen));
+    TRY(dupload(&pool, j->nsym + j->lo, m * 4, &d_nsym));
+    TRY(dupload(&pool, j->blob + h0, (size_t) rhoff[m], &d_hdr));
+    TRY(dupload(&pool, rhoff, (m + 1) * 8, &d_hoff));
+    TRY(dupload(&pool, rooff, m * 8, &d_ooff));
+    TRY(dalloc(&pool, (size_t) obytes, &d_out));
+    TRY(dx_pack2_encode(j->ctx, j->arrow ? DX_ALPHA_ARROW : DX_ALPHA_BASES, d_text, d_off, d_tlen, d_nsym, m,
+                        d_hdr, d_hoff, d_out, d_ooff));
+    TRY(dx_d2h(j->ctx, j->img + o0, d_out, (size_t) obytes));
+  }
+done:
+  dfree_all(&pool);
+  free(roff); free(rhoff); free(rooff);
+  j->rc = rc;
+  return NULL;
+}
+
+int dx_file_pack2_sharded(dx_ctx **ctxs, int nctx, int arrow, const uint8_t *text, size_t n,
+                          uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
+{ uint64_t  cnt = 0, i, *off = NULL, *hoff = NULL, *ooff = NULL;
+  uint32_t *tlen = NULL, *nsym = NULL;
+  int32_t  *hdr4 = NULL, lwell = 0;
+  uint16_t *cnr4 = NULL;
+  uint8_t  *blob = NULL, *img = NULL;
+  size_t    plen = 0, at;
+  p2_job   *jobs = NULL;
+  pthread_t *th = NULL;
+  int       rc, k, started = 0;
+
+  if (ctxs == NULL || nctx < 1 || out == NULL || out_len == NULL) return DX_E_ARG;
+  if (nctx == 1) return dx_file_pack2(ctxs[0], arrow, text, n, out, out_len, errline, errcode);
+  *out = NULL; *out_len = 0;
+
+  TRY(dx_index_seq(arrow, text, n, 0, NULL, NULL, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
+  off  = malloc((cnt + 1) * sizeof(*off));
+  tlen = malloc((cnt + 1) * sizeof(*tlen));
+  nsym = malloc((cnt + 1) * sizeof(*nsym));
+  hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+  cnr4 = malloc((cnt + 1) * 4 * sizeof(*cnr4));
+  hoff = malloc((cnt + 1) * sizeof(*hoff));
+  ooff = malloc((cnt + 1) * sizeof(*ooff));
+  if (!off || !tlen || !nsym || !hdr4 || !cnr4 || !hoff || !ooff) { rc = DX_E_NOMEM; goto done; }
+  TRY(dx_index_seq(arrow, text, n, cnt, off, tlen, nsym, hdr4, cnr4, &cnt, &plen, errline, errcode));
+  blob = malloc(dx_frame_bound(hdr4, cnt, 0, arrow) + 16);
+  if (!blob) { rc = DX_E_NOMEM; goto done; }
+  TRY(dx_frame_headers(hdr4, cnr4, cnt, arrow, &lwell, blob, hoff));     /* one pass: well deltas chain over the whole file */
+
+  at = 2 + 4 + plen;
+  for (i = 0; i < cnt; i++)
+    { ooff[i] = at;
+      at += (size_t) (hoff[i+1] - hoff[i]) + (((size_t) nsym[i] + 3) >> 2);
+    }
+  ooff[cnt] = at;
+  img = malloc(at + 16);
+  if (!img) { rc = DX_E_NOMEM; goto done; }
+  { uint16_t key = 0x55aa;
+    int32_t  pl  = (int32_t) plen;
+    memcpy(img, &key, 2);
+    memcpy(img + 2, &pl, 4);
+    memcpy(img + 6, text, plen);
+  }
+
+  jobs = calloc((size_t) nctx, sizeof(*jobs));
+  th   = calloc((size_t) nctx, sizeof(*th));
+  if (!jobs || !th) { rc = DX_E_NOMEM; goto done; }
+  { uint64_t lo = 0;
+    const uint64_t tbytes = cnt ? off[cnt - 1] + tlen[cnt - 1] - off[0] : 0;
+    for (k = 0; k < nctx; k++)
+      { uint64_t hi = lo;
+        const uint64_t want = off[0] + tbytes / (uint64_t) nctx * (uint64_t) (k + 1);
+        if (k == nctx - 1) hi = cnt;
+        else while (hi < cnt && off[hi] < want) hi++;
+        jobs[k].ctx = ctxs[k]; jobs[k].arrow = arrow; jobs[k].text = text; jobs[k].off = off; jobs[k].ooff = ooff;
+        jobs[k].hoff = hoff; jobs[k].tlen = tlen; jobs[k].nsym = nsym; jobs[k].blob = blob; jobs[k].img = img;
+        jobs[k].lo = lo; jobs[k].hi = hi;
+        lo = hi;
+      }
+  }
+  for (k = 0; k < nctx; k++)
+    { if (pthread_create(&th[k], NULL, p2_main, &jobs[k]) != 0) { rc = DX_E_NOMEM; break; }
+      started++;
+    }
+  for (k = 0; k < started; k++)
+    pthread_join(th[k], NULL);
+  if (started < nctx) goto done;
+  rc = DX_OK;
+  for (k = 0; k < nctx; k++)
+    if (jobs[k].rc != DX_OK) { rc = jobs[k].rc; break; }
+  if (rc == DX_OK)
+    { *out = img; *out_len = at; img = NULL; }
+
+done:
+  free(off); free(hoff); free(ooff); free(tlen); free(nsym); free(hdr4); free(cnr4); free(blob); free(img);
+  free(jobs); free(th);
+  return rc;
 }
 
 /* ==========================================================================================
@@ -446,7 +582,6 @@ done:
  *  of the 12 KB histograms -- after which every shard is encoded with identical tables and the
  *  record streams are concatenated in order.  No RCCL.
  * ========================================================================================== */
-#include <pthread.h>
 
 typedef struct shard_job shard_job;
 

@@ -298,6 +298,10 @@ int  dx_file_dexqv  (dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
  * bytes to dx_file_dexqv.  nctx == 1 is dx_file_dexqv.                                          */
 int  dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n, int lossy,
                            uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
+/* dexta / dexar of ONE file on several GPUs: contiguous read ranges balanced by text bytes, one host
+ * thread per context, no exchange at all; identical bytes to dx_file_pack2.        */
+int  dx_file_pack2_sharded(dx_ctx **ctxs, int nctx, int arrow, const uint8_t *text, size_t n,
+                           uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
 int  dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper,
                      uint8_t **out, size_t *out_len);                       /* undexqv.c:101-208 */
 void dx_file_free(void *p);

@@ -132,3 +132,16 @@ def test_cli_dexqv_on_several_contexts(tmp_path):
     r = subprocess.run([os.path.join(BIN, "dexqv"), "-k", "m"], cwd=str(tmp_path), capture_output=True, env=env)
     assert r.returncode == 0, r.stderr
     assert _read(tmp_path / "m.dexqv") == O.dexqv(qv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,ext,kind", [("dexta", "fasta", "fasta"), ("dexar", "arrow", "arrow")])
+def test_cli_pack2_on_several_contexts(tmp_path, tool, ext, kind):
+    """DEXGPU_DEVICES also shards a .fasta/.arrow file's reads (dx_file_pack2_sharded)."""
+    txt = synth.make_seqfile(kind, 40, seed=9, mean=3000).text
+    _write(tmp_path / f"m.{ext}", txt)
+    env = dict(os.environ, DEXGPU_DEVICES="0,0,0")
+    r = subprocess.run([os.path.join(BIN, tool), "-k", "m"], cwd=str(tmp_path), capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr
+    want = O.dexta(txt) if kind == "fasta" else O.dexar(txt)
+    assert _read(tmp_path / f"m.{'dexta' if kind == 'fasta' else 'dexar'}") == want

@@ -548,6 +548,24 @@ def test_file_dexqv_sharded_over_contexts(ctx, nctx, lossy):
             x.close()
 
 
+@pytest.mark.parametrize("nctx", [2, 5])
+@pytest.mark.parametrize("kind", ["fasta", "arrow"])
+def test_file_pack2_sharded_over_contexts(ctx, nctx, kind):
+    """dx_file_pack2_sharded: read ranges on several contexts (here all on device 0), one host thread
+    each; the image is byte-identical to the single-context one and to the reference's."""
+    lens = np.array([0, 3, 900, 17, 20000] + [int(x) for x in np.random.default_rng(3).integers(1, 6000, 70)], np.uint32)
+    c = synth.make_seqfile(kind, len(lens), seed=41, lens=lens)
+    others = [api.Context(0) for _ in range(nctx - 1)]
+    try:
+        got = api.pack2_sharded([ctx] + others, c.text, arrow=(kind == "arrow"))
+    finally:
+        for o in others:
+            o.close()
+    assert got == (O.dexta(c.text) if kind == "fasta" else O.dexar(c.text))
+    with pytest.raises(L.DexGPUError):
+        api.pack2_sharded([ctx, ctx], b"no header\nACGT\n")
+
+
 def test_in_memory_entry_api(ctx):
     """dx_entries_* (QVcoding_Scan1 / Compress_Next_QVentry1 shape): bare records + per-entry offsets
     equal the oracle's per-entry encodes with the tables of the same scan."""
