@@ -858,28 +858,45 @@ __device__ __forceinline__ void encode_runs_step(wave_out &o, wave_out &ot, cons
       if (cnt)
         base0 = first ? (uint32_t) R.list[first - 1] + 1u : 0u - C;
       uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, nb = 0, zor = 0, tacc = 0, base = base0;
+      // three tokens at a time, each look-up level for all three before the next level: the
+      // dependent LDS reads (position -> symbol -> code) cost three waits per group, not per token
       #pragma unroll 1
-      for (uint32_t j = 0; j < T; j++)
-        if (j < cnt)
-          { const uint32_t pos = R.list[first + j];
-            const uint32_t x   = R.chunk[pos];
-            const uint32_t run = pos - base;
-            base = pos + 1u;
-            const uint32_t rt = rstab[run > 255u ? 255u : run];       // QV.c:479-487
-            const uint32_t st = nstab[x];
-            STOK_APPEND(rt)
-            if (rt & 0x80u)
-              { const uint32_t lit = (run << 16) | 16u;
-                STOK_APPEND(lit)
-                w0 |= run & 0xffff0000u;                              // OCODE(16,run) with run >= 2^16 (QV.c:411,420)
-                nb += 16u;
+      for (uint32_t j0 = 0; j0 < T; j0 += 3u)
+        { uint32_t pos[3], rt[3], st[3], tg[3];
+          #pragma unroll
+          for (int k = 0; k < 3; k++)
+            pos[k] = j0 + k < cnt ? (uint32_t) R.list[first + j0 + k] : 0u;
+          #pragma unroll
+          for (int k = 0; k < 3; k++)
+            { st[k] = R.chunk[pos[k]];
+              if (TAGS) tg[k] = tagchunk[pos[k]];
+            }
+          #pragma unroll
+          for (int k = 0; k < 3; k++)
+            { const uint32_t run = pos[k] - (k ? pos[k - 1] + 1u : base);
+              rt[k] = rstab[run > 255u ? 255u : run];                 // QV.c:479-487
+              st[k] = nstab[st[k]];
+              if (TAGS) tg[k] = tagcode[tg[k]];
+            }
+          #pragma unroll
+          for (int k = 0; k < 3; k++)
+            if (j0 + k < cnt)
+              { STOK_APPEND(rt[k])
+                if (rt[k] & 0x80u)
+                  { const uint32_t run = pos[k] - (k ? pos[k - 1] + 1u : base);
+                    const uint32_t lit = (run << 16) | 16u;
+                    STOK_APPEND(lit)
+                    w0 |= run & 0xffff0000u;                          // OCODE(16,run) with run >= 2^16 (QV.c:411,420)
+                    nb += 16u;
+                  }
+                STOK_APPEND(st[k])
+                nb  += 64u - (rt[k] & 0x3fu) - (st[k] & 0xffu);
+                zor |= rt[k] | st[k];
+                if (TAGS)
+                  tacc = (tacc << 2) | tg[k];
               }
-            STOK_APPEND(st)
-            nb  += 64u - (rt & 0x3fu) - (st & 0xffu);
-            zor |= rt | st;
-            if (TAGS)
-              tacc = (tacc << 2) | (uint32_t) tagcode[tagchunk[pos]];
-          }
+          base = pos[2] + 1u;                                         // only used when the lane has a next group
+        }
       const uint32_t incl = wave_incl_scan(nb);
       if (!__any((int) ((zor & 32u) | (nb > 128u))))
         { FOR_EACH_ROUND(o, incl, nb,
