@@ -115,6 +115,32 @@ struct wave_out
   uint32_t  winbits;      // bits in the window
 };
 
+// The same in 16-byte units, for the periodic drain of a well-filled window (16-byte aligned):
+// whole groups of four words leave with one ds_read_b128 + one (unaligned) 16-byte store per
+// lane; the up to three completed words left over stay in the window with the partial one.
+__device__ __forceinline__ void flush_quads(wave_out &o, bool swap)
+{ const int      lane = lane_id();
+  const uint32_t nq   = o.winbits >> 7;
+  u32x4         *win4 = (u32x4 *) o.win;
+  wave_sync();
+  for (uint32_t j = lane; j < nq; j += 64)
+    { u32x4 v = win4[j];
+      if (swap)
+        { v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y);
+          v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+        }
+      *(u32x4_u *) (o.seg + 4ull * o.wordbase + 16ull * j) = v;
+    }
+  const u32x4 rest = win4[nq];
+  const u32x4 zero = { 0u, 0u, 0u, 0u };
+  wave_sync();
+  for (uint32_t j = lane; j <= nq; j += 64)
+    win4[j] = (j == 0) ? rest : zero;
+  o.wordbase += 4u * nq;
+  o.winbits  &= 127u;
+  wave_sync();
+}
+
 // store the window's completed words and slide the partial word to win[0]
 __device__ __forceinline__ void flush_words(wave_out &o, bool swap)
 { const int      lane  = lane_id();

@@ -48,7 +48,7 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
                     const uint8_t *__restrict__ hdr, const uint64_t *__restrict__ hdr_off,
                     uint8_t *__restrict__ out, const uint64_t *__restrict__ out_off,
                     uint32_t *__restrict__ status, uint32_t *__restrict__ ticket)
-{ __shared__ uint32_t s_win[DX_WAVES_PER_BLK][P2_WIN_WORDS];
+{ __shared__ __attribute__((aligned(16))) uint32_t s_win[DX_WAVES_PER_BLK][P2_WIN_WORDS];
   __shared__ uint8_t  s_code[256];       // Number_Read / Number_Arrow as a table: 256 B = one LDS
                                          // bank per dword, so the 64 look-ups of a wave never conflict
   const int       lane  = lane_id();
@@ -109,7 +109,7 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
             }
           o.winbits += 2u * wave_total(incl);
           if (o.winbits >= P2_FLUSH_BITS)
-            flush_words(o, true);
+            flush_quads(o, true);
           c = d;
           pos += DX_STEP;
         }

@@ -709,7 +709,7 @@ __device__ __forceinline__ uint32_t fsr(uint32_t hi, uint32_t lo, uint32_t s)
         lo_   = hi_;                                                                            \
       }                                                                                         \
     if ((o).winbits >= QV_FLUSH_BITS)                                                           \
-      flush_words((o), false);                                                                  \
+      flush_quads((o), false);                                                                  \
   }
 
 // write the partial word and the pad word (QV.c:436-442); returns the segment's byte size
@@ -932,7 +932,7 @@ __device__ __forceinline__ void encode_runs_step(wave_out &o, wave_out &ot, cons
             }
           ot.winbits += 2u * m;
           if (ot.winbits >= TAG_FLUSH_BITS)
-            flush_words(ot, true);
+            flush_quads(ot, true);
         }
     }
   C = run_after(R, total, sv, C);
@@ -979,7 +979,7 @@ __device__ __forceinline__ void encode_tags_step(wave_out &o, const u32x4 &t, ui
     }
   o.winbits += 2u * wave_total(incl);
   if (o.winbits >= TAG_FLUSH_BITS)
-    flush_words(o, true);
+    flush_quads(o, true);
 }
 
 __device__ __forceinline__ uint32_t finish_tags(wave_out &o)
@@ -1015,8 +1015,8 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint8_t  s_tagcode[256];
-  __shared__ uint32_t s_win[DX_WAVES_PER_BLK][QV_WIN_WORDS];
-  __shared__ uint32_t s_tag[DX_WAVES_PER_BLK][TAG_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_win[DX_WAVES_PER_BLK][QV_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tag[DX_WAVES_PER_BLK][TAG_WIN_WORDS];
   __shared__ __attribute__((aligned(16))) uint8_t s_chunk[DX_WAVES_PER_BLK][DX_STEP];
   __shared__ __attribute__((aligned(16))) uint8_t s_tchunk[DX_WAVES_PER_BLK][DX_STEP];
   __shared__ uint16_t s_list[DX_WAVES_PER_BLK][DX_STEP];
