@@ -37,42 +37,95 @@ struct dec_args
   int             flip;         // words were written by a host of the other endianness (GETFLIP, QV.c:553-568)
 };
 
-// MSB-first bit reader over little-endian 32-bit words; never reads past `end`.  Words come from a
-// 16-byte register cache refilled with one global_load_dwordx4.
-struct bitrd { const uint8_t *p, *end; uint64_t buf; int nb; bool flip; u32x4 cache; int ci; };
+// MSB-first bit reader over little-endian 32-bit words; never reads past `end`.
+//
+// A wave waits on ALL of its outstanding global loads at once (one vmcnt per wave), so a lane that
+// fetches the next piece of its own stream whenever it happens to run dry stalls the other 63 for
+// a full memory latency -- and with 64 independent streams some lane runs dry in almost every
+// iteration.  Here the lanes fetch together: each owns a 16-word ring in LDS plus one 16-byte chunk
+// in flight in registers; br_pump (wave-uniform, once per decode iteration) fires when any lane is
+// down to 4 unread words, commits every lane's chunk in flight to its ring (issued one pump ago:
+// long since arrived) and issues the next.  Words then reach the bit buffer from the ring through a
+// one-word prefetch register, never from memory.
+#define DEC_RING_WORDS  16
+#define DEC_RING_STRIDE 18                                 // words per row: 8-byte aligned, rows spread over the banks
+struct bitrd
+{ const uint8_t *p;              // next byte to fetch
+  uint32_t       left;           // words of the segment not fetched yet
+  uint32_t      *ring;           // this lane's LDS row
+  uint32_t       rp, wp;         // words taken from / committed to the ring
+  u32x4          pend;           // chunk in flight
+  uint32_t       pend_words;     // its size (0: none)
+  uint64_t       buf;            // bit buffer, next bit in bit 63
+  int            nb;             // valid bits in buf
+  uint32_t       nw;             // ring[rp - 1], prefetched
+  bool           flip;
+};
 
-__device__ __forceinline__ void br_init(bitrd &r, const uint8_t *p, const uint8_t *end, bool flip)
-{ r.p = p; r.end = end; r.buf = 0; r.nb = 0; r.flip = flip; r.ci = 4;
-  r.cache.x = r.cache.y = r.cache.z = r.cache.w = 0u;
+__device__ __forceinline__ void br_issue(bitrd &r)
+{ if (r.left >= 4u)
+    { r.pend = *(const u32x4_u *) r.p;
+      r.pend_words = 4;
+    }
+  else                                                     // segments are whole words (QV.c:436-442)
+    { r.pend.x = *(const u32_u *) r.p;
+      r.pend.y = r.left >= 2u ? *(const u32_u *) (r.p + 4) : 0u;
+      r.pend.z = r.left >= 3u ? *(const u32_u *) (r.p + 8) : 0u;
+      r.pend.w = 0u;
+      r.pend_words = r.left;
+    }
+  r.p    += 4 * r.pend_words;
+  r.left -= r.pend_words;
+}
+
+__device__ __forceinline__ void br_commit(bitrd &r)
+{ u32x4 v = r.pend;
+  if (r.flip)
+    { v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y);
+      v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+    }
+  uint64_t *slot = (uint64_t *) (r.ring + (r.wp & (DEC_RING_WORDS - 1)));
+  slot[0] = ((uint64_t) v.y << 32) | v.x;
+  slot[1] = ((uint64_t) v.w << 32) | v.z;
+  r.wp += r.pend_words;
+  r.pend_words = 0;
+}
+
+// once per decode iteration, all lanes of the wave together
+__device__ __forceinline__ void br_pump(bitrd &r)
+{ const int avail = (int) (r.wp - r.rp);
+  if (__any(avail <= 4 && (r.pend_words | r.left) != 0u))
+    { if (r.pend_words && avail <= DEC_RING_WORDS - 4)
+        br_commit(r);
+      if (!r.pend_words && r.left)
+        br_issue(r);
+    }
+}
+
+__device__ __forceinline__ void br_init(bitrd &r, const uint8_t *p, const uint8_t *end, bool flip, uint32_t *ring)
+{ r.p = p; r.left = (uint32_t) ((end - p) >> 2); r.ring = ring; r.rp = 0; r.wp = 0; r.pend_words = 0;
+  r.buf = 0; r.nb = 0; r.flip = flip;
+  r.pend.x = r.pend.y = r.pend.z = r.pend.w = 0u;
+  if (r.left) { br_issue(r); br_commit(r); }               // prime: one chunk in the ring ...
+  if (r.left) br_issue(r);                                 // ... and one in flight
+  r.nw = r.ring[0];
+  r.rp = 1;
 }
 
 __device__ __forceinline__ void br_fill(bitrd &r)
-{ while (r.nb <= 32 && r.p < r.end)
-    { if (r.ci == 4)
-        { if (r.p + 16 <= r.end)
-            r.cache = *(const u32x4_u *) r.p;
-          else                                             // segments are whole words (QV.c:436-442)
-            { r.cache.x = *(const u32_u *) r.p;
-              r.cache.y = r.p + 8  <= r.end ? *(const u32_u *) (r.p + 4) : 0u;
-              r.cache.z = r.p + 12 <= r.end ? *(const u32_u *) (r.p + 8) : 0u;
-              r.cache.w = 0u;
-            }
-          r.ci = 0;
-        }
-      const uint32_t w = r.ci == 0 ? r.cache.x : (r.ci == 1 ? r.cache.y : (r.ci == 2 ? r.cache.z : r.cache.w));
-      r.buf |= (uint64_t) (r.flip ? __builtin_bswap32(w) : w) << (32 - r.nb);
+{ if (r.nb <= 32)
+    { r.buf |= (uint64_t) r.nw << (32 - r.nb);
       r.nb  += 32;
-      r.p   += 4;
-      r.ci  += 1;
+      r.nw   = r.ring[r.rp & (DEC_RING_WORDS - 1)];        // stale words past the segment's end are never decoded
+      r.rp  += 1;
     }
 }
 __device__ __forceinline__ uint32_t br_peek16(const bitrd &r) { return (uint32_t) (r.buf >> 48); }
 __device__ __forceinline__ void     br_skip(bitrd &r, int n)  { r.buf <<= n; r.nb -= n; }
 
 // next code of scheme s: returns symbol, consumes its bits
-__device__ __forceinline__ uint32_t dec_symbol(bitrd &r, const uint16_t *prim, const uint32_t *lng)
-{ br_fill(r);
-  const uint32_t w = br_peek16(r);
+__device__ __forceinline__ uint32_t dec_symbol_nofill(bitrd &r, const uint16_t *prim, const uint32_t *lng)
+{ const uint32_t w = br_peek16(r);
   uint32_t e = prim[w >> (16 - DX_DEC_BITS)];
   if ((e >> 8) == 0)                                       // code longer than the primary index
     { const uint32_t cnt = lng[0];
@@ -86,6 +139,11 @@ __device__ __forceinline__ uint32_t dec_symbol(bitrd &r, const uint16_t *prim, c
     }
   br_skip(r, (int) (e >> 8));
   return e & 0xffu;
+}
+
+__device__ __forceinline__ uint32_t dec_symbol(bitrd &r, const uint16_t *prim, const uint32_t *lng)
+{ br_fill(r);
+  return dec_symbol_nofill(r, prim, lng);
 }
 
 // byte sink: 8 bytes gathered in a register go to the lane's LDS row (4 slots); a full row leaves
@@ -137,14 +195,15 @@ __device__ __forceinline__ void bs_end(bsink &o)
   o.slot = 0;
 }
 
-#define DEC_BLOCK 1024                                     // two 16-wave workgroups per CU, each with its own tables
+#define DEC_BLOCK 1024                                     // one 16-wave workgroup per CU (142 KB of LDS)
 #define DEC_NWAVE (DEC_BLOCK / 64)
 
-__global__ __launch_bounds__(DEC_BLOCK, 2)
+__global__ __launch_bounds__(DEC_BLOCK)
 void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *status, uint32_t *next_task)
 { __shared__ uint16_t s_dec[6][DX_DEC_SIZE];               // 24 KB
   __shared__ uint32_t s_long[6][1 + DX_LONG_MAX];          // 6 KB
   __shared__ __attribute__((aligned(8))) uint8_t s_row[DEC_BLOCK][DEC_ROW_BYTES];    // 40 KB
+  __shared__ __attribute__((aligned(8))) uint32_t s_ring[DEC_BLOCK][DEC_RING_STRIDE]; // 72 KB
   for (int k = threadIdx.x; k < 6 * DX_DEC_SIZE; k += DEC_BLOCK)          (&s_dec[0][0])[k]  = g_dec[k];
   for (int k = threadIdx.x; k < 6 * (1 + DX_LONG_MAX); k += DEC_BLOCK)    (&s_long[0][0])[k] = g_long[k];
   __syncthreads();
@@ -174,7 +233,7 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
         at += sg[k];
 
       bitrd rd;
-      br_init(rd, a.in + at, a.in + at + sg[line], a.flip != 0);
+      br_init(rd, a.in + at, a.in + at + sg[line], a.flip != 0, s_ring[threadIdx.x]);
       bsink o  = { a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u), 0, 0, (uint64_t *) s_row[threadIdx.x], 0 };
       const int rc = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
       const uint16_t *prim = s_dec[q];
@@ -182,9 +241,26 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       const bool esc = a.type[q] == 2;
       uint32_t j = 0, bad = 0;
 
-      if (rc < 0)                                          // Decode, QV.c:586-596
+      if (rc < 0 && !esc)                                  // Decode, QV.c:586-596; codes <= 16 bits: two per refill
+        { while (j + 2u <= L)
+            { br_pump(rd);
+              br_fill(rd);                                 // >= 33 bits: enough for two codes
+              const uint32_t c0 = dec_symbol_nofill(rd, prim, lng);
+              const uint32_t c1 = dec_symbol_nofill(rd, prim, lng);
+              bs_put(o, c0);
+              bs_put(o, c1);
+              j += 2;
+            }
+          if (j < L)
+            { br_pump(rd);
+              bs_put(o, dec_symbol(rd, prim, lng));
+              j += 1;
+            }
+        }
+      else if (rc < 0)
         while (j < L)
-          { uint32_t c = dec_symbol(rd, prim, lng);
+          { br_pump(rd);
+            uint32_t c = dec_symbol(rd, prim, lng);
             if (esc && c == 255u)
               { br_fill(rd);
                 c = br_peek16(rd) >> 8;
@@ -197,7 +273,8 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
         { const uint16_t *rprim = s_dec[q == 0 ? DX_DRUN : DX_SRUN];
           const uint32_t *rlng  = s_long[q == 0 ? DX_DRUN : DX_SRUN];
           while (j < L)
-            { uint32_t c = dec_symbol(rd, rprim, rlng);
+            { br_pump(rd);
+              uint32_t c = dec_symbol(rd, rprim, rlng);
               if (c == 255u)
                 { br_fill(rd);
                   c = br_peek16(rd);
@@ -299,7 +376,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   a.out = d_out; a.out_off = d_out_off; a.delChar = ctx->delChar; a.subChar = ctx->subChar; a.upper = (flags & DX_DECODE_UPPER) != 0; a.flip = (flags & DX_DECODE_FLIP) != 0;
   for (int s = 0; s < 4; s++) a.type[s] = ctx->sym_type[s];
   uint64_t blocks = (4 * ((n + 63) / 64) + DEC_NWAVE - 1) / DEC_NWAVE;
-  const uint64_t cap = (uint64_t) ctx->num_cu * 2;
+  const uint64_t cap = (uint64_t) ctx->num_cu;
   if (blocks > cap) blocks = cap;
   uint32_t *d_next = (uint32_t *) (ctx->d_u64 + 16);       // task counter of k_qv_decode
   DX_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
