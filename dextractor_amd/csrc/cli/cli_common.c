@@ -7,6 +7,8 @@
  * read whole, handed to the GPU through the whole-file drivers of libdexgpu, and the result is
  * written whole.  There is no CPU codec here: without a HIP device the tools fail loudly.
  */
+#include <pthread.h>
+#include <sys/stat.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,7 +54,11 @@ static const char *Prog;
 
 static uint8_t *slurp(FILE *f, size_t *n)
 { size_t cap = 1 << 20, len = 0, k;
-  uint8_t *buf = malloc(cap);
+  uint8_t *buf;
+  struct stat st;
+  if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0)
+    cap = (size_t) st.st_size + 1;                     /* a regular file: one allocation, no regrowth copies */
+  buf = malloc(cap);
   if (buf == NULL) return NULL;
   while ((k = fread(buf + len, 1, cap - len, f)) > 0)
     { len += k;
@@ -161,6 +167,69 @@ static int convert(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, int opt_U
   return 1;
 }
 
+/* The GPU contexts are opened on a second thread while the first input file is being read
+   (HIP initialisation and a large read each take a few hundred milliseconds). */
+static dx_ctx *Ctx0 = NULL;
+static void *open_contexts(void *arg)
+{ dx_ctx *ctx = NULL;
+  int     k;
+  const char *dev = getenv("DEXGPU_DEVICE"), *devs = getenv("DEXGPU_DEVICES");
+  (void) arg;
+  if (devs != NULL && *devs != '\0')              /* "all" or a comma list, e.g. 0,1,2,3 */
+    { if (strcmp(devs, "all") == 0)
+        { int nd = dx_device_count();
+          for (k = 0; k < nd && k < 64; k++)
+            if (dx_open(k, &Ctxs[Nctx]) == DX_OK) Nctx += 1;
+        }
+      else
+        { const char *q = devs;
+          while (*q != '\0' && Nctx < 64)
+            { char *e;
+              long  d = strtol(q, &e, 10);
+              if (e == q) break;
+              if (dx_open((int) d, &Ctxs[Nctx]) != DX_OK)
+                { fprintf(stderr, "%s: cannot open GPU %ld: %s\n", Prog, d, dx_last_error(NULL));
+                  exit(1);
+                }
+              Nctx += 1;
+              q = (*e == ',') ? e + 1 : e;
+            }
+        }
+      if (Nctx > 0) ctx = Ctxs[0];
+    }
+  if (ctx == NULL && dx_open(dev ? atoi(dev) : 0, &ctx) != DX_OK)
+    { fprintf(stderr, "%s: cannot open a GPU: %s\n", Prog, dx_last_error(NULL));
+      exit(1);
+    }
+  Ctx0 = ctx;
+  return NULL;
+}
+
+static pthread_t Opener;
+static int       Opening = 0;
+
+/* leave only after the opener thread is done: exit() while HIP initialises on another thread is unsafe */
+static void leave(int code)
+{ if (Opening)
+    { pthread_join(Opener, NULL);
+      Opening = 0;
+    }
+  exit(code);
+}
+
+/* DEXGPU_TIMING=1: wall-clock marks on stderr (where an end-to-end run spends its time) */
+#include <time.h>
+static void tmark(const char *what)
+{ static double t0 = -1.0;
+  struct timespec ts;
+  double now;
+  if (getenv("DEXGPU_TIMING") == NULL) return;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  now = ts.tv_sec + 1e-9 * ts.tv_nsec;
+  if (t0 < 0) t0 = now;
+  fprintf(stderr, "[%s %8.1f ms] %s\n", Prog, (now - t0) * 1e3, what);
+}
+
 int dex_tool_main(int tool, int argc, char *argv[])
 { const tool_t *t = &TOOLS[tool];
   int     flags[128], i, j, k, width = 80;
@@ -221,35 +290,9 @@ int dex_tool_main(int tool, int argc, char *argv[])
       exit(1);
     }
 
-  { const char *dev = getenv("DEXGPU_DEVICE"), *devs = getenv("DEXGPU_DEVICES");
-    if (devs != NULL && *devs != '\0')              /* "all" or a comma list, e.g. 0,1,2,3 */
-      { if (strcmp(devs, "all") == 0)
-          { int nd = dx_device_count();
-            for (k = 0; k < nd && k < 64; k++)
-              if (dx_open(k, &Ctxs[Nctx]) == DX_OK) Nctx += 1;
-          }
-        else
-          { const char *q = devs;
-            while (*q != '\0' && Nctx < 64)
-              { char *e;
-                long  d = strtol(q, &e, 10);
-                if (e == q) break;
-                if (dx_open((int) d, &Ctxs[Nctx]) != DX_OK)
-                  { fprintf(stderr, "%s: cannot open GPU %ld: %s\n", Prog, d, dx_last_error(NULL));
-                    exit(1);
-                  }
-                Nctx += 1;
-                q = (*e == ',') ? e + 1 : e;
-              }
-          }
-        if (Nctx > 0) ctx = Ctxs[0];
-      }
-    if (ctx == NULL && dx_open(dev ? atoi(dev) : 0, &ctx) != DX_OK)
-      { fprintf(stderr, "%s: cannot open a GPU: %s\n", Prog, dx_last_error(NULL));
-        exit(1);
-      }
-  }
-
+  tmark("start");
+  Opening = pthread_create(&Opener, NULL, open_contexts, NULL) == 0;
+  if (!Opening) open_contexts(NULL);
   for (i = 1; i < argc; i++)
     { char    *pwd = NULL, *root, *src = NULL, *dst = NULL;
       FILE    *input, *output;
@@ -269,11 +312,11 @@ int dex_tool_main(int tool, int argc, char *argv[])
           dst  = catenate(pwd, root, t->dst_ext);
           if ((input = fopen(src, "r")) == NULL)
             { fprintf(stderr, "%s: Cannot open %s for 'r'\n", Prog, src);   /* Fopen, DB.c:103-110 */
-              exit(1);
+              leave(1);
             }
           if ((output = fopen(dst, "w")) == NULL)
             { fprintf(stderr, "%s: Cannot open %s for 'w'\n", Prog, dst);
-              exit(1);
+              leave(1);
             }
         }
 
@@ -283,19 +326,28 @@ int dex_tool_main(int tool, int argc, char *argv[])
         }
 
       in = slurp(input, &n);
+      tmark("input read");
+      if (Opening)
+        { pthread_join(Opener, NULL);
+          Opening = 0;
+        }
+      ctx = Ctx0;
+      tmark("GPU context open");
       if (in == NULL)
         { fprintf(stderr, "%s: Out of memory (Allocating read buffer)\n", Prog);
-          exit(1);
+          leave(1);
         }
       st = convert(ctx, tool, in, n, UPPER, LOSSY, width, &out, &out_len);
       if (st != 0)
-        exit(st);
+        leave(st);
+      tmark("converted (index, copies, kernels)");
       if (out_len > 0 && fwrite(out, 1, out_len, output) != out_len)
         { fprintf(stderr, "%s: System error, write failed!\n", Prog);
-          exit(2);
+          leave(2);
         }
       dx_file_free(out);
       free(in);
+      tmark("output written");
 
       if (!PIPE)
         { fclose(input);

@@ -570,13 +570,14 @@ static void build_wlut(const dx_scheme *s, wlut *t)
 typedef struct { const uint8_t *p, *end; uint64_t buf; int nb; uint64_t T; int flip; } wrd;
 
 static void w_fill(wrd *r)
-{ while (r->nb <= 32 && r->p + 4 <= r->end)
+{ if (r->p + 4 <= r->end)                               /* (well predicted; the data-dependent part is branch-free) */
     { uint32_t w;
+      const uint64_t take = (uint64_t) 0 - (uint64_t) (r->nb <= 32);      /* all ones: the buffer has room for a word */
       memcpy(&w, r->p, 4);
       if (r->flip) w = flip32(w);
-      r->buf |= (uint64_t) w << (32 - r->nb);
-      r->nb  += 32;
-      r->p   += 4;
+      r->buf |= ((uint64_t) w << ((32 - r->nb) & 63)) & take;
+      r->nb  += (int) (32 & take);
+      r->p   += 4 & take;
     }
 }
 static uint32_t w_peek(wrd *r) { w_fill(r); return (uint32_t) (r->buf >> 48); }
@@ -589,30 +590,90 @@ static uint32_t pad_words(uint64_t T, uint32_t last)    /* QV.c:436-442 */
   return w + ((T > 0 && llen > 16u) ? 1u : 0u);
 }
 
+/* Several codes per look-up for the walk, which needs lengths only: for every 12-bit window, how
+   many whole codes it holds, their total length and the length of the last one (escape codes end
+   a group: the 8-bit literal that follows is not a code).  8 KB per scheme: stays in L1. */
+#define MW_BITS 12
+typedef struct { uint8_t nbits, nsym, last, pad; } mwent;
+typedef struct { mwent e[1 << MW_BITS]; } mwlut;
+
+static void build_mwlut(const wlut *t, int esc, mwlut *m)
+{ uint32_t x;
+  for (x = 0; x < (1u << MW_BITS); x++)
+    { uint32_t pos = 0, cnt = 0, last = 0;
+      for (;;)
+        { uint32_t e = t->e[((x << (16 - MW_BITS)) << pos) & 0xffffu], l = e >> 8;
+          if (l == 0 || pos + l > MW_BITS || (esc && (e & 0xff) == 255)) break;
+          pos += l; cnt += 1; last = l;
+        }
+      m->e[x].nbits = (uint8_t) pos; m->e[x].nsym = (uint8_t) cnt; m->e[x].last = (uint8_t) last; m->e[x].pad = 0;
+    }
+}
+
 /* bytes of a plain-coded segment of rlen symbols starting at p (QV.c:510-599) */
-static int64_t walk_plain(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *t, int esc, int flip)
+static int64_t walk_plain(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *t, const mwlut *m,
+                          int esc, int flip)
 { wrd r = { p, end, 0, 0, 0, flip };
-  uint32_t j, last = 0;
+  uint32_t j = 0, last = 0;
   int64_t bytes;
-  for (j = 0; j < rlen; j++)
-    { uint32_t e = t->e[w_peek(&r)];
-      last = e >> 8;
-      w_skip(&r, (int) last);
-      if (esc && (e & 0xff) == 255)
-        { w_peek(&r); w_skip(&r, 8); last = 8; }
+  while (j < rlen)
+    { uint32_t w = w_peek(&r);
+      const mwent g = m->e[w >> (16 - MW_BITS)];
+      if (g.nsym && j + g.nsym <= rlen)
+        { w_skip(&r, g.nbits);
+          j   += g.nsym;
+          last = g.last;
+          continue;
+        }
+      { uint32_t e = t->e[w];
+        last = e >> 8;
+        w_skip(&r, (int) last);
+        if (esc && (e & 0xff) == 255)
+          { w_peek(&r); w_skip(&r, 8); last = 8; }
+        j += 1;
+      }
     }
   bytes = 4 * (int64_t) pad_words(r.T, last);
   return (p + bytes <= end) ? bytes : -1;
 }
 
+/* The same for a run-coded stream: a (run code, symbol code) pair that fits the window whole and
+   needs no literal (run < 255, symbol not escaped). */
+typedef struct { uint8_t nbits, run, last, ok; } rwent;
+typedef struct { rwent e[1 << MW_BITS]; } rwlut;
+
+static void build_rwlut(const wlut *rt, const wlut *nt, int esc, rwlut *m)
+{ uint32_t x;
+  for (x = 0; x < (1u << MW_BITS); x++)
+    { const uint32_t w  = x << (16 - MW_BITS);
+      const uint32_t e1 = rt->e[w], l1 = e1 >> 8;
+      rwent g = { 0, 0, 0, 0 };
+      if (l1 > 0 && l1 < MW_BITS && (e1 & 0xff) != 255)
+        { const uint32_t e2 = nt->e[(w << l1) & 0xffffu], l2 = e2 >> 8;
+          if (l2 > 0 && l1 + l2 <= MW_BITS && !(esc && (e2 & 0xff) == 255))
+            { g.nbits = (uint8_t) (l1 + l2); g.run = (uint8_t) (e1 & 0xff); g.last = (uint8_t) l2; g.ok = 1; }
+        }
+      m->e[x] = g;
+    }
+}
+
 /* run-coded segment (QV.c:604-691); *nonrun receives the number of non-run symbols */
 static int64_t walk_runs(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *nt, int esc,
-                         const wlut *rt, uint32_t *nonrun, int flip)
+                         const wlut *rt, const rwlut *pair, uint32_t *nonrun, int flip)
 { wrd r = { p, end, 0, 0, 0, flip };
   uint32_t j = 0, last = 0, nn = 0;
   int64_t bytes;
   while (j < rlen)
-    { uint32_t e = rt->e[w_peek(&r)], c = e & 0xff;
+    { uint32_t w = w_peek(&r), e, c;
+      const rwent g = pair->e[w >> (16 - MW_BITS)];
+      if (g.ok && j + g.run < rlen)                      /* run, then a symbol that exists */
+        { w_skip(&r, g.nbits);
+          j   += (uint32_t) g.run + 1u;
+          nn  += 1;
+          last = g.last;
+          continue;
+        }
+      e = rt->e[w]; c = e & 0xff;
       last = e >> 8;
       w_skip(&r, (int) last);
       if (c == 255)
@@ -642,6 +703,8 @@ void dx_qv_index_free(dx_qv_index *x)
 
 int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
 { wlut    *lut[6] = { NULL, NULL, NULL, NULL, NULL, NULL };
+  mwlut   *mlut[4] = { NULL, NULL, NULL, NULL };
+  rwlut   *rlut[2] = { NULL, NULL };
   size_t   at = 0, used = 0;
   uint64_t cap = 0, hat = 0;
   uint16_t key;
@@ -663,6 +726,19 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
       lut[s] = malloc(sizeof(wlut));
       if (lut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
       build_wlut(&x->coding.s[s], lut[s]);
+      if (s < 4)
+        { mlut[s] = malloc(sizeof(mwlut));
+          if (mlut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
+          build_mwlut(lut[s], x->coding.s[s].type == 2, mlut[s]);
+        }
+    }
+
+  for (s = 0; s < 2; s++)
+    { const int sym = s ? DX_SUB : DX_DEL, run = s ? DX_SRUN : DX_DRUN;
+      if (lut[run] == NULL) continue;
+      rlut[s] = malloc(sizeof(rwlut));
+      if (rlut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
+      build_rwlut(lut[run], lut[sym], x->coding.s[sym].type == 2, rlut[s]);
     }
 
   while (at < n)                                          /* undexqv.c:119-208 */
@@ -711,25 +787,25 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
 
       clen = rlen;                                        /* QV.c:1433-1462 */
       if (x->coding.delChar < 0)
-        b = walk_plain(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2, x->flip);
+        b = walk_plain(img + at, end, rlen, lut[DX_DEL], mlut[DX_DEL], x->coding.s[DX_DEL].type == 2, x->flip);
       else
-        b = walk_runs(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2, lut[DX_DRUN], &clen, x->flip);
+        b = walk_runs(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2, lut[DX_DRUN], rlut[0], &clen, x->flip);
       if (b < 0) { rc = DX_E_FORMAT; goto fail; }
       sg[0] = (uint32_t) b; at += (size_t) b;
       sg[1] = (clen + 3) >> 2;
       if (at + sg[1] > n) { rc = DX_E_FORMAT; goto fail; }
       at += sg[1];
-      b = walk_plain(img + at, end, rlen, lut[DX_INS], x->coding.s[DX_INS].type == 2, x->flip);   /* QV.c:1464 */
+      b = walk_plain(img + at, end, rlen, lut[DX_INS], mlut[DX_INS], x->coding.s[DX_INS].type == 2, x->flip);   /* QV.c:1464 */
       if (b < 0) { rc = DX_E_FORMAT; goto fail; }
       sg[2] = (uint32_t) b; at += (size_t) b;
-      b = walk_plain(img + at, end, rlen, lut[DX_MRG], x->coding.s[DX_MRG].type == 2, x->flip);   /* QV.c:1467 */
+      b = walk_plain(img + at, end, rlen, lut[DX_MRG], mlut[DX_MRG], x->coding.s[DX_MRG].type == 2, x->flip);   /* QV.c:1467 */
       if (b < 0) { rc = DX_E_FORMAT; goto fail; }
       sg[3] = (uint32_t) b; at += (size_t) b;
       if (x->coding.subChar < 0)                                                          /* QV.c:1470-1478 */
-        b = walk_plain(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2, x->flip);
+        b = walk_plain(img + at, end, rlen, lut[DX_SUB], mlut[DX_SUB], x->coding.s[DX_SUB].type == 2, x->flip);
       else
         { uint32_t nn;
-          b = walk_runs(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2, lut[DX_SRUN], &nn, x->flip);
+          b = walk_runs(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2, lut[DX_SRUN], rlut[1], &nn, x->flip);
         }
       if (b < 0) { rc = DX_E_FORMAT; goto fail; }
       sg[4] = (uint32_t) b; at += (size_t) b;
@@ -742,10 +818,14 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   x->rec_off[x->n] = at;
   x->hdr_off[x->n] = hat;
   for (s = 0; s < 6; s++) free(lut[s]);
+  for (s = 0; s < 4; s++) free(mlut[s]);
+  free(rlut[0]); free(rlut[1]);
   return DX_OK;
 
 fail:
   for (s = 0; s < 6; s++) free(lut[s]);
+  for (s = 0; s < 4; s++) free(mlut[s]);
+  free(rlut[0]); free(rlut[1]);
   dx_qv_index_free(x);
   return rc;
 }
