@@ -9,6 +9,7 @@
  */
 #include <pthread.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -52,12 +53,23 @@ static const char *Prog;
 
 /* ---- whole-file I/O ---------------------------------------------------------------------- */
 
-static uint8_t *slurp(FILE *f, size_t *n)
+/* The whole input as one buffer.  A regular file is mapped (no copy through a read buffer: the
+   upload to the GPU reads the page cache directly); a pipe is read to its end.  *mapped tells
+   unslurp which. */
+static uint8_t *slurp(FILE *f, size_t *n, int *mapped)
 { size_t cap = 1 << 20, len = 0, k;
   uint8_t *buf;
   struct stat st;
+  *mapped = 0;
   if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0)
-    cap = (size_t) st.st_size + 1;                     /* a regular file: one allocation, no regrowth copies */
+    { void *m = mmap(NULL, (size_t) st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fileno(f), 0);
+      if (m != MAP_FAILED)
+        { *mapped = 1;
+          *n = (size_t) st.st_size;
+          return (uint8_t *) m;
+        }
+      cap = (size_t) st.st_size + 1;
+    }
   buf = malloc(cap);
   if (buf == NULL) return NULL;
   while ((k = fread(buf + len, 1, cap - len, f)) > 0)
@@ -70,6 +82,11 @@ static uint8_t *slurp(FILE *f, size_t *n)
     }
   *n = len;
   return buf;
+}
+
+static void unslurp(uint8_t *buf, size_t n, int mapped)
+{ if (mapped) munmap(buf, n);
+  else        free(buf);
 }
 
 /* directory part / root name, as PathTo and Root do (DB.c:112-160) */
@@ -298,7 +315,7 @@ int dex_tool_main(int tool, int argc, char *argv[])
       FILE    *input, *output;
       uint8_t *in, *out = NULL;
       size_t   n = 0, out_len = 0;
-      int      st;
+      int      st, mapped = 0;
 
       if (PIPE)
         { input  = stdin;
@@ -325,7 +342,7 @@ int dex_tool_main(int tool, int argc, char *argv[])
           fflush(stderr);
         }
 
-      in = slurp(input, &n);
+      in = slurp(input, &n, &mapped);
       tmark("input read");
       if (Opening)
         { pthread_join(Opener, NULL);
@@ -346,7 +363,7 @@ int dex_tool_main(int tool, int argc, char *argv[])
           leave(2);
         }
       dx_file_free(out);
-      free(in);
+      unslurp(in, n, mapped);
       tmark("output written");
 
       if (!PIPE)
