@@ -619,6 +619,7 @@ static int64_t walk_plain(const uint8_t *p, const uint8_t *end, uint32_t rlen, c
   while (j < rlen)
     { uint32_t w = w_peek(&r);
       const mwent g = m->e[w >> (16 - MW_BITS)];
+      if (r.nb < 0) return -1;                           /* more bits consumed than the image holds */
       if (g.nsym && j + g.nsym <= rlen)
         { w_skip(&r, g.nbits);
           j   += g.nsym;
@@ -627,6 +628,7 @@ static int64_t walk_plain(const uint8_t *p, const uint8_t *end, uint32_t rlen, c
         }
       { uint32_t e = t->e[w];
         last = e >> 8;
+        if (last == 0) return -1;                          /* no such code */
         w_skip(&r, (int) last);
         if (esc && (e & 0xff) == 255)
           { w_peek(&r); w_skip(&r, 8); last = 8; }
@@ -666,6 +668,7 @@ static int64_t walk_runs(const uint8_t *p, const uint8_t *end, uint32_t rlen, co
   while (j < rlen)
     { uint32_t w = w_peek(&r), e, c;
       const rwent g = pair->e[w >> (16 - MW_BITS)];
+      if (r.nb < 0) return -1;                           /* more bits consumed than the image holds */
       if (g.ok && j + g.run < rlen)                      /* run, then a symbol that exists */
         { w_skip(&r, g.nbits);
           j   += (uint32_t) g.run + 1u;
@@ -675,6 +678,7 @@ static int64_t walk_runs(const uint8_t *p, const uint8_t *end, uint32_t rlen, co
         }
       e = rt->e[w]; c = e & 0xff;
       last = e >> 8;
+      if (last == 0) return -1;                            /* no such code */
       w_skip(&r, (int) last);
       if (c == 255)
         { c = w_peek(&r); w_skip(&r, 16); last = 16; }
@@ -683,6 +687,7 @@ static int64_t walk_runs(const uint8_t *p, const uint8_t *end, uint32_t rlen, co
       if (j < rlen)
         { e = nt->e[w_peek(&r)];
           last = e >> 8;
+          if (last == 0) return -1;
           w_skip(&r, (int) last);
           if (esc && (e & 0xff) == 255)
             { w_peek(&r); w_skip(&r, 8); last = 8; }
@@ -766,8 +771,10 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
           beg = h[0]; end_ = h[1]; qv = h[2];
           at += 6;
         }
-      if (end_ < beg) { rc = DX_E_FORMAT; goto fail; }
-      rlen = (uint32_t) (end_ - beg);
+      if (end_ < beg || (int64_t) end_ - (int64_t) beg > 0x7fffffff) { rc = DX_E_FORMAT; goto fail; }
+      rlen = (uint32_t) ((int64_t) end_ - (int64_t) beg);
+      if ((uint64_t) rlen > 65536u * 8u * (uint64_t) (n - at) + 64u)      /* a token has >= 1 bit and covers <= 65536 symbols */
+        { rc = DX_E_FORMAT; goto fail; }
 
       if (x->n == cap)
         { cap = cap ? 2 * cap : 1024;
