@@ -1090,12 +1090,19 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
           else                                           // Encode
             { const uint32_t m4 = mask * 0x01010101u;
               u32x4 c = fetch(p, pos, L, over);
-              for (uint32_t base = 0; base < L; base += DX_STEP)
-                { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
-                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, s_stok[q], m4);
-                  c = d;
-                  pos += DX_STEP;
+              // ins and mrg are always plain: with the table at a compile-time LDS address a look-up
+              // address is one SDWA shift of the byte (no base to add)
+#define PLAIN_LOOP(STAB)                                                                        \
+              for (uint32_t base = 0; base < L; base += DX_STEP)                                 \
+                { const u32x4 d = fetch(p, pos + DX_STEP, L, over);                              \
+                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4); \
+                  c = d;                                                                         \
+                  pos += DX_STEP;                                                                \
                 }
+              if (q == 1)      { PLAIN_LOOP(s_stok[1]) }
+              else if (q == 2) { PLAIN_LOOP(s_stok[2]) }
+              else             { PLAIN_LOOP(s_stok[q]) }
+#undef PLAIN_LOOP
               got = finish_words(o, last_piece_plain(tab, p, L, mask));
               if (q == 0)                                // no delChar: the whole tag line is packed
                 { ot.seg = dst + want; ot.wordbase = 0; ot.winbits = 0;
