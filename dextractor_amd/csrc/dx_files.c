@@ -51,6 +51,96 @@ static void dfree_all(dpool *pool)
 }
 
 /* ==========================================================================================
+ *  dexta / dexar
+ * ========================================================================================== */
+int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
+                  uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
+{ dpool     pool = { {0}, 0, ctx };
+  uint64_t  cnt = 0, i, *off = NULL, *hoff = NULL, *ooff = NULL;
+  uint32_t *tlen = NULL, *nsym = NULL;
+  int32_t  *hdr4 = NULL, lwell = 0;
+  uint16_t *cnr4 = NULL;
+  uint8_t  *blob = NULL, *img = NULL;
+  size_t    plen = 0, at, total;
+  void     *d_text = NULL, *d_off = NULL, *d_tlen = NULL, *d_nsym = NULL, *d_hdr, *d_hoff, *d_out, *d_ooff;
+  int       rc;
+
+  if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
+  *out = NULL; *out_len = 0;
+
+  /* index: on the GPU for large images (newline scan, record extents there; only header lines come
+     back), on the host for small ones and for anything the GPU front end rejects (exact message) */
+  if (n > 0) TRY(dupload(&pool, text, n, &d_text));
+  if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL)
+    { uint64_t *go = NULL; uint32_t *gt = NULL, *gs = NULL;
+      rc = dx_index_seq_device(ctx, arrow, d_text, n, &go, &gt, &gs, &cnt, &hdr4, &cnr4, &plen, errline, errcode);
+      if (rc == DX_OK)
+        { d_off = go; d_tlen = gt; d_nsym = gs;
+          pool.p[pool.n++] = go; pool.p[pool.n++] = gt; pool.p[pool.n++] = gs;
+          nsym = malloc((cnt + 1) * sizeof(*nsym));
+          if (!nsym) { rc = DX_E_NOMEM; goto done; }
+          TRY(dx_d2h(ctx, nsym, d_nsym, cnt * 4));
+        }
+      else if (rc != DX_E_FORMAT)
+        goto done;
+      rc = DX_OK;
+    }
+  if (d_off == NULL)
+    { TRY(dx_index_seq(arrow, text, n, 0, NULL, NULL, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
+      off  = malloc((cnt + 1) * sizeof(*off));
+      tlen = malloc((cnt + 1) * sizeof(*tlen));
+      nsym = malloc((cnt + 1) * sizeof(*nsym));
+      hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+      cnr4 = malloc((cnt + 1) * 4 * sizeof(*cnr4));
+      if (!off || !tlen || !nsym || !hdr4 || !cnr4) { rc = DX_E_NOMEM; goto done; }
+      TRY(dx_index_seq(arrow, text, n, cnt, off, tlen, nsym, hdr4, cnr4, &cnt, &plen, errline, errcode));
+      TRY(dupload(&pool, off,  cnt * 8, &d_off));
+      TRY(dupload(&pool, tlen, cnt * 4, &d_tlen));
+      TRY(dupload(&pool, nsym, cnt * 4, &d_nsym));
+    }
+  hoff = malloc((cnt + 1) * sizeof(*hoff));
+  ooff = malloc((cnt + 1) * sizeof(*ooff));
+  if (!hoff || !ooff) { rc = DX_E_NOMEM; goto done; }
+
+  blob = malloc(dx_frame_bound(hdr4, cnt, 0, arrow) + 16);
+  if (!blob) { rc = DX_E_NOMEM; goto done; }
+  TRY(dx_frame_headers(hdr4, cnr4, cnt, arrow, &lwell, blob, hoff));
+
+  at = 2 + 4 + plen;                                   /* key, prefix length, prefix: dexta.c:124-129 */
+  for (i = 0; i < cnt; i++)
+    { ooff[i] = at;
+      at += (size_t) (hoff[i+1] - hoff[i]) + (((size_t) nsym[i] + 3) >> 2);
+    }
+  total = at;
+
+  img = malloc(total + 16);
+  if (!img) { rc = DX_E_NOMEM; goto done; }
+  { uint16_t key = 0x55aa;
+    int32_t  pl  = (int32_t) plen;
+    memcpy(img, &key, 2);
+    memcpy(img + 2, &pl, 4);
+    memcpy(img + 6, text, plen);
+  }
+
+  if (cnt > 0)
+    { TRY(dupload(&pool, blob, (size_t) hoff[cnt], &d_hdr));
+      TRY(dupload(&pool, hoff, (cnt + 1) * 8, &d_hoff));
+      TRY(dupload(&pool, ooff, cnt * 8, &d_ooff));
+      TRY(dalloc(&pool, total, &d_out));
+      TRY(dx_pack2_encode(ctx, arrow ? DX_ALPHA_ARROW : DX_ALPHA_BASES, d_text, d_off, d_tlen, d_nsym, cnt,
+                          d_hdr, d_hoff, d_out, d_ooff));
+      TRY(dx_d2h(ctx, img + ooff[0], (uint8_t *) d_out + ooff[0], total - (size_t) ooff[0]));
+    }
+  *out = img; *out_len = total; img = NULL;
+  rc = DX_OK;
+
+done:
+  dfree_all(&pool);
+  free(off); free(hoff); free(ooff); free(tlen); free(nsym); free(hdr4); free(cnr4); free(blob); free(img);
+  return rc;
+}
+
+/* ==========================================================================================
  *  dexta / dexar of one file on several GPUs: reads are independent, so contiguous read ranges
  *  (balanced by text bytes) go to one host thread per context; nothing is exchanged -- the only
  *  cross-record datum, the previous well of a range's first read, is known from the host index.
@@ -182,96 +272,6 @@ int dx_file_pack2_sharded(dx_ctx **ctxs, int nctx, int arrow, const uint8_t *tex
 done:
   free(off); free(hoff); free(ooff); free(tlen); free(nsym); free(hdr4); free(cnr4); free(blob); free(img);
   free(jobs); free(th);
-  return rc;
-}
-
-/* ==========================================================================================
- *  dexta / dexar
- * ========================================================================================== */
-int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
-                  uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
-{ dpool     pool = { {0}, 0, ctx };
-  uint64_t  cnt = 0, i, *off = NULL, *hoff = NULL, *ooff = NULL;
-  uint32_t *tlen = NULL, *nsym = NULL;
-  int32_t  *hdr4 = NULL, lwell = 0;
-  uint16_t *cnr4 = NULL;
-  uint8_t  *blob = NULL, *img = NULL;
-  size_t    plen = 0, at, total;
-  void     *d_text = NULL, *d_off = NULL, *d_tlen = NULL, *d_nsym = NULL, *d_hdr, *d_hoff, *d_out, *d_ooff;
-  int       rc;
-
-  if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
-  *out = NULL; *out_len = 0;
-
-  /* index: on the GPU for large images (newline scan, record extents there; only header lines come
-     back), on the host for small ones and for anything the GPU front end rejects (exact message) */
-  if (n > 0) TRY(dupload(&pool, text, n, &d_text));
-  if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL)
-    { uint64_t *go = NULL; uint32_t *gt = NULL, *gs = NULL;
-      rc = dx_index_seq_device(ctx, arrow, d_text, n, &go, &gt, &gs, &cnt, &hdr4, &cnr4, &plen, errline, errcode);
-      if (rc == DX_OK)
-        { d_off = go; d_tlen = gt; d_nsym = gs;
-          pool.p[pool.n++] = go; pool.p[pool.n++] = gt; pool.p[pool.n++] = gs;
-          nsym = malloc((cnt + 1) * sizeof(*nsym));
-          if (!nsym) { rc = DX_E_NOMEM; goto done; }
-          TRY(dx_d2h(ctx, nsym, d_nsym, cnt * 4));
-        }
-      else if (rc != DX_E_FORMAT)
-        goto done;
-      rc = DX_OK;
-    }
-  if (d_off == NULL)
-    { TRY(dx_index_seq(arrow, text, n, 0, NULL, NULL, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
-      off  = malloc((cnt + 1) * sizeof(*off));
-      tlen = malloc((cnt + 1) * sizeof(*tlen));
-      nsym = malloc((cnt + 1) * sizeof(*nsym));
-      hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
-      cnr4 = malloc((cnt + 1) * 4 * sizeof(*cnr4));
-      if (!off || !tlen || !nsym || !hdr4 || !cnr4) { rc = DX_E_NOMEM; goto done; }
-      TRY(dx_index_seq(arrow, text, n, cnt, off, tlen, nsym, hdr4, cnr4, &cnt, &plen, errline, errcode));
-      TRY(dupload(&pool, off,  cnt * 8, &d_off));
-      TRY(dupload(&pool, tlen, cnt * 4, &d_tlen));
-      TRY(dupload(&pool, nsym, cnt * 4, &d_nsym));
-    }
-  hoff = malloc((cnt + 1) * sizeof(*hoff));
-  ooff = malloc((cnt + 1) * sizeof(*ooff));
-  if (!hoff || !ooff) { rc = DX_E_NOMEM; goto done; }
-
-  blob = malloc(dx_frame_bound(hdr4, cnt, 0, arrow) + 16);
-  if (!blob) { rc = DX_E_NOMEM; goto done; }
-  TRY(dx_frame_headers(hdr4, cnr4, cnt, arrow, &lwell, blob, hoff));
-
-  at = 2 + 4 + plen;                                   /* key, prefix length, prefix: dexta.c:124-129 */
-  for (i = 0; i < cnt; i++)
-    { ooff[i] = at;
-      at += (size_t) (hoff[i+1] - hoff[i]) + (((size_t) nsym[i] + 3) >> 2);
-    }
-  total = at;
-
-  img = malloc(total + 16);
-  if (!img) { rc = DX_E_NOMEM; goto done; }
-  { uint16_t key = 0x55aa;
-    int32_t  pl  = (int32_t) plen;
-    memcpy(img, &key, 2);
-    memcpy(img + 2, &pl, 4);
-    memcpy(img + 6, text, plen);
-  }
-
-  if (cnt > 0)
-    { TRY(dupload(&pool, blob, (size_t) hoff[cnt], &d_hdr));
-      TRY(dupload(&pool, hoff, (cnt + 1) * 8, &d_hoff));
-      TRY(dupload(&pool, ooff, cnt * 8, &d_ooff));
-      TRY(dalloc(&pool, total, &d_out));
-      TRY(dx_pack2_encode(ctx, arrow ? DX_ALPHA_ARROW : DX_ALPHA_BASES, d_text, d_off, d_tlen, d_nsym, cnt,
-                          d_hdr, d_hoff, d_out, d_ooff));
-      TRY(dx_d2h(ctx, img + ooff[0], (uint8_t *) d_out + ooff[0], total - (size_t) ooff[0]));
-    }
-  *out = img; *out_len = total; img = NULL;
-  rc = DX_OK;
-
-done:
-  dfree_all(&pool);
-  free(off); free(hoff); free(ooff); free(tlen); free(nsym); free(hdr4); free(cnr4); free(blob); free(img);
   return rc;
 }
 
