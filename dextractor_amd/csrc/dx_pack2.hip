@@ -262,6 +262,8 @@ extern "C" int dx_pack2_encode(dx_ctx *ctx, int alphabet,
   if ((d_hdr == NULL) != (d_hdr_off == NULL))
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: d_hdr and d_hdr_off must be given together");
   if (n == 0) return DX_OK;
+  if (n >= (1ull << 31))
+    return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: more than 2^31 - 1 reads in one batch");
   if (!d_text || !d_off || !d_tlen || !d_nsym || !d_out || !d_out_off)
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
@@ -293,6 +295,8 @@ extern "C" int dx_pack2_decode(dx_ctx *ctx, int letters,
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: line width must be >= 1 "
                                   "(the reference loops forever on -w0, undexta.c:265)");
   if (n == 0) return DX_OK;
+  if (n >= (1ull << 31))
+    return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: more than 2^31 - 1 reads in one batch");
   if (!d_in || !d_in_off || !d_nsym || !d_out || !d_out_off)
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));

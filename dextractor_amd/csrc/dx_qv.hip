@@ -1126,6 +1126,8 @@ static int check_batch(dx_ctx *ctx, const dx_qv_batch *b, const char *who)
   if (b == NULL) return dx_fail(ctx, DX_E_ARG, "%s: NULL batch", who);
   if (b->n && (!b->d_text || !b->d_off || !b->d_len))
     return dx_fail(ctx, DX_E_ARG, "%s: NULL device pointer in batch", who);
+  if (b->n >= (1ull << 31))                              // the kernels hand out entries through a 32-bit counter
+    return dx_fail(ctx, DX_E_ARG, "%s: more than 2^31 - 1 entries in one batch", who);
   return DX_OK;
 }
 

@@ -367,6 +367,8 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
 { if (ctx == NULL) return DX_E_ARG;
   if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_decode: call dx_qv_set_coding first");
   if (n == 0) return DX_OK;
+  if (n >= (1ull << 31))
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_decode: more than 2^31 - 1 entries in one batch");
   if (!d_in || !d_rec_off || !d_seg || !d_len || !d_out || !d_out_off)
     return dx_fail(ctx, DX_E_ARG, "dx_qv_decode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
