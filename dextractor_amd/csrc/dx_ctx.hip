@@ -167,7 +167,7 @@ int dx_scratch(dx_ctx *ctx, size_t bytes, void **p)
   return DX_OK;
 }
 
-// Number of workgroups for a one-wave-per-unit grid-stride kernel: enough waves to fill the
+// Number of workgroups for a one-wave-per-unit kernel: enough waves to fill the
 // chip (waves_per_cu resident waves on each of the CUs) but never more than the units.
 int dx_grid_waves(dx_ctx *ctx, uint64_t n_units, int waves_per_cu)
 { uint64_t waves = (uint64_t) ctx->num_cu * (uint64_t) waves_per_cu;

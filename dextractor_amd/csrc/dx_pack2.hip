@@ -11,11 +11,11 @@
 // Roofline: HBM.  Algorithmic bytes per symbol: encode 1 (+1/80 for the newlines of 80-column
 // text) read + 0.25 written; decode 0.25 read + 1 (+1/80) written.
 //
-// Layout: one 64-lane wavefront per read, grid-stride over reads.  A wave walks the read's text
-// 1 KiB per step (16 bytes per lane, one unaligned global_load_dwordx4), drops the '\n' bytes by
-// a lane-local compaction + wave prefix sum of the kept counts, ORs each lane's <=32 code bits
-// into a small LDS word window at the bit position the prefix sum gives, and flushes the
-// completed 32-bit words with coalesced (unaligned) dword stores.
+// Layout: one 64-lane wavefront per read; the waves draw reads from a ticket counter, 16 at a
+// time.  A wave walks the read's text 1 KiB per step (16 bytes per lane, one unaligned
+// global_load_dwordx4), maps the bytes through a 256-byte LDS table, deletes the 2-bit slots of
+// the '\n' bytes, ORs each lane's <=32 code bits into a small LDS word window at the bit position
+// a wave prefix sum of the kept counts gives, and drains the window in 16-byte units.
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 

@@ -11,12 +11,14 @@
 // written (C = output bytes per base, ~1.44).  The size pass re-reads 4 B/base (counted against
 // `achieved`, not as algorithmic bytes).
 //
-// Layout: one 64-lane wavefront per .quiva entry, grid-stride over entries.  A wave walks the
+// Layout: one 64-lane wavefront per .quiva entry; the waves draw entries from a ticket counter
+// (next_unit), so they neither march in step nor wait for the longest entry.  A wave walks the
 // streams 1 KiB per step (16 bytes per lane, one unaligned global_load_dwordx4 each), with the
 // next step's chunks already in flight (register prefetch) while the current ones are processed.
 // Code tables live in LDS as packed tokens; a DPP inclusive prefix sum over the lanes' bit counts
-// places every lane's bits in a per-wave LDS word window (ds_or_b32); completed 32-bit words
-// leave with coalesced dword stores at the segment's (byte-granular) file offset.
+// places every lane's bits in a per-wave LDS word window (ds_or_b32); completed words leave in
+// 16-byte units at the segment's (byte-granular) file offset.  All three kernels are bound by
+// VALU issue, not by HBM: what counts is instructions per byte.
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 
