@@ -62,6 +62,7 @@ extern "C" int dx_open(int device, dx_ctx **out)
   OPEN_HIP(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   OPEN_HIP(hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking));
+  OPEN_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
   ctx->stream = ctx->own;
   OPEN_HIP(hipMalloc((void **) &ctx->d_tok, DX_TOK_WORDS * sizeof(uint32_t)));
   OPEN_HIP(hipMalloc((void **) &ctx->d_dec, 6 * DX_DEC_SIZE * sizeof(uint16_t)));
@@ -90,6 +91,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);
   (void) hipStreamDestroy(ctx->own);
+  (void) hipStreamDestroy(ctx->side);
   delete ctx;
 }
 
@@ -180,7 +182,7 @@ int dx_grid_waves(dx_ctx *ctx, uint64_t n_units, int waves_per_cu)
 
 static const char *k_names[DX_K_COUNT] =
   { "k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
-    "k_qv_encode", "k_qv_decode", "k_synth", "k_index" };
+    "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact" };
 
 extern "C" const char *dx_kernel_name(int kernel)
 { return (kernel >= 0 && kernel < DX_K_COUNT) ? k_names[kernel] : "?"; }

@@ -24,6 +24,7 @@ struct dx_pending { hipEvent_t a, b; int kernel; };
 struct dx_ctx
 { int          device;
   hipStream_t  own, stream;
+  hipStream_t  side;             // second stream: compaction beside the next group's encode (dx_qv_encode_onepass)
   int          num_cu;
   char         err[512];
 
@@ -41,6 +42,7 @@ struct dx_ctx
   int       coding_set;
   int       lossy;
   int       delChar, subChar;
+  uint32_t  bps[4];            // upper bound of encoded bits per symbol of del/ins/mrg/sub (dx_qv_encode_onepass)
 
   // scratch owned by the context
   uint32_t *d_status;          // device error flags (bit 0: symbol count mismatch)

@@ -659,6 +659,31 @@ void k_scan_apply(const uint32_t *in, uint64_t n, const uint64_t *tile_sum, uint
     out[n] = *grand;
 }
 
+// the same for one group of a longer array: offsets start at base_in[0]; base_out[0] = where the next group starts
+__global__ __launch_bounds__(DX_BLOCK)
+void k_scan_apply_base(const uint32_t *in, uint64_t n, const uint64_t *tile_sum, uint64_t *out /* n+1 */,
+                       const uint64_t *grand, const uint64_t *base_in, uint64_t *base_out)
+{ __shared__ uint64_t s_wave[DX_WAVES_PER_BLK];
+  const uint64_t t0 = (uint64_t) blockIdx.x * SCAN_TILE + (uint64_t) threadIdx.x * SCAN_ITEMS;
+  uint32_t v[SCAN_ITEMS];
+  uint64_t s = 0;
+  for (int k = 0; k < SCAN_ITEMS; k++)
+    { v[k] = t0 + k < n ? in[t0 + k] : 0u;
+      s   += v[k];
+    }
+  uint64_t tot;
+  uint64_t at = *base_in + tile_sum[blockIdx.x] + block_excl_scan(s, s_wave, tot);
+  for (int k = 0; k < SCAN_ITEMS; k++)
+    if (t0 + k < n)
+      { out[t0 + k] = at;
+        at += v[k];
+      }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    { out[n]    = *base_in + *grand;
+      *base_out = *base_in + *grand;
+    }
+}
+
 // =============================================================================================
 //  encode pass
 // =============================================================================================
@@ -1011,9 +1036,22 @@ __device__ __forceinline__ uint32_t encode_all_tags(wave_out &ot, const uint8_t 
   return finish_tags(ot);
 }
 
+// Scratch mode of k_qv_encode (dx_qv_encode_onepass): the entry is written compactly (del, ins,
+// mrg, sub; the tags at the slot's end) into a slot of a size bounded from the tables, and the
+// sizes it turns out to have are recorded, instead of being taken from a size pass.
+struct enc_scratch
+{ uint8_t        *base;        // NULL: direct mode (offsets and sizes from k_qv_sizes)
+  const uint64_t *slot_off;    // n + 1
+  uint32_t       *seg_out;     // n x 5
+  uint32_t       *rec_size;    // n
+};
+
+__host__ __device__ __forceinline__ uint32_t tag_room(uint32_t L) { return (((L + 3u) >> 2) + 7u) & ~3u; }
+
 __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
-                 const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status, uint32_t *ticket)
+                 const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status, uint32_t *ticket,
+                 enc_scratch sc)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint8_t  s_tagcode[256];
@@ -1038,14 +1076,24 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
   for (uint64_t r = next_unit(ticket), nxt; r < a.n; r = nxt)
     { nxt = next_unit(ticket);
       const uint32_t  L   = a.len[r];
+      const bool      S   = sc.base != NULL;             // scratch mode
       const uint32_t *sg  = seg + 5 * r;
-      uint8_t        *dst = out + rec_off[r];
-      if (hdr != NULL)                                   // record framing (dexqv.c:128-139)
-        { const uint64_t h0 = hdr_off[r];
-          const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
-          for (uint32_t k = lane; k < hl; k += 64)
-            dst[k] = hdr[h0 + k];
-          dst += hl;
+      uint32_t       *sgw = sc.seg_out + 5 * r;
+      uint8_t        *dst, *tag_at = NULL;
+      uint32_t        sum = 0;
+      if (S)
+        { dst    = sc.base + sc.slot_off[r];
+          tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
+        }
+      else
+        { dst = out + rec_off[r];
+          if (hdr != NULL)                               // record framing (dexqv.c:128-139)
+            { const uint64_t h0 = hdr_off[r];
+              const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
+              for (uint32_t k = lane; k < hl; k += 64)
+                dst[k] = hdr[h0 + k];
+              dst += hl;
+            }
         }
       const uint8_t *p1   = line_ptr(a, r, L, 1);
       const bool     over = can_overread(a, line_ptr(a, r, L, 4), L);
@@ -1060,7 +1108,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
           const uint8_t  *p    = line_ptr(a, r, L, line);
           const int       rci  = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
           const uint32_t *tab  = s_tok[q];
-          const uint32_t  want = sg[line];
+          const uint32_t  want = S ? 0u : sg[line];
           const uint32_t  mask = !a.lossy ? 0xffu : (q == 1 ? 0xfeu : (q == 2 ? 0xfcu : 0xffu));   // QV.c:1406-1415
           o.seg = dst; o.wordbase = 0; o.winbits = 0;
           uint32_t got, pos = 16u * lane;
@@ -1069,7 +1117,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
             { const uint32_t *rtab = s_tok[q == 0 ? DX_DRUN : DX_SRUN];
               const bool      tags = q == 0;
               uint32_t C = 0;
-              ot.seg = dst + want; ot.wordbase = 0; ot.winbits = 0;
+              ot.seg = S ? tag_at : dst + want; ot.wordbase = 0; ot.winbits = 0;
               u32x4 c = fetch(p, pos, L, over), t = c;
               if (tags) t = fetch(p1, pos, L, over);
               for (uint32_t base = 0; base < L; base += DX_STEP)
@@ -1085,8 +1133,9 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
               const uint32_t last = C > 0 ? encode_trailing_run(o, C, rtab) : last_piece_plain(tab, p, L, 0xffu);
               got = finish_words(o, last);
               if (tags)
-                { bad |= finish_tags(ot) ^ sg[1];
-                  dst += sg[1];
+                { const uint32_t tb = finish_tags(ot);
+                  if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
+                  else   { bad |= tb ^ sg[1]; dst += sg[1]; }
                 }
             }
           else                                           // Encode
@@ -1107,17 +1156,93 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 #undef PLAIN_LOOP
               got = finish_words(o, last_piece_plain(tab, p, L, mask));
               if (q == 0)                                // no delChar: the whole tag line is packed
-                { ot.seg = dst + want; ot.wordbase = 0; ot.winbits = 0;
-                  bad |= encode_all_tags(ot, p1, L, over) ^ sg[1];
-                  dst += sg[1];
+                { ot.seg = S ? tag_at : dst + want; ot.wordbase = 0; ot.winbits = 0;
+                  const uint32_t tb = encode_all_tags(ot, p1, L, over);
+                  if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
+                  else   { bad |= tb ^ sg[1]; dst += sg[1]; }
                 }
             }
-          bad |= got ^ want;
-          dst += want;
+          if (S)
+            { if (lane == 0) sgw[line] = got;
+              sum += got;
+              dst += got;
+            }
+          else
+            { bad |= got ^ want;
+              dst += want;
+            }
+        }
+      if (S)
+        { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
+          if (lane == 0)
+            sc.rec_size[r] = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
         }
       if (bad && lane == 0)
-        atomicOr(status, 2u);                            // sizes disagree with k_qv_sizes
+        atomicOr(status, 2u);                            // sizes disagree with k_qv_sizes / slot overflow
     }
+}
+
+// per-entry slot size for the scratch mode: sum over the streams of the table-derived bound
+__global__ __launch_bounds__(DX_BLOCK)
+void k_qv_bounds(const uint32_t *len, uint64_t n, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t *bound)
+{ const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t L = len[i];
+  const uint64_t bits = L * b0 + L * b1 + L * b2 + L * b3;
+  const uint64_t bytes = ((bits + 7) >> 3) + 4 * 20 + tag_room((uint32_t) L);     // + partial and pad words, trailing run tokens
+  bound[i] = (uint32_t) ((bytes + 15) & ~(uint64_t) 15);                          // (entries of < 2^27 symbols)
+}
+
+// bytes [0, nbytes) from src to dst, both arbitrarily aligned, by one wave: a byte-wise head up to
+// dst's 16-byte boundary, then aligned 16-byte stores fed by unaligned loads, four in flight per lane
+__device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint32_t nbytes)
+{ const uint32_t lane = (uint32_t) lane_id();
+  uint32_t head = (uint32_t) ((16u - ((uintptr_t) dst & 15u)) & 15u);
+  if (head > nbytes) head = nbytes;
+  if (lane < head) dst[lane] = src[lane];
+  dst += head; src += head; nbytes -= head;
+  const uint32_t n16 = nbytes >> 4;
+  uint32_t k = lane;
+  for (; k + 192u < n16; k += 256u)
+    { const u32x4 v0 = *(const u32x4_u *) (src + 16ull * k),          v1 = *(const u32x4_u *) (src + 16ull * (k + 64u));
+      const u32x4 v2 = *(const u32x4_u *) (src + 16ull * (k + 128u)), v3 = *(const u32x4_u *) (src + 16ull * (k + 192u));
+      *(u32x4 *) (dst + 16ull * k)          = v0; *(u32x4 *) (dst + 16ull * (k + 64u))  = v1;
+      *(u32x4 *) (dst + 16ull * (k + 128u)) = v2; *(u32x4 *) (dst + 16ull * (k + 192u)) = v3;
+    }
+  for (; k < n16; k += 64u)
+    *(u32x4 *) (dst + 16ull * k) = *(const u32x4_u *) (src + 16ull * k);
+  for (uint32_t t = 16u * n16 + lane; t < nbytes; t += 64u)
+    dst[t] = src[t];
+}
+
+#define COMPACT_BATCH 8u
+// scratch slots -> the record stream: header, del, tags, ins + mrg + sub (QV.c:1393-1423 order)
+__global__ __launch_bounds__(DX_BLOCK)
+void k_qv_compact(uint64_t n, const uint32_t *len, const uint8_t *scratch, const uint64_t *slot_off, const uint32_t *seg,
+                  const uint64_t *rec_off, const uint8_t *hdr, const uint64_t *hdr_off, uint8_t *out, uint64_t out_cap,
+                  uint32_t *status, uint32_t *ticket)
+{ for (uint64_t r0 = next_unit(ticket, COMPACT_BATCH), nxt; r0 < n; r0 = nxt)
+  { nxt = next_unit(ticket, COMPACT_BATCH);              // (one same-address atomic costs ~11 ns chip-wide)
+    for (uint64_t r = r0; r < r0 + COMPACT_BATCH && r < n; r++)
+    { const uint32_t *sg  = seg + 5 * r;
+      const uint8_t  *src = scratch + slot_off[r];
+      uint8_t        *dst = out + rec_off[r];
+      if (rec_off[r + 1] > out_cap)                      // d_out is too small: report, never overrun
+        { if (lane_id() == 0) atomicOr(status, 8u);
+          continue;
+        }
+      if (hdr != NULL)
+        { const uint64_t h0 = hdr_off[r];
+          const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
+          for (uint32_t k = (uint32_t) lane_id(); k < hl; k += 64)
+            dst[k] = hdr[h0 + k];
+          dst += hl;
+        }
+      wave_copy(dst, src, sg[0]);
+      wave_copy(dst + sg[0], scratch + slot_off[r + 1] - tag_room(len[r]), sg[1]);
+      wave_copy(dst + sg[0] + sg[1], src + sg[0], sg[2] + sg[3] + sg[4]);
+    }
+  }
 }
 
 // =============================================================================================
@@ -1269,7 +1394,24 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
   DX_HIP(ctx, hipMemcpyAsync(ctx->d_long, lng, lng_v.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int s = 0; s < 4; s++)
-    ctx->sym_type[s] = c->s[s].type;
+    { ctx->sym_type[s] = c->s[s].type;
+      // most bits one symbol position can cost: its own code (with the 8-bit literal of an escape), and
+      // in a run-coded line the dearest (run token + symbol)/(run + 1)
+      uint32_t maxsym = 0, bound;
+      for (int x = 0; x < 256; x++)
+        if (TOK_LEN(tok[s * 256 + x]) > maxsym) maxsym = TOK_LEN(tok[s * 256 + x]);
+      bound = maxsym;
+      const int rs = s == DX_DEL ? (c->delChar >= 0 ? DX_DRUN : -1) : (s == DX_SUB ? (c->subChar >= 0 ? DX_SRUN : -1) : -1);
+      if (rs >= 0)
+        { bound = 0;
+          for (uint32_t r = 0; r < 256; r++)
+            { const uint32_t t = tok[rs * 256 + r], bits = TOK_LEN(t) + (TOK_ESC(t) ? 16u : 0u) + maxsym;
+              const uint32_t per = (bits + r) / (r + 1);
+              if (per > bound) bound = per;
+            }
+        }
+      ctx->bps[s] = bound;
+    }
   ctx->coding_set = 1;
   ctx->lossy   = lossy != 0;
   ctx->delChar = c->delChar;
@@ -1355,12 +1497,156 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket);
+            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL });
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (st & 2u)
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode: a segment's size differs from what dx_qv_sizes "
                                        "computed (d_seg / coding do not belong to this batch?)");
+  return DX_OK;
+}
+
+// side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
+static int onepass_side(dx_ctx *ctx, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
+                        uint64_t *d_rec_off, const uint64_t *base_in, uint64_t *base_out, const uint32_t *d_len,
+                        const uint8_t *d_slots, const uint64_t *d_slot, const uint32_t *d_seg, const uint8_t *d_hdr,
+                        const uint64_t *d_hdr_off, uint8_t *d_out, uint64_t out_cap, uint32_t *d_tick)
+{ DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, ctx->stream));
+  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) mt, DX_BLOCK, d_size, m, d_tile);
+  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, mt, d_gran);
+  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply_base, (int) mt, DX_BLOCK, d_size, m, (const uint64_t *) d_tile, d_rec_off,
+            (const uint64_t *) d_gran, base_in, base_out);
+  DX_LAUNCH(ctx, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, 16), DX_BLOCK,
+            m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
+            ctx->d_status, d_tick);
+  return DX_OK;
+}
+
+extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                                    uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap,
+                                    uint64_t *total)
+{ int e = check_batch(ctx, b, "dx_qv_encode_onepass");
+  if (e) return e;
+  if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode_onepass: call dx_qv_set_coding first");
+  if ((d_hdr == NULL) != (d_hdr_off == NULL))
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_encode_onepass: d_hdr and d_hdr_off must be given together");
+  if (d_rec_off == NULL || (b->n && (!d_seg || !d_out)))
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_encode_onepass: NULL device pointer");
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  const uint64_t n = b->n;
+  if (n == 0)
+    { uint64_t z = 0;
+      DX_HIP(ctx, hipMemcpyAsync(d_rec_off, &z, 8, hipMemcpyHostToDevice, ctx->stream));
+      DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (total) *total = 0;
+      return DX_OK;
+    }
+  // Groups of entries: the encoder (issue-bound) works through them on the context's stream while the
+  // compaction of the group before (pure HBM traffic) runs beside it on the side stream.  Small groups
+  // lose more in kernel tails than the overlap gains: at least ~120 k entries each, at most 8 groups.
+  int G = (int) (n / 120000);
+  if (G > 8) G = 8;
+  if (G < 1) G = 1;
+  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments)
+    { G = atoi(getenv("DEXGPU_ONEPASS_GROUPS")); if (G < 1) G = 1; if (G > 8) G = 8; }
+  const uint64_t gs = (n + G - 1) / G;
+
+  const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
+  const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255);
+  uint64_t       region = 0, gstart[9] = { 0 };          // slot offset at which each group starts; largest group's extent
+  uint8_t       *scr    = NULL;
+  uint32_t      *d_bound = NULL, *d_size = NULL;
+  uint64_t      *d_slot = NULL, *d_tile = NULL, *d_gran = NULL;
+  // the slot layout needs the scratch to exist and the scratch's size needs the layout: lay out, size,
+  // and lay out again if the buffer had to move.  Two alternating regions hold the groups' slots.
+  for (int pass = 0; pass < 2; pass++)
+    { void *base;
+      if ((e = dx_scratch(ctx, small + (G > 1 ? 2 : 1) * region + 512, &base))) return e;
+      if (pass == 1 && base == (void *) scr) break;
+      scr     = (uint8_t *) base;
+      d_bound = (uint32_t *) scr;
+      d_size  = (uint32_t *) (scr + a4);
+      d_slot  = (uint64_t *) (scr + 2 * a4);
+      d_tile  = (uint64_t *) (scr + 2 * a4 + a8);
+      d_gran  = d_tile + ntiles;
+      DX_LAUNCH(ctx, DX_K_SCAN, k_qv_bounds, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK,
+                (const uint32_t *) b->d_len, n, ctx->bps[0], ctx->bps[1], ctx->bps[2], ctx->bps[3], d_bound);
+      DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) ntiles, DX_BLOCK, (const uint32_t *) d_bound, n, d_tile);
+      DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, ntiles, d_gran);
+      DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, (const uint32_t *) d_bound, n,
+                (const uint64_t *) d_tile, d_slot, (const uint64_t *) d_gran);
+      for (int g = 0; g <= G; g++)
+        { const uint64_t at = (uint64_t) g * gs < n ? (uint64_t) g * gs : n;
+          DX_HIP(ctx, hipMemcpyAsync(&gstart[g], d_slot + at, 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+      DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      region = 0;
+      for (int g = 0; g < G; g++)
+        if (gstart[g + 1] - gstart[g] > region) region = gstart[g + 1] - gstart[g];
+      region = (region + 255) & ~(uint64_t) 255;
+    }
+  uint8_t *d_slots = scr + ((small + 255) & ~(size_t) 255);
+
+  hipStream_t    A = ctx->stream, B = ctx->side;
+  hipEvent_t     enc_done[8], cmp_done[8], done;
+  uint64_t      *d_base = ctx->d_u64 + 24;               // [0], [1]: running record offset, ping-pong
+  uint32_t      *d_tick_enc = (uint32_t *) (ctx->d_u64 + 19), *d_tick_cmp = (uint32_t *) (ctx->d_u64 + 22);
+  qv_args        a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
+  for (int g = 0; g < G; g++)
+    { DX_HIP(ctx, hipEventCreateWithFlags(&enc_done[g], hipEventDisableTiming));
+      DX_HIP(ctx, hipEventCreateWithFlags(&cmp_done[g], hipEventDisableTiming));
+    }
+  DX_HIP(ctx, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
+  DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
+  int rc = DX_OK, ng = 0;                                // ng: groups run so far (selects the ping-pong base)
+  for (int g = 0; g < G && rc == DX_OK; g++)
+    { const uint64_t g0 = (uint64_t) g * gs, g1 = g0 + gs < n ? g0 + gs : n;
+      if (g0 >= g1) break;
+      const uint64_t m = g1 - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
+      // this group's slots live in region g & 1: slot_off[r] is file-wide, so shift the base
+      uint8_t *slots_g = d_slots + (uint64_t) (g & 1) * region - gstart[g];
+      qv_args ag = a;
+      ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
+      const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
+      if (g >= 2)
+        DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[g - 2], 0));    // the region is free once its last tenant has been copied out
+      DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
+      DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, m, 4 * ENC_WAVES), DX_BLOCK,
+                ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) NULL, (const uint32_t *) NULL,
+                (uint8_t *) NULL, ctx->d_status, d_tick_enc, enc_scratch{ slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 });
+      DX_HIP(ctx, hipEventRecord(enc_done[g], A));
+      // side stream: offsets of this group (continuing where the last one ended), then its compaction
+      DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g], 0));
+      ctx->stream = B;                                   // (the launch macro and its timing events follow ctx->stream)
+      rc = onepass_side(ctx, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
+                        b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp);
+      ctx->stream = A;
+      (void) hipEventRecord(cmp_done[g], B);
+      ng += 1;
+    }
+  uint64_t tot = 0;
+  uint32_t st  = 0;
+  if (rc == DX_OK)
+    { (void) hipEventRecord(done, B);
+      (void) hipStreamWaitEvent(A, done, 0);             // the caller's stream sees the finished output
+      if (hipMemcpyAsync(&tot, d_base + (ng & 1), 8, hipMemcpyDeviceToHost, A) != hipSuccess ||
+          hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A) != hipSuccess ||
+          hipStreamSynchronize(A) != hipSuccess)
+        rc = dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
+    }
+  else
+    (void) hipStreamSynchronize(B);
+  for (int g = 0; g < G; g++) { (void) hipEventDestroy(enc_done[g]); (void) hipEventDestroy(cmp_done[g]); }
+  (void) hipEventDestroy(done);
+  if (rc != DX_OK) return rc;
+  if (total) *total = tot;
+  if (st & 2u)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry outgrew its scratch slot");
+  if (tot > out_cap || (st & 8u))
+    return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
+                   (unsigned long long) tot, (unsigned long long) out_cap);
   return DX_OK;
 }

@@ -61,7 +61,7 @@ int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes);
 /* Per-kernel device time, measured with HIP events on the context's stream around every launch
  * while profiling is enabled.  Kernel ids: */
 enum { DX_K_PACK2_ENC = 0, DX_K_PACK2_DEC, DX_K_QV_PRESCAN, DX_K_QV_HIST, DX_K_QV_SIZES, DX_K_SCAN,
-       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_INDEX, DX_K_COUNT };
+       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_INDEX, DX_K_QV_COMPACT, DX_K_COUNT };
 int         dx_profile(dx_ctx *ctx, int enable);                  /* enabling resets the counters */
 int         dx_profile_get(dx_ctx *ctx, int kernel, double *ms_total, uint64_t *launches);  /* syncs */
 const char *dx_kernel_name(int kernel);
@@ -245,6 +245,15 @@ int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_hdr_off,
  * kernel re-derives every segment size and returns DX_E_MISMATCH if one disagrees.              */
 int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                  const uint64_t *d_rec_off, const uint32_t *d_seg, uint8_t *d_out);
+
+/* Compress_Next_QVentry x n WITHOUT a size pass: every entry is first encoded into a scratch slot whose
+ * size is bounded from the code tables, its five segment sizes are recorded (d_seg, n x 5: the same index
+ * dx_qv_sizes produces), a scan turns them into d_rec_off (n + 1), and a copy kernel moves header +
+ * segments to d_out.  *total receives the stream's size; DX_E_SPACE if it exceeds out_cap (nothing
+ * useful is in d_out then).  The bytes are those of dx_qv_sizes + dx_qv_encode.  Scratch (about 4x
+ * the output) is owned by the context.                                                              */
+int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                         uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total);
 
 /* Uncompress_Next_QVentry (QV.c:1428-1481: Decode, Decode_Run, Unpack_Tag) for n records whose
  * segment starts are known: record i starts at d_in + d_rec_off[i] with d_hdr_off[i+1] -

@@ -14,7 +14,7 @@ import csv, glob, json, os, shutil, sys, collections
 def main():
     tag = sys.argv[1]
     src = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "gpurun_out"
-    opt = {"entries": 1000000, "mean": 10000, "dist": "fixed"}
+    opt = {"entries": 1000000, "mean": 10000, "dist": "fixed", "passes": 3}   # passes: warmup + steps of the PMC runs
     for i, a in enumerate(sys.argv):
         if a.startswith("--") and a[2:] in opt:
             opt[a[2:]] = type(opt[a[2:]])(sys.argv[i + 1])
@@ -38,6 +38,7 @@ def main():
         out["kernels"][name] = {"fetch_bytes": fe, "write_bytes": wr,
                                 "hbm_bytes_per_launch": (fe or 0) + (wr or 0),
                                 "launches_sampled": len(c.get("FETCH_SIZE", []))}
+    out["launches_per_step"] = {k: max(1, round(v["launches_sampled"] / opt["passes"])) for k, v in out["kernels"].items()}
     json.dump(out, open(os.path.join(here, f"{tag}_traffic.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(here, "traffic.json"), "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))

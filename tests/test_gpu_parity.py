@@ -719,3 +719,57 @@ def test_dexqv_dense_token_stretches(ctx):
     want = O.dexqv(txt)
     assert ctx.dexqv(txt) == want
     assert ctx.undexqv(want, upper=False) == O.undexqv(want, upper=False)
+
+
+def _two_pass(ctx, c, coding, lossy=False):
+    n = len(c.len)
+    b, keep = _upload_quiva(ctx, c)
+    ctx.qv_set_coding(coding, lossy)
+    blob, hoff, _ = api.frame_headers(c.hdr)
+    d_hdr, d_hoff = ctx.to_device(blob), ctx.to_device(hoff)
+    d_rec, d_seg = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n)
+    total = ctx.qv_sizes(b, d_hoff, d_seg, d_rec)
+    d_out = ctx.alloc(max(total, 4))
+    ctx.qv_encode(b, d_hdr, d_hoff, d_rec, d_seg, d_out)
+    return (total, d_out.download(np.uint8, total).tobytes(), d_rec.download(np.uint64).copy(),
+            d_seg.download(np.uint32, 5 * n).copy(), (b, keep, d_hdr, d_hoff))
+
+
+@pytest.mark.parametrize("groups", [None, "3", "8"])
+@pytest.mark.parametrize("case", ["pacbio", "small_lengths", "dense", "sparse", "lossy", "long_codes", "no_runs"])
+def test_encode_onepass_equals_two_pass(ctx, case, groups, monkeypatch):
+    """dx_qv_encode_onepass (scratch slots bounded from the tables + compaction, no size pass) gives the
+    bytes, record offsets and segment index of dx_qv_sizes + dx_qv_encode."""
+    if groups:                                                    # several groups: two streams, alternating scratch regions
+        monkeypatch.setenv("DEXGPU_ONEPASS_GROUPS", groups)
+    lossy = case == "lossy"
+    if case == "small_lengths":
+        lens = np.array(list(range(0, 70)) + [1023, 1024, 1025, 2047, 4097, 0, 1, 9000], np.uint32)
+        c = synth.make_quiva(len(lens), seed=5, lens=lens)
+    elif case in ("dense", "sparse"):
+        p_ = 0.03 if case == "dense" else 0.995
+        c = synth.make_quiva(40, seed=6, mean=5000, prof=synth.pacbio_profile(del_run_p=p_, sub_run_p=p_))
+    else:
+        c = synth.make_quiva(90, seed=7, mean=6000)
+    st = O.qv_scan(c.text)
+    if case == "long_codes":
+        sub = st.subChar if st.subChar >= 0 else int(np.argmax(O.hist_array(st)[3]))
+        coding = _fixed_coding(16, 16, True, st.delChar, sub)
+    elif case == "no_runs":
+        coding = _fixed_coding(7, 9, False, -1, -1)
+    else:
+        b0, keep0 = _upload_quiva(ctx, c)
+        p = ctx.qv_prescan(b0)
+        hist, tot = ctx.qv_hist(b0, p)
+        coding = api.qv_build(hist, tot, p, lossy)
+    total, out, rec, seg, (b, keep, d_hdr, d_hoff) = _two_pass(ctx, c, coding, lossy)
+    n = len(c.len)
+    d_rec2, d_seg2, d_out2 = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n), ctx.alloc(total + 64)
+    total2 = ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg2, d_rec2, d_out2, total + 64)
+    assert total2 == total
+    assert (d_rec2.download(np.uint64) == rec).all()
+    assert (d_seg2.download(np.uint32, 5 * n) == seg).all()
+    assert d_out2.download(np.uint8, total).tobytes() == out
+    with pytest.raises(L.DexGPUError) as e:                      # too small an output buffer is reported, not overrun
+        ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg2, d_rec2, d_out2, max(total - 1, 0))
+    assert e.value.code == -8
