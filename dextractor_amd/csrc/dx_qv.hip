@@ -279,10 +279,16 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
   nrun += sv - total;                                            // wave-uniform
   for (uint32_t i = lane; i < total; i += 64)
     { RUN_TOKEN(R, i, C, pos, x, run)
-      if (run < HRUN_FAST) atomicAdd(&hr[run][col], 1u);
-      else                 atomicAdd(&slow_r[run > 255u ? 255u : run], 1u);       // QV.c:717-720
-      if (x < HSYM_FAST)   atomicAdd(&hs[x][col], 1u);
-      else                 atomicAdd(&slow_s[x], 1u);
+      if (!__any(run >= HRUN_FAST || x >= HSYM_FAST))              // the usual case, decided once for the wave
+        { atomicAdd(&hr[run][col], 1u);
+          atomicAdd(&hs[x][col], 1u);
+        }
+      else
+        { if (run < HRUN_FAST) atomicAdd(&hr[run][col], 1u);
+          else                 atomicAdd(&slow_r[run > 255u ? 255u : run], 1u);   // QV.c:717-720
+          if (x < HSYM_FAST)   atomicAdd(&hs[x][col], 1u);
+          else                 atomicAdd(&slow_s[x], 1u);
+        }
     }
   C = run_after(R, total, sv, C);
   wave_sync();
