@@ -63,6 +63,8 @@ extern "C" int dx_open(int device, dx_ctx **out)
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   OPEN_HIP(hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking));
   OPEN_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  for (int k = 0; k < 17; k++)
+    OPEN_HIP(hipEventCreateWithFlags(&ctx->ev[k], hipEventDisableTiming));
   ctx->stream = ctx->own;
   OPEN_HIP(hipMalloc((void **) &ctx->d_tok, DX_TOK_WORDS * sizeof(uint32_t)));
   OPEN_HIP(hipMalloc((void **) &ctx->d_dec, 6 * DX_DEC_SIZE * sizeof(uint16_t)));
@@ -92,6 +94,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_scratch);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
+  for (int k = 0; k < 17; k++) (void) hipEventDestroy(ctx->ev[k]);
   delete ctx;
 }
 

@@ -1596,15 +1596,10 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
   uint8_t *d_slots = scr + ((small + 255) & ~(size_t) 255);
 
   hipStream_t    A = ctx->stream, B = ctx->side;
-  hipEvent_t     enc_done[8], cmp_done[8], done;
+  hipEvent_t    *enc_done = ctx->ev, *cmp_done = ctx->ev + 8, done = ctx->ev[16];
   uint64_t      *d_base = ctx->d_u64 + 24;               // [0], [1]: running record offset, ping-pong
   uint32_t      *d_tick_enc = (uint32_t *) (ctx->d_u64 + 19), *d_tick_cmp = (uint32_t *) (ctx->d_u64 + 22);
   qv_args        a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
-  for (int g = 0; g < G; g++)
-    { DX_HIP(ctx, hipEventCreateWithFlags(&enc_done[g], hipEventDisableTiming));
-      DX_HIP(ctx, hipEventCreateWithFlags(&cmp_done[g], hipEventDisableTiming));
-    }
-  DX_HIP(ctx, hipEventCreateWithFlags(&done, hipEventDisableTiming));
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
   DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
   int rc = DX_OK, ng = 0;                                // ng: groups run so far (selects the ping-pong base)
@@ -1645,8 +1640,6 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
     }
   else
     (void) hipStreamSynchronize(B);
-  for (int g = 0; g < G; g++) { (void) hipEventDestroy(enc_done[g]); (void) hipEventDestroy(cmp_done[g]); }
-  (void) hipEventDestroy(done);
   if (rc != DX_OK) return rc;
   if (total) *total = tot;
   if (st & 2u)
