@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc.sh "<counters...>" tag
+# usage (from the repo root, on the GPU box): bash profiles/tools/pmc.sh "<counter group 1>" "<counter group 2>" ...
 # collects SQ counters for a 200k-entry bench run
 R=$PWD
 cd /tmp && export TMPDIR=/tmp

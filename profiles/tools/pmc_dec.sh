@@ -1,4 +1,5 @@
 #!/bin/bash
+# usage (repo root, GPU box): bash profiles/tools/pmc_dec.sh "<counter group>" ...   (counters of the decode kernels)
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 i=0

@@ -1,4 +1,5 @@
 #!/bin/bash
+# usage (repo root, GPU box): bash profiles/tools/profile.sh ; then, here: python profiles/summarize.py <tag>
 # full-size profile set for profiles/summarize.py: kernel stats + FETCH_SIZE + WRITE_SIZE passes
 R=$PWD
 mkdir -p $R/gpurun_out
