@@ -306,10 +306,26 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
 // the next 2-bit code of the tag segment as a letter; one wavefront per entry.
 __global__ __launch_bounds__(DX_BLOCK)
 void k_qv_decode_tags(dec_args a)
-{ const int      lane  = lane_id();
+{ // four tag bytes per look-up: index = (which of the 4 positions hold a non-run symbol) << 8 | the next
+  // four 2-bit codes; the entry has letters at those positions (codes consumed in order), 'n' elsewhere
+  __shared__ uint32_t s_quad[16 * 256];                    // 16 KB
+  for (uint32_t k = threadIdx.x; k < 16u * 256u; k += DX_BLOCK)
+    { const uint32_t m = k >> 8, fold_ = a.upper ? 32u : 0u;
+      uint32_t c = k & 0xffu, v = 0;
+      for (int j = 0; j < 4; j++)
+        { uint32_t ch = 'n';
+          if ((m >> j) & 1u)
+            { ch = (0x74676361u >> (8 * (c >> 6))) & 0xffu;       // "acgt", Lower_Read DB.c:367
+              c  = (c << 2) & 0xffu;
+            }
+          v |= (ch - fold_) << (8 * j);
+        }
+      s_quad[k] = v;
+    }
+  __syncthreads();
+  const int      lane  = lane_id();
   const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
   const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
-  const uint32_t fold  = a.upper ? 32u : 0u;               // undexqv.c:198-204: every tag byte - 32
 
   for (uint64_t r = wave0; r < a.n; r += nwave)
     { const uint32_t  L   = a.len[r];
@@ -335,17 +351,15 @@ void k_qv_decode_tags(dec_args a)
             { if (b0 + 8u <= tb) bits = *(const u64_u *) (src + b0);
               else for (uint32_t k = b0; k < tb; k++) bits |= (uint64_t) src[k] << (8 * (k - b0));
             }
-          uint32_t w[4] = { 0u, 0u, 0u, 0u };
+          // the lane's codes, first one in the top bits (symbol idx sits at bit pair idx & 3 of byte b0)
+          const uint64_t be = ((uint64_t) __builtin_bswap32((uint32_t) bits) << 32) | __builtin_bswap32((uint32_t) (bits >> 32));
+          uint32_t cw = (uint32_t) ((be << (2u * (idx & 3u))) >> 32);
+          uint32_t w[4];
           #pragma unroll
-          for (int b = 0; b < 16; b++)
-            { uint32_t ch = 'n';
-              if ((nr >> b) & 1u)
-                { const uint32_t rel  = idx - 4u * b0;
-                  const uint32_t code = (uint32_t) (bits >> (8u * (rel >> 2) + 6u - 2u * (rel & 3u))) & 3u;
-                  ch = (0x74676361u >> (8 * code)) & 0xffu;       // "acgt", Lower_Read DB.c:367
-                  idx += 1;
-                }
-              w[b >> 2] |= (ch - fold) << (8 * (b & 3));
+          for (int k = 0; k < 4; k++)
+            { const uint32_t m4 = (nr >> (4 * k)) & 15u;
+              w[k] = s_quad[(m4 << 8) | (cw >> 24)];
+              cw <<= 2u * (uint32_t) __popc(m4);
             }
           if (valid == 16)
             { u32x4 v = { w[0], w[1], w[2], w[3] };
