@@ -12,14 +12,15 @@
 // text) read + 0.25 written; decode 0.25 read + 1 (+1/80) written.
 //
 // Layout: one 64-lane wavefront per read; the waves draw reads from a ticket counter, 16 at a
-// time.  A wave walks the read's text 1 KiB per step (16 bytes per lane, one unaligned
+// time.  A wave walks the read's text 2 KiB per step (32 bytes per lane, two unaligned
 // global_load_dwordx4), maps the bytes through a 256-byte LDS table, deletes the 2-bit slots of
 // the '\n' bytes, ORs each lane's <=32 code bits into a small LDS word window at the bit position
 // a wave prefix sum of the kept counts gives, and drains the window in 16-byte units.
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 
-#define P2_WIN_WORDS  320                // per-wave LDS window: flush threshold + one step (64 words) + slack
+#define P2_STEP       2048u              // text bytes a wave consumes per step: two 16-byte chunks per lane
+#define P2_WIN_WORDS  448                // per-wave LDS window: flush threshold + one step (128 words) + slack
 #define P2_FLUSH_BITS 8192u
 #define P2_BATCH      16u                // reads a wave draws at a time (one same-address atomic costs ~11 ns chip-wide)
 
@@ -78,40 +79,59 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
         }
       o.seg = dst; o.wordbase = 0; o.winbits = 0;
 
-      uint32_t pos = 16u * lane;
-      u32x4 c = p2_fetch(src, pos, T);
-      for (uint32_t base = 0; base < T; base += DX_STEP)
-        { const u32x4 d = p2_fetch(src, pos + DX_STEP, T);       // next step already in flight
-          const uint32_t valid = pos >= T ? 0u : (T - pos >= 16u ? 16u : T - pos);
-          // the 16 bytes' codes, first one in the top bits, as if there were no line ends
-          uint32_t acc = 0;
+      // 32 consecutive bytes per lane and step (two chunks): the prefix sum, the window bookkeeping
+      // and the drain are paid once per 2 KiB
+      uint32_t pos = 32u * lane;
+      u32x4 cA = p2_fetch(src, pos, T), cB = p2_fetch(src, pos + 16u, T);
+      for (uint32_t base = 0; base < T; base += P2_STEP)
+        { const u32x4 dA = p2_fetch(src, pos + P2_STEP, T), dB = p2_fetch(src, pos + P2_STEP + 16u, T);   // next step in flight
+          const uint32_t left   = pos >= T ? 0u : T - pos;
+          const uint32_t validA = left >= 16u ? 16u : left, validB = left >= 32u ? 16u : (left > 16u ? left - 16u : 0u);
+          // the bytes' codes, first one in the top bits, as if there were no line ends
+          uint32_t accA = 0, accB = 0;
           #pragma unroll
           for (int b = 0; b < 16; b++)
-            acc = (acc << 2) | (uint32_t) s_code[BYTE_AT(c, b)];
-          // drop the slots of the line ends, last one first so that the earlier slots stay put
-          uint32_t nl = chunk_eq_mask(c, '\n');                  // missing bytes read as 0: never set
-          const uint32_t cnt = valid - __popc(nl);
-          while (nl)
-            { const uint32_t p = 31u - (uint32_t) __clz(nl);      // byte position; its slot: bits 31-2p, 30-2p
-              const uint32_t K = 30u - 2u * p;
-              const uint32_t below = (1u << K) - 1u, upto = (4u << K) - 1u;
-              acc = (acc & ~upto) | ((acc & below) << 2);
-              nl ^= 1u << p;
+            { accA = (accA << 2) | (uint32_t) s_code[BYTE_AT(cA, b)];
+              accB = (accB << 2) | (uint32_t) s_code[BYTE_AT(cB, b)];
             }
-          acc = cnt ? acc & (~0u << (32u - 2u * cnt)) : 0u;      // slots past the kept symbols (missing bytes)
+          // drop the slots of the line ends, last one first so that the earlier slots stay put
+          uint32_t nlA = chunk_eq_mask(cA, '\n'), nlB = chunk_eq_mask(cB, '\n');   // missing bytes read as 0: never set
+          const uint32_t cntA = validA - __popc(nlA), cntB = validB - __popc(nlB), cnt = cntA + cntB;
+          while (nlA | nlB)
+            { if (nlA)
+                { const uint32_t p = 31u - (uint32_t) __clz(nlA);  // byte position; its slot: bits 31-2p, 30-2p
+                  const uint32_t K = 30u - 2u * p;
+                  const uint32_t below = (1u << K) - 1u, upto = (4u << K) - 1u;
+                  accA = (accA & ~upto) | ((accA & below) << 2);
+                  nlA ^= 1u << p;
+                }
+              if (nlB)
+                { const uint32_t p = 31u - (uint32_t) __clz(nlB);
+                  const uint32_t K = 30u - 2u * p;
+                  const uint32_t below = (1u << K) - 1u, upto = (4u << K) - 1u;
+                  accB = (accB & ~upto) | ((accB & below) << 2);
+                  nlB ^= 1u << p;
+                }
+            }
+          accA = cntA ? accA & (~0u << (32u - 2u * cntA)) : 0u;    // slots past the kept symbols (missing bytes)
+          accB = cntB ? accB & (~0u << (32u - 2u * cntB)) : 0u;
+          // the lane's string, left-aligned in 64 bits: A's codes, then B's
+          const uint64_t V  = ((uint64_t) accA << 32) | ((uint64_t) accB << (32u - 2u * cntA));
+          const uint32_t hi = (uint32_t) (V >> 32), lo = (uint32_t) V;
           const uint32_t incl = wave_incl_scan(cnt);
           if (cnt)
             { const uint32_t bit = o.winbits + 2u * (incl - cnt);
-              const uint32_t w = bit >> 5, s = bit & 31u;
-              atomicOr(&o.win[w], acc >> s);
-              if (s && 2u * cnt + s > 32u)
-                atomicOr(&o.win[w + 1], acc << (32u - s));
+              const uint32_t w = bit >> 5, sh = bit & 31u;
+              const uint32_t x0 = hi >> sh, x1 = __builtin_amdgcn_alignbit(hi, lo, sh), x2 = __builtin_amdgcn_alignbit(lo, 0u, sh);
+              atomicOr(&o.win[w], x0);
+              if (x1) atomicOr(&o.win[w + 1], x1);
+              if (x2) atomicOr(&o.win[w + 2], x2);
             }
           o.winbits += 2u * wave_total(incl);
           if (o.winbits >= P2_FLUSH_BITS)
             flush_quads(o, true);
-          c = d;
-          pos += DX_STEP;
+          cA = dA; cB = dB;
+          pos += P2_STEP;
         }
 
       flush_words(o, true);
