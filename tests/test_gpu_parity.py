@@ -736,7 +736,7 @@ def _two_pass(ctx, c, coding, lossy=False):
 
 
 @pytest.mark.parametrize("groups", [None, "3", "8"])
-@pytest.mark.parametrize("case", ["pacbio", "small_lengths", "dense", "sparse", "lossy", "long_codes", "no_runs"])
+@pytest.mark.parametrize("case", ["pacbio", "small_lengths", "dense", "sparse", "lossy", "long_codes", "no_runs", "huge_entry"])
 def test_encode_onepass_equals_two_pass(ctx, case, groups, monkeypatch):
     """dx_qv_encode_onepass (scratch slots bounded from the tables + compaction, no size pass) gives the
     bytes, record offsets and segment index of dx_qv_sizes + dx_qv_encode."""
@@ -746,6 +746,9 @@ def test_encode_onepass_equals_two_pass(ctx, case, groups, monkeypatch):
     if case == "small_lengths":
         lens = np.array(list(range(0, 70)) + [1023, 1024, 1025, 2047, 4097, 0, 1, 9000], np.uint32)
         c = synth.make_quiva(len(lens), seed=5, lens=lens)
+    elif case == "huge_entry":
+        lens = np.array([300, 140000, 5, 70001, 0, 2000], np.uint32)
+        c = synth.make_quiva(len(lens), seed=8, lens=lens)
     elif case in ("dense", "sparse"):
         p_ = 0.03 if case == "dense" else 0.995
         c = synth.make_quiva(40, seed=6, mean=5000, prof=synth.pacbio_profile(del_run_p=p_, sub_run_p=p_))
