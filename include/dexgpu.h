@@ -250,8 +250,10 @@ int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const 
  * size is bounded from the code tables, its five segment sizes are recorded (d_seg, n x 5: the same index
  * dx_qv_sizes produces), a scan turns them into d_rec_off (n + 1), and a copy kernel moves header +
  * segments to d_out.  *total receives the stream's size; DX_E_SPACE if it exceeds out_cap (nothing
- * useful is in d_out then).  The bytes are those of dx_qv_sizes + dx_qv_encode.  Scratch (about 4x
- * the output) is owned by the context.                                                              */
+ * useful is in d_out then).  The bytes are those of dx_qv_sizes + dx_qv_encode (QV.c:1381-1426).  The
+ * entries are worked through in groups; the copy of one group runs on a second stream of the context
+ * beside the encode of the next.  Scratch (two group-sized regions, about 1 x the output for large
+ * batches) is owned by the context and kept for the next call.                                      */
 int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total);
 
