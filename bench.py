@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
-"""dexqv-encode throughput on MI355X (BASELINE.json metric: input GB/s, round-trip bit-exact).
+"""dexqv-encode throughput on MI355X (BASELINE.json metric: input GB/s at 1/2/4/8 GPUs, round-trip bit-exact).
 
-One "step" = one complete dexqv encode of the resident synthetic .quiva batch:
-    k_qv_prescan -> k_qv_hist -> (12 KB to host, Huffman tables, ~6 KB back) -> k_qv_sizes ->
-    k_scan -> k_qv_encode
-with the input image already in HBM when the timed region starts and the .dexqv record stream
-left in HBM.  Workload at N=1: BASELINE.json configs[3] -- 1 M entries x 10 kb (5e10 stream
-bytes); weak scaling for N>1 (every rank holds its own 1 M-entry slice of one corpus; the only
-exchange is the 12 KB histogram sum + 32 B of scan state on the host side, via gloo -- no RCCL
-on the data path).
+One "step" = one complete dexqv encode of the resident synthetic .quiva batch by the PRODUCT encoder
+(the one dx_file_dexqv and the CLI use):
+    k_qv_prescan -> k_qv_hist -> (12 KB to host, Huffman tables, ~6 KB back) -> dx_qv_encode_onepass
+with the input image already in HBM when the timed region starts and the .dexqv record stream left in
+HBM.  Workload at N=1: BASELINE.json configs[3] -- 1 M entries x 10 kb (5e10 stream bytes).  N>1:
+configs[4] -- every rank holds a 2.5 M-entry slice (125 GB of stream bytes; 1 TB over 8 GPUs) of ONE
+corpus, contiguous entry ranges; the only exchange is host-side (gloo): the scan state and the 12 KB
+histogram sum, after which every rank builds identical tables -- no RCCL on the data path.
 
-Prints ONE JSON line (rank 0).  `value` = 5 * bases * steps / wall over all ranks, in GB/s.
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+`--gpus N` without a launcher starts the N ranks itself (child processes, before anything touches the
+GPU); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one rank.
+Prints ONE JSON line (rank 0).  `value` = 5 * bases * steps / wall over all ranks, in GB/s.  At N=1 the
+line also carries, under "other_workloads", the lognormal-length dexqv run and the dexta / dexar
+(BASELINE configs[1]/[2]) runs with their own roofline and CPU baseline (skip: --only-main).
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -26,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ENTRIES_1GPU = 1_000_000         # BASELINE configs[3]
+ENTRIES_SHARD = 2_500_000        # BASELINE configs[4]: 1 TB over 8 GPUs = 2.5 M entries x 10 kb per GPU
 
 
 def parse():
@@ -33,7 +42,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--entries", type=int, default=1_000_000, help="entries per GPU")
+    ap.add_argument("--entries", type=int, default=None,
+                    help=f"entries per GPU (default {ENTRIES_1GPU} at N=1, {ENTRIES_SHARD} per rank at N>1)")
     ap.add_argument("--mean", type=int, default=10_000)
     ap.add_argument("--dist", default="fixed", choices=["fixed", "lognormal"])
     ap.add_argument("--lossy", action="store_true")
@@ -49,6 +59,8 @@ def parse():
                     help="dexqv: dx_qv_sizes + dx_qv_encode instead of dx_qv_encode_onepass (scratch slots + compaction)")
     ap.add_argument("--no-verify", action="store_true",
                     help="dexqv: skip the (untimed) full-size on-device decode + compare after the timed steps")
+    ap.add_argument("--only-main", action="store_true",
+                    help="N=1: only the headline workload, without the lognormal / dexta / dexar extras")
     return ap.parse_args()
 
 
@@ -58,25 +70,105 @@ def trace(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+# ------------------------------------------------------------------------------------------------
+#  --gpus N without a launcher: start the N ranks as child processes BEFORE anything touches the GPU
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(n):
+    """One child process per GPU (never exec from a process that has initialised HIP: this parent has
+    imported neither torch nor the library).  Rank 0 inherits stdout and prints the JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, left = 0, set(range(n))
+    while left:                                   # a failing rank takes the others down with it (exact PIDs)
+        for r in sorted(left):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            left.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                print(f"bench.py: rank {r} exited with {c}; stopping the other ranks", file=sys.stderr)
+                for q in left:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc if rc >= 0 else 1
+
+
+class Ptr:                                        # torch-owned device memory seen through the C-ABI
+    def __init__(self, t):
+        self.t, self.ptr = t, t.data_ptr()
+
+
 def main():
     args = parse()
-    if args.workload != "dexqv":
-        return pack2_main(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (starts N "
+              f"ranks itself) or `python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 bench.py "
+              f"--gpus N`", file=sys.stderr)
+        sys.exit(2)
+    if args.workload != "dexqv":
+        if world > 1:
+            print("bench.py: the dexta/dexar lines are single-GPU (reads shard with no exchange at all)", file=sys.stderr)
+            sys.exit(2)
+        print(json.dumps(pack2_bench(args, args.workload == "dexar")))
+        return
     if os.environ.get("DEXGPU_BENCH_ONE_DEVICE"):        # testing the N>1 path on a 1-GPU box
         local = 0
+    if args.entries is None:
+        args.entries = ENTRIES_1GPU if world == 1 else ENTRIES_SHARD
 
+    line = dexqv_bench(args, rank, world, local, cpu=(world == 1 and not args.no_cpu_baseline))
+    if rank != 0:
+        return
+    if world == 1 and not args.only_main:
+        extra = {}
+        a2 = argparse.Namespace(**vars(args))
+        a2.dist = "lognormal" if args.dist == "fixed" else "fixed"
+        trace("extra: dexqv, other length distribution")
+        try:
+            l2 = dexqv_bench(a2, 0, 1, local, cpu=False, front=False)
+            extra["dexqv_" + a2.dist] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
+                                                              "roundtrip_bit_exact", "pipeline", "decode")}
+        except Exception as e:                               # an extra must never cost the headline line
+            extra["dexqv_" + a2.dist] = {"error": repr(e)}
+        for w in ("dexta", "dexar"):
+            trace(f"extra: {w}")
+            try:
+                extra[w] = pack2_bench(args, w == "dexar")
+            except Exception as e:
+                extra[w] = {"error": repr(e)}
+        line["other_workloads"] = extra
+    print(json.dumps(line))
+
+
+# ------------------------------------------------------------------------------------------------
+#  dexqv (BASELINE configs[3] at N=1, configs[4] at N>1)
+# ------------------------------------------------------------------------------------------------
+def dexqv_bench(args, rank, world, local, cpu=True, front=True):
     import torch
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local)
 
     from dextractor_amd import _lib as L
-    from dextractor_amd import api, synth
+    from dextractor_amd import api, shard, synth
 
     ctx = api.Context(local)
     n = args.entries
@@ -98,9 +190,6 @@ def main():
     t_hdr4 = torch.from_numpy(hdr4.reshape(-1)).cuda()
     t_lut = torch.from_numpy(prof.table().reshape(-1)).cuda()
 
-    class Ptr:                                   # torch-owned device memory seen through the C-ABI
-        def __init__(self, t): self.t, self.ptr = t, t.data_ptr()
-
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     p_text, p_off, p_len = Ptr(d_text), Ptr(t_off), Ptr(t_len)
     ctx.synth_quiva(args.seed, entry0, n, p_off, p_len, Ptr(t_hdr4), Ptr(t_lut), prof.del_run, movie, p_text)
@@ -114,29 +203,36 @@ def main():
     p_hoff = Ptr(torch.from_numpy(hoff.view(np.int64)).cuda())
     p_rec = Ptr(torch.empty(n + 1, dtype=torch.int64, device="cuda"))
     p_seg = Ptr(torch.empty(5 * n, dtype=torch.int32, device="cuda"))
-    out_cap = int(2.2 * bases) + int(hoff[-1]) + 4096
-    p_out = Ptr(torch.empty(out_cap, dtype=torch.uint8, device="cuda"))
+    state = {"out_cap": 0, "p_out": None}
 
-    state = {}
+    def sub_hist(i0, i1):                        # substitution-QV bytes of local entries [i0, i1) (only when the
+        h = np.zeros(256, np.int64)              # 100000-symbol threshold lies beyond rank 0: tiny slices)
+        for i in range(i0, i1):
+            o, ln = int(off[i]), int(lens[i])
+            h += torch.bincount(d_text[o + 4 * (ln + 1): o + 4 * (ln + 1) + ln].long(), minlength=256).cpu().numpy()
+        return h
 
     def step():
         p = ctx.qv_prescan(batch, entry0)
-        if world > 1:                        # one file sharded over the ranks: agree on the scan state
-            mine = torch.tensor([p.delChar, p.del_first, p.subChar, p.sub_first], dtype=torch.int64)
-            every = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(every, mine)
-            found = [e for e in every if e[0] >= 0]
-            d = found[0] if found else every[0]
-            p = L.QVParams(int(d[0]), int(every[0][2]), int(d[1]), int(every[0][3]))
-        hist, tot = ctx.qv_hist(batch, p, entry0)
+        if world > 1:                        # one file sharded over the ranks: agree on the scan state (host, gloo)
+            dC, dF, sC, sF = shard.agree_params(dist, (p.delChar, p.del_first), lens, entry0, sub_hist)
+            p = L.QVParams(dC, sC, dF, sF)
+        mine, tot = ctx.qv_hist(batch, p, entry0)
+        hist = mine
         if world > 1:                        # host-side sum of the 12 KB histograms (no RCCL)
-            h = torch.from_numpy(np.concatenate([hist.reshape(-1), [tot]]).astype(np.int64))
+            h = torch.from_numpy(np.concatenate([mine.reshape(-1), [tot]]).astype(np.int64))
             dist.all_reduce(h)
             hist, tot = h[:-1].numpy().astype(np.uint64).reshape(6, 256), int(h[-1])
         th = time.perf_counter()
         coding = api.qv_build(hist, tot, p, args.lossy)
         state["host_build_us"] = round((time.perf_counter() - th) * 1e6, 1)      # Huffman tables on the host
         ctx.qv_set_coding(coding, args.lossy)
+        need = int(hoff[-1]) + api.qv_out_bound(mine, n, coding, args.lossy)     # from this rank's own counts
+        if need > state["out_cap"]:          # first step only (the corpus does not change between steps)
+            state["p_out"] = None
+            state["p_out"] = Ptr(torch.empty(need + 4096, dtype=torch.uint8, device="cuda"))
+            state["out_cap"] = need + 4096
+        p_out, out_cap = state["p_out"], state["out_cap"]
         if not args.twopass:
             total = ctx.qv_encode_onepass(batch, p_hdr, p_hoff, p_seg, p_rec, p_out, out_cap)
         else:
@@ -157,6 +253,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if state["p_out"] is None:               # --warmup 0: the output buffer is sized (untimed) before the clock starts
+        step()
     fence()
     ctx.profile(True)
     t0 = time.perf_counter()
@@ -166,68 +264,77 @@ def main():
     dt = time.perf_counter() - t0
     times = ctx.kernel_times()
     ctx.profile(False)
+    p_out = state["p_out"]
 
     roundtrip = None
     if not args.no_verify:
-        # size-independent property at full size: decode(encode(x)) == x, entirely on the device
-        # (the decoder is fed by the encoder's own index); headers are copied, data lines rebuilt
-        trace("verify: allocate")
-        d_back = torch.zeros_like(d_text)
-        torch.cuda.synchronize()
-        ctx.profile(True)
-        trace("verify: decode")
-        ctx.qv_decode(p_out, p_rec, p_hoff, p_seg, p_len, n, True, Ptr(d_back), p_off)
-        ctx.sync(); torch.cuda.synchronize()
-        trace("verify: compare")
-        dec_ms = ctx.kernel_times().get("k_qv_decode", (0.0, 0))[0]
-        ctx.profile(False)
+        # size-independent property at full size: decode(encode(x)) == x, entirely on the device (the decoder
+        # is fed by the encoder's own index), in chunks of entries so that any corpus size fits.  The decoder
+        # writes only the five data lines of an entry; the chunk buffer is zero elsewhere and header bytes are
+        # never zero, so the number of differing bytes must equal the number of header bytes exactly.
+        trace("verify: decode + compare")
+        chunk = max(1, min(n, int(6e9 // (5 * (args.mean + 1) + hlen))))
+        ends = np.concatenate([off[1:] - hlen, [text_bytes]]).astype(np.uint64)   # end of each entry's record
+        roundtrip, dec_ms = True, 0.0
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            lo, hi = int(off[a]) - hlen, int(ends[b - 1])
+            d_back = torch.zeros(hi - lo + 64, dtype=torch.uint8, device="cuda")
+            o_rel = Ptr(torch.from_numpy((off[a:b] - np.uint64(lo)).view(np.int64)).cuda())
+            torch.cuda.synchronize()
+            ctx.profile(True)
+            ctx.qv_decode(p_out, Ptr(p_rec.t[a:]), Ptr(p_hoff.t[a:]), Ptr(p_seg.t[5 * a:]), Ptr(t_len[a:]), b - a, True,
+                          Ptr(d_back), o_rel)
+            ctx.sync(); torch.cuda.synchronize()
+            kt = ctx.kernel_times()
+            dec_ms += kt.get("k_qv_decode", (0.0, 0))[0]
+            ctx.profile(False)
+            diff = int((d_back[: hi - lo] != d_text[lo:hi]).sum())
+            roundtrip = roundtrip and diff == (b - a) * hlen
+            del d_back, o_rel
         state["decode"] = {"kernel": "k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),
                            "output_GBps": round(5.0 * bases / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None}
-        # compare only the 5 data lines of every entry (fixed-length corpora: one strided view)
-        if args.dist == "fixed":
-            rec = hlen + 5 * (args.mean + 1)
-            a = d_text[: n * rec].view(n, rec)[:, hlen:]
-            b = d_back[: n * rec].view(n, rec)[:, hlen:]
-            roundtrip = bool(torch.equal(a, b))
-        else:
-            idx = torch.from_numpy(np.concatenate([[0], np.cumsum(rec_bytes)]).astype(np.int64)).cuda()
-            ok = True
-            for i in range(0, n, max(1, n // 64)):           # sampled entries for ragged corpora
-                lo, hi = int(off[i]), int(off[i]) + 5 * (int(lens[i]) + 1)
-                ok = ok and bool(torch.equal(d_text[lo:hi], d_back[lo:hi]))
-            roundtrip = ok
-        del d_back
 
     # GPU text front end on the same resident image (untimed extra): newline scan -> entry index
-    front = None
-    if not args.no_verify:
+    fr = None
+    if front and not args.no_verify:
         torch.cuda.synchronize()
         ctx.profile(True)
         trace("front end: index")
         t1 = time.perf_counter()
         o2, l2, h2, pl2 = ctx.index_quiva_device(p_text, text_bytes)
-        trace("front end: done")
         t2 = time.perf_counter()
         kt = ctx.kernel_times().get("k_index", (0.0, 0))
         ctx.profile(False)
-        front = {"entries": int(len(l2)), "wall_ms": round((t2 - t1) * 1e3, 2), "kernel_ms": round(kt[0], 3),
-                 "text_GBps_kernels": round(text_bytes / (kt[0] * 1e-3) / 1e9, 1) if kt[0] else None,
-                 "index_identical": bool((o2 == off).all() and (l2 == lens).all() and (h2 == hdr4).all())}
+        fr = {"entries": int(len(l2)), "wall_ms": round((t2 - t1) * 1e3, 2), "kernel_ms": round(kt[0], 3),
+              "text_GBps_kernels": round(text_bytes / (kt[0] * 1e-3) / 1e9, 1) if kt[0] else None,
+              "index_identical": bool((o2 == off).all() and (l2 == lens).all() and (h2 == hdr4).all())}
 
+    tables_same = None
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
-        bb = torch.tensor([bases, state["total"]], dtype=torch.int64)
+        bb = torch.tensor([bases, state["total"], 1 if roundtrip in (True, None) else 0], dtype=torch.int64)
         dist.all_reduce(bb)
         all_bases, all_out = int(bb[0]), int(bb[1])
+        if roundtrip is not None:
+            roundtrip = int(bb[2]) == world
+        # every rank must have built the same tables: compare the coding images
+        import hashlib
+        img = api.qv_write_coding(state["coding"], b"@" + movie.encode())
+        sig = torch.tensor([int.from_bytes(hashlib.sha256(img).digest()[:7], "little")], dtype=torch.int64)
+        every = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(every, sig)
+        tables_same = all(int(e[0]) == int(every[0][0]) for e in every)
     else:
         all_bases, all_out = bases, state["total"]
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        ctx.close()
+        return None
 
     value = 5.0 * all_bases * args.steps / dt / 1e9
 
@@ -243,16 +350,8 @@ def main():
             kern[k]["algo_bytes"] = algo[k]
             kern[k]["GBps"] = algo[k] / (kern[k]["ms_avg"] * 1e-3) / 1e9
     dom = max(algo, key=lambda k: kern.get(k, {}).get("ms_avg", 0.0) * kern.get(k, {}).get("launches_per_step", 1))
-    traffic = None
-    if os.path.exists(args.traffic_file):
-        try:
-            tf = json.load(open(args.traffic_file))
-            if tf.get("entries") == n and tf.get("mean") == args.mean and tf.get("dist") == args.dist:
-                traffic = tf["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-                if traffic is not None and tf.get("launches_per_step", {}).get(dom, 1) != kern[dom]["launches_per_step"]:
-                    traffic = None                           # profile taken with another grouping
-        except Exception:
-            traffic = None
+    traffic = read_traffic(args.traffic_file, "dexqv", dom, dict(entries=n, mean=args.mean, dist=args.dist),
+                           kern[dom]["launches_per_step"])
     roofline = {"kernel": dom, "bound": "hbm", "achieved": round(kern[dom]["GBps"], 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algo_bytes_per_launch": algo[dom]}
@@ -265,38 +364,59 @@ def main():
             "encoder": "two pass (sizes, encode)" if args.twopass else "one pass (scratch slots, compaction on a second stream)"}
     pipe["frac"] = round(pipe["GBps"] / HBM_PEAK_GBS, 4)
 
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state,
-                           dict(p_out=p_out, p_rec=p_rec, n=n, movie=movie))
+    cpu_res = None
+    if cpu:
+        cpu_res = cpu_baseline(ctx, api, d_text, off, lens, hlen, args, state,
+                               dict(p_out=p_out, p_rec=p_rec, n=n, movie=movie))
 
+    which = "BASELINE.json configs[3]" if world == 1 else f"BASELINE.json configs[4] slice: {world * n} entries over {world} GPUs"
     line = {
         "metric": "dexqv encode input GB/s (5 QV/tag stream bytes per base; .dexqv bit-exact vs reference)",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"dexqv 5-stream Huffman encode, {n} x {args.mean} .quiva per GPU "
-                               f"({args.dist} lengths, BASELINE.json configs[3]), HBM-resident",
+                               f"({args.dist} lengths, {which}), HBM-resident",
                    "entries_per_gpu": n, "mean_len": args.mean, "lossy": bool(args.lossy),
                    "input_bytes_per_gpu": 5 * bases, "text_image_bytes_per_gpu": text_bytes,
                    "output_bytes": all_out, "ratio": round(5.0 * all_bases / all_out, 3),
-                   "sharding": "contiguous entry ranges, one file (host-side 12 KB histogram sum)" if world > 1 else "single GPU"},
+                   "sharding": "contiguous entry ranges of one file (host-side scan state + 12 KB histogram sum, gloo; no RCCL)"
+                               if world > 1 else "single GPU"},
         "roofline": roofline,
-        "cpu_baseline": cpu,
+        "cpu_baseline": cpu_res,
         "roundtrip_bit_exact": roundtrip,
+        "tables_identical_across_ranks": tables_same,
         "host_table_build_us": state.get("host_build_us"),
         "decode": state.get("decode"),
-        "text_front_end": front,
+        "text_front_end": fr,
         "pipeline": pipe,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                     for k, v in kern.items()},
     }
-    print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    del d_text, p_out, state["p_out"], p_text
+    ctx.close()
+    torch.cuda.empty_cache()
+    return line
 
 
-def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state, big):
+def read_traffic(path, workload, kernel, want, launches_per_step=1):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json), when it was
+    collected on the same workload shape; None otherwise."""
+    try:
+        tf = json.load(open(path))
+        tf = tf.get("workloads", {}).get(workload, tf if workload == "dexqv" else {})
+        if any(tf.get(k) != v for k, v in want.items()):
+            return None
+        if tf.get("launches_per_step", {}).get(kernel, 1) != launches_per_step:
+            return None                                   # profile taken with another grouping
+        return tf["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(ctx, api, d_text, off, lens, hlen, args, state, big):
     """Time the CPU path on a bounded sample of the same corpus (first S entries), on this host.
     kind "reference": the real reference `dexqv` (oracle/_ref, compiled from the reference's own
     sources); kind "port": the oracle's C restatement.  Also checks the GPU output for the same
@@ -335,21 +455,25 @@ def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state, bi
 
     # secondary number: end-to-end wall time of the drop-in CLI on the same sample file (tmpfs -> tmpfs,
     # includes process start, HIP init, PCIe both ways and the host parse) -- never the headline value
-    cli = os.path.join(ROOT, "dextractor_amd", "bin", "dexqv")
-    if os.path.isfile(cli):
+    for tool, srcname, payload, expect in (("dexqv", "s.quiva", sample, want), ("undexqv", "s.dexqv", want, None)):
+        cli = os.path.join(ROOT, "dextractor_amd", "bin", tool)
+        if not os.path.isfile(cli):
+            continue
         with tempfile.TemporaryDirectory(dir=shm) as d:
-            src = os.path.join(d, "s.quiva")
+            src = os.path.join(d, srcname)
             with open(src, "wb") as f:
-                f.write(sample)
+                f.write(payload)
+            flags = ["-k"] + (["-l"] if args.lossy and tool == "dexqv" else []) + (["-U"] if tool == "undexqv" else [])
             t0 = time.perf_counter()
-            rc_ = subprocess.call([cli, "-k"] + (["-l"] if args.lossy else []) + [src])
+            rc_ = subprocess.call([cli] + flags + [src])
             dtc = time.perf_counter() - t0
             same = False
             if rc_ == 0:
-                with open(os.path.join(d, "s.dexqv"), "rb") as f:
-                    same = f.read() == want
-        res["cli_end_to_end"] = {"seconds": round(dtc, 2), "GBps": round(5 * sbases / dtc / 1e9, 3),
-                                 "output_identical": bool(same)}
+                with open(os.path.join(d, "s.dexqv" if tool == "dexqv" else "s.quiva"), "rb") as f:
+                    back = f.read()
+                same = (back == expect) if expect is not None else (args.lossy or back == sample)
+        res["cli_end_to_end" if tool == "dexqv" else "cli_undexqv_end_to_end"] = {
+            "seconds": round(dtc, 2), "GBps": round(5 * sbases / dtc / 1e9, 3), "output_identical": bool(same)}
 
     # how the single-threaded reference would be deployed: one independent copy per host core
     trace("cpu_baseline: all cores")
@@ -395,15 +519,18 @@ def cpu_baseline(ctx, api, batch, d_text, off, lens, hdr4, hlen, args, state, bi
     return res
 
 
-def pack2_main(args):
-    """BASELINE configs[1]/[2]: 2-bit pack + unpack of `--reads` x `--mean` reads (80-column text).
-    A host-generated tile of 20000 reads is replicated on the device to the full size."""
+# ------------------------------------------------------------------------------------------------
+#  dexta / dexar (BASELINE configs[1] / [2])
+# ------------------------------------------------------------------------------------------------
+def pack2_bench(args, arrow):
+    """2-bit pack + unpack of `--reads` x `--mean` reads (80-column text).  A host-generated tile of
+    20000 reads is replicated on the device to the full size.  Returns the JSON line as a dict."""
     import torch
     from dextractor_amd import _lib as L
     from dextractor_amd import api, synth
     torch.cuda.set_device(0)
     ctx = api.Context(0)
-    arrow = args.workload == "dexar"
+    name = "dexar" if arrow else "dexta"
     n0 = min(20000, args.reads)
     tile = synth.make_seqfile("arrow" if arrow else "fasta", n0, seed=args.seed, dist="fixed", mean=args.mean)
     reps = max(1, args.reads // n0)
@@ -425,8 +552,6 @@ def pack2_main(args):
     ooff = np.concatenate([[0], np.cumsum(rec)[:-1]]).astype(np.uint64)
     out_bytes = int(rec.sum())
 
-    class Ptr:
-        def __init__(self, t): self.t, self.ptr = t, t.data_ptr()
     up = lambda a, dt: Ptr(torch.from_numpy(np.ascontiguousarray(a).view(dt)).cuda())
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     p_text, p_off, p_tlen, p_nsym = Ptr(d_text), up(off, np.int64), up(tlen, np.int32), up(nsym, np.int32)
@@ -468,20 +593,56 @@ def pack2_main(args):
     text_in = int(tlen.astype(np.uint64).sum())
     enc_ms, dec_ms = times["k_pack2_encode"][0] / args.steps, times["k_pack2_decode"][0] / args.steps
     algo_enc, algo_dec = text_in + out_bytes, (out_bytes + text_in)
-    line = {"metric": f"{args.workload} 2-bit pack input GB/s (+ unpack); round-trip bit-exact",
+
+    # CPU baseline: the real reference tool on the host tile (one core), and the GPU file driver on the
+    # same tile compared with its output byte for byte
+    cpu = None
+    if not args.no_cpu_baseline:
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", name)
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        ext = ".arrow" if arrow else ".fasta"
+        cpu = {"unit": "GB/s", "cores": 1, "sample": f"{n0} reads of the bench tile ({tb / 1e9:.2f} GB of text)"}
+        want = None
+        if os.path.isfile(ref_bin):
+            with tempfile.TemporaryDirectory(dir=shm) as d:
+                src = os.path.join(d, "s" + ext)
+                with open(src, "wb") as f:
+                    f.write(tile.text)
+                t1 = time.perf_counter()
+                subprocess.check_call([ref_bin, "-k", src])
+                dtc = time.perf_counter() - t1
+                with open(os.path.join(d, "s." + name), "rb") as f:
+                    want = f.read()
+            cpu.update(kind="reference", value=round(tb / dtc / 1e9, 4), seconds=round(dtc, 2))
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import _oracle as O
+            t1 = time.perf_counter()
+            want = (O.dexar if arrow else O.dexta)(tile.text)
+            dtc = time.perf_counter() - t1
+            cpu.update(kind="port", value=round(tb / dtc / 1e9, 4), seconds=round(dtc, 2))
+        got = (ctx.dexar if arrow else ctx.dexta)(tile.text)
+        cpu["gpu_output_identical"] = bool(got == want)
+
+    tr = read_traffic(args.traffic_file, name, "k_pack2_encode", dict(reads=n, mean=args.mean))
+    line = {"metric": f"{name} 2-bit pack input GB/s (+ unpack); round-trip bit-exact",
             "value": round(text_in / (enc_ms * 1e-3) / 1e9, 2), "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload} + un{args.workload}, {n} x {args.mean} reads, 80-column text, HBM-resident "
+            "config": {"workload": f"{name} + un{name}, {n} x {args.mean} reads, 80-column text, HBM-resident "
                                    f"(BASELINE.json configs[{2 if arrow else 1}])", "reads": n, "bases": bases,
                        "text_bytes": text_in, "packed_bytes": out_bytes},
             "roofline": {"kernel": "k_pack2_encode", "bound": "hbm", "achieved": round(algo_enc / (enc_ms * 1e-3) / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_enc / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": None, "algo_bytes_per_launch": algo_enc},
+                         "traffic": tr, "algo_bytes_per_launch": algo_enc},
             "decode": {"kernel": "k_pack2_decode", "ms": round(dec_ms, 3), "GBps": round(algo_dec / (dec_ms * 1e-3) / 1e9, 1),
-                       "frac": round(algo_dec / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "encode_ms": round(enc_ms, 3), "roundtrip_bit_exact": same, "cpu_baseline": None}
-    print(json.dumps(line))
+                       "frac": round(algo_dec / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "traffic": read_traffic(args.traffic_file, name, "k_pack2_decode", dict(reads=n, mean=args.mean))},
+            "encode_ms": round(enc_ms, 3), "roundtrip_bit_exact": same, "cpu_baseline": cpu}
+    del d_text, p_text, p_out, p_back
+    ctx.close()
+    torch.cuda.empty_cache()
+    return line
 
 
 if __name__ == "__main__":

@@ -285,6 +285,14 @@ def qv_build(hist, tot, params, lossy=False) -> L.QVCoding:
     return c
 
 
+def qv_out_bound(hist, n, coding, lossy=False) -> int:
+    """dx_qv_out_bound: bytes (without framing) the batch whose raw histograms are `hist` can encode to at most."""
+    lib = L.load()
+    h = L.HIST()
+    np.ctypeslib.as_array(h)[:] = np.asarray(hist, dtype=np.uint64).reshape(6, 256)
+    return int(lib.dx_qv_out_bound(C.byref(h), int(n), C.byref(coding), int(lossy)))
+
+
 def qv_write_coding(coding, prefix: bytes) -> bytes:
     lib = L.load()
     n = C.c_size_t()

@@ -368,12 +368,17 @@ int dex_tool_main(int tool, int argc, char *argv[])
 
       if (!PIPE)
         { fclose(input);
-          fclose(output);
+          if (fclose(output) != 0)                         /* a deferred write error (ENOSPC, quota, NFS) surfaces here: */
+            { fprintf(stderr, "%s: System error, write failed!\n", Prog);   /* the source must survive it */
+              leave(2);
+            }
           if (!KEEP)
             unlink(src);
         }
-      else
-        fflush(output);
+      else if (fflush(output) != 0)
+        { fprintf(stderr, "%s: System error, write failed!\n", Prog);
+          leave(2);
+        }
       free(root); free(pwd); free(src); free(dst);
 
       if (VERBOSE)

@@ -43,6 +43,13 @@ static int dupload(dpool *pool, const void *src, size_t bytes, void **out)
   return rc;
 }
 
+/* The encoder of the file drivers is dx_qv_encode_onepass (no size pass; the same bytes).  DEXGPU_TWOPASS
+ * in the environment selects dx_qv_sizes + dx_qv_encode instead (kept for comparison and as a cross-check). */
+static int two_pass(void)
+{ const char *e = getenv("DEXGPU_TWOPASS");
+  return e != NULL && e[0] != '\0' && e[0] != '0';
+}
+
 static void dfree_all(dpool *pool)
 { int i;
   for (i = 0; i < pool->n; i++)
@@ -341,6 +348,7 @@ int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_
     { uint8_t  byte;
       int      beg, end, qv = 0, k;
       uint16_t cnr[4] = { 0, 0, 0, 0 };
+      uint32_t rlen;
       size_t   clen;
 
       rd(&r, &byte, 1);
@@ -357,17 +365,23 @@ int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_
         }
       else
         { beg = rd_u16(&r, flip); end = rd_u16(&r, flip); qv = rd_u16(&r, flip); }
-      if (r.bad || end < beg) { rc = DX_E_FORMAT; goto done; }
-      clen = ((size_t) (end - beg) + 3) >> 2;
+      if (r.bad || end < beg || (int64_t) end - (int64_t) beg > 0x7fffffff)   /* (hostile headers: no int overflow) */
+        { rc = DX_E_FORMAT; goto done; }
+      rlen = (uint32_t) ((int64_t) end - (int64_t) beg);
+      clen = ((size_t) rlen + 3) >> 2;
       if (r.at + clen > r.n) { rc = DX_E_FORMAT; goto done; }
 
       if (cnt == cap)
-        { cap  = cap ? 2 * cap : 1024;
-          ioff = realloc(ioff, cap * sizeof(*ioff));
-          ooff = realloc(ooff, cap * sizeof(*ooff));
-          hat  = realloc(hat,  (cap + 1) * sizeof(*hat));
-          nsym = realloc(nsym, cap * sizeof(*nsym));
-          if (!ioff || !ooff || !hat || !nsym) { rc = DX_E_NOMEM; goto done; }
+        { void *t;                                        /* a failed realloc leaves the old block to `done` */
+          cap  = cap ? 2 * cap : 1024;
+          if ((t = realloc(ioff, cap * sizeof(*ioff))) == NULL) { rc = DX_E_NOMEM; goto done; }
+          ioff = t;
+          if ((t = realloc(ooff, cap * sizeof(*ooff))) == NULL) { rc = DX_E_NOMEM; goto done; }
+          ooff = t;
+          if ((t = realloc(hat, (cap + 1) * sizeof(*hat))) == NULL) { rc = DX_E_NOMEM; goto done; }
+          hat = t;
+          if ((t = realloc(nsym, cap * sizeof(*nsym))) == NULL) { rc = DX_E_NOMEM; goto done; }
+          nsym = t;
         }
       if ((rc = tb_room(&hd, (size_t) plen + 160)) != DX_OK) goto done;
       hat[cnt] = hd.len;
@@ -381,7 +395,7 @@ int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_
         hd.len += (size_t) sprintf(hd.p + hd.len, "%s/%d/%d_%d RQ=0.%d\n", name, well, beg, end, qv);
 
       ioff[cnt] = r.at;
-      nsym[cnt] = (uint32_t) (end - beg);
+      nsym[cnt] = rlen;
       r.at += clen;
       cnt  += 1;
     }
@@ -497,15 +511,23 @@ int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
   if (rc != DX_OK && rc != DX_E_SPACE) goto done;
   head = 2 + clen;
 
-  TRY(dx_qv_sizes(ctx, &b, d_hoff, d_seg, d_rec, &total));
+  /* pass 2, dexqv.c:112-143: Compress_Next_QVentry for every entry */
+  if (!two_pass())
+    { const uint64_t cap = hoff[cnt] + dx_qv_out_bound((const uint64_t (*)[256]) hist, cnt, cd, lossy);
+      TRY(dalloc(&pool, cap, &d_out));
+      TRY(dx_qv_encode_onepass(ctx, &b, d_hdr, d_hoff, d_seg, d_rec, d_out, cap, &total));
+    }
+  else
+    { TRY(dx_qv_sizes(ctx, &b, d_hoff, d_seg, d_rec, &total));
+      TRY(dalloc(&pool, total, &d_out));
+      TRY(dx_qv_encode(ctx, &b, d_hdr, d_hoff, d_rec, d_seg, d_out));
+    }
   img = malloc(head + total + 16);
   if (!img) { rc = DX_E_NOMEM; goto done; }
   { uint16_t key = 0x55aa;                                                 /* dexqv.c:105-108 */
     memcpy(img, &key, 2);
     TRY(dx_qv_write_coding(cd, (const char *) text, plen, img + 2, clen, &clen));
   }
-  TRY(dalloc(&pool, total, &d_out));
-  TRY(dx_qv_encode(ctx, &b, d_hdr, d_hoff, d_rec, d_seg, d_out));          /* pass 2, dexqv.c:112-143 */
   TRY(dx_d2h(ctx, img + head, d_out, total));
   *out = img; *out_len = head + total; img = NULL;
   rc = DX_OK;
@@ -587,6 +609,10 @@ typedef struct shard_job shard_job;
 
 typedef struct
   { int               nsh, lossy, rc;
+    int               ok;                    /* written by shard 0 in its merge steps only, read by all after the next barrier */
+    int               go;                    /* start gate: 0 wait, 1 run, -1 a thread could not be created: leave */
+    pthread_mutex_t   gate_mx;
+    pthread_cond_t    gate_cv;
     pthread_barrier_t bar;
     const uint8_t    *text;
     const uint64_t   *off;
@@ -610,6 +636,9 @@ struct shard_job
     uint64_t     hist[6][256], tot, bytes, at;
   };
 
+/* Steps alternate between "every shard works and sets its own rc" and "shard 0 folds the results",
+ * with a barrier after each: shard 0 reads the others' rc only in its folding steps (nobody writes
+ * then) and publishes the verdict in a->ok, which the working steps read (nobody writes it then).   */
 static int all_ok(shard_all *a)
 { int k;
   for (k = 0; k < a->nsh; k++)
@@ -626,6 +655,12 @@ static void *shard_main(void *arg)
   void       *d_text = NULL, *d_off = NULL, *d_len = NULL, *d_hdr = NULL, *d_hoff = NULL, *d_rec = NULL, *d_seg = NULL, *d_out = NULL;
   dx_qv_batch b;
   int         rc = DX_OK, k;
+
+  pthread_mutex_lock(&a->gate_mx);                        /* all threads exist, or none runs */
+  while (a->go == 0) pthread_cond_wait(&a->gate_cv, &a->gate_mx);
+  k = a->go;
+  pthread_mutex_unlock(&a->gate_mx);
+  if (k < 0) return NULL;
 
   memset(&b, 0, sizeof(b));
   j->p.delChar = j->p.subChar = -1; j->p.del_first = j->p.sub_first = -1;
@@ -672,7 +707,7 @@ static void *shard_main(void *arg)
   j->rc = rc;
   pthread_barrier_wait(&a->bar);
 
-  if (j->id == 0 && all_ok(a))                           /* merge the scan state (lowest entry wins) */
+  if (j->id == 0 && (a->ok = all_ok(a)))                 /* merge the scan state (lowest entry wins) */
     { a->p.delChar = a->p.subChar = -1; a->p.del_first = a->p.sub_first = -1;
       for (k = 0; k < a->nsh; k++)
         if (a->jobs[k].p.delChar >= 0 && (a->p.delChar < 0 || a->jobs[k].p.del_first < a->p.del_first))
@@ -683,11 +718,11 @@ static void *shard_main(void *arg)
     }
   pthread_barrier_wait(&a->bar);
 
-  if (all_ok(a) && m > 0)
+  if (a->ok && m > 0)
     j->rc = dx_qv_hist(j->ctx, &b, j->lo, &a->p, j->hist, &j->tot);        /* QV.c:988-1017, per shard */
   pthread_barrier_wait(&a->bar);
 
-  if (j->id == 0 && all_ok(a))                           /* host-side sum + Create_QVcoding */
+  if (j->id == 0 && (a->ok = all_ok(a)))                 /* host-side sum + Create_QVcoding */
     { int s, x;
       memset(a->hist, 0, sizeof(a->hist)); a->tot = 0;
       for (k = 0; k < a->nsh; k++)
@@ -697,18 +732,28 @@ static void *shard_main(void *arg)
           a->tot += a->jobs[k].tot;
         }
       a->rc = dx_qv_build((const uint64_t (*)[256]) a->hist, a->tot, &a->p, a->lossy, &a->cd);
+      a->ok = a->rc == DX_OK;
     }
   pthread_barrier_wait(&a->bar);
 
-  if (all_ok(a) && m > 0)
+  if (a->ok && m > 0)                                    /* Compress_Next_QVentry for the shard's entries */
     { rc = dx_qv_set_coding(j->ctx, &a->cd, a->lossy);
-      if (rc == DX_OK) rc = dx_qv_sizes(j->ctx, &b, d_hoff, d_seg, d_rec, &total);
+      if (rc == DX_OK && !two_pass())
+        { const uint64_t cap = hoff[m] + dx_qv_out_bound((const uint64_t (*)[256]) j->hist, m, &a->cd, a->lossy);
+          rc = dalloc(&pool, cap, &d_out);
+          if (rc == DX_OK) rc = dx_qv_encode_onepass(j->ctx, &b, d_hdr, d_hoff, d_seg, d_rec, d_out, cap, &total);
+        }
+      else if (rc == DX_OK)
+        { rc = dx_qv_sizes(j->ctx, &b, d_hoff, d_seg, d_rec, &total);
+          if (rc == DX_OK) rc = dalloc(&pool, total, &d_out);
+          if (rc == DX_OK) rc = dx_qv_encode(j->ctx, &b, d_hdr, d_hoff, d_rec, d_seg, d_out);
+        }
       j->bytes = total;
       j->rc = rc;
     }
   pthread_barrier_wait(&a->bar);
 
-  if (j->id == 0 && all_ok(a))                           /* layout of the final image */
+  if (j->id == 0 && (a->ok = all_ok(a)))                 /* layout of the final image */
     { size_t clen = 0, plen = 0;
       const uint8_t *h = a->text, *slash = memchr(h + 1, '/', (size_t) (a->off[0] - 1));
       plen = slash ? (size_t) (slash - h) : 0;
@@ -726,15 +771,12 @@ static void *shard_main(void *arg)
           memcpy(a->img, &key, 2);
           a->rc = dx_qv_write_coding(&a->cd, (const char *) a->text, plen, a->img + 2, clen, &clen);
         }
+      a->ok = a->rc == DX_OK;
     }
   pthread_barrier_wait(&a->bar);
 
-  if (all_ok(a) && m > 0)
-    { rc = dalloc(&pool, total, &d_out);
-      if (rc == DX_OK) rc = dx_qv_encode(j->ctx, &b, d_hdr, d_hoff, d_rec, d_seg, d_out);
-      if (rc == DX_OK) rc = dx_d2h(j->ctx, a->img + j->at, d_out, total);
-      j->rc = rc;
-    }
+  if (a->ok && m > 0)
+    j->rc = dx_d2h(j->ctx, a->img + j->at, d_out, total);
   dfree_all(&pool);
   free(roff); free(hoff); free(blob);
   return NULL;
@@ -777,6 +819,9 @@ int dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n
     a.cut = e < cnt ? e : 0;                 /* never reached: no subChar at all, shard 0 finds that too */
   }
   pthread_barrier_init(&a.bar, NULL, (unsigned) nctx);
+  pthread_mutex_init(&a.gate_mx, NULL);
+  pthread_cond_init(&a.gate_cv, NULL);
+  a.go = 0; a.ok = 1;
   { uint64_t per = cnt / (uint64_t) nctx, extra = cnt % (uint64_t) nctx, lo = 0;
     for (k = 0; k < nctx; k++)
       { uint64_t m = per + ((uint64_t) k < extra ? 1 : 0);
@@ -785,25 +830,29 @@ int dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n
         lo += m;
       }
   }
-  for (k = 0; k < nctx; k++)
-    { if (pthread_create(&th[k], NULL, shard_main, &a.jobs[k]) != 0)
-        { /* cannot run short-handed: the barriers count nctx threads */
-          rc = DX_E_NOMEM;
-          for (; started > 0; started--) pthread_cancel(th[started-1]);
-          goto done_bar;
-        }
+  for (k = 0; k < nctx; k++)                              /* the barriers count nctx threads: all of them or none */
+    { if (pthread_create(&th[k], NULL, shard_main, &a.jobs[k]) != 0) break;
       started += 1;
     }
-  for (k = 0; k < nctx; k++)
+  pthread_mutex_lock(&a.gate_mx);
+  a.go = started == nctx ? 1 : -1;
+  pthread_cond_broadcast(&a.gate_cv);
+  pthread_mutex_unlock(&a.gate_mx);
+  for (k = 0; k < started; k++)
     pthread_join(th[k], NULL);
-  rc = a.rc;
-  for (k = 0; k < nctx && rc == DX_OK; k++)
-    rc = a.jobs[k].rc;
+  if (started < nctx)
+    rc = DX_E_NOMEM;
+  else
+    { rc = a.rc;
+      for (k = 0; k < nctx && rc == DX_OK; k++)
+        rc = a.jobs[k].rc;
+    }
   if (rc == DX_OK)
     { *out = a.img; *out_len = a.total; a.img = NULL; }
 
-done_bar:
   pthread_barrier_destroy(&a.bar);
+  pthread_mutex_destroy(&a.gate_mx);
+  pthread_cond_destroy(&a.gate_cv);
 done:
   free(off); free(len); free(hdr4); free(a.jobs); free(th); free(a.img);
   return rc;
@@ -888,9 +937,16 @@ int dx_entries_compress(dx_ctx *ctx, const dx_entries *e, int lossy, dx_qv_codin
   TRY(dx_qv_hist(ctx, &b, 0, &p, hist, &tot));
   TRY(dx_qv_build((const uint64_t (*)[256]) hist, tot, &p, lossy, coding));   /* Create_QVcoding */
   TRY(dx_qv_set_coding(ctx, coding, lossy));
-  TRY(dx_qv_sizes(ctx, &b, NULL, d_seg, d_rec, &total));
-  TRY(dalloc(&pool, total, &d_out));
-  TRY(dx_qv_encode(ctx, &b, NULL, NULL, d_rec, d_seg, d_out));   /* Compress_Next_QVentry1 x n */
+  if (!two_pass())                                              /* Compress_Next_QVentry1 x n */
+    { const uint64_t cap = dx_qv_out_bound((const uint64_t (*)[256]) hist, e->n, coding, lossy);
+      TRY(dalloc(&pool, cap, &d_out));
+      TRY(dx_qv_encode_onepass(ctx, &b, NULL, NULL, d_seg, d_rec, d_out, cap, &total));
+    }
+  else
+    { TRY(dx_qv_sizes(ctx, &b, NULL, d_seg, d_rec, &total));
+      TRY(dalloc(&pool, total, &d_out));
+      TRY(dx_qv_encode(ctx, &b, NULL, NULL, d_rec, d_seg, d_out));
+    }
   res = malloc(total + 16);
   ro  = malloc((e->n + 1) * sizeof(*ro));
   if (!res || !ro) { rc = DX_E_NOMEM; goto done; }

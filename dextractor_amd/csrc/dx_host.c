@@ -242,6 +242,49 @@ int dx_qv_build(const uint64_t hist[6][256], uint64_t totChar, const dx_qv_param
   return DX_OK;
 }
 
+/* Upper bound, from the raw histograms of a batch (dx_qv_hist) and the coding built from them or from
+ * the whole file, of the bytes Compress_Next_QVentry writes for the batch's `n` entries (without framing
+ * bytes): every symbol costs exactly its code (QV.c:427-434, 489-497), every non-run symbol of a
+ * run-coded line is preceded by one run token and an entry ends with at most one more (QV.c:475-487):
+ * the runs the histogram counted (entries from del_first / sub_first on) are priced exactly, the others
+ * at the dearest run token; per entry at most one partial and one pad word for each of the four code
+ * segments (QV.c:436-442) and a last partial tag byte.  Sizes d_out for dx_qv_encode_onepass.        */
+uint64_t dx_qv_out_bound(const uint64_t hist[6][256], uint64_t n, const dx_qv_coding *c, int lossy)
+{ uint64_t bits = 0, tags = 0;
+  int      s, x;
+  if (hist == NULL || c == NULL) return 0;
+  for (s = 0; s < 4; s++)
+    { const int      rc  = s == DX_DEL ? c->delChar : (s == DX_SUB ? c->subChar : -1);
+      const int      rs  = s == DX_DEL ? DX_DRUN : DX_SRUN;
+      const int      msk = !lossy ? 0xff : (s == DX_INS ? 0xfe : (s == DX_MRG ? 0xfc : 0xff));   /* QV.c:1406-1415 */
+      const dx_scheme *sc = &c->s[s];
+      uint64_t nonrun = 0;
+      for (x = 0; x < 256; x++)
+        { const int y = x & msk;
+          uint64_t  l = (uint64_t) sc->lens[y];
+          if (x == rc) continue;
+          if (sc->type == 2 && sc->bits[y] == sc->bits[255] && sc->lens[y] == sc->lens[255]) l += 8;   /* QV.c:432 */
+          bits   += hist[s][x] * l;
+          nonrun += hist[s][x];
+        }
+      if (s == DX_DEL) tags = nonrun;                     /* Pack_Tag keeps the tags of the non-run positions */
+      if (rc >= 0)
+        { const dx_scheme *rn = &c->s[rs];
+          uint64_t counted = 0, dearest = 0;
+          for (x = 0; x < 256; x++)
+            { uint64_t l = (uint64_t) rn->lens[x];
+              if (rn->bits[x] == rn->bits[255] && rn->lens[x] == rn->lens[255]) l += 16;               /* QV.c:486 */
+              if (l > dearest) dearest = l;
+              bits    += hist[rs][x] * l;
+              counted += hist[rs][x];
+            }
+          if (nonrun + n > counted)
+            bits += (nonrun + n - counted) * dearest;
+        }
+    }
+  return (bits + 7) / 8 + tags / 4 + n * (4 * 8 + 1) + 64;
+}
+
 /* ==========================================================================================
  *  coding header image (QV.c:300-375, 1173-1320)
  * ========================================================================================== */
@@ -720,9 +763,17 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   if (n < 2) return DX_E_FORMAT;
   memcpy(&key, img, 2);                                   /* undexqv.c:103-110 */
   if (key == 0x55aa || key == 0xaa55) { x->newv = 1; at = 2; }
-  x->prefix = malloc(n + 1);                              /* the prefix cannot be longer than the image */
-  if (x->prefix == NULL) return DX_E_NOMEM;
-  rc = dx_qv_read_coding(img + at, n - at, &x->coding, &x->flip, x->prefix, n + 1, &used);
+  { uint16_t k2 = 0;                                      /* prefix length first (QV.c:1222-1256): key, two run chars, int32 */
+    uint32_t pl = 0;
+    if (n - at < 10) return DX_E_FORMAT;
+    memcpy(&k2, img + at, 2);
+    memcpy(&pl, img + at + 6, 4);
+    if (k2 != 0x33cc) pl = flip32(pl);
+    if ((uint64_t) pl > (uint64_t) (n - at - 10)) return DX_E_FORMAT;
+    x->prefix = malloc((size_t) pl + 1);
+    if (x->prefix == NULL) return DX_E_NOMEM;
+    rc = dx_qv_read_coding(img + at, n - at, &x->coding, &x->flip, x->prefix, (size_t) pl + 1, &used);
+  }
   if (rc != DX_OK) goto fail;
   at += used;
 
@@ -778,12 +829,17 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
 
       if (x->n == cap)
         { cap = cap ? 2 * cap : 1024;
-          x->rec_off = realloc(x->rec_off, (cap + 1) * sizeof(uint64_t));
-          x->hdr_off = realloc(x->hdr_off, (cap + 1) * sizeof(uint64_t));
-          x->seg     = realloc(x->seg, cap * 5 * sizeof(uint32_t));
-          x->len     = realloc(x->len, cap * sizeof(uint32_t));
-          x->hdr4    = realloc(x->hdr4, cap * 4 * sizeof(int32_t));
-          if (!x->rec_off || !x->hdr_off || !x->seg || !x->len || !x->hdr4) { rc = DX_E_NOMEM; goto fail; }
+          void *t;                                        /* a failed realloc leaves the old block to dx_qv_index_free */
+          if ((t = realloc(x->rec_off, (cap + 1) * sizeof(uint64_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
+          x->rec_off = t;
+          if ((t = realloc(x->hdr_off, (cap + 1) * sizeof(uint64_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
+          x->hdr_off = t;
+          if ((t = realloc(x->seg, cap * 5 * sizeof(uint32_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
+          x->seg = t;
+          if ((t = realloc(x->len, cap * sizeof(uint32_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
+          x->len = t;
+          if ((t = realloc(x->hdr4, cap * 4 * sizeof(int32_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
+          x->hdr4 = t;
         }
       x->rec_off[x->n] = h0;
       x->hdr_off[x->n] = hat;

@@ -257,6 +257,14 @@ int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const 
 int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total);
 
+/* Host helper sizing d_out for dx_qv_encode_onepass: an upper bound of the bytes the batch's n entries
+ * encode to (framing bytes not included), from the batch's own raw histograms (what dx_qv_hist added
+ * for it) and the coding in force -- every symbol priced at its code (QV.c:427-434), run tokens at
+ * theirs (QV.c:475-497), partial / pad words (QV.c:436-442) and tag bytes (QV.c:810-819) per entry.
+ * Within a few percent of the real size once the file is much longer than the 100000 symbols after which
+ * the run histograms start (the runs before are priced at the dearest run token).                    */
+uint64_t dx_qv_out_bound(const uint64_t hist[6][256], uint64_t n, const dx_qv_coding *c, int lossy);
+
 /* Uncompress_Next_QVentry (QV.c:1428-1481: Decode, Decode_Run, Unpack_Tag) for n records whose
  * segment starts are known: record i starts at d_in + d_rec_off[i] with d_hdr_off[i+1] -
  * d_hdr_off[i] framing bytes (NULL: none) followed by segments of d_seg[5*i+k] bytes -- exactly

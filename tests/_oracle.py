@@ -155,6 +155,21 @@ def run_ref(tool, flags, src_bytes, src_ext, dst_ext, tmpdir):
         return f.read()
 
 
+def legacy_dexqv(dx, walk):
+    """The same .dexqv in the older layout undexqv still reads (undexqv.c:104-109, 159-179): no 0x55aa
+    key in front of the coding's 0x33cc, and beg / end / qv of every record as uint16 instead of int32.
+    All three fields of every record must fit 16 bits.  `walk` = api.qv_walk(dx)."""
+    import struct
+    out = bytearray(dx[2:int(walk["rec_off"][0])])
+    for i in range(walk["n"]):
+        r0, r1 = int(walk["rec_off"][i]), int(walk["rec_off"][i + 1])
+        hl = int(walk["hdr_off"][i + 1] - walk["hdr_off"][i])
+        beg, end, qv = struct.unpack("<iii", dx[r0 + hl - 12: r0 + hl])
+        assert 0 <= beg < 65536 and 0 <= end < 65536 and 0 <= qv < 65536
+        out += dx[r0: r0 + hl - 12] + struct.pack("<HHH", beg, end, qv) + dx[r0 + hl: r1]
+    return bytes(out)
+
+
 def byteswap_dexqv(dx, walk):
     """The same .dexqv as a host of the other endianness would have written it (every uint16 /
     int32 / uint32 field and code word byte-swapped; tag bytes and well bytes unchanged).

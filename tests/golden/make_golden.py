@@ -12,6 +12,8 @@ and the bytes the reference produced for it:
     <case>.fasta  -> <case>.dexta  -> <case>.rt.fasta   (undexta, flags in CASES)
     <case>.arrow  -> <case>.dexar  -> <case>.rt.arrow   (undexar)
     <case>.quiva  -> <case>.dexqv  -> <case>.rt.quiva   (undexqv -U)
+    qv_tiny.legacy.dexqv (older layout, derived from qv_tiny.dexqv) -> qv_tiny.legacy.rt.quiva (undexqv -U),
+                                                                         qv_tiny.legacy.rt_lower.quiva (undexqv)
 
 Large inputs are stored gzip-compressed; for the 10 MB BASELINE config-1 corpus only the seed and
 the SHA-256 of the reference's outputs are stored (hashes.json).  Fixtures are data: inputs and
@@ -240,6 +242,18 @@ def main():
         CASES.append({"name": name, "kind": "quiva", "flags": flags,
                       "input": "qv_full" if name == "qv_lossy" else name,
                       "rt_is_input": store_rt(name + ".rt.quiva", rt, txt)})
+
+    # ---- older .dexqv layout (no 0x55aa key, uint16 beg/end/qv: undexqv.c:104-109, 159-179) ----
+    # No current tool writes it; the image is derived from the reference's own qv_tiny.dexqv (fields
+    # narrowed, key dropped) and the expected text is what the REAL reference undexqv prints for it.
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O                                  # noqa: E402  (only its byte-shuffling helper)
+    from dextractor_amd import api                       # noqa: E402  (host-side walk: record boundaries)
+    dx = run_tool("dexqv", [], qv["qv_tiny"][0], ".quiva", ".dexqv")
+    leg = O.legacy_dexqv(dx, api.qv_walk(dx))
+    store("qv_tiny.legacy.dexqv", leg)
+    store("qv_tiny.legacy.rt.quiva", run_tool("undexqv", ["-U"], leg, ".dexqv", ".quiva"))
+    store("qv_tiny.legacy.rt_lower.quiva", run_tool("undexqv", [], leg, ".dexqv", ".quiva"))
 
     # ---- BASELINE config 1: 1000 reads, mean 10 kb -- hashes only ----
     c1 = synth.make_seqfile("fasta", 1000, seed=20261003, mean=10000)

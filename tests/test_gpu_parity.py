@@ -416,6 +416,24 @@ def test_undexqv_byteswapped_file(ctx, name):
     assert ctx.undexqv(fl, upper=True) == ctx.undexqv(dx, upper=True) == O.undexqv(fl, upper=True)
 
 
+def test_undexqv_older_layout(ctx):
+    """No 0x55aa key and uint16 beg/end/qv (undexqv.c:104-109, 159-179); expected text = the real reference
+    undexqv's output for this image (tests/golden/make_golden.py)."""
+    leg = O.golden("qv_tiny.legacy.dexqv")
+    assert ctx.undexqv(leg, upper=True) == O.golden("qv_tiny.legacy.rt.quiva")
+    assert ctx.undexqv(leg, upper=False) == O.golden("qv_tiny.legacy.rt_lower.quiva")
+
+
+def test_file_drivers_two_pass_switch_gives_the_same_bytes(ctx, monkeypatch):
+    """DEXGPU_TWOPASS selects dx_qv_sizes + dx_qv_encode in the file drivers instead of the one-pass
+    encoder: same file."""
+    c = synth.make_quiva(50, seed=23, mean=5000)
+    want = O.dexqv(c.text)
+    assert ctx.dexqv(c.text) == want
+    monkeypatch.setenv("DEXGPU_TWOPASS", "1")
+    assert ctx.dexqv(c.text) == want
+
+
 def test_undexta_legacy_and_byteswapped_keys(ctx):
     """undexta accepts 0x33cc (uint16 fields) and byte-swapped files (undexta.c:140-159, 211-240)."""
     import struct
@@ -527,12 +545,30 @@ def test_dexqv_large_file_uses_gpu_index_and_still_matches(ctx, monkeypatch):
     assert str(e1.value) == str(e2.value)
 
 
+def _dev(k):
+    """Device of the k-th context of a sharded run: distinct GPUs when the box has several, else device 0."""
+    return k % max(1, L.load().dx_device_count())
+
+
+def test_file_dexqv_sharded_cut_beyond_shard0(ctx):
+    """~250 k symbols over 4 contexts: the 100000-symbol threshold of QV.c:1006 lies beyond shard 0, whose
+    prefix batch must then supply subChar (csrc/dx_files.c)."""
+    c = synth.make_quiva(28, seed=17, mean=9000)
+    cs = [api.Context(_dev(k)) for k in range(4)]
+    try:
+        assert api.dexqv_sharded(cs, c.text, 0) == O.dexqv(c.text, 0)
+    finally:
+        for x in cs:
+            x.close()
+
+
 @pytest.mark.parametrize("nctx", [2, 5])
 @pytest.mark.parametrize("lossy", [0, 1])
 def test_file_dexqv_sharded_over_contexts(ctx, nctx, lossy):
-    """dx_file_dexqv_sharded: host threads + host-side merge; here all contexts sit on device 0."""
+    """dx_file_dexqv_sharded: host threads + host-side merge; one context per GPU when several are
+    visible, otherwise all on device 0."""
     c = synth.make_quiva(43, seed=71, mean=7000)
-    cs = [api.Context(0) for _ in range(nctx)]
+    cs = [api.Context(_dev(k)) for k in range(nctx)]
     try:
         got = api.dexqv_sharded(cs, c.text, lossy)
     finally:
@@ -540,7 +576,7 @@ def test_file_dexqv_sharded_over_contexts(ctx, nctx, lossy):
             x.close()
     assert got == O.dexqv(c.text, lossy)
     tiny = synth.make_quiva(3, seed=72, mean=100)                 # fewer entries than contexts
-    cs = [api.Context(0) for _ in range(nctx)]
+    cs = [api.Context(_dev(k)) for k in range(nctx)]
     try:
         assert api.dexqv_sharded(cs, tiny.text, lossy) == O.dexqv(tiny.text, lossy)
     finally:
@@ -555,7 +591,7 @@ def test_file_pack2_sharded_over_contexts(ctx, nctx, kind):
     each; the image is byte-identical to the single-context one and to the reference's."""
     lens = np.array([0, 3, 900, 17, 20000] + [int(x) for x in np.random.default_rng(3).integers(1, 6000, 70)], np.uint32)
     c = synth.make_seqfile(kind, len(lens), seed=41, lens=lens)
-    others = [api.Context(0) for _ in range(nctx - 1)]
+    others = [api.Context(_dev(k + 1)) for k in range(nctx - 1)]
     try:
         got = api.pack2_sharded([ctx] + others, c.text, arrow=(kind == "arrow"))
     finally:
@@ -770,9 +806,27 @@ def test_encode_onepass_equals_two_pass(ctx, case, groups, monkeypatch):
     d_rec2, d_seg2, d_out2 = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n), ctx.alloc(total + 64)
     total2 = ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg2, d_rec2, d_out2, total + 64)
     assert total2 == total
-    assert (d_rec2.download(np.uint64) == rec).all()
-    assert (d_seg2.download(np.uint32, 5 * n) == seg).all()
-    assert d_out2.download(np.uint8, total).tobytes() == out
+    rec2, seg2 = d_rec2.download(np.uint64), d_seg2.download(np.uint32, 5 * n).reshape(n, 5)
+    out2 = d_out2.download(np.uint8, total).tobytes()
+    # the one-pass encoder (the product path of the file drivers) directly against the oracle, entry by entry
+    ref_cd = O.Coding()
+    C.memmove(C.byref(ref_cd), C.byref(coding), C.sizeof(coding))
+    blob, hoff, _ = api.frame_headers(c.hdr)
+    text = np.frombuffer(c.text, np.uint8)
+    at = 0
+    for i in range(n):
+        Ln, o = int(c.len[i]), int(c.off[i])
+        lines = np.stack([text[o + k * (Ln + 1): o + k * (Ln + 1) + Ln] for k in range(5)])
+        body, want_seg = O.qv_encode_entry(ref_cd, lossy, lines)
+        want_rec = blob[int(hoff[i]): int(hoff[i + 1])].tobytes() + body
+        assert int(rec2[i]) == at and list(seg2[i]) == want_seg
+        assert out2[at: at + len(want_rec)] == want_rec
+        at += len(want_rec)
+    assert at == total2 == int(rec2[n])
+    # ... and against the two-pass encoder
+    assert (rec2 == rec).all()
+    assert (seg2.reshape(-1) == seg).all()
+    assert out2 == out
     with pytest.raises(L.DexGPUError) as e:                      # too small an output buffer is reported, not overrun
         ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg2, d_rec2, d_out2, max(total - 1, 0))
     assert e.value.code == -8

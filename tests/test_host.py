@@ -211,6 +211,36 @@ def test_walk_byteswapped_file():
     assert (w2["seg"] == w["seg"]).all() and (w2["hdr4"] == w["hdr4"]).all() and (w2["rec_off"] == w["rec_off"]).all()
 
 
+def test_walk_older_layout():
+    """No 0x55aa key, uint16 beg/end/qv (undexqv.c:104-109, 159-179): same index, 6 fewer framing bytes per record."""
+    dx, leg = O.golden("qv_tiny.dexqv"), O.golden("qv_tiny.legacy.dexqv")
+    w, w2 = api.qv_walk(dx), api.qv_walk(leg)
+    assert (w2["newv"], w2["flip"], w2["n"]) == (0, 0, w["n"])
+    assert (w2["seg"] == w["seg"]).all() and (w2["hdr4"] == w["hdr4"]).all() and (w2["len"] == w["len"]).all()
+    assert (np.diff(w["hdr_off"]) - np.diff(w2["hdr_off"]) == 6).all()
+    assert int(w2["rec_off"][-1]) == len(leg) and w2["prefix"] == w["prefix"]
+
+
+def test_out_bound_covers_the_encoded_size():
+    """dx_qv_out_bound (sizes d_out of the one-pass encoder) from the raw histograms: never below, and for
+    ordinary files close to, the bytes the oracle encodes."""
+    for name, lossy in (("qv_full", 0), ("qv_full", 1), ("qv_runs", 0), ("qv_type2", 0), ("qv_nodel", 0), ("qv_tiny", 0)):
+        txt = O.golden(name + ".quiva")
+        st = O.qv_scan(txt)
+        coding = O.qv_create(st, lossy)
+        hist = O.hist_array(st).astype(np.uint64).copy()
+        hist[4:] -= 1                                         # the oracle's run bins start at 1 (QV.c:934-935); dx_qv_hist's at 0
+        cd = L.QVCoding()
+        C.memmove(C.byref(cd), C.byref(coding), C.sizeof(cd))
+        n = len(api.index_quiva(txt)[1])
+        w = api.qv_walk(O.dexqv(txt, lossy))
+        body = int(w["rec_off"][-1] - w["rec_off"][0]) - int(w["hdr_off"][-1])
+        bound = api.qv_out_bound(hist, n, cd, lossy)
+        assert body <= bound
+        if name == "qv_full":                                 # (the runs before sub_first are priced at the dearest run token)
+            assert bound < 1.25 * body
+
+
 def test_no_gpu_means_loud_failure(tmp_path):
     """There is no CPU fallback: without a HIP device the library and the tools refuse to work."""
     import subprocess

@@ -33,16 +33,21 @@ def _worker(rank, world, port, text, off, lens, hdr4, lossy, q):
         start = int(off[lo]) - _hdr_len(text, int(off[lo])) if hi > lo else 0
         stop = int(off[hi - 1]) + 5 * (int(lens[hi - 1]) + 1) if hi > lo else 0
         piece = text[start:stop]
-        st = O.qv_scan(piece)
-        # local -> global scan state
-        mine = torch.tensor([st.delChar, lo + st.del_first if st.delChar >= 0 else -1,
-                             st.subChar, lo + st.sub_first if st.subChar >= 0 else -1], dtype=torch.int64)
-        every = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(every, mine)
-        dC, dF, sC, sF = shard.merge_params([tuple(int(v) for v in e) for e in every])
+        st = O.qv_scan(piece) if hi > lo else None
+        t8 = np.frombuffer(text, np.uint8)
+
+        def sub_hist(i0, i1):                                 # substitution-QV bytes of local entries [i0, i1)
+            h = np.zeros(256, np.int64)
+            for i in range(lo + i0, lo + i1):
+                Ln, o = int(lens[i]), int(off[i])
+                h += np.bincount(t8[o + 4 * (Ln + 1): o + 4 * (Ln + 1) + Ln], minlength=256)
+            return h
+
+        mine = (st.delChar, lo + st.del_first) if st is not None and st.delChar >= 0 else (-1, -1)
+        dC, dF, sC, sF = shard.agree_params(dist, mine, lens[lo:hi], lo, sub_hist)
         # raw histograms of the slice under the GLOBAL scan state
         h = _raw_hist_with_params(piece, lo, dC, dF, sC, sF)
-        ht = torch.from_numpy(np.concatenate([h.reshape(-1), [st.totChar]]).astype(np.int64))
+        ht = torch.from_numpy(np.concatenate([h.reshape(-1), [int(lens[lo:hi].astype(np.uint64).sum())]]).astype(np.int64))
         dist.all_reduce(ht)                                   # host-side sum, 12 KB
         hist, tot = ht[:-1].numpy().astype(np.uint64).reshape(6, 256), int(ht[-1])
         coding = api.qv_build(hist, tot, L.QVParams(dC, sC, dF, sF), lossy)
@@ -54,7 +59,6 @@ def _worker(rank, world, port, text, off, lens, hdr4, lossy, q):
                 ref.s[s].bits[k] = coding.s[s].bits[k]; ref.s[s].lens[k] = coding.s[s].lens[k]
         ref.delChar, ref.subChar = coding.delChar, coding.subChar
         blob, hoff, _ = api.frame_headers(hdr4[lo:hi], None, shard.previous_well(hdr4, lo))
-        t8 = np.frombuffer(text, np.uint8)
         out = []
         for i in range(lo, hi):
             Ln, o = int(lens[i]), int(off[i])
@@ -91,21 +95,40 @@ def _raw_hist_with_params(piece, lo, dC, dF, sC, sF):
     return h
 
 
-@pytest.mark.parametrize("lossy", [False, True])
-def test_two_rank_sharded_dexqv_equals_single(lossy):
-    c = synth.make_quiva(31, seed=91, mean=9000)              # > 200000 symbols: both run schemes
-    want = O.dexqv(c.text, lossy)
-    world, port = 2, _free_port()
+def _run_sharded(c, world, lossy):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, c.text, c.off, c.len, c.hdr, lossy, q))
              for r in range(world)]
     for p in procs: p.start()
-    got = sorted(q.get(timeout=120) for _ in range(world))
+    got = sorted(q.get(timeout=180) for _ in range(world))
     for p in procs: p.join(30)
     assert all(p.exitcode == 0 for p in procs)
-    img = shard.concat(got[0][1], [g[2] for g in got])
-    assert img == want
+    return shard.concat(got[0][1], [g[2] for g in got])
+
+
+@pytest.mark.parametrize("lossy", [False, True])
+def test_two_rank_sharded_dexqv_equals_single(lossy):
+    c = synth.make_quiva(31, seed=91, mean=9000)              # > 200000 symbols: both run schemes
+    assert _run_sharded(c, 2, lossy) == O.dexqv(c.text, lossy)
+
+
+def test_four_rank_cut_beyond_rank0():
+    """~250 k symbols over 4 ranks: the 100000-symbol threshold (QV.c:1006) lies in rank 1's slice, so
+    subChar must come from the histograms of ranks 0 and 1 together, not from rank 0 alone."""
+    c = synth.make_quiva(28, seed=17, mean=9000)
+    lo1, _ = shard.entry_range(28, 1, 4)
+    assert int(c.len[:lo1].astype(np.uint64).sum()) < 100000 <= int(c.len.astype(np.uint64).sum())
+    want = O.dexqv(c.text, False)
+    assert O.qv_scan(c.text).subChar >= 0                     # the single-process scan does choose one
+    assert _run_sharded(c, 4, False) == want
+
+
+def test_three_rank_short_file_has_no_subchar():
+    c = synth.make_quiva(9, seed=5, mean=6000)                # < 100000 symbols in all: no subChar anywhere
+    assert int(c.len.astype(np.uint64).sum()) < 100000
+    assert _run_sharded(c, 3, False) == O.dexqv(c.text, False)
 
 
 def test_entry_range_covers():
@@ -120,3 +143,11 @@ def test_entry_range_covers():
 def test_merge_params():
     assert shard.merge_params([(-1, -1, 63, 4), (50, 17, -1, -1), (50, 30, -1, -1)]) == (50, 17, 63, 4)
     assert shard.merge_params([(-1, -1, -1, -1)]) == (-1, -1, -1, -1)
+    # cut located across ranks: 60 k + 60 k symbols, threshold inside rank 1 (its 2nd entry)
+    h0, h1 = np.zeros(256, np.int64), np.zeros(256, np.int64)
+    h0[63], h0[40], h1[40] = 10, 9, 5
+    got = shard.merge_params([(-1, -1, -1, -1), (50, 7, -1, -1)], rank_tots=[60000, 60000], sub_hists=[h0, h1],
+                             lo_of_rank=[0, 6], lens_of_rank=[[10000] * 6, [30000, 30000]])
+    assert got == (50, 7, 40, 7)                              # 40: 14 > 63: 10; entry 6 + 1
+    assert shard.sub_cut([10, 20]) is None
+    assert shard.local_cut([5, 5, 5], 10) == 1 and shard.local_cut([5, 5, 5], 11) == 2
