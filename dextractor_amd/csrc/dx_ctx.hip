@@ -47,6 +47,7 @@ extern "C" int dx_open(int device, dx_ctx **out)
   ctx->coding_set = 0;
   ctx->d_scratch = NULL;
   ctx->scratch_bytes = 0;
+  memset(&ctx->tk, 0, sizeof(ctx->tk));
 
 #define OPEN_HIP(call)                                                                       \
   do { hipError_t e_ = (call);                                                               \
@@ -92,6 +93,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_status);
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);
+  (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
   for (int k = 0; k < 17; k++) (void) hipEventDestroy(ctx->ev[k]);

@@ -45,6 +45,21 @@ struct dx_ctx
   int       delChar, subChar;
   uint32_t  bps[4];            // upper bound of encoded bits per symbol of del/ins/mrg/sub (dx_qv_encode_onepass)
 
+  // run-length tokens the histogram pass leaves for the encoder (dx_qv.hip: "token hand-over")
+  struct
+  { uint16_t *del, *sub;       // token slots of the deletion / substitution stream, tok_off[r] .. tok_off[r+1]
+    uint64_t *off;             // n + 1 slot offsets, in tokens
+    uint32_t *info;            // n x 4: tokens of del | bit 31 unusable, of sub | bit 31, open run at the end of del, of sub
+    size_t    cap_tokens, cap_entries;        // what the buffers above hold
+    // the batch and scan state they were made for (the encoder uses them only for exactly this batch)
+    const void *text, *boff, *blen;
+    uint64_t    n, text_bytes;
+    uint32_t    pad;
+    int         delChar, subChar;
+    uint64_t    unusable;      // entries of the batch whose tokens cannot be used (encoded by the generic kernel)
+    int         valid;
+  } tk;
+
   // scratch owned by the context
   uint32_t *d_status;          // device error flags (bit 0: symbol count mismatch)
   uint64_t *d_u64;             // small device scalars (prescan keys, totals, ...)

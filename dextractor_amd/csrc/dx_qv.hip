@@ -268,27 +268,78 @@ __device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool 
       }
 }
 
+// ---------------------------------------------------------------------------------------------
+//  token hand-over: the histogram pass tokenises, the encoder only codes
+// ---------------------------------------------------------------------------------------------
+// Histogram_Runs (QV.c:709-724) and Encode_Run (QV.c:475-497) cut a run-coded line into the same
+// (run length, symbol) tokens.  The kernels are bound by vector-instruction issue, not by HBM, so the
+// cut is made once: while it histograms a run-coded line, k_qv_hist also stores its tokens, 16 bits
+// each -- bits [0,2) the 2-bit code of the deletion tag under the symbol (Pack_Tag + Number_Read,
+// QV.c:810-819; 0 for the substitution line), [2,9) the symbol, [9,16) the run in front of it -- into a
+// slot of len/2 + 64 tokens per entry, with the token count and the run left open at the line's end.
+// k_qv_encode_fast then walks dense token arrays instead of the text.  An entry whose line has a symbol
+// >= 128, a run >= 127 or more tokens than its slot holds is marked unusable and encoded from the text
+// by the generic kernel, as is everything when the tokens were made for another batch or scan state.
+#define TOK_RUN_MAX  127u                      // run field saturates here: the entry goes to the generic kernel
+#define TOK_BAD      0x80000000u               // info word: the stream's tokens are unusable
+
+struct tok_sink
+{ uint16_t       *del, *sub;                   // NULL del: no tokens wanted
+  const uint64_t *off;                         // n + 1 slot offsets (tokens)
+  uint32_t       *info;                        // n x 4
+  unsigned long long *unusable;                // count of entries with an unusable stream
+};
+
+__host__ __device__ __forceinline__ uint32_t tok_room(uint32_t L) { return (((L >> 1) + 64u) + 7u) & ~7u; }
+
+// does this entry have to be encoded from the text (generic kernel)?  info: the n x 4 words k_qv_hist left
+__device__ __forceinline__ bool tok_unusable(const uint32_t *info, uint64_t r, int delChar, int subChar)
+{ return (delChar >= 0 && (info[4 * r] & TOK_BAD)) || (subChar >= 0 && (info[4 * r + 1] & TOK_BAD)); }
+
 // one step of a run-coded stream: non-run symbols and the run before each (QV.c:709-724); the run
-// character itself is counted with popcounts instead of LDS atomics (it is 80-85 % of the stream)
+// character itself is counted with popcounts instead of LDS atomics (it is 80-85 % of the stream).
+// `count`: the run histogram takes part (entries from del_first / sub_first on, QV.c:1003, 1016).
+// `tok` != NULL: the step's tokens are stored at tok[ntok ...] (tagchunk: this step's deletion tags).
 __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c, int valid, uint32_t sv, uint32_t rc,
                                                uint32_t &C, uint32_t &nrun, uint32_t (*hs)[HCOLS], uint32_t *slow_s,
-                                               uint32_t (*hr)[HCOLS], uint32_t *slow_r)
+                                               uint32_t (*hr)[HCOLS], uint32_t *slow_r, bool count,
+                                               uint16_t *tok, uint32_t &ntok, uint32_t cap, uint32_t &bad,
+                                               const uint8_t *tagchunk, const uint8_t *tagcode)
 { const int      lane  = lane_id();
   const uint32_t col   = (uint32_t) lane & (HCOLS - 1);
   const uint32_t total = run_collect(R, c, valid, rc);
   nrun += sv - total;                                            // wave-uniform
+  bool emit = false;
+  if (tok != NULL && !bad)
+    { emit = ntok + total <= cap;
+      if (!emit) bad = 1;                                        // more tokens than the slot holds
+    }
+  uint32_t odd = 0;
   for (uint32_t i = lane; i < total; i += 64)
     { RUN_TOKEN(R, i, C, pos, x, run)
-      if (!__any(run >= HRUN_FAST || x >= HSYM_FAST))              // the usual case, decided once for the wave
+      if (count && !__any(run >= HRUN_FAST || x >= HSYM_FAST))     // the usual case, decided once for the wave
         { atomicAdd(&hr[run][col], 1u);
           atomicAdd(&hs[x][col], 1u);
         }
       else
-        { if (run < HRUN_FAST) atomicAdd(&hr[run][col], 1u);
-          else                 atomicAdd(&slow_r[run > 255u ? 255u : run], 1u);   // QV.c:717-720
+        { if (count)
+            { if (run < HRUN_FAST) atomicAdd(&hr[run][col], 1u);
+              else                 atomicAdd(&slow_r[run > 255u ? 255u : run], 1u);   // QV.c:717-720
+            }
           if (x < HSYM_FAST)   atomicAdd(&hs[x][col], 1u);
           else                 atomicAdd(&slow_s[x], 1u);
         }
+      if (emit)
+        { uint32_t t = (x << 2) | ((run < TOK_RUN_MAX ? run : TOK_RUN_MAX) << 9);
+          if (tagchunk != NULL)
+            t |= tagcode[tagchunk[pos]];
+          tok[ntok + i] = (uint16_t) t;
+          odd |= (x >= 128u || run >= TOK_RUN_MAX) ? 1u : 0u;
+        }
+    }
+  if (emit)
+    { ntok += total;
+      if (__any((int) odd)) bad = 1;
     }
   C = run_after(R, total, sv, C);
   wave_sync();
@@ -306,31 +357,51 @@ __device__ __forceinline__ uint32_t hist_bin_of(uint32_t k)
 
 __global__ __launch_bounds__(HIST_BLOCK)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
-               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket)
+               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts)
 { __shared__ hist_lds H;
   __shared__ __attribute__((aligned(16))) uint8_t s_chunk[HIST_NWAVE][DX_STEP];
+  __shared__ __attribute__((aligned(16))) uint8_t s_tchunk[HIST_NWAVE][DX_STEP];
   __shared__ uint16_t s_list[HIST_NWAVE][DX_STEP];
+  __shared__ uint8_t  s_tagcode[256];
   const int      lane  = lane_id();
   const int      tid   = threadIdx.x;
   const run_lds  R     = { s_chunk[tid >> 6], s_list[tid >> 6] };
+  uint8_t *const tchunk = s_tchunk[tid >> 6];
   uint32_t *const words = &H.sym[0][0][0];                      // the whole of H as words
   const uint32_t  nwords = sizeof(hist_lds) / 4;
+  const bool      toks  = ts.del != NULL;
 
   for (uint32_t k = tid; k < nwords; k += HIST_BLOCK) words[k] = 0;
+  if (tid < 256)
+    { const int u = tid & 0xdf;                                  // Number_Read's letter -> 2-bit code (DB.c:393-416)
+      s_tagcode[tid] = (uint8_t) (u == 'C' ? 1 : (u == 'G' ? 2 : (u == 'T' ? 3 : 0)));
+    }
   __syncthreads();
 
   uint64_t tot = 0, since = 0;
+  uint32_t unusable = 0;
   for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
   { nxt = next_unit(ticket, TICKET_BATCH);             // drawn early: the atomic's latency hides behind these entries
     for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
     { const uint32_t  L = a.len[r];
       const long long g = (long long) (entry0 + r);
-      const bool drun = a.delChar >= 0 && g >= del_first;
-      const bool srun = a.subChar >= 0 && g >= sub_first;
+      const bool drun = a.delChar >= 0 && (toks || g >= del_first);      // tokenised (and, from del_first on, run-histogrammed)
+      const bool srun = a.subChar >= 0 && (toks || g >= sub_first);
+      const bool dcnt = a.delChar >= 0 && g >= del_first, scnt = a.subChar >= 0 && g >= sub_first;
       const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2);
       const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
+      const uint8_t *p1 = line_ptr(a, r, L, 1);
       const bool over = can_overread(a, p4, L);       // p4 is the last line of the entry
       uint32_t C0 = 0, C4 = 0, n0 = 0, n4 = 0;
+      uint16_t *tk0 = NULL, *tk4 = NULL;
+      uint32_t  nt0 = 0, nt4 = 0, cap = 0, bad0 = 0, bad4 = 0;
+      if (toks)
+        { const uint64_t t0 = ts.off[r];
+          cap = (uint32_t) (ts.off[r + 1] - t0);
+          if (drun) tk0 = ts.del + t0;
+          if (srun) tk4 = ts.sub + t0;
+        }
+      const bool tags = tk0 != NULL;
 
       uint32_t pos = 16u * lane;
       u32x4 c0 = fetch(p0, pos, L, over), c2 = fetch(p2, pos, L, over);
@@ -339,25 +410,42 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
         { const uint32_t np = pos + DX_STEP;           // next step's chunks go in flight first
           const u32x4 d0 = fetch(p0, np, L, over), d2 = fetch(p2, np, L, over);
           const u32x4 d3 = fetch(p3, np, L, over), d4 = fetch(p4, np, L, over);
+          u32x4 t1 = c0;
+          if (tags) t1 = fetch(p1, pos, L, over);      // this step's deletion tags; landed once ins and mrg are counted
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
           const bool     full  = sv == DX_STEP;
           const int      valid = valid_of(pos, L);
-          if (drun) hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.sym[DX_DEL], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN]);
-          else      hist_plain_step(c0, valid, full, H.sym[DX_DEL], H.slow[DX_DEL]);
           hist_plain_step(c2, valid, full, H.sym[DX_INS], H.slow[DX_INS]);
           hist_plain_step(c3, valid, full, H.sym[DX_MRG], H.slow[DX_MRG]);
-          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.sym[DX_SUB], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN]);
+          if (drun)
+            { if (tags) *(u32x4 *) (tchunk + 16 * lane) = t1;    // (run_collect's barrier orders it before the look-ups)
+              hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.sym[DX_DEL], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN],
+                             dcnt, tk0, nt0, cap, bad0, tags ? tchunk : (const uint8_t *) NULL, s_tagcode);
+            }
+          else      hist_plain_step(c0, valid, full, H.sym[DX_DEL], H.slow[DX_DEL]);
+          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.sym[DX_SUB], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
+                                   scnt, tk4, nt4, cap, bad4, (const uint8_t *) NULL, s_tagcode);
           else      hist_plain_step(c4, valid, full, H.sym[DX_SUB], H.slow[DX_SUB]);
           c0 = d0; c2 = d2; c3 = d3; c4 = d4;
           pos = np;
         }
       if (drun)                                        // trailing run + the run character's own count
-        { if (C0 > 0 && lane == 0) atomicAdd(&H.slow[DX_DRUN][C0 > 255u ? 255u : C0], 1u);
+        { if (dcnt && C0 > 0 && lane == 0) atomicAdd(&H.slow[DX_DRUN][C0 > 255u ? 255u : C0], 1u);
           if (lane == 0 && n0) atomicAdd(&H.slow[DX_DEL][a.delChar], n0);
         }
       if (srun)
-        { if (C4 > 0 && lane == 0) atomicAdd(&H.slow[DX_SRUN][C4 > 255u ? 255u : C4], 1u);
+        { if (scnt && C4 > 0 && lane == 0) atomicAdd(&H.slow[DX_SRUN][C4 > 255u ? 255u : C4], 1u);
           if (lane == 0 && n4) atomicAdd(&H.slow[DX_SUB][a.subChar], n4);
+        }
+      if (toks)
+        { if (lane == 0)
+            { uint32_t *w = ts.info + 4 * r;
+              w[0] = nt0 | ((bad0 || !drun) ? TOK_BAD : 0u);
+              w[1] = nt4 | ((bad4 || !srun) ? TOK_BAD : 0u);
+              w[2] = C0;
+              w[3] = C4;
+            }
+          unusable += ((drun && bad0) || (srun && bad4)) ? 1u : 0u;
         }
       tot   += L;
       since += L;
@@ -372,6 +460,8 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   }
   if (lane == 0 && tot)
     atomicAdd(g_tot, (unsigned long long) tot);
+  if (lane == 0 && unusable)
+    atomicAdd(ts.unusable, (unsigned long long) unusable);
   __syncthreads();
   // fold the 32 copies of every fast bin (rotated start: the lanes of a wave read distinct banks)
   for (uint32_t bin = tid; bin < HIST_FAST_WORDS / HCOLS; bin += HIST_BLOCK)
@@ -384,6 +474,13 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
     { const uint32_t v = (&H.slow[0][0])[k];
       if (v) atomicAdd(&g_hist[k], (unsigned long long) v);
     }
+}
+
+// slot sizes of the token hand-over (tokens per entry)
+__global__ __launch_bounds__(DX_BLOCK)
+void k_tok_rooms(const uint32_t *len, uint64_t n, uint32_t *room)
+{ const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
+  if (i < n) room[i] = tok_room(len[i]);
 }
 
 // =============================================================================================
@@ -1057,7 +1154,7 @@ __host__ __device__ __forceinline__ uint32_t tag_room(uint32_t L) { return (((L 
 __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
                  const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status, uint32_t *ticket,
-                 enc_scratch sc)
+                 enc_scratch sc, const uint32_t *only /* NULL, or token info: just the entries k_qv_encode_fast leaves out */)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint8_t  s_tagcode[256];
@@ -1081,6 +1178,8 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 
   for (uint64_t r = next_unit(ticket), nxt; r < a.n; r = nxt)
     { nxt = next_unit(ticket);
+      if (only != NULL && !tok_unusable(only, r, a.delChar, a.subChar))
+        continue;
       const uint32_t  L   = a.len[r];
       const bool      S   = sc.base != NULL;             // scratch mode
       const uint32_t *sg  = seg + 5 * r;
@@ -1251,6 +1350,8 @@ void k_qv_compact(uint64_t n, const uint32_t *len, const uint8_t *scratch, const
   }
 }
 
+#include "dx_qv_fast.hpp"
+
 // =============================================================================================
 //  C-ABI
 // =============================================================================================
@@ -1308,6 +1409,50 @@ extern "C" int dx_qv_prescan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0,
   return DX_OK;
 }
 
+// Token slots for the batch: offsets by a scan of the per-entry rooms, buffers grown as needed.  Returns
+// false (and leaves the hand-over off) when tokens are not wanted or the memory is not to be had.
+static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params *p, uint8_t *scr, size_t scr_at)
+{ ctx->tk.valid = 0;
+  const char *off = getenv("DEXGPU_NO_TOKENS");
+  if ((off != NULL && off[0] != '\0' && off[0] != '0') || (p->delChar < 0 && p->subChar < 0))
+    return false;
+  const uint64_t n      = b->n;
+  const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  uint32_t *d_room = (uint32_t *) (scr + scr_at);
+  uint64_t *d_tile = (uint64_t *) (scr + scr_at + ((n * 4 + 63) & ~(size_t) 63));
+  uint64_t *d_gran = d_tile + ntiles;
+  if (ctx->tk.cap_entries < n)
+    { (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info);
+      ctx->tk.off = NULL; ctx->tk.info = NULL; ctx->tk.cap_entries = 0;
+      if (hipMalloc((void **) &ctx->tk.off, (n + 1) * 8) != hipSuccess ||
+          hipMalloc((void **) &ctx->tk.info, n * 16) != hipSuccess)
+        { (void) hipGetLastError(); return false; }
+      ctx->tk.cap_entries = n;
+    }
+  hipLaunchKernelGGL(k_tok_rooms, dim3((unsigned) ((n + DX_BLOCK - 1) / DX_BLOCK)), dim3(DX_BLOCK), 0, ctx->stream,
+                     (const uint32_t *) b->d_len, n, d_room);
+  hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, (const uint32_t *) d_room, n, d_tile);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(DX_BLOCK), 0, ctx->stream, d_tile, ntiles, d_gran);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, (const uint32_t *) d_room, n,
+                     (const uint64_t *) d_tile, ctx->tk.off, (const uint64_t *) d_gran);
+  uint64_t total = 0;
+  if (hipMemcpyAsync(&total, d_gran, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    { (void) hipGetLastError(); return false; }
+  if (ctx->tk.cap_tokens < total)
+    { (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub);
+      ctx->tk.del = NULL; ctx->tk.sub = NULL; ctx->tk.cap_tokens = 0;
+      if (hipMalloc((void **) &ctx->tk.del, total * 2 + 64) != hipSuccess ||
+          hipMalloc((void **) &ctx->tk.sub, total * 2 + 64) != hipSuccess)
+        { (void) hipGetLastError();                   // not enough memory for the hand-over: the generic encoder does it all
+          (void) hipFree(ctx->tk.del); ctx->tk.del = NULL;
+          return false;
+        }
+      ctx->tk.cap_tokens = total;
+    }
+  return true;
+}
+
 extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, const dx_qv_params *p,
                           uint64_t hist[6][256], uint64_t *totChar)
 { int e = check_batch(ctx, b, "dx_qv_hist");
@@ -1316,22 +1461,36 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
     return dx_fail(ctx, DX_E_ARG, "dx_qv_hist: NULL argument");
   if (b->n == 0) return DX_OK;
   DX_HIP(ctx, hipSetDevice(ctx->device));
-  unsigned long long *d_hist;
-  if ((e = dx_scratch(ctx, (6 * 256 + 1) * 8, (void **) &d_hist))) return e;
-  DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 1) * 8, ctx->stream));
+  const uint64_t n      = b->n;
+  const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  const size_t   hbytes = ((6 * 256 + 2) * 8 + 255) & ~(size_t) 255;
+  uint8_t *scr;
+  if ((e = dx_scratch(ctx, hbytes + ((n * 4 + 63) & ~(size_t) 63) + (ntiles + 2) * 8 + 64, (void **) &scr))) return e;
+  unsigned long long *d_hist = (unsigned long long *) scr;
+  DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 2) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
+  tok_sink ts = { NULL, NULL, NULL, NULL, d_hist + 6 * 256 + 1 };
+  if (tokens_prepare(ctx, b, p, scr, hbytes))
+    { ts.del = ctx->tk.del; ts.sub = ctx->tk.sub; ts.off = ctx->tk.off; ts.info = ctx->tk.info; }
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE;       // one 16-wave workgroup per CU
   DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, (int) (hist_blocks < (uint64_t) ctx->num_cu ? hist_blocks : (uint64_t) ctx->num_cu), HIST_BLOCK,
-            a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket);
-  uint64_t host[6 * 256 + 1];
+            a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts);
+  uint64_t host[6 * 256 + 2];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int s = 0; s < 6; s++)
     for (int k = 0; k < 256; k++)
       hist[s][k] += host[s * 256 + k];
   *totChar += host[6 * 256];
+  if (ts.del != NULL)                                   // the tokens belong to exactly this batch and scan state
+    { ctx->tk.text = b->d_text; ctx->tk.boff = b->d_off; ctx->tk.blen = b->d_len;
+      ctx->tk.n = b->n; ctx->tk.text_bytes = b->text_bytes; ctx->tk.pad = b->line_pad;
+      ctx->tk.delChar = p->delChar; ctx->tk.subChar = p->subChar;
+      ctx->tk.unusable = host[6 * 256 + 1];
+      ctx->tk.valid = 1;
+    }
   return DX_OK;
 }
 
@@ -1503,7 +1662,8 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL });
+            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL },
+            (const uint32_t *) NULL);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1600,6 +1760,12 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
   uint64_t      *d_base = ctx->d_u64 + 24;               // [0], [1]: running record offset, ping-pong
   uint32_t      *d_tick_enc = (uint32_t *) (ctx->d_u64 + 19), *d_tick_cmp = (uint32_t *) (ctx->d_u64 + 22);
   qv_args        a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
+  // the token hand-over applies when k_qv_hist made its tokens for exactly this batch under the run characters now in force
+  // (a substitution run character dropped by Create_QVcoding, QV.c:1044, just leaves its tokens unused)
+  const bool fast = ctx->tk.valid && ctx->tk.text == (const void *) b->d_text && ctx->tk.boff == (const void *) b->d_off &&
+                    ctx->tk.blen == (const void *) b->d_len && ctx->tk.n == b->n && ctx->tk.text_bytes == b->text_bytes &&
+                    ctx->tk.pad == b->line_pad && ctx->tk.delChar == ctx->delChar &&
+                    (ctx->subChar < 0 || ctx->subChar == ctx->tk.subChar) && getenv("DEXGPU_NO_TOKENS") == NULL;
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
   DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
   int rc = DX_OK, ng = 0;                                // ng: groups run so far (selects the ping-pong base)
@@ -1614,10 +1780,21 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
       if (g >= 2)
         DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[g - 2], 0));    // the region is free once its last tenant has been copied out
-      DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-      DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, m, 4 * ENC_WAVES), DX_BLOCK,
-                ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                (uint8_t *) NULL, ctx->d_status, d_tick_enc, enc_scratch{ slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 });
+      const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 };
+      const uint32_t   *only = NULL;
+      if (fast)                                          // entries with usable tokens: walked from the tokens
+        { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
+          only = tg.info;
+          DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
+          DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast, dx_grid_waves(ctx, m, 4 * FAST_WAVES), DX_BLOCK,
+                    ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg);
+        }
+      if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
+        { DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
+          DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, m, 4 * ENC_WAVES), DX_BLOCK,
+                    ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) NULL, (const uint32_t *) NULL,
+                    (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g, only);
+        }
       DX_HIP(ctx, hipEventRecord(enc_done[g], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction
       DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g], 0));

@@ -1,0 +1,206 @@
+// dx_qv_fast.hpp -- k_qv_encode_fast: Compress_Next_QVentry (QV.c:1381-1426) from the token hand-over.
+// (Textually included by dx_qv.hip after the encoder's building blocks; not a stand-alone header.)
+//
+// The run-coded lines of an entry arrive as dense 16-bit tokens made by k_qv_hist (see "token hand-over"
+// in dx_qv.hip): Encode_Run (QV.c:475-497) is then a walk over an array -- no equality masks, no
+// position lists, no second read of the deletion, tag and substitution lines -- and Pack_Tag +
+// Number_Read + Compress_Read (QV.c:810-819, 1402-1404) is the 2-bit field already sitting in each
+// deletion token.  The insertion and merge lines (always plain, QV.c:1417-1418) are read from the text.
+// Entries are written into scratch slots exactly as the generic kernel's scratch mode does (del, ins,
+// mrg, sub compactly; tags at the slot's end) and their five sizes recorded; entries whose tokens are
+// marked unusable are left to the generic kernel.
+#define TOK_TP 8u                                        // tokens a lane takes per pass (one 16-byte load)
+
+struct tok_src
+{ const uint16_t *del, *sub;
+  const uint64_t *off;                                   // slot offsets (tokens), n + 1
+  const uint32_t *info;                                  // n x 4 (see k_qv_hist)
+};
+
+// Encode_Run over the line's tokens.  Passes of up to 64 * TOK_TP tokens: a lane loads TOK_TP
+// consecutive tokens with one 16-byte load, looks up run and symbol codes (shift tokens), chains them
+// into one string of <= 128 bits, and a single prefix sum + placement per pass puts the strings into
+// the window; with TAGS the lanes' 2-bit tag fields go into the tag window the same way.
+template <bool TAGS>
+__device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, const uint16_t *tok, uint32_t cnt,
+                                                  const uint32_t *ntab, const uint32_t *rtab,
+                                                  const uint32_t *nstab, const uint32_t *rstab)
+{ const uint32_t lane = (uint32_t) lane_id();
+  for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
+    { const uint32_t m     = cnt - k0 < 64u * TOK_TP ? cnt - k0 : 64u * TOK_TP;
+      const uint32_t T     = (m + 63u) >> 6;                       // tokens per lane in this pass (wave-uniform)
+      const uint32_t first = k0 + lane * T;
+      const uint32_t c     = first < k0 + m ? (k0 + m - first < T ? k0 + m - first : T) : 0u;
+      u32x4 tw = { 0u, 0u, 0u, 0u };
+      if (c)
+        tw = *(const u32x4_u *) (tok + first);                    // (may read up to 7 tokens past the count: inside the padded buffer)
+      uint32_t rt[TOK_TP], st[TOK_TP];
+      #pragma unroll
+      for (int k = 0; k < (int) TOK_TP; k++)                       // all look-ups first: one round of LDS waits per pass
+        { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
+          rt[k] = rstab[t16 >> 9];                                 // QV.c:479-487 (runs below TOK_RUN_MAX: no clamp needed)
+          st[k] = *(const uint32_t *) ((const uint8_t *) nstab + (t16 & 0x1fcu));
+        }
+      uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, nb = 0, zor = 0, tacc = 0;
+      #pragma unroll
+      for (int k = 0; k < (int) TOK_TP; k++)
+        if ((uint32_t) k < c)
+          { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
+            STOK_APPEND(rt[k])
+            if (rt[k] & 0x80u)                                     // escaped run: its 16-bit literal follows (QV.c:486-487)
+              { const uint32_t lit = ((t16 >> 9) << 16) | 16u;
+                STOK_APPEND(lit)
+                nb += 16u;
+              }
+            STOK_APPEND(st[k])
+            nb  += 64u - (rt[k] & 0x3fu) - (st[k] & 0xffu);
+            zor |= rt[k] | st[k];
+            if (TAGS)
+              tacc = (tacc << 2) | (t16 & 3u);
+          }
+      const uint32_t incl = wave_incl_scan(nb);
+      if (!__any((int) ((zor & 32u) | (nb > 128u))))
+        { FOR_EACH_ROUND(o, incl, nb,
+            { place_bits128(o.win, bit_, nb, w0, w1, w2, w3); })
+        }
+      else                                    // a symbol or run without a code, or a string > 128 bits
+        { FOR_EACH_ROUND(o, incl, nb,
+            { bit_acc s;
+              acc_begin(s, bit_);
+              _Pragma("unroll 1")
+              for (uint32_t j = 0; j < c; j++)
+                { const uint32_t t16 = tok[first + j];
+                  const uint32_t run = t16 >> 9;
+                  const uint32_t re  = rtab[run];
+                  const uint32_t se  = ntab[(t16 >> 2) & 0x7fu];
+                  acc_put(s, o.win, TOK_ESC(re) ? ((TOK_BITS(re) << 16) | run) : TOK_BITS(re),
+                          TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u));
+                  acc_put(s, o.win, TOK_BITS(se), TOK_LEN(se));
+                }
+              acc_end(s, o.win);
+            })
+        }
+      if (TAGS)
+        { if (c)
+            { const uint32_t bit = ot.winbits + 2u * (first - k0);
+              const uint32_t w = bit >> 5, sh = bit & 31u;
+              const uint32_t v = tacc << (32u - 2u * c);
+              atomicOr(&ot.win[w], v >> sh);
+              if (sh + 2u * c > 32u)
+                atomicOr(&ot.win[w + 1], v << (32u - sh));
+            }
+          ot.winbits += 2u * m;
+          if (ot.winbits >= TAG_FLUSH_BITS)
+            flush_quads(ot, true);
+        }
+    }
+}
+
+#ifndef FAST_WAVES
+#define FAST_WAVES 4
+#endif
+
+__global__ __launch_bounds__(DX_BLOCK, FAST_WAVES)
+void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
+                      enc_scratch sc, tok_src tk)
+{ __shared__ uint32_t s_tok[6][256];
+  __shared__ uint32_t s_stok[6][256];
+  __shared__ uint8_t  s_tagcode[256];
+  __shared__ __attribute__((aligned(16))) uint32_t s_win[DX_WAVES_PER_BLK][QV_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tag[DX_WAVES_PER_BLK][TAG_WIN_WORDS];
+  load_tables(s_tok, g_tok);
+  load_shift_tables(s_stok, s_tagcode, g_tok);
+  const int lane = lane_id();
+  const int wid  = threadIdx.x >> 6;
+
+  wave_out o, ot;
+  o.win  = s_win[wid];
+  ot.win = s_tag[wid];
+  for (int j = lane; j < QV_WIN_WORDS; j += 64)  o.win[j]  = 0;
+  for (int j = lane; j < TAG_WIN_WORDS; j += 64) ot.win[j] = 0;
+  wave_sync();
+
+  for (uint64_t r = next_unit(ticket), nxt; r < a.n; r = nxt)
+    { nxt = next_unit(ticket);
+      if (tok_unusable(tk.info, r, a.delChar, a.subChar))
+        continue;                                        // the generic kernel encodes this entry from the text
+      const uint32_t  L      = a.len[r];
+      const uint32_t *inf    = tk.info + 4 * r;
+      const uint64_t  toff   = tk.off[r];
+      uint32_t       *sgw    = sc.seg_out + 5 * r;
+      uint8_t        *dst    = sc.base + sc.slot_off[r];
+      uint8_t        *tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
+      const uint8_t  *p1     = line_ptr(a, r, L, 1);
+      const bool      over   = can_overread(a, line_ptr(a, r, L, 4), L);
+      uint32_t        sum    = 0;
+
+      // The four QV streams in file order: del (its tag segment goes to the slot's end), ins, mrg, sub
+      // (QV.c:1393-1423).
+      #pragma unroll 1
+      for (int q = 0; q < 4; q++)
+        { const int       line = q ? q + 1 : 0;
+          const int       rci  = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
+          const uint32_t *tab  = s_tok[q];
+          o.seg = dst; o.wordbase = 0; o.winbits = 0;
+          uint32_t got;
+
+          if (rci >= 0)                                  // Encode_Run from the tokens; for del also the tags
+            { const int       rs   = q == 0 ? DX_DRUN : DX_SRUN;
+              const uint32_t *rtab = s_tok[rs];
+              const uint16_t *tok  = (q == 0 ? tk.del : tk.sub) + toff;
+              const uint32_t  cnt  = inf[q == 0 ? 0 : 1] & ~TOK_BAD;
+              const uint32_t  C    = inf[q == 0 ? 2 : 3];           // run left open at the line's end
+              ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
+              if (q == 0) encode_token_line<true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs]);
+              else        encode_token_line<false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs]);
+              uint32_t last;
+              if (C > 0)
+                last = encode_trailing_run(o, C, rtab);
+              else if (cnt > 0)                          // the line ends in its last token's symbol
+                { const uint32_t e = tab[((uint32_t) tok[cnt - 1] >> 2) & 0x7fu];
+                  last = TOK_ESC(e) ? 8u : TOK_LEN(e);
+                }
+              else
+                last = 0;                                // empty line
+              got = finish_words(o, last);
+              if (q == 0)
+                { const uint32_t tb = finish_tags(ot);
+                  if (lane == 0) sgw[1] = tb;
+                  sum += tb;
+                }
+            }
+          else                                           // Encode
+            { const uint8_t *p    = line_ptr(a, r, L, line);
+              const uint32_t mask = !a.lossy ? 0xffu : (q == 1 ? 0xfeu : (q == 2 ? 0xfcu : 0xffu));   // QV.c:1406-1415
+              const uint32_t m4   = mask * 0x01010101u;
+              uint32_t pos = 16u * lane;
+              u32x4 c = fetch(p, pos, L, over);
+#define PLAIN_LOOP(STAB)                                                                        \
+              for (uint32_t base = 0; base < L; base += DX_STEP)                                 \
+                { const u32x4 d = fetch(p, pos + DX_STEP, L, over);                              \
+                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4); \
+                  c = d;                                                                         \
+                  pos += DX_STEP;                                                                \
+                }
+              if (q == 1)      { PLAIN_LOOP(s_stok[1]) }
+              else if (q == 2) { PLAIN_LOOP(s_stok[2]) }
+              else             { PLAIN_LOOP(s_stok[q]) }
+#undef PLAIN_LOOP
+              got = finish_words(o, last_piece_plain(tab, p, L, mask));
+              if (q == 0)                                // no delChar: the whole tag line is packed
+                { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
+                  const uint32_t tb = encode_all_tags(ot, p1, L, over);
+                  if (lane == 0) sgw[1] = tb;
+                  sum += tb;
+                }
+            }
+          if (lane == 0) sgw[line] = got;
+          sum += got;
+          dst += got;
+        }
+      if (dst > tag_at && lane == 0)
+        atomicOr(status, 2u);                            // the slot bound was too small: never expected
+      if (lane == 0)
+        sc.rec_size[r] = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
+    }
+}

@@ -50,8 +50,13 @@ def test_dexar_golden(ctx, case):
     assert ctx.undexar(dx, width) == rt
 
 
+@pytest.mark.parametrize("tokens", [True, False], ids=["tokens", "text"])
 @pytest.mark.parametrize("case", O.cases("quiva"), ids=lambda c: c["name"])
-def test_dexqv_golden(ctx, case):
+def test_dexqv_golden(ctx, case, tokens, monkeypatch):
+    """The reference's own .dexqv bytes through the file driver: with the token hand-over between the scan and
+    the encoder (k_qv_encode_fast) and, DEXGPU_NO_TOKENS set, with the generic kernel reading the text."""
+    if not tokens:
+        monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
     txt, dx = O.golden(case["input"] + ".quiva"), O.golden(case["name"] + ".dexqv")
     got = ctx.dexqv(txt, "-l" in case["flags"])
     assert len(got) == len(dx)
@@ -757,9 +762,9 @@ def test_dexqv_dense_token_stretches(ctx):
     assert ctx.undexqv(want, upper=False) == O.undexqv(want, upper=False)
 
 
-def _two_pass(ctx, c, coding, lossy=False):
+def _two_pass(ctx, c, coding, lossy=False, given=None):
     n = len(c.len)
-    b, keep = _upload_quiva(ctx, c)
+    b, keep = given if given is not None else _upload_quiva(ctx, c)
     ctx.qv_set_coding(coding, lossy)
     blob, hoff, _ = api.frame_headers(c.hdr)
     d_hdr, d_hoff = ctx.to_device(blob), ctx.to_device(hoff)
@@ -771,13 +776,19 @@ def _two_pass(ctx, c, coding, lossy=False):
             d_seg.download(np.uint32, 5 * n).copy(), (b, keep, d_hdr, d_hoff))
 
 
+@pytest.mark.parametrize("tokens", [True, False], ids=["tokens", "text"])
 @pytest.mark.parametrize("groups", [None, "3", "8"])
-@pytest.mark.parametrize("case", ["pacbio", "small_lengths", "dense", "sparse", "lossy", "long_codes", "no_runs", "huge_entry"])
-def test_encode_onepass_equals_two_pass(ctx, case, groups, monkeypatch):
+@pytest.mark.parametrize("case", ["pacbio", "small_lengths", "dense", "sparse", "lossy", "long_codes", "no_runs", "huge_entry",
+                                  "odd_entries"])
+def test_encode_onepass_equals_two_pass(ctx, case, groups, tokens, monkeypatch):
     """dx_qv_encode_onepass (scratch slots bounded from the tables + compaction, no size pass) gives the
-    bytes, record offsets and segment index of dx_qv_sizes + dx_qv_encode."""
+    bytes of the oracle, entry by entry, and the bytes, record offsets and segment index of dx_qv_sizes +
+    dx_qv_encode -- from the tokens k_qv_hist left for the batch (k_qv_encode_fast, with the generic kernel
+    for the entries whose tokens are unusable) and, without them, from the text alone."""
     if groups:                                                    # several groups: two streams, alternating scratch regions
         monkeypatch.setenv("DEXGPU_ONEPASS_GROUPS", groups)
+    if not tokens:
+        monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
     lossy = case == "lossy"
     if case == "small_lengths":
         lens = np.array(list(range(0, 70)) + [1023, 1024, 1025, 2047, 4097, 0, 1, 9000], np.uint32)
@@ -788,20 +799,35 @@ def test_encode_onepass_equals_two_pass(ctx, case, groups, monkeypatch):
     elif case in ("dense", "sparse"):
         p_ = 0.03 if case == "dense" else 0.995
         c = synth.make_quiva(40, seed=6, mean=5000, prof=synth.pacbio_profile(del_run_p=p_, sub_run_p=p_))
+    elif case == "odd_entries":                                   # among ordinary entries: runs of 126 / 127 / 300 (the token's run
+        c = synth.make_quiva(40, seed=9, mean=4000)               # field ends at 126), a byte >= 128, a line without run characters
+        txt, rc_d = bytearray(c.text), O.qv_scan(c.text).delChar
+        def put(e, line, at, data):
+            o_ = int(c.off[e]) + line * (int(c.len[e]) + 1) + at
+            txt[o_: o_ + len(data)] = data
+        for e, run in ((3, 126), (5, 127), (9, 300)):
+            put(e, 0, 49, b"5" + bytes([rc_d]) * run + b"5"); put(e, 1, 49, b"A" + b"N" * run + b"A")
+        put(12, 0, 7, bytes([200])); put(12, 1, 7, b"C")
+        put(14, 4, 100, bytes([131, 132]))
+        ln17 = int(c.len[17])
+        put(17, 0, 0, bytes(34 + (k % 11) for k in range(ln17))); put(17, 1, 0, b"ACGT" * (ln17 // 4) + b"A" * (ln17 % 4))
+        c.text = bytes(txt)
     else:
         c = synth.make_quiva(90, seed=7, mean=6000)
     st = O.qv_scan(c.text)
+    b, keep = _upload_quiva(ctx, c)
     if case == "long_codes":
         sub = st.subChar if st.subChar >= 0 else int(np.argmax(O.hist_array(st)[3]))
         coding = _fixed_coding(16, 16, True, st.delChar, sub)
     elif case == "no_runs":
         coding = _fixed_coding(7, 9, False, -1, -1)
     else:
-        b0, keep0 = _upload_quiva(ctx, c)
-        p = ctx.qv_prescan(b0)
-        hist, tot = ctx.qv_hist(b0, p)
+        p = ctx.qv_prescan(b)
+        hist, tot = ctx.qv_hist(b, p)
         coding = api.qv_build(hist, tot, p, lossy)
-    total, out, rec, seg, (b, keep, d_hdr, d_hoff) = _two_pass(ctx, c, coding, lossy)
+    total, out, rec, seg, (b, keep, d_hdr, d_hoff) = _two_pass(ctx, c, coding, lossy, given=(b, keep))
+    # tokens for exactly this batch under the run characters of the coding in force (also for the hand-made codings)
+    ctx.qv_hist(b, L.QVParams(coding.delChar, coding.subChar, 0, 0))
     n = len(c.len)
     d_rec2, d_seg2, d_out2 = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n), ctx.alloc(total + 64)
     total2 = ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg2, d_rec2, d_out2, total + 64)
