@@ -93,7 +93,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_status);
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);
-  (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info);
+  (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
   for (int k = 0; k < 17; k++) (void) hipEventDestroy(ctx->ev[k]);

@@ -44,12 +44,15 @@ struct dx_ctx
   int       lossy;
   int       delChar, subChar;
   uint32_t  bps[4];            // upper bound of encoded bits per symbol of del/ins/mrg/sub (dx_qv_encode_onepass)
+  uint32_t  pair_lo[2];        // ins, mrg: lowest coded byte value when the coded values span <= 64 (pair tables), else ~0
 
   // run-length tokens the histogram pass leaves for the encoder (dx_qv.hip: "token hand-over")
   struct
   { uint16_t *del, *sub;       // token slots of the deletion / substitution stream, tok_off[r] .. tok_off[r+1]
     uint64_t *off;             // n + 1 slot offsets, in tokens
     uint32_t *info;            // n x 4: tokens of del | bit 31 unusable, of sub | bit 31, open run at the end of del, of sub
+    unsigned long long *count; // device copy of `unusable`, followed in the same allocation by ...
+    uint32_t *list;            // ... the indices of those entries (any order)
     size_t    cap_tokens, cap_entries;        // what the buffers above hold
     // the batch and scan state they were made for (the encoder uses them only for exactly this batch)
     const void *text, *boff, *blen;

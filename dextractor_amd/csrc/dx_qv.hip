@@ -119,12 +119,6 @@ __device__ __forceinline__ uint32_t run_collect(const run_lds &R, const u32x4 &c
   return wave_total(incl);
 }
 
-// token i of the step (i < total): symbol and preceding run length
-#define RUN_TOKEN(R, i, C, pos, x, run)                                                         \
-  const uint32_t pos = (R).list[i];                                                             \
-  const uint32_t x   = (R).chunk[pos];                                                          \
-  const uint32_t run = (i) ? pos - (uint32_t) (R).list[(i) - 1] - 1u : (C) + pos;
-
 // run open at the end of a step of sv bytes with `total` tokens
 __device__ __forceinline__ uint32_t run_after(const run_lds &R, uint32_t total, uint32_t sv, uint32_t C)
 { return total ? sv - 1u - (uint32_t) R.list[total - 1] : C + sv; }
@@ -287,7 +281,8 @@ struct tok_sink
 { uint16_t       *del, *sub;                   // NULL del: no tokens wanted
   const uint64_t *off;                         // n + 1 slot offsets (tokens)
   uint32_t       *info;                        // n x 4
-  unsigned long long *unusable;                // count of entries with an unusable stream
+  unsigned long long *unusable;                // count of entries with an unusable stream ...
+  uint32_t       *list;                        // ... and their indices in the batch (any order)
 };
 
 __host__ __device__ __forceinline__ uint32_t tok_room(uint32_t L) { return (((L >> 1) + 64u) + 7u) & ~7u; }
@@ -315,27 +310,53 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
       if (!emit) bad = 1;                                        // more tokens than the slot holds
     }
   uint32_t odd = 0;
-  for (uint32_t i = lane; i < total; i += 64)
-    { RUN_TOKEN(R, i, C, pos, x, run)
-      if (count && !__any(run >= HRUN_FAST || x >= HSYM_FAST))     // the usual case, decided once for the wave
-        { atomicAdd(&hr[run][col], 1u);
-          atomicAdd(&hs[x][col], 1u);
+  // Two tokens per lane per round (i and i + 64): the look-ups of a token hang on each other (position ->
+  // symbol and tag -> tag code), so the second token's chain runs in the shadow of the first one's.
+  for (uint32_t i0 = 0; i0 < total; i0 += 128u)
+    { uint32_t pos[2], x[2], run[2], tg[2];
+      bool     on[2];
+      #pragma unroll
+      for (int k = 0; k < 2; k++)
+        { const uint32_t i = i0 + 64u * k + (uint32_t) lane;
+          on[k]  = i < total;
+          pos[k] = on[k] ? (uint32_t) R.list[i] : 0u;
+          run[k] = on[k] && i ? (uint32_t) R.list[i - 1] + 1u : 0u - C;       // where the run in front of the token starts
         }
-      else
-        { if (count)
-            { if (run < HRUN_FAST) atomicAdd(&hr[run][col], 1u);
-              else                 atomicAdd(&slow_r[run > 255u ? 255u : run], 1u);   // QV.c:717-720
-            }
-          if (x < HSYM_FAST)   atomicAdd(&hs[x][col], 1u);
-          else                 atomicAdd(&slow_s[x], 1u);
+      #pragma unroll
+      for (int k = 0; k < 2; k++)
+        { x[k]   = R.chunk[pos[k]];
+          tg[k]  = tagchunk != NULL ? (uint32_t) tagchunk[pos[k]] : 0u;
+          run[k] = pos[k] - run[k];
         }
-      if (emit)
-        { uint32_t t = (x << 2) | ((run < TOK_RUN_MAX ? run : TOK_RUN_MAX) << 9);
-          if (tagchunk != NULL)
-            t |= tagcode[tagchunk[pos]];
-          tok[ntok + i] = (uint16_t) t;
-          odd |= (x >= 128u || run >= TOK_RUN_MAX) ? 1u : 0u;
+      if (emit && tagchunk != NULL)
+        {
+          #pragma unroll
+          for (int k = 0; k < 2; k++)
+            tg[k] = tagcode[tg[k]];
         }
+      const bool fastbins = !__any((on[0] && (run[0] >= HRUN_FAST || x[0] >= HSYM_FAST)) ||
+                                   (on[1] && (run[1] >= HRUN_FAST || x[1] >= HSYM_FAST)));
+      #pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (on[k])
+          { if (fastbins)                                            // the usual case, decided once for the wave
+              { if (count) atomicAdd(&hr[run[k]][col], 1u);
+                atomicAdd(&hs[x[k]][col], 1u);
+              }
+            else
+              { if (count)
+                  { if (run[k] < HRUN_FAST) atomicAdd(&hr[run[k]][col], 1u);
+                    else                    atomicAdd(&slow_r[run[k] > 255u ? 255u : run[k]], 1u);   // QV.c:717-720
+                  }
+                if (x[k] < HSYM_FAST) atomicAdd(&hs[x[k]][col], 1u);
+                else                  atomicAdd(&slow_s[x[k]], 1u);
+              }
+            if (emit)
+              { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9);
+                tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;
+                odd |= (x[k] >= 128u || run[k] >= TOK_RUN_MAX) ? 1u : 0u;
+              }
+          }
     }
   if (emit)
     { ntok += total;
@@ -379,7 +400,6 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   __syncthreads();
 
   uint64_t tot = 0, since = 0;
-  uint32_t unusable = 0;
   for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
   { nxt = next_unit(ticket, TICKET_BATCH);             // drawn early: the atomic's latency hides behind these entries
     for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
@@ -406,12 +426,14 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
       uint32_t pos = 16u * lane;
       u32x4 c0 = fetch(p0, pos, L, over), c2 = fetch(p2, pos, L, over);
       u32x4 c3 = fetch(p3, pos, L, over), c4 = fetch(p4, pos, L, over);
+      u32x4 t1 = c0;
+      if (tags) t1 = fetch(p1, pos, L, over);          // the deletion tags travel with the step's other chunks
       for (uint32_t base = 0; base < L; base += DX_STEP)
         { const uint32_t np = pos + DX_STEP;           // next step's chunks go in flight first
           const u32x4 d0 = fetch(p0, np, L, over), d2 = fetch(p2, np, L, over);
           const u32x4 d3 = fetch(p3, np, L, over), d4 = fetch(p4, np, L, over);
-          u32x4 t1 = c0;
-          if (tags) t1 = fetch(p1, pos, L, over);      // this step's deletion tags; landed once ins and mrg are counted
+          u32x4 u1 = d0;
+          if (tags) u1 = fetch(p1, np, L, over);
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
           const bool     full  = sv == DX_STEP;
           const int      valid = valid_of(pos, L);
@@ -426,7 +448,7 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.sym[DX_SUB], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
                                    scnt, tk4, nt4, cap, bad4, (const uint8_t *) NULL, s_tagcode);
           else      hist_plain_step(c4, valid, full, H.sym[DX_SUB], H.slow[DX_SUB]);
-          c0 = d0; c2 = d2; c3 = d3; c4 = d4;
+          c0 = d0; c2 = d2; c3 = d3; c4 = d4; t1 = u1;
           pos = np;
         }
       if (drun)                                        // trailing run + the run character's own count
@@ -445,7 +467,8 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
               w[2] = C0;
               w[3] = C4;
             }
-          unusable += ((drun && bad0) || (srun && bad4)) ? 1u : 0u;
+          if (((drun && bad0) || (srun && bad4)) && lane == 0)      // rare: the generic kernel works through this list
+            ts.list[atomicAdd(ts.unusable, 1ull)] = (uint32_t) r;
         }
       tot   += L;
       since += L;
@@ -460,8 +483,6 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   }
   if (lane == 0 && tot)
     atomicAdd(g_tot, (unsigned long long) tot);
-  if (lane == 0 && unusable)
-    atomicAdd(ts.unusable, (unsigned long long) unusable);
   __syncthreads();
   // fold the 32 copies of every fast bin (rotated start: the lanes of a wave read distinct banks)
   for (uint32_t bin = tid; bin < HIST_FAST_WORDS / HCOLS; bin += HIST_BLOCK)
@@ -487,7 +508,7 @@ void k_tok_rooms(const uint32_t *len, uint64_t n, uint32_t *room)
 //  token tables in LDS
 // =============================================================================================
 __device__ __forceinline__ void load_tables(uint32_t (*s_tok)[256], const uint32_t *g_tok)
-{ for (int k = threadIdx.x; k < DX_TOK_WORDS; k += DX_BLOCK)
+{ for (int k = threadIdx.x; k < DX_TOK_WORDS; k += (int) blockDim.x)
     (&s_tok[0][0])[k] = g_tok[k];
   __syncthreads();
 }
@@ -870,11 +891,11 @@ __device__ __forceinline__ uint32_t shift_token(uint32_t t)
 // tables 0..3: symbol schemes; 4, 5: run schemes, bare run code with bit 7 = escape (the 16-bit
 // literal follows, QV.c:486-487); tagcode: Number_Read's letter -> 2-bit code (DB.c:319-338)
 __device__ __forceinline__ void load_shift_tables(uint32_t (*s_stok)[256], uint8_t *s_tagcode, const uint32_t *g_tok)
-{ for (int k = threadIdx.x; k < 6 * 256; k += DX_BLOCK)
+{ for (int k = threadIdx.x; k < 6 * 256; k += (int) blockDim.x)
     { const uint32_t t = g_tok[k];
       (&s_stok[0][0])[k] = shift_token(t) | ((k >= 4 * 256 && TOK_ESC(t)) ? 0x80u : 0u);
     }
-  for (int k = threadIdx.x; k < 256; k += DX_BLOCK)
+  for (int k = threadIdx.x; k < 256; k += (int) blockDim.x)
     { const int u = k & 0xdf;
       s_tagcode[k] = (uint8_t) (u == 'C' ? 1 : (u == 'G' ? 2 : (u == 'T' ? 3 : 0)));
     }
@@ -1154,7 +1175,8 @@ __host__ __device__ __forceinline__ uint32_t tag_room(uint32_t L) { return (((L 
 __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
                  const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status, uint32_t *ticket,
-                 enc_scratch sc, const uint32_t *only /* NULL, or token info: just the entries k_qv_encode_fast leaves out */)
+                 enc_scratch sc, const uint32_t *only_list, const unsigned long long *only_count, uint64_t first_entry,
+                 const uint32_t *only_info)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint8_t  s_tagcode[256];
@@ -1176,10 +1198,34 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
   for (int j = lane; j < TAG_WIN_WORDS; j += 64) ot.win[j] = 0;
   wave_sync();
 
-  for (uint64_t r = next_unit(ticket), nxt; r < a.n; r = nxt)
-    { nxt = next_unit(ticket);
-      if (only != NULL && !tok_unusable(only, r, a.delChar, a.subChar))
-        continue;
+  // Which entries: all of the batch, drawn one by one from the ticket counter -- or, beside
+  // k_qv_encode_fast, just those of the list k_qv_hist made of the entries whose tokens are unusable
+  // (batch-wide indices, any order; this launch takes the ones in [first_entry, first_entry + n)).  The
+  // list is drawn 64 indices at a time, a lane each.
+  const uint64_t listed = only_list ? (uint64_t) *only_count : 0;
+  uint64_t pend = 0, nxt = only_list ? 0 : next_unit(ticket);
+  uint32_t mine = 0;
+  for (;;)
+    { uint64_t r;
+      if (only_list == NULL)
+        { r = nxt;
+          if (r >= a.n) break;
+          nxt = next_unit(ticket);
+        }
+      else
+        { while (pend == 0)
+            { const uint64_t t = next_unit(ticket, 64u);
+              if (t >= listed) break;
+              mine = t + (uint64_t) lane < listed ? only_list[t + (uint64_t) lane] : 0xffffffffu;
+              pend = __ballot(mine != 0xffffffffu && (uint64_t) mine >= first_entry && (uint64_t) mine - first_entry < a.n);
+            }
+          if (pend == 0) break;
+          const int l = __ffsll((unsigned long long) pend) - 1;
+          pend &= pend - 1;
+          r = (uint64_t) __builtin_amdgcn_readlane(mine, l) - first_entry;
+          if (!tok_unusable(only_info, r, a.delChar, a.subChar))
+            continue;                                    // (listed for a run character the coding dropped: the fast kernel has it)
+        }
       const uint32_t  L   = a.len[r];
       const bool      S   = sc.base != NULL;             // scratch mode
       const uint32_t *sg  = seg + 5 * r;
@@ -1422,11 +1468,13 @@ static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params
   uint64_t *d_tile = (uint64_t *) (scr + scr_at + ((n * 4 + 63) & ~(size_t) 63));
   uint64_t *d_gran = d_tile + ntiles;
   if (ctx->tk.cap_entries < n)
-    { (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info);
-      ctx->tk.off = NULL; ctx->tk.info = NULL; ctx->tk.cap_entries = 0;
+    { (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
+      ctx->tk.off = NULL; ctx->tk.info = NULL; ctx->tk.count = NULL; ctx->tk.list = NULL; ctx->tk.cap_entries = 0;
       if (hipMalloc((void **) &ctx->tk.off, (n + 1) * 8) != hipSuccess ||
-          hipMalloc((void **) &ctx->tk.info, n * 16) != hipSuccess)
+          hipMalloc((void **) &ctx->tk.info, n * 16) != hipSuccess ||
+          hipMalloc((void **) &ctx->tk.count, 8 + n * 4) != hipSuccess)
         { (void) hipGetLastError(); return false; }
+      ctx->tk.list = (uint32_t *) (ctx->tk.count + 1);
       ctx->tk.cap_entries = n;
     }
   hipLaunchKernelGGL(k_tok_rooms, dim3((unsigned) ((n + DX_BLOCK - 1) / DX_BLOCK)), dim3(DX_BLOCK), 0, ctx->stream,
@@ -1469,9 +1517,9 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   unsigned long long *d_hist = (unsigned long long *) scr;
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 2) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
-  tok_sink ts = { NULL, NULL, NULL, NULL, d_hist + 6 * 256 + 1 };
+  tok_sink ts = { NULL, NULL, NULL, NULL, d_hist + 6 * 256 + 1, NULL };
   if (tokens_prepare(ctx, b, p, scr, hbytes))
-    { ts.del = ctx->tk.del; ts.sub = ctx->tk.sub; ts.off = ctx->tk.off; ts.info = ctx->tk.info; }
+    { ts.del = ctx->tk.del; ts.sub = ctx->tk.sub; ts.off = ctx->tk.off; ts.info = ctx->tk.info; ts.list = ctx->tk.list; }
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE;       // one 16-wave workgroup per CU
@@ -1489,6 +1537,8 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
       ctx->tk.n = b->n; ctx->tk.text_bytes = b->text_bytes; ctx->tk.pad = b->line_pad;
       ctx->tk.delChar = p->delChar; ctx->tk.subChar = p->subChar;
       ctx->tk.unusable = host[6 * 256 + 1];
+      // the generic kernel reads the count on the device: kept in front of the list (the scratch it was counted in is reused)
+      DX_HIP(ctx, hipMemcpyAsync(ctx->tk.count, d_hist + 6 * 256 + 1, 8, hipMemcpyDeviceToDevice, ctx->stream));
       ctx->tk.valid = 1;
     }
   return DX_OK;
@@ -1577,6 +1627,15 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
         }
       ctx->bps[s] = bound;
     }
+  for (int s = 0; s < 2; s++)                            // ins, mrg: band of coded byte values for the pair tables
+    { int lo = -1, hi = -1;                                // (k_qv_encode_fast: two symbols per look-up)
+      for (int x = 0; x < 256; x++)
+        if (c->s[DX_INS + s].lens[x] > 0)
+          { if (lo < 0) lo = x;
+            hi = x;
+          }
+      ctx->pair_lo[s] = (lo >= 0 && lo <= 192 && hi - lo < 64 && getenv("DEXGPU_NO_PAIRS") == NULL) ? (uint32_t) lo : 0xffffffffu;
+    }
   ctx->coding_set = 1;
   ctx->lossy   = lossy != 0;
   ctx->delChar = c->delChar;
@@ -1663,7 +1722,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
             a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL },
-            (const uint32_t *) NULL);
+            (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1671,6 +1730,15 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode: a segment's size differs from what dx_qv_sizes "
                                        "computed (d_seg / coding do not belong to this batch?)");
   return DX_OK;
+}
+
+// grid of k_qv_encode_fast: FAST_BLOCK-thread workgroups, 4 * FAST_WAVES waves per CU, no more waves than entries
+static int fast_grid(dx_ctx *ctx, uint64_t entries)
+{ const uint64_t per_cu = (uint64_t) (4 * FAST_WAVES * 64 / FAST_BLOCK);
+  uint64_t g = (uint64_t) ctx->num_cu * (per_cu ? per_cu : 1);
+  const uint64_t need = (entries + FAST_NWAVE - 1) / FAST_NWAVE;
+  if (need < g) g = need;
+  return (int) (g ? g : 1);
 }
 
 // side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
@@ -1781,19 +1849,22 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       if (g >= 2)
         DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[g - 2], 0));    // the region is free once its last tenant has been copied out
       const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 };
-      const uint32_t   *only = NULL;
       if (fast)                                          // entries with usable tokens: walked from the tokens
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
-          only = tg.info;
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast, dx_grid_waves(ctx, m, 4 * FAST_WAVES), DX_BLOCK,
-                    ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg);
+          DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast, fast_grid(ctx, m), FAST_BLOCK,
+                    ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
+                    ctx->pair_lo[0], ctx->pair_lo[1]);
         }
       if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
-        { DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, m, 4 * ENC_WAVES), DX_BLOCK,
+        { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;
+          DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
+          DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, work, 4 * ENC_WAVES), DX_BLOCK,
                     ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                    (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g, only);
+                    (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g,
+                    fast ? (const uint32_t *) ctx->tk.list : (const uint32_t *) NULL,
+                    fast ? (const unsigned long long *) ctx->tk.count : (const unsigned long long *) NULL, g0,
+                    fast ? (const uint32_t *) (ctx->tk.info + 4 * g0) : (const uint32_t *) NULL);
         }
       DX_HIP(ctx, hipEventRecord(enc_done[g], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction

@@ -96,20 +96,86 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
     }
 }
 
-#ifndef FAST_WAVES
-#define FAST_WAVES 4
-#endif
+// ---------------------------------------------------------------------------------------------
+//  plain lines two symbols per look-up
+// ---------------------------------------------------------------------------------------------
+// The insertion and merge QVs of a file sit in a narrow band of byte values (a few dozen symbols).  When a
+// line's coded symbols span at most 64 values starting at `lo` (<= 192), a 4096-entry table per line holds,
+// for every ordered pair of them, the two codes already chained into one shift token (if they have <= 24
+// bits together): half the look-ups and half the chain steps of Encode (QV.c:427-434) per byte.  The table
+// is built from the shift tokens by every workgroup at its start.  Pair index of bytes (b0, b1) in stream
+// order: (b0 - lo) + 64 * (b1 - lo).  A step with a byte outside the band, a pair without a token or a
+// lane string beyond 128 bits is handed to the one-symbol step.
+#define PAIR_NONE 0xffffffffu
 
-__global__ __launch_bounds__(DX_BLOCK, FAST_WAVES)
+__device__ __forceinline__ void build_pair_tables(uint32_t (*s_pair)[4096], const uint32_t (*s_stok)[256],
+                                                  uint32_t lo_ins, uint32_t lo_mrg)
+{ for (uint32_t k = threadIdx.x; k < 2u * 4096u; k += blockDim.x)
+    { const uint32_t q = 1u + (k >> 12), idx = k & 4095u, lo = q == 1u ? lo_ins : lo_mrg;
+      const uint32_t a = lo + (idx & 63u), b = lo + (idx >> 6);
+      uint32_t tok = 32u;                                            // "no code": the step goes to the one-symbol path
+      if (lo != PAIR_NONE && a < 256u && b < 256u)
+        { const uint32_t t1 = s_stok[q][a], t2 = s_stok[q][b];
+          const uint32_t s1 = t1 & 0xffu, s2 = t2 & 0xffu;           // 32 - length each
+          if (s1 < 32u && s2 < 32u && s1 + s2 >= 40u)                // both coded, <= 24 bits together
+            tok = (t1 & 0xffffff00u) | ((t2 & 0xffffff00u) >> (32u - s1)) | (s1 + s2 - 32u);
+        }
+      (&s_pair[0][0])[k] = tok;
+    }
+  __syncthreads();
+}
+
+// one full step (16 bytes per lane) of Encode through the pair table; false: not applicable to this step
+__device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 &c, const uint32_t *ptab, uint32_t lo4, uint32_t m4)
+{ uint32_t tok[8];
+  uint32_t ssum = 0, zor = 0, bad = 0;
+  #pragma unroll
+  for (int w = 0; w < 4; w++)
+    { const uint32_t x = (chunk_word(c, w) & m4) - lo4;              // bytes - lo: all < 64 in the band (no borrow then)
+      const uint32_t m = (x & 0x003f003fu) | ((x >> 2) & 0x0fc00fc0u);   // two 12-bit pair indices, one per half word
+      bad |= x;
+      tok[2 * w]     = ptab[m & 0xffffu];
+      tok[2 * w + 1] = ptab[m >> 16];
+    }
+  #pragma unroll
+  for (int k = 0; k < 8; k++)
+    { ssum += tok[k] & 0xffu;
+      zor  |= tok[k];
+    }
+  const uint32_t nb = 256u - ssum;
+  if (__any((int) ((bad & 0xc0c0c0c0u) | (zor & 32u) | (nb > 128u))))
+    return false;
+  const uint32_t incl = wave_incl_scan(nb);
+  FOR_EACH_ROUND(o, incl, nb,
+    { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+      _Pragma("unroll")
+      for (int k = 0; k < 8; k++)
+        STOK_APPEND(tok[k])
+      place_bits128(o.win, bit_, nb, w0, w1, w2, w3);
+    })
+  return true;
+}
+
+#ifndef FAST_WAVES
+#define FAST_WAVES 4                                     // waves per SIMD the register allocation leaves room for
+#endif
+#ifndef FAST_BLOCK
+#define FAST_BLOCK 512                                   // 8 waves share the 44 KB of tables: two workgroups per CU
+#endif
+#define FAST_NWAVE (FAST_BLOCK / 64)
+
+__global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
-                      enc_scratch sc, tok_src tk)
+                      enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
+  __shared__ uint32_t s_pair[2][4096];
   __shared__ uint8_t  s_tagcode[256];
-  __shared__ __attribute__((aligned(16))) uint32_t s_win[DX_WAVES_PER_BLK][QV_WIN_WORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t s_tag[DX_WAVES_PER_BLK][TAG_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_win[FAST_NWAVE][QV_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tag[FAST_NWAVE][TAG_WIN_WORDS];
   load_tables(s_tok, g_tok);
   load_shift_tables(s_stok, s_tagcode, g_tok);
+  build_pair_tables(s_pair, s_stok, pair_lo_ins, pair_lo_mrg);
   const int lane = lane_id();
   const int wid  = threadIdx.x >> 6;
 
@@ -182,9 +248,27 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                   c = d;                                                                         \
                   pos += DX_STEP;                                                                \
                 }
-              if (q == 1)      { PLAIN_LOOP(s_stok[1]) }
-              else if (q == 2) { PLAIN_LOOP(s_stok[2]) }
+#define PAIR_LOOP(STAB, PTAB, LO)                                                               \
+              { const uint32_t lo4 = (LO) * 0x01010101u;                                         \
+                for (uint32_t base = 0; base < L; base += DX_STEP)                               \
+                  { const u32x4 d = fetch(p, pos + DX_STEP, L, over);                            \
+                    const bool full = L - base >= DX_STEP;                                       \
+                    if (!full || !encode_plain_step_pair(o, c, PTAB, lo4, m4))                   \
+                      encode_plain_step(o, c, valid_of(pos, L), full, tab, STAB, m4);            \
+                    c = d;                                                                       \
+                    pos += DX_STEP;                                                              \
+                  }                                                                              \
+              }
+              if (q == 1)
+                { if (pair_lo_ins != PAIR_NONE) PAIR_LOOP(s_stok[1], s_pair[0], pair_lo_ins)
+                  else                          { PLAIN_LOOP(s_stok[1]) }
+                }
+              else if (q == 2)
+                { if (pair_lo_mrg != PAIR_NONE) PAIR_LOOP(s_stok[2], s_pair[1], pair_lo_mrg)
+                  else                          { PLAIN_LOOP(s_stok[2]) }
+                }
               else             { PLAIN_LOOP(s_stok[q]) }
+#undef PAIR_LOOP
 #undef PLAIN_LOOP
               got = finish_words(o, last_piece_plain(tab, p, L, mask));
               if (q == 0)                                // no delChar: the whole tag line is packed

@@ -429,6 +429,18 @@ def test_undexqv_older_layout(ctx):
     assert ctx.undexqv(leg, upper=False) == O.golden("qv_tiny.legacy.rt_lower.quiva")
 
 
+@pytest.mark.parametrize("name", ["qv_full", "qv_lossy", "qv_type2", "qv_mid"])
+def test_dexqv_golden_without_pair_tables(ctx, name, monkeypatch):
+    """k_qv_encode_fast codes the insertion and merge lines two symbols per look-up when their coded byte
+    values span at most 64 (the usual case, all goldens); DEXGPU_NO_PAIRS keeps the one-symbol step: same bytes.
+    qv_type2's insertion scheme has 8-bit escapes: pairs beyond 24 bits fall back step by step."""
+    case = [c for c in O.cases("quiva") if c["name"] == name][0]
+    txt, dx = O.golden(case["input"] + ".quiva"), O.golden(name + ".dexqv")
+    assert ctx.dexqv(txt, "-l" in case["flags"]) == dx
+    monkeypatch.setenv("DEXGPU_NO_PAIRS", "1")
+    assert ctx.dexqv(txt, "-l" in case["flags"]) == dx
+
+
 def test_file_drivers_two_pass_switch_gives_the_same_bytes(ctx, monkeypatch):
     """DEXGPU_TWOPASS selects dx_qv_sizes + dx_qv_encode in the file drivers instead of the one-pass
     encoder: same file."""
