@@ -437,8 +437,8 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
           const bool     full  = sv == DX_STEP;
           const int      valid = valid_of(pos, L);
-          hist_plain_step(c2, valid, full, H.sym[DX_INS], H.slow[DX_INS]);
-          hist_plain_step(c3, valid, full, H.sym[DX_MRG], H.slow[DX_MRG]);
+          // The run-coded lines first: their token stores then have the two plain lines' worth of work to complete
+          // in before the step's end, where the wait for the prefetched chunks also waits for every older store.
           if (drun)
             { if (tags) *(u32x4 *) (tchunk + 16 * lane) = t1;    // (run_collect's barrier orders it before the look-ups)
               hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.sym[DX_DEL], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN],
@@ -448,6 +448,8 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.sym[DX_SUB], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
                                    scnt, tk4, nt4, cap, bad4, (const uint8_t *) NULL, s_tagcode);
           else      hist_plain_step(c4, valid, full, H.sym[DX_SUB], H.slow[DX_SUB]);
+          hist_plain_step(c2, valid, full, H.sym[DX_INS], H.slow[DX_INS]);
+          hist_plain_step(c3, valid, full, H.sym[DX_MRG], H.slow[DX_MRG]);
           c0 = d0; c2 = d2; c3 = d3; c4 = d4; t1 = u1;
           pos = np;
         }
@@ -1741,6 +1743,8 @@ static int fast_grid(dx_ctx *ctx, uint64_t entries)
   return (int) (g ? g : 1);
 }
 
+#define ONEPASS_MAX_GROUPS 64
+
 // side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
 static int onepass_side(dx_ctx *ctx, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
                         uint64_t *d_rec_off, const uint64_t *base_in, uint64_t *base_out, const uint32_t *d_len,
@@ -1776,20 +1780,36 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       if (total) *total = 0;
       return DX_OK;
     }
-  // Groups of entries: the encoder (issue-bound) works through them on the context's stream while the
-  // compaction of the group before (pure HBM traffic) runs beside it on the side stream.  Small groups
-  // lose more in kernel tails than the overlap gains: at least ~120 k entries each, at most 8 groups.
-  int G = (int) (n / 120000);
-  if (G > 8) G = 8;
-  if (G < 1) G = 1;
-  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments)
-    { G = atoi(getenv("DEXGPU_ONEPASS_GROUPS")); if (G < 1) G = 1; if (G > 8) G = 8; }
-  const uint64_t gs = (n + G - 1) / G;
-
+  // Groups of entries: the encoder works through them on the context's stream while the compaction of the
+  // group before runs beside it on the side stream.  Every group boundary costs kernel tails and launch gaps,
+  // and the last group's compaction runs exposed: so a few large groups (a quarter of the batch, at most
+  // 250 k entries: the two scratch regions are sized for the largest) and then halving ones at the end.
+  uint64_t gb[ONEPASS_MAX_GROUPS + 1];
+  int      G = 0;
+  gb[0] = 0;
+  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests: that many equal groups)
+    { int k = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
+      if (k < 1) k = 1;
+      if (k > ONEPASS_MAX_GROUPS) k = ONEPASS_MAX_GROUPS;
+      const uint64_t gs = (n + (uint64_t) k - 1) / (uint64_t) k;
+      for (uint64_t at = 0; at < n; at += gs)
+        gb[++G] = at + gs < n ? at + gs : n;
+    }
+  else if (n < 240000)
+    gb[++G] = n;
+  else
+    { uint64_t big = n / 4, at = 0;
+      if (big > 250000) big = 250000;
+      while (n - at > big && G < ONEPASS_MAX_GROUPS - 6)
+        { at += big; gb[++G] = at; }
+      while (n - at > 40000 && G < ONEPASS_MAX_GROUPS - 1)  // the tail: halves
+        { at += (n - at) / 2; gb[++G] = at; }
+      gb[++G] = n;
+    }
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
   const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255);
-  uint64_t       region = 0, gstart[9] = { 0 };          // slot offset at which each group starts; largest group's extent
+  uint64_t       region = 0, gstart[ONEPASS_MAX_GROUPS + 1] = { 0 };   // slot offset at which each group starts; largest group's extent
   uint8_t       *scr    = NULL;
   uint32_t      *d_bound = NULL, *d_size = NULL;
   uint64_t      *d_slot = NULL, *d_tile = NULL, *d_gran = NULL;
@@ -1812,9 +1832,7 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, (const uint32_t *) d_bound, n,
                 (const uint64_t *) d_tile, d_slot, (const uint64_t *) d_gran);
       for (int g = 0; g <= G; g++)
-        { const uint64_t at = (uint64_t) g * gs < n ? (uint64_t) g * gs : n;
-          DX_HIP(ctx, hipMemcpyAsync(&gstart[g], d_slot + at, 8, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        DX_HIP(ctx, hipMemcpyAsync(&gstart[g], d_slot + gb[g], 8, hipMemcpyDeviceToHost, ctx->stream));
       DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
       region = 0;
       for (int g = 0; g < G; g++)
@@ -1838,8 +1856,8 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
   DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
   int rc = DX_OK, ng = 0;                                // ng: groups run so far (selects the ping-pong base)
   for (int g = 0; g < G && rc == DX_OK; g++)
-    { const uint64_t g0 = (uint64_t) g * gs, g1 = g0 + gs < n ? g0 + gs : n;
-      if (g0 >= g1) break;
+    { const uint64_t g0 = gb[g], g1 = gb[g + 1];
+      if (g0 >= g1) continue;
       const uint64_t m = g1 - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
       // this group's slots live in region g & 1: slot_off[r] is file-wide, so shift the base
       uint8_t *slots_g = d_slots + (uint64_t) (g & 1) * region - gstart[g];
@@ -1847,7 +1865,7 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
       if (g >= 2)
-        DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[g - 2], 0));    // the region is free once its last tenant has been copied out
+        DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 2) & 7], 0));    // the region is free once its last tenant has been copied out
       const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 };
       if (fast)                                          // entries with usable tokens: walked from the tokens
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
@@ -1866,14 +1884,14 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
                     fast ? (const unsigned long long *) ctx->tk.count : (const unsigned long long *) NULL, g0,
                     fast ? (const uint32_t *) (ctx->tk.info + 4 * g0) : (const uint32_t *) NULL);
         }
-      DX_HIP(ctx, hipEventRecord(enc_done[g], A));
+      DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction
-      DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g], 0));
+      DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g & 7], 0));
       ctx->stream = B;                                   // (the launch macro and its timing events follow ctx->stream)
       rc = onepass_side(ctx, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
                         b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp);
       ctx->stream = A;
-      (void) hipEventRecord(cmp_done[g], B);
+      (void) hipEventRecord(cmp_done[g & 7], B);
       ng += 1;
     }
   uint64_t tot = 0;
