@@ -339,8 +339,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
     value = 5.0 * all_bases * args.steps / dt / 1e9
 
     # ---- roofline of the dominant kernel (per-launch algorithmic bytes / measured launch time) -----
-    # (the histogram pass runs as two kernels side by side: deletion + substitution lines, insertion + merge lines)
-    algo = {"k_qv_hist": 2.0 * bases, "k_qv_hist_plain": 2.0 * bases, "k_qv_sizes": 4.0 * bases,
+    algo = {"k_qv_hist": 4.0 * bases, "k_qv_sizes": 4.0 * bases,
             "k_qv_encode": 5.0 * bases + state["total"]}
     kern = {k: {"ms_avg": ms / cnt, "launches": cnt} for k, (ms, cnt) in times.items()}
     for k, b in algo.items():

@@ -19,7 +19,7 @@ DX_ALPHA_BASES, DX_ALPHA_ARROW = 0, 1
 DX_LETTERS_LOWER, DX_LETTERS_UPPER, DX_LETTERS_ARROW = 0, 1, 2
 DX_DEL, DX_INS, DX_MRG, DX_SUB, DX_DRUN, DX_SRUN = range(6)
 KERNELS = ["k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
-           "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact", "k_qv_hist_plain"]
+           "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact"]
 
 
 class QVBatch(C.Structure):

@@ -238,20 +238,12 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 #define HSYM_FAST    128
 #define HRUN_FAST    64
 
-// The pass runs as two kernels side by side on every CU (two streams): k_qv_hist_plain counts the
-// insertion and merge lines (always plain, QV.c:989-990), k_qv_hist_runs the deletion and substitution
-// lines (run-coded or not) and makes their tokens.  Apart they leave each other room: the run kernel's 16
-// waves per CU are bounded by its 118 KB of LDS, the plain kernel's waves (34 KB, few registers) fill the
-// rest of the CU, and with more waves to choose from the vector unit idles less.
-struct hist_lds_runs
-{ uint32_t sym[2][HSYM_FAST][HCOLS];     // del, sub: 32 KB
+struct hist_lds
+{ uint32_t sym[4][HSYM_FAST][HCOLS];     // 64 KB
   uint32_t run[2][HRUN_FAST][HCOLS];     // 16 KB
-  uint32_t slow[4][256];                 // del, sub, dRun, sRun: 4 KB
+  uint32_t slow[6][256];                 //  6 KB
 };
-struct hist_lds_plain
-{ uint32_t sym[2][HSYM_FAST][HCOLS];     // ins, mrg: 32 KB
-  uint32_t slow[2][256];                 //  2 KB
-};
+#define HIST_FAST_WORDS (4 * HSYM_FAST * HCOLS + 2 * HRUN_FAST * HCOLS)
 
 __device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool full, uint32_t (*h)[HCOLS], uint32_t *slow)
 { const uint32_t col = (uint32_t) lane_id() & (HCOLS - 1);
@@ -317,33 +309,6 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
     { emit = ntok + total <= cap;
       if (!emit) bad = 1;                                        // more tokens than the slot holds
     }
-#ifdef HIST_ONE_TOKEN
-  uint32_t odd = 0;
-  for (uint32_t i = lane; i < total; i += 64)
-    { const uint32_t pos = R.list[i];
-      const uint32_t x   = R.chunk[pos];
-      const uint32_t run = i ? pos - (uint32_t) R.list[i - 1] - 1u : C + pos;
-      if (count && !__any(run >= HRUN_FAST || x >= HSYM_FAST))     // the usual case, decided once for the wave
-        { atomicAdd(&hr[run][col], 1u);
-          atomicAdd(&hs[x][col], 1u);
-        }
-      else
-        { if (count)
-            { if (run < HRUN_FAST) atomicAdd(&hr[run][col], 1u);
-              else                 atomicAdd(&slow_r[run > 255u ? 255u : run], 1u);   // QV.c:717-720
-            }
-          if (x < HSYM_FAST)   atomicAdd(&hs[x][col], 1u);
-          else                 atomicAdd(&slow_s[x], 1u);
-        }
-      if (emit)
-        { uint32_t t = (x << 2) | ((run < TOK_RUN_MAX ? run : TOK_RUN_MAX) << 9);
-          if (tagchunk != NULL)
-            t |= tagcode[tagchunk[pos]];
-          tok[ntok + i] = (uint16_t) t;
-          odd |= (x >= 128u || run >= TOK_RUN_MAX) ? 1u : 0u;
-        }
-    }
-#else
   uint32_t odd = 0;
   // Two tokens per lane per round (i and i + 64): the look-ups of a token hang on each other (position ->
   // symbol and tag -> tag code), so the second token's chain runs in the shadow of the first one's.
@@ -388,16 +353,11 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
               }
             if (emit)
               { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9);
-#ifndef ABL_NOSTORE
                 tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;
-#else
-                asm volatile("" :: "v"(t));
-#endif
                 odd |= (x[k] >= 128u || run[k] >= TOK_RUN_MAX) ? 1u : 0u;
               }
           }
     }
-#endif
   if (emit)
     { ntok += total;
       if (__any((int) odd)) bad = 1;
@@ -406,94 +366,20 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
   wave_sync();
 }
 
-// bin of g_hist[6*256] that LDS word k of the run kernel's tables counts (fast tables, then the slow ones)
-__device__ __forceinline__ uint32_t runs_bin_of(uint32_t k)
-{ if (k < 2 * HSYM_FAST * HCOLS)
-    return (k / (HSYM_FAST * HCOLS) ? DX_SUB : DX_DEL) * 256u + (k / HCOLS) % HSYM_FAST;
-  k -= 2 * HSYM_FAST * HCOLS;
+// bin of the histogram g_hist[6*256] that LDS word k (of the fast tables, then the slow ones) counts
+__device__ __forceinline__ uint32_t hist_bin_of(uint32_t k)
+{ if (k < 4 * HSYM_FAST * HCOLS)
+    return (k / (HSYM_FAST * HCOLS)) * 256u + (k / HCOLS) % HSYM_FAST;
+  k -= 4 * HSYM_FAST * HCOLS;
   if (k < 2 * HRUN_FAST * HCOLS)
     return (4u + k / (HRUN_FAST * HCOLS)) * 256u + (k / HCOLS) % HRUN_FAST;
-  k -= 2 * HRUN_FAST * HCOLS;                            // slow: del, sub, dRun, sRun
-  const uint32_t t = k >> 8;
-  return (t == 0 ? DX_DEL : (t == 1 ? DX_SUB : (t == 2 ? DX_DRUN : DX_SRUN))) * 256u + (k & 255u);
+  return k - 2 * HRUN_FAST * HCOLS;
 }
 
-// ... and of the plain kernel's
-__device__ __forceinline__ uint32_t plain_bin_of(uint32_t k)
-{ if (k < 2 * HSYM_FAST * HCOLS)
-    return (k / (HSYM_FAST * HCOLS) ? DX_MRG : DX_INS) * 256u + (k / HCOLS) % HSYM_FAST;
-  k -= 2 * HSYM_FAST * HCOLS;
-  return ((k >> 8) ? DX_MRG : DX_INS) * 256u + (k & 255u);
-}
-
-// all LDS bins of a workgroup into the global histogram: the 32 copies of a fast bin are summed first
-// (rotated start: the lanes of a wave read distinct banks)
-template <typename BIN_OF>
-__device__ __forceinline__ void hist_fold(uint32_t *words, uint32_t fast_words, uint32_t nwords, unsigned long long *g_hist, BIN_OF bin_of)
-{ const uint32_t tid = threadIdx.x, lane = (uint32_t) lane_id();
-  for (uint32_t bin = tid; bin < fast_words / HCOLS; bin += blockDim.x)
-    { uint32_t v = 0;
-      for (uint32_t j = 0; j < HCOLS; j++)
-        v += words[bin * HCOLS + ((j + lane) & (HCOLS - 1))];
-      if (v) atomicAdd(&g_hist[bin_of(bin * HCOLS)], (unsigned long long) v);
-    }
-  for (uint32_t k = fast_words + tid; k < nwords; k += blockDim.x)
-    { const uint32_t v = words[k];
-      if (v) atomicAdd(&g_hist[bin_of(k)], (unsigned long long) v);
-    }
-}
-
-// insertion and merge lines (Histogram_Seqs, QV.c:702-707, 989-990); also counts the symbols (totChar)
 __global__ __launch_bounds__(HIST_BLOCK)
-void k_qv_hist_plain(qv_args a, unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket)
-{ __shared__ hist_lds_plain H;
-  const int lane = lane_id(), tid = threadIdx.x;
-  uint32_t *const words  = &H.sym[0][0][0];
-  const uint32_t  nwords = sizeof(hist_lds_plain) / 4, fast = 2 * HSYM_FAST * HCOLS;
-  for (uint32_t k = tid; k < nwords; k += HIST_BLOCK) words[k] = 0;
-  __syncthreads();
-
-  uint64_t tot = 0, since = 0;
-  for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
-  { nxt = next_unit(ticket, TICKET_BATCH);
-    for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
-    { const uint32_t L  = a.len[r];
-      const uint8_t *p2 = line_ptr(a, r, L, 2), *p3 = line_ptr(a, r, L, 3);
-      const bool over = can_overread(a, p3, L);
-      uint32_t pos = 16u * lane;
-      u32x4 c2 = fetch(p2, pos, L, over), c3 = fetch(p3, pos, L, over);
-      for (uint32_t base = 0; base < L; base += DX_STEP)
-        { const uint32_t np = pos + DX_STEP;
-          const u32x4 d2 = fetch(p2, np, L, over), d3 = fetch(p3, np, L, over);
-          const bool full  = L - base >= DX_STEP;
-          const int  valid = valid_of(pos, L);
-          hist_plain_step(c2, valid, full, H.sym[0], H.slow[0]);
-          hist_plain_step(c3, valid, full, H.sym[1], H.slow[1]);
-          c2 = d2; c3 = d3;
-          pos = np;
-        }
-      tot   += L;
-      since += L;
-      if (since >= (1ull << 26))                       // keep the 32-bit LDS bins far from overflow
-        { for (uint32_t k = lane; k < nwords; k += 64)
-            { const uint32_t v = atomicExch(&words[k], 0u);
-              if (v) atomicAdd(&g_hist[plain_bin_of(k)], (unsigned long long) v);
-            }
-          since = 0;
-        }
-    }
-  }
-  if (lane == 0 && tot)
-    atomicAdd(g_tot, (unsigned long long) tot);
-  __syncthreads();
-  hist_fold(words, fast, nwords, g_hist, plain_bin_of);
-}
-
-// deletion and substitution lines: Histogram_Seqs + Histogram_Runs (QV.c:702-724, 988-1017) and the token hand-over
-__global__ __launch_bounds__(HIST_BLOCK)
-void k_qv_hist_runs(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
-                    unsigned long long *g_hist /* 6*256 */, uint32_t *ticket, tok_sink ts)
-{ __shared__ hist_lds_runs H;
+void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
+               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts)
+{ __shared__ hist_lds H;
   __shared__ __attribute__((aligned(16))) uint8_t s_chunk[HIST_NWAVE][DX_STEP];
   __shared__ __attribute__((aligned(16))) uint8_t s_tchunk[HIST_NWAVE][DX_STEP];
   __shared__ uint16_t s_list[HIST_NWAVE][DX_STEP];
@@ -503,10 +389,8 @@ void k_qv_hist_runs(qv_args a, uint64_t entry0, long long del_first, long long s
   const run_lds  R     = { s_chunk[tid >> 6], s_list[tid >> 6] };
   uint8_t *const tchunk = s_tchunk[tid >> 6];
   uint32_t *const words = &H.sym[0][0][0];                      // the whole of H as words
-  const uint32_t  nwords = sizeof(hist_lds_runs) / 4, fast = 2 * HSYM_FAST * HCOLS + 2 * HRUN_FAST * HCOLS;
+  const uint32_t  nwords = sizeof(hist_lds) / 4;
   const bool      toks  = ts.del != NULL;
-  uint32_t (*const hdel)[HCOLS] = H.sym[0], (*const hsub)[HCOLS] = H.sym[1];
-  uint32_t *const sdel = H.slow[0], *const ssub = H.slow[1], *const sdrun = H.slow[2], *const ssrun = H.slow[3];
 
   for (uint32_t k = tid; k < nwords; k += HIST_BLOCK) words[k] = 0;
   if (tid < 256)
@@ -515,7 +399,7 @@ void k_qv_hist_runs(qv_args a, uint64_t entry0, long long del_first, long long s
     }
   __syncthreads();
 
-  uint64_t since = 0;
+  uint64_t tot = 0, since = 0;
   for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
   { nxt = next_unit(ticket, TICKET_BATCH);             // drawn early: the atomic's latency hides behind these entries
     for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
@@ -524,7 +408,9 @@ void k_qv_hist_runs(qv_args a, uint64_t entry0, long long del_first, long long s
       const bool drun = a.delChar >= 0 && (toks || g >= del_first);      // tokenised (and, from del_first on, run-histogrammed)
       const bool srun = a.subChar >= 0 && (toks || g >= sub_first);
       const bool dcnt = a.delChar >= 0 && g >= del_first, scnt = a.subChar >= 0 && g >= sub_first;
-      const uint8_t *p0 = line_ptr(a, r, L, 0), *p1 = line_ptr(a, r, L, 1), *p4 = line_ptr(a, r, L, 4);
+      const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2);
+      const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
+      const uint8_t *p1 = line_ptr(a, r, L, 1);
       const bool over = can_overread(a, p4, L);       // p4 is the last line of the entry
       uint32_t C0 = 0, C4 = 0, n0 = 0, n4 = 0;
       uint16_t *tk0 = NULL, *tk4 = NULL;
@@ -538,36 +424,42 @@ void k_qv_hist_runs(qv_args a, uint64_t entry0, long long del_first, long long s
       const bool tags = tk0 != NULL;
 
       uint32_t pos = 16u * lane;
-      u32x4 c0 = fetch(p0, pos, L, over), c4 = fetch(p4, pos, L, over);
+      u32x4 c0 = fetch(p0, pos, L, over), c2 = fetch(p2, pos, L, over);
+      u32x4 c3 = fetch(p3, pos, L, over), c4 = fetch(p4, pos, L, over);
       u32x4 t1 = c0;
       if (tags) t1 = fetch(p1, pos, L, over);          // the deletion tags travel with the step's other chunks
       for (uint32_t base = 0; base < L; base += DX_STEP)
         { const uint32_t np = pos + DX_STEP;           // next step's chunks go in flight first
-          const u32x4 d0 = fetch(p0, np, L, over), d4 = fetch(p4, np, L, over);
+          const u32x4 d0 = fetch(p0, np, L, over), d2 = fetch(p2, np, L, over);
+          const u32x4 d3 = fetch(p3, np, L, over), d4 = fetch(p4, np, L, over);
           u32x4 u1 = d0;
           if (tags) u1 = fetch(p1, np, L, over);
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
           const bool     full  = sv == DX_STEP;
           const int      valid = valid_of(pos, L);
+          // The run-coded lines first: their token stores then have the two plain lines' worth of work to complete
+          // in before the step's end, where the wait for the prefetched chunks also waits for every older store.
           if (drun)
             { if (tags) *(u32x4 *) (tchunk + 16 * lane) = t1;    // (run_collect's barrier orders it before the look-ups)
-              hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, hdel, sdel, H.run[0], sdrun,
+              hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.sym[DX_DEL], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN],
                              dcnt, tk0, nt0, cap, bad0, tags ? tchunk : (const uint8_t *) NULL, s_tagcode);
             }
-          else      hist_plain_step(c0, valid, full, hdel, sdel);
-          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, hsub, ssub, H.run[1], ssrun,
+          else      hist_plain_step(c0, valid, full, H.sym[DX_DEL], H.slow[DX_DEL]);
+          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.sym[DX_SUB], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
                                    scnt, tk4, nt4, cap, bad4, (const uint8_t *) NULL, s_tagcode);
-          else      hist_plain_step(c4, valid, full, hsub, ssub);
-          c0 = d0; c4 = d4; t1 = u1;
+          else      hist_plain_step(c4, valid, full, H.sym[DX_SUB], H.slow[DX_SUB]);
+          hist_plain_step(c2, valid, full, H.sym[DX_INS], H.slow[DX_INS]);
+          hist_plain_step(c3, valid, full, H.sym[DX_MRG], H.slow[DX_MRG]);
+          c0 = d0; c2 = d2; c3 = d3; c4 = d4; t1 = u1;
           pos = np;
         }
       if (drun)                                        // trailing run + the run character's own count
-        { if (dcnt && C0 > 0 && lane == 0) atomicAdd(&sdrun[C0 > 255u ? 255u : C0], 1u);
-          if (lane == 0 && n0) atomicAdd(&sdel[a.delChar], n0);
+        { if (dcnt && C0 > 0 && lane == 0) atomicAdd(&H.slow[DX_DRUN][C0 > 255u ? 255u : C0], 1u);
+          if (lane == 0 && n0) atomicAdd(&H.slow[DX_DEL][a.delChar], n0);
         }
       if (srun)
-        { if (scnt && C4 > 0 && lane == 0) atomicAdd(&ssrun[C4 > 255u ? 255u : C4], 1u);
-          if (lane == 0 && n4) atomicAdd(&ssub[a.subChar], n4);
+        { if (scnt && C4 > 0 && lane == 0) atomicAdd(&H.slow[DX_SRUN][C4 > 255u ? 255u : C4], 1u);
+          if (lane == 0 && n4) atomicAdd(&H.slow[DX_SUB][a.subChar], n4);
         }
       if (toks)
         { if (lane == 0)
@@ -580,18 +472,31 @@ void k_qv_hist_runs(qv_args a, uint64_t entry0, long long del_first, long long s
           if (((drun && bad0) || (srun && bad4)) && lane == 0)      // rare: the generic kernel works through this list
             ts.list[atomicAdd(ts.unusable, 1ull)] = (uint32_t) r;
         }
+      tot   += L;
       since += L;
       if (since >= (1ull << 26))                       // keep the 32-bit LDS bins far from overflow
         { for (uint32_t k = lane; k < nwords; k += 64)
             { const uint32_t v = atomicExch(&words[k], 0u);
-              if (v) atomicAdd(&g_hist[runs_bin_of(k)], (unsigned long long) v);
+              if (v) atomicAdd(&g_hist[hist_bin_of(k)], (unsigned long long) v);
             }
           since = 0;
         }
     }
   }
+  if (lane == 0 && tot)
+    atomicAdd(g_tot, (unsigned long long) tot);
   __syncthreads();
-  hist_fold(words, fast, nwords, g_hist, runs_bin_of);
+  // fold the 32 copies of every fast bin (rotated start: the lanes of a wave read distinct banks)
+  for (uint32_t bin = tid; bin < HIST_FAST_WORDS / HCOLS; bin += HIST_BLOCK)
+    { uint32_t v = 0;
+      for (uint32_t j = 0; j < HCOLS; j++)
+        v += words[bin * HCOLS + ((j + (uint32_t) lane) & (HCOLS - 1))];
+      if (v) atomicAdd(&g_hist[hist_bin_of(bin * HCOLS)], (unsigned long long) v);
+    }
+  for (uint32_t k = tid; k < 6 * 256; k += HIST_BLOCK)
+    { const uint32_t v = (&H.slow[0][0])[k];
+      if (v) atomicAdd(&g_hist[k], (unsigned long long) v);
+    }
 }
 
 // slot sizes of the token hand-over (tokens per entry)
@@ -1617,22 +1522,11 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   tok_sink ts = { NULL, NULL, NULL, NULL, d_hist + 6 * 256 + 1, NULL };
   if (tokens_prepare(ctx, b, p, scr, hbytes))
     { ts.del = ctx->tk.del; ts.sub = ctx->tk.sub; ts.off = ctx->tk.off; ts.info = ctx->tk.info; ts.list = ctx->tk.list; }
-  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17), *d_ticket2 = (uint32_t *) (ctx->d_u64 + 30);
+  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
-  DX_HIP(ctx, hipMemsetAsync(d_ticket2, 0, 4, ctx->stream));
-  const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE;       // one 16-wave workgroup of each kernel per CU
-  const int      hgrid = (int) (hist_blocks < (uint64_t) ctx->num_cu ? hist_blocks : (uint64_t) ctx->num_cu);
-  // the plain kernel on the side stream, beside the run kernel on the context's stream
-  hipStream_t A = ctx->stream, B = ctx->side;
-  DX_HIP(ctx, hipEventRecord(ctx->ev[16], A));
-  DX_HIP(ctx, hipStreamWaitEvent(B, ctx->ev[16], 0));
-  ctx->stream = B;
-  DX_LAUNCH(ctx, DX_K_QV_HIST_PLAIN, k_qv_hist_plain, hgrid, HIST_BLOCK, a, d_hist, d_hist + 6 * 256, d_ticket2);
-  ctx->stream = A;
-  DX_HIP(ctx, hipEventRecord(ctx->ev[15], B));
-  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist_runs, hgrid, HIST_BLOCK,
-            a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_ticket, ts);
-  DX_HIP(ctx, hipStreamWaitEvent(A, ctx->ev[15], 0));
+  const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE;       // one 16-wave workgroup per CU
+  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, (int) (hist_blocks < (uint64_t) ctx->num_cu ? hist_blocks : (uint64_t) ctx->num_cu), HIST_BLOCK,
+            a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts);
   uint64_t host[6 * 256 + 2];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -61,7 +61,7 @@ int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes);
 /* Per-kernel device time, measured with HIP events on the context's stream around every launch
  * while profiling is enabled.  Kernel ids: */
 enum { DX_K_PACK2_ENC = 0, DX_K_PACK2_DEC, DX_K_QV_PRESCAN, DX_K_QV_HIST, DX_K_QV_SIZES, DX_K_SCAN,
-       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_INDEX, DX_K_QV_COMPACT, DX_K_QV_HIST_PLAIN, DX_K_COUNT };
+       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_INDEX, DX_K_QV_COMPACT, DX_K_COUNT };
 int         dx_profile(dx_ctx *ctx, int enable);                  /* enabling resets the counters */
 int         dx_profile_get(dx_ctx *ctx, int kernel, double *ms_total, uint64_t *launches);  /* syncs */
 const char *dx_kernel_name(int kernel);
