@@ -1744,6 +1744,7 @@ static int fast_grid(dx_ctx *ctx, uint64_t entries)
 }
 
 #define ONEPASS_MAX_GROUPS 64
+#define ONEPASS_REGION_CAP ((uint64_t) 32 << 30)          // bytes of one of the two scratch regions of dx_qv_encode_onepass
 
 // side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
 static int onepass_side(dx_ctx *ctx, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
@@ -1781,31 +1782,36 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       return DX_OK;
     }
   // Groups of entries: the encoder works through them on the context's stream while the compaction of the
-  // group before runs beside it on the side stream.  Every group boundary costs kernel tails and launch gaps,
-  // and the last group's compaction runs exposed: so a few large groups (a quarter of the batch, at most
-  // 250 k entries: the two scratch regions are sized for the largest) and then halving ones at the end.
+  // group before runs beside it on the side stream.  Both stages move memory at close to the rate the
+  // two can share, so what counts is the number of group boundaries (kernel tails, launch gaps, the wait
+  // for a scratch region to be free): as few groups as the scratch budget allows (two regions of at most
+  // ONEPASS_REGION_CAP bytes, sized from the table-derived slot bounds), two from 240 k entries on so that
+  // half of the compaction is hidden.  (Measured, 1 M x 10 kb: 2 groups 31.1 ms per step, 4: 31.3, 8: 32.9,
+  // 16: 35.0, 64: 46.7.)
   uint64_t gb[ONEPASS_MAX_GROUPS + 1];
-  int      G = 0;
-  gb[0] = 0;
-  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests: that many equal groups)
-    { int k = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
-      if (k < 1) k = 1;
-      if (k > ONEPASS_MAX_GROUPS) k = ONEPASS_MAX_GROUPS;
-      const uint64_t gs = (n + (uint64_t) k - 1) / (uint64_t) k;
-      for (uint64_t at = 0; at < n; at += gs)
-        gb[++G] = at + gs < n ? at + gs : n;
+  int      G = 1;
+  { uint64_t per_entry = 0;                              // mean slot bound, from the bits-per-symbol bounds of the tables
+    const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
+    const uint64_t syms = b->text_bytes ? b->text_bytes / 5 : 0;       // (a file image: five lines per entry)
+    per_entry = syms ? (syms / n) * bits / 8 + syms / n / 4 + 128 : 0;
+    if (n >= 240000) G = 2;
+    if (per_entry)
+      while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
+    else if (n >= 240000)
+      G = (int) (n / 250000) > 2 ? (int) (n / 250000) : 2;
+    if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
+  }
+  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests)
+    { G = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
+      if (G < 1) G = 1;
+      if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
     }
-  else if (n < 240000)
-    gb[++G] = n;
-  else
-    { uint64_t big = n / 4, at = 0;
-      if (big > 250000) big = 250000;
-      while (n - at > big && G < ONEPASS_MAX_GROUPS - 6)
-        { at += big; gb[++G] = at; }
-      while (n - at > 40000 && G < ONEPASS_MAX_GROUPS - 1)  // the tail: halves
-        { at += (n - at) / 2; gb[++G] = at; }
-      gb[++G] = n;
-    }
+  { const uint64_t gs = (n + (uint64_t) G - 1) / (uint64_t) G;
+    G = 0;
+    gb[0] = 0;
+    for (uint64_t at = 0; at < n; at += gs)
+      gb[++G] = at + gs < n ? at + gs : n;
+  }
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
   const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255);
