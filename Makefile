@@ -14,7 +14,7 @@ CFLAGS   = -O2 -fPIC -Iinclude -Wall -Wextra
 
 HIP_SRC  = dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth dx_index
 HIP_OBJ  = $(HIP_SRC:%=$(BUILD)/%.o)
-C_OBJ    = $(BUILD)/dx_host.o $(BUILD)/dx_files.o
+C_OBJ    = $(BUILD)/dx_host.o $(BUILD)/dx_files.o $(BUILD)/dx_compat.o
 TOOLS    = dexta undexta dexar undexar dexqv undexqv
 
 all: lib cli
@@ -25,7 +25,7 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/dx_internal.hpp $(CSRC)/dx_device.hpp includ
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(BUILD)/%.o: $(CSRC)/%.c include/dexgpu.h
+$(BUILD)/%.o: $(CSRC)/%.c include/dexgpu.h include/dexcompat.h
 	@mkdir -p $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 

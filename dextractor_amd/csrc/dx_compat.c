@@ -1,0 +1,123 @@
+/*
+ * dx_compat.c -- QVcoding_Scan1 / Create_QVcoding / Write_QVcoding / Compress_Next_QVentry1 /
+ * Free_QVcoding (QV.h:61-87) for a dex2DB-style caller, over the batch API of libdexgpu.
+ * See include/dexcompat.h.  Static state, as in QV.c (which keeps its histograms and the coding
+ * in file-scope variables: QV.c:860-862, 1030).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "dexgpu.h"
+#include "dexcompat.h"
+
+static dx_ctx       *Ctx     = NULL;
+static dx_entries   *Batch   = NULL;      /* entries gathered by QVcoding_Scan1 */
+static uint32_t     *Lens    = NULL;      /* their lengths: the second pass is checked against them */
+static uint64_t      Nent = 0, LensCap = 0;
+static dx_qv_coding  Tables;              /* what Create_QVcoding built */
+static uint8_t      *Records = NULL;      /* every entry already compressed (Create_QVcoding) */
+static uint64_t     *Coff    = NULL;      /* n + 1 offsets into Records */
+static uint64_t      Next    = 0;         /* entry the next Compress_Next_QVentry1 call writes */
+static QVcoding      Coding;              /* the object handed to the caller (QV.c:1030: static there too) */
+
+static void die(const char *msg)
+{ fprintf(stderr, "libdexgpu: %s\n", msg);          /* batch error convention, DB.h:45-47 */
+  exit(1);
+}
+
+static void drop_results(void)
+{ dx_file_free(Records); dx_file_free(Coff);
+  Records = NULL; Coff = NULL; Next = 0;
+}
+
+void QVcoding_Scan1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub)
+{ if (rlen == 0)                                    /* reset: QV.c:871-886 */
+    { dx_entries_free(Batch);
+      Batch = dx_entries_new();
+      if (Batch == NULL) die("Out of memory (QVcoding_Scan1)");
+      Nent = 0;
+      drop_results();
+      return;
+    }
+  if (Batch == NULL)
+    { Batch = dx_entries_new();
+      if (Batch == NULL) die("Out of memory (QVcoding_Scan1)");
+    }
+  if (dx_entries_add(Batch, rlen, del, tag, ins, mrg, sub) != DX_OK)
+    die("Out of memory (QVcoding_Scan1)");
+  if (Nent == LensCap)
+    { uint64_t  nc = LensCap ? 2 * LensCap : 1024;
+      uint32_t *t  = realloc(Lens, nc * sizeof(*t));
+      if (t == NULL) die("Out of memory (QVcoding_Scan1)");
+      Lens = t; LensCap = nc;
+    }
+  Lens[Nent++] = (uint32_t) rlen;
+}
+
+QVcoding *Create_QVcoding(int lossy)
+{ size_t nbytes = 0;
+  int    rc;
+  if (Batch == NULL || Nent == 0)
+    die("Create_QVcoding: no entries were scanned");
+  if (Ctx == NULL)
+    { const char *d = getenv("DEXGPU_DEVICE");
+      if (dx_open(d ? atoi(d) : 0, &Ctx) != DX_OK)
+        { fprintf(stderr, "libdexgpu: cannot open a GPU (%s)\n", dx_last_error(NULL));
+          exit(1);
+        }
+    }
+  drop_results();
+  rc = dx_entries_compress(Ctx, Batch, lossy, &Tables, &Records, &nbytes, &Coff);
+  if (rc != DX_OK)
+    { fprintf(stderr, "libdexgpu: Create_QVcoding: %s\n", dx_last_error(Ctx));
+      exit(1);
+    }
+  dx_entries_free(Batch);                           /* the streams are no longer needed: the records exist */
+  Batch = NULL;
+  memset(&Coding, 0, sizeof(Coding));
+  Coding.delScheme = &Tables;                       /* opaque to the caller, as in the reference */
+  Coding.delChar   = Tables.delChar;
+  Coding.subChar   = Tables.subChar;
+  Coding.flip      = 0;
+  Coding.prefix    = NULL;                          /* set by the caller before Write_QVcoding (dex2DB.c:561-565) */
+  return &Coding;
+}
+
+void Write_QVcoding(FILE *output, QVcoding *coding)
+{ size_t   need = 0, plen;
+  uint8_t *buf;
+  if (coding == NULL || coding->delScheme != (void *) &Tables)
+    die("Write_QVcoding: not the coding Create_QVcoding returned");
+  plen = coding->prefix ? strlen(coding->prefix) : 0;
+  dx_qv_write_coding(&Tables, coding->prefix, plen, NULL, 0, &need);
+  buf = malloc(need + 1);
+  if (buf == NULL) die("Out of memory (Write_QVcoding)");
+  if (dx_qv_write_coding(&Tables, coding->prefix, plen, buf, need, &need) != DX_OK ||
+      fwrite(buf, 1, need, output) != need)
+    die("Write_QVcoding: write failed");
+  free(buf);
+}
+
+void Compress_Next_QVentry1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub,
+                            FILE *output, QVcoding *coding, int lossy)
+{ size_t k;
+  (void) del; (void) tag; (void) ins; (void) mrg; (void) sub; (void) lossy;
+  if (coding == NULL || coding->delScheme != (void *) &Tables || Records == NULL)
+    die("Compress_Next_QVentry1: call Create_QVcoding first");
+  if (Next >= Nent || (uint32_t) rlen != Lens[Next])
+    die("Compress_Next_QVentry1: the entries must come in the order they were scanned in");
+  k = (size_t) (Coff[Next + 1] - Coff[Next]);
+  if (k && fwrite(Records + Coff[Next], 1, k, output) != k)
+    die("Compress_Next_QVentry1: write failed");
+  Next += 1;
+}
+
+void Free_QVcoding(QVcoding *coding)                /* QV.c:1324-1334: the auxiliary storage, not the object */
+{ if (coding != NULL)
+    { free(coding->prefix);
+      coding->prefix = NULL;
+    }
+  drop_results();
+  free(Lens); Lens = NULL; LensCap = 0; Nent = 0;
+}

@@ -1,0 +1,47 @@
+/*
+ * dexcompat.h -- the reference's per-entry QV entry points under their own names, over libdexgpu.
+ *
+ * dex2DB.c:511-643, 732-839 builds a .qvs track by calling, per read,
+ *     QVcoding_Scan1 (QV.h:61)  ->  Create_QVcoding (QV.h:68)  ->  Write_QVcoding (QV.h:75)  ->
+ *     Compress_Next_QVentry1 (QV.h:87) per read again  ->  Free_QVcoding (QV.h:79).
+ * A GPU cannot be fed one entry at a time, so these shims gather: QVcoding_Scan1 copies the entry into a
+ * batch (dx_entries_add), Create_QVcoding scans AND compresses the whole batch on the GPU
+ * (dx_entries_compress: dx_qv_prescan / dx_qv_hist / dx_qv_build / dx_qv_encode_onepass), and
+ * Compress_Next_QVentry1 writes the already finished bytes of the next entry.  The caller contract is the
+ * reference's own use (dex2DB.c): the second pass presents the entries of the first, in the same order.
+ * Same static-state model as QV.c (one scan at a time per process); errors follow the reference's batch
+ * convention (message on stderr, exit(1); DB.h:45-47).  The GPU is device DEXGPU_DEVICE (default 0).
+ */
+#ifndef DEXCOMPAT_H
+#define DEXCOMPAT_H
+
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct                 /* QV.h:31-42, field for field (the scheme pointers are opaque there too) */
+  { void    *delScheme;
+    void    *insScheme;
+    void    *mrgScheme;
+    void    *subScheme;
+    void    *dRunScheme;
+    void    *sRunScheme;
+    int      delChar;
+    int      subChar;
+    int      flip;
+    char    *prefix;
+  } QVcoding;
+
+void      QVcoding_Scan1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub);   /* QV.c:866-920; rlen == 0: reset */
+QVcoding *Create_QVcoding(int lossy);                                                        /* QV.c:1029-1169 */
+void      Write_QVcoding(FILE *output, QVcoding *coding);                                    /* QV.c:1173-1210 */
+void      Compress_Next_QVentry1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub,
+                                 FILE *output, QVcoding *coding, int lossy);                 /* QV.c:1343-1379 */
+void      Free_QVcoding(QVcoding *coding);                                                   /* QV.c:1324-1334 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -868,3 +868,119 @@ def test_encode_onepass_equals_two_pass(ctx, case, groups, tokens, monkeypatch):
     with pytest.raises(L.DexGPUError) as e:                      # too small an output buffer is reported, not overrun
         ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg2, d_rec2, d_out2, max(total - 1, 0))
     assert e.value.code == -8
+
+
+def test_record_offsets_beyond_4gib(ctx):
+    """A few thousand huge entries (700 k symbols each, 17.5 GB of text generated on the device): the record
+    stream grows past 4 GiB, so every 64-bit offset path is exercised (slot offsets, record offsets, the
+    compaction, the decoder's addresses).  Checked through size-independent properties: offsets strictly
+    increasing with the segment index adding up, the on-device decode of the first and last entries equal to
+    the text, and the LAST two records (offsets > 4 GiB) decoded by the oracle with the batch's own tables."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.mem_get_info()[0] < 60 * 2**30:
+        pytest.skip("needs ~60 GB of free device memory")
+    n, Ln, seed, movie = 5000, 700_000, 11, "m000_000"
+    hlen = 1 + len(movie) + 1 + 8 + 1 + 7 + 1 + 7 + 6 + 3 + 1
+    lens = np.full(n, Ln, np.uint32)
+    hdr4 = synth.headers(n, seed, lens, 0)
+    rec_bytes = hlen + 5 * (lens.astype(np.uint64) + 1)
+    off = (np.concatenate([[0], np.cumsum(rec_bytes)[:-1]]) + hlen).astype(np.uint64)
+    text_bytes = int(rec_bytes.sum())
+    prof = synth.pacbio_profile()
+
+    class Ptr:
+        def __init__(self, t): self.t, self.ptr = t, t.data_ptr()
+    d_text = torch.empty(text_bytes + 64, dtype=torch.uint8, device="cuda")
+    t_off, t_len = torch.from_numpy(off.view(np.int64)).cuda(), torch.from_numpy(lens.view(np.int32)).cuda()
+    p_text, p_off, p_len = Ptr(d_text), Ptr(t_off), Ptr(t_len)
+    ctx.synth_quiva(seed, 0, n, p_off, p_len, Ptr(torch.from_numpy(hdr4.reshape(-1)).cuda()),
+                    Ptr(torch.from_numpy(prof.table().reshape(-1)).cuda()), prof.del_run, movie, p_text)
+    ctx.sync()
+    b = ctx.qv_batch(p_text, p_off, p_len, n, text_bytes=text_bytes + 64)
+    p = ctx.qv_prescan(b)
+    hist, tot = ctx.qv_hist(b, p)
+    assert tot == n * Ln
+    coding = api.qv_build(hist, tot, p)
+    ctx.qv_set_coding(coding)
+    blob, hoff, _ = api.frame_headers(hdr4)
+    p_hdr, p_hoff = Ptr(torch.from_numpy(blob.copy()).cuda()), Ptr(torch.from_numpy(hoff.view(np.int64)).cuda())
+    p_rec = Ptr(torch.empty(n + 1, dtype=torch.int64, device="cuda"))
+    p_seg = Ptr(torch.empty(5 * n, dtype=torch.int32, device="cuda"))
+    cap = int(hoff[-1]) + api.qv_out_bound(hist, n, coding)
+    p_out = Ptr(torch.empty(cap + 64, dtype=torch.uint8, device="cuda"))
+    total = ctx.qv_encode_onepass(b, p_hdr, p_hoff, p_seg, p_rec, p_out, cap)
+    rec = p_rec.t.cpu().numpy().astype(np.uint64)
+    seg = p_seg.t.cpu().numpy().astype(np.uint64).reshape(n, 5)
+    assert total == int(rec[-1]) > 2**32 and total <= cap
+    assert (np.diff(rec) == seg.sum(axis=1) + np.diff(hoff)).all()         # offsets = running sum of framing + segments
+    # on-device decode of the first and the last 8 entries
+    for a0 in (0, n - 8):
+        lo, hi = int(off[a0]) - hlen, int(off[a0 + 7]) + 5 * (Ln + 1)
+        d_back = torch.zeros(hi - lo + 64, dtype=torch.uint8, device="cuda")
+        o_rel = Ptr(torch.from_numpy((off[a0:a0 + 8] - np.uint64(lo)).view(np.int64)).cuda())
+        ctx.qv_decode(p_out, Ptr(p_rec.t[a0:]), Ptr(p_hoff.t[a0:]), Ptr(p_seg.t[5 * a0:]), Ptr(t_len[a0:]), 8, True, Ptr(d_back), o_rel)
+        ctx.sync()
+        assert int((d_back[: hi - lo] != d_text[lo:hi]).sum()) == 8 * hlen   # only the (unwritten) header bytes differ
+    # the last two records through the oracle
+    body = p_out.t[int(rec[n - 2]): int(rec[n])].cpu().numpy().tobytes()
+    img = b"\xaa\x55" + api.qv_write_coding(coding, ("@" + movie).encode()) + body
+    txt = O.undexqv(img, upper=True)
+    want = d_text[int(off[n - 2]) - hlen: int(off[n - 1]) + 5 * (Ln + 1)].cpu().numpy().tobytes()
+    strip = lambda b_: [ln for ln in b_.split(b"\n") if not ln.startswith(b"@")]
+    assert strip(txt) == strip(want)
+
+
+def test_old_name_shims_like_dex2db(ctx, tmp_path):
+    """include/dexcompat.h: QVcoding_Scan1 / Create_QVcoding / Write_QVcoding / Compress_Next_QVentry1 /
+    Free_QVcoding called the way dex2DB.c:511-643 calls them (reset, one scan call per read, create, write the
+    coding with the caller's prefix, one compress call per read in the same order): the file written equals
+    Write_QVcoding's image + the oracle's per-entry encodes with the tables of the same scan."""
+    lib = L.load()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.malloc.restype = C.c_void_p
+
+    class QVcoding(C.Structure):
+        _fields_ = [(k, C.c_void_p) for k in ("delScheme", "insScheme", "mrgScheme", "subScheme", "dRunScheme", "sRunScheme")] + \
+                   [("delChar", C.c_int), ("subChar", C.c_int), ("flip", C.c_int), ("prefix", C.c_void_p)]
+    lib.Create_QVcoding.restype = C.POINTER(QVcoding)
+    lib.Write_QVcoding.argtypes = [C.c_void_p, C.POINTER(QVcoding)]
+    lib.QVcoding_Scan1.argtypes = [C.c_int] + [C.c_char_p] * 5
+    lib.Compress_Next_QVentry1.argtypes = [C.c_int] + [C.c_char_p] * 5 + [C.c_void_p, C.POINTER(QVcoding), C.c_int]
+    lib.Free_QVcoding.argtypes = [C.POINTER(QVcoding)]
+
+    c = synth.make_quiva(29, seed=31, mean=8000)
+    text = np.frombuffer(c.text, np.uint8)
+    ents = []
+    for i in range(len(c.len)):
+        Ln, o = int(c.len[i]), int(c.off[i])
+        ents.append([text[o + k * (Ln + 1): o + k * (Ln + 1) + Ln].tobytes() for k in range(5)])
+    lib.QVcoding_Scan1(0, None, None, None, None, None)            # dex2DB.c:511
+    for lines in ents:
+        lib.QVcoding_Scan1(len(lines[0]), *lines)                  # dex2DB.c:554
+    coding = lib.Create_QVcoding(0)                                # dex2DB.c:557
+    prefix = b".qvs"
+    buf = libc.malloc(len(prefix) + 1)                             # the caller mallocs the prefix (dex2DB.c:561-565)
+    C.memmove(buf, prefix + b"\0", len(prefix) + 1)
+    coding.contents.prefix = buf
+    path = str(tmp_path / "x.qvs").encode()
+    f = libc.fopen(path, b"wb")
+    lib.Write_QVcoding(f, coding)                                  # dex2DB.c:566
+    for lines in ents:
+        lib.Compress_Next_QVentry1(len(lines[0]), *lines, f, coding, 0)   # dex2DB.c:619
+    libc.fclose(f)
+    dC, sC = coding.contents.delChar, coding.contents.subChar
+    lib.Free_QVcoding(coding)                                      # frees the prefix too
+    got = open(path, "rb").read()
+
+    ref = O.qv_create(O.qv_scan(c.text))
+    assert (dC, sC) == (ref.delChar, ref.subChar)
+    cd = L.QVCoding()
+    C.memmove(C.byref(cd), C.byref(ref), C.sizeof(cd))
+    want = api.qv_write_coding(cd, prefix)
+    for lines in ents:
+        body, _ = O.qv_encode_entry(ref, False, np.stack([np.frombuffer(x, np.uint8) for x in lines]))
+        want += body
+    assert got == want

@@ -24,6 +24,12 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in dexgpu.h but not exported"
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    compat = open(os.path.join(ROOT, "include", "dexcompat.h")).read()
+    compat = re.sub(r"/\*.*?\*/", "", compat, flags=re.S)
+    old_names = set(re.findall(r"\b([A-Z][A-Za-z_]+_QV[a-z]+1?|QVcoding_Scan1)\s*\(", compat))
+    assert old_names == {"QVcoding_Scan1", "Create_QVcoding", "Write_QVcoding", "Compress_Next_QVentry1", "Free_QVcoding"}
+    for name in old_names:
+        assert hasattr(lib, name), f"{name} declared in dexcompat.h but not exported"
 
 
 def _params(st):
