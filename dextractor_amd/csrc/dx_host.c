@@ -749,17 +749,250 @@ void dx_qv_index_free(dx_qv_index *x)
   memset(x, 0, sizeof(*x));
 }
 
+/* everything a walk needs besides the image */
+typedef struct
+  { wlut  *lut[6];
+    mwlut *mlut[4];
+    rwlut *rlut[2];
+    const dx_qv_coding *cd;
+    int    newv, flip;
+  } walk_tabs;
+
+typedef struct { uint32_t hdr_bytes, len, seg[5]; int32_t dwell, beg, end, qv; } walk_rec;
+
+/* One record at img + at (undexqv.c:119-208): the framing fields, then the five segments walked code by
+   code.  Returns the offset behind the record; 0 if there is no well-formed record here.            */
+static size_t walk_record(const walk_tabs *t, const uint8_t *img, size_t n, size_t at, walk_rec *r)
+{ const uint8_t *end = img + n;
+  const size_t   h0  = at;
+  const dx_qv_coding *cd = t->cd;
+  int32_t  beg, end_, qv, dw = 0;
+  uint32_t rlen, clen;
+  int64_t  b;
+
+  while (at < n && img[at] == 255) { dw += 255; at += 1; }
+  if (at >= n) return 0;
+  dw += img[at++];
+  if (t->newv)
+    { if (at + 12 > n) return 0;
+      memcpy(&beg, img + at, 4); memcpy(&end_, img + at + 4, 4); memcpy(&qv, img + at + 8, 4);
+      if (t->flip)                                        /* undexqv.c:140-148 */
+        { beg = (int32_t) flip32((uint32_t) beg); end_ = (int32_t) flip32((uint32_t) end_); qv = (int32_t) flip32((uint32_t) qv); }
+      at += 12;
+    }
+  else
+    { uint16_t h[3];
+      if (at + 6 > n) return 0;
+      memcpy(h, img + at, 6);
+      if (t->flip) { h[0] = flip16(h[0]); h[1] = flip16(h[1]); h[2] = flip16(h[2]); }
+      beg = h[0]; end_ = h[1]; qv = h[2];
+      at += 6;
+    }
+  if (end_ < beg || (int64_t) end_ - (int64_t) beg > 0x7fffffff) return 0;
+  rlen = (uint32_t) ((int64_t) end_ - (int64_t) beg);
+  if ((uint64_t) rlen > 65536u * 8u * (uint64_t) (n - at) + 64u)      /* a token has >= 1 bit and covers <= 65536 symbols */
+    return 0;
+  r->hdr_bytes = (uint32_t) (at - h0);
+  r->len = rlen; r->dwell = dw; r->beg = beg; r->end = end_; r->qv = qv;
+
+  clen = rlen;                                            /* QV.c:1433-1462 */
+  if (cd->delChar < 0)
+    b = walk_plain(img + at, end, rlen, t->lut[DX_DEL], t->mlut[DX_DEL], cd->s[DX_DEL].type == 2, t->flip);
+  else
+    b = walk_runs(img + at, end, rlen, t->lut[DX_DEL], cd->s[DX_DEL].type == 2, t->lut[DX_DRUN], t->rlut[0], &clen, t->flip);
+  if (b < 0) return 0;
+  r->seg[0] = (uint32_t) b; at += (size_t) b;
+  r->seg[1] = (clen + 3) >> 2;
+  if (at + r->seg[1] > n) return 0;
+  at += r->seg[1];
+  b = walk_plain(img + at, end, rlen, t->lut[DX_INS], t->mlut[DX_INS], cd->s[DX_INS].type == 2, t->flip);   /* QV.c:1464 */
+  if (b < 0) return 0;
+  r->seg[2] = (uint32_t) b; at += (size_t) b;
+  b = walk_plain(img + at, end, rlen, t->lut[DX_MRG], t->mlut[DX_MRG], cd->s[DX_MRG].type == 2, t->flip);   /* QV.c:1467 */
+  if (b < 0) return 0;
+  r->seg[3] = (uint32_t) b; at += (size_t) b;
+  if (cd->subChar < 0)                                                          /* QV.c:1470-1478 */
+    b = walk_plain(img + at, end, rlen, t->lut[DX_SUB], t->mlut[DX_SUB], cd->s[DX_SUB].type == 2, t->flip);
+  else
+    { uint32_t nn;
+      b = walk_runs(img + at, end, rlen, t->lut[DX_SUB], cd->s[DX_SUB].type == 2, t->lut[DX_SRUN], t->rlut[1], &nn, t->flip);
+    }
+  if (b < 0) return 0;
+  r->seg[4] = (uint32_t) b; at += (size_t) b;
+  return at;
+}
+
+/* records of img[from, to) appended to a growing list; stops at `to` exactly (returns it), behind it
+   (a record straddles `to`: returns that offset) or 0 on a malformed record / out of memory (*rc says which) */
+typedef struct { walk_rec *r; uint64_t n, cap; } rec_list;
+
+static size_t walk_span(const walk_tabs *t, const uint8_t *img, size_t n, size_t from, size_t to, rec_list *L, int *rc)
+{ size_t at = from;
+  while (at < to)
+    { size_t nx;
+      if (L->n == L->cap)
+        { uint64_t  nc = L->cap ? 2 * L->cap : 1024;
+          walk_rec *q  = realloc(L->r, nc * sizeof(*q));
+          if (q == NULL) { *rc = DX_E_NOMEM; return 0; }
+          L->r = q; L->cap = nc;
+        }
+      nx = walk_record(t, img, n, at, &L->r[L->n]);
+      if (nx == 0) { *rc = DX_E_FORMAT; return 0; }
+      L->n += 1;
+      at = nx;
+    }
+  return at;
+}
+
+/* ---- the walk on several host threads ---------------------------------------------------------
+ * Where a record starts is only known by walking from the file's first record -- but a guessed start can be
+ * CHECKED: the image is cut into pieces, a thread per piece looks for the first offset in its piece at which
+ * a plausible record header stands (0 <= beg <= end, a sane quality value) AND from which two consecutive
+ * records walk cleanly, and then walks from there to the start the next thread found.  Arriving there
+ * exactly proves both guesses (a walk from a wrong offset does not re-synchronise onto record boundaries:
+ * framing fields and pad words are not self-delimiting); any thread that overshoots its neighbour's start
+ * condemns the attempt, and the file is walked front to back as before.  Results are identical by
+ * construction: only offsets verified by an unbroken chain of walks from the first record are kept.   */
+typedef struct
+  { const walk_tabs *t;
+    const uint8_t   *img;
+    size_t           n, lo, hi;       /* piece [lo, hi) */
+    size_t           start, stop;     /* where this thread's records begin / must end */
+    size_t           landed;
+    rec_list         L;
+    int              rc;
+  } walk_job;
+
+static int header_plausible(const walk_tabs *t, const uint8_t *img, size_t n, size_t at)
+{ int32_t beg, end_, qv;
+  int k = 0;
+  while (at < n && img[at] == 255 && k < 64) { at += 1; k += 1; }
+  if (at + 13 > n) return 0;
+  at += 1;
+  memcpy(&beg, img + at, 4); memcpy(&end_, img + at + 4, 4); memcpy(&qv, img + at + 8, 4);
+  if (t->flip)
+    { beg = (int32_t) flip32((uint32_t) beg); end_ = (int32_t) flip32((uint32_t) end_); qv = (int32_t) flip32((uint32_t) qv); }
+  return beg >= 0 && end_ >= beg && end_ - beg <= (1 << 27) && qv >= 0 && qv < 1000000 &&
+         (uint64_t) (end_ - beg) <= 8u * (uint64_t) (n - at);
+}
+
+static void *walk_find(void *arg)                       /* first checked record start in the piece (0: none) */
+{ walk_job *j = arg;
+  size_t p;
+  j->start = 0;
+  for (p = j->lo; p < j->hi; p++)
+    if (header_plausible(j->t, j->img, j->n, p))
+      { walk_rec r;
+        size_t a = walk_record(j->t, j->img, j->n, p, &r), b;
+        if (a == 0) continue;
+        if (a == j->n) { j->start = p; break; }         /* the file's last record */
+        if (!header_plausible(j->t, j->img, j->n, a)) continue;
+        b = walk_record(j->t, j->img, j->n, a, &r);
+        if (b == 0) continue;
+        j->start = p;
+        break;
+      }
+  return NULL;
+}
+
+static void *walk_piece(void *arg)
+{ walk_job *j = arg;
+  j->rc = DX_OK;
+  j->landed = walk_span(j->t, j->img, j->n, j->start, j->stop, &j->L, &j->rc);
+  return NULL;
+}
+
+#include <pthread.h>
+#include <unistd.h>
+
+#define WALK_PIECE_MIN ((size_t) 2 << 20)               /* bytes of image a thread should at least have */
+#define WALK_THREADS_MAX 64
+
+/* records of img[first, n) into *out on up to `threads` threads; DX_E_MISMATCH: the guesses did not chain up */
+#include <time.h>
+static void walk_mark(const char *what)                  /* DEXGPU_TIMING=1: where the walk's time goes */
+{ static double t0 = 0;
+  struct timespec ts;
+  double now;
+  if (getenv("DEXGPU_TIMING") == NULL) return;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  now = (double) ts.tv_sec * 1e3 + (double) ts.tv_nsec / 1e6;
+  if (what == NULL) { t0 = now; return; }
+  fprintf(stderr, "[walk %8.1f ms] %s\n", now - t0, what);
+}
+
+static int walk_parallel(const walk_tabs *t, const uint8_t *img, size_t n, size_t first, int threads, rec_list *out)
+{ walk_job  job[WALK_THREADS_MAX];
+  pthread_t th[WALK_THREADS_MAX];
+  int       T = threads, k, m, rc = DX_OK, made;
+  size_t    piece;
+  if (T > WALK_THREADS_MAX) T = WALK_THREADS_MAX;
+  if ((size_t) T > (n - first) / WALK_PIECE_MIN) T = (int) ((n - first) / WALK_PIECE_MIN);
+  if (T < 2) return DX_E_MISMATCH;
+  piece = (n - first) / (size_t) T;
+  memset(job, 0, sizeof(job));
+  for (k = 0; k < T; k++)
+    { job[k].t = t; job[k].img = img; job[k].n = n;
+      job[k].lo = first + (size_t) k * piece;
+      job[k].hi = k == T - 1 ? n : first + (size_t) (k + 1) * piece;
+    }
+  job[0].start = first;
+  made = 0;                                             /* guesses: pieces 1 .. T-1 */
+  for (k = 1; k < T; k++)
+    { if (pthread_create(&th[k], NULL, walk_find, &job[k]) != 0) break;
+      made = k;
+    }
+  for (k = 1; k <= made; k++) pthread_join(th[k], NULL);
+  walk_mark("record starts guessed and checked");
+  if (made < T - 1) return DX_E_MISMATCH;
+  m = 0;                                                /* pieces without a start are walked by their predecessor */
+  for (k = 1; k < T; k++)
+    if (job[k].start != 0)
+      { job[m].stop = job[k].start;
+        m += 1;
+        if (m != k) job[m] = job[k];
+      }
+  job[m].stop = n;
+  T = m + 1;
+  made = -1;
+  for (k = 0; k < T; k++)
+    { if (pthread_create(&th[k], NULL, walk_piece, &job[k]) != 0) break;
+      made = k;
+    }
+  for (k = 0; k <= made; k++) pthread_join(th[k], NULL);
+  walk_mark("pieces walked");
+  if (made < T - 1) rc = DX_E_MISMATCH;
+  for (k = 0; k < T && rc == DX_OK; k++)
+    if (job[k].rc == DX_E_NOMEM) rc = DX_E_NOMEM;
+    else if (job[k].rc != DX_OK || job[k].landed != job[k].stop) rc = DX_E_MISMATCH;   /* a wrong guess (or a damaged file): walk it front to back */
+  if (rc == DX_OK)
+    { uint64_t tot = 0, at = 0;
+      for (k = 0; k < T; k++) tot += job[k].L.n;
+      out->r = malloc((tot + 1) * sizeof(walk_rec));
+      if (out->r == NULL) rc = DX_E_NOMEM;
+      else
+        { for (k = 0; k < T; k++)
+            { memcpy(out->r + at, job[k].L.r, job[k].L.n * sizeof(walk_rec));
+              at += job[k].L.n;
+            }
+          out->n = out->cap = tot;
+        }
+    }
+  for (k = 0; k < T; k++) free(job[k].L.r);
+  return rc;
+}
+
 int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
-{ wlut    *lut[6] = { NULL, NULL, NULL, NULL, NULL, NULL };
-  mwlut   *mlut[4] = { NULL, NULL, NULL, NULL };
-  rwlut   *rlut[2] = { NULL, NULL };
-  size_t   at = 0, used = 0;
-  uint64_t cap = 0, hat = 0;
-  uint16_t key;
-  int      rc = DX_OK, well = 0, s;
+{ walk_tabs t;
+  rec_list  L = { NULL, 0, 0 };
+  size_t    at = 0, used = 0;
+  uint64_t  hat = 0, i;
+  uint16_t  key;
+  int       rc = DX_OK, well = 0, s, threads;
 
   if (img == NULL || x == NULL) return DX_E_ARG;
   memset(x, 0, sizeof(*x));
+  memset(&t, 0, sizeof(t));
   if (n < 2) return DX_E_FORMAT;
   memcpy(&key, img, 2);                                   /* undexqv.c:103-110 */
   if (key == 0x55aa || key == 0xaa55) { x->newv = 1; at = 2; }
@@ -776,119 +1009,78 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   }
   if (rc != DX_OK) goto fail;
   at += used;
+  t.cd = &x->coding; t.newv = x->newv; t.flip = x->flip;
 
   for (s = 0; s < 6; s++)
     { if ((s == DX_DRUN && x->coding.delChar < 0) || (s == DX_SRUN && x->coding.subChar < 0)) continue;
-      lut[s] = malloc(sizeof(wlut));
-      if (lut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
-      build_wlut(&x->coding.s[s], lut[s]);
+      t.lut[s] = malloc(sizeof(wlut));
+      if (t.lut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
+      build_wlut(&x->coding.s[s], t.lut[s]);
       if (s < 4)
-        { mlut[s] = malloc(sizeof(mwlut));
-          if (mlut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
-          build_mwlut(lut[s], x->coding.s[s].type == 2, mlut[s]);
+        { t.mlut[s] = malloc(sizeof(mwlut));
+          if (t.mlut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
+          build_mwlut(t.lut[s], x->coding.s[s].type == 2, t.mlut[s]);
         }
     }
-
   for (s = 0; s < 2; s++)
     { const int sym = s ? DX_SUB : DX_DEL, run = s ? DX_SRUN : DX_DRUN;
-      if (lut[run] == NULL) continue;
-      rlut[s] = malloc(sizeof(rwlut));
-      if (rlut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
-      build_rwlut(lut[run], lut[sym], x->coding.s[sym].type == 2, rlut[s]);
+      if (t.lut[run] == NULL) continue;
+      t.rlut[s] = malloc(sizeof(rwlut));
+      if (t.rlut[s] == NULL) { rc = DX_E_NOMEM; goto fail; }
+      build_rwlut(t.lut[run], t.lut[sym], x->coding.s[sym].type == 2, t.rlut[s]);
     }
 
-  while (at < n)                                          /* undexqv.c:119-208 */
-    { const uint8_t *end = img + n;
-      size_t   h0 = at;
-      int32_t  beg, end_, qv;
-      uint32_t rlen, clen, *sg;
-      int64_t  b;
-
-      while (at < n && img[at] == 255) { well += 255; at += 1; }
-      if (at >= n) { rc = DX_E_FORMAT; goto fail; }
-      well += img[at++];
-      if (x->newv)
-        { if (at + 12 > n) { rc = DX_E_FORMAT; goto fail; }
-          memcpy(&beg, img + at, 4); memcpy(&end_, img + at + 4, 4); memcpy(&qv, img + at + 8, 4);
-          if (x->flip)                                    /* undexqv.c:140-148 */
-            { beg = (int32_t) flip32((uint32_t) beg); end_ = (int32_t) flip32((uint32_t) end_); qv = (int32_t) flip32((uint32_t) qv); }
-          at += 12;
-        }
-      else
-        { uint16_t h[3];
-          if (at + 6 > n) { rc = DX_E_FORMAT; goto fail; }
-          memcpy(h, img + at, 6);
-          if (x->flip) { h[0] = flip16(h[0]); h[1] = flip16(h[1]); h[2] = flip16(h[2]); }
-          beg = h[0]; end_ = h[1]; qv = h[2];
-          at += 6;
-        }
-      if (end_ < beg || (int64_t) end_ - (int64_t) beg > 0x7fffffff) { rc = DX_E_FORMAT; goto fail; }
-      rlen = (uint32_t) ((int64_t) end_ - (int64_t) beg);
-      if ((uint64_t) rlen > 65536u * 8u * (uint64_t) (n - at) + 64u)      /* a token has >= 1 bit and covers <= 65536 symbols */
-        { rc = DX_E_FORMAT; goto fail; }
-
-      if (x->n == cap)
-        { cap = cap ? 2 * cap : 1024;
-          void *t;                                        /* a failed realloc leaves the old block to dx_qv_index_free */
-          if ((t = realloc(x->rec_off, (cap + 1) * sizeof(uint64_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
-          x->rec_off = t;
-          if ((t = realloc(x->hdr_off, (cap + 1) * sizeof(uint64_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
-          x->hdr_off = t;
-          if ((t = realloc(x->seg, cap * 5 * sizeof(uint32_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
-          x->seg = t;
-          if ((t = realloc(x->len, cap * sizeof(uint32_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
-          x->len = t;
-          if ((t = realloc(x->hdr4, cap * 4 * sizeof(int32_t))) == NULL) { rc = DX_E_NOMEM; goto fail; }
-          x->hdr4 = t;
-        }
-      x->rec_off[x->n] = h0;
-      x->hdr_off[x->n] = hat;
-      hat += at - h0;
-      x->len[x->n] = rlen;
-      x->hdr4[4*x->n] = well; x->hdr4[4*x->n+1] = beg; x->hdr4[4*x->n+2] = end_; x->hdr4[4*x->n+3] = qv;
-      sg = x->seg + 5 * x->n;
-
-      clen = rlen;                                        /* QV.c:1433-1462 */
-      if (x->coding.delChar < 0)
-        b = walk_plain(img + at, end, rlen, lut[DX_DEL], mlut[DX_DEL], x->coding.s[DX_DEL].type == 2, x->flip);
-      else
-        b = walk_runs(img + at, end, rlen, lut[DX_DEL], x->coding.s[DX_DEL].type == 2, lut[DX_DRUN], rlut[0], &clen, x->flip);
-      if (b < 0) { rc = DX_E_FORMAT; goto fail; }
-      sg[0] = (uint32_t) b; at += (size_t) b;
-      sg[1] = (clen + 3) >> 2;
-      if (at + sg[1] > n) { rc = DX_E_FORMAT; goto fail; }
-      at += sg[1];
-      b = walk_plain(img + at, end, rlen, lut[DX_INS], mlut[DX_INS], x->coding.s[DX_INS].type == 2, x->flip);   /* QV.c:1464 */
-      if (b < 0) { rc = DX_E_FORMAT; goto fail; }
-      sg[2] = (uint32_t) b; at += (size_t) b;
-      b = walk_plain(img + at, end, rlen, lut[DX_MRG], mlut[DX_MRG], x->coding.s[DX_MRG].type == 2, x->flip);   /* QV.c:1467 */
-      if (b < 0) { rc = DX_E_FORMAT; goto fail; }
-      sg[3] = (uint32_t) b; at += (size_t) b;
-      if (x->coding.subChar < 0)                                                          /* QV.c:1470-1478 */
-        b = walk_plain(img + at, end, rlen, lut[DX_SUB], mlut[DX_SUB], x->coding.s[DX_SUB].type == 2, x->flip);
-      else
-        { uint32_t nn;
-          b = walk_runs(img + at, end, rlen, lut[DX_SUB], x->coding.s[DX_SUB].type == 2, lut[DX_SRUN], rlut[1], &nn, x->flip);
-        }
-      if (b < 0) { rc = DX_E_FORMAT; goto fail; }
-      sg[4] = (uint32_t) b; at += (size_t) b;
-      x->n += 1;
+  /* the records: on several threads when the image is large (32-bit framing fields only: the older
+     16-bit ones are too easily plausible), else -- and whenever the guesses do not chain up -- front to back */
+  { const char *e = getenv("DEXGPU_WALK_THREADS");
+    long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    threads = e ? atoi(e) : (int) (cores > 32 ? 32 : cores);
+  }
+  walk_mark(NULL);
+  rc = DX_E_MISMATCH;
+  if (threads > 1 && x->newv && n - at >= 4 * WALK_PIECE_MIN)
+    rc = walk_parallel(&t, img, n, at, threads, &L);
+  if (rc == DX_E_MISMATCH && getenv("DEXGPU_WALK_REQUIRE_PARALLEL") != NULL)
+    goto fail;                                            /* (tests: no silent front-to-back walk) */
+  if (rc == DX_E_MISMATCH)
+    { L.r = NULL; L.n = L.cap = 0;
+      rc = DX_OK;
+      if (walk_span(&t, img, n, at, n, &L, &rc) == 0 && rc == DX_OK && at < n) rc = DX_E_FORMAT;
     }
-  if (x->rec_off == NULL)
-    { x->rec_off = calloc(1, sizeof(uint64_t));
-      x->hdr_off = calloc(1, sizeof(uint64_t));
+  if (rc != DX_OK) goto fail;
+
+  x->n       = L.n;
+  x->rec_off = malloc((L.n + 1) * sizeof(uint64_t));
+  x->hdr_off = malloc((L.n + 1) * sizeof(uint64_t));
+  x->seg     = malloc((L.n + 1) * 5 * sizeof(uint32_t));
+  x->len     = malloc((L.n + 1) * sizeof(uint32_t));
+  x->hdr4    = malloc((L.n + 1) * 4 * sizeof(int32_t));
+  if (!x->rec_off || !x->hdr_off || !x->seg || !x->len || !x->hdr4) { rc = DX_E_NOMEM; goto fail; }
+  for (i = 0; i < L.n; i++)
+    { const walk_rec *r = &L.r[i];
+      x->rec_off[i] = at;
+      x->hdr_off[i] = hat;
+      hat  += r->hdr_bytes;
+      well += r->dwell;                                   /* undexqv.c:124-133: wells are a running sum */
+      x->len[i] = r->len;
+      x->hdr4[4*i] = well; x->hdr4[4*i+1] = r->beg; x->hdr4[4*i+2] = r->end; x->hdr4[4*i+3] = r->qv;
+      memcpy(x->seg + 5*i, r->seg, sizeof(r->seg));
+      at += (size_t) r->hdr_bytes + r->seg[0] + r->seg[1] + r->seg[2] + r->seg[3] + r->seg[4];
     }
-  x->rec_off[x->n] = at;
-  x->hdr_off[x->n] = hat;
-  for (s = 0; s < 6; s++) free(lut[s]);
-  for (s = 0; s < 4; s++) free(mlut[s]);
-  free(rlut[0]); free(rlut[1]);
+  x->rec_off[L.n] = at;
+  x->hdr_off[L.n] = hat;
+  walk_mark("index assembled");
+  free(L.r);
+  for (s = 0; s < 6; s++) free(t.lut[s]);
+  for (s = 0; s < 4; s++) free(t.mlut[s]);
+  free(t.rlut[0]); free(t.rlut[1]);
   return DX_OK;
 
 fail:
-  for (s = 0; s < 6; s++) free(lut[s]);
-  for (s = 0; s < 4; s++) free(mlut[s]);
-  free(rlut[0]); free(rlut[1]);
+  free(L.r);
+  for (s = 0; s < 6; s++) free(t.lut[s]);
+  for (s = 0; s < 4; s++) free(t.mlut[s]);
+  free(t.rlut[0]); free(t.rlut[1]);
   dx_qv_index_free(x);
   return rc;
 }

@@ -217,6 +217,36 @@ def test_walk_byteswapped_file():
     assert (w2["seg"] == w["seg"]).all() and (w2["hdr4"] == w["hdr4"]).all() and (w2["rec_off"] == w["rec_off"]).all()
 
 
+def test_walk_on_several_threads_equals_front_to_back(monkeypatch):
+    """Large images are walked by several host threads from guessed-and-verified record starts (dx_host.c):
+    same index as the front-to-back walk; a damaged image is still rejected."""
+    c = synth.make_quiva(900, seed=77, mean=9000)
+    dx = O.dexqv(c.text)
+    assert len(dx) > 8 << 20
+    monkeypatch.setenv("DEXGPU_WALK_THREADS", "1")
+    w1 = api.qv_walk(dx)
+    monkeypatch.setenv("DEXGPU_WALK_THREADS", "7")
+    monkeypatch.setenv("DEXGPU_WALK_REQUIRE_PARALLEL", "1")
+    w7 = api.qv_walk(dx)
+    assert w7["n"] == w1["n"] == len(c.len)
+    for k in ("rec_off", "hdr_off", "seg", "len", "hdr4"):
+        assert (w7[k] == w1[k]).all()
+    monkeypatch.delenv("DEXGPU_WALK_REQUIRE_PARALLEL")
+    bad = bytearray(dx)
+    bad[len(bad) // 2: len(bad) // 2 + 64] = bytes(64)        # a hole in the middle: no chain of walks survives it ...
+    got = None
+    try:
+        got = api.qv_walk(bytes(bad))
+    except L.DexGPUError as e:
+        assert e.code == -3
+    if got is not None:                                       # ... unless the damaged codes still parse: then as front to back
+        monkeypatch.setenv("DEXGPU_WALK_THREADS", "1")
+        ref = api.qv_walk(bytes(bad))
+        assert (got["rec_off"] == ref["rec_off"]).all()
+    with pytest.raises(L.DexGPUError):
+        api.qv_walk(dx[:-9])
+
+
 def test_walk_older_layout():
     """No 0x55aa key, uint16 beg/end/qv (undexqv.c:104-109, 159-179): same index, 6 fewer framing bytes per record."""
     dx, leg = O.golden("qv_tiny.dexqv"), O.golden("qv_tiny.legacy.dexqv")
