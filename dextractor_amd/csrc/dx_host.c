@@ -866,13 +866,15 @@ typedef struct
 static int header_plausible(const walk_tabs *t, const uint8_t *img, size_t n, size_t at)
 { int32_t beg, end_, qv;
   int k = 0;
-  while (at < n && img[at] == 255 && k < 64) { at += 1; k += 1; }
+  while (at < n && img[at] == 255 && k < 16) { at += 1; k += 1; }
   if (at + 13 > n) return 0;
   at += 1;
   memcpy(&beg, img + at, 4); memcpy(&end_, img + at + 4, 4); memcpy(&qv, img + at + 8, 4);
   if (t->flip)
     { beg = (int32_t) flip32((uint32_t) beg); end_ = (int32_t) flip32((uint32_t) end_); qv = (int32_t) flip32((uint32_t) qv); }
-  return beg >= 0 && end_ >= beg && end_ - beg <= (1 << 27) && qv >= 0 && qv < 1000000 &&
+  /* A guess that passes costs a walk of its (garbage) length: entries beyond 4 M symbols are left to be
+     reached by the neighbouring thread's walk rather than guessed at (1 in ~10^7 offsets passes by chance). */
+  return beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= (1 << 22) && qv >= 0 && qv < 1000000 &&
          (uint64_t) (end_ - beg) <= 8u * (uint64_t) (n - at);
 }
 

@@ -1,47 +1,99 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output (gpurun_out/prof_{stats,fetch,write}) into committed summaries.
+"""Condense rocprofv3 output (gpurun_out/prof_*, written by profiles/tools/profile_all.sh) into committed summaries.
 
-    python profiles/summarize.py <round-tag> [gpurun_out] [--entries N --mean M --dist D]
+    python profiles/summarize.py <round-tag> [gpurun_out]
 
-Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim),
-profiles/<tag>_traffic.json (PMC passes: FETCH_SIZE / WRITE_SIZE per launch, corrected as
-MI355X_MICROARCH.md prescribes: both counters are in KiB; on gfx950 FETCH_SIZE reports half the
-bytes of a wide 16 B/lane streaming read, so it is doubled) and refreshes profiles/traffic.json
-(read by bench.py for roofline.traffic).
+Writes, under profiles/:
+  <tag>_kernel_stats.csv, <tag>_kernel_stats_dexta.csv, <tag>_kernel_stats_dexar.csv
+        rocprofv3 --kernel-trace --stats summaries, verbatim
+  <tag>_traffic.json (and traffic.json, which bench.py reads for roofline.traffic)
+        HBM bytes per launch of every kernel from the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs,
+        kernel trace only), corrected as MI355X_MICROARCH.md prescribes: both counters are in KiB; on gfx950
+        FETCH_SIZE reports half the bytes of a wide 16 B/lane streaming read, so it is doubled
+  <tag>_sq_counters.json
+        SQ counters per launch of the dexqv kernels on a 200 k-entry batch (instructions per 5 KiB wave-step)
 """
 import csv, glob, json, os, shutil, sys, collections
 
-def main():
-    tag = sys.argv[1]
-    src = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "gpurun_out"
-    opt = {"entries": 1000000, "mean": 10000, "dist": "fixed", "passes": 3}   # passes: warmup + steps of the PMC runs
-    for i, a in enumerate(sys.argv):
-        if a.startswith("--") and a[2:] in opt:
-            opt[a[2:]] = type(opt[a[2:]])(sys.argv[i + 1])
-    here = os.path.dirname(os.path.abspath(__file__))
-    ks = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
-    if ks:
-        shutil.copy(ks[0], os.path.join(here, f"{tag}_kernel_stats.csv"))
+BENCH_ID = {"k_qv_encode_fast": "k_qv_encode", "k_qv_encode": "k_qv_encode", "k_qv_hist": "k_qv_hist",
+            "k_qv_compact": "k_qv_compact", "k_qv_decode": "k_qv_decode", "k_qv_decode_tags": "k_qv_decode",
+            "k_pack2_encode": "k_pack2_encode", "k_pack2_decode": "k_pack2_decode", "k_qv_sizes": "k_qv_sizes"}
+
+
+def kname(full):
+    n = full.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0]
+
+
+def counters(src, sub):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
-    for which in ("fetch", "write"):
-        for f in glob.glob(os.path.join(src, f"prof_{which}", "*", "*_counter_collection.csv")):
-            for r in csv.DictReader(open(f)):
-                name = r["Kernel_Name"].split("(")[0]
-                per[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out = {"tag": tag, **opt, "units": "bytes per launch", "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count on 16 B/lane streams); WRITE_SIZE KiB x 1024",
-           "kernels": {}}
-    for name, c in sorted(per.items()):
+    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            per[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+def traffic(src, suffix, steps):
+    fe, wr = counters(src, "prof_fetch" + suffix), counters(src, "prof_write" + suffix)
+    out, lps = {}, {}
+    for name in sorted(set(fe) | set(wr)):
         if not name.startswith("k_"):
             continue
-        fe = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024 * 2 if c.get("FETCH_SIZE") else None
-        wr = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024 if c.get("WRITE_SIZE") else None
-        out["kernels"][name] = {"fetch_bytes": fe, "write_bytes": wr,
-                                "hbm_bytes_per_launch": (fe or 0) + (wr or 0),
-                                "launches_sampled": len(c.get("FETCH_SIZE", []))}
-    out["launches_per_step"] = {k: max(1, round(v["launches_sampled"] / opt["passes"])) for k, v in out["kernels"].items()}
-    json.dump(out, open(os.path.join(here, f"{tag}_traffic.json"), "w"), indent=1)
-    json.dump(out, open(os.path.join(here, "traffic.json"), "w"), indent=1)
-    print(json.dumps(out["kernels"], indent=1))
+        f = fe.get(name, {}).get("FETCH_SIZE", [])
+        w = wr.get(name, {}).get("WRITE_SIZE", [])
+        out[name] = {"fetch_bytes": sum(f) / len(f) * 1024 * 2 if f else None,
+                     "write_bytes": sum(w) / len(w) * 1024 if w else None,
+                     "launches_sampled": len(f) or len(w)}
+        out[name]["hbm_bytes_per_launch"] = (out[name]["fetch_bytes"] or 0) + (out[name]["write_bytes"] or 0)
+        lps[name] = max(1, round(out[name]["launches_sampled"] / steps))
+    # per bench kernel id (bench.py lumps the fast and the generic encode kernel, and the two decode kernels)
+    ids = collections.defaultdict(lambda: {"hbm_bytes_per_step": 0.0})
+    for name, v in out.items():
+        b = BENCH_ID.get(name)
+        if b:
+            ids[b]["hbm_bytes_per_step"] += v["hbm_bytes_per_launch"] * lps[name]
+    return out, lps, ids
+
+
+def main():
+    tag = sys.argv[1]
+    src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
+    here = os.path.dirname(os.path.abspath(__file__))
+    for suffix in ("", "_dexta", "_dexar"):
+        ks = glob.glob(os.path.join(src, "prof_stats" + suffix, "*", "*_kernel_stats.csv"))
+        if ks:
+            shutil.copy(ks[0], os.path.join(here, f"{tag}_kernel_stats{suffix}.csv"))
+    steps = 4                                            # PMC passes: warmup 1 + steps 3
+    doc = {"tag": tag, "units": "bytes", "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count on 16 B/lane streams); WRITE_SIZE KiB x 1024",
+           "workloads": {}}
+    k, lps, ids = traffic(src, "", steps)
+    enc_lps = lps.get("k_qv_encode_fast", 1)
+    dq = {"entries": 1000000, "mean": 10000, "dist": "fixed", "kernels": dict(k), "launches_per_step": dict(lps)}
+    for b, v in ids.items():                             # what bench.py looks up: bytes per launch of its kernel ids
+        n = enc_lps if b == "k_qv_encode" else 1
+        dq["kernels"].setdefault(b, {})
+        dq["kernels"][b] = dict(dq["kernels"][b], hbm_bytes_per_launch=v["hbm_bytes_per_step"] / n, hbm_bytes_per_step=v["hbm_bytes_per_step"])
+        dq["launches_per_step"][b] = n
+    doc["workloads"]["dexqv"] = dq
+    for w in ("dexta", "dexar"):
+        k, lps, ids = traffic(src, "_" + w, steps)
+        if k:
+            doc["workloads"][w] = {"reads": 10000000, "mean": 10000, "kernels": k, "launches_per_step": lps}
+    json.dump(doc, open(os.path.join(here, f"{tag}_traffic.json"), "w"), indent=1)
+    json.dump(doc, open(os.path.join(here, "traffic.json"), "w"), indent=1)
+    sq = {}
+    for i in (1, 2):
+        for name, c in counters(src, f"prof_sq{i}").items():
+            if name.startswith("k_qv_") or name.startswith("k_pack2"):
+                sq.setdefault(name, {}).update({kk: round(sum(v) / len(v)) for kk, v in c.items()})
+    for name, c in sq.items():
+        if "SQ_INSTS_VALU" in c:
+            c["VALU_per_5KiB_wave_step"] = round(c["SQ_INSTS_VALU"] / 2e6, 1)     # 200 k entries x 10 steps
+    json.dump({"tag": tag, "batch": "200000 x 10000", "per_launch": sq}, open(os.path.join(here, f"{tag}_sq_counters.json"), "w"), indent=1)
+    print(json.dumps({w: {kk: round(vv["hbm_bytes_per_launch"] / 1e9, 3) for kk, vv in d["kernels"].items()} for w, d in doc["workloads"].items()}, indent=1))
+
 
 if __name__ == "__main__":
     main()
