@@ -84,51 +84,49 @@ static uint8_t *slurp(FILE *f, size_t *n, int *mapped)
   return buf;
 }
 
-/* The whole output image to a regular file: large images by several threads, a slice of the file each
-   (page-cache and tmpfs writes are memory copies: one thread moves ~4 GB/s of them); pipes and small
-   outputs by fwrite.  0 on success.                                                                   */
-typedef struct { int fd; const uint8_t *p; size_t n; off_t at; int bad; } wjob;
+/* The whole output image to a regular file: large images through a shared mapping of the file that several
+   threads fill, a slice each (writes into the page cache or tmpfs are memory copies plus page allocation;
+   write() calls on one file queue up behind its inode lock, page faults on a mapping do not); pipes, small
+   outputs and anything that cannot be mapped by fwrite.  0 on success.                                  */
+typedef struct { uint8_t *dst; const uint8_t *src; size_t n; } wjob;
 
-static void *write_slice(void *arg)
+static void *copy_slice(void *arg)
 { wjob *j = arg;
-  while (j->n > 0)
-    { ssize_t k = pwrite(j->fd, j->p, j->n > ((size_t) 1 << 30) ? ((size_t) 1 << 30) : j->n, j->at);
-      if (k <= 0) { j->bad = 1; break; }
-      j->p += k; j->n -= (size_t) k; j->at += k;
-    }
+  memcpy(j->dst, j->src, j->n);
   return NULL;
 }
 
 static int write_image(FILE *f, const uint8_t *buf, size_t n)
 { struct stat st;
   long cores = sysconf(_SC_NPROCESSORS_ONLN);
-  int  T = cores > 8 ? 8 : (int) cores, k, made = 0, bad = 0;
-  if (n < ((size_t) 32 << 20) || T < 2 || fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode))
+  int  T = cores > 16 ? 16 : (int) cores, k, made = 0;
+  off_t base;
+  uint8_t *map;
+  if (n < ((size_t) 32 << 20) || T < 2 || fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || fflush(f) != 0 ||
+      (base = lseek(fileno(f), 0, SEEK_CUR)) != 0 || ftruncate(fileno(f), (off_t) n) != 0)
     return (n > 0 && fwrite(buf, 1, n, f) != n) ? -1 : 0;
-  { wjob      job[8];
-    pthread_t th[8];
-    off_t     base;
+  map = mmap(NULL, n, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(f), 0);
+  if (map == MAP_FAILED)
+    return (fwrite(buf, 1, n, f) != n) ? -1 : 0;
+  { wjob      job[16];
+    pthread_t th[16];
     size_t    slice = (n / (size_t) T + 4095) & ~(size_t) 4095;
-    if (fflush(f) != 0) return -1;
-    base = lseek(fileno(f), 0, SEEK_CUR);
-    if (base < 0) return -1;
     for (k = 0; k < T; k++)
       { size_t lo = (size_t) k * slice, hi = lo + slice < n ? lo + slice : n;
         if (lo >= n) break;
-        job[k].fd = fileno(f); job[k].p = buf + lo; job[k].n = hi - lo; job[k].at = base + (off_t) lo; job[k].bad = 0;
-        if (k > 0 && pthread_create(&th[k], NULL, write_slice, &job[k]) != 0)
-          { write_slice(&job[k]);                        /* no thread to be had: this one does the slice */
+        job[k].dst = map + lo; job[k].src = buf + lo; job[k].n = hi - lo;
+        if (k > 0 && pthread_create(&th[k], NULL, copy_slice, &job[k]) != 0)
+          { copy_slice(&job[k]);                          /* no thread to be had: this one does the slice */
             th[k] = pthread_self();
           }
         made = k + 1;
       }
-    write_slice(&job[0]);
+    copy_slice(&job[0]);
     for (k = 1; k < made; k++)
       if (!pthread_equal(th[k], pthread_self())) pthread_join(th[k], NULL);
-    for (k = 0; k < made; k++) bad |= job[k].bad;
-    if (lseek(fileno(f), base + (off_t) n, SEEK_SET) < 0) bad = 1;
   }
-  return bad ? -1 : 0;
+  if (munmap(map, n) != 0) return -1;
+  return lseek(fileno(f), (off_t) n, SEEK_SET) < 0 ? -1 : 0;
 }
 
 static void unslurp(uint8_t *buf, size_t n, int mapped)

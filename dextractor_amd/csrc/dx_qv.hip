@@ -1369,6 +1369,9 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
 }
 
 #define COMPACT_BATCH 8u
+#ifndef COMPACT_WAVES_PER_CU
+#define COMPACT_WAVES_PER_CU 16                         // (a copy kernel: few registers, no LDS)
+#endif
 // scratch slots -> the record stream: header, del, tags, ins + mrg + sub (QV.c:1393-1423 order)
 __global__ __launch_bounds__(DX_BLOCK)
 void k_qv_compact(uint64_t n, const uint32_t *len, const uint8_t *scratch, const uint64_t *slot_off, const uint32_t *seg,
@@ -1756,7 +1759,7 @@ static int onepass_side(dx_ctx *ctx, const uint32_t *d_size, uint64_t m, uint64_
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, mt, d_gran);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply_base, (int) mt, DX_BLOCK, d_size, m, (const uint64_t *) d_tile, d_rec_off,
             (const uint64_t *) d_gran, base_in, base_out);
-  DX_LAUNCH(ctx, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, 16), DX_BLOCK,
+  DX_LAUNCH(ctx, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, COMPACT_WAVES_PER_CU), DX_BLOCK,
             m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
             ctx->d_status, d_tick);
   return DX_OK;
