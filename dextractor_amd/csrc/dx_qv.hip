@@ -1785,36 +1785,39 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       return DX_OK;
     }
   // Groups of entries: the encoder works through them on the context's stream while the compaction of the
-  // group before runs beside it on the side stream.  Both stages move memory at close to the rate the
-  // two can share, so what counts is the number of group boundaries (kernel tails, launch gaps, the wait
-  // for a scratch region to be free): as few groups as the scratch budget allows (two regions of at most
-  // ONEPASS_REGION_CAP bytes, sized from the table-derived slot bounds), two from 240 k entries on so that
-  // half of the compaction is hidden.  (Measured, 1 M x 10 kb: 2 groups 31.1 ms per step, 4: 31.3, 8: 32.9,
-  // 16: 35.0, 64: 46.7.)
+  // group before runs beside it on the side stream.  Both stages move memory at close to the rate the two
+  // can share, so the shape of the schedule matters: every group boundary costs kernel tails and launch
+  // gaps, the first group's encode and the last group's compaction run alone.  Hence few groups of
+  // decreasing size -- 40 % of the batch (at most what ONEPASS_REGION_CAP bytes of slots hold), then 3/4 of
+  // the previous one each, the small rest last -- in three rotating scratch regions, so that a short encode
+  // never waits for the long compaction two groups back.  (Measured, 1 M x 10 kb, equal groups in two
+  // regions: 2 groups 31.1 ms per step, 4: 31.3, 8: 32.9, 16: 35.0, 64: 46.7.)
   uint64_t gb[ONEPASS_MAX_GROUPS + 1];
-  int      G = 1;
-  { uint64_t per_entry = 0;                              // mean slot bound, from the bits-per-symbol bounds of the tables
-    const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
-    const uint64_t syms = b->text_bytes ? b->text_bytes / 5 : 0;       // (a file image: five lines per entry)
-    per_entry = syms ? (syms / n) * bits / 8 + syms / n / 4 + 128 : 0;
-    if (n >= 240000) G = 2;
-    if (per_entry)
-      while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
-    else if (n >= 240000)
-      G = (int) (n / 250000) > 2 ? (int) (n / 250000) : 2;
-    if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
-  }
-  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests)
-    { G = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
-      if (G < 1) G = 1;
-      if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
+  int      G = 0;
+  gb[0] = 0;
+  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests: that many equal groups)
+    { int k = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
+      if (k < 1) k = 1;
+      if (k > ONEPASS_MAX_GROUPS) k = ONEPASS_MAX_GROUPS;
+      const uint64_t gs = (n + (uint64_t) k - 1) / (uint64_t) k;
+      for (uint64_t at = 0; at < n; at += gs)
+        gb[++G] = at + gs < n ? at + gs : n;
     }
-  { const uint64_t gs = (n + (uint64_t) G - 1) / (uint64_t) G;
-    G = 0;
-    gb[0] = 0;
-    for (uint64_t at = 0; at < n; at += gs)
-      gb[++G] = at + gs < n ? at + gs : n;
-  }
+  else if (n < 240000)
+    gb[++G] = n;
+  else
+    { const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
+      const uint64_t syms = b->text_bytes ? b->text_bytes / 5 / n : 10000;       // per entry (a file image: five lines each)
+      const uint64_t per_entry = syms * bits / 8 + syms / 4 + 128;               // mean slot bound
+      uint64_t size = n * 2 / 5, at = 0;
+      if (size * per_entry > ONEPASS_REGION_CAP) size = ONEPASS_REGION_CAP / per_entry;
+      if (size < 40000) size = 40000;
+      while (G < ONEPASS_MAX_GROUPS - 1 && n - at > size + n / 12)
+        { at += size; gb[++G] = at;
+          if (size > n / 10) size = size * 3 / 4;
+        }
+      gb[++G] = n;
+    }
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
   const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255);
@@ -1823,10 +1826,10 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
   uint32_t      *d_bound = NULL, *d_size = NULL;
   uint64_t      *d_slot = NULL, *d_tile = NULL, *d_gran = NULL;
   // the slot layout needs the scratch to exist and the scratch's size needs the layout: lay out, size,
-  // and lay out again if the buffer had to move.  Two alternating regions hold the groups' slots.
+  // and lay out again if the buffer had to move.  Three rotating regions hold the groups' slots.
   for (int pass = 0; pass < 2; pass++)
     { void *base;
-      if ((e = dx_scratch(ctx, small + (G > 1 ? 2 : 1) * region + 512, &base))) return e;
+      if ((e = dx_scratch(ctx, small + (G > 2 ? 3 : G) * region + 512, &base))) return e;
       if (pass == 1 && base == (void *) scr) break;
       scr     = (uint8_t *) base;
       d_bound = (uint32_t *) scr;
@@ -1868,13 +1871,13 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
     { const uint64_t g0 = gb[g], g1 = gb[g + 1];
       if (g0 >= g1) continue;
       const uint64_t m = g1 - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
-      // this group's slots live in region g & 1: slot_off[r] is file-wide, so shift the base
-      uint8_t *slots_g = d_slots + (uint64_t) (g & 1) * region - gstart[g];
+      // this group's slots live in region g % 3: slot_off[r] is file-wide, so shift the base
+      uint8_t *slots_g = d_slots + (uint64_t) (g % 3) * region - gstart[g];
       qv_args ag = a;
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
-      if (g >= 2)
-        DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 2) & 7], 0));    // the region is free once its last tenant has been copied out
+      if (g >= 3)
+        DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 3) & 7], 0));    // the region is free once its last tenant has been copied out
       const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 };
       if (fast)                                          // entries with usable tokens: walked from the tokens
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };

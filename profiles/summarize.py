@@ -43,17 +43,25 @@ def traffic(src, suffix, steps):
             continue
         f = fe.get(name, {}).get("FETCH_SIZE", [])
         w = wr.get(name, {}).get("WRITE_SIZE", [])
-        out[name] = {"fetch_bytes": sum(f) / len(f) * 1024 * 2 if f else None,
+        # the x2 is for wide coalesced streams (16 B per lane, consecutive lanes consecutive bytes): every kernel here
+        # but the lane-per-stream decoder, whose lanes each read their own line (raw request bytes kept for it)
+        scattered = name in ("k_qv_decode",)
+        out[name] = {"fetch_bytes": sum(f) / len(f) * 1024 * (1 if scattered else 2) if f else None,
+                     "fetch_bytes_raw_counter": sum(f) / len(f) * 1024 if f else None,
                      "write_bytes": sum(w) / len(w) * 1024 if w else None,
                      "launches_sampled": len(f) or len(w)}
         out[name]["hbm_bytes_per_launch"] = (out[name]["fetch_bytes"] or 0) + (out[name]["write_bytes"] or 0)
         lps[name] = max(1, round(out[name]["launches_sampled"] / steps))
     # per bench kernel id (bench.py lumps the fast and the generic encode kernel, and the two decode kernels)
-    ids = collections.defaultdict(lambda: {"hbm_bytes_per_step": 0.0})
+    # bench.py times the fast and the generic encode kernel under one id (and the two decode kernels): bytes and
+    # launches of an id are the sums over its kernels, so that bytes per launch there and ms per launch in bench.py
+    # average over the same launches
+    ids = collections.defaultdict(lambda: {"hbm_bytes_per_step": 0.0, "launches_per_step": 0})
     for name, v in out.items():
         b = BENCH_ID.get(name)
         if b:
             ids[b]["hbm_bytes_per_step"] += v["hbm_bytes_per_launch"] * lps[name]
+            ids[b]["launches_per_step"] += lps[name]
     return out, lps, ids
 
 
@@ -69,10 +77,9 @@ def main():
     doc = {"tag": tag, "units": "bytes", "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count on 16 B/lane streams); WRITE_SIZE KiB x 1024",
            "workloads": {}}
     k, lps, ids = traffic(src, "", steps)
-    enc_lps = lps.get("k_qv_encode_fast", 1)
     dq = {"entries": 1000000, "mean": 10000, "dist": "fixed", "kernels": dict(k), "launches_per_step": dict(lps)}
     for b, v in ids.items():                             # what bench.py looks up: bytes per launch of its kernel ids
-        n = enc_lps if b == "k_qv_encode" else 1
+        n = v["launches_per_step"]
         dq["kernels"].setdefault(b, {})
         dq["kernels"][b] = dict(dq["kernels"][b], hbm_bytes_per_launch=v["hbm_bytes_per_step"] / n, hbm_bytes_per_step=v["hbm_bytes_per_step"])
         dq["launches_per_step"][b] = n
