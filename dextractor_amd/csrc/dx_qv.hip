@@ -1785,39 +1785,36 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       return DX_OK;
     }
   // Groups of entries: the encoder works through them on the context's stream while the compaction of the
-  // group before runs beside it on the side stream.  Both stages move memory at close to the rate the two
-  // can share, so the shape of the schedule matters: every group boundary costs kernel tails and launch
-  // gaps, the first group's encode and the last group's compaction run alone.  Hence few groups of
-  // decreasing size -- 40 % of the batch (at most what ONEPASS_REGION_CAP bytes of slots hold), then 3/4 of
-  // the previous one each, the small rest last -- in three rotating scratch regions, so that a short encode
-  // never waits for the long compaction two groups back.  (Measured, 1 M x 10 kb, equal groups in two
-  // regions: 2 groups 31.1 ms per step, 4: 31.3, 8: 32.9, 16: 35.0, 64: 46.7.)
+  // group before runs beside it on the side stream.  Both stages move memory at close to the rate the
+  // two can share (each slows the other down by about what the overlap gains), so what counts is the
+  // number of group boundaries -- kernel tails, launch gaps, waits for a scratch region to be free: as few
+  // groups as the scratch budget allows (regions of at most ONEPASS_REGION_CAP bytes, sized from the
+  // table-derived slot bounds), two from 240 k entries on so that half of the compaction is hidden.
+  // Measured, 1 M x 10 kb, ms per step: 2 equal groups 31.0, 4: 31.3, 8: 32.9, 16: 35.0, 64: 46.7;
+  // 40 % / 30 % / 30 % in three regions: 31.4; 7 groups with a halving tail: 32.7.
   uint64_t gb[ONEPASS_MAX_GROUPS + 1];
-  int      G = 0;
-  gb[0] = 0;
-  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests: that many equal groups)
-    { int k = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
-      if (k < 1) k = 1;
-      if (k > ONEPASS_MAX_GROUPS) k = ONEPASS_MAX_GROUPS;
-      const uint64_t gs = (n + (uint64_t) k - 1) / (uint64_t) k;
-      for (uint64_t at = 0; at < n; at += gs)
-        gb[++G] = at + gs < n ? at + gs : n;
+  int      G = 1;
+  { const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
+    const uint64_t syms = b->text_bytes ? b->text_bytes / 5 / n : 0;   // per entry (a file image: five lines each)
+    const uint64_t per_entry = syms ? syms * bits / 8 + syms / 4 + 128 : 0;       // mean slot bound
+    if (n >= 240000) G = 2;
+    if (per_entry)
+      while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
+    else if (n >= 240000)
+      G = (int) (n / 250000) > 2 ? (int) (n / 250000) : 2;
+    if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
+  }
+  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests)
+    { G = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
+      if (G < 1) G = 1;
+      if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
     }
-  else if (n < 240000)
-    gb[++G] = n;
-  else
-    { const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
-      const uint64_t syms = b->text_bytes ? b->text_bytes / 5 / n : 10000;       // per entry (a file image: five lines each)
-      const uint64_t per_entry = syms * bits / 8 + syms / 4 + 128;               // mean slot bound
-      uint64_t size = n * 2 / 5, at = 0;
-      if (size * per_entry > ONEPASS_REGION_CAP) size = ONEPASS_REGION_CAP / per_entry;
-      if (size < 40000) size = 40000;
-      while (G < ONEPASS_MAX_GROUPS - 1 && n - at > size + n / 12)
-        { at += size; gb[++G] = at;
-          if (size > n / 10) size = size * 3 / 4;
-        }
-      gb[++G] = n;
-    }
+  { const uint64_t gs = (n + (uint64_t) G - 1) / (uint64_t) G;
+    G = 0;
+    gb[0] = 0;
+    for (uint64_t at = 0; at < n; at += gs)
+      gb[++G] = at + gs < n ? at + gs : n;
+  }
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
   const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255);
