@@ -199,7 +199,8 @@ __device__ __forceinline__ void bs_end(bsink &o)
 #define DEC_NWAVE (DEC_BLOCK / 64)
 
 __global__ __launch_bounds__(DEC_BLOCK)
-void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *status, uint32_t *next_task)
+void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *status, uint32_t *next_task,
+                 uint32_t kinds /* bit q set: this launch decodes stream kind q (0 del, 1 ins, 2 mrg, 3 sub) */)
 { __shared__ uint16_t s_dec[6][DX_DEC_SIZE];               // 24 KB
   __shared__ uint32_t s_long[6][1 + DX_LONG_MAX];          // 6 KB
   __shared__ __attribute__((aligned(8))) uint8_t s_row[DEC_BLOCK][DEC_ROW_BYTES];    // 40 KB
@@ -223,6 +224,8 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       const uint64_t g = (uint64_t) t < 2 * ngroup ? t >> 1 : ((uint64_t) t - 2 * ngroup) >> 1;
       const int      q = (uint64_t) t < 2 * ngroup ? 1 + (int) (t & 1u) : ((t & 1u) ? 3 : 0);
       const uint64_t r = g * 64 + (uint64_t) lane_id();
+      if (!((kinds >> q) & 1u))
+        continue;                                          // k_qv_decode_plain has this stream kind
       if (r < a.n)                                         // lanes past the last entry idle through this task
       {
       const int      line = q == 0 ? 0 : q + 1;            // output line / segment index
@@ -299,6 +302,225 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       bs_end(o);
       if (bad) atomicOr(status, 4u);
       }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  plain lines (Decode, QV.c:510-599, schemes without escape): k_qv_decode_plain
+// ---------------------------------------------------------------------------------------------
+// Same division of the work (a lane per entry, a wavefront = one stream kind of 64 consecutive entries),
+// a much shorter path per code -- the plain lines are three quarters of all codes:
+//  * input by whole aligned 64-byte lines: a lane fetches the next line of its stream with four 16-byte loads
+//    (nothing is fetched twice: the generic kernel's 16-byte reads cost 3.9 x the stream's bytes in memory
+//    requests) into a two-line ring in LDS; the wave pumps the rings once per 16 symbols when any lane is low;
+//    the stream's 32-bit words (the segment may start at any byte) come out of the ring by v_alignbyte;
+//  * table entries carry what the steps need where they need it: byte 0 = 32 - length (v_alignbit takes the
+//    shift from there), byte 1 = symbol (v_perm drops it into the output word), byte 2 = length (SDWA
+//    operand of the shifts): 7 vector instructions and one look-up per code;
+//  * all lanes decode code j at the same time, so the output position is a compile-time quantity: 16 symbols
+//    make four registers that leave as one 16-byte store; a refill (one word) is needed about every 9th code;
+//  * codes beyond the 11-bit primary index are rare: a block of 16 symbols in which any lane meets one is
+//    decoded again, symbol by symbol, from the saved reader state.
+#define DP_BLOCK   768                                     // 12 waves: rings 101 KB + tables 38 KB of LDS
+#define DP_NWAVE   (DP_BLOCK / 64)
+#define DP_RING    32                                      // dwords per lane: two lines
+#define DP_STRIDE  33                                      // row stride in dwords (rows spread over the banks)
+
+struct linerd
+{ const uint8_t *next;           // next aligned line to fetch
+  uint32_t       lines;          // lines not yet fetched
+  uint32_t      *ring;           // this lane's LDS row
+  uint32_t       rp, wp;         // dwords read from / committed to the ring (counted from the first line)
+  u32x4          p0, p1, p2, p3; // line in flight
+  uint32_t       pend;           // is one
+  uint32_t       prev, nxt;      // ring[rp - 2], ring[rp - 1]: the next word's two halves, prefetched
+  uint32_t       o;              // byte offset of the stream's words in the aligned dwords (0..3)
+  uint32_t       hi, lo;         // bit buffer: next bit in bit 31 of hi
+  int            nb;             // valid bits
+};
+
+__device__ __forceinline__ void lr_issue(linerd &r)
+{ const u32x4 *g = (const u32x4 *) r.next;
+  r.p0 = g[0]; r.p1 = g[1]; r.p2 = g[2]; r.p3 = g[3];
+  r.pend  = 1;
+  r.next += 64;
+  r.lines -= 1;
+}
+
+__device__ __forceinline__ void lr_commit(linerd &r)
+{ u32x4 *row = (u32x4 *) (r.ring + (r.wp & (DP_RING - 1)));      // (rows are 4-byte aligned only: four dword quads)
+  uint32_t *w = (uint32_t *) row;
+  w[0]  = r.p0.x; w[1]  = r.p0.y; w[2]  = r.p0.z; w[3]  = r.p0.w;
+  w[4]  = r.p1.x; w[5]  = r.p1.y; w[6]  = r.p1.z; w[7]  = r.p1.w;
+  w[8]  = r.p2.x; w[9]  = r.p2.y; w[10] = r.p2.z; w[11] = r.p2.w;
+  w[12] = r.p3.x; w[13] = r.p3.y; w[14] = r.p3.z; w[15] = r.p3.w;
+  r.wp  += 16;
+  r.pend = 0;
+}
+
+// once per block of 16 symbols, all lanes together: a lane consumes at most 8 dwords per block
+__device__ __forceinline__ void lr_pump(linerd &r)
+{ const int avail = (int) (r.wp - r.rp);
+  if (__any(avail <= 12 && (r.pend | r.lines) != 0u))
+    { if (r.pend && avail <= 16)                           // the half to be overwritten has been read
+        lr_commit(r);
+      if (!r.pend && r.lines)
+        lr_issue(r);
+    }
+}
+
+__device__ __forceinline__ void lr_init(linerd &r, const uint8_t *seg, uint32_t bytes, uint32_t *ring)
+{ const uintptr_t A = (uintptr_t) seg;
+  r.next  = (const uint8_t *) (A & ~(uintptr_t) 63);
+  r.lines = bytes ? (uint32_t) (((A + bytes - 1) >> 6) - (A >> 6)) + 1u : 0u;
+  r.ring  = ring; r.rp = 0; r.wp = 0; r.pend = 0;
+  r.o     = (uint32_t) (A & 3u);
+  r.hi = r.lo = 0; r.nb = 0;
+  r.prev = r.nxt = 0;
+  const uint32_t d0 = (uint32_t) ((A & 63u) >> 2);         // dword of the first line the stream starts in
+  if (r.lines) { lr_issue(r); lr_commit(r); }              // prime: one line in the ring ...
+  if (r.lines) lr_issue(r);                                // ... and one in flight
+  if (d0 == 15u && r.pend)                                 // the stream starts in the line's last dword: its second
+    { lr_commit(r);                                        // half is in the next line already
+      if (r.lines) lr_issue(r);
+    }
+  r.prev = r.ring[d0 & (DP_RING - 1)];
+  r.nxt  = r.ring[(d0 + 1u) & (DP_RING - 1)];
+  r.rp   = d0 + 2u;
+}
+
+// next 32-bit word of the stream (MSB-first bit order within little-endian words, QV.c:553-568)
+__device__ __forceinline__ uint32_t lr_word(linerd &r, bool flip)
+{ uint32_t w = __builtin_amdgcn_alignbyte(r.nxt, r.prev, r.o);
+  r.prev = r.nxt;
+  r.nxt  = r.ring[r.rp & (DP_RING - 1)];
+  r.rp  += 1;
+  if (flip) w = __builtin_bswap32(w);
+  return w;
+}
+
+// at least 32 valid bits afterwards (a refill adds a word behind the valid bits)
+__device__ __forceinline__ void lr_fill(linerd &r, bool flip)
+{ if (r.nb < 32)
+    { const uint32_t w = lr_word(r, flip);
+      r.hi |= w >> r.nb;
+      r.lo  = __builtin_amdgcn_alignbit(w, 0u, (uint32_t) r.nb);       // w << (32 - nb); 0 for nb == 0
+      r.nb += 32;
+    }
+}
+
+// code by code (blocks with a long code, the last symbols of a line): symbol, bits consumed
+__device__ __forceinline__ uint32_t lr_symbol(linerd &r, const uint32_t *tab, const uint32_t *lng, bool flip)
+{ lr_fill(r, flip);
+  const uint32_t w = r.hi >> 16;
+  const uint32_t e = tab[w >> (16 - DX_DEC_BITS)];
+  uint32_t len = (e >> 16) & 0xffu, sym = (e >> 8) & 0xffu;
+  if (len == 0)                                            // code longer than the primary index
+    { const uint32_t cnt = lng[0];
+      for (uint32_t k = 1; k <= cnt; k++)
+        { const uint32_t t = lng[k], l = (t >> 8) & 0xffu;
+          if ((w >> (16u - l)) == ((t >> 16) >> (16u - l)))
+            { len = l; sym = t & 0xffu;
+              break;
+            }
+        }
+      if (len == 0) len = 1;                               // no such code (corrupt stream): keep moving
+    }
+  r.hi  = __builtin_amdgcn_alignbit(r.hi, r.lo, 32u - len);
+  r.lo <<= len;
+  r.nb -= (int) len;
+  return sym;
+}
+
+__global__ __launch_bounds__(DP_BLOCK)
+void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds)
+{ __shared__ uint32_t s_tab[4][DX_DEC_SIZE];               // 32 KB: 32 - len | symbol << 8 | len << 16 (len 0: long code)
+  __shared__ uint32_t s_long[4][1 + DX_LONG_MAX];          //  4 KB
+  __shared__ uint32_t s_ring[DP_BLOCK][DP_STRIDE];         // 99 KB
+  for (int k = threadIdx.x; k < 4 * DX_DEC_SIZE; k += DP_BLOCK)
+    { const uint32_t e = g_dec[k], len = e >> 8;
+      (&s_tab[0][0])[k] = (len ? 32u - len : 32u) | ((e & 0xffu) << 8) | (len << 16);
+    }
+  for (int k = threadIdx.x; k < 4 * (1 + DX_LONG_MAX); k += DP_BLOCK) (&s_long[0][0])[k] = g_long[k];
+  __syncthreads();
+
+  const uint64_t ngroup = (a.n + 63) / 64;
+  const bool     flip   = a.flip != 0;
+  for (;;)
+    { uint32_t t = 0;
+      if (lane_id() == 0)
+        t = atomicAdd(next_task, 1u);
+      t = uniform(t);
+      if ((uint64_t) t >= 4 * ngroup) break;               // every wave gets here: the counter only grows
+      const uint64_t g = (uint64_t) t < 2 * ngroup ? t >> 1 : ((uint64_t) t - 2 * ngroup) >> 1;   // same order as k_qv_decode
+      const int      q = (uint64_t) t < 2 * ngroup ? 1 + (int) (t & 1u) : ((t & 1u) ? 3 : 0);
+      if (!((kinds >> q) & 1u))
+        continue;
+      const uint64_t r    = g * 64 + (uint64_t) lane_id();
+      const bool     live = r < a.n;
+      const int      line = q == 0 ? 0 : q + 1;            // output line / segment index
+      uint32_t L = 0, sbytes = 0;
+      const uint8_t *seg = a.in;
+      uint8_t *out = a.out;
+      if (live)
+        { const uint32_t *sg = a.seg + 5 * r;
+          uint64_t at = a.rec_off[r] + (a.hdr_off ? a.hdr_off[r + 1] - a.hdr_off[r] : 0);
+          for (int k = 0; k < line; k++)
+            at += sg[k];
+          L      = a.len[r];
+          sbytes = sg[line];
+          seg    = a.in + at;
+          out    = a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u);
+        }
+      linerd rd;
+      lr_init(rd, seg, live ? sbytes : 0u, s_ring[threadIdx.x]);
+      const uint32_t *tab = s_tab[q];
+      const uint32_t *lng = s_long[q];
+      uint32_t j = 0;
+
+      while (__any(j + 16u <= L))                          // blocks of 16 symbols, all lanes at the same symbol
+        { lr_pump(rd);
+          if (j + 16u <= L)
+            { const uint32_t s_hi = rd.hi, s_lo = rd.lo, s_rp = rd.rp, s_prev = rd.prev, s_nxt = rd.nxt;   // (the block touches
+              const int      s_nb = rd.nb;                                                                  //  nothing else)
+              uint32_t w[4] = { 0u, 0u, 0u, 0u }, zor = 0;
+              #pragma unroll
+              for (int k = 0; k < 16; k += 2)
+                { lr_fill(rd, flip);                       // >= 32 bits: enough for two codes of <= 16
+                  #pragma unroll
+                  for (int h = 0; h < 2; h++)
+                    { const uint32_t e = tab[rd.hi >> (32 - DX_DEC_BITS)];
+                      zor  |= e;
+                      rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, e);          // shift = 32 - len, in e's low bits
+                      rd.lo <<= (e >> 16) & 31u;
+                      rd.nb -= (int) ((e >> 16) & 31u);
+                      // symbol (byte 1 of e) into byte (k + h) & 3 of the output word
+                      w[(k + h) >> 2] = __builtin_amdgcn_perm(e, w[(k + h) >> 2],
+                                                              ((k + h) & 3) == 0 ? 0x03020105u : ((k + h) & 3) == 1 ? 0x03020500u :
+                                                              ((k + h) & 3) == 2 ? 0x03050100u : 0x05020100u);
+                    }
+                }
+              if (__any((int) (zor & 32u)))                // a long code somewhere: this block again, code by code
+                { rd.hi = s_hi; rd.lo = s_lo; rd.rp = s_rp; rd.prev = s_prev; rd.nxt = s_nxt; rd.nb = s_nb;
+                  #pragma unroll 1
+                  for (int k = 0; k < 16; k++)
+                    { const uint32_t c = lr_symbol(rd, tab, lng, flip);
+                      w[k >> 2] = (k & 3) ? (w[k >> 2] | (c << (8 * (k & 3)))) : c;
+                    }
+                }
+              const u32x4 v = { w[0], w[1], w[2], w[3] };
+              *(u32x4_u *) (out + j) = v;
+              j += 16;
+            }
+        }
+      if (live)                                            // the last symbols of the line, and its end
+        { while (j < L)
+            { if ((int) (rd.wp - rd.rp) <= 2 && rd.pend) lr_commit(rd);
+              out[j] = (uint8_t) lr_symbol(rd, tab, lng, flip);
+              j += 1;
+            }
+          out[L] = '\n';
+        }
     }
 }
 
@@ -394,10 +616,26 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   uint64_t blocks = (4 * ((n + 63) / 64) + DEC_NWAVE - 1) / DEC_NWAVE;
   const uint64_t cap = (uint64_t) ctx->num_cu;
   if (blocks > cap) blocks = cap;
-  uint32_t *d_next = (uint32_t *) (ctx->d_u64 + 16);       // task counter of k_qv_decode
+  // plain lines without escape codes go to k_qv_decode_plain, the rest (run-coded lines, schemes with 8-bit
+  // escapes) to the generic kernel; DEXGPU_GENERIC_DECODE keeps everything on the generic one
+  uint32_t plain = 0;
+  for (int q = 0; q < 4; q++)
+    { const int rc = q == 0 ? ctx->delChar : (q == 3 ? ctx->subChar : -1);
+      if (rc < 0 && ctx->sym_type[q] != 2) plain |= 1u << q;
+    }
+  if (getenv("DEXGPU_GENERIC_DECODE") != NULL) plain = 0;
+  uint32_t *d_next = (uint32_t *) (ctx->d_u64 + 16), *d_next2 = (uint32_t *) (ctx->d_u64 + 31);   // task counters
   DX_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
-  DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,
-            (const uint32_t *) ctx->d_long, ctx->d_status, d_next);
+  DX_HIP(ctx, hipMemsetAsync(d_next2, 0, 4, ctx->stream));
+  if (plain)
+    { uint64_t pb = (4 * ((n + 63) / 64) + DP_NWAVE - 1) / DP_NWAVE;
+      if (pb > cap) pb = cap;
+      DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_plain, (int) pb, DP_BLOCK, a, (const uint16_t *) ctx->d_dec,
+                (const uint32_t *) ctx->d_long, d_next2, plain);
+    }
+  if (plain != 15u)
+    DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,
+              (const uint32_t *) ctx->d_long, ctx->d_status, d_next, 15u & ~plain);
   DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));

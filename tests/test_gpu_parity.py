@@ -326,8 +326,30 @@ def test_errors_are_loud(ctx):
 
 # ---- decode (undexqv) --------------------------------------------------------------------------
 
+@pytest.fixture(params=["plain kernel", "generic kernel"])
+def decoder(request, monkeypatch):
+    """The plain lines are decoded by k_qv_decode_plain (aligned-line input rings, 16 symbols per store); with
+    DEXGPU_GENERIC_DECODE set everything goes through the generic lane-per-stream kernel: both must agree."""
+    if request.param == "generic kernel":
+        monkeypatch.setenv("DEXGPU_GENERIC_DECODE", "1")
+    return request.param
+
+
+def test_undexqv_ragged_lengths_and_alignments(ctx, decoder):
+    """Lengths around the decoder's block (16) and step sizes, entry groups of very unequal lengths (the 64 lanes
+    of a wavefront run out at different times), segments at every byte alignment (the well-delta chain and odd
+    tag segments shift them), a line ending exactly at a 64-byte line."""
+    lens = np.array([0, 1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 1023, 1024, 1025,
+                     4095, 4096, 4097, 9000, 3, 70001, 5, 12000, 1] + [int(x) for x in np.random.default_rng(5).integers(0, 700, 120)],
+                    np.uint32)
+    c = synth.make_quiva(len(lens), seed=41, lens=lens)
+    dx = O.dexqv(c.text)
+    assert ctx.undexqv(dx, upper=True) == c.text
+    assert ctx.undexqv(dx, upper=False) == O.undexqv(dx, upper=False)
+
+
 @pytest.mark.parametrize("case", O.cases("quiva"), ids=lambda c: c["name"])
-def test_undexqv_golden(ctx, case):
+def test_undexqv_golden(ctx, case, decoder):
     txt, dx = O.golden(case["input"] + ".quiva"), O.golden(case["name"] + ".dexqv")
     rt = txt if case["rt_is_input"] else O.golden(case["name"] + ".rt.quiva")
     assert ctx.undexqv(dx, upper=True) == rt                     # reference `undexqv -U` output
@@ -336,7 +358,7 @@ def test_undexqv_golden(ctx, case):
 
 @pytest.mark.parametrize("lossy", [0, 1])
 @pytest.mark.parametrize("seed,n,mean", [(1, 3, 300), (3, 40, 8000), (4, 700, 900), (6, 24, 30000)])
-def test_undexqv_vs_oracle(ctx, seed, n, mean, lossy):
+def test_undexqv_vs_oracle(ctx, seed, n, mean, lossy, decoder):
     c = synth.make_quiva(n, seed=seed, mean=mean)
     dx = O.dexqv(c.text, lossy)
     got = ctx.undexqv(dx, upper=True)
@@ -371,7 +393,7 @@ def test_device_round_trip_with_encoder_index(ctx):
     assert d_txt2.download(np.uint8, len(c.text)).tobytes() == c.text
 
 
-def test_undexqv_no_delchar_and_type2(ctx):
+def test_undexqv_no_delchar_and_type2(ctx, decoder):
     for name in ("qv_nodel", "qv_type2", "qv_runs"):
         dx = O.golden(name + ".dexqv")
         assert ctx.undexqv(dx, upper=False) == O.undexqv(dx, upper=False)
@@ -414,7 +436,7 @@ def test_dexqv_run_longer_than_16_bits(ctx):
 
 
 @pytest.mark.parametrize("name", ["qv_full", "qv_type2", "qv_runs", "qv_nodel"])
-def test_undexqv_byteswapped_file(ctx, name):
+def test_undexqv_byteswapped_file(ctx, name, decoder):
     """GETFLIP path (QV.c:553-568): a .dexqv written on a host of the other endianness."""
     dx = O.golden(name + ".dexqv")
     fl = O.byteswap_dexqv(dx, api.qv_walk(dx))
