@@ -314,13 +314,14 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
 //    (nothing is fetched twice: the generic kernel's 16-byte reads cost 3.9 x the stream's bytes in memory
 //    requests) into a two-line ring in LDS; the wave pumps the rings once per 16 symbols when any lane is low;
 //    the stream's 32-bit words (the segment may start at any byte) come out of the ring by v_alignbyte;
-//  * table entries carry what the steps need where they need it: byte 0 = 32 - length (v_alignbit takes the
-//    shift from there), byte 1 = symbol (v_perm drops it into the output word), byte 2 = length (SDWA
-//    operand of the shifts): 7 vector instructions and one look-up per code;
+//  * a 12-bit primary table (codes beyond it are rarer than 1 in 4096 symbols by construction of a Huffman
+//    code) whose 16-bit entries carry what the steps need where they need it: the low bits = 32 - length
+//    (v_alignbit takes its shift from there, for both halves of the bit buffer), byte 1 = symbol (v_perm
+//    drops it into the output word): 8 vector instructions and one look-up per code;
 //  * all lanes decode code j at the same time, so the output position is a compile-time quantity: 16 symbols
 //    make four registers that leave as one 16-byte store; a refill (one word) is needed about every 9th code;
-//  * codes beyond the 11-bit primary index are rare: a block of 16 symbols in which any lane meets one is
-//    decoded again, symbol by symbol, from the saved reader state.
+//  * a block of 16 symbols in which any lane meets a code beyond the primary index is decoded again, symbol
+//    by symbol, from the saved reader state.
 #define DP_BLOCK   768                                     // 12 waves: rings 101 KB + tables 38 KB of LDS
 #define DP_NWAVE   (DP_BLOCK / 64)
 #define DP_RING    32                                      // dwords per lane: two lines
@@ -409,12 +410,15 @@ __device__ __forceinline__ void lr_fill(linerd &r, bool flip)
     }
 }
 
+#define DP_BITS 12                                         // primary index of k_qv_decode_plain
+#define DP_SIZE (1 << DP_BITS)
+
 // code by code (blocks with a long code, the last symbols of a line): symbol, bits consumed
-__device__ __forceinline__ uint32_t lr_symbol(linerd &r, const uint32_t *tab, const uint32_t *lng, bool flip)
+__device__ __forceinline__ uint32_t lr_symbol(linerd &r, const uint16_t *tab, const uint32_t *lng, bool flip)
 { lr_fill(r, flip);
   const uint32_t w = r.hi >> 16;
-  const uint32_t e = tab[w >> (16 - DX_DEC_BITS)];
-  uint32_t len = (e >> 16) & 0xffu, sym = (e >> 8) & 0xffu;
+  const uint32_t e = tab[w >> (16 - DP_BITS)];
+  uint32_t len = (e & 31u) ? 32u - (e & 31u) : 0u, sym = e >> 8;
   if (len == 0)                                            // code longer than the primary index
     { const uint32_t cnt = lng[0];
       for (uint32_t k = 1; k <= cnt; k++)
@@ -434,14 +438,26 @@ __device__ __forceinline__ uint32_t lr_symbol(linerd &r, const uint32_t *tab, co
 
 __global__ __launch_bounds__(DP_BLOCK)
 void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds)
-{ __shared__ uint32_t s_tab[4][DX_DEC_SIZE];               // 32 KB: 32 - len | symbol << 8 | len << 16 (len 0: long code)
+{ __shared__ uint16_t s_tab[4][DP_SIZE];                   // 32 KB: 32 - len | symbol << 8 (low bits 0: longer than DP_BITS)
   __shared__ uint32_t s_long[4][1 + DX_LONG_MAX];          //  4 KB
   __shared__ uint32_t s_ring[DP_BLOCK][DP_STRIDE];         // 99 KB
-  for (int k = threadIdx.x; k < 4 * DX_DEC_SIZE; k += DP_BLOCK)
-    { const uint32_t e = g_dec[k], len = e >> 8;
-      (&s_tab[0][0])[k] = (len ? 32u - len : 32u) | ((e & 0xffu) << 8) | (len << 16);
-    }
   for (int k = threadIdx.x; k < 4 * (1 + DX_LONG_MAX); k += DP_BLOCK) (&s_long[0][0])[k] = g_long[k];
+  __syncthreads();
+  // the 12-bit table from the library's 11-bit one and its list of longer codes (QV.c:365-372 in two levels)
+  for (int k = threadIdx.x; k < 4 * DP_SIZE; k += DP_BLOCK)
+    { const int      sc = k >> DP_BITS;
+      const uint32_t i  = (uint32_t) k & (DP_SIZE - 1), e = g_dec[sc * DX_DEC_SIZE + (i >> (DP_BITS - DX_DEC_BITS))];
+      uint32_t len = e >> 8, sym = e & 0xffu;
+      if (len == 0)                                        // longer than 11 bits: exactly DP_BITS long?
+        { const uint32_t *lg = s_long[sc], cnt = lg[0], pre = i << (16 - DP_BITS);
+          for (uint32_t j = 1; j <= cnt; j++)
+            { const uint32_t t = lg[j], l = (t >> 8) & 0xffu;
+              if (l <= DP_BITS && (pre >> (16u - l)) == ((t >> 16) >> (16u - l)))
+                { len = l; sym = t & 0xffu; }              // (ascending symbol order: the last match wins, as in the list)
+            }
+        }
+      (&s_tab[0][0])[k] = (uint16_t) ((len ? 32u - len : 0u) | (sym << 8));
+    }
   __syncthreads();
 
   const uint64_t ngroup = (a.n + 63) / 64;
@@ -474,7 +490,7 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
         }
       linerd rd;
       lr_init(rd, seg, live ? sbytes : 0u, s_ring[threadIdx.x]);
-      const uint32_t *tab = s_tab[q];
+      const uint16_t *tab = s_tab[q];
       const uint32_t *lng = s_long[q];
       uint32_t j = 0;
 
@@ -483,24 +499,24 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
           if (j + 16u <= L)
             { const uint32_t s_hi = rd.hi, s_lo = rd.lo, s_rp = rd.rp, s_prev = rd.prev, s_nxt = rd.nxt;   // (the block touches
               const int      s_nb = rd.nb;                                                                  //  nothing else)
-              uint32_t w[4] = { 0u, 0u, 0u, 0u }, zor = 0;
+              uint32_t w[4] = { 0u, 0u, 0u, 0u }, zand = 31u;
               #pragma unroll
               for (int k = 0; k < 16; k += 2)
                 { lr_fill(rd, flip);                       // >= 32 bits: enough for two codes of <= 16
                   #pragma unroll
                   for (int h = 0; h < 2; h++)
-                    { const uint32_t e = tab[rd.hi >> (32 - DX_DEC_BITS)];
-                      zor  |= e;
-                      rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, e);          // shift = 32 - len, in e's low bits
-                      rd.lo <<= (e >> 16) & 31u;
-                      rd.nb -= (int) ((e >> 16) & 31u);
+                    { const uint32_t e = tab[rd.hi >> (32 - DP_BITS)];
+                      zand &= e;                           // 32 - len is 16..31 (bit 4 set) unless the code is longer than the index
+                      rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, e);          // << len: the shift 32 - len sits in e's low bits
+                      rd.lo = __builtin_amdgcn_alignbit(rd.lo, 0u, e);
+                      rd.nb += (int) (e & 31u) - 32;
                       // symbol (byte 1 of e) into byte (k + h) & 3 of the output word
                       w[(k + h) >> 2] = __builtin_amdgcn_perm(e, w[(k + h) >> 2],
                                                               ((k + h) & 3) == 0 ? 0x03020105u : ((k + h) & 3) == 1 ? 0x03020500u :
                                                               ((k + h) & 3) == 2 ? 0x03050100u : 0x05020100u);
                     }
                 }
-              if (__any((int) (zor & 32u)))                // a long code somewhere: this block again, code by code
+              if (__any((int) (~zand & 16u)))              // a long code somewhere: this block again, code by code
                 { rd.hi = s_hi; rd.lo = s_lo; rd.rp = s_rp; rd.prev = s_prev; rd.nxt = s_nxt; rd.nb = s_nb;
                   #pragma unroll 1
                   for (int k = 0; k < 16; k++)
