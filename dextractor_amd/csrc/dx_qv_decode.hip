@@ -312,8 +312,11 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
 // a much shorter path per code -- the plain lines are three quarters of all codes:
 //  * input by whole aligned 64-byte lines: a lane fetches the next line of its stream with four 16-byte loads
 //    (nothing is fetched twice: the generic kernel's 16-byte reads cost 3.9 x the stream's bytes in memory
-//    requests) into a two-line ring in LDS; the wave pumps the rings once per 16 symbols when any lane is low;
-//    the stream's 32-bit words (the segment may start at any byte) come out of the ring by v_alignbyte;
+//    requests) into a two-line ring in LDS.  A lane whose ring has room for a line issues the loads before a
+//    block of 8 codes and writes them to the ring behind it: the load's latency runs under the block, and no
+//    load is in flight across the loop's back edge (the compiler would wait there for EVERY outstanding memory
+//    operation, the block's own output store included -- that wait once cost 10 000 cycles per 16 codes).  The
+//    stream's 32-bit words (the segment may start at any byte) come out of the ring by v_alignbyte;
 //  * a 12-bit primary table (codes beyond it are rarer than 1 in 4096 symbols by construction of a Huffman
 //    code) whose 16-bit entries carry what the steps need where they need it: the low bits = 32 - length
 //    (v_alignbit takes its shift from there, for both halves of the bit buffer), byte 1 = symbol (v_perm
@@ -331,60 +334,47 @@ struct linerd
 { const uint8_t *next;           // next aligned line to fetch
   uint32_t       lines;          // lines not yet fetched
   uint32_t      *ring;           // this lane's LDS row
-  uint32_t       rp, wp;         // dwords read from / committed to the ring (counted from the first line)
-  u32x4          p0, p1, p2, p3; // line in flight
-  uint32_t       pend;           // is one
+  uint32_t       rp, wp;         // dwords read from / written to the ring (counted from the first line)
   uint32_t       prev, nxt;      // ring[rp - 2], ring[rp - 1]: the next word's two halves, prefetched
   uint32_t       o;              // byte offset of the stream's words in the aligned dwords (0..3)
   uint32_t       hi, lo;         // bit buffer: next bit in bit 31 of hi
   int            nb;             // valid bits
 };
 
-__device__ __forceinline__ void lr_issue(linerd &r)
+struct line64 { u32x4 a, b, c, d; };
+
+__device__ __forceinline__ line64 lr_load(linerd &r)
 { const u32x4 *g = (const u32x4 *) r.next;
-  r.p0 = g[0]; r.p1 = g[1]; r.p2 = g[2]; r.p3 = g[3];
-  r.pend  = 1;
-  r.next += 64;
+  line64 v = { g[0], g[1], g[2], g[3] };
+  r.next  += 64;
   r.lines -= 1;
+  return v;
 }
 
-__device__ __forceinline__ void lr_commit(linerd &r)
-{ u32x4 *row = (u32x4 *) (r.ring + (r.wp & (DP_RING - 1)));      // (rows are 4-byte aligned only: four dword quads)
-  uint32_t *w = (uint32_t *) row;
-  w[0]  = r.p0.x; w[1]  = r.p0.y; w[2]  = r.p0.z; w[3]  = r.p0.w;
-  w[4]  = r.p1.x; w[5]  = r.p1.y; w[6]  = r.p1.z; w[7]  = r.p1.w;
-  w[8]  = r.p2.x; w[9]  = r.p2.y; w[10] = r.p2.z; w[11] = r.p2.w;
-  w[12] = r.p3.x; w[13] = r.p3.y; w[14] = r.p3.z; w[15] = r.p3.w;
-  r.wp  += 16;
-  r.pend = 0;
+__device__ __forceinline__ void lr_store(linerd &r, const line64 &v)
+{ uint32_t *w = r.ring + (r.wp & (DP_RING - 1));           // (rows are 4-byte aligned only)
+  w[0]  = v.a.x; w[1]  = v.a.y; w[2]  = v.a.z; w[3]  = v.a.w;
+  w[4]  = v.b.x; w[5]  = v.b.y; w[6]  = v.b.z; w[7]  = v.b.w;
+  w[8]  = v.c.x; w[9]  = v.c.y; w[10] = v.c.z; w[11] = v.c.w;
+  w[12] = v.d.x; w[13] = v.d.y; w[14] = v.d.z; w[15] = v.d.w;
+  r.wp += 16;
 }
 
-// once per block of 16 symbols, all lanes together: a lane consumes at most 8 dwords per block
-__device__ __forceinline__ void lr_pump(linerd &r)
-{ const int avail = (int) (r.wp - r.rp);
-  if (__any(avail <= 12 && (r.pend | r.lines) != 0u))
-    { if (r.pend && avail <= 16)                           // the half to be overwritten has been read
-        lr_commit(r);
-      if (!r.pend && r.lines)
-        lr_issue(r);
-    }
-}
+// Ring discipline (blocks of 8 codes = at most 4 words + 2 of look-ahead): a lane with <= 16 unread dwords
+// fetches a line before the block and stores it behind the block, when at most 16 are unread for sure; one with
+// more does not, and has >= 13 left behind the block.  So a block starts with >= 13 unread dwords, always.
+__device__ __forceinline__ bool lr_wants(const linerd &r) { return r.lines != 0u && r.wp - r.rp <= 16u; }
 
 __device__ __forceinline__ void lr_init(linerd &r, const uint8_t *seg, uint32_t bytes, uint32_t *ring)
 { const uintptr_t A = (uintptr_t) seg;
-  r.next  = (const uint8_t *) (A & ~(uintptr_t) 63);
+  r.next  = seg - (A & 63u);                               // (pointer arithmetic, not a cast: the loads stay global_load)
   r.lines = bytes ? (uint32_t) (((A + bytes - 1) >> 6) - (A >> 6)) + 1u : 0u;
-  r.ring  = ring; r.rp = 0; r.wp = 0; r.pend = 0;
+  r.ring  = ring; r.rp = 0; r.wp = 0;
   r.o     = (uint32_t) (A & 3u);
   r.hi = r.lo = 0; r.nb = 0;
-  r.prev = r.nxt = 0;
   const uint32_t d0 = (uint32_t) ((A & 63u) >> 2);         // dword of the first line the stream starts in
-  if (r.lines) { lr_issue(r); lr_commit(r); }              // prime: one line in the ring ...
-  if (r.lines) lr_issue(r);                                // ... and one in flight
-  if (d0 == 15u && r.pend)                                 // the stream starts in the line's last dword: its second
-    { lr_commit(r);                                        // half is in the next line already
-      if (r.lines) lr_issue(r);
-    }
+  if (r.lines) { const line64 v = lr_load(r); lr_store(r, v); }      // the ring starts full: two lines
+  if (r.lines) { const line64 v = lr_load(r); lr_store(r, v); }
   r.prev = r.ring[d0 & (DP_RING - 1)];
   r.nxt  = r.ring[(d0 + 1u) & (DP_RING - 1)];
   r.rp   = d0 + 2u;
@@ -494,35 +484,42 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
       const uint32_t *lng = s_long[q];
       uint32_t j = 0;
 
-      while (__any(j + 16u <= L))                          // blocks of 16 symbols, all lanes at the same symbol
-        { lr_pump(rd);
-          if (j + 16u <= L)
-            { const uint32_t s_hi = rd.hi, s_lo = rd.lo, s_rp = rd.rp, s_prev = rd.prev, s_nxt = rd.nxt;   // (the block touches
-              const int      s_nb = rd.nb;                                                                  //  nothing else)
-              uint32_t w[4] = { 0u, 0u, 0u, 0u }, zand = 31u;
+      while (__any(j + 16u <= L))                          // 16 symbols per round, all lanes at the same symbol
+        { if (j + 16u <= L)
+            { uint32_t w[4] = { 0u, 0u, 0u, 0u };
               #pragma unroll
-              for (int k = 0; k < 16; k += 2)
-                { lr_fill(rd, flip);                       // >= 32 bits: enough for two codes of <= 16
+              for (int half = 0; half < 2; half++)         // two blocks of 8 codes, each with its own line fetch
+                { const uint32_t s_hi = rd.hi, s_lo = rd.lo, s_rp = rd.rp, s_prev = rd.prev, s_nxt = rd.nxt;
+                  const int      s_nb = rd.nb;             // (the block touches nothing else of the reader)
+                  const bool     fetch = lr_wants(rd);
+                  line64 ln = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
+                  if (fetch) ln = lr_load(rd);
+                  uint32_t zand = 31u;
                   #pragma unroll
-                  for (int h = 0; h < 2; h++)
-                    { const uint32_t e = tab[rd.hi >> (32 - DP_BITS)];
-                      zand &= e;                           // 32 - len is 16..31 (bit 4 set) unless the code is longer than the index
-                      rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, e);          // << len: the shift 32 - len sits in e's low bits
-                      rd.lo = __builtin_amdgcn_alignbit(rd.lo, 0u, e);
-                      rd.nb += (int) (e & 31u) - 32;
-                      // symbol (byte 1 of e) into byte (k + h) & 3 of the output word
-                      w[(k + h) >> 2] = __builtin_amdgcn_perm(e, w[(k + h) >> 2],
-                                                              ((k + h) & 3) == 0 ? 0x03020105u : ((k + h) & 3) == 1 ? 0x03020500u :
-                                                              ((k + h) & 3) == 2 ? 0x03050100u : 0x05020100u);
+                  for (int k = 8 * half; k < 8 * half + 8; k += 2)
+                    { lr_fill(rd, flip);                   // >= 32 bits: enough for two codes of <= 16
+                      #pragma unroll
+                      for (int h = 0; h < 2; h++)
+                        { const uint32_t e = tab[rd.hi >> (32 - DP_BITS)];
+                          zand &= e;                       // 32 - len is 16..31 (bit 4 set) unless the code is longer than the index
+                          rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, e);      // << len: the shift 32 - len sits in e's low bits
+                          rd.lo = __builtin_amdgcn_alignbit(rd.lo, 0u, e);
+                          rd.nb += (int) (e & 31u) - 32;
+                          // symbol (byte 1 of e) into byte (k + h) & 3 of the output word
+                          w[(k + h) >> 2] = __builtin_amdgcn_perm(e, w[(k + h) >> 2],
+                                                                  ((k + h) & 3) == 0 ? 0x03020105u : ((k + h) & 3) == 1 ? 0x03020500u :
+                                                                  ((k + h) & 3) == 2 ? 0x03050100u : 0x05020100u);
+                        }
                     }
-                }
-              if (__any((int) (~zand & 16u)))              // a long code somewhere: this block again, code by code
-                { rd.hi = s_hi; rd.lo = s_lo; rd.rp = s_rp; rd.prev = s_prev; rd.nxt = s_nxt; rd.nb = s_nb;
-                  #pragma unroll 1
-                  for (int k = 0; k < 16; k++)
-                    { const uint32_t c = lr_symbol(rd, tab, lng, flip);
-                      w[k >> 2] = (k & 3) ? (w[k >> 2] | (c << (8 * (k & 3)))) : c;
+                  if (__any((int) (~zand & 16u)))          // a long code somewhere: this block again, code by code
+                    { rd.hi = s_hi; rd.lo = s_lo; rd.rp = s_rp; rd.prev = s_prev; rd.nxt = s_nxt; rd.nb = s_nb;
+                      #pragma unroll 1
+                      for (int k = 8 * half; k < 8 * half + 8; k++)
+                        { const uint32_t c = lr_symbol(rd, tab, lng, flip);
+                          w[k >> 2] = (k & 3) ? (w[k >> 2] | (c << (8 * (k & 3)))) : c;
+                        }
                     }
+                  if (fetch) lr_store(rd, ln);             // at most 16 dwords are unread now: the other half of the ring is free
                 }
               const u32x4 v = { w[0], w[1], w[2], w[3] };
               *(u32x4_u *) (out + j) = v;
@@ -530,9 +527,8 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
             }
         }
       if (live)                                            // the last symbols of the line, and its end
-        { while (j < L)
-            { if ((int) (rd.wp - rd.rp) <= 2 && rd.pend) lr_commit(rd);
-              out[j] = (uint8_t) lr_symbol(rd, tab, lng, flip);
+        { while (j < L)                                    // (< 16 codes = at most 8 words: the ring holds >= 13)
+            { out[j] = (uint8_t) lr_symbol(rd, tab, lng, flip);
               j += 1;
             }
           out[L] = '\n';
