@@ -325,67 +325,75 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
 //    make four registers that leave as one 16-byte store; a refill (one word) is needed about every 9th code;
 //  * a block of 16 symbols in which any lane meets a code beyond the primary index is decoded again, symbol
 //    by symbol, from the saved reader state.
-#define DP_BLOCK   768                                     // 12 waves: rings 101 KB + tables 38 KB of LDS
+#define DP_BLOCK   1024                                    // 16 waves: rings 100 KB + tables 36 KB of LDS
 #define DP_NWAVE   (DP_BLOCK / 64)
-#define DP_RING    32                                      // dwords per lane: two lines
-#define DP_STRIDE  33                                      // row stride in dwords (rows spread over the banks)
+#define DP_RING    24                                      // dwords per lane: three half-lines
+#define DP_STRIDE  25                                      // row stride in dwords (rows spread over the banks)
 
 struct linerd
-{ const uint8_t *next;           // next aligned line to fetch
-  uint32_t       lines;          // lines not yet fetched
+{ const uint8_t *next;           // next aligned half-line (32 bytes) to fetch
+  uint32_t       halves;         // half-lines not yet fetched
   uint32_t      *ring;           // this lane's LDS row
-  uint32_t       rp, wp;         // dwords read from / written to the ring (counted from the first line)
-  uint32_t       prev, nxt;      // ring[rp - 2], ring[rp - 1]: the next word's two halves, prefetched
+  uint32_t       avail;          // dwords in the ring not yet read
+  uint32_t       ri, wi;         // ring positions (0 .. DP_RING - 1) of the next read / the next write
+  uint32_t       prev, nxt;      // the next word's two halves, prefetched from the ring
   uint32_t       o;              // byte offset of the stream's words in the aligned dwords (0..3)
   uint32_t       hi, lo;         // bit buffer: next bit in bit 31 of hi
   int            nb;             // valid bits
 };
 
-struct line64 { u32x4 a, b, c, d; };
+struct half32 { u32x4 a, b; };
 
-__device__ __forceinline__ line64 lr_load(linerd &r)
+__device__ __forceinline__ half32 lr_load(linerd &r)
 { const u32x4 *g = (const u32x4 *) r.next;
-  line64 v = { g[0], g[1], g[2], g[3] };
-  r.next  += 64;
-  r.lines -= 1;
+  half32 v = { g[0], g[1] };
+  r.next   += 32;
+  r.halves -= 1;
   return v;
 }
 
-__device__ __forceinline__ void lr_store(linerd &r, const line64 &v)
-{ uint32_t *w = r.ring + (r.wp & (DP_RING - 1));           // (rows are 4-byte aligned only)
-  w[0]  = v.a.x; w[1]  = v.a.y; w[2]  = v.a.z; w[3]  = v.a.w;
-  w[4]  = v.b.x; w[5]  = v.b.y; w[6]  = v.b.z; w[7]  = v.b.w;
-  w[8]  = v.c.x; w[9]  = v.c.y; w[10] = v.c.z; w[11] = v.c.w;
-  w[12] = v.d.x; w[13] = v.d.y; w[14] = v.d.z; w[15] = v.d.w;
-  r.wp += 16;
+__device__ __forceinline__ void lr_store(linerd &r, const half32 &v)
+{ uint32_t *w = r.ring + r.wi;                             // (wi is a multiple of 8: a half-line never wraps)
+  w[0] = v.a.x; w[1] = v.a.y; w[2] = v.a.z; w[3] = v.a.w;
+  w[4] = v.b.x; w[5] = v.b.y; w[6] = v.b.z; w[7] = v.b.w;
+  r.wi     = r.wi == DP_RING - 8 ? 0u : r.wi + 8u;
+  r.avail += 8;
 }
 
 // Ring discipline (blocks of 8 codes = at most 4 words + 2 of look-ahead): a lane with <= 16 unread dwords
-// fetches a line before the block and stores it behind the block, when at most 16 are unread for sure; one with
-// more does not, and has >= 13 left behind the block.  So a block starts with >= 13 unread dwords, always.
-__device__ __forceinline__ bool lr_wants(const linerd &r) { return r.lines != 0u && r.wp - r.rp <= 16u; }
+// fetches a half-line (two 16-byte loads) before the block and stores it behind the block, where at most 16 are
+// unread for sure (the ring holds 24); one with more does not, and has >= 13 left behind the block.  So a block
+// starts with >= 13 unread dwords, always.
+__device__ __forceinline__ bool lr_wants(const linerd &r) { return r.halves != 0u && r.avail <= 16u; }
+
+__device__ __forceinline__ uint32_t lr_next(linerd &r)      // next dword of the ring
+{ const uint32_t v = r.ring[r.ri];
+  r.ri     = r.ri == DP_RING - 1 ? 0u : r.ri + 1u;
+  r.avail -= 1;
+  return v;
+}
 
 __device__ __forceinline__ void lr_init(linerd &r, const uint8_t *seg, uint32_t bytes, uint32_t *ring)
 { const uintptr_t A = (uintptr_t) seg;
-  r.next  = seg - (A & 63u);                               // (pointer arithmetic, not a cast: the loads stay global_load)
-  r.lines = bytes ? (uint32_t) (((A + bytes - 1) >> 6) - (A >> 6)) + 1u : 0u;
-  r.ring  = ring; r.rp = 0; r.wp = 0;
-  r.o     = (uint32_t) (A & 3u);
+  r.next   = seg - (A & 31u);                              // (pointer arithmetic, not a cast: the loads stay global_load)
+  r.halves = bytes ? (uint32_t) (((A + bytes - 1) >> 5) - (A >> 5)) + 1u : 0u;
+  r.ring   = ring; r.avail = 0; r.ri = 0; r.wi = 0;
+  r.o      = (uint32_t) (A & 3u);
   r.hi = r.lo = 0; r.nb = 0;
-  const uint32_t d0 = (uint32_t) ((A & 63u) >> 2);         // dword of the first line the stream starts in
-  if (r.lines) { const line64 v = lr_load(r); lr_store(r, v); }      // the ring starts full: two lines
-  if (r.lines) { const line64 v = lr_load(r); lr_store(r, v); }
-  r.prev = r.ring[d0 & (DP_RING - 1)];
-  r.nxt  = r.ring[(d0 + 1u) & (DP_RING - 1)];
-  r.rp   = d0 + 2u;
+  #pragma unroll
+  for (int k = 0; k < 3; k++)                              // the ring starts full
+    if (r.halves) { const half32 v = lr_load(r); lr_store(r, v); }
+  r.ri    = (uint32_t) ((A & 31u) >> 2);                   // dword of the first half-line the stream starts in
+  r.avail = r.avail > r.ri ? r.avail - r.ri : 0u;
+  r.prev  = lr_next(r);
+  r.nxt   = lr_next(r);
 }
 
 // next 32-bit word of the stream (MSB-first bit order within little-endian words, QV.c:553-568)
 __device__ __forceinline__ uint32_t lr_word(linerd &r, bool flip)
 { uint32_t w = __builtin_amdgcn_alignbyte(r.nxt, r.prev, r.o);
   r.prev = r.nxt;
-  r.nxt  = r.ring[r.rp & (DP_RING - 1)];
-  r.rp  += 1;
+  r.nxt  = lr_next(r);
   if (flip) w = __builtin_bswap32(w);
   return w;
 }
@@ -426,11 +434,47 @@ __device__ __forceinline__ uint32_t lr_symbol(linerd &r, const uint16_t *tab, co
   return sym;
 }
 
+// one block: 8 codes into two output words, with the block's own half-line fetch around it
+__device__ __forceinline__ void dp_block8(linerd &rd, const uint16_t *tab, const uint32_t *lng, bool flip, uint32_t &o0, uint32_t &o1)
+{ const uint32_t s_hi = rd.hi, s_lo = rd.lo, s_ri = rd.ri, s_av = rd.avail, s_prev = rd.prev, s_nxt = rd.nxt;
+  const int      s_nb = rd.nb;                             // (the block touches nothing else of the reader)
+  const bool     fetch = lr_wants(rd);
+  half32 ln = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
+  if (fetch) ln = lr_load(rd);
+  uint32_t w[2] = { 0u, 0u }, zand = 31u;
+  #pragma unroll
+  for (int k = 0; k < 8; k += 2)
+    { lr_fill(rd, flip);                                   // >= 32 bits: enough for two codes of <= 16
+      #pragma unroll
+      for (int h = 0; h < 2; h++)
+        { const uint32_t e = tab[rd.hi >> (32 - DP_BITS)];
+          zand &= e;                                       // 32 - len is 16..31 (bit 4 set) unless the code is longer than the index
+          rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, e);          // << len: the shift 32 - len sits in e's low bits
+          rd.lo = __builtin_amdgcn_alignbit(rd.lo, 0u, e);
+          rd.nb += (int) (e & 31u) - 32;
+          // symbol (byte 1 of e) into byte (k + h) & 3 of the output word
+          w[(k + h) >> 2] = __builtin_amdgcn_perm(e, w[(k + h) >> 2],
+                                                  ((k + h) & 3) == 0 ? 0x03020105u : ((k + h) & 3) == 1 ? 0x03020500u :
+                                                  ((k + h) & 3) == 2 ? 0x03050100u : 0x05020100u);
+        }
+    }
+  if (__any((int) (~zand & 16u)))                          // a long code somewhere: this block again, code by code
+    { rd.hi = s_hi; rd.lo = s_lo; rd.ri = s_ri; rd.avail = s_av; rd.prev = s_prev; rd.nxt = s_nxt; rd.nb = s_nb;
+      #pragma unroll 1
+      for (int k = 0; k < 8; k++)
+        { const uint32_t c = lr_symbol(rd, tab, lng, flip);
+          w[k >> 2] = (k & 3) ? (w[k >> 2] | (c << (8 * (k & 3)))) : c;
+        }
+    }
+  if (fetch) lr_store(rd, ln);                             // at most 16 dwords are unread now: 8 of the ring's 24 are free
+  o0 = w[0]; o1 = w[1];
+}
+
 __global__ __launch_bounds__(DP_BLOCK)
 void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds)
 { __shared__ uint16_t s_tab[4][DP_SIZE];                   // 32 KB: 32 - len | symbol << 8 (low bits 0: longer than DP_BITS)
   __shared__ uint32_t s_long[4][1 + DX_LONG_MAX];          //  4 KB
-  __shared__ uint32_t s_ring[DP_BLOCK][DP_STRIDE];         // 99 KB
+  __shared__ uint32_t s_ring[DP_BLOCK][DP_STRIDE];         // 100 KB
   for (int k = threadIdx.x; k < 4 * (1 + DX_LONG_MAX); k += DP_BLOCK) (&s_long[0][0])[k] = g_long[k];
   __syncthreads();
   // the 12-bit table from the library's 11-bit one and its list of longer codes (QV.c:365-372 in two levels)
@@ -484,50 +528,36 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
       const uint32_t *lng = s_long[q];
       uint32_t j = 0;
 
-      while (__any(j + 16u <= L))                          // 16 symbols per round, all lanes at the same symbol
-        { if (j + 16u <= L)
-            { uint32_t w[4] = { 0u, 0u, 0u, 0u };
+      // 64 symbols per round, all lanes at the same symbol: 16 registers that leave as four 16-byte stores to
+      // consecutive addresses (a whole line's worth at once: single 16-byte stores per round cost as much as the decoding)
+      while (__any(j + 64u <= L))
+        { if (j + 64u <= L)
+            { uint32_t w[16];
               #pragma unroll
-              for (int half = 0; half < 2; half++)         // two blocks of 8 codes, each with its own line fetch
-                { const uint32_t s_hi = rd.hi, s_lo = rd.lo, s_rp = rd.rp, s_prev = rd.prev, s_nxt = rd.nxt;
-                  const int      s_nb = rd.nb;             // (the block touches nothing else of the reader)
-                  const bool     fetch = lr_wants(rd);
-                  line64 ln = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
-                  if (fetch) ln = lr_load(rd);
-                  uint32_t zand = 31u;
-                  #pragma unroll
-                  for (int k = 8 * half; k < 8 * half + 8; k += 2)
-                    { lr_fill(rd, flip);                   // >= 32 bits: enough for two codes of <= 16
-                      #pragma unroll
-                      for (int h = 0; h < 2; h++)
-                        { const uint32_t e = tab[rd.hi >> (32 - DP_BITS)];
-                          zand &= e;                       // 32 - len is 16..31 (bit 4 set) unless the code is longer than the index
-                          rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, e);      // << len: the shift 32 - len sits in e's low bits
-                          rd.lo = __builtin_amdgcn_alignbit(rd.lo, 0u, e);
-                          rd.nb += (int) (e & 31u) - 32;
-                          // symbol (byte 1 of e) into byte (k + h) & 3 of the output word
-                          w[(k + h) >> 2] = __builtin_amdgcn_perm(e, w[(k + h) >> 2],
-                                                                  ((k + h) & 3) == 0 ? 0x03020105u : ((k + h) & 3) == 1 ? 0x03020500u :
-                                                                  ((k + h) & 3) == 2 ? 0x03050100u : 0x05020100u);
-                        }
-                    }
-                  if (__any((int) (~zand & 16u)))          // a long code somewhere: this block again, code by code
-                    { rd.hi = s_hi; rd.lo = s_lo; rd.rp = s_rp; rd.prev = s_prev; rd.nxt = s_nxt; rd.nb = s_nb;
-                      #pragma unroll 1
-                      for (int k = 8 * half; k < 8 * half + 8; k++)
-                        { const uint32_t c = lr_symbol(rd, tab, lng, flip);
-                          w[k >> 2] = (k & 3) ? (w[k >> 2] | (c << (8 * (k & 3)))) : c;
-                        }
-                    }
-                  if (fetch) lr_store(rd, ln);             // at most 16 dwords are unread now: the other half of the ring is free
-                }
-              const u32x4 v = { w[0], w[1], w[2], w[3] };
-              *(u32x4_u *) (out + j) = v;
-              j += 16;
+              for (int b = 0; b < 8; b++)
+                dp_block8(rd, tab, lng, flip, w[2 * b], w[2 * b + 1]);
+              u32x4_u *g = (u32x4_u *) (out + j);
+              const u32x4 v0 = { w[0], w[1], w[2], w[3] },    v1 = { w[4], w[5], w[6], w[7] };
+              const u32x4 v2 = { w[8], w[9], w[10], w[11] },  v3 = { w[12], w[13], w[14], w[15] };
+#ifndef ABL_DEC_NOSTORE
+              g[0] = v0; g[1] = v1; g[2] = v2; g[3] = v3;
+#else
+              asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(g));
+#endif
+              j += 64;
+            }
+        }
+      while (__any(j + 8u <= L))                           // the blocks left
+        { if (j + 8u <= L)
+            { uint32_t w0, w1;
+              dp_block8(rd, tab, lng, flip, w0, w1);
+              *(u32_u *) (out + j)      = w0;
+              *(u32_u *) (out + j + 4u) = w1;
+              j += 8;
             }
         }
       if (live)                                            // the last symbols of the line, and its end
-        { while (j < L)                                    // (< 16 codes = at most 8 words: the ring holds >= 13)
+        { while (j < L)                                    // (< 8 codes = at most 4 words: the ring holds >= 13)
             { out[j] = (uint8_t) lr_symbol(rd, tab, lng, flip);
               j += 1;
             }
