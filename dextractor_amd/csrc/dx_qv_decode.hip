@@ -539,11 +539,7 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
               u32x4_u *g = (u32x4_u *) (out + j);
               const u32x4 v0 = { w[0], w[1], w[2], w[3] },    v1 = { w[4], w[5], w[6], w[7] };
               const u32x4 v2 = { w[8], w[9], w[10], w[11] },  v3 = { w[12], w[13], w[14], w[15] };
-#ifndef ABL_DEC_NOSTORE
               g[0] = v0; g[1] = v1; g[2] = v2; g[3] = v3;
-#else
-              asm volatile("" :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(g));
-#endif
               j += 64;
             }
         }
