@@ -559,7 +559,7 @@ struct size_tabs
 };
 
 __device__ __forceinline__ void load_size_tables(size_tabs &t, const uint32_t *g_tok, int delChar, int subChar)
-{ for (int k = threadIdx.x; k < 6 * 256; k += DX_BLOCK)
+{ for (int k = threadIdx.x; k < 6 * 256; k += (int) blockDim.x)
     { const uint32_t e = g_tok[k];
       uint32_t l = TOK_LEN(e) + ((k >= 4 * 256 && TOK_ESC(e)) ? 16u : 0u);
       if ((delChar >= 0 && k == DX_DEL * 256 + delChar) || (subChar >= 0 && k == DX_SUB * 256 + subChar))
@@ -567,7 +567,7 @@ __device__ __forceinline__ void load_size_tables(size_tabs &t, const uint32_t *g
       (&t.len[0][0])[k] = (uint8_t) l;
     }
   __syncthreads();
-  for (int k = threadIdx.x; k < 2 * 256; k += DX_BLOCK)
+  for (int k = threadIdx.x; k < 2 * 256; k += (int) blockDim.x)
     { const uint8_t *rl = t.len[4 + (k >> 8)];
       uint32_t m = (uint32_t) k & 0xffu, sum = 0;
       int prev = -1;
@@ -626,7 +626,8 @@ __device__ __forceinline__ uint32_t bits_runs_step(const u32x4 &c, int valid, ui
 
 __global__ __launch_bounds__(DX_BLOCK, SIZES_WAVES)
 void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *seg /* n x 5 */,
-                uint32_t *rec_size, uint32_t *ticket)
+                uint32_t *rec_size, uint32_t *ticket,
+                const uint32_t *only_list, const unsigned long long *only_count, uint64_t first_entry, const uint32_t *only_info)
 { __shared__ uint32_t  s_tok[6][256];
   __shared__ size_tabs s_t;
   load_tables(s_tok, g_tok);
@@ -636,9 +637,34 @@ void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint3
   const uint32_t im4 = imask * 0x01010101u, mm4 = mmask * 0x01010101u;
   const bool drun = a.delChar >= 0, srun = a.subChar >= 0;
 
-  for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
-  { nxt = next_unit(ticket, TICKET_BATCH);
-    for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
+  // all entries of the batch in pairs from the ticket counter -- or (beside k_qv_sizes_fast) just the listed ones whose
+  // tokens are unusable, as in k_qv_encode
+  const uint64_t listed = only_list ? (uint64_t) *only_count : 0;
+  uint64_t pend = 0;
+  uint32_t mine = 0;
+  for (uint64_t r0 = only_list ? 0 : next_unit(ticket, TICKET_BATCH), nxt = 0; ; r0 = nxt)
+  { uint64_t rlo, rhi;
+    if (only_list == NULL)
+      { if (r0 >= a.n) break;
+        nxt = next_unit(ticket, TICKET_BATCH);
+        rlo = r0; rhi = r0 + TICKET_BATCH < a.n ? r0 + TICKET_BATCH : a.n;
+      }
+    else
+      { while (pend == 0)
+          { const uint64_t t = next_unit(ticket, 64u);
+            if (t >= listed) break;
+            mine = t + (uint64_t) lane < listed ? only_list[t + (uint64_t) lane] : 0xffffffffu;
+            pend = __ballot(mine != 0xffffffffu && (uint64_t) mine >= first_entry && (uint64_t) mine - first_entry < a.n);
+          }
+        if (pend == 0) break;
+        const int l = __ffsll((unsigned long long) pend) - 1;
+        pend &= pend - 1;
+        rlo = (uint64_t) __builtin_amdgcn_readlane(mine, l) - first_entry;
+        rhi = rlo + 1;
+        if (!tok_unusable(only_info, rlo, a.delChar, a.subChar))
+          continue;
+      }
+    for (uint64_t r = rlo; r < rhi; r++)
     { const uint32_t L = a.len[r];
       const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2);
       const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
@@ -1178,7 +1204,7 @@ __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
                  const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status, uint32_t *ticket,
                  enc_scratch sc, const uint32_t *only_list, const unsigned long long *only_count, uint64_t first_entry,
-                 const uint32_t *only_info)
+                 const uint32_t *only_info, uint64_t out_cap)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint8_t  s_tagcode[256];
@@ -1239,7 +1265,11 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
           tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
         }
       else
-        { dst = out + rec_off[r];
+        { if (rec_off[r + 1] > out_cap)                  // (dx_qv_encode_onepass: d_out too small) report, never overrun
+            { if (lane == 0) atomicOr(status, 8u);
+              continue;
+            }
+          dst = out + rec_off[r];
           if (hdr != NULL)                               // record framing (dexqv.c:128-139)
             { const uint64_t h0 = hdr_off[r];
               const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
@@ -1699,7 +1729,8 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 18);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, n, 4 * SIZES_WAVES), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_seg, d_size, d_ticket);
+            a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_seg, d_size, d_ticket,
+            (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) ntiles, DX_BLOCK, (const uint32_t *) d_size, n, d_tile);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, ntiles, d_gran);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, (const uint32_t *) d_size, n,
@@ -1727,7 +1758,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
             a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL },
-            (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL);
+            (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1765,6 +1796,140 @@ static int onepass_side(dx_ctx *ctx, const uint32_t *d_size, uint64_t m, uint64_
   return DX_OK;
 }
 
+// The token hand-over applies when k_qv_hist made its tokens for exactly this batch under the run characters now in
+// force (a substitution run character dropped by Create_QVcoding, QV.c:1044, just leaves its tokens unused).
+static bool onepass_tokens_ok(const dx_ctx *ctx, const dx_qv_batch *b)
+{ return ctx->tk.valid && ctx->tk.text == (const void *) b->d_text && ctx->tk.boff == (const void *) b->d_off &&
+         ctx->tk.blen == (const void *) b->d_len && ctx->tk.n == b->n && ctx->tk.text_bytes == b->text_bytes &&
+         ctx->tk.pad == b->line_pad && ctx->tk.delChar == ctx->delChar &&
+         (ctx->subChar < 0 || ctx->subChar == ctx->tk.subChar) && getenv("DEXGPU_NO_TOKENS") == NULL;
+}
+
+// dx_qv_encode_onepass with the token hand-over and no scratch slots (DEXGPU_DIRECT_ENCODE, or no memory for the
+// slots).  The entries go in a few groups of growing size; on the side stream k_qv_sizes_fast (+ the scan) runs
+// ahead through all groups; on the context's stream k_qv_encode_fast writes group g's records in place as soon
+// as that group's offsets exist.  Only the first, small group's sizes are waited for with nothing to do.
+// Entries with unusable tokens take the generic kernels (sizes and encode from the text).
+static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total)
+{ const uint64_t n = b->n;
+  const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  const size_t   a4 = (n * 4 + 255) & ~(size_t) 255;
+  uint8_t *scr;
+  int e;
+  if ((e = dx_scratch(ctx, a4 + (ntiles + 2) * 8 + 512, (void **) &scr))) return e;
+  uint32_t *d_size = (uint32_t *) scr;
+  uint64_t *d_tile = (uint64_t *) (scr + a4), *d_gran = d_tile + ntiles;
+
+  uint64_t gb[ONEPASS_MAX_GROUPS + 1];
+  int      G = 0;
+  gb[0] = 0;
+  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests: that many equal groups)
+    { int k = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
+      if (k < 1) k = 1;
+      if (k > ONEPASS_MAX_GROUPS) k = ONEPASS_MAX_GROUPS;
+      const uint64_t gs = (n + (uint64_t) k - 1) / (uint64_t) k;
+      for (uint64_t at = 0; at < n; at += gs)
+        gb[++G] = at + gs < n ? at + gs : n;
+    }
+  else if (n < 160000)
+    gb[++G] = n;
+  else                                                   // 1/16 of the batch, then 2.5 x the one before: a group's sizes
+    { uint64_t size = n / 16, at = 0;                    // are ready before the encoder has finished the group before it
+      if (size < 40000) size = 40000;
+      while (G < ONEPASS_MAX_GROUPS - 1 && n - at > size + size / 2)
+        { at += size; gb[++G] = at;
+          size = size * 5 / 2;
+        }
+      gb[++G] = n;
+    }
+
+  hipStream_t A = ctx->stream, B = ctx->side;
+  hipEvent_t *sz_done = ctx->ev, fork = ctx->ev[16], join = ctx->ev[15];
+  uint64_t   *d_base = ctx->d_u64 + 24;                  // [0], [1]: running record offset, ping-pong
+  uint32_t   *d_tick_enc = (uint32_t *) (ctx->d_u64 + 19), *d_tick_sz = (uint32_t *) (ctx->d_u64 + 22);
+  const qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
+  const bool    odd = ctx->tk.unusable > 0;              // some entries need the generic kernels
+  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
+  DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
+  DX_HIP(ctx, hipEventRecord(fork, A));
+  DX_HIP(ctx, hipStreamWaitEvent(B, fork, 0));
+  int rc = DX_OK;
+  ctx->stream = B;                                       // (the launch macro and its timing events follow ctx->stream)
+  for (int g = 0; g < G && rc == DX_OK; g++)             // side stream: sizes and record offsets of every group, in order
+    { const uint64_t g0 = gb[g], m = gb[g + 1] - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
+      qv_args ag = a;
+      ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
+      const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
+      const tok_src   tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
+      rc = DX_E_HIP;
+      if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
+      dx_prof_begin(ctx, DX_K_QV_SIZES);
+      hipLaunchKernelGGL(k_qv_sizes_fast, dim3(fast_grid(ctx, (m + TICKET_BATCH - 1) / TICKET_BATCH)), dim3(FAST_BLOCK), 0, B,
+                         ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz, tg);
+      dx_prof_end(ctx);
+      if (odd)
+        { if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
+          dx_prof_begin(ctx, DX_K_QV_SIZES);
+          hipLaunchKernelGGL(k_qv_sizes, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * SIZES_WAVES)),
+                             dim3(DX_BLOCK), 0, B, ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz,
+                             (const uint32_t *) ctx->tk.list, (const unsigned long long *) ctx->tk.count, g0,
+                             (const uint32_t *) (ctx->tk.info + 4 * g0));
+          dx_prof_end(ctx);
+        }
+      dx_prof_begin(ctx, DX_K_SCAN);
+      hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned) mt), dim3(DX_BLOCK), 0, B, (const uint32_t *) (d_size + g0), m, d_tile);
+      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(DX_BLOCK), 0, B, d_tile, mt, d_gran);
+      hipLaunchKernelGGL(k_scan_apply_base, dim3((unsigned) mt), dim3(DX_BLOCK), 0, B, (const uint32_t *) (d_size + g0), m,
+                         (const uint64_t *) d_tile, d_rec_off + g0, (const uint64_t *) d_gran,
+                         (const uint64_t *) (d_base + (g & 1)), d_base + ((g + 1) & 1));
+      dx_prof_end(ctx);
+      if (hipGetLastError() != hipSuccess || hipEventRecord(sz_done[g & 7], B) != hipSuccess) break;
+      // context's stream: the group's records, in place
+      if (hipStreamWaitEvent(A, sz_done[g & 7], 0) != hipSuccess || hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
+      ctx->stream = A;
+      dx_prof_begin(ctx, DX_K_QV_ENCODE);
+      hipLaunchKernelGGL(k_qv_encode_fast, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
+                         ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+                         ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
+                         (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap);
+      dx_prof_end(ctx);
+      if (odd)
+        { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) { ctx->stream = B; break; }
+          dx_prof_begin(ctx, DX_K_QV_ENCODE);
+          hipLaunchKernelGGL(k_qv_encode, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * ENC_WAVES)),
+                             dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
+                             (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
+                             d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, (const uint32_t *) ctx->tk.list,
+                             (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + 4 * g0), out_cap);
+          dx_prof_end(ctx);
+        }
+      ctx->stream = B;
+      if (hipGetLastError() != hipSuccess) break;
+      rc = DX_OK;
+    }
+  ctx->stream = A;
+  (void) hipEventRecord(join, B);
+  (void) hipStreamWaitEvent(A, join, 0);                 // the caller's stream sees everything finished
+  uint64_t tot = 0;
+  uint32_t st  = 0;
+  if (rc != DX_OK)
+    { (void) hipStreamSynchronize(A);
+      return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: a launch failed (%s)", hipGetErrorString(hipGetLastError()));
+    }
+  if (hipMemcpyAsync(&tot, d_base + (G & 1), 8, hipMemcpyDeviceToHost, A) != hipSuccess ||
+      hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A) != hipSuccess ||
+      hipStreamSynchronize(A) != hipSuccess)
+    return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
+  if (total) *total = tot;
+  if (tot > out_cap || (st & 8u))
+    return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
+                   (unsigned long long) tot, (unsigned long long) out_cap);
+  if (st & 2u)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an encoded segment differs in size from what the size kernel computed");
+  return DX_OK;
+}
+
 extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                                     uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap,
                                     uint64_t *total)
@@ -1784,6 +1949,12 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       if (total) *total = 0;
       return DX_OK;
     }
+  // DEXGPU_DIRECT_ENCODE: sizes first, records written in place, no scratch slots (onepass_direct) -- what also runs
+  // when the slots below cannot be allocated.  It is the slower of the two (34.5 ms against 31.0, 1 M x 10 kb): its
+  // size kernel reads the 30 GB of plain lines once more, the compaction it saves moves 2 x 14 GB.
+  if (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_DIRECT_ENCODE") != NULL)
+    return onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, total);
+
   // Groups of entries: the encoder works through them on the context's stream while the compaction of the
   // group before runs beside it on the side stream.  Both stages move memory at close to the rate the
   // two can share (each slows the other down by about what the overlap gains), so what counts is the
@@ -1826,7 +1997,11 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
   // and lay out again if the buffer had to move.  Three rotating regions hold the groups' slots.
   for (int pass = 0; pass < 2; pass++)
     { void *base;
-      if ((e = dx_scratch(ctx, small + (G > 2 ? 3 : G) * region + 512, &base))) return e;
+      if ((e = dx_scratch(ctx, small + (G > 2 ? 3 : G) * region + 512, &base)))
+        { if (pass == 1 && onepass_tokens_ok(ctx, b))   // no room for the slots: the scheme that needs none
+            return onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, total);
+          return e;
+        }
       if (pass == 1 && base == (void *) scr) break;
       scr     = (uint8_t *) base;
       d_bound = (uint32_t *) scr;
@@ -1857,10 +2032,7 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
   qv_args        a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   // the token hand-over applies when k_qv_hist made its tokens for exactly this batch under the run characters now in force
   // (a substitution run character dropped by Create_QVcoding, QV.c:1044, just leaves its tokens unused)
-  const bool fast = ctx->tk.valid && ctx->tk.text == (const void *) b->d_text && ctx->tk.boff == (const void *) b->d_off &&
-                    ctx->tk.blen == (const void *) b->d_len && ctx->tk.n == b->n && ctx->tk.text_bytes == b->text_bytes &&
-                    ctx->tk.pad == b->line_pad && ctx->tk.delChar == ctx->delChar &&
-                    (ctx->subChar < 0 || ctx->subChar == ctx->tk.subChar) && getenv("DEXGPU_NO_TOKENS") == NULL;
+  const bool fast = onepass_tokens_ok(ctx, b);
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
   DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
   int rc = DX_OK, ng = 0;                                // ng: groups run so far (selects the ping-pong base)
@@ -1881,7 +2053,8 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
           DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast, fast_grid(ctx, m), FAST_BLOCK,
                     ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
-                    ctx->pair_lo[0], ctx->pair_lo[1]);
+                    ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
+                    (uint8_t *) NULL, (uint64_t) 0);
         }
       if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
         { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;
@@ -1891,7 +2064,7 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
                     (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g,
                     fast ? (const uint32_t *) ctx->tk.list : (const uint32_t *) NULL,
                     fast ? (const unsigned long long *) ctx->tk.count : (const unsigned long long *) NULL, g0,
-                    fast ? (const uint32_t *) (ctx->tk.info + 4 * g0) : (const uint32_t *) NULL);
+                    fast ? (const uint32_t *) (ctx->tk.info + 4 * g0) : (const uint32_t *) NULL, ~(uint64_t) 0);
         }
       DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction

@@ -166,7 +166,8 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
 
 __global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
-                      enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg)
+                      enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
+                      const uint8_t *hdr, const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint64_t out_cap)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint32_t s_pair[2][4096];
@@ -190,15 +191,38 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
     { nxt = next_unit(ticket);
       if (tok_unusable(tk.info, r, a.delChar, a.subChar))
         continue;                                        // the generic kernel encodes this entry from the text
+      // Two modes.  Scratch (sc.base != NULL): the entry goes into its slot, the sizes it turns out to have are
+      // recorded.  Direct: the sizes are known (k_qv_sizes_fast), the record is written where it belongs --
+      // framing bytes, del words, tag bytes, ins, mrg, sub words (QV.c:1393-1423) -- and every size is checked.
+      const bool      S      = sc.base != NULL;
       const uint32_t  L      = a.len[r];
       const uint32_t *inf    = tk.info + 4 * r;
       const uint64_t  toff   = tk.off[r];
-      uint32_t       *sgw    = sc.seg_out + 5 * r;
-      uint8_t        *dst    = sc.base + sc.slot_off[r];
-      uint8_t        *tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
+      const uint32_t *sg     = seg + 5 * r;              // (direct mode)
+      uint32_t       *sgw    = sc.seg_out + 5 * r;       // (scratch mode)
+      uint8_t        *dst, *tag_at;
+      if (S)
+        { dst    = sc.base + sc.slot_off[r];
+          tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
+        }
+      else
+        { if (rec_off[r + 1] > out_cap)                  // d_out is too small: report, never overrun
+            { if (lane == 0) atomicOr(status, 8u);
+              continue;
+            }
+          dst = out + rec_off[r];
+          if (hdr != NULL)                               // record framing (dexqv.c:128-139)
+            { const uint64_t h0 = hdr_off[r];
+              const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
+              for (uint32_t k = (uint32_t) lane; k < hl; k += 64)
+                dst[k] = hdr[h0 + k];
+              dst += hl;
+            }
+          tag_at = dst + sg[0];
+        }
       const uint8_t  *p1     = line_ptr(a, r, L, 1);
       const bool      over   = can_overread(a, line_ptr(a, r, L, 4), L);
-      uint32_t        sum    = 0;
+      uint32_t        sum    = 0, bad = 0;
 
       // The four QV streams in file order: del (its tag segment goes to the slot's end), ins, mrg, sub
       // (QV.c:1393-1423).
@@ -231,8 +255,8 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               got = finish_words(o, last);
               if (q == 0)
                 { const uint32_t tb = finish_tags(ot);
-                  if (lane == 0) sgw[1] = tb;
-                  sum += tb;
+                  if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
+                  else   { bad |= tb ^ sg[1]; dst += sg[1]; }
                 }
             }
           else                                           // Encode
@@ -274,17 +298,129 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               if (q == 0)                                // no delChar: the whole tag line is packed
                 { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
                   const uint32_t tb = encode_all_tags(ot, p1, L, over);
-                  if (lane == 0) sgw[1] = tb;
-                  sum += tb;
+                  if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
+                  else   { bad |= tb ^ sg[1]; dst += sg[1]; }
                 }
             }
-          if (lane == 0) sgw[line] = got;
-          sum += got;
+          if (S)
+            { if (lane == 0) sgw[line] = got;
+              sum += got;
+            }
+          else
+            bad |= got ^ sg[line];
           dst += got;
         }
-      if (dst > tag_at && lane == 0)
-        atomicOr(status, 2u);                            // the slot bound was too small: never expected
-      if (lane == 0)
-        sc.rec_size[r] = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
+      if (S)
+        { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
+          if (lane == 0)
+            sc.rec_size[r] = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
+        }
+      if (bad && lane == 0)
+        atomicOr(status, 2u);                            // slot overflow / a size differs from what k_qv_sizes_fast computed
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+//  k_qv_sizes_fast: the five segment sizes of every entry, from the tokens and the two plain lines
+// ---------------------------------------------------------------------------------------------
+// With the sizes known up front the encoder writes every record where it belongs and the scratch round trip
+// (slots + compaction: 2 x the output in extra HBM traffic, and a compaction kernel competing with the encoder)
+// is gone.  Sizes need code LENGTHS only: per token two byte-wide look-ups (run length table, symbol length
+// table; both 256 B = conflict-free), per byte of the insertion / merge lines one; the pad rule QV.c:436-442 in
+// closed form.  Reads the tokens (~0.7 B per base) and the two plain lines (2 B per base): a memory-bound kernel
+// with a quarter of the encoder's instructions, run for group g + 1 beside the encoder of group g.
+__device__ __forceinline__ uint32_t token_bits(const uint16_t *tok, uint32_t cnt, const uint8_t *slen, const uint8_t *rlen)
+{ const uint32_t lane = (uint32_t) lane_id();
+  uint32_t acc = 0;
+  for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
+    { const uint32_t first = k0 + lane * TOK_TP;
+      const uint32_t c     = first < cnt ? (cnt - first < TOK_TP ? cnt - first : TOK_TP) : 0u;
+      u32x4 tw = { 0u, 0u, 0u, 0u };
+      if (c)
+        tw = *(const u32x4_u *) (tok + first);
+      #pragma unroll
+      for (int k = 0; k < (int) TOK_TP; k++)
+        { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
+          const uint32_t l   = (uint32_t) rlen[t16 >> 9] + (uint32_t) slen[(t16 >> 2) & 0x7fu];
+          acc += (uint32_t) k < c ? l : 0u;
+        }
+    }
+  return acc;                                            // (per lane; < 2^32 for entries of < 2^27 symbols)
+}
+
+__global__ __launch_bounds__(FAST_BLOCK)
+void k_qv_sizes_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *seg /* n x 5 */, uint32_t *rec_size,
+                     uint32_t *ticket, tok_src tk)
+{ __shared__ uint32_t  s_tok[6][256];
+  __shared__ size_tabs s_t;
+  load_tables(s_tok, g_tok);
+  load_size_tables(s_t, g_tok, a.delChar, a.subChar);
+  const int lane = lane_id();
+
+  for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
+  { nxt = next_unit(ticket, TICKET_BATCH);
+    for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
+    { if (tok_unusable(tk.info, r, a.delChar, a.subChar))
+        continue;                                        // k_qv_sizes (generic) has this entry
+      const uint32_t  L    = a.len[r];
+      const uint32_t *inf  = tk.info + 4 * r;
+      const uint64_t  toff = tk.off[r];
+      const bool      over = can_overread(a, line_ptr(a, r, L, 4), L);
+      uint32_t s0 = 0, s2 = 0, s3 = 0, s4 = 0;
+      uint32_t s1 = (L + 3u) >> 2;                       // all tags kept unless the deletion line is run-coded
+      #pragma unroll 1
+      for (int q = 0; q < 4; q++)
+        { const int       line = q ? q + 1 : 0;
+          const int       rci  = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
+          const uint32_t *tab  = s_tok[q];
+          uint64_t T;
+          uint32_t last;
+          if (rci >= 0)                                  // Encode_Run: token lengths (QV.c:475-497)
+            { const int       rs  = q == 0 ? DX_DRUN : DX_SRUN;
+              const uint16_t *tok = (q == 0 ? tk.del : tk.sub) + toff;
+              const uint32_t  cnt = inf[q == 0 ? 0 : 1] & ~TOK_BAD, C = inf[q == 0 ? 2 : 3];
+              T = wave_sum(token_bits(tok, cnt, s_t.len[q], s_t.len[rs]));
+              if (C > 0)                                 // run-only token at the line's end
+                { const uint32_t e = s_tok[rs][C > 255u ? 255u : C];
+                  T   += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
+                  last = TOK_ESC(e) ? 16u : TOK_LEN(e);
+                }
+              else if (cnt > 0)
+                { const uint32_t e = tab[((uint32_t) tok[cnt - 1] >> 2) & 0x7fu];
+                  last = TOK_ESC(e) ? 8u : TOK_LEN(e);
+                }
+              else
+                last = 0;
+              if (q == 0) s1 = (cnt + 3u) >> 2;          // Pack_Tag's count, QV.c:810-819
+            }
+          else                                           // Encode: code lengths of the line's bytes (QV.c:427-434)
+            { const uint8_t *p    = line_ptr(a, r, L, line);
+              const uint32_t mask = !a.lossy ? 0xffu : (q == 1 ? 0xfeu : (q == 2 ? 0xfcu : 0xffu));
+              const uint32_t m4   = mask * 0x01010101u;
+              uint32_t pos = 16u * lane, acc = 0;
+              u32x4 c = fetch(p, pos, L, over);
+              T = 0;
+              for (uint32_t base = 0; base < L; base += DX_STEP)
+                { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
+                  acc += bits_syms_step(c, valid_of(pos, L), s_t.len[q], m4);
+                  c = d;
+                  pos += DX_STEP;
+                  if ((base & 0x3ffffffu) == 0x3fffc00u)           // fold long before a 32-bit lane sum can wrap
+                    { T += wave_sum(acc); acc = 0; }
+                }
+              T   += wave_sum(acc);
+              last = last_piece_plain(tab, p, L, mask);
+            }
+          const uint32_t bytes = seg_bytes(T, last);
+          if (q == 0) s0 = bytes; else if (q == 1) s2 = bytes; else if (q == 2) s3 = bytes; else s4 = bytes;
+        }
+      if (lane == 0)
+        { const uint32_t hl = hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u;
+          uint32_t *sg = seg + 5 * r;
+          sg[0] = s0; sg[1] = s1; sg[2] = s2; sg[3] = s3; sg[4] = s4;
+          rec_size[r] = hl + s0 + s1 + s2 + s3 + s4;
+        }
+    }
+  }
 }

@@ -810,19 +810,23 @@ def _two_pass(ctx, c, coding, lossy=False, given=None):
             d_seg.download(np.uint32, 5 * n).copy(), (b, keep, d_hdr, d_hoff))
 
 
-@pytest.mark.parametrize("tokens", [True, False], ids=["tokens", "text"])
+@pytest.mark.parametrize("tokens", ["tokens", "tokens_direct", "text"])
 @pytest.mark.parametrize("groups", [None, "3", "8"])
 @pytest.mark.parametrize("case", ["pacbio", "small_lengths", "dense", "sparse", "lossy", "long_codes", "no_runs", "huge_entry",
                                   "odd_entries"])
 def test_encode_onepass_equals_two_pass(ctx, case, groups, tokens, monkeypatch):
-    """dx_qv_encode_onepass (scratch slots bounded from the tables + compaction, no size pass) gives the
-    bytes of the oracle, entry by entry, and the bytes, record offsets and segment index of dx_qv_sizes +
-    dx_qv_encode -- from the tokens k_qv_hist left for the batch (k_qv_encode_fast, with the generic kernel
-    for the entries whose tokens are unusable) and, without them, from the text alone."""
-    if groups:                                                    # several groups: two streams, alternating scratch regions
+    """dx_qv_encode_onepass gives the bytes of the oracle, entry by entry, and the bytes, record offsets and
+    segment index of dx_qv_sizes + dx_qv_encode.  Three routes: from the tokens k_qv_hist left for the batch
+    into scratch slots + compaction (k_qv_encode_fast; the generic kernel for the entries whose tokens are
+    unusable) -- the product path; from the tokens, sizes first (k_qv_sizes_fast) and the records written in
+    place (DEXGPU_DIRECT_ENCODE, the route taken when the slots cannot be allocated); and without tokens, from
+    the text alone (scratch slots bounded from the tables)."""
+    if groups:                                                    # several groups: two streams
         monkeypatch.setenv("DEXGPU_ONEPASS_GROUPS", groups)
-    if not tokens:
+    if tokens == "text":
         monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
+    if tokens == "tokens_direct":
+        monkeypatch.setenv("DEXGPU_DIRECT_ENCODE", "1")
     lossy = case == "lossy"
     if case == "small_lengths":
         lens = np.array(list(range(0, 70)) + [1023, 1024, 1025, 2047, 4097, 0, 1, 9000], np.uint32)
