@@ -6,7 +6,7 @@ i=0
 for set in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pmcd_$i
-  rocprofv3 --kernel-trace --pmc $set -d /tmp/pmcd_$i -o p -f csv -- python3 $R/bench.py --no-check --no-cpu-baseline --entries 200000 --steps 1 --warmup 1 > /tmp/pmcd_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d /tmp/pmcd_$i -o p -f csv -- python3 $R/bench.py --only-main --no-check --no-cpu-baseline --entries 200000 --steps 1 --warmup 1 > /tmp/pmcd_$i.log 2>&1
   python3 - <<PY
 import csv,glob,collections
 per=collections.defaultdict(lambda: collections.defaultdict(list))
