@@ -273,7 +273,8 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         # writes only the five data lines of an entry; the chunk buffer is zero elsewhere and header bytes are
         # never zero, so the number of differing bytes must equal the number of header bytes exactly.
         trace("verify: decode + compare")
-        chunk = max(1, min(n, int(6e9 // (5 * (args.mean + 1) + hlen))))
+        free_b = torch.cuda.mem_get_info()[0]                     # as few decode launches as the free memory allows:
+        chunk = max(1, min(n, int(max(6e9, 0.7 * free_b) // (5 * (args.mean + 1) + hlen))))   # (a launch = one pool of tasks)
         ends = np.concatenate([off[1:] - hlen, [text_bytes]]).astype(np.uint64)   # end of each entry's record
         roundtrip, dec_ms = True, 0.0
         for a in range(0, n, chunk):
@@ -289,7 +290,10 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
             kt = ctx.kernel_times()
             dec_ms += kt.get("k_qv_decode", (0.0, 0))[0]
             ctx.profile(False)
-            diff = int((d_back[: hi - lo] != d_text[lo:hi]).sum())
+            diff = 0
+            for c0 in range(0, hi - lo, 1 << 32):                 # compared in slices: no chunk-sized temporary
+                c1 = min(hi - lo, c0 + (1 << 32))
+                diff += int((d_back[c0:c1] != d_text[lo + c0: lo + c1]).sum())
             roundtrip = roundtrip and diff == (b - a) * hlen
             del d_back, o_rel
         state["decode"] = {"kernel": "k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),
