@@ -47,6 +47,8 @@ extern "C" int dx_open(int device, dx_ctx **out)
   ctx->coding_set = 0;
   ctx->d_scratch = NULL;
   ctx->scratch_bytes = 0;
+  ctx->d_scan = NULL;
+  ctx->scan_words = 0;
   memset(&ctx->tk, 0, sizeof(ctx->tk));
 
 #define OPEN_HIP(call)                                                                       \
@@ -93,6 +95,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_status);
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);
+  (void) hipFree(ctx->d_scan);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
@@ -192,19 +195,19 @@ static const char *k_names[DX_K_COUNT] =
 extern "C" const char *dx_kernel_name(int kernel)
 { return (kernel >= 0 && kernel < DX_K_COUNT) ? k_names[kernel] : "?"; }
 
-void dx_prof_begin(dx_ctx *ctx, int kernel)
+void dx_prof_begin_on(dx_ctx *ctx, int kernel, hipStream_t stream)
 { if (!ctx->profiling) return;
   dx_pending p;
   p.kernel = kernel;
   if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)
     return;
-  (void) hipEventRecord(p.a, ctx->stream);
+  (void) hipEventRecord(p.a, stream);
   ctx->pend.push_back(p);
 }
 
-void dx_prof_end(dx_ctx *ctx)
+void dx_prof_end_on(dx_ctx *ctx, hipStream_t stream)
 { if (!ctx->profiling || ctx->pend.empty()) return;
-  (void) hipEventRecord(ctx->pend.back().b, ctx->stream);
+  (void) hipEventRecord(ctx->pend.back().b, stream);
 }
 
 static int prof_collect(dx_ctx *ctx)

@@ -68,12 +68,16 @@ struct dx_ctx
   uint64_t *d_u64;             // small device scalars (prescan keys, totals, ...)
   void     *d_scratch;         // grow-only scratch (scan partials, histograms, sizes)
   size_t    scratch_bytes;
+  uint64_t *d_scan;            // grow-only tile sums of dx_scan_u32 (its callers hold d_scratch)
+  size_t    scan_words;
 };
 
 int  dx_fail(dx_ctx *ctx, int code, const char *fmt, ...);
 int  dx_scratch(dx_ctx *ctx, size_t bytes, void **p);
-void dx_prof_begin(dx_ctx *ctx, int kernel);
-void dx_prof_end(dx_ctx *ctx);
+void dx_prof_begin_on(dx_ctx *ctx, int kernel, hipStream_t stream);
+void dx_prof_end_on(dx_ctx *ctx, hipStream_t stream);
+static inline void dx_prof_begin(dx_ctx *ctx, int kernel) { dx_prof_begin_on(ctx, kernel, ctx->stream); }
+static inline void dx_prof_end(dx_ctx *ctx)               { dx_prof_end_on(ctx, ctx->stream); }
 int  dx_grid_waves(dx_ctx *ctx, uint64_t n_units, int waves_per_cu);
 
 #define DX_HIP(ctx, call)                                                                   \
@@ -84,9 +88,10 @@ int  dx_grid_waves(dx_ctx *ctx, uint64_t n_units, int waves_per_cu);
      } while (0)
 
 // Launch `kern<<<grid, block, 0, ctx->stream>>>(...)` bracketed by profiling events.
-#define DX_LAUNCH(ctx, id, kern, grid, block, ...)                                          \
-  do { dx_prof_begin(ctx, id);                                                              \
-       hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);    \
-       dx_prof_end(ctx);                                                                    \
+#define DX_LAUNCH_ON(ctx, strm, id, kern, grid, block, ...)                                 \
+  do { dx_prof_begin_on(ctx, id, strm);                                                     \
+       hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, strm, __VA_ARGS__);             \
+       dx_prof_end_on(ctx, strm);                                                           \
        DX_HIP(ctx, hipGetLastError());                                                      \
      } while (0)
+#define DX_LAUNCH(ctx, id, kern, grid, block, ...) DX_LAUNCH_ON(ctx, (ctx)->stream, id, kern, grid, block, __VA_ARGS__)

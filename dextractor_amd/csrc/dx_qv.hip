@@ -1688,9 +1688,13 @@ int dx_scan_u32(dx_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out, 
       return DX_OK;
     }
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  uint64_t *d_tile;
-  DX_HIP(ctx, hipMalloc((void **) &d_tile, (ntiles + 2) * 8));
-  uint64_t *d_gran = d_tile + ntiles;
+  if (ntiles + 2 > ctx->scan_words)                      // grow-only: no allocation per call
+    { (void) hipFree(ctx->d_scan);
+      ctx->d_scan = NULL; ctx->scan_words = 0;
+      DX_HIP(ctx, hipMalloc((void **) &ctx->d_scan, (ntiles + 2) * 2 * 8));
+      ctx->scan_words = (ntiles + 2) * 2;
+    }
+  uint64_t *d_tile = ctx->d_scan, *d_gran = d_tile + ntiles;
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) ntiles, DX_BLOCK, d_in, n, d_tile);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, ntiles, d_gran);
   DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, d_in, n, (const uint64_t *) d_tile, d_out,
@@ -1698,7 +1702,6 @@ int dx_scan_u32(dx_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out, 
   uint64_t t = 0;
   DX_HIP(ctx, hipMemcpyAsync(&t, d_gran, 8, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  DX_HIP(ctx, hipFree(d_tile));
   if (total) *total = t;
   return DX_OK;
 }
@@ -1781,16 +1784,16 @@ static int fast_grid(dx_ctx *ctx, uint64_t entries)
 #define ONEPASS_REGION_CAP ((uint64_t) 32 << 30)          // bytes of one of the two scratch regions of dx_qv_encode_onepass
 
 // side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
-static int onepass_side(dx_ctx *ctx, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
+static int onepass_side(dx_ctx *ctx, hipStream_t B, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
                         uint64_t *d_rec_off, const uint64_t *base_in, uint64_t *base_out, const uint32_t *d_len,
                         const uint8_t *d_slots, const uint64_t *d_slot, const uint32_t *d_seg, const uint8_t *d_hdr,
                         const uint64_t *d_hdr_off, uint8_t *d_out, uint64_t out_cap, uint32_t *d_tick)
-{ DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, ctx->stream));
-  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) mt, DX_BLOCK, d_size, m, d_tile);
-  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, mt, d_gran);
-  DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply_base, (int) mt, DX_BLOCK, d_size, m, (const uint64_t *) d_tile, d_rec_off,
-            (const uint64_t *) d_gran, base_in, base_out);
-  DX_LAUNCH(ctx, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, COMPACT_WAVES_PER_CU), DX_BLOCK,
+{ DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, B));
+  DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_tiles, (int) mt, DX_BLOCK, d_size, m, d_tile);
+  DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, mt, d_gran);
+  DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_apply_base, (int) mt, DX_BLOCK, d_size, m, (const uint64_t *) d_tile, d_rec_off,
+               (const uint64_t *) d_gran, base_in, base_out);
+  DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, COMPACT_WAVES_PER_CU), DX_BLOCK,
             m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
             ctx->d_status, d_tick);
   return DX_OK;
@@ -1855,7 +1858,6 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
   DX_HIP(ctx, hipEventRecord(fork, A));
   DX_HIP(ctx, hipStreamWaitEvent(B, fork, 0));
   int rc = DX_OK;
-  ctx->stream = B;                                       // (the launch macro and its timing events follow ctx->stream)
   for (int g = 0; g < G && rc == DX_OK; g++)             // side stream: sizes and record offsets of every group, in order
     { const uint64_t g0 = gb[g], m = gb[g + 1] - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
       qv_args ag = a;
@@ -1864,51 +1866,48 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       const tok_src   tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
       rc = DX_E_HIP;
       if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
-      dx_prof_begin(ctx, DX_K_QV_SIZES);
+      dx_prof_begin_on(ctx, DX_K_QV_SIZES, B);
       hipLaunchKernelGGL(k_qv_sizes_fast, dim3(fast_grid(ctx, (m + TICKET_BATCH - 1) / TICKET_BATCH)), dim3(FAST_BLOCK), 0, B,
                          ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz, tg);
-      dx_prof_end(ctx);
+      dx_prof_end_on(ctx, B);
       if (odd)
         { if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
-          dx_prof_begin(ctx, DX_K_QV_SIZES);
+          dx_prof_begin_on(ctx, DX_K_QV_SIZES, B);
           hipLaunchKernelGGL(k_qv_sizes, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * SIZES_WAVES)),
                              dim3(DX_BLOCK), 0, B, ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz,
                              (const uint32_t *) ctx->tk.list, (const unsigned long long *) ctx->tk.count, g0,
                              (const uint32_t *) (ctx->tk.info + 4 * g0));
-          dx_prof_end(ctx);
+          dx_prof_end_on(ctx, B);
         }
-      dx_prof_begin(ctx, DX_K_SCAN);
+      dx_prof_begin_on(ctx, DX_K_SCAN, B);
       hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned) mt), dim3(DX_BLOCK), 0, B, (const uint32_t *) (d_size + g0), m, d_tile);
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(DX_BLOCK), 0, B, d_tile, mt, d_gran);
       hipLaunchKernelGGL(k_scan_apply_base, dim3((unsigned) mt), dim3(DX_BLOCK), 0, B, (const uint32_t *) (d_size + g0), m,
                          (const uint64_t *) d_tile, d_rec_off + g0, (const uint64_t *) d_gran,
                          (const uint64_t *) (d_base + (g & 1)), d_base + ((g + 1) & 1));
-      dx_prof_end(ctx);
+      dx_prof_end_on(ctx, B);
       if (hipGetLastError() != hipSuccess || hipEventRecord(sz_done[g & 7], B) != hipSuccess) break;
       // context's stream: the group's records, in place
       if (hipStreamWaitEvent(A, sz_done[g & 7], 0) != hipSuccess || hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
-      ctx->stream = A;
-      dx_prof_begin(ctx, DX_K_QV_ENCODE);
+      dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
       hipLaunchKernelGGL(k_qv_encode_fast, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
                          ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
                          ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
                          (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap);
-      dx_prof_end(ctx);
+      dx_prof_end_on(ctx, A);
       if (odd)
-        { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) { ctx->stream = B; break; }
-          dx_prof_begin(ctx, DX_K_QV_ENCODE);
+        { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
+          dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
           hipLaunchKernelGGL(k_qv_encode, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * ENC_WAVES)),
                              dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
                              (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
                              d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, (const uint32_t *) ctx->tk.list,
                              (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + 4 * g0), out_cap);
-          dx_prof_end(ctx);
+          dx_prof_end_on(ctx, A);
         }
-      ctx->stream = B;
       if (hipGetLastError() != hipSuccess) break;
       rc = DX_OK;
     }
-  ctx->stream = A;
   (void) hipEventRecord(join, B);
   (void) hipStreamWaitEvent(A, join, 0);                 // the caller's stream sees everything finished
   uint64_t tot = 0;
@@ -2069,10 +2068,8 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction
       DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g & 7], 0));
-      ctx->stream = B;                                   // (the launch macro and its timing events follow ctx->stream)
-      rc = onepass_side(ctx, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
+      rc = onepass_side(ctx, B, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
                         b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp);
-      ctx->stream = A;
       (void) hipEventRecord(cmp_done[g & 7], B);
       ng += 1;
     }

@@ -325,10 +325,15 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
 //    make four registers that leave as one 16-byte store; a refill (one word) is needed about every 9th code;
 //  * a block of 16 symbols in which any lane meets a code beyond the primary index is decoded again, symbol
 //    by symbol, from the saved reader state.
+#ifndef DP_BLOCK
 #define DP_BLOCK   1024                                    // 16 waves: rings 100 KB + tables 36 KB of LDS
+#endif
 #define DP_NWAVE   (DP_BLOCK / 64)
+#ifndef DP_RING
 #define DP_RING    24                                      // dwords per lane: three half-lines
-#define DP_STRIDE  25                                      // row stride in dwords (rows spread over the banks)
+#endif
+#define DP_WG_PER_CU ((160 * 1024) / ((DP_BLOCK * (DP_RING + 1) * 4) + 37 * 1024))   // rings + 36.6 KB of tables
+#define DP_STRIDE  (DP_RING + 1)                           // row stride in dwords (rows spread over the banks)
 
 struct linerd
 { const uint8_t *next;           // next aligned half-line (32 bytes) to fetch
@@ -364,7 +369,7 @@ __device__ __forceinline__ void lr_store(linerd &r, const half32 &v)
 // fetches a half-line (two 16-byte loads) before the block and stores it behind the block, where at most 16 are
 // unread for sure (the ring holds 24); one with more does not, and has >= 13 left behind the block.  So a block
 // starts with >= 13 unread dwords, always.
-__device__ __forceinline__ bool lr_wants(const linerd &r) { return r.halves != 0u && r.avail <= 16u; }
+__device__ __forceinline__ bool lr_wants(const linerd &r) { return r.halves != 0u && r.avail <= DP_RING - 8u; }
 
 __device__ __forceinline__ uint32_t lr_next(linerd &r)      // next dword of the ring
 { const uint32_t v = r.ring[r.ri];
@@ -381,7 +386,7 @@ __device__ __forceinline__ void lr_init(linerd &r, const uint8_t *seg, uint32_t 
   r.o      = (uint32_t) (A & 3u);
   r.hi = r.lo = 0; r.nb = 0;
   #pragma unroll
-  for (int k = 0; k < 3; k++)                              // the ring starts full
+  for (int k = 0; k < DP_RING / 8; k++)                    // the ring starts full
     if (r.halves) { const half32 v = lr_load(r); lr_store(r, v); }
   r.ri    = (uint32_t) ((A & 31u) >> 2);                   // dword of the first half-line the stream starts in
   r.avail = r.avail > r.ri ? r.avail - r.ri : 0u;
@@ -667,7 +672,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   DX_HIP(ctx, hipMemsetAsync(d_next2, 0, 4, ctx->stream));
   if (plain)
     { uint64_t pb = (4 * ((n + 63) / 64) + DP_NWAVE - 1) / DP_NWAVE;
-      if (pb > cap) pb = cap;
+      if (pb > cap * DP_WG_PER_CU) pb = cap * DP_WG_PER_CU;
       DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_plain, (int) pb, DP_BLOCK, a, (const uint16_t *) ctx->d_dec,
                 (const uint32_t *) ctx->d_long, d_next2, plain);
     }
