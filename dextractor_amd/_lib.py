@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DEXGPU_LIB") or os.path.join(HERE, "libdexgpu.so")   
 
 DX_OK = 0
 ERR_NAMES = {-1: "DX_E_ARG", -2: "DX_E_HIP", -3: "DX_E_FORMAT", -4: "DX_E_DEGENERATE",
-             -5: "DX_E_UNSUPPORTED", -6: "DX_E_NOMEM", -7: "DX_E_MISMATCH", -8: "DX_E_SPACE"}
+             -5: "DX_E_UNSUPPORTED", -6: "DX_E_NOMEM", -7: "DX_E_MISMATCH", -8: "DX_E_SPACE", -9: "DX_E_IO"}
 
 DX_ALPHA_BASES, DX_ALPHA_ARROW = 0, 1
 DX_LETTERS_LOWER, DX_LETTERS_UPPER, DX_LETTERS_ARROW = 0, 1, 2
@@ -50,6 +50,7 @@ class QVIndex(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/dexgpu.h declares
 _P = C.c_void_p
+SINK_FN = C.CFUNCTYPE(C.c_int, _P, C.POINTER(C.c_uint8), C.c_size_t, C.c_size_t)     # dx_sink_fn
 SIGNATURES = {
     "dx_device_count": (C.c_int, []),
     "dx_open": (C.c_int, [C.c_int, C.POINTER(_P)]),
@@ -109,6 +110,12 @@ SIGNATURES = {
     "dx_file_pack2_sharded": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dx_file_undexqv": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "dx_file_dexqv_to": (C.c_int, [_P, _P, C.c_size_t, C.c_int, SINK_FN, _P, C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "dx_file_undexqv_plan": (C.c_int, [_P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "dx_file_undexqv_run": (C.c_int, [_P, _P, C.c_int, SINK_FN, _P]),
+    "dx_file_undexqv_plan_free": (None, [_P]),
+    "dx_d2h_stream": (C.c_int, [_P, _P, C.c_size_t, SINK_FN, _P]),
     "dx_file_free": (None, [_P]),
     "dx_entries_new": (_P, []),
     "dx_entries_free": (None, [_P]),

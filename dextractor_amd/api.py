@@ -240,6 +240,31 @@ class Context:
     def undexqv(self, img: bytes, upper=False) -> bytes:
         return self._file_call(self.lib.dx_file_undexqv, img, len(img), int(upper))
 
+    def dexqv_stream(self, quiva: bytes, sink, lossy=False) -> int:
+        """dx_file_dexqv_to: sink(data: bytes, at: int) -> falsy to go on; returns the image's size."""
+        total, line, code = C.c_size_t(), C.c_uint64(), C.c_int()
+        cb = L.SINK_FN(lambda user, data, n, at: 1 if sink(C.string_at(data, n), at) else 0)
+        rc = self.lib.dx_file_dexqv_to(self.h, quiva, len(quiva), int(lossy), cb, None, C.byref(total),
+                                       C.byref(line), C.byref(code))
+        if rc != 0:
+            raise L.DexGPUError(rc, f"line {line.value} (DX_IDX code {code.value}): " + (self.lib.dx_last_error(self.h) or b"").decode())
+        return total.value
+
+    def undexqv_stream(self, img: bytes, sink, upper=False) -> int:
+        """dx_file_undexqv_plan + dx_file_undexqv_run: sink(data: bytes, at: int) -> falsy to go on; returns the
+        text's size.  (The plan alone -- the host walk -- is `undexqv_plan_size`, which needs no GPU.)"""
+        plan, total = C.c_void_p(), C.c_size_t()
+        keep = C.create_string_buffer(img, len(img))              # must outlive the run
+        rc = self.lib.dx_file_undexqv_plan(keep, len(img), C.byref(plan), C.byref(total))
+        if rc != 0:
+            raise L.DexGPUError(rc, "dx_file_undexqv_plan")
+        try:
+            cb = L.SINK_FN(lambda user, data, n, at: 1 if sink(C.string_at(data, n), at) else 0)
+            self._chk(self.lib.dx_file_undexqv_run(self.h, plan, int(upper), cb, None))
+        finally:
+            self.lib.dx_file_undexqv_plan_free(plan)
+        return total.value
+
 
 def dexqv_sharded(contexts, quiva: bytes, lossy=False) -> bytes:
     """One .quiva file over several contexts/GPUs (dx_file_dexqv_sharded)."""
@@ -383,3 +408,14 @@ def index_seq(text: bytes, arrow=False):
     lib.dx_index_seq(int(arrow), text, len(text), n, off.ctypes.data, tl.ctypes.data, ns.ctypes.data,
                      hdr.ctypes.data, cnr.ctypes.data, C.byref(cnt), C.byref(pl), C.byref(line), C.byref(code))
     return off, tl, ns, hdr, cnr, pl.value
+
+
+def undexqv_plan_size(img: bytes) -> int:
+    """Size of the text dx_file_undexqv would produce, from the host walk alone (no GPU, no context)."""
+    lib = L.load()
+    plan, total = C.c_void_p(), C.c_size_t()
+    rc = lib.dx_file_undexqv_plan(img, len(img), C.byref(plan), C.byref(total))
+    if rc != 0:
+        raise L.DexGPUError(rc, "dx_file_undexqv_plan")
+    lib.dx_file_undexqv_plan_free(plan)
+    return total.value

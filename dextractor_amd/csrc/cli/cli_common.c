@@ -10,6 +10,7 @@
 #include <pthread.h>
 #include <sys/stat.h>
 #include <sys/mman.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -85,9 +86,11 @@ static uint8_t *slurp(FILE *f, size_t *n, int *mapped)
 }
 
 /* The whole output image to a regular file: large images through a shared mapping of the file that several
-   threads fill, a slice each (writes into the page cache or tmpfs are memory copies plus page allocation;
-   write() calls on one file queue up behind its inode lock, page faults on a mapping do not); pipes, small
-   outputs and anything that cannot be mapped by fwrite.  0 on success.                                  */
+   threads fill, a slice each (write() calls on one file queue up behind its inode lock, page faults on a
+   mapping do not).  The file's pages are allocated first, in one posix_fallocate call: threads that fault
+   fresh pages into one file contend for its page-cache lock (1 GiB to tmpfs, 8 threads: 2.6 s; allocated
+   first: 0.09 s + 0.12 s of copying), and a full file system is an error return instead of a SIGBUS.
+   Pipes, small outputs and anything that cannot be mapped go by fwrite.  0 on success.                    */
 typedef struct { uint8_t *dst; const uint8_t *src; size_t n; } wjob;
 
 static void *copy_slice(void *arg)
@@ -103,7 +106,8 @@ static int write_image(FILE *f, const uint8_t *buf, size_t n)
   off_t base;
   uint8_t *map;
   if (n < ((size_t) 32 << 20) || T < 2 || fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || fflush(f) != 0 ||
-      (base = lseek(fileno(f), 0, SEEK_CUR)) != 0 || ftruncate(fileno(f), (off_t) n) != 0)
+      (base = lseek(fileno(f), 0, SEEK_CUR)) != 0 || posix_fallocate(fileno(f), 0, (off_t) n) != 0 ||
+      ftruncate(fileno(f), (off_t) n) != 0)
     return (n > 0 && fwrite(buf, 1, n, f) != n) ? -1 : 0;
   map = mmap(NULL, n, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(f), 0);
   if (map == MAP_FAILED)
@@ -190,6 +194,8 @@ static void report_text_error(int tool, uint64_t line, int code)
 static dx_ctx *Ctxs[64];     /* DEXGPU_DEVICES: one context per listed GPU; a file's entries are sharded over them */
 static int     Nctx = 0;
 
+static int report_failure(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, int rc, uint64_t line, int code);
+
 static int convert(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, int opt_U, int opt_l, int width,
                    uint8_t **out, size_t *out_len)
 { uint64_t line = 0;
@@ -207,9 +213,28 @@ static int convert(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, int opt_U
       case TOOL_DEXQV:   rc = dx_file_dexqv(ctx, in, n, opt_l, out, out_len, &line, &code); break;
       default:           rc = dx_file_undexqv(ctx, in, n, opt_U, out, out_len); break;
     }
-  if (rc == DX_OK)
-    return 0;
-  if (rc == DX_E_FORMAT && (tool == TOOL_DEXTA || tool == TOOL_DEXAR || tool == TOOL_DEXQV))
+  return rc == DX_OK ? 0 : report_failure(ctx, tool, in, n, rc, line, code);
+}
+
+/* sinks of dx_file_undexqv_run: the output file at its offset / a buffer */
+static int sink_pwrite(void *user, uint8_t *data, size_t len, size_t at)
+{ const int fd = *(int *) user;
+  size_t done = 0;
+  while (done < len)
+    { ssize_t k = pwrite(fd, data + done, len - done, (off_t) (at + done));
+      if (k <= 0) return 1;
+      done += (size_t) k;
+    }
+  return 0;
+}
+
+static int sink_memory(void *user, uint8_t *data, size_t len, size_t at)
+{ memcpy((uint8_t *) user + at, data, len);
+  return 0;
+}
+
+static int report_failure(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, int rc, uint64_t line, int code)
+{ if (rc == DX_E_FORMAT && (tool == TOOL_DEXTA || tool == TOOL_DEXAR || tool == TOOL_DEXQV))
     { report_text_error(tool, line, code);
       return 1;
     }
@@ -389,6 +414,46 @@ int dex_tool_main(int tool, int argc, char *argv[])
 
       in = slurp(input, &n, &mapped);
       tmark("input read");
+      if (tool == TOOL_UNDEXQV && in != NULL && Nctx <= 1)
+        { /* The text goes from the GPU into the output file chunk by chunk (no image of it in this process):
+             its size comes from the host walk over the record stream, which runs while the GPU context is
+             still being opened, and so does the allocation of the file's pages. */
+          dx_undexqv_plan *plan = NULL;
+          struct stat      os;
+          int              rc = dx_file_undexqv_plan(in, n, &plan, &out_len), direct, fd = fileno(output);
+          tmark("records walked");
+          if (rc == DX_OK)
+            { direct = fflush(output) == 0 && fstat(fd, &os) == 0 && S_ISREG(os.st_mode) && lseek(fd, 0, SEEK_CUR) == 0 &&
+                       (out_len == 0 || posix_fallocate(fd, 0, (off_t) out_len) == 0) && ftruncate(fd, (off_t) out_len) == 0;
+              tmark("output file allocated");
+              if (Opening)
+                { pthread_join(Opener, NULL);
+                  Opening = 0;
+                }
+              ctx = Ctx0;
+              tmark("GPU context open");
+              if (direct)
+                { rc = dx_file_undexqv_run(ctx, plan, UPPER, sink_pwrite, &fd);
+                  if (rc == DX_OK && lseek(fd, (off_t) out_len, SEEK_SET) < 0) rc = DX_E_IO;
+                }
+              else                                        /* a pipe: through memory */
+                { out = malloc(out_len + 16);
+                  rc  = out == NULL ? DX_E_NOMEM : dx_file_undexqv_run(ctx, plan, UPPER, sink_memory, out);
+                  if (rc == DX_OK && out_len > 0 && fwrite(out, 1, out_len, output) != out_len) rc = DX_E_IO;
+                  free(out);
+                }
+              dx_file_undexqv_plan_free(plan);
+            }
+          if (rc == DX_E_IO)
+            { fprintf(stderr, "%s: System error, write failed!\n", Prog);
+              leave(2);
+            }
+          if (rc != DX_OK)
+            leave(report_failure(Ctx0, tool, in, n, rc, 0, 0));
+          unslurp(in, n, mapped);
+          tmark("output written");
+          goto written;
+        }
       if (Opening)
         { pthread_join(Opener, NULL);
           Opening = 0;
@@ -398,6 +463,25 @@ int dex_tool_main(int tool, int argc, char *argv[])
       if (in == NULL)
         { fprintf(stderr, "%s: Out of memory (Allocating read buffer)\n", Prog);
           leave(1);
+        }
+      if (tool == TOOL_DEXQV && Nctx <= 1)
+        { /* the .dexqv image goes from the GPU into the output file chunk by chunk, if that is a regular file */
+          struct stat os;
+          int         fd = fileno(output);
+          if (fflush(output) == 0 && fstat(fd, &os) == 0 && S_ISREG(os.st_mode) && lseek(fd, 0, SEEK_CUR) == 0)
+            { uint64_t line = 0;
+              int      code = 0, rc = dx_file_dexqv_to(ctx, in, n, LOSSY, sink_pwrite, &fd, &out_len, &line, &code);
+              if (rc == DX_OK && lseek(fd, (off_t) out_len, SEEK_SET) < 0) rc = DX_E_IO;
+              if (rc == DX_E_IO)
+                { fprintf(stderr, "%s: System error, write failed!\n", Prog);
+                  leave(2);
+                }
+              if (rc != DX_OK)
+                leave(report_failure(ctx, tool, in, n, rc, line, code));
+              unslurp(in, n, mapped);
+              tmark("output written");
+              goto written;
+            }
         }
       st = convert(ctx, tool, in, n, UPPER, LOSSY, width, &out, &out_len);
       if (st != 0)
@@ -410,6 +494,7 @@ int dex_tool_main(int tool, int argc, char *argv[])
       dx_file_free(out);
       unslurp(in, n, mapped);
       tmark("output written");
+written:
 
       if (!PIPE)
         { fclose(input);

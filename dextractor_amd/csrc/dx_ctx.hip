@@ -1,5 +1,6 @@
 // dx_ctx.hip -- context, device memory and per-kernel timing plumbing of libdexgpu.
 #include "dx_internal.hpp"
+#include <pthread.h>
 
 #include <stdlib.h>
 
@@ -49,6 +50,7 @@ extern "C" int dx_open(int device, dx_ctx **out)
   ctx->scratch_bytes = 0;
   ctx->d_scan = NULL;
   ctx->scan_words = 0;
+  ctx->h_stage[0] = ctx->h_stage[1] = NULL;
   memset(&ctx->tk, 0, sizeof(ctx->tk));
 
 #define OPEN_HIP(call)                                                                       \
@@ -96,6 +98,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);
   (void) hipFree(ctx->d_scan);
+  if (ctx->h_stage[0]) (void) hipHostFree(ctx->h_stage[0]);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
@@ -150,6 +153,90 @@ extern "C" int dx_d2h(dx_ctx *ctx, void *dst, const void *d_src, size_t bytes)
   DX_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return DX_OK;
+}
+
+// ---- dx_d2h_stream: chunks through two pinned buffers, a helper thread feeding the sink ----------
+#define DX_STAGE_BYTES ((size_t) 32 << 20)
+
+struct stream_job
+{ pthread_mutex_t mx;
+  pthread_cond_t  cv;
+  uint8_t        *buf[2];
+  size_t          len[2], at[2];
+  int             full[2];        // slot holds a chunk the sink has not taken yet
+  int             done, failed;   // producer finished; the sink said stop
+  dx_sink_fn      sink;
+  void           *user;
+};
+
+static void *stream_consumer(void *arg)
+{ stream_job *j = (stream_job *) arg;
+  for (int slot = 0; ; slot ^= 1)
+    { pthread_mutex_lock(&j->mx);
+      while (!j->full[slot] && !j->done) pthread_cond_wait(&j->cv, &j->mx);
+      const bool have = j->full[slot] != 0;
+      pthread_mutex_unlock(&j->mx);
+      if (!have) break;                                    // done, and nothing left in this slot: chunks come in slot order
+      const int bad = j->failed ? 0 : j->sink(j->user, j->buf[slot], j->len[slot], j->at[slot]);
+      pthread_mutex_lock(&j->mx);
+      if (bad) j->failed = 1;
+      j->full[slot] = 0;
+      pthread_cond_broadcast(&j->cv);
+      pthread_mutex_unlock(&j->mx);
+    }
+  return NULL;
+}
+
+extern "C" int dx_d2h_stream(dx_ctx *ctx, const void *d_src, size_t bytes, dx_sink_fn sink, void *user)
+{ if (ctx == NULL || sink == NULL || (bytes && d_src == NULL)) return DX_E_ARG;
+  if (bytes == 0) return DX_OK;
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->h_stage[0] == NULL)
+    { void *h = NULL;
+      if (hipHostMalloc(&h, 2 * DX_STAGE_BYTES, hipHostMallocDefault) != hipSuccess)
+        return dx_fail(ctx, DX_E_NOMEM, "dx_d2h_stream: no pinned staging memory");
+      ctx->h_stage[0] = (uint8_t *) h;
+      ctx->h_stage[1] = (uint8_t *) h + DX_STAGE_BYTES;
+    }
+  stream_job j;
+  pthread_mutex_init(&j.mx, NULL);
+  pthread_cond_init(&j.cv, NULL);
+  j.buf[0] = ctx->h_stage[0]; j.buf[1] = ctx->h_stage[1];
+  j.full[0] = j.full[1] = 0; j.done = 0; j.failed = 0; j.sink = sink; j.user = user;
+  pthread_t th;
+  const bool threaded = pthread_create(&th, NULL, stream_consumer, &j) == 0;
+  int    rc = DX_OK, slot = 0;
+  for (size_t at = 0; at < bytes && rc == DX_OK; at += DX_STAGE_BYTES, slot ^= 1)
+    { const size_t len = bytes - at < DX_STAGE_BYTES ? bytes - at : DX_STAGE_BYTES;
+      pthread_mutex_lock(&j.mx);
+      while (j.full[slot]) pthread_cond_wait(&j.cv, &j.mx);          // the sink is done with this buffer
+      const int failed = j.failed;
+      pthread_mutex_unlock(&j.mx);
+      if (failed) break;
+      if (hipMemcpyAsync(j.buf[slot], (const uint8_t *) d_src + at, len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        { rc = dx_fail(ctx, DX_E_HIP, "dx_d2h_stream: copy failed (%s)", hipGetErrorString(hipGetLastError()));
+          break;
+        }
+      if (!threaded)                                       // no helper thread to be had: in line
+        { if (sink(user, j.buf[slot], len, at)) j.failed = 1;
+          continue;
+        }
+      pthread_mutex_lock(&j.mx);
+      j.len[slot] = len; j.at[slot] = at; j.full[slot] = 1;
+      pthread_cond_broadcast(&j.cv);
+      pthread_mutex_unlock(&j.mx);
+    }
+  pthread_mutex_lock(&j.mx);
+  j.done = 1;
+  pthread_cond_broadcast(&j.cv);
+  pthread_mutex_unlock(&j.mx);
+  if (threaded) pthread_join(th, NULL);
+  pthread_cond_destroy(&j.cv);
+  pthread_mutex_destroy(&j.mx);
+  if (rc == DX_OK && j.failed)
+    rc = dx_fail(ctx, DX_E_IO, "dx_d2h_stream: the sink refused data");
+  return rc;
 }
 
 extern "C" int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes)

@@ -433,8 +433,16 @@ done:
 /* ==========================================================================================
  *  dexqv
  * ========================================================================================== */
-int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
-                  uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
+/* a sink that sees its chunks `shift` bytes further on (the record stream follows the file's head) */
+typedef struct { dx_sink_fn sink; void *user; size_t shift; } shifted_sink;
+static int pass_shifted(void *arg, uint8_t *data, size_t len, size_t at)
+{ shifted_sink *h = arg;
+  return h->sink(h->user, data, len, at + h->shift);
+}
+
+/* out != NULL: the image in memory; else through the sink, in order, nothing before all of it is known to exist */
+static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uint8_t **out, dx_sink_fn sink, void *user,
+                      size_t *out_len, uint64_t *errline, int *errcode)
 { dpool        pool = { {0}, 0, ctx };
   uint64_t     cnt = 0, *off = NULL, *hoff = NULL, total = 0, tot = 0;
   uint32_t    *len = NULL;
@@ -448,8 +456,9 @@ int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
   void        *d_text, *d_off = NULL, *d_len = NULL, *d_hdr, *d_hoff, *d_rec, *d_seg, *d_out;
   int          rc;
 
-  if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
-  *out = NULL; *out_len = 0;
+  if (ctx == NULL || (out == NULL && sink == NULL) || out_len == NULL) return DX_E_ARG;
+  if (out) *out = NULL;
+  *out_len = 0;
 
   /* pass 1 of the reference (QVcoding_Scan, dexqv.c:81-82): validate + index.  Large images are
    * indexed on the GPU (newline scan + structure checks there, only the header lines come back);
@@ -522,14 +531,22 @@ int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
       TRY(dalloc(&pool, total, &d_out));
       TRY(dx_qv_encode(ctx, &b, d_hdr, d_hoff, d_rec, d_seg, d_out));
     }
-  img = malloc(head + total + 16);
+  img = malloc(head + (out ? total : 0) + 16);
   if (!img) { rc = DX_E_NOMEM; goto done; }
   { uint16_t key = 0x55aa;                                                 /* dexqv.c:105-108 */
     memcpy(img, &key, 2);
     TRY(dx_qv_write_coding(cd, (const char *) text, plen, img + 2, clen, &clen));
   }
-  TRY(dx_d2h(ctx, img + head, d_out, total));
-  *out = img; *out_len = head + total; img = NULL;
+  if (out)
+    { TRY(dx_d2h(ctx, img + head, d_out, total));
+      *out = img; img = NULL;
+    }
+  else
+    { shifted_sink h = { sink, user, head };
+      if (sink(user, img, head, 0)) { rc = DX_E_IO; goto done; }
+      TRY(dx_d2h_stream(ctx, d_out, total, pass_shifted, &h));
+    }
+  *out_len = head + total;
   rc = DX_OK;
 
 done:
@@ -538,63 +555,142 @@ done:
   return rc;
 }
 
+int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
+                  uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
+{ if (out == NULL) return DX_E_ARG;
+  return dexqv_core(ctx, text, n, lossy, out, NULL, NULL, out_len, errline, errcode);
+}
+
+int dx_file_dexqv_to(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, dx_sink_fn sink, void *user,
+                     size_t *out_len, uint64_t *errline, int *errcode)
+{ if (sink == NULL) return DX_E_ARG;
+  return dexqv_core(ctx, text, n, lossy, NULL, sink, user, out_len, errline, errcode);
+}
+
 /* ==========================================================================================
  *  undexqv
  * ========================================================================================== */
+/* undexqv in two steps (dexgpu.h): the plan is host work only, the run is the GPU's */
+struct dx_undexqv_plan
+  { const uint8_t *img;
+    size_t         n, total;
+    dx_qv_index    x;
+    tbuf           hd;            /* the header lines, one after the other */
+    uint64_t      *ooff, *hat;    /* per entry: where its five data lines start in the text; where its header line starts in hd */
+  };
+
+void dx_file_undexqv_plan_free(dx_undexqv_plan *p)
+{ if (p == NULL) return;
+  dx_qv_index_free(&p->x);
+  free(p->ooff); free(p->hat); free(p->hd.p);
+  free(p);
+}
+
+int dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len)
+{ dx_undexqv_plan *p;
+  size_t   plen, total = 0;
+  uint64_t i;
+  int      rc;
+
+  if (img == NULL || plan == NULL || out_len == NULL) return DX_E_ARG;
+  *plan = NULL; *out_len = 0;
+  p = calloc(1, sizeof(*p));
+  if (p == NULL) return DX_E_NOMEM;
+  rc = dx_qv_walk(img, n, &p->x);                         /* boundary walk (host) */
+  if (rc != DX_OK) { free(p); return rc; }
+  p->img = img; p->n = n;
+  plen = strlen(p->x.prefix);
+  p->ooff = malloc((p->x.n + 1) * sizeof(*p->ooff));
+  p->hat  = malloc((p->x.n + 1) * sizeof(*p->hat));
+  if (!p->ooff || !p->hat) { rc = DX_E_NOMEM; goto fail; }
+  for (i = 0; i < p->x.n; i++)                            /* header lines, undexqv.c:182 */
+    { const int32_t *h = p->x.hdr4 + 4*i;
+      if ((rc = tb_room(&p->hd, plen + 80)) != DX_OK) goto fail;
+      p->hat[i]  = p->hd.len;
+      p->hd.len += (size_t) sprintf(p->hd.p + p->hd.len, "%s/%d/%d_%d RQ=0.%d\n", p->x.prefix, h[0], h[1], h[2], h[3]);
+      total     += p->hd.len - (size_t) p->hat[i];
+      p->ooff[i] = total;
+      total     += 5 * ((size_t) p->x.len[i] + 1);        /* undexqv.c:206-207 */
+    }
+  p->hat[p->x.n] = p->hd.len;
+  p->ooff[p->x.n] = total;
+  p->total = total;
+  *plan = p; *out_len = total;
+  return DX_OK;
+
+fail:
+  dx_file_undexqv_plan_free(p);
+  return rc;
+}
+
+/* a chunk of the decoded text on its way out: the header lines that fall into it are laid over it */
+typedef struct { const dx_undexqv_plan *p; dx_sink_fn sink; void *user; } hdr_patch;
+
+static int patch_and_pass(void *arg, uint8_t *data, size_t len, size_t at)
+{ hdr_patch *h = arg;
+  const dx_undexqv_plan *p = h->p;
+  uint64_t lo = 0, hi = p->x.n, i;
+  while (lo < hi)                                         /* first entry whose data lines start beyond `at` */
+    { uint64_t mid = (lo + hi) / 2;
+      if (p->ooff[mid] > at) hi = mid; else lo = mid + 1;
+    }
+  for (i = lo; i < p->x.n; i++)
+    { const size_t hl = (size_t) (p->hat[i+1] - p->hat[i]), h0 = (size_t) p->ooff[i] - hl, h1 = (size_t) p->ooff[i];
+      const size_t c0 = h0 > at ? h0 : at, c1 = h1 < at + len ? h1 : at + len;
+      if (h0 >= at + len) break;
+      if (c0 < c1)
+        memcpy(data + (c0 - at), p->hd.p + p->hat[i] + (c0 - h0), c1 - c0);
+    }
+  return h->sink(h->user, data, len, at);
+}
+
+int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sink_fn sink, void *user)
+{ dpool     pool = { {0}, 0, ctx };
+  void     *d_in, *d_rec, *d_hoff, *d_seg, *d_len, *d_out, *d_ooff;
+  hdr_patch h = { p, sink, user };
+  int       rc = DX_OK;
+
+  if (ctx == NULL || p == NULL || sink == NULL) return DX_E_ARG;
+  if (p->x.n > 0)
+    { TRY(dx_qv_set_coding(ctx, &p->x.coding, 0));
+      TRY(dupload(&pool, p->img, p->n, &d_in));
+      TRY(dupload(&pool, p->x.rec_off, (p->x.n + 1) * 8, &d_rec));
+      TRY(dupload(&pool, p->x.hdr_off, (p->x.n + 1) * 8, &d_hoff));
+      TRY(dupload(&pool, p->x.seg, p->x.n * 5 * 4, &d_seg));
+      TRY(dupload(&pool, p->x.len, p->x.n * 4, &d_len));
+      TRY(dupload(&pool, p->ooff, p->x.n * 8, &d_ooff));
+      TRY(dalloc(&pool, p->total, &d_out));
+      TRY(dx_qv_decode(ctx, d_in, d_rec, d_hoff, d_seg, d_len, p->x.n,
+                       (upper ? DX_DECODE_UPPER : 0) | (p->x.flip ? DX_DECODE_FLIP : 0), d_out, d_ooff));
+      TRY(dx_d2h_stream(ctx, d_out, p->total, patch_and_pass, &h));
+    }
+done:
+  dfree_all(&pool);
+  return rc;
+}
+
+typedef struct { uint8_t *res; } mem_sink;
+static int to_memory(void *user, uint8_t *data, size_t len, size_t at)
+{ memcpy(((mem_sink *) user)->res + at, data, len);
+  return 0;
+}
+
 int dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper, uint8_t **out, size_t *out_len)
-{ dpool       pool = { {0}, 0, ctx };
-  dx_qv_index x;
-  tbuf        hd = { NULL, 0, 0 };
-  uint64_t   *ooff = NULL, *hat = NULL, i;
-  uint8_t    *res = NULL;
-  size_t      total = 0, plen;
-  void       *d_in, *d_rec, *d_hoff, *d_seg, *d_len, *d_out, *d_ooff;
-  int         rc;
+{ dx_undexqv_plan *p = NULL;
+  mem_sink m = { NULL };
+  size_t   total = 0;
+  int      rc;
 
   if (ctx == NULL || out == NULL || out_len == NULL || img == NULL) return DX_E_ARG;
   *out = NULL; *out_len = 0;
-  rc = dx_qv_walk(img, n, &x);                            /* sequential boundary walk (host) */
+  rc = dx_file_undexqv_plan(img, n, &p, &total);
   if (rc != DX_OK) return rc;
-  plen = strlen(x.prefix);
-
-  ooff = malloc((x.n + 1) * sizeof(*ooff));
-  hat  = malloc((x.n + 1) * sizeof(*hat));
-  if (!ooff || !hat) { rc = DX_E_NOMEM; goto done; }
-  for (i = 0; i < x.n; i++)                               /* header lines, undexqv.c:182 */
-    { const int32_t *h = x.hdr4 + 4*i;
-      if ((rc = tb_room(&hd, plen + 80)) != DX_OK) goto done;
-      hat[i]  = hd.len;
-      hd.len += (size_t) sprintf(hd.p + hd.len, "%s/%d/%d_%d RQ=0.%d\n", x.prefix, h[0], h[1], h[2], h[3]);
-      total  += hd.len - (size_t) hat[i];
-      ooff[i] = total;
-      total  += 5 * ((size_t) x.len[i] + 1);              /* undexqv.c:206-207 */
-    }
-  hat[x.n] = hd.len;
-  res = malloc(total + 16);
-  if (!res) { rc = DX_E_NOMEM; goto done; }
-
-  if (x.n > 0)
-    { TRY(dx_qv_set_coding(ctx, &x.coding, 0));
-      TRY(dupload(&pool, img, n, &d_in));
-      TRY(dupload(&pool, x.rec_off, (x.n + 1) * 8, &d_rec));
-      TRY(dupload(&pool, x.hdr_off, (x.n + 1) * 8, &d_hoff));
-      TRY(dupload(&pool, x.seg, x.n * 5 * 4, &d_seg));
-      TRY(dupload(&pool, x.len, x.n * 4, &d_len));
-      TRY(dupload(&pool, ooff, x.n * 8, &d_ooff));
-      TRY(dalloc(&pool, total, &d_out));
-      TRY(dx_qv_decode(ctx, d_in, d_rec, d_hoff, d_seg, d_len, x.n,
-                       (upper ? DX_DECODE_UPPER : 0) | (x.flip ? DX_DECODE_FLIP : 0), d_out, d_ooff));
-      TRY(dx_d2h(ctx, res, d_out, total));
-      for (i = 0; i < x.n; i++)
-        memcpy(res + ooff[i] - (hat[i+1] - hat[i]), hd.p + hat[i], (size_t) (hat[i+1] - hat[i]));
-    }
-  *out = res; *out_len = total; res = NULL;
-  rc = DX_OK;
-
-done:
-  dfree_all(&pool);
-  dx_qv_index_free(&x);
-  free(ooff); free(hat); free(hd.p); free(res);
+  m.res = malloc(total + 16);
+  if (m.res == NULL) rc = DX_E_NOMEM;
+  else               rc = dx_file_undexqv_run(ctx, p, upper, to_memory, &m);
+  if (rc == DX_OK) { *out = m.res; *out_len = total; }
+  else             free(m.res);
+  dx_file_undexqv_plan_free(p);
   return rc;
 }
 

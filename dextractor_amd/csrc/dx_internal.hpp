@@ -70,6 +70,7 @@ struct dx_ctx
   size_t    scratch_bytes;
   uint64_t *d_scan;            // grow-only tile sums of dx_scan_u32 (its callers hold d_scratch)
   size_t    scan_words;
+  uint8_t  *h_stage[2];        // pinned staging of dx_d2h_stream (made at its first call)
 };
 
 int  dx_fail(dx_ctx *ctx, int code, const char *fmt, ...);

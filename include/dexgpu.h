@@ -37,6 +37,7 @@ extern "C" {
 #define DX_E_NOMEM       (-6)
 #define DX_E_MISMATCH    (-7)   /* device-side consistency check failed (e.g. symbol count != expected) */
 #define DX_E_SPACE       (-8)   /* output buffer too small */
+#define DX_E_IO          (-9)   /* a caller's sink refused data (dx_d2h_stream) */
 
 typedef struct dx_ctx dx_ctx;
 
@@ -56,6 +57,13 @@ int dx_malloc(dx_ctx *ctx, size_t bytes, void **d_ptr);
 int dx_free  (dx_ctx *ctx, void *d_ptr);
 int dx_h2d   (dx_ctx *ctx, void *d_dst, const void *src, size_t bytes);   /* synchronous */
 int dx_d2h   (dx_ctx *ctx, void *dst, const void *d_src, size_t bytes);   /* synchronous */
+/* Device memory to a consumer on the host, in order, in chunks (32 MiB) through two pinned staging buffers the
+ * context owns: sink(user, data, len, at) is called on a helper thread for the bytes [at, at + len) while the
+ * next chunk is in flight; it may modify data[0 .. len) and returns 0, or nonzero to stop (DX_E_IO comes back).
+ * For outputs headed to a file: a pwrite per chunk costs no page fault in the caller's address space, where
+ * dx_d2h into fresh memory pays one per 4 KiB (0.25 s per GiB, single-threaded).                             */
+typedef int (*dx_sink_fn)(void *user, uint8_t *data, size_t len, size_t at);
+int dx_d2h_stream(dx_ctx *ctx, const void *d_src, size_t bytes, dx_sink_fn sink, void *user);
 int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes);
 
 /* Per-kernel device time, measured with HIP events on the context's stream around every launch
@@ -312,6 +320,11 @@ int  dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32
                      uint8_t **out, size_t *out_len);
 int  dx_file_dexqv  (dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
                      uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
+/* dx_file_dexqv with the .dexqv image delivered through a sink instead (the file's head, then the record stream
+ * in chunks: dx_d2h_stream), for a caller that writes it straight to a file.  The sink sees nothing unless the
+ * whole input was valid and encoded.                                                                       */
+int  dx_file_dexqv_to(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, dx_sink_fn sink, void *user,
+                      size_t *out_len, uint64_t *errline, int *errcode);
 /* dexqv of ONE file on several GPUs (one context each; contiguous entry ranges, one host thread per
  * context, scan state and 12 KB histograms merged on the host, outputs concatenated): identical
  * bytes to dx_file_dexqv.  nctx == 1 is dx_file_dexqv.                                          */
@@ -323,6 +336,15 @@ int  dx_file_pack2_sharded(dx_ctx **ctxs, int nctx, int arrow, const uint8_t *te
                            uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
 int  dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper,
                      uint8_t **out, size_t *out_len);                       /* undexqv.c:101-208 */
+/* The same in two steps, for a caller that wants the text somewhere else than in a malloc'd image (the CLI
+ * streams it into the output file).  The plan -- the host walk over the record stream (dx_qv_walk) and the
+ * header lines, undexqv.c:182 -- needs no GPU (it can run while a context is still being opened) and tells
+ * the output's size; the run decodes on the GPU and delivers the text through the sink, in order
+ * (dx_d2h_stream).  img must stay valid until the run is over.                                           */
+typedef struct dx_undexqv_plan dx_undexqv_plan;
+int  dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len);
+int  dx_file_undexqv_run (dx_ctx *ctx, const dx_undexqv_plan *plan, int upper, dx_sink_fn sink, void *user);
+void dx_file_undexqv_plan_free(dx_undexqv_plan *plan);
 void dx_file_free(void *p);
 
 /* ------------------------------------------------------------------------------------------

@@ -356,6 +356,43 @@ def test_undexqv_golden(ctx, case, decoder):
     assert ctx.undexqv(dx, upper=False) == O.undexqv(dx, upper=False)
 
 
+def test_undexqv_streamed_equals_whole(ctx):
+    """dx_file_undexqv_plan + _run (what the CLI uses: the text leaves through a sink in 32 MiB chunks, header lines
+    laid over each chunk on its way) against the reference's text -- 90 MB of it, so that header lines straddle
+    chunk boundaries -- and a sink that refuses data."""
+    c = synth.make_quiva(1800, seed=21, mean=10000)
+    dx = ctx.dexqv(c.text)
+    got = bytearray(len(c.text))
+    chunks = []
+    def sink(data, at):
+        got[at: at + len(data)] = data
+        chunks.append((at, len(data)))
+    assert ctx.undexqv_stream(dx, sink, upper=True) == len(c.text)
+    assert bytes(got) == c.text
+    assert len(chunks) == (len(c.text) + (32 << 20) - 1) // (32 << 20)
+    assert [a for a, _ in chunks] == sorted(a for a, _ in chunks) and sum(n for _, n in chunks) == len(c.text)
+    with pytest.raises(L.DexGPUError) as e:
+        ctx.undexqv_stream(dx, lambda data, at: at > 0, upper=True)
+    assert e.value.code == -9
+    # dx_file_dexqv_to: the .dexqv image through a sink (head first, then the record stream in chunks)
+    parts = {}
+    assert ctx.dexqv_stream(c.text, lambda data, at: parts.__setitem__(at, data) and False) == len(dx)
+    assert b"".join(parts[k] for k in sorted(parts)) == dx and len(parts) >= 2
+    with pytest.raises(L.DexGPUError) as e:                       # a malformed file: the sink sees nothing
+        ctx.dexqv_stream(c.text[:-7], lambda data, at: parts.__setitem__("bad", data) and False)
+    assert e.value.code == -3 and "bad" not in parts
+    for case in O.cases("quiva"):                                 # and the goldens, small: one chunk
+        dxg = O.golden(case["name"] + ".dexqv")
+        rt = O.golden(case["input"] + ".quiva") if case["rt_is_input"] else O.golden(case["name"] + ".rt.quiva")
+        parts = {}
+        ctx.undexqv_stream(dxg, lambda data, at: parts.__setitem__(at, data) and False, upper=True)
+        assert b"".join(parts[k] for k in sorted(parts)) == rt
+        parts = {}
+        ctx.dexqv_stream(O.golden(case["input"] + ".quiva"), lambda data, at: parts.__setitem__(at, data) and False,
+                         lossy="-l" in case["flags"])
+        assert b"".join(parts[k] for k in sorted(parts)) == dxg
+
+
 @pytest.mark.parametrize("lossy", [0, 1])
 @pytest.mark.parametrize("seed,n,mean", [(1, 3, 300), (3, 40, 8000), (4, 700, 900), (6, 24, 30000)])
 def test_undexqv_vs_oracle(ctx, seed, n, mean, lossy, decoder):

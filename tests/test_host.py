@@ -198,6 +198,17 @@ def test_walk_bare_file_index(case):
         assert dx[int(w["rec_off"][i]) + hl: int(w["rec_off"][i + 1])] == body
 
 
+@pytest.mark.parametrize("case", O.cases("quiva"), ids=lambda c: c["name"])
+def test_undexqv_plan_knows_the_text_size_without_a_gpu(case):
+    """dx_file_undexqv_plan (host walk + header lines, undexqv.c:182, 206-207): the size of the reference's output."""
+    dx = O.golden(case["name"] + ".dexqv")
+    rt = O.golden(case["input"] + ".quiva") if case["rt_is_input"] else O.golden(case["name"] + ".rt.quiva")
+    assert api.undexqv_plan_size(dx) == len(rt)
+    with pytest.raises(L.DexGPUError) as e:
+        api.undexqv_plan_size(dx[: len(dx) // 2])
+    assert e.value.code == -3
+
+
 def test_walk_rejects_garbage():
     with pytest.raises(L.DexGPUError):
         api.qv_walk(b"\xaa\x55\xcc\x33" + bytes(40))
