@@ -240,6 +240,13 @@ class Context:
     def undexqv(self, img: bytes, upper=False) -> bytes:
         return self._file_call(self.lib.dx_file_undexqv, img, len(img), int(upper))
 
+    def unpack2_stream(self, img: bytes, sink, mode=L.DX_LETTERS_LOWER, width=80) -> int:
+        """dx_file_unpack2_to: sink(data: bytes, at: int) -> falsy to go on; returns the text's size."""
+        total = C.c_size_t()
+        cb = L.SINK_FN(lambda user, data, n, at: 1 if sink(C.string_at(data, n), at) else 0)
+        self._chk(self.lib.dx_file_unpack2_to(self.h, int(mode), img, len(img), int(width), cb, None, C.byref(total)))
+        return total.value
+
     def dexqv_stream(self, quiva: bytes, sink, lossy=False) -> int:
         """dx_file_dexqv_to: sink(data: bytes, at: int) -> falsy to go on; returns the image's size."""
         total, line, code = C.c_size_t(), C.c_uint64(), C.c_int()

@@ -464,13 +464,18 @@ int dex_tool_main(int tool, int argc, char *argv[])
         { fprintf(stderr, "%s: Out of memory (Allocating read buffer)\n", Prog);
           leave(1);
         }
-      if (tool == TOOL_DEXQV && Nctx <= 1)
-        { /* the .dexqv image goes from the GPU into the output file chunk by chunk, if that is a regular file */
+      if ((tool == TOOL_DEXQV && Nctx <= 1) || tool == TOOL_UNDEXTA || tool == TOOL_UNDEXAR)
+        { /* the output goes from the GPU into the output file chunk by chunk, if that is a regular file */
           struct stat os;
           int         fd = fileno(output);
           if (fflush(output) == 0 && fstat(fd, &os) == 0 && S_ISREG(os.st_mode) && lseek(fd, 0, SEEK_CUR) == 0)
             { uint64_t line = 0;
-              int      code = 0, rc = dx_file_dexqv_to(ctx, in, n, LOSSY, sink_pwrite, &fd, &out_len, &line, &code);
+              int      code = 0, rc;
+              if (tool == TOOL_DEXQV)
+                rc = dx_file_dexqv_to(ctx, in, n, LOSSY, sink_pwrite, &fd, &out_len, &line, &code);
+              else
+                rc = dx_file_unpack2_to(ctx, tool == TOOL_UNDEXAR ? DX_LETTERS_ARROW : (UPPER ? DX_LETTERS_UPPER : DX_LETTERS_LOWER),
+                                        in, n, (uint32_t) width, sink_pwrite, &fd, &out_len);
               if (rc == DX_OK && lseek(fd, (off_t) out_len, SEEK_SET) < 0) rc = DX_E_IO;
               if (rc == DX_E_IO)
                 { fprintf(stderr, "%s: System error, write failed!\n", Prog);

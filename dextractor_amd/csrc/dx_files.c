@@ -309,9 +309,34 @@ static int tb_room(tbuf *b, size_t more)
   return DX_OK;
 }
 
-/* mode: DX_LETTERS_LOWER / _UPPER (dexta images) or _ARROW (dexar images) */
-int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
-                    uint8_t **out, size_t *out_len)
+/* A chunk of decoded text on its way out (dx_d2h_stream): the header lines that fall into it are laid over it.
+   Entry i's text starts at ooff[i]; its header line, hd[hat[i] .. hat[i+1]), ends there.                 */
+typedef struct
+  { uint64_t n; const uint64_t *ooff, *hat; const char *hd;
+    dx_sink_fn sink; void *user;
+  } hdr_patch;
+
+static int patch_and_pass(void *arg, uint8_t *data, size_t len, size_t at)
+{ hdr_patch *h = arg;
+  uint64_t lo = 0, hi = h->n, i;
+  while (lo < hi)                                         /* first entry whose text starts beyond `at` */
+    { uint64_t mid = (lo + hi) / 2;
+      if (h->ooff[mid] > at) hi = mid; else lo = mid + 1;
+    }
+  for (i = lo; i < h->n; i++)
+    { const size_t hl = (size_t) (h->hat[i+1] - h->hat[i]), h0 = (size_t) h->ooff[i] - hl, h1 = (size_t) h->ooff[i];
+      const size_t c0 = h0 > at ? h0 : at, c1 = h1 < at + len ? h1 : at + len;
+      if (h0 >= at + len) break;
+      if (c0 < c1)
+        memcpy(data + (c0 - at), h->hd + h->hat[i] + (c0 - h0), c1 - c0);
+    }
+  return h->sink(h->user, data, len, at);
+}
+
+/* mode: DX_LETTERS_LOWER / _UPPER (dexta images) or _ARROW (dexar images); out != NULL: the text in memory,
+   else through the sink */
+static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
+                        uint8_t **out, dx_sink_fn sink, void *user, size_t *out_len)
 { dpool     pool = { {0}, 0, ctx };
   rsrc      r = { img, n, 0, 0 };
   tbuf      hd = { NULL, 0, 0 };               /* all header lines, concatenated */
@@ -325,9 +350,10 @@ int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_
   size_t    total = 0;
   void     *d_in, *d_ioff, *d_nsym, *d_out, *d_ooff;
 
-  if (ctx == NULL || out == NULL || out_len == NULL || img == NULL) return DX_E_ARG;
+  if (ctx == NULL || (out == NULL && sink == NULL) || out_len == NULL || img == NULL) return DX_E_ARG;
   if (width == 0) return DX_E_ARG;
-  *out = NULL; *out_len = 0;
+  if (out) *out = NULL;
+  *out_len = 0;
 
   rd(&r, &key, 2);                                        /* undexta.c:138-159, undexar.c:136-145 */
   if (r.bad) return DX_E_FORMAT;
@@ -407,8 +433,10 @@ int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_
       ooff[i] = total;
       total  += L + (L + width - 1) / width;
     }
-  res = malloc(total + 16);
-  if (!res) { rc = DX_E_NOMEM; goto done; }
+  if (out)
+    { res = malloc(total + 16);
+      if (!res) { rc = DX_E_NOMEM; goto done; }
+    }
 
   if (cnt > 0)
     { TRY(dupload(&pool, img, n, &d_in));
@@ -417,17 +445,35 @@ int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_
       TRY(dupload(&pool, ooff, cnt * 8, &d_ooff));
       TRY(dalloc(&pool, total, &d_out));
       TRY(dx_pack2_decode(ctx, mode, d_in, d_ioff, d_nsym, cnt, width, d_out, d_ooff));
-      TRY(dx_d2h(ctx, res, d_out, total));
-      for (i = 0; i < cnt; i++)
-        memcpy(res + ooff[i] - (hat[i+1] - hat[i]), hd.p + hat[i], (size_t) (hat[i+1] - hat[i]));
+      if (out)
+        { TRY(dx_d2h(ctx, res, d_out, total));
+          for (i = 0; i < cnt; i++)
+            memcpy(res + ooff[i] - (hat[i+1] - hat[i]), hd.p + hat[i], (size_t) (hat[i+1] - hat[i]));
+        }
+      else
+        { hdr_patch h = { cnt, ooff, hat, hd.p, sink, user };
+          TRY(dx_d2h_stream(ctx, d_out, total, patch_and_pass, &h));
+        }
     }
-  *out = res; *out_len = total; res = NULL;
+  if (out) { *out = res; res = NULL; }
+  *out_len = total;
   rc = DX_OK;
 
 done:
   dfree_all(&pool);
   free(name); free(hd.p); free(ioff); free(ooff); free(hat); free(nsym); free(res);
   return rc;
+}
+
+int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width, uint8_t **out, size_t *out_len)
+{ if (out == NULL) return DX_E_ARG;
+  return unpack2_core(ctx, mode, img, n, width, out, NULL, NULL, out_len);
+}
+
+int dx_file_unpack2_to(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
+                       dx_sink_fn sink, void *user, size_t *out_len)
+{ if (sink == NULL) return DX_E_ARG;
+  return unpack2_core(ctx, mode, img, n, width, NULL, sink, user, out_len);
 }
 
 /* ==========================================================================================
@@ -623,34 +669,14 @@ fail:
   return rc;
 }
 
-/* a chunk of the decoded text on its way out: the header lines that fall into it are laid over it */
-typedef struct { const dx_undexqv_plan *p; dx_sink_fn sink; void *user; } hdr_patch;
-
-static int patch_and_pass(void *arg, uint8_t *data, size_t len, size_t at)
-{ hdr_patch *h = arg;
-  const dx_undexqv_plan *p = h->p;
-  uint64_t lo = 0, hi = p->x.n, i;
-  while (lo < hi)                                         /* first entry whose data lines start beyond `at` */
-    { uint64_t mid = (lo + hi) / 2;
-      if (p->ooff[mid] > at) hi = mid; else lo = mid + 1;
-    }
-  for (i = lo; i < p->x.n; i++)
-    { const size_t hl = (size_t) (p->hat[i+1] - p->hat[i]), h0 = (size_t) p->ooff[i] - hl, h1 = (size_t) p->ooff[i];
-      const size_t c0 = h0 > at ? h0 : at, c1 = h1 < at + len ? h1 : at + len;
-      if (h0 >= at + len) break;
-      if (c0 < c1)
-        memcpy(data + (c0 - at), p->hd.p + p->hat[i] + (c0 - h0), c1 - c0);
-    }
-  return h->sink(h->user, data, len, at);
-}
-
 int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sink_fn sink, void *user)
 { dpool     pool = { {0}, 0, ctx };
   void     *d_in, *d_rec, *d_hoff, *d_seg, *d_len, *d_out, *d_ooff;
-  hdr_patch h = { p, sink, user };
+  hdr_patch h;
   int       rc = DX_OK;
 
   if (ctx == NULL || p == NULL || sink == NULL) return DX_E_ARG;
+  h.n = p->x.n; h.ooff = p->ooff; h.hat = p->hat; h.hd = p->hd.p; h.sink = sink; h.user = user;
   if (p->x.n > 0)
     { TRY(dx_qv_set_coding(ctx, &p->x.coding, 0));
       TRY(dupload(&pool, p->img, p->n, &d_in));

@@ -320,6 +320,9 @@ int  dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32
                      uint8_t **out, size_t *out_len);
 int  dx_file_dexqv  (dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
                      uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
+/* dx_file_unpack2 with the text delivered through a sink, in order (dx_d2h_stream), header lines in place */
+int  dx_file_unpack2_to(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
+                        dx_sink_fn sink, void *user, size_t *out_len);
 /* dx_file_dexqv with the .dexqv image delivered through a sink instead (the file's head, then the record stream
  * in chunks: dx_d2h_stream), for a caller that writes it straight to a file.  The sink sees nothing unless the
  * whole input was valid and encoded.                                                                       */

@@ -381,6 +381,13 @@ def test_undexqv_streamed_equals_whole(ctx):
     with pytest.raises(L.DexGPUError) as e:                       # a malformed file: the sink sees nothing
         ctx.dexqv_stream(c.text[:-7], lambda data, at: parts.__setitem__("bad", data) and False)
     assert e.value.code == -3 and "bad" not in parts
+    # dx_file_unpack2_to: 70 MB of fasta text back out of its .dexta image, header lines across chunk boundaries
+    f = synth.make_seqfile("fasta", 7000, seed=22, mean=10000)
+    dxa = ctx.dexta(f.text)
+    back = bytearray(len(f.text))
+    assert ctx.unpack2_stream(dxa, lambda data, at: back.__setitem__(slice(at, at + len(data)), data) and False,
+                              mode=L.DX_LETTERS_UPPER, width=80) == len(f.text)
+    assert bytes(back) == ctx.undexta(dxa, upper=True) == f.text
     for case in O.cases("quiva"):                                 # and the goldens, small: one chunk
         dxg = O.golden(case["name"] + ".dexqv")
         rt = O.golden(case["input"] + ".quiva") if case["rt_is_input"] else O.golden(case["name"] + ".rt.quiva")
