@@ -468,9 +468,14 @@ def cpu_baseline(ctx, api, d_text, off, lens, hlen, args, state, big):
             with open(src, "wb") as f:
                 f.write(payload)
             flags = ["-k"] + (["-l"] if args.lossy and tool == "dexqv" else []) + (["-U"] if tool == "undexqv" else [])
-            t0 = time.perf_counter()
-            rc_ = subprocess.call([cli] + flags + [src])
-            dtc = time.perf_counter() - t0
+            dtc, runs = None, []
+            for _ in range(3):                     # best of three (the first start of a tool on a box pages its libraries in)
+                t0 = time.perf_counter()
+                rc_ = subprocess.call([cli] + flags + [src])
+                runs.append(round(time.perf_counter() - t0, 3))
+                dtc = runs[-1] if dtc is None else min(dtc, runs[-1])
+                if rc_ != 0:
+                    break
             same = False
             if rc_ == 0:
                 with open(os.path.join(d, "s.dexqv" if tool == "dexqv" else "s.quiva"), "rb") as f:
@@ -481,7 +486,8 @@ def cpu_baseline(ctx, api, d_text, off, lens, hlen, args, state, big):
                     data = lambda b_: [ln for ln in b_.split(b"\n") if not ln.startswith(b"@")]
                     same = args.lossy or data(back) == data(sample)
         res["cli_end_to_end" if tool == "dexqv" else "cli_undexqv_end_to_end"] = {
-            "seconds": round(dtc, 2), "GBps": round(5 * sbases / dtc / 1e9, 3), "output_identical": bool(same)}
+            "seconds": round(dtc, 3), "GBps": round(5 * sbases / dtc / 1e9, 3), "output_identical": bool(same),
+            "runs_s": runs, "note": "process start to exit, tmpfs to tmpfs, best of the runs; this process holds the GPU meanwhile"}
 
     # how the single-threaded reference would be deployed: one independent copy per host core
     trace("cpu_baseline: all cores")
