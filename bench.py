@@ -274,7 +274,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         # never zero, so the number of differing bytes must equal the number of header bytes exactly.
         trace("verify: decode + compare")
         free_b = torch.cuda.mem_get_info()[0]                     # as few decode launches as the free memory allows:
-        chunk = max(1, min(n, int(max(6e9, 0.7 * free_b) // (5 * (args.mean + 1) + hlen))))   # (a launch = one pool of tasks)
+        chunk = max(1, min(n, int(max(6e9, 0.6 * free_b) // (5 * (args.mean + 1) + hlen))))   # (a launch = one pool of tasks)
         ends = np.concatenate([off[1:] - hlen, [text_bytes]]).astype(np.uint64)   # end of each entry's record
         roundtrip, dec_ms = True, 0.0
         for a in range(0, n, chunk):
@@ -291,9 +291,9 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
             dec_ms += kt.get("k_qv_decode", (0.0, 0))[0]
             ctx.profile(False)
             diff = 0
-            for c0 in range(0, hi - lo, 1 << 32):                 # compared in slices: no chunk-sized temporary
-                c1 = min(hi - lo, c0 + (1 << 32))
-                diff += int((d_back[c0:c1] != d_text[lo + c0: lo + c1]).sum())
+            for c0 in range(0, hi - lo, 1 << 29):                 # compared in slices: no chunk-sized temporaries
+                c1 = min(hi - lo, c0 + (1 << 29))
+                diff += int(torch.count_nonzero(d_back[c0:c1] != d_text[lo + c0: lo + c1]))
             roundtrip = roundtrip and diff == (b - a) * hlen
             del d_back, o_rel
         state["decode"] = {"kernel": "k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),

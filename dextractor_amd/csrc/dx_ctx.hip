@@ -50,6 +50,7 @@ extern "C" int dx_open(int device, dx_ctx **out)
   ctx->scratch_bytes = 0;
   ctx->d_scan = NULL;
   ctx->scan_words = 0;
+  ctx->onepass_min_groups = 0;
   ctx->h_stage[0] = ctx->h_stage[1] = NULL;
   memset(&ctx->tk, 0, sizeof(ctx->tk));
 

@@ -45,6 +45,7 @@ struct dx_ctx
   int       delChar, subChar;
   uint32_t  bps[4];            // upper bound of encoded bits per symbol of del/ins/mrg/sub (dx_qv_encode_onepass)
   uint32_t  pair_lo[2];        // ins, mrg: lowest coded byte value when the coded values span <= 64 (pair tables), else ~0
+  int       onepass_min_groups;// dx_qv_encode_onepass: fewest groups whose scratch regions have fitted the device so far
 
   // run-length tokens the histogram pass leaves for the encoder (dx_qv.hip: "token hand-over")
   struct

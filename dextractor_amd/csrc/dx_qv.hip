@@ -1969,9 +1969,20 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
     const uint64_t per_entry = syms ? syms * bits / 8 + syms / 4 + 128 : 0;       // mean slot bound
     if (n >= 240000) G = 2;
     if (per_entry)
-      while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
+      { while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
+        // ... and as the free device memory allows (the scratch that exists counts as free: it is replaced): more,
+        // smaller groups when two big regions do not fit (a 125 GB shard leaves ~40 GB beside its tokens and output)
+        size_t free_b = 0, all_b = 0;
+        if (hipMemGetInfo(&free_b, &all_b) == hipSuccess)
+          { const uint64_t avail = (uint64_t) free_b + ctx->scratch_bytes;
+            while (G < ONEPASS_MAX_GROUPS &&
+                   (uint64_t) (G > 2 ? 3 : G) * ((n + G - 1) / G * per_entry) + 28 * n + (1ull << 30) > avail)
+              G++;
+          }
+      }
     else if (n >= 240000)
       G = (int) (n / 250000) > 2 ? (int) (n / 250000) : 2;
+    if (G < ctx->onepass_min_groups) G = ctx->onepass_min_groups;      // (what an earlier call had to fall back to)
     if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
   }
   if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests)
@@ -1979,6 +1990,7 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       if (G < 1) G = 1;
       if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
     }
+layout:
   { const uint64_t gs = (n + (uint64_t) G - 1) / (uint64_t) G;
     G = 0;
     gb[0] = 0;
@@ -1997,7 +2009,13 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
   for (int pass = 0; pass < 2; pass++)
     { void *base;
       if ((e = dx_scratch(ctx, small + (G > 2 ? 3 : G) * region + 512, &base)))
-        { if (pass == 1 && onepass_tokens_ok(ctx, b))   // no room for the slots: the scheme that needs none
+        { (void) hipGetLastError();                      // (the failed allocation's error is dealt with here)
+          if (pass == 1 && G >= 2 && 2 * G <= ONEPASS_MAX_GROUPS && getenv("DEXGPU_ONEPASS_GROUPS") == NULL)
+            { G = G < 3 ? 4 : 2 * G;                     // no room for regions this big: more, smaller groups
+              ctx->onepass_min_groups = G;
+              goto layout;
+            }
+          if (pass == 1 && onepass_tokens_ok(ctx, b))    // no room for any slots: the scheme that needs none
             return onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, total);
           return e;
         }
