@@ -142,7 +142,7 @@ def main():
         try:
             l2 = dexqv_bench(a2, 0, 1, local, cpu=False, front=False)
             extra["dexqv_" + a2.dist] = {k: l2[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
-                                                              "roundtrip_bit_exact", "pipeline", "decode")}
+                                                              "roundtrip_bit_exact", "pipeline", "decode", "decode_indexed")}
         except Exception as e:                               # an extra must never cost the headline line
             extra["dexqv_" + a2.dist] = {"error": repr(e)}
         for w in ("dexta", "dexar"):
@@ -276,28 +276,54 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         free_b = torch.cuda.mem_get_info()[0]                     # as few decode launches as the free memory allows:
         chunk = max(1, min(n, int(max(6e9, 0.6 * free_b) // (5 * (args.mean + 1) + hlen))))   # (a launch = one pool of tasks)
         ends = np.concatenate([off[1:] - hlen, [text_bytes]]).astype(np.uint64)   # end of each entry's record
-        roundtrip, dec_ms = True, 0.0
-        for a in range(0, n, chunk):
-            b = min(n, a + chunk)
-            lo, hi = int(off[a]) - hlen, int(ends[b - 1])
-            d_back = torch.zeros(hi - lo + 64, dtype=torch.uint8, device="cuda")
-            o_rel = Ptr(torch.from_numpy((off[a:b] - np.uint64(lo)).view(np.int64)).cuda())
-            torch.cuda.synchronize()
-            ctx.profile(True)
-            ctx.qv_decode(p_out, Ptr(p_rec.t[a:]), Ptr(p_hoff.t[a:]), Ptr(p_seg.t[5 * a:]), Ptr(t_len[a:]), b - a, True,
-                          Ptr(d_back), o_rel)
-            ctx.sync(); torch.cuda.synchronize()
-            kt = ctx.kernel_times()
-            dec_ms += kt.get("k_qv_decode", (0.0, 0))[0]
-            ctx.profile(False)
-            diff = 0
-            for c0 in range(0, hi - lo, 1 << 29):                 # compared in slices: no chunk-sized temporaries
-                c1 = min(hi - lo, c0 + (1 << 29))
-                diff += int(torch.count_nonzero(d_back[c0:c1] != d_text[lo + c0: lo + c1]))
-            roundtrip = roundtrip and diff == (b - a) * hlen
-            del d_back, o_rel
-        state["decode"] = {"kernel": "k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),
+        def decode_all():
+          roundtrip, dec_ms = True, 0.0
+          for a in range(0, n, chunk):
+              b = min(n, a + chunk)
+              lo, hi = int(off[a]) - hlen, int(ends[b - 1])
+              d_back = torch.zeros(hi - lo + 64, dtype=torch.uint8, device="cuda")
+              o_rel = Ptr(torch.from_numpy((off[a:b] - np.uint64(lo)).view(np.int64)).cuda())
+              torch.cuda.synchronize()
+              ctx.profile(True)
+              ctx.qv_decode(p_out, Ptr(p_rec.t[a:]), Ptr(p_hoff.t[a:]), Ptr(p_seg.t[5 * a:]), Ptr(t_len[a:]), b - a, True,
+                            Ptr(d_back), o_rel)
+              ctx.sync(); torch.cuda.synchronize()
+              kt = ctx.kernel_times()
+              dec_ms += kt.get("k_qv_decode", (0.0, 0))[0]
+              ctx.profile(False)
+              diff = 0
+              for c0 in range(0, hi - lo, 1 << 29):                 # compared in slices: no chunk-sized temporaries
+                  c1 = min(hi - lo, c0 + (1 << 29))
+                  diff += int(torch.count_nonzero(d_back[c0:c1] != d_text[lo + c0: lo + c1]))
+              roundtrip = roundtrip and diff == (b - a) * hlen
+              del d_back, o_rel
+          return roundtrip, dec_ms
+
+        roundtrip, dec_ms = decode_all()                          # lane-per-line kernels (what a bare .dexqv gets too)
+        state["decode"] = {"kernel": "k_qv_decode_plain + k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),
                            "output_GBps": round(5.0 * bases / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None}
+        if not args.twopass:
+            # ... and with the encoder's sub-block index (dx_qv_subindex): one more, untimed, encode that leaves the index,
+            # then the plain lines are decoded a wavefront per line (k_qv_decode_sub)
+            trace("verify: decode with the sub-block index")
+            ctx.qv_subindex(True)
+            ctx.profile(True)
+            step()
+            fence()
+            kt = ctx.kernel_times()
+            enc_ix_ms = sum(kt.get(k, (0.0, 0))[0] for k in ("k_qv_prescan", "k_qv_hist", "k_qv_encode", "k_qv_compact", "k_scan", "k_qv_sizes"))
+            ctx.profile(False)
+            ok2, dec2_ms = decode_all()
+            ctx.qv_subindex(False)
+            roundtrip = roundtrip and ok2
+            kk_ = np.clip((lens.astype(np.int64) + 1023) >> 10, 1, 16)
+            nsub_ = (lens.astype(np.int64) + 16 * kk_ - 1) // (16 * kk_)
+            state["decode_indexed"] = {"kernel": "k_qv_decode_sub + k_qv_decode + k_qv_decode_tags", "ms": round(dec2_ms, 2),
+                                       "output_GBps": round(5.0 * bases / (dec2_ms * 1e-3) / 1e9, 1) if dec2_ms else None,
+                                       "index_bytes": int(16 * nsub_.sum()),
+                                       "bit_exact": bool(ok2),
+                                       "note": "index written by one extra untimed step of the same encoder; kernels of that step: "
+                                               + str(round(enc_ix_ms, 2)) + " ms"}
 
     # GPU text front end on the same resident image (untimed extra): newline scan -> entry index
     fr = None
@@ -392,6 +418,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         "tables_identical_across_ranks": tables_same,
         "host_table_build_us": state.get("host_build_us"),
         "decode": state.get("decode"),
+        "decode_indexed": state.get("decode_indexed"),
         "text_front_end": fr,
         "pipeline": pipe,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}

@@ -110,6 +110,7 @@ SIGNATURES = {
     "dx_file_pack2_sharded": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dx_file_undexqv": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "dx_qv_subindex": (C.c_int, [_P, C.c_int]),
     "dx_file_unpack2_to": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_uint32, SINK_FN, _P, C.POINTER(C.c_size_t)]),
     "dx_file_dexqv_to": (C.c_int, [_P, _P, C.c_size_t, C.c_int, SINK_FN, _P, C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),

@@ -13,8 +13,18 @@ import numpy as np
 from . import _lib as L
 
 
+class DevView:
+    """A pointer into a DevBuf (which stays the owner)."""
+
+    def __init__(self, base: "DevBuf", byte_offset: int):
+        self.base, self.ptr = base, base.ptr + int(byte_offset)
+
+
 class DevBuf:
     """A device allocation owned by a Context."""
+
+    def offset(self, nbytes: int) -> DevView:
+        return DevView(self, nbytes)
 
     def __init__(self, ctx: "Context", nbytes: int):
         self.ctx, self.nbytes = ctx, int(nbytes)
@@ -239,6 +249,9 @@ class Context:
 
     def undexqv(self, img: bytes, upper=False) -> bytes:
         return self._file_call(self.lib.dx_file_undexqv, img, len(img), int(upper))
+
+    def qv_subindex(self, on=True):
+        self._chk(self.lib.dx_qv_subindex(self.h, int(bool(on))))
 
     def unpack2_stream(self, img: bytes, sink, mode=L.DX_LETTERS_LOWER, width=80) -> int:
         """dx_file_unpack2_to: sink(data: bytes, at: int) -> falsy to go on; returns the text's size."""

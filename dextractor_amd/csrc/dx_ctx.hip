@@ -1,6 +1,7 @@
 // dx_ctx.hip -- context, device memory and per-kernel timing plumbing of libdexgpu.
 #include "dx_internal.hpp"
 #include <pthread.h>
+#include <string.h>
 
 #include <stdlib.h>
 
@@ -51,6 +52,7 @@ extern "C" int dx_open(int device, dx_ctx **out)
   ctx->d_scan = NULL;
   ctx->scan_words = 0;
   ctx->onepass_min_groups = 0;
+  memset(&ctx->sx, 0, sizeof(ctx->sx));
   ctx->h_stage[0] = ctx->h_stage[1] = NULL;
   memset(&ctx->tk, 0, sizeof(ctx->tk));
 
@@ -99,6 +101,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);
   (void) hipFree(ctx->d_scan);
+  (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room);
   if (ctx->h_stage[0]) (void) hipHostFree(ctx->h_stage[0]);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipStreamDestroy(ctx->own);

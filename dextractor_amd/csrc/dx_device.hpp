@@ -104,6 +104,10 @@ __device__ __forceinline__ uint32_t chunk_eq_mask(const u32x4 &v, uint32_t c)
 
 __device__ __forceinline__ void store32_u(uint8_t *p, uint32_t v) { *(u32_u *) p = v; }
 
+// sub-block index of the plain QV lines (dx_qv.hip writes it, dx_qv_decode.hip reads it): sub-blocks of 16 * kk symbols
+__host__ __device__ __forceinline__ uint32_t sub_kk(uint32_t L)    { const uint32_t k = (L + 1023u) >> 10; return k < 1u ? 1u : (k > 16u ? 16u : k); }
+__host__ __device__ __forceinline__ uint32_t sub_count(uint32_t L) { const uint32_t K = 16u * sub_kk(L); return (L + K - 1u) / K; }
+
 // ---------------------------------------------------------------------------------------------
 //  per-wave output window: bits are ORed into a zeroed LDS word window (MSB-first within 32-bit
 //  words) and leave as coalesced, possibly unaligned, dword stores at the segment's byte address

@@ -64,6 +64,17 @@ struct dx_ctx
     int         valid;
   } tk;
 
+  // sub-block index of the plain lines, left by dx_qv_encode_onepass for dx_qv_decode when dx_qv_subindex is on
+  struct
+  { int       want, valid;
+    uint32_t *idx;               // bit offsets, 4 * sub_count(len) words per entry
+    uint64_t *off;               // n + 1: where each entry's words start
+    uint32_t *room;              // n: scratch of the offsets' scan
+    size_t    cap_idx, cap_entries;
+    const void *out, *seg;       // the record stream and segment index it belongs to
+    uint64_t    n;
+  } sx;
+
   // scratch owned by the context
   uint32_t *d_status;          // device error flags (bit 0: symbol count mismatch)
   uint64_t *d_u64;             // small device scalars (prescan keys, totals, ...)

@@ -953,9 +953,41 @@ __device__ __forceinline__ void place_bits128(uint32_t *win, uint32_t bit, uint3
   if (x4) atomicOr(&win[we - 4], x4);
 }
 
+// ---- sub-block index of the plain lines (decoder side: k_qv_decode_sub, dx_qv_decode.hip) --------------------
+// A Huffman stream decodes front to back only; the encoder, though, knows where every code starts.  On request
+// (dx_qv_subindex) it leaves, for each plain line, the bit offset of every K-th symbol, K = 16 * kk,
+// kk = min(16, ceil(L / 1024)): at most 64 sub-blocks for lines up to 16 k symbols, 256-symbol sub-blocks beyond.
+// A sub-block always starts with a lane's 16 symbols of some step, whose bit offset the step's prefix sum gives.
+// Per entry 4 * nsub(L) words (a line that is run-coded leaves its share unused), at sub_off[r].
+// (sub_kk, sub_count: dx_device.hpp)
+
+struct sub_mark
+{ uint32_t *at;               // this line's nsub words, NULL: no index wanted
+  uint32_t  rem, quo;         // the lane's 16 symbols of this step are symbols 16 * (quo * kk + rem) ... of the line
+  uint32_t  kk, dr, dq;       // per step: 64 lanes further = dq sub-blocks and dr lanes
+};
+
+__device__ __forceinline__ void sub_begin(sub_mark &m, uint32_t *at, uint32_t L)
+{ const uint64_t A = (uint64_t) at;                             // wave-uniform values: keep them in scalar registers
+  m.at = (uint32_t *) (((uint64_t) uniform((uint32_t) (A >> 32)) << 32) | uniform((uint32_t) A));
+  m.kk = uniform(sub_kk(L));
+  m.quo = (uint32_t) lane_id() / m.kk; m.rem = (uint32_t) lane_id() % m.kk;
+  m.dq  = uniform(64u / m.kk);         m.dr  = uniform(64u % m.kk);
+}
+
+// `start` = bit offset of this lane's codes in the stream, `some` = the lane has symbols in this step
+__device__ __forceinline__ void sub_step(sub_mark &m, uint32_t start, bool some)
+{ if (m.at == NULL) return;
+  if (m.rem == 0 && some) m.at[m.quo] = start;
+  m.quo += m.dq; m.rem += m.dr;
+  if (m.rem >= m.kk) { m.rem -= m.kk; m.quo += 1; }
+}
+
+struct sub_sink { uint32_t *idx; const uint64_t *off; };           // idx == NULL: none wanted
+
 // one step of Encode (QV.c:427-434): 16 table look-ups per lane, prefix sum, bits into the window
 __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, int valid, bool full,
-                                                  const uint32_t *tab, const uint32_t *stab, uint32_t m4)
+                                                  const uint32_t *tab, const uint32_t *stab, uint32_t m4, sub_mark &sm)
 { uint32_t tok[16];
   uint32_t ssum = 0, zor = 0;
   if (full)
@@ -980,6 +1012,7 @@ __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, i
   const uint32_t nb   = 512u - ssum;
   const uint32_t k    = 16u - (uint32_t) valid;                        // dummies (0 unless ragged)
   const uint32_t incl = wave_incl_scan(nb);
+  sub_step(sm, 32u * o.wordbase + o.winbits + incl - nb, valid > 0);
   const bool fast = !__any((int) ((zor & 32u) | (nb + k > 128u)));
   if (fast)
     { // every token has 1..24 bits and the lane's string fits 128 bits: branch-free packing.  The
@@ -1204,7 +1237,7 @@ __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
                  const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status, uint32_t *ticket,
                  enc_scratch sc, const uint32_t *only_list, const unsigned long long *only_count, uint64_t first_entry,
-                 const uint32_t *only_info, uint64_t out_cap)
+                 const uint32_t *only_info, uint64_t out_cap, sub_sink sx)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint8_t  s_tagcode[256];
@@ -1329,10 +1362,12 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 #define PLAIN_LOOP(STAB)                                                                        \
               for (uint32_t base = 0; base < L; base += DX_STEP)                                 \
                 { const u32x4 d = fetch(p, pos + DX_STEP, L, over);                              \
-                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4); \
+                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4, sm); \
                   c = d;                                                                         \
                   pos += DX_STEP;                                                                \
                 }
+              sub_mark sm;
+              sub_begin(sm, sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_count(L) : (uint32_t *) NULL, L);
               if (q == 1)      { PLAIN_LOOP(s_stok[1]) }
               else if (q == 2) { PLAIN_LOOP(s_stok[2]) }
               else             { PLAIN_LOOP(s_stok[q]) }
@@ -1675,6 +1710,7 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
   ctx->lossy   = lossy != 0;
   ctx->delChar = c->delChar;
   ctx->subChar = c->subChar;
+  ctx->sx.valid = 0;                                     // (a sub-block index belongs to a stream of the tables before)
   return DX_OK;
 }
 
@@ -1755,13 +1791,15 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   if (b->n == 0) return DX_OK;
   if (!d_rec_off || !d_seg || !d_out) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->sx.out == (const void *) d_out) ctx->sx.valid = 0;            // (the two-pass encoder leaves no sub-block index)
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
             a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL },
-            (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0);
+            (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0,
+            sub_sink{ NULL, NULL });
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1796,6 +1834,53 @@ static int onepass_side(dx_ctx *ctx, hipStream_t B, const uint32_t *d_size, uint
   DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, COMPACT_WAVES_PER_CU), DX_BLOCK,
             m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
             ctx->d_status, d_tick);
+  return DX_OK;
+}
+
+// ---- sub-block index: room for it -----------------------------------------------------------------------------
+__global__ __launch_bounds__(DX_BLOCK)
+void k_sub_rooms(const uint32_t *len, uint64_t n, uint32_t *room)
+{ const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
+  if (i < n) room[i] = 4u * sub_count(len[i]);
+}
+
+extern "C" int dx_qv_subindex(dx_ctx *ctx, int on)
+{ if (ctx == NULL) return DX_E_ARG;
+  ctx->sx.want = on != 0;
+  if (!on) ctx->sx.valid = 0;
+  return DX_OK;
+}
+
+// offsets (a scan of the rooms) and the index buffer for this batch; *idx = NULL when no index is wanted
+static int subindex_prepare(dx_ctx *ctx, const dx_qv_batch *b, const void *d_out, const void *d_seg, uint32_t **idx)
+{ *idx = NULL;
+  ctx->sx.valid = 0;
+  if (!ctx->sx.want || b->n == 0) return DX_OK;
+  const uint64_t n = b->n;
+  if (n > ctx->sx.cap_entries)
+    { (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room);
+      ctx->sx.off = NULL; ctx->sx.room = NULL; ctx->sx.cap_entries = 0;
+      if (hipMalloc((void **) &ctx->sx.off, (n + 1) * 8) != hipSuccess || hipMalloc((void **) &ctx->sx.room, n * 4) != hipSuccess)
+        { (void) hipGetLastError();
+          return dx_fail(ctx, DX_E_NOMEM, "dx_qv_subindex: no memory for the offsets of %llu entries", (unsigned long long) n);
+        }
+      ctx->sx.cap_entries = n;
+    }
+  DX_LAUNCH(ctx, DX_K_SCAN, k_sub_rooms, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK, (const uint32_t *) b->d_len, n, ctx->sx.room);
+  uint64_t words = 0;
+  int e = dx_scan_u32(ctx, ctx->sx.room, n, ctx->sx.off, &words);
+  if (e) return e;
+  if (words + 4 > ctx->sx.cap_idx)
+    { (void) hipFree(ctx->sx.idx);
+      ctx->sx.idx = NULL; ctx->sx.cap_idx = 0;
+      if (hipMalloc((void **) &ctx->sx.idx, (words + 4) * 4) != hipSuccess)
+        { (void) hipGetLastError();
+          return dx_fail(ctx, DX_E_NOMEM, "dx_qv_subindex: no memory for %llu index words", (unsigned long long) words);
+        }
+      ctx->sx.cap_idx = words + 4;
+    }
+  ctx->sx.out = d_out; ctx->sx.seg = d_seg; ctx->sx.n = n;
+  *idx = ctx->sx.idx;
   return DX_OK;
 }
 
@@ -1847,6 +1932,8 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       gb[++G] = n;
     }
 
+  uint32_t *sx_idx = NULL;
+  if ((e = subindex_prepare(ctx, b, d_out, d_seg, &sx_idx))) return e;
   hipStream_t A = ctx->stream, B = ctx->side;
   hipEvent_t *sz_done = ctx->ev, fork = ctx->ev[16], join = ctx->ev[15];
   uint64_t   *d_base = ctx->d_u64 + 24;                  // [0], [1]: running record offset, ping-pong
@@ -1863,6 +1950,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       qv_args ag = a;
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
+      const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL };
       const tok_src   tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
       rc = DX_E_HIP;
       if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
@@ -1893,7 +1981,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       hipLaunchKernelGGL(k_qv_encode_fast, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
                          ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
                          ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
-                         (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap);
+                         (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
       dx_prof_end_on(ctx, A);
       if (odd)
         { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
@@ -1902,7 +1990,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
                              dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
                              (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
                              d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, (const uint32_t *) ctx->tk.list,
-                             (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + 4 * g0), out_cap);
+                             (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + 4 * g0), out_cap, sx_g);
           dx_prof_end_on(ctx, A);
         }
       if (hipGetLastError() != hipSuccess) break;
@@ -1926,6 +2014,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
                    (unsigned long long) tot, (unsigned long long) out_cap);
   if (st & 2u)
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an encoded segment differs in size from what the size kernel computed");
+  ctx->sx.valid = sx_idx != NULL;
   return DX_OK;
 }
 
@@ -2042,6 +2131,8 @@ layout:
     }
   uint8_t *d_slots = scr + ((small + 255) & ~(size_t) 255);
 
+  uint32_t *sx_idx = NULL;
+  if ((e = subindex_prepare(ctx, b, d_out, d_seg, &sx_idx))) return e;
   hipStream_t    A = ctx->stream, B = ctx->side;
   hipEvent_t    *enc_done = ctx->ev, *cmp_done = ctx->ev + 8, done = ctx->ev[16];
   uint64_t      *d_base = ctx->d_u64 + 24;               // [0], [1]: running record offset, ping-pong
@@ -2062,6 +2153,7 @@ layout:
       qv_args ag = a;
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
+      const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL };
       if (g >= 3)
         DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 3) & 7], 0));    // the region is free once its last tenant has been copied out
       const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 };
@@ -2071,7 +2163,7 @@ layout:
           DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast, fast_grid(ctx, m), FAST_BLOCK,
                     ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
                     ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                    (uint8_t *) NULL, (uint64_t) 0);
+                    (uint8_t *) NULL, (uint64_t) 0, sx_g);
         }
       if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
         { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;
@@ -2081,7 +2173,7 @@ layout:
                     (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g,
                     fast ? (const uint32_t *) ctx->tk.list : (const uint32_t *) NULL,
                     fast ? (const unsigned long long *) ctx->tk.count : (const unsigned long long *) NULL, g0,
-                    fast ? (const uint32_t *) (ctx->tk.info + 4 * g0) : (const uint32_t *) NULL, ~(uint64_t) 0);
+                    fast ? (const uint32_t *) (ctx->tk.info + 4 * g0) : (const uint32_t *) NULL, ~(uint64_t) 0, sx_g);
         }
       DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction
@@ -2110,5 +2202,6 @@ layout:
   if (tot > out_cap || (st & 8u))
     return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
                    (unsigned long long) tot, (unsigned long long) out_cap);
+  ctx->sx.valid = sx_idx != NULL;
   return DX_OK;
 }

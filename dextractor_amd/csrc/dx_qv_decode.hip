@@ -475,15 +475,13 @@ __device__ __forceinline__ void dp_block8(linerd &rd, const uint16_t *tab, const
   o0 = w[0]; o1 = w[1];
 }
 
-__global__ __launch_bounds__(DP_BLOCK)
-void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds)
-{ __shared__ uint16_t s_tab[4][DP_SIZE];                   // 32 KB: 32 - len | symbol << 8 (low bits 0: longer than DP_BITS)
-  __shared__ uint32_t s_long[4][1 + DX_LONG_MAX];          //  4 KB
-  __shared__ uint32_t s_ring[DP_BLOCK][DP_STRIDE];         // 100 KB
-  for (int k = threadIdx.x; k < 4 * (1 + DX_LONG_MAX); k += DP_BLOCK) (&s_long[0][0])[k] = g_long[k];
+// the 12-bit tables of the four symbol schemes from the library's 11-bit ones and their lists of longer codes
+// (QV.c:365-372 in two levels); every thread of the workgroup takes part
+__device__ __forceinline__ void dp_build_tables(uint16_t (*s_tab)[DP_SIZE], uint32_t (*s_long)[1 + DX_LONG_MAX],
+                                                const uint16_t *g_dec, const uint32_t *g_long)
+{ for (int k = threadIdx.x; k < 4 * (1 + DX_LONG_MAX); k += (int) blockDim.x) (&s_long[0][0])[k] = g_long[k];
   __syncthreads();
-  // the 12-bit table from the library's 11-bit one and its list of longer codes (QV.c:365-372 in two levels)
-  for (int k = threadIdx.x; k < 4 * DP_SIZE; k += DP_BLOCK)
+  for (int k = threadIdx.x; k < 4 * DP_SIZE; k += (int) blockDim.x)
     { const int      sc = k >> DP_BITS;
       const uint32_t i  = (uint32_t) k & (DP_SIZE - 1), e = g_dec[sc * DX_DEC_SIZE + (i >> (DP_BITS - DX_DEC_BITS))];
       uint32_t len = e >> 8, sym = e & 0xffu;
@@ -498,6 +496,14 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
       (&s_tab[0][0])[k] = (uint16_t) ((len ? 32u - len : 0u) | (sym << 8));
     }
   __syncthreads();
+}
+
+__global__ __launch_bounds__(DP_BLOCK)
+void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds)
+{ __shared__ uint16_t s_tab[4][DP_SIZE];                   // 32 KB: 32 - len | symbol << 8 (low bits 0: longer than DP_BITS)
+  __shared__ uint32_t s_long[4][1 + DX_LONG_MAX];          //  4 KB
+  __shared__ uint32_t s_ring[DP_BLOCK][DP_STRIDE];         // 100 KB
+  dp_build_tables(s_tab, s_long, g_dec, g_long);
 
   const uint64_t ngroup = (a.n + 63) / 64;
   const bool     flip   = a.flip != 0;
@@ -564,6 +570,199 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
             }
           out[L] = '\n';
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  plain lines with the encoder's sub-block index (dx_qv_subindex): k_qv_decode_sub
+// ---------------------------------------------------------------------------------------------
+// A wavefront per (entry, line): lane b decodes sub-block first + b -- K consecutive symbols whose first code's
+// bit offset the index gives -- so the 64 lanes read ONE contiguous piece of the record stream and write 64
+// consecutive K-byte pieces of ONE output line, where a lane per line touches 64 different lines per access.
+// Per round the wave copies the words its sub-blocks span into its LDS window (coalesced dwords, the stream's
+// word alignment restored on the way), as many sub-blocks as the window holds (all 64 unless the codes average
+// more than 9 bits); the lanes then run the same code sequence as k_qv_decode_plain's blocks -- 12-bit look-up,
+// two v_alignbit, one v_perm per code -- with refills that are plain LDS reads: no ring, no fetch.  Sixteen
+// symbols leave as one 16-byte store; K is a multiple of 16, only the line's last sub-block can be ragged.
+// LDS: only the tables of the NK plain kinds present (9 KB each) + a 5 KB window per wave; with the usual two
+// plain lines (ins, mrg) two 12-wave workgroups share a CU (78 KB each), 6 waves per SIMD instead of the 4 of the
+// lane-per-line kernels -- the kernel is bound by the look-up -> shift -> look-up chain of a lane and by VALU issue,
+// no longer by memory, and every further wave hides more of that chain.
+#define DS_BLOCK 768
+#define DS_NWAVE (DS_BLOCK / 64)
+#define DS_WIN   1280                                      // words per wave: 5 KB
+
+struct winrd
+{ const uint32_t *win;
+  uint32_t wi;                   // next word of the window
+  uint32_t hi, lo;               // bit buffer: next bit in bit 31 of hi
+  int      nb;                   // valid bits
+};
+
+__device__ __forceinline__ void wr_fill(winrd &r)           // at least 32 valid bits afterwards
+{ if (r.nb < 32)
+    { const uint32_t w = r.win[r.wi];
+      r.wi += 1;
+      r.hi |= w >> r.nb;
+      r.lo  = __builtin_amdgcn_alignbit(w, 0u, (uint32_t) r.nb);        // w << (32 - nb); 0 for nb == 0
+      r.nb += 32;
+    }
+}
+
+__device__ __forceinline__ uint32_t wr_symbol(winrd &r, const uint16_t *tab, const uint32_t *lng)
+{ wr_fill(r);
+  const uint32_t w = r.hi >> 16;
+  const uint32_t e = tab[w >> (16 - DP_BITS)];
+  uint32_t len = (e & 31u) ? 32u - (e & 31u) : 0u, sym = e >> 8;
+  if (len == 0)                                            // code longer than the primary index
+    { const uint32_t cnt = lng[0];
+      for (uint32_t k = 1; k <= cnt; k++)
+        { const uint32_t t = lng[k], l = (t >> 8) & 0xffu;
+          if ((w >> (16u - l)) == ((t >> 16) >> (16u - l)))
+            { len = l; sym = t & 0xffu;
+              break;
+            }
+        }
+      if (len == 0) len = 1;                               // no such code (corrupt stream): keep moving
+    }
+  r.hi  = __builtin_amdgcn_alignbit(r.hi, r.lo, 32u - len);
+  r.lo <<= len;
+  r.nb -= (int) len;
+  return sym;
+}
+
+// 8 codes into two output words
+__device__ __forceinline__ void ds_block8(winrd &rd, const uint16_t *tab, const uint32_t *lng, uint32_t &o0, uint32_t &o1)
+{ const winrd saved = rd;
+  uint32_t w[2] = { 0u, 0u }, zand = 31u;
+  #pragma unroll
+  for (int k = 0; k < 8; k += 2)
+    { wr_fill(rd);                                         // >= 32 bits: enough for two codes of <= 16
+      #pragma unroll
+      for (int h = 0; h < 2; h++)
+        { const uint32_t e = tab[rd.hi >> (32 - DP_BITS)];
+          zand &= e;                                       // 32 - len is 16..31 (bit 4 set) unless the code is longer than the index
+          rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, e);
+          rd.lo = __builtin_amdgcn_alignbit(rd.lo, 0u, e);
+          rd.nb += (int) (e & 31u) - 32;
+          w[(k + h) >> 2] = __builtin_amdgcn_perm(e, w[(k + h) >> 2],
+                                                  ((k + h) & 3) == 0 ? 0x03020105u : ((k + h) & 3) == 1 ? 0x03020500u :
+                                                  ((k + h) & 3) == 2 ? 0x03050100u : 0x05020100u);
+        }
+    }
+  if (__any((int) (~zand & 16u)))                          // a long code somewhere: this block again, code by code
+    { rd = saved;
+      #pragma unroll 1
+      for (int k = 0; k < 8; k++)
+        { const uint32_t c = wr_symbol(rd, tab, lng);
+          w[k >> 2] = (k & 3) ? (w[k >> 2] | (c << (8 * (k & 3)))) : c;
+        }
+    }
+  o0 = w[0]; o1 = w[1];
+}
+
+template <int NK>
+__global__ __launch_bounds__(DS_BLOCK)
+void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds,
+                     const uint32_t *sub_idx, const uint64_t *sub_off)
+{ __shared__ uint16_t s_tab[NK][DP_SIZE];                  // 8 KB each
+  __shared__ uint32_t s_long[NK][1 + DX_LONG_MAX];         // 1 KB each
+  __shared__ uint32_t s_win[DS_NWAVE][DS_WIN];             // 60 KB
+  // tables of the kinds present, in the order of their bits (dp_build_tables for a subset)
+  { int slot_of[4], nk = 0;
+    for (int q = 0; q < 4; q++) slot_of[q] = ((kinds >> q) & 1u) ? nk++ : -1;
+    for (int q = 0; q < 4; q++)
+      if (slot_of[q] >= 0)
+        for (int k = threadIdx.x; k < 1 + DX_LONG_MAX; k += DS_BLOCK) s_long[slot_of[q]][k] = g_long[q * (1 + DX_LONG_MAX) + k];
+    __syncthreads();
+    for (int q = 0; q < 4; q++)
+      if (slot_of[q] >= 0)
+        for (int i_ = threadIdx.x; i_ < DP_SIZE; i_ += DS_BLOCK)
+          { const uint32_t i = (uint32_t) i_, e = g_dec[q * DX_DEC_SIZE + (i >> (DP_BITS - DX_DEC_BITS))];
+            uint32_t len = e >> 8, sym = e & 0xffu;
+            if (len == 0)                                  // longer than 11 bits: exactly DP_BITS long?
+              { const uint32_t *lg = s_long[slot_of[q]], cnt = lg[0], pre = i << (16 - DP_BITS);
+                for (uint32_t j = 1; j <= cnt; j++)
+                  { const uint32_t t = lg[j], l = (t >> 8) & 0xffu;
+                    if (l <= DP_BITS && (pre >> (16u - l)) == ((t >> 16) >> (16u - l)))
+                      { len = l; sym = t & 0xffu; }
+                  }
+              }
+            s_tab[slot_of[q]][i] = (uint16_t) ((len ? 32u - len : 0u) | (sym << 8));
+          }
+    __syncthreads();
+  }
+  uint32_t *const win  = s_win[threadIdx.x >> 6];
+  const int       lane = lane_id();
+
+  for (;;)                                                 // a task = the plain lines of one entry (n < 2^31)
+    { uint32_t t = 0;
+      if (lane == 0)
+        t = atomicAdd(next_task, 1u);
+      t = uniform(t);
+      if ((uint64_t) t >= a.n) break;                      // every wave gets here: the counter only grows
+      const uint64_t r = t;
+      int slot = -1;
+      #pragma unroll 1
+      for (uint32_t q = 0; q < 4; q++)
+      { if (!((kinds >> q) & 1u)) continue;
+        slot += 1;
+      const int       line = q == 0 ? 0 : (int) q + 1;     // output line / segment index
+      const uint32_t  L    = a.len[r];
+      const uint32_t *sg   = a.seg + 5 * r;
+      uint64_t at = a.rec_off[r] + (a.hdr_off ? a.hdr_off[r + 1] - a.hdr_off[r] : 0);
+      for (int k = 0; k < line; k++)
+        at += sg[k];
+      const uint8_t  *seg    = a.in + at;
+      const uint32_t  sbytes = sg[line];
+      uint8_t        *out    = a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u);
+      const uint32_t  K      = 16u * sub_kk(L), nsub = sub_count(L);
+      const uint32_t *sub    = sub_idx + sub_off[r] + (uint64_t) q * nsub;
+      const uint16_t *tab    = s_tab[slot];
+      const uint32_t *lng    = s_long[slot];
+
+      for (uint32_t first = 0; first < nsub; )
+        { const uint32_t j  = first + (uint32_t) lane;
+          const bool     in = j < nsub;
+          const uint32_t b0 = in ? sub[j] : 0xffffffffu;
+          const uint32_t b1 = j + 1 < nsub ? sub[j + 1] : 8u * sbytes;
+          const uint32_t w0 = uniform(b0) >> 5;            // the round's first word of the stream
+          const uint32_t endw = ((b1 + 31u) >> 5) + 2u - w0;             // words up to this lane's end + the look-ahead
+          const uint32_t m  = (uint32_t) __popcll(__ballot(in && endw <= DS_WIN));   // (offsets ascend: a prefix of the lanes)
+          const uint32_t mm = m ? m : 1u;                  // a single sub-block always fits (256 codes of <= 16 bits = 128 words)
+          const uint32_t nw = (uint32_t) __builtin_amdgcn_readlane((int) (endw < DS_WIN ? endw : DS_WIN), (int) mm - 1);
+          for (uint32_t i = (uint32_t) lane; i < nw; i += 64)
+            { const uint64_t byte = 4ull * (w0 + i);
+              win[i] = byte + 4u <= sbytes ? *(const u32_u *) (seg + byte) : 0u;     // (segments are whole words, QV.c:436-442)
+            }
+          wave_sync();
+          if ((uint32_t) lane < mm && in)
+            { const uint32_t cnt = L - j * K < K ? L - j * K : K;
+              uint8_t *o = out + (uint64_t) j * K;
+              winrd rd;
+              rd.win = win;
+              { const uint32_t sb = b0 - 32u * w0, off = sb & 31u;
+                rd.wi = (sb >> 5) + 1u;
+                rd.hi = win[sb >> 5] << off; rd.lo = 0u; rd.nb = 32 - (int) off;
+              }
+              uint32_t t16 = 0;
+              for (; t16 + 16u <= K; t16 += 16u)           // (all lanes but the line's last sub-block's run all of these)
+                if (t16 + 16u <= cnt)
+                  { uint32_t x0, x1, x2, x3;
+                    ds_block8(rd, tab, lng, x0, x1);
+                    ds_block8(rd, tab, lng, x2, x3);
+                    const u32x4 v = { x0, x1, x2, x3 };
+                    *(u32x4_u *) (o + t16) = v;
+                  }
+              for (uint32_t k = cnt & ~15u; k < cnt; k++)  // the ragged end of the line
+                o[k] = (uint8_t) wr_symbol(rd, tab, lng);
+            }
+          wave_sync();
+          first += mm;
+        }
+      if (lane == 0)
+        out[L] = '\n';
+      }
     }
 }
 
@@ -670,15 +869,39 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   uint32_t *d_next = (uint32_t *) (ctx->d_u64 + 16), *d_next2 = (uint32_t *) (ctx->d_u64 + 31);   // task counters
   DX_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
   DX_HIP(ctx, hipMemsetAsync(d_next2, 0, 4, ctx->stream));
+  const uint32_t plain_kinds = plain;
+  // the encoder's sub-block index for this very stream (dx_qv_subindex): a wavefront per line instead of a lane
+  if (plain && ctx->sx.valid && d_in == ctx->sx.out && !(flags & DX_DECODE_FLIP) && getenv("DEXGPU_NO_SUBINDEX") == NULL &&
+      (const uint32_t *) d_seg >= (const uint32_t *) ctx->sx.seg &&
+      ((const uint32_t *) d_seg - (const uint32_t *) ctx->sx.seg) % 5 == 0)
+    { const uint64_t first = (uint64_t) ((const uint32_t *) d_seg - (const uint32_t *) ctx->sx.seg) / 5;
+      if (first + n <= ctx->sx.n)
+        { uint32_t *d_next3 = (uint32_t *) (ctx->d_u64 + 30);
+          DX_HIP(ctx, hipMemsetAsync(d_next3, 0, 4, ctx->stream));
+          const int nk = __builtin_popcount(plain);
+          uint64_t sb = (n + DS_NWAVE - 1) / DS_NWAVE;
+          if (sb > cap * (nk <= 2 ? 2 : 1)) sb = cap * (nk <= 2 ? 2 : 1);       // two workgroups per CU fit with <= 2 tables
+#define SUB_LAUNCH(NK)                                                                                        \
+          DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_sub<NK>, (int) sb, DS_BLOCK, a, (const uint16_t *) ctx->d_dec,   \
+                    (const uint32_t *) ctx->d_long, d_next3, plain, (const uint32_t *) ctx->sx.idx,            \
+                    (const uint64_t *) (ctx->sx.off + first))
+          if (nk == 1)      SUB_LAUNCH(1);
+          else if (nk == 2) SUB_LAUNCH(2);
+          else if (nk == 3) SUB_LAUNCH(3);
+          else              SUB_LAUNCH(4);
+#undef SUB_LAUNCH
+          plain = 0;                                       // done; the run-coded lines and the tags follow as ever
+        }
+    }
   if (plain)
     { uint64_t pb = (4 * ((n + 63) / 64) + DP_NWAVE - 1) / DP_NWAVE;
       if (pb > cap * DP_WG_PER_CU) pb = cap * DP_WG_PER_CU;
       DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_plain, (int) pb, DP_BLOCK, a, (const uint16_t *) ctx->d_dec,
                 (const uint32_t *) ctx->d_long, d_next2, plain);
     }
-  if (plain != 15u)
+  if (plain_kinds != 15u)
     DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,
-              (const uint32_t *) ctx->d_long, ctx->d_status, d_next, 15u & ~plain);
+              (const uint32_t *) ctx->d_long, ctx->d_status, d_next, 15u & ~plain_kinds);
   DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -126,7 +126,8 @@ __device__ __forceinline__ void build_pair_tables(uint32_t (*s_pair)[4096], cons
 }
 
 // one full step (16 bytes per lane) of Encode through the pair table; false: not applicable to this step
-__device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 &c, const uint32_t *ptab, uint32_t lo4, uint32_t m4)
+__device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 &c, const uint32_t *ptab, uint32_t lo4, uint32_t m4,
+                                                       sub_mark &sm)
 { uint32_t tok[8];
   uint32_t ssum = 0, zor = 0, bad = 0;
   #pragma unroll
@@ -146,6 +147,7 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
   if (__any((int) ((bad & 0xc0c0c0c0u) | (zor & 32u) | (nb > 128u))))
     return false;
   const uint32_t incl = wave_incl_scan(nb);
+  sub_step(sm, 32u * o.wordbase + o.winbits + incl - nb, true);
   FOR_EACH_ROUND(o, incl, nb,
     { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
       _Pragma("unroll")
@@ -167,7 +169,8 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
 __global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
                       enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
-                      const uint8_t *hdr, const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint64_t out_cap)
+                      const uint8_t *hdr, const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint64_t out_cap,
+                      sub_sink sx)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint32_t s_pair[2][4096];
@@ -268,7 +271,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
 #define PLAIN_LOOP(STAB)                                                                        \
               for (uint32_t base = 0; base < L; base += DX_STEP)                                 \
                 { const u32x4 d = fetch(p, pos + DX_STEP, L, over);                              \
-                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4); \
+                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4, sm); \
                   c = d;                                                                         \
                   pos += DX_STEP;                                                                \
                 }
@@ -277,12 +280,14 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                 for (uint32_t base = 0; base < L; base += DX_STEP)                               \
                   { const u32x4 d = fetch(p, pos + DX_STEP, L, over);                            \
                     const bool full = L - base >= DX_STEP;                                       \
-                    if (!full || !encode_plain_step_pair(o, c, PTAB, lo4, m4))                   \
-                      encode_plain_step(o, c, valid_of(pos, L), full, tab, STAB, m4);            \
+                    if (!full || !encode_plain_step_pair(o, c, PTAB, lo4, m4, sm))               \
+                      encode_plain_step(o, c, valid_of(pos, L), full, tab, STAB, m4, sm);        \
                     c = d;                                                                       \
                     pos += DX_STEP;                                                              \
                   }                                                                              \
               }
+              sub_mark sm;
+              sub_begin(sm, sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_count(L) : (uint32_t *) NULL, L);
               if (q == 1)
                 { if (pair_lo_ins != PAIR_NONE) PAIR_LOOP(s_stok[1], s_pair[0], pair_lo_ins)
                   else                          { PLAIN_LOOP(s_stok[1]) }

@@ -437,6 +437,90 @@ def test_device_round_trip_with_encoder_index(ctx):
     assert d_txt2.download(np.uint8, len(c.text)).tobytes() == c.text
 
 
+@pytest.mark.parametrize("route", ["scratch", "direct", "text"])
+@pytest.mark.parametrize("case", ["ragged", "long_codes", "no_runs", "lossy", "long_entries", "odd_entries"])
+def test_decode_with_the_encoders_subblock_index(ctx, case, route, monkeypatch):
+    """dx_qv_subindex: the one-pass encoder (each of its routes) leaves the bit offset of every K-th symbol of the plain
+    lines; dx_qv_decode of that stream in the same context then runs k_qv_decode_sub, a wavefront per line.  Same text
+    as without the index, byte for byte -- whole batch, a contiguous part of it, and after the index has gone stale."""
+    if route == "direct":
+        monkeypatch.setenv("DEXGPU_DIRECT_ENCODE", "1")
+    if route == "text":
+        monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
+    lossy = case == "lossy"
+    if case == "ragged":                                          # every sub-block shape: 0, < 16, multiples of 16, around 1024 / 16384
+        lens = np.array(list(range(0, 70)) + [255, 256, 257, 1023, 1024, 1025, 1040, 2047, 2048, 2049, 4097, 9999, 10000,
+                                              16383, 16384, 16385, 16400] + [7000] * 30, np.uint32)
+        c = synth.make_quiva(len(lens), seed=31, lens=lens)
+    elif case == "long_entries":                                  # 256-symbol sub-blocks, several rounds of 64 per line
+        lens = np.array([70001, 140000, 33000, 16385, 5], np.uint32)
+        c = synth.make_quiva(len(lens), seed=32, lens=lens)
+    elif case == "odd_entries":                                   # entries of the unusable list go through the generic encoder
+        c = synth.make_quiva(40, seed=9, mean=4000)
+        txt, rc_d = bytearray(c.text), O.qv_scan(c.text).delChar
+        for e, run in ((3, 126), (5, 127), (9, 300)):
+            o_ = int(c.off[e]) + 49
+            txt[o_: o_ + run + 2] = b"5" + bytes([rc_d]) * run + b"5"
+            o1 = int(c.off[e]) + (int(c.len[e]) + 1) + 49
+            txt[o1: o1 + run + 2] = b"A" + b"N" * run + b"A"
+        c.text = bytes(txt)
+    else:
+        c = synth.make_quiva(120, seed=33, mean=6000)
+    st = O.qv_scan(c.text)
+    n = len(c.len)
+    b, keep = _upload_quiva(ctx, c)
+    if case == "long_codes":                                      # 16-bit codes: the sub-blocks of a round outgrow the window
+        sub = st.subChar if st.subChar >= 0 else int(np.argmax(O.hist_array(st)[3]))
+        coding = _fixed_coding(16, 16, True, st.delChar, sub)
+        ctx.qv_hist(b, L.QVParams(coding.delChar, coding.subChar, 0, 0))
+    elif case == "no_runs":                                       # all four lines plain
+        coding = _fixed_coding(7, 9, False, -1, -1)
+        ctx.qv_hist(b, L.QVParams(-1, -1, 0, 0))
+    else:
+        p = ctx.qv_prescan(b)
+        hist, tot = ctx.qv_hist(b, p)
+        coding = api.qv_build(hist, tot, p, lossy)
+    ctx.qv_set_coding(coding, lossy)
+    blob, hoff, _ = api.frame_headers(c.hdr)
+    d_hdr, d_hoff = ctx.to_device(blob), ctx.to_device(hoff)
+    d_rec, d_seg = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n)
+    cap = len(c.text) + 4096 * n + 4096
+    d_out = ctx.alloc(cap)
+
+    def decode(first=0, count=None, wipe=True):
+        count = n - first if count is None else count
+        img = np.frombuffer(c.text, np.uint8).copy()
+        for i in range(n):
+            img[int(c.off[i]): int(c.off[i]) + 5 * (int(c.len[i]) + 1)] = 0
+        d_txt = ctx.to_device(img)
+        ctx.qv_decode(d_out, d_rec.offset(8 * first), d_hoff.offset(8 * first), d_seg.offset(20 * first),
+                      keep[2].offset(4 * first), count, True, d_txt, keep[1].offset(8 * first))
+        return d_txt.download(np.uint8, len(c.text)).tobytes()
+
+    ctx.qv_subindex(False)
+    ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg, d_rec, d_out, cap)
+    want = decode()                                               # the lane-per-line kernels
+    ctx.qv_subindex(True)
+    try:
+        total = ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg, d_rec, d_out, cap)
+        ctx.profile(True)
+        got = decode()
+        ran = ctx.kernel_times()
+        ctx.profile(False)
+        assert got == want
+        if not lossy and case not in ("long_codes", "no_runs"):   # (the hand-made tables do not cover every byte value)
+            assert got == c.text
+        assert ran["k_qv_decode"][1] == (2 if case == "no_runs" else 3)      # sub + (run lines) + tags: no lane-per-line plain kernel
+        first, count = n // 3, n // 2                             # a contiguous part of the batch
+        part = decode(first, count)
+        lo, hi = int(c.off[first]), int(c.off[first + count - 1]) + 5 * (int(c.len[first + count - 1]) + 1)
+        assert part[lo:hi] == want[lo:hi]
+        ctx.qv_set_coding(coding, lossy)                          # tables set again: the index is dropped, the old kernels decode
+        assert decode() == want
+    finally:
+        ctx.qv_subindex(False)
+
+
 def test_undexqv_no_delchar_and_type2(ctx, decoder):
     for name in ("qv_nodel", "qv_type2", "qv_runs"):
         dx = O.golden(name + ".dexqv")
