@@ -165,6 +165,8 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if os.environ.get("DEXGPU_BENCH_ONE_DEVICE"):      # (testing the N > 1 path on a one-GPU box: every rank on device 0)
+        local = 0
     torch.cuda.set_device(local)
 
     from dextractor_amd import _lib as L
