@@ -1,3 +1,7 @@
+"""Debugging aid (GPU box): one encode with the sub-block index + one decode, with a watchdog and per-line diffs.
+
+    python tools/dbg/dbg_sub.py [scratch|direct|text] [len,len,...]
+"""
 import sys, os, faulthandler
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 faulthandler.dump_traceback_later(40, exit=True)
