@@ -104,9 +104,11 @@ __device__ __forceinline__ uint32_t chunk_eq_mask(const u32x4 &v, uint32_t c)
 
 __device__ __forceinline__ void store32_u(uint8_t *p, uint32_t v) { *(u32_u *) p = v; }
 
-// sub-block index of the plain QV lines (dx_qv.hip writes it, dx_qv_decode.hip reads it): sub-blocks of 16 * kk symbols
-__host__ __device__ __forceinline__ uint32_t sub_kk(uint32_t L)    { const uint32_t k = (L + 1023u) >> 10; return k < 1u ? 1u : (k > 16u ? 16u : k); }
-__host__ __device__ __forceinline__ uint32_t sub_count(uint32_t L) { const uint32_t K = 16u * sub_kk(L); return (L + K - 1u) / K; }
+// group index of the plain QV lines (dx_qv.hip writes it, dx_qv_decode.hip reads it): one byte per group of 16
+// symbols = the group's code bits minus its symbols; sub_words(L) 32-bit words per line
+__host__ __device__ __forceinline__ uint32_t sub_groups(uint32_t L) { return (L + 15u) >> 4; }
+__host__ __device__ __forceinline__ uint32_t sub_words(uint32_t L)  { return (sub_groups(L) + 3u) >> 2; }
+#define SUB_NONE 255u                                       // first byte of a line: no index (a symbol without a code)
 
 // ---------------------------------------------------------------------------------------------
 //  per-wave output window: bits are ORed into a zeroed LDS word window (MSB-first within 32-bit

@@ -67,7 +67,7 @@ struct dx_ctx
   // sub-block index of the plain lines, left by dx_qv_encode_onepass for dx_qv_decode when dx_qv_subindex is on
   struct
   { int       want, valid;
-    uint32_t *idx;               // bit offsets, 4 * sub_count(len) words per entry
+    uint32_t *idx;               // one byte per group of 16 symbols, 4 * sub_words(len) words per entry
     uint64_t *off;               // n + 1: where each entry's words start
     uint32_t *room;              // n: scratch of the offsets' scan
     size_t    cap_idx, cap_entries;

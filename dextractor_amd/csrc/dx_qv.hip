@@ -953,34 +953,30 @@ __device__ __forceinline__ void place_bits128(uint32_t *win, uint32_t bit, uint3
   if (x4) atomicOr(&win[we - 4], x4);
 }
 
-// ---- sub-block index of the plain lines (decoder side: k_qv_decode_sub, dx_qv_decode.hip) --------------------
+// ---- group index of the plain lines (decoder side: k_qv_decode_sub, dx_qv_decode.hip) -----------------------
 // A Huffman stream decodes front to back only; the encoder, though, knows where every code starts.  On request
-// (dx_qv_subindex) it leaves, for each plain line, the bit offset of every K-th symbol, K = 16 * kk,
-// kk = min(16, ceil(L / 1024)): at most 64 sub-blocks for lines up to 16 k symbols, 256-symbol sub-blocks beyond.
-// A sub-block always starts with a lane's 16 symbols of some step, whose bit offset the step's prefix sum gives.
-// Per entry 4 * nsub(L) words (a line that is run-coded leaves its share unused), at sub_off[r].
-// (sub_kk, sub_count: dx_device.hpp)
-
+// (dx_qv_subindex) it leaves, for each plain line, one byte per group of 16 symbols -- the 16 a lane codes in a
+// step -- holding the group's code bits minus its symbols (16 codes of 1..16 bits: 0..240).  The prefix sum of 64
+// such bytes gives the decoder the bit at which each of 64 consecutive groups starts.  A line with a symbol that
+// has no code (hand-made tables) gets SUB_NONE in its first byte: that line is decoded group after group.
+// Per entry 4 * sub_words(L) words, at sub_off[r].
 struct sub_mark
-{ uint32_t *at;               // this line's nsub words, NULL: no index wanted
-  uint32_t  rem, quo;         // the lane's 16 symbols of this step are symbols 16 * (quo * kk + rem) ... of the line
-  uint32_t  kk, dr, dq;       // per step: 64 lanes further = dq sub-blocks and dr lanes
+{ uint8_t *at;                // this line's bytes, NULL: no index wanted
+  uint32_t g;                 // the group this lane codes in this step
 };
 
-__device__ __forceinline__ void sub_begin(sub_mark &m, uint32_t *at, uint32_t L)
-{ const uint64_t A = (uint64_t) at;                             // wave-uniform values: keep them in scalar registers
-  m.at = (uint32_t *) (((uint64_t) uniform((uint32_t) (A >> 32)) << 32) | uniform((uint32_t) A));
-  m.kk = uniform(sub_kk(L));
-  m.quo = (uint32_t) lane_id() / m.kk; m.rem = (uint32_t) lane_id() % m.kk;
-  m.dq  = uniform(64u / m.kk);         m.dr  = uniform(64u % m.kk);
+__device__ __forceinline__ void sub_begin(sub_mark &m, uint32_t *at)
+{ const uint64_t A = (uint64_t) at;                             // wave-uniform: keep it in scalar registers
+  m.at = (uint8_t *) (((uint64_t) uniform((uint32_t) (A >> 32)) << 32) | uniform((uint32_t) A));
+  m.g  = (uint32_t) lane_id();
 }
 
-// `start` = bit offset of this lane's codes in the stream, `some` = the lane has symbols in this step
-__device__ __forceinline__ void sub_step(sub_mark &m, uint32_t start, bool some)
+// nb = code bits of this lane's `valid` symbols of the step; nocode = one of them has no code
+__device__ __forceinline__ void sub_step(sub_mark &m, uint32_t nb, uint32_t valid, bool nocode)
 { if (m.at == NULL) return;
-  if (m.rem == 0 && some) m.at[m.quo] = start;
-  m.quo += m.dq; m.rem += m.dr;
-  if (m.rem >= m.kk) { m.rem -= m.kk; m.quo += 1; }
+  if (valid) m.at[m.g] = (uint8_t) (nb - valid);
+  if (__any((int) nocode)) { wave_sync(); if (lane_id() == 0) m.at[0] = (uint8_t) SUB_NONE; m.at = NULL; }
+  m.g += 64u;
 }
 
 struct sub_sink { uint32_t *idx; const uint64_t *off; };           // idx == NULL: none wanted
@@ -1012,7 +1008,7 @@ __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, i
   const uint32_t nb   = 512u - ssum;
   const uint32_t k    = 16u - (uint32_t) valid;                        // dummies (0 unless ragged)
   const uint32_t incl = wave_incl_scan(nb);
-  sub_step(sm, 32u * o.wordbase + o.winbits + incl - nb, valid > 0);
+  sub_step(sm, nb, (uint32_t) valid, (zor & 32u) != 0u);
   const bool fast = !__any((int) ((zor & 32u) | (nb + k > 128u)));
   if (fast)
     { // every token has 1..24 bits and the lane's string fits 128 bits: branch-free packing.  The
@@ -1367,7 +1363,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
                   pos += DX_STEP;                                                                \
                 }
               sub_mark sm;
-              sub_begin(sm, sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_count(L) : (uint32_t *) NULL, L);
+              sub_begin(sm, sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_words(L) : (uint32_t *) NULL);
               if (q == 1)      { PLAIN_LOOP(s_stok[1]) }
               else if (q == 2) { PLAIN_LOOP(s_stok[2]) }
               else             { PLAIN_LOOP(s_stok[q]) }
@@ -1841,7 +1837,7 @@ static int onepass_side(dx_ctx *ctx, hipStream_t B, const uint32_t *d_size, uint
 __global__ __launch_bounds__(DX_BLOCK)
 void k_sub_rooms(const uint32_t *len, uint64_t n, uint32_t *room)
 { const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
-  if (i < n) room[i] = 4u * sub_count(len[i]);
+  if (i < n) room[i] = 4u * sub_words(len[i]);
 }
 
 extern "C" int dx_qv_subindex(dx_ctx *ctx, int on)

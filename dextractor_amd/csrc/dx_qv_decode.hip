@@ -574,23 +574,22 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
 }
 
 // ---------------------------------------------------------------------------------------------
-//  plain lines with the encoder's sub-block index (dx_qv_subindex): k_qv_decode_sub
+//  plain lines with the encoder's group index (dx_qv_subindex): k_qv_decode_sub
 // ---------------------------------------------------------------------------------------------
-// A wavefront per (entry, line): lane b decodes sub-block first + b -- K consecutive symbols whose first code's
-// bit offset the index gives -- so the 64 lanes read ONE contiguous piece of the record stream and write 64
-// consecutive K-byte pieces of ONE output line, where a lane per line touches 64 different lines per access.
-// Per round the wave copies the words its sub-blocks span into its LDS window (coalesced dwords, the stream's
-// word alignment restored on the way), as many sub-blocks as the window holds (all 64 unless the codes average
-// more than 9 bits); the lanes then run the same code sequence as k_qv_decode_plain's blocks -- 12-bit look-up,
-// two v_alignbit, one v_perm per code -- with refills that are plain LDS reads: no ring, no fetch.  Sixteen
-// symbols leave as one 16-byte store; K is a multiple of 16, only the line's last sub-block can be ragged.
+// A wavefront per (entry, plain line).  The index holds the code bits of every group of 16 symbols; per round the
+// wave takes the next 4 x 64 groups, turns the bit counts into start offsets with four prefix sums, copies the
+// words they span into its LDS window (coalesced dwords, the stream's word alignment restored on the way) and
+// lane b decodes groups b, 64 + b, 128 + b, 192 + b of the round: the 64 lanes' 16-byte stores of one step are
+// 1 KiB of consecutive addresses -- whole lines leave the L2 once -- where a lane per line touches 64 different
+// lines per access.  The lanes run the same code sequence as k_qv_decode_plain's blocks (12-bit look-up, two
+// v_alignbit, one v_perm per code) with refills that are plain LDS reads: no ring, no fetch.  A line marked
+// SUB_NONE (a symbol without a code: hand-made tables only) is decoded group after group by one lane.
 // LDS: only the tables of the NK plain kinds present (9 KB each) + a 5 KB window per wave; with the usual two
-// plain lines (ins, mrg) two 12-wave workgroups share a CU (78 KB each), 6 waves per SIMD instead of the 4 of the
-// lane-per-line kernels -- the kernel is bound by the look-up -> shift -> look-up chain of a lane and by VALU issue,
-// no longer by memory, and every further wave hides more of that chain.
+// plain lines (ins, mrg) two 12-wave workgroups share a CU (78 KB each), 6 waves per SIMD.
 #define DS_BLOCK 768
 #define DS_NWAVE (DS_BLOCK / 64)
 #define DS_WIN   1280                                      // words per wave: 5 KB
+#define DS_STEPS 4                                         // steps of 64 groups per round (one step always fits: <= 515 words)
 
 struct winrd
 { const uint32_t *win;
@@ -716,49 +715,69 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
       const uint8_t  *seg    = a.in + at;
       const uint32_t  sbytes = sg[line];
       uint8_t        *out    = a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u);
-      const uint32_t  K      = 16u * sub_kk(L), nsub = sub_count(L);
-      const uint32_t *sub    = sub_idx + sub_off[r] + (uint64_t) q * nsub;
+      const uint32_t  G      = sub_groups(L);
+      const uint8_t  *at8    = (const uint8_t *) (sub_idx + sub_off[r] + (uint64_t) q * sub_words(L));
       const uint16_t *tab    = s_tab[slot];
       const uint32_t *lng    = s_long[slot];
+      const bool      serial = G > 0 && uniform((uint32_t) at8[0]) == SUB_NONE;
+      uint32_t base = 0;                                   // bit at which the round's first group starts
 
-      for (uint32_t first = 0; first < nsub; )
-        { const uint32_t j  = first + (uint32_t) lane;
-          const bool     in = j < nsub;
-          const uint32_t b0 = in ? sub[j] : 0xffffffffu;
-          const uint32_t b1 = j + 1 < nsub ? sub[j + 1] : 8u * sbytes;
-          const uint32_t w0 = uniform(b0) >> 5;            // the round's first word of the stream
-          const uint32_t endw = ((b1 + 31u) >> 5) + 2u - w0;             // words up to this lane's end + the look-ahead
-          const uint32_t m  = (uint32_t) __popcll(__ballot(in && endw <= DS_WIN));   // (offsets ascend: a prefix of the lanes)
-          const uint32_t mm = m ? m : 1u;                  // a single sub-block always fits (256 codes of <= 16 bits = 128 words)
-          const uint32_t nw = (uint32_t) __builtin_amdgcn_readlane((int) (endw < DS_WIN ? endw : DS_WIN), (int) mm - 1);
+      for (uint32_t g0 = 0; g0 < G; )
+        { // bit counts of up to DS_STEPS x 64 groups, their starts, and how many steps the window holds
+          uint32_t d[DS_STEPS], st[DS_STEPS], upto[DS_STEPS];
+          uint32_t run = base, steps = 0;
+          #pragma unroll
+          for (int k = 0; k < DS_STEPS; k++)
+            { const uint32_t g = g0 + 64u * k + (uint32_t) lane;
+              const uint32_t valid = g < G ? (L - 16u * g < 16u ? L - 16u * g : 16u) : 0u;
+              d[k] = valid ? (uint32_t) at8[g] + valid : 0u;
+              if (serial) d[k] = valid && lane == 0 && k == 0 ? 16u * valid : 0u;      // (an upper bound: one group at a time)
+            }
+          #pragma unroll
+          for (int k = 0; k < DS_STEPS; k++)
+            { const uint32_t incl = wave_incl_scan(d[k]);
+              st[k]   = run + incl - d[k];
+              run    += wave_total(incl);
+              upto[k] = run;
+              if (((upto[k] + 31u) >> 5) + 2u - (base >> 5) <= DS_WIN && g0 + 64u * k < G && (!serial || k == 0)) steps = k + 1;
+            }
+          const uint32_t w0 = base >> 5;
+          const uint32_t nw = ((upto[steps - 1] + 31u) >> 5) + 2u - w0;
           for (uint32_t i = (uint32_t) lane; i < nw; i += 64)
             { const uint64_t byte = 4ull * (w0 + i);
               win[i] = byte + 4u <= sbytes ? *(const u32_u *) (seg + byte) : 0u;     // (segments are whole words, QV.c:436-442)
             }
           wave_sync();
-          if ((uint32_t) lane < mm && in)
-            { const uint32_t cnt = L - j * K < K ? L - j * K : K;
-              uint8_t *o = out + (uint64_t) j * K;
-              winrd rd;
-              rd.win = win;
-              { const uint32_t sb = b0 - 32u * w0, off = sb & 31u;
-                rd.wi = (sb >> 5) + 1u;
-                rd.hi = win[sb >> 5] << off; rd.lo = 0u; rd.nb = 32 - (int) off;
-              }
-              uint32_t t16 = 0;
-              for (; t16 + 16u <= K; t16 += 16u)           // (all lanes but the line's last sub-block's run all of these)
-                if (t16 + 16u <= cnt)
-                  { uint32_t x0, x1, x2, x3;
-                    ds_block8(rd, tab, lng, x0, x1);
-                    ds_block8(rd, tab, lng, x2, x3);
-                    const u32x4 v = { x0, x1, x2, x3 };
-                    *(u32x4_u *) (o + t16) = v;
+          uint32_t used = 0;                               // serial mode: bits the group really took
+          #pragma unroll
+          for (int k = 0; k < DS_STEPS; k++)
+            if ((uint32_t) k < steps)
+              { const uint32_t g = g0 + 64u * k + (uint32_t) lane;
+                const uint32_t valid = g < G && (!serial || lane == 0) ? (L - 16u * g < 16u ? L - 16u * g : 16u) : 0u;
+                if (valid)
+                  { winrd rd;
+                    rd.win = win;
+                    { const uint32_t sb = st[k] - 32u * w0, off = sb & 31u;
+                      rd.wi = (sb >> 5) + 1u;
+                      rd.hi = win[sb >> 5] << off; rd.lo = 0u; rd.nb = 32 - (int) off;
+                    }
+                    uint8_t *o = out + 16ull * g;
+                    if (valid == 16u)
+                      { uint32_t x0, x1, x2, x3;
+                        ds_block8(rd, tab, lng, x0, x1);
+                        ds_block8(rd, tab, lng, x2, x3);
+                        const u32x4 v = { x0, x1, x2, x3 };
+                        *(u32x4_u *) o = v;
+                      }
+                    else
+                      for (uint32_t j = 0; j < valid; j++)   // the ragged end of the line
+                        o[j] = (uint8_t) wr_symbol(rd, tab, lng);
+                    used = 32u * (rd.wi - 1u - ((st[k] - 32u * w0) >> 5)) + (32u - ((st[k] - 32u * w0) & 31u)) - (uint32_t) rd.nb;
                   }
-              for (uint32_t k = cnt & ~15u; k < cnt; k++)  // the ragged end of the line
-                o[k] = (uint8_t) wr_symbol(rd, tab, lng);
-            }
+              }
           wave_sync();
-          first += mm;
+          if (serial) { base += uniform(used); g0 += 1; }
+          else        { base  = upto[steps - 1]; g0 += 64u * steps; }
         }
       if (lane == 0)
         out[L] = '\n';

@@ -147,7 +147,7 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
   if (__any((int) ((bad & 0xc0c0c0c0u) | (zor & 32u) | (nb > 128u))))
     return false;
   const uint32_t incl = wave_incl_scan(nb);
-  sub_step(sm, 32u * o.wordbase + o.winbits + incl - nb, true);
+  sub_step(sm, nb, 16u, false);
   FOR_EACH_ROUND(o, incl, nb,
     { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
       _Pragma("unroll")
@@ -287,7 +287,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                   }                                                                              \
               }
               sub_mark sm;
-              sub_begin(sm, sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_count(L) : (uint32_t *) NULL, L);
+              sub_begin(sm, sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_words(L) : (uint32_t *) NULL);
               if (q == 1)
                 { if (pair_lo_ins != PAIR_NONE) PAIR_LOOP(s_stok[1], s_pair[0], pair_lo_ins)
                   else                          { PLAIN_LOOP(s_stok[1]) }
