@@ -305,9 +305,9 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         state["decode"] = {"kernel": "k_qv_decode_plain + k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),
                            "output_GBps": round(5.0 * bases / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None}
         if not args.twopass:
-            # ... and with the encoder's sub-block index (dx_qv_subindex): one more, untimed, encode that leaves the index,
+            # ... and with the encoder's group index (dx_qv_subindex): one more, untimed, encode that leaves the index,
             # then the plain lines are decoded a wavefront per line (k_qv_decode_sub)
-            trace("verify: decode with the sub-block index")
+            trace("verify: decode with the group index")
             ctx.qv_subindex(True)
             ctx.profile(True)
             step()

@@ -64,7 +64,7 @@ struct dx_ctx
     int         valid;
   } tk;
 
-  // sub-block index of the plain lines, left by dx_qv_encode_onepass for dx_qv_decode when dx_qv_subindex is on
+  // group index of the plain lines, left by dx_qv_encode_onepass for dx_qv_decode when dx_qv_subindex is on
   struct
   { int       want, valid;
     uint32_t *idx;               // one byte per group of 16 symbols, 4 * sub_words(len) words per entry

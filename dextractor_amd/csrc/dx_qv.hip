@@ -1706,7 +1706,7 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
   ctx->lossy   = lossy != 0;
   ctx->delChar = c->delChar;
   ctx->subChar = c->subChar;
-  ctx->sx.valid = 0;                                     // (a sub-block index belongs to a stream of the tables before)
+  ctx->sx.valid = 0;                                     // (a group index belongs to a stream of the tables before)
   return DX_OK;
 }
 
@@ -1787,7 +1787,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   if (b->n == 0) return DX_OK;
   if (!d_rec_off || !d_seg || !d_out) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
-  if (ctx->sx.out == (const void *) d_out) ctx->sx.valid = 0;            // (the two-pass encoder leaves no sub-block index)
+  if (ctx->sx.out == (const void *) d_out) ctx->sx.valid = 0;            // (the two-pass encoder leaves no group index)
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
@@ -1833,7 +1833,7 @@ static int onepass_side(dx_ctx *ctx, hipStream_t B, const uint32_t *d_size, uint
   return DX_OK;
 }
 
-// ---- sub-block index: room for it -----------------------------------------------------------------------------
+// ---- group index: room for it -----------------------------------------------------------------------------
 __global__ __launch_bounds__(DX_BLOCK)
 void k_sub_rooms(const uint32_t *len, uint64_t n, uint32_t *room)
 { const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;

@@ -589,7 +589,9 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
 #define DS_BLOCK 768
 #define DS_NWAVE (DS_BLOCK / 64)
 #define DS_WIN   1280                                      // words per wave: 5 KB
+#ifndef DS_STEPS
 #define DS_STEPS 4                                         // steps of 64 groups per round (one step always fits: <= 515 words)
+#endif
 
 struct winrd
 { const uint32_t *win;
@@ -889,7 +891,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   DX_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
   DX_HIP(ctx, hipMemsetAsync(d_next2, 0, 4, ctx->stream));
   const uint32_t plain_kinds = plain;
-  // the encoder's sub-block index for this very stream (dx_qv_subindex): a wavefront per line instead of a lane
+  // the encoder's group index for this very stream (dx_qv_subindex): a wavefront per line instead of a lane
   if (plain && ctx->sx.valid && d_in == ctx->sx.out && !(flags & DX_DECODE_FLIP) && getenv("DEXGPU_NO_SUBINDEX") == NULL &&
       (const uint32_t *) d_seg >= (const uint32_t *) ctx->sx.seg &&
       ((const uint32_t *) d_seg - (const uint32_t *) ctx->sx.seg) % 5 == 0)

@@ -305,12 +305,12 @@ typedef struct
 int  dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *idx);
 void dx_qv_index_free(dx_qv_index *idx);
 
-/* Sub-block index (on = 1): dx_qv_encode_onepass also leaves, in the context, the bit offset of every K-th symbol
- * of each plain line (K = 16 .. 256 by line length; 4 bytes per sub-block, ~7 % of the output for 10 kb entries);
- * a dx_qv_decode of that record stream (same d_in / d_seg, the whole batch or a contiguous part of it) in the same
- * context then decodes each such line with a whole wavefront, 64 sub-blocks at a time, instead of a lane
- * (k_qv_decode_sub).  The .dexqv bytes do not change; a stream decoded without the index (a bare file, another
- * context) takes the lane-per-line kernels.  Off by default.                                                    */
+/* Group index (on = 1): dx_qv_encode_onepass also leaves, in the context, one byte per group of 16 symbols of each
+ * plain line -- the group's code bits minus its symbols (6 % of those lines' text); a dx_qv_decode of that record
+ * stream (same d_in / d_seg, the whole batch or a contiguous part of it) in the same context then decodes each such
+ * line with a whole wavefront, 64 consecutive groups at a time, instead of a lane (k_qv_decode_sub).  The .dexqv
+ * bytes do not change; a stream decoded without the index (a bare file, another context) takes the lane-per-line
+ * kernels.  Off by default.                                                                                      */
 int  dx_qv_subindex(dx_ctx *ctx, int on);
 
 /* ------------------------------------------------------------------------------------------

@@ -439,20 +439,20 @@ def test_device_round_trip_with_encoder_index(ctx):
 
 @pytest.mark.parametrize("route", ["scratch", "direct", "text"])
 @pytest.mark.parametrize("case", ["ragged", "long_codes", "no_runs", "lossy", "long_entries", "odd_entries"])
-def test_decode_with_the_encoders_subblock_index(ctx, case, route, monkeypatch):
-    """dx_qv_subindex: the one-pass encoder (each of its routes) leaves the bit offset of every K-th symbol of the plain
-    lines; dx_qv_decode of that stream in the same context then runs k_qv_decode_sub, a wavefront per line.  Same text
+def test_decode_with_the_encoders_group_index(ctx, case, route, monkeypatch):
+    """dx_qv_subindex: the one-pass encoder (each of its routes) leaves the code bits of every group of 16 symbols of the
+    plain lines; dx_qv_decode of that stream in the same context then runs k_qv_decode_sub, a wavefront per line.  Same text
     as without the index, byte for byte -- whole batch, a contiguous part of it, and after the index has gone stale."""
     if route == "direct":
         monkeypatch.setenv("DEXGPU_DIRECT_ENCODE", "1")
     if route == "text":
         monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
     lossy = case == "lossy"
-    if case == "ragged":                                          # every sub-block shape: 0, < 16, multiples of 16, around 1024 / 16384
+    if case == "ragged":                                          # every group shape: 0, < 16, multiples of 16, around a step (1024) and a round
         lens = np.array(list(range(0, 70)) + [255, 256, 257, 1023, 1024, 1025, 1040, 2047, 2048, 2049, 4097, 9999, 10000,
                                               16383, 16384, 16385, 16400] + [7000] * 30, np.uint32)
         c = synth.make_quiva(len(lens), seed=31, lens=lens)
-    elif case == "long_entries":                                  # 256-symbol sub-blocks, several rounds of 64 per line
+    elif case == "long_entries":                                  # many rounds per line
         lens = np.array([70001, 140000, 33000, 16385, 5], np.uint32)
         c = synth.make_quiva(len(lens), seed=32, lens=lens)
     elif case == "odd_entries":                                   # entries of the unusable list go through the generic encoder
@@ -469,7 +469,7 @@ def test_decode_with_the_encoders_subblock_index(ctx, case, route, monkeypatch):
     st = O.qv_scan(c.text)
     n = len(c.len)
     b, keep = _upload_quiva(ctx, c)
-    if case == "long_codes":                                      # 16-bit codes: the sub-blocks of a round outgrow the window
+    if case == "long_codes":                                      # 16-bit codes: a round of 4 steps outgrows the window
         sub = st.subChar if st.subChar >= 0 else int(np.argmax(O.hist_array(st)[3]))
         coding = _fixed_coding(16, 16, True, st.delChar, sub)
         ctx.qv_hist(b, L.QVParams(coding.delChar, coding.subChar, 0, 0))
