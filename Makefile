@@ -21,9 +21,13 @@ all: lib cli
 
 lib: $(LIB)
 
-$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/dx_internal.hpp $(CSRC)/dx_device.hpp include/dexgpu.h
+# every device compile also leaves the kernels' register / LDS / scratch use in $(BUILD)/<file>.res (compiler remarks);
+# the library target condenses them into dextractor_amd/kernel_resources.txt, which tests/test_host.py checks:
+# some kernels must stay under a register count to share a CU with another kernel
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/dx_internal.hpp $(CSRC)/dx_device.hpp $(CSRC)/dx_qv_fast.hpp include/dexgpu.h
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/$*.res; rc=$$?; \
+	  grep -v "kernel-resource-usage\|^ *[0-9]* | \|^ *| *^" $(BUILD)/$*.res >&2; exit $$rc
 
 $(BUILD)/%.o: $(CSRC)/%.c include/dexgpu.h include/dexcompat.h
 	@mkdir -p $(BUILD)
@@ -31,6 +35,10 @@ $(BUILD)/%.o: $(CSRC)/%.c include/dexgpu.h include/dexcompat.h
 
 $(LIB): $(HIP_OBJ) $(C_OBJ)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $^ -Wl,-rpath,/opt/rocm/lib -Wl,-soname,libdexgpu.so -lpthread
+	@cat $(HIP_SRC:%=$(BUILD)/%.res) | sed -n 's/.*remark: *//p' | sed 's/ \[-Rpass-analysis=kernel-resource-usage\]//' | \
+	  awk '/^Function Name:/ { if (n) print n, v, s, l, o; n = $$3 } /^VGPRs:/ { v = "vgprs=" $$2 } /^ScratchSize/ { s = "scratch=" $$NF } \
+	       /^LDS Size/ { l = "lds=" $$NF } /^Occupancy/ { o = "waves_per_simd=" $$NF } END { if (n) print n, v, s, l, o }' \
+	  > $(dir $(LIB))kernel_resources$(if $(filter $(LIB),dextractor_amd/libdexgpu.so),,_$(notdir $(basename $(LIB)))).txt
 
 cli: $(LIB) $(TOOLS:%=dextractor_amd/bin/%)
 

@@ -1974,10 +1974,16 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       // context's stream: the group's records, in place
       if (hipStreamWaitEvent(A, sz_done[g & 7], 0) != hipSuccess || hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
       dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
-      hipLaunchKernelGGL(k_qv_encode_fast, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                         ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
-                         ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
-                         (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
+      if (sx_idx)
+        hipLaunchKernelGGL(k_qv_encode_fast<true>, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+                           ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
+                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
+      else
+        hipLaunchKernelGGL(k_qv_encode_fast<false>, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+                           ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
+                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
       dx_prof_end_on(ctx, A);
       if (odd)
         { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
@@ -2156,10 +2162,16 @@ layout:
       if (fast)                                          // entries with usable tokens: walked from the tokens
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast, fast_grid(ctx, m), FAST_BLOCK,
-                    ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
-                    ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                    (uint8_t *) NULL, (uint64_t) 0, sx_g);
+          if (sx_idx)
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast<true>, fast_grid(ctx, m), FAST_BLOCK,
+                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
+                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g);
+          else
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast<false>, fast_grid(ctx, m), FAST_BLOCK,
+                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
+                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g);
         }
       if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
         { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;

@@ -166,6 +166,12 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
 #endif
 #define FAST_NWAVE (FAST_BLOCK / 64)
 
+// SUB: with the group index (dx_qv_subindex).  Two instances because of registers: the compaction of the group
+// before runs BESIDE this kernel (k_qv_compact: 52 VGPRs -> 56 allocated), and its waves only find room on a SIMD
+// whose four encoder waves leave 64 of the 512 registers, i.e. at <= 112 each.  The plain instance has 110; with the
+// index code compiled in it had 116 (-> 120 allocated) even when no index was asked for, the two kernels ran one
+// after the other, and a step took 32.7 ms instead of 31.0.
+template <bool SUB>
 __global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
                       enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
@@ -287,7 +293,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                   }                                                                              \
               }
               sub_mark sm;
-              sub_begin(sm, sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_words(L) : (uint32_t *) NULL);
+              sub_begin(sm, SUB && sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_words(L) : (uint32_t *) NULL);
               if (q == 1)
                 { if (pair_lo_ins != PAIR_NONE) PAIR_LOOP(s_stok[1], s_pair[0], pair_lo_ins)
                   else                          { PLAIN_LOOP(s_stok[1]) }

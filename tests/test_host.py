@@ -288,6 +288,30 @@ def test_out_bound_covers_the_encoded_size():
             assert bound < 1.25 * body
 
 
+def test_register_budgets_of_the_kernels_that_share_a_cu():
+    """The build leaves every kernel's register / scratch / LDS use in dextractor_amd/kernel_resources.txt.  The
+    compaction of a group runs beside the next group's encoder (dx_qv_encode_onepass): its waves (<= 56 VGPRs) only fit
+    a SIMD whose four encoder waves use <= 112 each -- at 116 the two kernels ran one after the other and a step took
+    5 % longer.  No kernel may spill to scratch."""
+    path = os.path.join(os.path.dirname(L.LIB_PATH), "kernel_resources.txt")
+    if not os.path.isfile(path):
+        pytest.skip("no kernel_resources.txt (library built without the Makefile)")
+    res = {}
+    for ln in open(path):
+        f = ln.split()
+        res[f[0]] = {k: int(v) for k, v in (x.split("=") for x in f[1:])}
+    def of(prefix):
+        hit = [v for k, v in res.items() if k.startswith(prefix)]
+        assert hit, prefix
+        return hit
+    assert all(v["scratch"] == 0 for v in res.values()), {k: v for k, v in res.items() if v["scratch"]}
+    assert all(v["vgprs"] <= 112 for v in of("_Z16k_qv_encode_fastILb0EE"))      # the product encoder, no group index
+    assert all(v["vgprs"] <= 112 for v in of("_Z11k_qv_encode7qv_args"))         # the generic encoder
+    assert all(v["vgprs"] <= 56 for v in of("_Z12k_qv_compact"))
+    assert all(v["waves_per_simd"] >= 4 for v in of("_Z9k_qv_hist") + of("_Z16k_qv_encode_fast") + of("_Z17k_qv_decode_plain"))
+    assert all(v["waves_per_simd"] >= 6 for v in of("_Z15k_qv_decode_subILi2EE"))
+
+
 def test_no_gpu_means_loud_failure(tmp_path):
     """There is no CPU fallback: without a HIP device the library and the tools refuse to work."""
     import subprocess
