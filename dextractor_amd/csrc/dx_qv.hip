@@ -2083,10 +2083,25 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
     }
 layout:
   { const uint64_t gs = (n + (uint64_t) G - 1) / (uint64_t) G;
+    const char *split = getenv("DEXGPU_ONEPASS_SPLIT");  // (experiments: group sizes in percent, e.g. 20,40,40)
     G = 0;
     gb[0] = 0;
-    for (uint64_t at = 0; at < n; at += gs)
-      gb[++G] = at + gs < n ? at + gs : n;
+    if (split != NULL && *split && n >= 1000)
+      { uint64_t at = 0;
+        while (*split && G < ONEPASS_MAX_GROUPS - 1)
+          { char *e2;
+            const long pc = strtol(split, &e2, 10);
+            if (e2 == split || pc <= 0) break;
+            at += n * (uint64_t) pc / 100;
+            if (at >= n) break;
+            gb[++G] = at;
+            split = *e2 == ',' ? e2 + 1 : e2;
+          }
+        gb[++G] = n;
+      }
+    else
+      for (uint64_t at = 0; at < n; at += gs)
+        gb[++G] = at + gs < n ? at + gs : n;
   }
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
