@@ -195,6 +195,49 @@ __device__ __forceinline__ void bs_end(bsink &o)
   o.slot = 0;
 }
 
+// The same sink for a run-coded line, cheaper: the 8-byte register starts out as eight run characters, so a run only
+// moves the position (whole registers of run characters leave as they are) and a symbol is one XOR into its byte.
+struct rsink { uint8_t *p; uint64_t acc, pat; uint32_t sh /* bit position in acc: 8 * bytes held */; uint64_t *row; int slot; uint32_t rc; };
+
+__device__ __forceinline__ void rs_push8(rsink &o)
+{ o.row[o.slot] = o.acc;
+  o.acc = o.pat;
+  if (++o.slot == DEC_ROW_SLOTS)
+    { const uint64_t a0 = o.row[0], a1 = o.row[1], a2 = o.row[2], a3 = o.row[3];
+      const u32x4 v0 = { (uint32_t) a0, (uint32_t) (a0 >> 32), (uint32_t) a1, (uint32_t) (a1 >> 32) };
+      const u32x4 v1 = { (uint32_t) a2, (uint32_t) (a2 >> 32), (uint32_t) a3, (uint32_t) (a3 >> 32) };
+      u32x4_u *g = (u32x4_u *) o.p;
+      g[0] = v0; g[1] = v1;
+      o.p += 8 * DEC_ROW_SLOTS; o.slot = 0;
+    }
+}
+
+__device__ __forceinline__ void rs_run(rsink &o, uint32_t count)
+{ o.sh += 8u * count;
+  while (o.sh >= 64u)
+    { rs_push8(o);
+      o.sh -= 64u;
+    }
+}
+
+__device__ __forceinline__ void rs_sym(rsink &o, uint32_t b)
+{ o.acc ^= (uint64_t) (b ^ o.rc) << o.sh;
+  o.sh  += 8u;
+  if (o.sh == 64u)
+    { rs_push8(o);
+      o.sh = 0;
+    }
+}
+
+__device__ __forceinline__ void rs_end(rsink &o)
+{ for (int k = 0; k < o.slot; k++)
+    { *(u64_u *) o.p = o.row[k];
+      o.p += 8;
+    }
+  for (uint32_t k = 0; k < (o.sh >> 3); k++)
+    o.p[k] = (uint8_t) (o.acc >> (8 * k));
+}
+
 #define DEC_BLOCK 1024                                     // one 16-wave workgroup per CU (142 KB of LDS)
 #define DEC_NWAVE (DEC_BLOCK / 64)
 
@@ -272,7 +315,36 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
             bs_put(o, c);
             j += 1;
           }
-      else                                                 // Decode_Run, QV.c:665-688
+      else if (!esc)                                       // Decode_Run, QV.c:665-688, symbols without an escape code:
+        { const uint16_t *rprim = s_dec[q == 0 ? DX_DRUN : DX_SRUN];       // one refill covers run code + symbol code
+          const uint32_t *rlng  = s_long[q == 0 ? DX_DRUN : DX_SRUN];
+          rsink ro;
+          ro.p = o.p; ro.rc = (uint32_t) rc; ro.pat = (uint64_t) (uint32_t) rc * 0x0101010101010101ull; ro.acc = ro.pat;
+          ro.sh = 0; ro.row = o.row; ro.slot = 0;
+          while (j < L)
+            { br_pump(rd);
+              br_fill(rd);                                 // >= 33 bits
+              uint32_t c = dec_symbol_nofill(rd, rprim, rlng);
+              if (c == 255u)                               // run of 255 or more: 16-bit literal (QV.c:670-676)
+                { br_fill(rd);
+                  c = br_peek16(rd);
+                  br_skip(rd, 16);
+                  br_fill(rd);
+                }
+              if (c > L - j) { bad = 1; c = L - j; }       // corrupt stream: never write past the line
+              rs_run(ro, c);
+              j += c;
+              if (j < L)
+                { rs_sym(ro, dec_symbol_nofill(rd, prim, lng));
+                  j += 1;
+                }
+            }
+          rs_sym(ro, '\n');
+          rs_end(ro);
+          if (bad) atomicOr(status, 4u);
+          continue;                                        // (the line is complete: its end is written above)
+        }
+      else                                                 // ... with one (scheme type 2)
         { const uint16_t *rprim = s_dec[q == 0 ? DX_DRUN : DX_SRUN];
           const uint32_t *rlng  = s_long[q == 0 ? DX_DRUN : DX_SRUN];
           while (j < L)
