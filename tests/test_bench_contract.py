@@ -1,0 +1,49 @@
+"""bench.py's contract with the driver: one JSON line with the agreed fields, at N = 1 and -- every rank on device 0
+of a one-GPU box -- through the self-launched N = 2 path (gloo exchange of the scan state and the histograms)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIELDS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+          "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _run(extra, env=None):
+    e = dict(os.environ, **(env or {}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=e, cwd=ROOT, timeout=600,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                         # exactly one JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, timeout=120,
+                         env=dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode != 0 and b"--gpus 2 but WORLD_SIZE=4" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_line_single_gpu():
+    d = _run(["--entries", "30000", "--steps", "2", "--warmup", "1", "--only-main", "--no-cpu-baseline"])
+    assert all(k in d for k in FIELDS)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "GB/s" and d["dtype"] == "u8"
+    assert d["roundtrip_bit_exact"] is True and d["decode_indexed"]["bit_exact"] is True
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert abs(d["value"] - 5 * 30000 * 10000 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_line_two_ranks_on_one_device():
+    d = _run(["--gpus", "2", "--entries", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+             env={"DEXGPU_BENCH_ONE_DEVICE": "1"})
+    assert all(k in d for k in FIELDS)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["tables_identical_across_ranks"] is True and d["roundtrip_bit_exact"] is True
+    assert abs(d["value"] - 2 * 5 * 20000 * 10000 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]     # whole job
