@@ -318,10 +318,12 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
             ok2, dec2_ms = decode_all()
             ctx.qv_subindex(False)
             roundtrip = roundtrip and ok2
-            words_ = (((lens.astype(np.int64) + 15) >> 4) + 3) >> 2              # sub_words(L): one byte per 16 symbols, per line
-            state["decode_indexed"] = {"kernel": "k_qv_decode_sub + k_qv_decode + k_qv_decode_tags", "ms": round(dec2_ms, 2),
+            L64 = lens.astype(np.int64)
+            words_ = 4 * ((((L64 + 15) >> 4) + 3) >> 2) \
+                     + 2 * (1 + 64 * ((((((L64 >> 1) + 64) + 7) & ~7) + 511) >> 9))   # sub_entry_words(L): plain lines a byte per 16 symbols,
+            state["decode_indexed"] = {"kernel": "k_qv_decode_sub + k_qv_decode_runs + k_qv_decode + k_qv_decode_tags", "ms": round(dec2_ms, 2),
                                        "output_GBps": round(5.0 * bases / (dec2_ms * 1e-3) / 1e9, 1) if dec2_ms else None,
-                                       "index_bytes": int(16 * words_.sum()),             # room for four lines per entry; the plain ones use theirs
+                                       "index_bytes": int(4 * words_.sum()),              # run-coded lines a word per 8 tokens (room by the token bound)
                                        "bit_exact": bool(ok2),
                                        "note": "index written by one extra untimed step of the same encoder; kernels of that step: "
                                                + str(round(enc_ix_ms, 2)) + " ms"}

@@ -101,7 +101,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);
   (void) hipFree(ctx->d_scan);
-  (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room);
+  (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room); (void) hipFree(ctx->sx.none);
   if (ctx->h_stage[0]) (void) hipHostFree(ctx->h_stage[0]);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipStreamDestroy(ctx->own);

@@ -70,6 +70,7 @@ struct dx_ctx
     uint32_t *idx;               // one byte per group of 16 symbols, 4 * sub_words(len) words per entry
     uint64_t *off;               // n + 1: where each entry's words start
     uint32_t *room;              // n: scratch of the offsets' scan
+    uint32_t *none;              // device counter: run-coded lines the encoders left without an index (RUN_NONE)
     size_t    cap_idx, cap_entries;
     const void *out, *seg;       // the record stream and segment index it belongs to
     uint64_t    n;

@@ -979,7 +979,7 @@ __device__ __forceinline__ void sub_step(sub_mark &m, uint32_t nb, uint32_t vali
   m.g += 64u;
 }
 
-struct sub_sink { uint32_t *idx; const uint64_t *off; };           // idx == NULL: none wanted
+struct sub_sink { uint32_t *idx; const uint64_t *off; uint32_t *none; };      // idx == NULL: none wanted; none: counts the RUN_NONE lines
 
 // one step of Encode (QV.c:427-434): 16 table look-ups per lane, prefix sum, bits into the window
 __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, int valid, bool full,
@@ -1329,6 +1329,10 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
             { const uint32_t *rtab = s_tok[q == 0 ? DX_DRUN : DX_SRUN];
               const bool      tags = q == 0;
               uint32_t C = 0;
+              if (sx.idx && lane == 0)                   // no group index from this encoder: the lane-per-line decoder takes the line
+                { sx.idx[sx.off[r] + 4ull * sub_words(L) + (q == 0 ? 0u : run_words(L))] = RUN_NONE;
+                  atomicAdd(sx.none, 1u);
+                }
               ot.seg = S ? tag_at : dst + want; ot.wordbase = 0; ot.winbits = 0;
               u32x4 c = fetch(p, pos, L, over), t = c;
               if (tags) t = fetch(p1, pos, L, over);
@@ -1795,7 +1799,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
             a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL },
             (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0,
-            sub_sink{ NULL, NULL });
+            sub_sink{ NULL, NULL, NULL });
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1837,7 +1841,7 @@ static int onepass_side(dx_ctx *ctx, hipStream_t B, const uint32_t *d_size, uint
 __global__ __launch_bounds__(DX_BLOCK)
 void k_sub_rooms(const uint32_t *len, uint64_t n, uint32_t *room)
 { const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
-  if (i < n) room[i] = 4u * sub_words(len[i]);
+  if (i < n) room[i] = sub_entry_words(len[i]);
 }
 
 extern "C" int dx_qv_subindex(dx_ctx *ctx, int on)
@@ -1875,6 +1879,11 @@ static int subindex_prepare(dx_ctx *ctx, const dx_qv_batch *b, const void *d_out
         }
       ctx->sx.cap_idx = words + 4;
     }
+  if (ctx->sx.none == NULL && hipMalloc((void **) &ctx->sx.none, 64) != hipSuccess)
+    { (void) hipGetLastError();
+      return dx_fail(ctx, DX_E_NOMEM, "dx_qv_subindex: no memory");
+    }
+  DX_HIP(ctx, hipMemsetAsync(ctx->sx.none, 0, 4, ctx->stream));
   ctx->sx.out = d_out; ctx->sx.seg = d_seg; ctx->sx.n = n;
   *idx = ctx->sx.idx;
   return DX_OK;
@@ -1946,7 +1955,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       qv_args ag = a;
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
-      const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL };
+      const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL, ctx->sx.none };
       const tok_src   tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
       rc = DX_E_HIP;
       if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
@@ -2170,7 +2179,7 @@ layout:
       qv_args ag = a;
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
-      const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL };
+      const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL, ctx->sx.none };
       if (g >= 3)
         DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 3) & 7], 0));    // the region is free once its last tenant has been copied out
       const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 };

@@ -21,6 +21,7 @@
 // algorithmic bytes: 75 GB of HBM traffic per 10 GB decoded).
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
+#include <vector>
 
 struct dec_args
 { const uint8_t  *in;
@@ -243,11 +244,16 @@ __device__ __forceinline__ void rs_end(rsink &o)
 
 __global__ __launch_bounds__(DEC_BLOCK)
 void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *status, uint32_t *next_task,
-                 uint32_t kinds /* bit q set: this launch decodes stream kind q (0 del, 1 ins, 2 mrg, 3 sub) */)
+                 uint32_t kinds /* bit q set: this launch decodes stream kind q (0 del, 1 ins, 2 mrg, 3 sub) */,
+                 const uint32_t *skip_idx, const uint64_t *skip_off, uint32_t skip_kinds /* run-coded kinds whose indexed
+                 lines k_qv_decode_runs has decoded: only the lines without an index (RUN_NONE) are left for this kernel */,
+                 const uint32_t *none_count /* how many such lines the batch has */)
 { __shared__ uint16_t s_dec[6][DX_DEC_SIZE];               // 24 KB
   __shared__ uint32_t s_long[6][1 + DX_LONG_MAX];          // 6 KB
   __shared__ __attribute__((aligned(8))) uint8_t s_row[DEC_BLOCK][DEC_ROW_BYTES];    // 40 KB
   __shared__ __attribute__((aligned(8))) uint32_t s_ring[DEC_BLOCK][DEC_RING_STRIDE]; // 72 KB
+  if (skip_idx != NULL && (kinds & ~skip_kinds) == 0u && *none_count == 0u)
+    return;                                                // every line of this launch had its index: nothing left
   for (int k = threadIdx.x; k < 6 * DX_DEC_SIZE; k += DEC_BLOCK)          (&s_dec[0][0])[k]  = g_dec[k];
   for (int k = threadIdx.x; k < 6 * (1 + DX_LONG_MAX); k += DEC_BLOCK)    (&s_long[0][0])[k] = g_long[k];
   __syncthreads();
@@ -269,7 +275,12 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       const uint64_t r = g * 64 + (uint64_t) lane_id();
       if (!((kinds >> q) & 1u))
         continue;                                          // k_qv_decode_plain has this stream kind
-      if (r < a.n)                                         // lanes past the last entry idle through this task
+      bool mine = r < a.n;                                 // lanes past the last entry idle through this task
+      if (mine && skip_idx != NULL && ((skip_kinds >> q) & 1u))
+        { const uint32_t Lr = a.len[r];
+          mine = skip_idx[skip_off[r] + 4ull * sub_words(Lr) + (q == 0 ? 0u : run_words(Lr))] == RUN_NONE;
+        }
+      if (mine)
       {
       const int      line = q == 0 ? 0 : q + 1;            // output line / segment index
       const uint32_t L  = a.len[r];
@@ -859,6 +870,182 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+//  run-coded lines with the encoder's group index: k_qv_decode_runs
+// ---------------------------------------------------------------------------------------------
+// A wavefront per (entry, run-coded line).  The index holds, for every group of <= 8 consecutive (run, symbol)
+// tokens -- what a lane of the encoder coded in a pass -- the bits they take and the positions they cover.  The
+// wave first stores the whole line as run characters (coalesced), then goes through the passes of 512 tokens the
+// way the encoder did: two prefix sums turn the groups' bits and spans into where each lane starts reading and
+// writing, the words are staged in the LDS window, and every lane decodes its tokens -- run code (+ 16-bit literal),
+// symbol code -- advancing by the run and storing only the symbol's byte.  All lanes hold the same number of
+// tokens (the line's last pass aside), so the wave runs in step; the stores of a pass fall into about 1 KB.
+#define DR_BLOCK 1024                                      // 16 waves: tables 36 KB + 16 x (1.75 + 5) KB = 144 KB
+#define DR_NWAVE (DR_BLOCK / 64)
+#define DR_WIN   448                                       // words per wave: a pass's bits (<= RUN_PASSBITS, the encoder saw to it) + slack
+#define DR_STRETCH (RUN_STRETCH / 4)                       // words per wave for a pass's piece of the line (the encoder saw to it that it fits)
+
+template <int NK>                                          // run-coded kinds in the launch: 1 or 2 (del, sub)
+__global__ __launch_bounds__(DR_BLOCK)
+void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *status, uint32_t *next_task,
+                      uint32_t kinds, const uint32_t *sub_idx, const uint64_t *sub_off)
+{ __shared__ uint16_t s_tab[2 * NK][DP_SIZE];              // per kind: symbols, runs (8 KB each)
+  __shared__ uint32_t s_long[2 * NK][1 + DX_LONG_MAX];
+  __shared__ uint32_t s_win[DR_NWAVE][DR_WIN];             // 52 KB
+  __shared__ uint32_t s_str[DR_NWAVE][DR_STRETCH];         // (see DR_BLOCK)
+  { int nk = 0;
+    for (int q = 0; q < 4; q++)
+      if ((kinds >> q) & 1u)
+        { const int src[2] = { q, q == 0 ? DX_DRUN : DX_SRUN };
+          for (int h = 0; h < 2; h++)
+            for (int k = threadIdx.x; k < 1 + DX_LONG_MAX; k += DR_BLOCK) s_long[2 * nk + h][k] = g_long[src[h] * (1 + DX_LONG_MAX) + k];
+          nk += 1;
+        }
+    __syncthreads();
+    nk = 0;
+    for (int q = 0; q < 4; q++)
+      if ((kinds >> q) & 1u)
+        { const int src[2] = { q, q == 0 ? DX_DRUN : DX_SRUN };
+          for (int h = 0; h < 2; h++)
+            for (int i_ = threadIdx.x; i_ < DP_SIZE; i_ += DR_BLOCK)
+              { const uint32_t i = (uint32_t) i_, e = g_dec[src[h] * DX_DEC_SIZE + (i >> (DP_BITS - DX_DEC_BITS))];
+                uint32_t len = e >> 8, sym = e & 0xffu;
+                if (len == 0)
+                  { const uint32_t *lg = s_long[2 * nk + h], cnt = lg[0], pre = i << (16 - DP_BITS);
+                    for (uint32_t j = 1; j <= cnt; j++)
+                      { const uint32_t t = lg[j], l = (t >> 8) & 0xffu;
+                        if (l <= DP_BITS && (pre >> (16u - l)) == ((t >> 16) >> (16u - l)))
+                          { len = l; sym = t & 0xffu; }
+                      }
+                  }
+                s_tab[2 * nk + h][i] = (uint16_t) ((len ? 32u - len : 0u) | (sym << 8));
+              }
+          nk += 1;
+        }
+    __syncthreads();
+  }
+  uint32_t *const win  = s_win[threadIdx.x >> 6], *const stretch = s_str[threadIdx.x >> 6];
+  const int       lane = lane_id();
+
+  for (;;)                                                 // a task = the run-coded lines of one entry
+    { uint32_t t = 0;
+      if (lane == 0)
+        t = atomicAdd(next_task, 1u);
+      t = uniform(t);
+      if ((uint64_t) t >= a.n) break;
+      const uint64_t r = t;
+      int slot = -1;
+      #pragma unroll 1
+      for (uint32_t q = 0; q < 4; q += 3)                  // del (0), sub (3)
+      { if (!((kinds >> q) & 1u)) continue;
+        slot += 1;
+        const uint32_t  L   = a.len[r];
+        const uint32_t *hdr = sub_idx + sub_off[r] + 4ull * sub_words(L) + (q == 0 ? 0u : run_words(L));
+        const uint32_t  cnt = uniform(hdr[0]);
+        if (cnt == RUN_NONE) continue;                     // not indexed: k_qv_decode takes this line
+        if (cnt > ((((L >> 1) + 64u) + 7u) & ~7u))         // more tokens than the line can have: not an index (never follow it)
+          { if (lane == 0) atomicOr(status, 4u);
+            continue;
+          }
+        const int       line = q == 0 ? 0 : 4;
+        const uint32_t *sg   = a.seg + 5 * r;
+        uint64_t at = a.rec_off[r] + (a.hdr_off ? a.hdr_off[r + 1] - a.hdr_off[r] : 0);
+        for (int k = 0; k < line; k++)
+          at += sg[k];
+        const uint8_t  *seg    = a.in + at;
+        const uint32_t  sbytes = sg[line];
+        uint8_t        *out    = a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u);
+        const uint32_t  rc     = (uint32_t) (q == 0 ? a.delChar : a.subChar);
+        const uint16_t *stab   = s_tab[2 * slot], *rtab = s_tab[2 * slot + 1];
+        const uint32_t *slng   = s_long[2 * slot], *rlng = s_long[2 * slot + 1];
+        const uint32_t *g16    = hdr + 1;
+
+        uint32_t base_bit = 0, base_pos = 0, bad = 0;
+        const uint32_t pat = rc * 0x01010101u;
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 512u)
+          { const uint32_t m     = cnt - k0 < 512u ? cnt - k0 : 512u;
+            const uint32_t T     = (m + 63u) >> 6;         // tokens per lane in this pass (as the encoder cut them)
+            const uint32_t first = (uint32_t) lane * T;
+            const uint32_t c     = first < m ? (m - first < T ? m - first : T) : 0u;
+            const uint32_t gw    = g16[(k0 >> 3) + (uint32_t) lane];      // (64 groups per pass)
+            const uint32_t bits  = c ? gw & 0xffffu : 0u, span = c ? gw >> 16 : 0u;
+            const uint32_t ib = wave_incl_scan(bits), ip = wave_incl_scan(span);
+            const uint32_t sb = base_bit + ib - bits;
+            uint32_t       pos = ip - span;                // relative to the pass's first position
+            const uint32_t tb = wave_total(ib);
+            uint32_t       tp = wave_total(ip);
+            if (base_pos + tp > L) { tp = L - base_pos; bad = 1; }        // corrupt index: never past the line
+            const bool staged = tp <= RUN_STRETCH;         // (long runs: the pass covers more than the buffer holds)
+            const uint32_t w0 = base_bit >> 5;
+            uint32_t nw = ((base_bit + tb + 31u) >> 5) + 2u - w0;
+            if (nw > DR_WIN) { nw = DR_WIN; bad = 1; }     // (cannot happen with a sound index)
+            for (uint32_t i = (uint32_t) lane; i < nw; i += 64)
+              { const uint64_t byte = 4ull * (w0 + i);
+                win[i] = byte + 4u <= sbytes ? *(const u32_u *) (seg + byte) : 0u;
+              }
+            if (staged)
+              for (uint32_t i = (uint32_t) lane; i < (tp + 3u) >> 2; i += 64)    // the pass's stretch of the line: run characters
+                stretch[i] = pat;
+            else                                           // ... in memory, and done before the symbols go over them
+              { uint8_t *o = out + base_pos;
+                for (uint32_t k = 16u * (uint32_t) lane; k < tp; k += 1024u)
+                  if (k + 16u <= tp) { const u32x4 v = { pat, pat, pat, pat }; *(u32x4_u *) (o + k) = v; }
+                  else for (uint32_t j = k; j < tp; j++) o[j] = (uint8_t) rc;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_s_waitcnt(0);
+              }
+            wave_sync();
+            if (c)
+              { winrd rd;
+                rd.win = win;
+                { const uint32_t s0 = sb - 32u * w0, off = s0 & 31u;
+                  rd.wi = (s0 >> 5) + 1u;
+                  rd.hi = win[s0 >> 5] << off; rd.lo = 0u; rd.nb = 32 - (int) off;
+                }
+                #pragma unroll 1
+                for (uint32_t k = 0; k < T; k++)
+                  if (k < c)
+                    { uint32_t run = wr_symbol(rd, rtab, rlng);      // (fills first: >= 32 bits)
+                      if (run == 255u)                               // 16-bit literal, QV.c:670-676
+                        { wr_fill(rd);
+                          run = rd.hi >> 16;
+                          rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, 16u);
+                          rd.lo <<= 16;
+                          rd.nb -= 16;
+                        }
+                      pos += run;
+                      const uint32_t x = wr_symbol(rd, stab, slng);
+                      if (pos >= tp)   bad = 1;                        // corrupt stream / index
+                      else if (staged) ((uint8_t *) stretch)[pos] = (uint8_t) x;
+                      else             out[base_pos + pos] = (uint8_t) x;
+                      pos += 1;
+                    }
+              }
+            wave_sync();
+            if (staged)
+            { uint8_t *o = out + base_pos;                 // the stretch leaves in 16-byte pieces, its last bytes one by one
+              for (uint32_t i = (uint32_t) lane; 16u * i < tp; i += 64)
+                if (16u * i + 16u <= tp)
+                  { const u32x4 v = { stretch[4 * i], stretch[4 * i + 1], stretch[4 * i + 2], stretch[4 * i + 3] };
+                    *(u32x4_u *) (o + 16u * i) = v;
+                  }
+                else
+                  for (uint32_t j = 16u * i; j < tp; j++) o[j] = ((const uint8_t *) stretch)[j];
+            }
+            wave_sync();
+            base_bit += tb;
+            base_pos += tp;
+          }
+        // behind the last token: the run left open at the line's end (QV.c:497-504), and the line's end
+        for (uint32_t k = base_pos + 16u * (uint32_t) lane; k < L; k += 1024u)
+          if (k + 16u <= L) { const u32x4 v = { pat, pat, pat, pat }; *(u32x4_u *) (out + k) = v; }
+          else for (uint32_t j = k; j < L; j++) out[j] = (uint8_t) rc;
+        if (lane == 0) out[L] = '\n';
+        if (__any((int) bad) && lane == 0) atomicOr(status, 4u);
+      }
+    }
+}
+
 // Tag line of each entry (QV.c:1437-1461): tag[p] = 'n' where del[p] is the run character, else
 // the next 2-bit code of the tag segment as a letter; one wavefront per entry.
 __global__ __launch_bounds__(DX_BLOCK)
@@ -963,6 +1150,9 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   DX_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
   DX_HIP(ctx, hipMemsetAsync(d_next2, 0, 4, ctx->stream));
   const uint32_t plain_kinds = plain;
+  const uint32_t *skip_idx = NULL;
+  const uint64_t *skip_off = NULL;
+  uint32_t        skip_kinds = 0;
   // the encoder's group index for this very stream (dx_qv_subindex): a wavefront per line instead of a lane
   if (plain && ctx->sx.valid && d_in == ctx->sx.out && !(flags & DX_DECODE_FLIP) && getenv("DEXGPU_NO_SUBINDEX") == NULL &&
       (const uint32_t *) d_seg >= (const uint32_t *) ctx->sx.seg &&
@@ -983,7 +1173,27 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
           else if (nk == 3) SUB_LAUNCH(3);
           else              SUB_LAUNCH(4);
 #undef SUB_LAUNCH
-          plain = 0;                                       // done; the run-coded lines and the tags follow as ever
+          plain = 0;                                       // done
+          // the run-coded lines whose symbols have no escape code, by their token groups; what has no index
+          // (entries the generic encoder took) is left to k_qv_decode below
+          uint32_t runs = 0;
+          if (ctx->delChar >= 0 && ctx->sym_type[0] != 2) runs |= 1u;
+          if (ctx->subChar >= 0 && ctx->sym_type[3] != 2) runs |= 8u;
+          if (runs && getenv("DEXGPU_NO_RUNINDEX") == NULL)
+            { uint32_t *d_next4 = (uint32_t *) (ctx->d_u64 + 29);
+              DX_HIP(ctx, hipMemsetAsync(d_next4, 0, 4, ctx->stream));
+              uint64_t rb = (n + DR_NWAVE - 1) / DR_NWAVE;
+              if (rb > cap) rb = cap;
+              if (runs == 9u)
+                DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_runs<2>, (int) rb, DR_BLOCK, a, (const uint16_t *) ctx->d_dec,
+                          (const uint32_t *) ctx->d_long, ctx->d_status, d_next4, runs, (const uint32_t *) ctx->sx.idx,
+                          (const uint64_t *) (ctx->sx.off + first));
+              else
+                DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_runs<1>, (int) rb, DR_BLOCK, a, (const uint16_t *) ctx->d_dec,
+                          (const uint32_t *) ctx->d_long, ctx->d_status, d_next4, runs, (const uint32_t *) ctx->sx.idx,
+                          (const uint64_t *) (ctx->sx.off + first));
+              skip_idx = ctx->sx.idx; skip_off = ctx->sx.off + first; skip_kinds = runs;
+            }
         }
     }
   if (plain)
@@ -994,7 +1204,8 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
     }
   if (plain_kinds != 15u)
     DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,
-              (const uint32_t *) ctx->d_long, ctx->d_status, d_next, 15u & ~plain_kinds);
+              (const uint32_t *) ctx->d_long, ctx->d_status, d_next, 15u & ~plain_kinds,
+              (const uint32_t *) skip_idx, (const uint64_t *) skip_off, skip_kinds, (const uint32_t *) ctx->sx.none);
   DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));

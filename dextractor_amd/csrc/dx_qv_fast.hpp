@@ -21,11 +21,14 @@ struct tok_src
 // consecutive tokens with one 16-byte load, looks up run and symbol codes (shift tokens), chains them
 // into one string of <= 128 bits, and a single prefix sum + placement per pass puts the strings into
 // the window; with TAGS the lanes' 2-bit tag fields go into the tag window the same way.
+// gix (group index, dx_qv_subindex): the line's header word, then one word per lane and pass.
 template <bool TAGS>
 __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, const uint16_t *tok, uint32_t cnt,
                                                   const uint32_t *ntab, const uint32_t *rtab,
-                                                  const uint32_t *nstab, const uint32_t *rstab)
+                                                  const uint32_t *nstab, const uint32_t *rstab, uint32_t *gix, uint32_t *none_count)
 { const uint32_t lane = (uint32_t) lane_id();
+  uint32_t *g16 = gix ? gix + 1 + lane : (uint32_t *) NULL;
+  uint32_t  wide = 0;                                              // a group that does not fit its 16 bits
   for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
     { const uint32_t m     = cnt - k0 < 64u * TOK_TP ? cnt - k0 : 64u * TOK_TP;
       const uint32_t T     = (m + 63u) >> 6;                       // tokens per lane in this pass (wave-uniform)
@@ -41,11 +44,12 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           rt[k] = rstab[t16 >> 9];                                 // QV.c:479-487 (runs below TOK_RUN_MAX: no clamp needed)
           st[k] = *(const uint32_t *) ((const uint8_t *) nstab + (t16 & 0x1fcu));
         }
-      uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, nb = 0, zor = 0, tacc = 0;
+      uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, nb = 0, zor = 0, tacc = 0, span = 0;
       #pragma unroll
       for (int k = 0; k < (int) TOK_TP; k++)
         if ((uint32_t) k < c)
           { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
+            span += (t16 >> 9) + 1u;
             STOK_APPEND(rt[k])
             if (rt[k] & 0x80u)                                     // escaped run: its 16-bit literal follows (QV.c:486-487)
               { const uint32_t lit = ((t16 >> 9) << 16) | 16u;
@@ -59,6 +63,11 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
               tacc = (tacc << 2) | (t16 & 3u);
           }
       const uint32_t incl = wave_incl_scan(nb);
+      if (g16)
+        { *g16 = nb | (span << 16);
+          g16 += 64;
+          wide |= ((zor & 32u) || wave_total(incl) > RUN_PASSBITS) ? 1u : 0u;
+        }
       if (!__any((int) ((zor & 32u) | (nb > 128u))))
         { FOR_EACH_ROUND(o, incl, nb,
             { place_bits128(o.win, bit_, nb, w0, w1, w2, w3); })
@@ -92,6 +101,13 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           ot.winbits += 2u * m;
           if (ot.winbits >= TAG_FLUSH_BITS)
             flush_quads(ot, true);
+        }
+    }
+  if (gix)
+    { const bool none = __any((int) wide) != 0;
+      if (lane == 0)
+        { gix[0] = none ? RUN_NONE : cnt;
+          if (none) atomicAdd(none_count, 1u);
         }
     }
 }
@@ -250,8 +266,9 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               const uint32_t  cnt  = inf[q == 0 ? 0 : 1] & ~TOK_BAD;
               const uint32_t  C    = inf[q == 0 ? 2 : 3];           // run left open at the line's end
               ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
-              if (q == 0) encode_token_line<true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs]);
-              else        encode_token_line<false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs]);
+              uint32_t *gix = SUB && sx.idx ? sx.idx + sx.off[r] + 4ull * sub_words(L) + (q == 0 ? 0u : run_words(L)) : (uint32_t *) NULL;
+              if (q == 0) encode_token_line<true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, sx.none);
+              else        encode_token_line<false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, sx.none);
               uint32_t last;
               if (C > 0)
                 last = encode_trailing_run(o, C, rtab);

@@ -17,7 +17,7 @@ import csv, glob, json, os, shutil, sys, collections
 
 BENCH_ID = {"k_qv_encode_fast": "k_qv_encode", "k_qv_encode": "k_qv_encode", "k_qv_hist": "k_qv_hist",
             "k_qv_compact": "k_qv_compact", "k_qv_decode": "k_qv_decode", "k_qv_decode_tags": "k_qv_decode",
-            "k_qv_decode_plain": "k_qv_decode", "k_qv_decode_sub": "k_qv_decode", "k_qv_sizes_fast": "k_qv_sizes",
+            "k_qv_decode_plain": "k_qv_decode", "k_qv_decode_sub": "k_qv_decode", "k_qv_decode_runs": "k_qv_decode", "k_qv_sizes_fast": "k_qv_sizes",
             "k_pack2_encode": "k_pack2_encode", "k_pack2_decode": "k_pack2_decode", "k_qv_sizes": "k_qv_sizes"}
 
 
@@ -46,7 +46,7 @@ def traffic(src, suffix, steps):
         w = wr.get(name, {}).get("WRITE_SIZE", [])
         # the x2 is for wide coalesced streams (16 B per lane, consecutive lanes consecutive bytes): every kernel here
         # but the lane-per-stream decoder, whose lanes each read their own line (raw request bytes kept for it)
-        scattered = name in ("k_qv_decode", "k_qv_decode_plain", "k_qv_decode_sub")
+        scattered = name in ("k_qv_decode", "k_qv_decode_plain", "k_qv_decode_sub", "k_qv_decode_runs")
         out[name] = {"fetch_bytes": sum(f) / len(f) * 1024 * (1 if scattered else 2) if f else None,
                      "fetch_bytes_raw_counter": sum(f) / len(f) * 1024 if f else None,
                      "write_bytes": sum(w) / len(w) * 1024 if w else None,

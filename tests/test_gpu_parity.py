@@ -438,7 +438,7 @@ def test_device_round_trip_with_encoder_index(ctx):
 
 
 @pytest.mark.parametrize("route", ["scratch", "direct", "text"])
-@pytest.mark.parametrize("case", ["ragged", "long_codes", "no_runs", "lossy", "long_entries", "odd_entries"])
+@pytest.mark.parametrize("case", ["ragged", "long_codes", "no_runs", "lossy", "long_entries", "odd_entries", "long_runs"])
 def test_decode_with_the_encoders_group_index(ctx, case, route, monkeypatch):
     """dx_qv_subindex: the one-pass encoder (each of its routes) leaves the code bits of every group of 16 symbols of the
     plain lines; dx_qv_decode of that stream in the same context then runs k_qv_decode_sub, a wavefront per line.  Same text
@@ -448,14 +448,32 @@ def test_decode_with_the_encoders_group_index(ctx, case, route, monkeypatch):
     if route == "text":
         monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
     lossy = case == "lossy"
-    if case == "ragged":                                          # every group shape: 0, < 16, multiples of 16, around a step (1024) and a round
+    if case == "long_runs":                                       # runs of hundreds and thousands: passes that cover more of the line
+        c = synth.make_quiva(30, seed=34, mean=20000)             # than the decoder stages (RUN_STRETCH), 16-bit run literals
+        txt, rc_d = bytearray(c.text), O.qv_scan(c.text).delChar
+        for e, (at, run) in enumerate([(100, 300), (50, 5000), (7, 9000), (0, 126), (3000, 4000), (10, 70000)]):
+            Le = int(c.len[e])
+            run = min(run, Le - at - 2)
+            o_ = int(c.off[e]) + at
+            txt[o_: o_ + run] = bytes([rc_d]) * run
+            o1 = int(c.off[e]) + (Le + 1) + at
+            txt[o1: o1 + run] = b"N" * run
+        for e in (10, 11):                                        # hundreds of runs of 100 (tokens stay usable): a pass of 512
+            Le, o_ = int(c.len[e]), int(c.off[e])                 # tokens covers ~50 k positions, far more than RUN_STRETCH
+            unit_d, unit_t = bytes([rc_d]) * 100 + b"5", b"N" * 100 + b"A"
+            k = (Le - 200) // 101
+            txt[o_ + 100: o_ + 100 + 101 * k] = unit_d * k
+            txt[o_ + (Le + 1) + 100: o_ + (Le + 1) + 100 + 101 * k] = unit_t * k
+        c.text = bytes(txt)
+    elif case == "ragged":                                        # every group shape: 0, < 16, multiples of 16, around a step (1024) and a round
         lens = np.array(list(range(0, 70)) + [255, 256, 257, 1023, 1024, 1025, 1040, 2047, 2048, 2049, 4097, 9999, 10000,
                                               16383, 16384, 16385, 16400] + [7000] * 30, np.uint32)
         c = synth.make_quiva(len(lens), seed=31, lens=lens)
     elif case == "long_entries":                                  # many rounds per line
         lens = np.array([70001, 140000, 33000, 16385, 5], np.uint32)
         c = synth.make_quiva(len(lens), seed=32, lens=lens)
-    elif case == "odd_entries":                                   # entries of the unusable list go through the generic encoder
+    elif case == "odd_entries":                                   # entries of the unusable list go through the generic encoder:
+                                                                  # their run-coded lines have no index (RUN_NONE) and take k_qv_decode
         c = synth.make_quiva(40, seed=9, mean=4000)
         txt, rc_d = bytearray(c.text), O.qv_scan(c.text).delChar
         for e, run in ((3, 126), (5, 127), (9, 300)):
@@ -510,7 +528,8 @@ def test_decode_with_the_encoders_group_index(ctx, case, route, monkeypatch):
         assert got == want
         if not lossy and case not in ("long_codes", "no_runs"):   # (the hand-made tables do not cover every byte value)
             assert got == c.text
-        assert ran["k_qv_decode"][1] == (2 if case == "no_runs" else 3)      # sub + (run lines) + tags: no lane-per-line plain kernel
+        # k_qv_decode_sub + (k_qv_decode_runs + k_qv_decode for what has no index) + tags: no lane-per-line plain kernel
+        assert ran["k_qv_decode"][1] == (2 if case == "no_runs" else 4)
         first, count = n // 3, n // 2                             # a contiguous part of the batch
         part = decode(first, count)
         lo, hi = int(c.off[first]), int(c.off[first + count - 1]) + 5 * (int(c.len[first + count - 1]) + 1)
