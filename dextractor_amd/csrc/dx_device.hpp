@@ -109,17 +109,15 @@ __device__ __forceinline__ void store32_u(uint8_t *p, uint32_t v) { *(u32_u *) p
 __host__ __device__ __forceinline__ uint32_t sub_groups(uint32_t L) { return (L + 15u) >> 4; }
 __host__ __device__ __forceinline__ uint32_t sub_words(uint32_t L)  { return (sub_groups(L) + 3u) >> 2; }
 #define SUB_NONE 255u                                       // first byte of a line: no index (a symbol without a code)
-// ... and of the run-coded lines: a header word (the line's token count, or RUN_NONE) and one word per group of <= 8
-// tokens -- the tokens a lane of k_qv_encode_fast codes in a pass: bits | span << 16 (span = positions the group's
-// runs and symbols cover).  run_words(L) words per line, after the four plain shares of the entry.
+// ... and of the run-coded lines, after the four plain shares of the entry: three header words -- the deletion line's
+// token count or RUN_NONE, the same for the substitution line, the passes reserved for the deletion line -- then one
+// word per group of <= 8 tokens (the tokens a lane of k_qv_encode_fast codes in a pass of 512): bits | span << 16
+// (span = positions the group's runs and symbols cover), 64 per pass, deletion line first.
 #define RUN_NONE 0xffffffffu
 #define RUN_STRETCH 5120u                                   // positions of a pass the decoder stages in LDS (a longer pass goes byte by byte)
 #define RUN_PASSBITS 13312u                                 // bits the 64 groups of a pass may take together (416 words of the decoder's window; else: no index)
-__host__ __device__ __forceinline__ uint32_t run_words(uint32_t L)
-{ const uint32_t room = (((L >> 1) + 64u) + 7u) & ~7u;          // tok_room(L), dx_qv.hip
-  return 1u + 64u * ((room + 511u) >> 9);
-}
-__host__ __device__ __forceinline__ uint32_t sub_entry_words(uint32_t L) { return 4u * sub_words(L) + 2u * run_words(L); }
+__host__ __device__ __forceinline__ uint32_t run_passes(uint32_t tokens) { return (tokens + 511u) >> 9; }
+__host__ __device__ __forceinline__ uint32_t run_base(uint32_t L) { return 4u * sub_words(L); }    // words before the three header words
 
 // ---------------------------------------------------------------------------------------------
 //  per-wave output window: bits are ORed into a zeroed LDS word window (MSB-first within 32-bit

@@ -1330,7 +1330,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
               const bool      tags = q == 0;
               uint32_t C = 0;
               if (sx.idx && lane == 0)                   // no group index from this encoder: the lane-per-line decoder takes the line
-                { sx.idx[sx.off[r] + 4ull * sub_words(L) + (q == 0 ? 0u : run_words(L))] = RUN_NONE;
+                { sx.idx[sx.off[r] + run_base(L) + (q == 0 ? 0u : 1u)] = RUN_NONE;
                   atomicAdd(sx.none, 1u);
                 }
               ot.seg = S ? tag_at : dst + want; ot.wordbase = 0; ot.winbits = 0;
@@ -1839,9 +1839,15 @@ static int onepass_side(dx_ctx *ctx, hipStream_t B, const uint32_t *d_size, uint
 
 // ---- group index: room for it -----------------------------------------------------------------------------
 __global__ __launch_bounds__(DX_BLOCK)
-void k_sub_rooms(const uint32_t *len, uint64_t n, uint32_t *room)
+void k_sub_rooms(const uint32_t *len, uint64_t n, const uint32_t *info /* token counts (k_qv_hist), or NULL */, uint32_t *room)
 { const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
-  if (i < n) room[i] = sub_entry_words(len[i]);
+  if (i >= n) return;
+  uint32_t passes = 0;                                   // group words only where k_qv_encode_fast will write them
+  if (info != NULL)
+    { const uint32_t d = info[4 * i], s = info[4 * i + 1];
+      passes = ((d & TOK_BAD) ? 0u : run_passes(d)) + ((s & TOK_BAD) ? 0u : run_passes(s));
+    }
+  room[i] = run_base(len[i]) + 3u + 64u * passes;
 }
 
 extern "C" int dx_qv_subindex(dx_ctx *ctx, int on)
@@ -1852,6 +1858,7 @@ extern "C" int dx_qv_subindex(dx_ctx *ctx, int on)
 }
 
 // offsets (a scan of the rooms) and the index buffer for this batch; *idx = NULL when no index is wanted
+static bool onepass_tokens_ok(const dx_ctx *ctx, const dx_qv_batch *b);
 static int subindex_prepare(dx_ctx *ctx, const dx_qv_batch *b, const void *d_out, const void *d_seg, uint32_t **idx)
 { *idx = NULL;
   ctx->sx.valid = 0;
@@ -1866,7 +1873,8 @@ static int subindex_prepare(dx_ctx *ctx, const dx_qv_batch *b, const void *d_out
         }
       ctx->sx.cap_entries = n;
     }
-  DX_LAUNCH(ctx, DX_K_SCAN, k_sub_rooms, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK, (const uint32_t *) b->d_len, n, ctx->sx.room);
+  DX_LAUNCH(ctx, DX_K_SCAN, k_sub_rooms, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK, (const uint32_t *) b->d_len, n,
+            onepass_tokens_ok(ctx, b) ? (const uint32_t *) ctx->tk.info : (const uint32_t *) NULL, ctx->sx.room);
   uint64_t words = 0;
   int e = dx_scan_u32(ctx, ctx->sx.room, n, ctx->sx.off, &words);
   if (e) return e;

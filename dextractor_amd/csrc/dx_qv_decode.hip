@@ -278,7 +278,7 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       bool mine = r < a.n;                                 // lanes past the last entry idle through this task
       if (mine && skip_idx != NULL && ((skip_kinds >> q) & 1u))
         { const uint32_t Lr = a.len[r];
-          mine = skip_idx[skip_off[r] + 4ull * sub_words(Lr) + (q == 0 ? 0u : run_words(Lr))] == RUN_NONE;
+          mine = skip_idx[skip_off[r] + run_base(Lr) + (q == 0 ? 0u : 1u)] == RUN_NONE;
         }
       if (mine)
       {
@@ -940,13 +940,16 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
       { if (!((kinds >> q) & 1u)) continue;
         slot += 1;
         const uint32_t  L   = a.len[r];
-        const uint32_t *hdr = sub_idx + sub_off[r] + 4ull * sub_words(L) + (q == 0 ? 0u : run_words(L));
-        const uint32_t  cnt = uniform(hdr[0]);
+        const uint32_t *hdr = sub_idx + sub_off[r] + run_base(L);         // three header words, then the groups
+        const uint32_t  cnt = uniform(hdr[q == 0 ? 0 : 1]);
         if (cnt == RUN_NONE) continue;                     // not indexed: k_qv_decode takes this line
-        if (cnt > ((((L >> 1) + 64u) + 7u) & ~7u))         // more tokens than the line can have: not an index (never follow it)
-          { if (lane == 0) atomicOr(status, 4u);
-            continue;
-          }
+        { const uint64_t share = sub_off[r + 1] - sub_off[r];              // words of this entry in the index
+          const uint64_t need  = (uint64_t) run_base(L) + 3u + 64ull * ((q == 0 ? 0u : uniform(hdr[2])) + run_passes(cnt));
+          if (cnt > ((((L >> 1) + 64u) + 7u) & ~7u) || need > share)       // not an index this entry can have: never follow it
+            { if (lane == 0) atomicOr(status, 4u);
+              continue;
+            }
+        }
         const int       line = q == 0 ? 0 : 4;
         const uint32_t *sg   = a.seg + 5 * r;
         uint64_t at = a.rec_off[r] + (a.hdr_off ? a.hdr_off[r + 1] - a.hdr_off[r] : 0);
@@ -958,7 +961,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
         const uint32_t  rc     = (uint32_t) (q == 0 ? a.delChar : a.subChar);
         const uint16_t *stab   = s_tab[2 * slot], *rtab = s_tab[2 * slot + 1];
         const uint32_t *slng   = s_long[2 * slot], *rlng = s_long[2 * slot + 1];
-        const uint32_t *g16    = hdr + 1;
+        const uint32_t *g16    = hdr + 3 + (q == 0 ? 0u : 64u * uniform(hdr[2]));
 
         uint32_t base_bit = 0, base_pos = 0, bad = 0;
         const uint32_t pat = rc * 0x01010101u;

@@ -21,13 +21,14 @@ struct tok_src
 // consecutive tokens with one 16-byte load, looks up run and symbol codes (shift tokens), chains them
 // into one string of <= 128 bits, and a single prefix sum + placement per pass puts the strings into
 // the window; with TAGS the lanes' 2-bit tag fields go into the tag window the same way.
-// gix (group index, dx_qv_subindex): the line's header word, then one word per lane and pass.
+// gix (group index, dx_qv_subindex): the line's header word; groups: one word per lane and pass.
 template <bool TAGS>
 __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, const uint16_t *tok, uint32_t cnt,
                                                   const uint32_t *ntab, const uint32_t *rtab,
-                                                  const uint32_t *nstab, const uint32_t *rstab, uint32_t *gix, uint32_t *none_count)
+                                                  const uint32_t *nstab, const uint32_t *rstab, uint32_t *gix, uint32_t *groups,
+                                                  uint32_t *none_count)
 { const uint32_t lane = (uint32_t) lane_id();
-  uint32_t *g16 = gix ? gix + 1 + lane : (uint32_t *) NULL;
+  uint32_t *g16 = gix ? groups + lane : (uint32_t *) NULL;
   uint32_t  wide = 0;                                              // a group that does not fit its 16 bits
   for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
     { const uint32_t m     = cnt - k0 < 64u * TOK_TP ? cnt - k0 : 64u * TOK_TP;
@@ -266,9 +267,16 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               const uint32_t  cnt  = inf[q == 0 ? 0 : 1] & ~TOK_BAD;
               const uint32_t  C    = inf[q == 0 ? 2 : 3];           // run left open at the line's end
               ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
-              uint32_t *gix = SUB && sx.idx ? sx.idx + sx.off[r] + 4ull * sub_words(L) + (q == 0 ? 0u : run_words(L)) : (uint32_t *) NULL;
-              if (q == 0) encode_token_line<true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, sx.none);
-              else        encode_token_line<false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, sx.none);
+              uint32_t *gix = NULL, *grp = NULL;           // group index: header word and group words of this line
+              if (SUB && sx.idx)
+                { uint32_t *base = sx.idx + sx.off[r] + run_base(L);
+                  const uint32_t pd = (inf[0] & TOK_BAD) ? 0u : run_passes(inf[0]);     // (as k_sub_rooms laid it out)
+                  gix = base + (q == 0 ? 0u : 1u);
+                  grp = base + 3u + (q == 0 ? 0u : 64u * pd);
+                  if (lane == 0) base[2] = pd;
+                }
+              if (q == 0) encode_token_line<true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none);
+              else        encode_token_line<false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none);
               uint32_t last;
               if (C > 0)
                 last = encode_trailing_run(o, C, rtab);
