@@ -305,12 +305,14 @@ typedef struct
 int  dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *idx);
 void dx_qv_index_free(dx_qv_index *idx);
 
-/* Group index (on = 1): dx_qv_encode_onepass also leaves, in the context, one byte per group of 16 symbols of each
- * plain line -- the group's code bits minus its symbols (6 % of those lines' text); a dx_qv_decode of that record
- * stream (same d_in / d_seg, the whole batch or a contiguous part of it) in the same context then decodes each such
- * line with a whole wavefront, 64 consecutive groups at a time, instead of a lane (k_qv_decode_sub).  The .dexqv
+/* Group index (on = 1): dx_qv_encode_onepass also leaves, in the context, where the codes are: one byte per group of
+ * 16 symbols of each plain line (the group's code bits), one word per group of <= 8 (run, symbol) tokens of each
+ * run-coded line (bits and positions covered) -- about 4.5 KB per 10 kb entry.  A dx_qv_decode of that record stream
+ * (same d_in / d_seg, the whole batch or a contiguous part of it) in the same context then decodes each line with a
+ * whole wavefront, 64 consecutive groups at a time, instead of a lane (k_qv_decode_sub, k_qv_decode_runs).  The .dexqv
  * bytes do not change; a stream decoded without the index (a bare file, another context) takes the lane-per-line
- * kernels.  Off by default.                                                                                      */
+ * kernels, as do the lines of entries the fast encoder does not handle (runs of 127 and more, bytes >= 128).  Off by
+ * default.                                                                                                       */
 int  dx_qv_subindex(dx_ctx *ctx, int on);
 
 /* ------------------------------------------------------------------------------------------
