@@ -965,6 +965,13 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
 
         uint32_t base_bit = 0, base_pos = 0, bad = 0;
         const uint32_t pat = rc * 0x01010101u;
+        // the deletion line's tokens also say where the tag line has letters (Unpack_Tag + Lower_Read, QV.c:1437-1461):
+        // token i's tag is the i-th 2-bit code of the tag segment; every other position is 'n'
+        const bool     tags  = q == 0;
+        const uint8_t *tsrc  = seg + sbytes;               // (the tag segment follows the deletion segment)
+        const uint32_t tbytes = sg[1];
+        uint8_t       *tout  = out + (uint64_t) L + 1u;
+        const uint32_t fold  = a.upper ? 32u : 0u, tpat = ('n' - fold) * 0x01010101u;
         for (uint32_t k0 = 0; k0 < cnt; k0 += 512u)
           { const uint32_t m     = cnt - k0 < 512u ? cnt - k0 : 512u;
             const uint32_t T     = (m + 63u) >> 6;         // tokens per lane in this pass (as the encoder cut them)
@@ -998,6 +1005,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 __builtin_amdgcn_s_waitcnt(0);
               }
             wave_sync();
+            uint32_t posk[8];                              // where this lane's symbols went (the tag letters go to the same places)
             if (c)
               { winrd rd;
                 rd.win = win;
@@ -1005,8 +1013,8 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                   rd.wi = (s0 >> 5) + 1u;
                   rd.hi = win[s0 >> 5] << off; rd.lo = 0u; rd.nb = 32 - (int) off;
                 }
-                #pragma unroll 1
-                for (uint32_t k = 0; k < T; k++)
+                #pragma unroll
+                for (uint32_t k = 0; k < 8; k++)
                   if (k < c)
                     { uint32_t run = wr_symbol(rd, rtab, rlng);      // (fills first: >= 32 bits)
                       if (run == 255u)                               // 16-bit literal, QV.c:670-676
@@ -1018,9 +1026,12 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                         }
                       pos += run;
                       const uint32_t x = wr_symbol(rd, stab, slng);
-                      if (pos >= tp)   bad = 1;                        // corrupt stream / index
-                      else if (staged) ((uint8_t *) stretch)[pos] = (uint8_t) x;
-                      else             out[base_pos + pos] = (uint8_t) x;
+                      if (pos >= tp)   { bad = 1; pos = tp ? tp - 1u : 0u; }   // corrupt stream / index: stay inside
+                      if (tp)
+                        { if (staged) ((uint8_t *) stretch)[pos] = (uint8_t) x;
+                          else        out[base_pos + pos] = (uint8_t) x;
+                        }
+                      posk[k] = pos;
                       pos += 1;
                     }
               }
@@ -1036,6 +1047,47 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                   for (uint32_t j = 16u * i; j < tp; j++) o[j] = ((const uint8_t *) stretch)[j];
             }
             wave_sync();
+            if (tags)                                      // the same piece of the tag line: 'n', letters at the tokens' places
+              { uint8_t *o = tout + base_pos;
+                if (staged)
+                  for (uint32_t i = (uint32_t) lane; i < (tp + 3u) >> 2; i += 64)
+                    stretch[i] = tpat;
+                else
+                  { for (uint32_t k = 16u * (uint32_t) lane; k < tp; k += 1024u)
+                      if (k + 16u <= tp) { const u32x4 v = { tpat, tpat, tpat, tpat }; *(u32x4_u *) (o + k) = v; }
+                      else for (uint32_t j = k; j < tp; j++) o[j] = (uint8_t) tpat;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __builtin_amdgcn_s_waitcnt(0);
+                  }
+                wave_sync();
+                if (c && tp)
+                  { const uint32_t tix = k0 + first, b0 = tix >> 2;             // this lane's first token and its tag byte
+                    uint32_t W = 0;                                               // the next 3 tag bytes, first code in the top bits
+                    #pragma unroll
+                    for (uint32_t j = 0; j < 3; j++)
+                      W |= (b0 + j < tbytes ? (uint32_t) tsrc[b0 + j] : 0u) << (24u - 8u * j);
+                    W <<= 2u * (tix & 3u);
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 8; k++)
+                      if (k < c)
+                        { const uint32_t ch = ((0x74676361u >> (8u * (W >> 30))) & 0xffu) - fold;   // "acgt", Lower_Read DB.c:367
+                          W <<= 2;
+                          if (staged) ((uint8_t *) stretch)[posk[k]] = (uint8_t) ch;
+                          else        o[posk[k]] = (uint8_t) ch;
+                        }
+                  }
+                wave_sync();
+                if (staged)
+                  { for (uint32_t i = (uint32_t) lane; 16u * i < tp; i += 64)
+                      if (16u * i + 16u <= tp)
+                        { const u32x4 v = { stretch[4 * i], stretch[4 * i + 1], stretch[4 * i + 2], stretch[4 * i + 3] };
+                          *(u32x4_u *) (o + 16u * i) = v;
+                        }
+                      else
+                        for (uint32_t j = 16u * i; j < tp; j++) o[j] = ((const uint8_t *) stretch)[j];
+                  }
+                wave_sync();
+              }
             base_bit += tb;
             base_pos += tp;
           }
@@ -1044,6 +1096,12 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
           if (k + 16u <= L) { const u32x4 v = { pat, pat, pat, pat }; *(u32x4_u *) (out + k) = v; }
           else for (uint32_t j = k; j < L; j++) out[j] = (uint8_t) rc;
         if (lane == 0) out[L] = '\n';
+        if (tags)
+          { for (uint32_t k = base_pos + 16u * (uint32_t) lane; k < L; k += 1024u)
+              if (k + 16u <= L) { const u32x4 v = { tpat, tpat, tpat, tpat }; *(u32x4_u *) (tout + k) = v; }
+              else for (uint32_t j = k; j < L; j++) tout[j] = (uint8_t) tpat;
+            if (lane == 0) tout[L] = '\n';
+          }
         if (__any((int) bad) && lane == 0) atomicOr(status, 4u);
       }
     }
@@ -1052,7 +1110,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
 // Tag line of each entry (QV.c:1437-1461): tag[p] = 'n' where del[p] is the run character, else
 // the next 2-bit code of the tag segment as a letter; one wavefront per entry.
 __global__ __launch_bounds__(DX_BLOCK)
-void k_qv_decode_tags(dec_args a)
+void k_qv_decode_tags(dec_args a, const uint32_t *skip_idx, const uint64_t *skip_off)
 { // four tag bytes per look-up: index = (which of the 4 positions hold a non-run symbol) << 8 | the next
   // four 2-bit codes; the entry has letters at those positions (codes consumed in order), 'n' elsewhere
   __shared__ uint32_t s_quad[16 * 256];                    // 16 KB
@@ -1076,6 +1134,8 @@ void k_qv_decode_tags(dec_args a)
 
   for (uint64_t r = wave0; r < a.n; r += nwave)
     { const uint32_t  L   = a.len[r];
+      if (skip_idx != NULL && skip_idx[skip_off[r] + run_base(L)] != RUN_NONE)
+        continue;                                          // k_qv_decode_runs wrote this entry's tag line with its deletion line
       const uint32_t *sg  = a.seg + 5 * r;
       const uint8_t  *src = a.in + a.rec_off[r] + (a.hdr_off ? a.hdr_off[r + 1] - a.hdr_off[r] : 0) + sg[0];
       const uint32_t  tb  = sg[1];                         // packed tag bytes
@@ -1209,7 +1269,8 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
     DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,
               (const uint32_t *) ctx->d_long, ctx->d_status, d_next, 15u & ~plain_kinds,
               (const uint32_t *) skip_idx, (const uint64_t *) skip_off, skip_kinds, (const uint32_t *) ctx->sx.none);
-  DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a);
+  DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a,
+            (skip_kinds & 1u) ? (const uint32_t *) skip_idx : (const uint32_t *) NULL, (const uint64_t *) skip_off);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
