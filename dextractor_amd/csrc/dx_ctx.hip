@@ -1,6 +1,7 @@
 // dx_ctx.hip -- context, device memory and per-kernel timing plumbing of libdexgpu.
 #include "dx_internal.hpp"
 #include <pthread.h>
+#include <time.h>
 #include <string.h>
 
 #include <stdlib.h>
@@ -25,10 +26,22 @@ extern "C" int dx_device_count(void)
   return n;
 }
 
+// DEXGPU_TIMING: where opening a context spends its time (stderr)
+static void open_mark(const char *what)
+{ static double t0 = -1.0;
+  if (getenv("DEXGPU_TIMING") == NULL) return;
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  const double now = ts.tv_sec + 1e-9 * ts.tv_nsec;
+  if (t0 < 0) t0 = now;
+  fprintf(stderr, "[dx_open %8.1f ms] %s\n", (now - t0) * 1e3, what);
+}
+
 extern "C" int dx_open(int device, dx_ctx **out)
 { if (out == NULL)
     return dx_fail(NULL, DX_E_ARG, "dx_open: NULL result pointer");
   *out = NULL;
+  open_mark("start");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -37,6 +50,7 @@ extern "C" int dx_open(int device, dx_ctx **out)
   if (device < 0 || device >= n)
     return dx_fail(NULL, DX_E_ARG, "dx_open: device %d out of range (0..%d)", device, n - 1);
 
+  open_mark("device count");
   dx_ctx *ctx = new dx_ctx();
   ctx->device = device;
   ctx->err[0] = '\0';
@@ -66,13 +80,17 @@ extern "C" int dx_open(int device, dx_ctx **out)
      } while (0)
 
   OPEN_HIP(hipSetDevice(device));
+  open_mark("set device");
   hipDeviceProp_t prop;
   OPEN_HIP(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  open_mark("device properties");
   OPEN_HIP(hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking));
   OPEN_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+  open_mark("streams");
   for (int k = 0; k < 17; k++)
     OPEN_HIP(hipEventCreateWithFlags(&ctx->ev[k], hipEventDisableTiming));
+  open_mark("events");
   ctx->stream = ctx->own;
   OPEN_HIP(hipMalloc((void **) &ctx->d_tok, DX_TOK_WORDS * sizeof(uint32_t)));
   OPEN_HIP(hipMalloc((void **) &ctx->d_dec, 6 * DX_DEC_SIZE * sizeof(uint16_t)));
@@ -80,6 +98,7 @@ extern "C" int dx_open(int device, dx_ctx **out)
   OPEN_HIP(hipMalloc((void **) &ctx->d_status, 64));
   OPEN_HIP(hipMalloc((void **) &ctx->d_u64, 64 * sizeof(uint64_t)));
   OPEN_HIP(hipMemset(ctx->d_status, 0, 64));
+  open_mark("allocations");
 #undef OPEN_HIP
   *out = ctx;
   return DX_OK;
