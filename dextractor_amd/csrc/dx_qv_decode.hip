@@ -21,7 +21,6 @@
 // algorithmic bytes: 75 GB of HBM traffic per 10 GB decoded).
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
-#include <vector>
 
 struct dec_args
 { const uint8_t  *in;
