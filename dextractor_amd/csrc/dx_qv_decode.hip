@@ -246,7 +246,8 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
                  uint32_t kinds /* bit q set: this launch decodes stream kind q (0 del, 1 ins, 2 mrg, 3 sub) */,
                  const uint32_t *skip_idx, const uint64_t *skip_off, uint32_t skip_kinds /* run-coded kinds whose indexed
                  lines k_qv_decode_runs has decoded: only the lines without an index (RUN_NONE) are left for this kernel */,
-                 const uint32_t *none_count /* how many such lines the batch has */)
+                 const uint32_t *none_count /* how many such lines the batch has */,
+                 uint32_t first_task /* tasks before this one belong to kinds not in `kinds` (the plain lines come first) */)
 { __shared__ uint16_t s_dec[6][DX_DEC_SIZE];               // 24 KB
   __shared__ uint32_t s_long[6][1 + DX_LONG_MAX];          // 6 KB
   __shared__ __attribute__((aligned(8))) uint8_t s_row[DEC_BLOCK][DEC_ROW_BYTES];    // 40 KB
@@ -265,7 +266,7 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
   for (;;)
     { uint32_t t = 0;
       if (lane_id() == 0)
-        t = atomicAdd(next_task, 1u);
+        t = atomicAdd(next_task, 1u) + first_task;
       t = uniform(t);
       if ((uint64_t) t >= 4 * ngroup) break;               // every wave gets here: the counter only grows
       // order: ins and mrg of every group, then del and sub
@@ -1267,7 +1268,8 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   if (plain_kinds != 15u)
     DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,
               (const uint32_t *) ctx->d_long, ctx->d_status, d_next, 15u & ~plain_kinds,
-              (const uint32_t *) skip_idx, (const uint64_t *) skip_off, skip_kinds, (const uint32_t *) ctx->sx.none);
+              (const uint32_t *) skip_idx, (const uint64_t *) skip_off, skip_kinds, (const uint32_t *) ctx->sx.none,
+              ((15u & ~plain_kinds) & 6u) == 0u ? (uint32_t) (2 * ((n + 63) / 64)) : 0u);
   DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a,
             (skip_kinds & 1u) ? (const uint32_t *) skip_idx : (const uint32_t *) NULL, (const uint64_t *) skip_off);
   uint32_t st = 0;
