@@ -46,6 +46,8 @@ def parse():
                     help=f"entries per GPU (default {ENTRIES_1GPU} at N=1, {ENTRIES_SHARD} per rank at N>1)")
     ap.add_argument("--mean", type=int, default=10_000)
     ap.add_argument("--dist", default="fixed", choices=["fixed", "lognormal"])
+    ap.add_argument("--with-index", action="store_true",
+                    help="dexqv: the timed steps also write the group index (dx_qv_subindex) -- what it costs the encoder")
     ap.add_argument("--lossy", action="store_true")
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--cpu-sample-entries", type=int, default=20000)
@@ -253,6 +255,8 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         if world > 1:
             dist.barrier()
 
+    if args.with_index:
+        ctx.qv_subindex(True)
     for _ in range(args.warmup):
         step()
     if state["p_out"] is None:               # --warmup 0: the output buffer is sized (untimed) before the clock starts
@@ -266,6 +270,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
     dt = time.perf_counter() - t0
     times = ctx.kernel_times()
     ctx.profile(False)
+    ctx.qv_subindex(False)
     p_out = state["p_out"]
 
     roundtrip = None
