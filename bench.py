@@ -46,6 +46,8 @@ def parse():
                     help=f"entries per GPU (default {ENTRIES_1GPU} at N=1, {ENTRIES_SHARD} per rank at N>1)")
     ap.add_argument("--mean", type=int, default=10_000)
     ap.add_argument("--dist", default="fixed", choices=["fixed", "lognormal"])
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="dexqv: every step ends its own encode (dx_qv_encode_onepass) instead of begin / end across steps")
     ap.add_argument("--with-index", action="store_true",
                     help="dexqv: the timed steps also write the group index (dx_qv_subindex) -- what it costs the encoder")
     ap.add_argument("--lossy", action="store_true")
@@ -233,11 +235,22 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         ctx.qv_set_coding(coding, args.lossy)
         need = int(hoff[-1]) + api.qv_out_bound(mine, n, coding, args.lossy)     # from this rank's own counts
         if need > state["out_cap"]:          # first step only (the corpus does not change between steps)
+            if state.get("begun"):
+                state["total"] = ctx.qv_encode_onepass_end()
+                state["begun"] = False
             state["p_out"] = None
             state["p_out"] = Ptr(torch.empty(need + 4096, dtype=torch.uint8, device="cuda"))
             state["out_cap"] = need + 4096
         p_out, out_cap = state["p_out"], state["out_cap"]
-        if not args.twopass:
+        if not args.twopass and not args.no_pipeline:
+            # consecutive steps are consecutive batches of one job: the encode is queued (begin) and collected (end) just
+            # before the next one starts, so that the last group's compaction runs beside the next batch's scan
+            if state.get("begun"):
+                state["total"] = ctx.qv_encode_onepass_end()
+            ctx.qv_encode_onepass_begin(batch, p_hdr, p_hoff, p_seg, p_rec, p_out, out_cap)
+            state["begun"] = True
+            total = state.get("total", 0)
+        elif not args.twopass:
             total = ctx.qv_encode_onepass(batch, p_hdr, p_hoff, p_seg, p_rec, p_out, out_cap)
         else:
             total = ctx.qv_sizes(batch, p_hoff, p_seg, p_rec)
@@ -250,6 +263,9 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         state.update(total=total, coding=coding, params=p)
 
     def fence():
+        if state.get("begun"):                # the job's last encode: its compaction belongs inside the timed region
+            state["total"] = ctx.qv_encode_onepass_end()
+            state["begun"] = False
         ctx.sync()
         torch.cuda.synchronize()
         if world > 1:

@@ -96,6 +96,8 @@ SIGNATURES = {
     "dx_qv_sizes": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, C.POINTER(C.c_uint64)]),
     "dx_qv_encode": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, _P, _P]),
     "dx_qv_encode_onepass": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "dx_qv_encode_onepass_begin": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, _P, _P, C.c_uint64]),
+    "dx_qv_encode_onepass_end": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "dx_qv_out_bound": (C.c_uint64, [C.POINTER(HIST), C.c_uint64, C.POINTER(QVCoding), C.c_int]),
     "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
     "dx_qv_walk": (C.c_int, [_P, C.c_size_t, _P]),

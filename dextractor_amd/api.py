@@ -160,6 +160,18 @@ class Context:
                                                 d_out.ptr, out_cap, C.byref(tot)))
         return tot.value
 
+    def qv_encode_onepass_begin(self, batch, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap):
+        """dx_qv_encode_onepass_begin: queue the encode; the next batch's prescan / hist / build / set_coding may follow."""
+        self._chk(self.lib.dx_qv_encode_onepass_begin(self.h, C.byref(batch), d_hdr.ptr if d_hdr else None,
+                                                      d_hdr_off.ptr if d_hdr_off else None, d_seg.ptr, d_rec_off.ptr,
+                                                      d_out.ptr, out_cap))
+
+    def qv_encode_onepass_end(self) -> int:
+        """dx_qv_encode_onepass_end: wait for the encode that has begun; returns the stream's size."""
+        tot = C.c_uint64()
+        self._chk(self.lib.dx_qv_encode_onepass_end(self.h, C.byref(tot)))
+        return tot.value
+
     def qv_decode(self, d_in, d_rec_off, d_hdr_off, d_seg, d_len, n, upper, d_out, d_out_off, flip=False):
         flags = (1 if upper else 0) | (2 if flip else 0)          # DX_DECODE_UPPER | DX_DECODE_FLIP
         self._chk(self.lib.dx_qv_decode(self.h, d_in.ptr, d_rec_off.ptr, d_hdr_off.ptr if d_hdr_off else None,

@@ -68,6 +68,8 @@ extern "C" int dx_open(int device, dx_ctx **out)
   ctx->onepass_min_groups = 0;
   memset(&ctx->sx, 0, sizeof(ctx->sx));
   ctx->h_stage[0] = ctx->h_stage[1] = NULL;
+  ctx->d_hscr = NULL; ctx->hscr_bytes = 0;
+  memset(&ctx->op, 0, sizeof(ctx->op));
   memset(&ctx->tk, 0, sizeof(ctx->tk));
 
 #define OPEN_HIP(call)                                                                       \
@@ -108,6 +110,7 @@ extern "C" void dx_close(dx_ctx *ctx)
 { if (ctx == NULL)
     return;
   (void) hipSetDevice(ctx->device);
+  (void) hipStreamSynchronize(ctx->side);
   (void) hipStreamSynchronize(ctx->stream);
   for (auto &p : ctx->pend)
     { (void) hipEventDestroy(p.a);
@@ -120,6 +123,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_u64);
   (void) hipFree(ctx->d_scratch);
   (void) hipFree(ctx->d_scan);
+  (void) hipFree(ctx->d_hscr);
   (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room); (void) hipFree(ctx->sx.none);
   if (ctx->h_stage[0]) (void) hipHostFree(ctx->h_stage[0]);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
@@ -270,7 +274,9 @@ extern "C" int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes)
 }
 
 int dx_scratch(dx_ctx *ctx, size_t bytes, void **p)
-{ if (bytes > ctx->scratch_bytes)
+{ if (ctx->op.pending && !ctx->op.direct)                  // an encode has begun: its last compaction reads this buffer
+    DX_HIP(ctx, hipStreamSynchronize(ctx->side));
+  if (bytes > ctx->scratch_bytes)
     { DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_scratch)
         DX_HIP(ctx, hipFree(ctx->d_scratch));

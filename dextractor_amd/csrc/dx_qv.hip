@@ -1583,7 +1583,19 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   hbytes = ((6 * 256 + 2) * 8 + 255) & ~(size_t) 255;
   uint8_t *scr;
-  if ((e = dx_scratch(ctx, hbytes + ((n * 4 + 63) & ~(size_t) 63) + (ntiles + 2) * 8 + 64, (void **) &scr))) return e;
+  { const size_t want = hbytes + ((n * 4 + 63) & ~(size_t) 63) + (ntiles + 2) * 8 + 64;
+    if (want > ctx->hscr_bytes)                          // (its own buffer: see dx_ctx.op)
+      { DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void) hipFree(ctx->d_hscr);
+        ctx->d_hscr = NULL; ctx->hscr_bytes = 0;
+        if (hipMalloc(&ctx->d_hscr, want + want / 4) != hipSuccess)
+          { (void) hipGetLastError();
+            return dx_fail(ctx, DX_E_NOMEM, "dx_qv_hist: no memory for %zu bytes of scratch", want);
+          }
+        ctx->hscr_bytes = want + want / 4;
+      }
+    scr = (uint8_t *) ctx->d_hscr;
+  }
   unsigned long long *d_hist = (unsigned long long *) scr;
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 2) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
@@ -2037,11 +2049,15 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
   return DX_OK;
 }
 
-extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
-                                    uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap,
-                                    uint64_t *total)
+static int onepass_end(dx_ctx *ctx, uint64_t *total);
+
+// wait = false: everything is queued and the function returns; onepass_end collects the total and the status
+static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                        uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total, bool wait)
 { int e = check_batch(ctx, b, "dx_qv_encode_onepass");
   if (e) return e;
+  if (ctx->op.pending)
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_encode_onepass: an encode has begun in this context: end it first (dx_qv_encode_onepass_end)");
   if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode_onepass: call dx_qv_set_coding first");
   if ((d_hdr == NULL) != (d_hdr_off == NULL))
     return dx_fail(ctx, DX_E_ARG, "dx_qv_encode_onepass: d_hdr and d_hdr_off must be given together");
@@ -2054,13 +2070,19 @@ extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uin
       DX_HIP(ctx, hipMemcpyAsync(d_rec_off, &z, 8, hipMemcpyHostToDevice, ctx->stream));
       DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (total) *total = 0;
+      if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = DX_OK; ctx->op.total = 0; }
       return DX_OK;
     }
   // DEXGPU_DIRECT_ENCODE: sizes first, records written in place, no scratch slots (onepass_direct) -- what also runs
   // when the slots below cannot be allocated.  It is the slower of the two (34.5 ms against 31.0, 1 M x 10 kb): its
   // size kernel reads the 30 GB of plain lines once more, the compaction it saves moves 2 x 14 GB.
   if (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_DIRECT_ENCODE") != NULL)
-    return onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, total);
+    { uint64_t t = 0;
+      const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
+      if (total) *total = t;
+      if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }   // (this route does not pipeline)
+      return rc;
+    }
 
   // Groups of entries: the encoder works through them on the context's stream while the compaction of the
   // group before runs beside it on the side stream.  Both stages move memory at close to the rate the
@@ -2139,7 +2161,12 @@ layout:
               goto layout;
             }
           if (pass == 1 && onepass_tokens_ok(ctx, b))    // no room for any slots: the scheme that needs none
-            return onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, total);
+            { uint64_t t = 0;
+              const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
+              if (total) *total = t;
+              if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }
+              return rc;
+            }
           return e;
         }
       if (pass == 1 && base == (void *) scr) break;
@@ -2223,25 +2250,53 @@ layout:
       (void) hipEventRecord(cmp_done[g & 7], B);
       ng += 1;
     }
+  if (rc != DX_OK)
+    { (void) hipStreamSynchronize(B);
+      return rc;
+    }
+  (void) hipEventRecord(done, B);
+  ctx->op.pending = 1; ctx->op.direct = 0; ctx->op.d_total = d_base + (ng & 1); ctx->op.out_cap = out_cap; ctx->op.sx_idx = sx_idx;
+  if (!wait) return DX_OK;                               // (the last compaction is still running on the side stream)
+  return onepass_end(ctx, total);
+}
+
+// the other half: the caller's stream waits for the last compaction, total and status come back
+static int onepass_end(dx_ctx *ctx, uint64_t *total)
+{ if (!ctx->op.pending)
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_encode_onepass_end: no encode has begun in this context");
+  ctx->op.pending = 0;
+  if (ctx->op.direct)
+    { if (total) *total = ctx->op.total;
+      return ctx->op.rc;
+    }
+  hipStream_t A = ctx->stream;
   uint64_t tot = 0;
   uint32_t st  = 0;
-  if (rc == DX_OK)
-    { (void) hipEventRecord(done, B);
-      (void) hipStreamWaitEvent(A, done, 0);             // the caller's stream sees the finished output
-      if (hipMemcpyAsync(&tot, d_base + (ng & 1), 8, hipMemcpyDeviceToHost, A) != hipSuccess ||
-          hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A) != hipSuccess ||
-          hipStreamSynchronize(A) != hipSuccess)
-        rc = dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
-    }
-  else
-    (void) hipStreamSynchronize(B);
-  if (rc != DX_OK) return rc;
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  (void) hipStreamWaitEvent(A, ctx->ev[16], 0);          // the caller's stream sees the finished output
+  if (hipMemcpyAsync(&tot, ctx->op.d_total, 8, hipMemcpyDeviceToHost, A) != hipSuccess ||
+      hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A) != hipSuccess ||
+      hipStreamSynchronize(A) != hipSuccess)
+    return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
   if (total) *total = tot;
   if (st & 2u)
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry outgrew its scratch slot");
-  if (tot > out_cap || (st & 8u))
+  if (tot > ctx->op.out_cap || (st & 8u))
     return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
-                   (unsigned long long) tot, (unsigned long long) out_cap);
-  ctx->sx.valid = sx_idx != NULL;
+                   (unsigned long long) tot, (unsigned long long) ctx->op.out_cap);
+  ctx->sx.valid = ctx->op.sx_idx != NULL;
   return DX_OK;
+}
+
+extern "C" int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                                    uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total)
+{ return onepass_impl(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, total, true); }
+
+extern "C" int dx_qv_encode_onepass_begin(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap)
+{ return onepass_impl(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, NULL, false); }
+
+extern "C" int dx_qv_encode_onepass_end(dx_ctx *ctx, uint64_t *total)
+{ if (ctx == NULL) return DX_E_ARG;
+  return onepass_end(ctx, total);
 }

@@ -264,6 +264,16 @@ int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const 
  * batches) is owned by the context and kept for the next call.                                      */
 int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total);
+/* The same in two halves, for a caller with more batches to come: _begin queues everything and returns while the
+ * last group's compaction is still running on the context's second stream; _end makes the context's stream wait
+ * for it and hands back the stream's size and the verdict (DX_E_SPACE, ...).  Between the two, the NEXT batch's
+ * dx_qv_prescan, dx_qv_hist, dx_qv_build and dx_qv_set_coding may run (in that order: they touch nothing the
+ * compaction reads) -- the compaction then hides behind the histogram pass, 3 ms of a 31 ms step; every other call
+ * of the context first waits for the compaction.  One encode at a time per context.  d_out, d_seg, d_rec_off are
+ * complete once _end has returned.                                                                             */
+int dx_qv_encode_onepass_begin(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                               uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap);
+int dx_qv_encode_onepass_end(dx_ctx *ctx, uint64_t *total);
 
 /* Host helper sizing d_out for dx_qv_encode_onepass: an upper bound of the bytes the batch's n entries
  * encode to (framing bytes not included), from the batch's own raw histograms (what dx_qv_hist added

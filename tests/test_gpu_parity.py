@@ -1043,6 +1043,47 @@ def test_encode_onepass_equals_two_pass(ctx, case, groups, tokens, monkeypatch):
     assert e.value.code == -8
 
 
+def test_encode_begin_end_pipelines_two_batches(ctx):
+    """dx_qv_encode_onepass_begin / _end: batch A's encode is queued, batch B's prescan + hist + table build run while
+    A's last compaction may still be going, then A is collected and B encoded the same way: both streams equal the
+    one-call encoder's; a second begin before the end, and an end without a begin, are refused."""
+    ca, cb = synth.make_quiva(300, seed=41, mean=6000), synth.make_quiva(260, seed=42, mean=7000)
+    def prep(c):
+        b, keep = _upload_quiva(ctx, c)
+        blob, hoff, _ = api.frame_headers(c.hdr)
+        n = len(c.len)
+        return dict(c=c, b=b, keep=keep, n=n, d_hdr=ctx.to_device(blob), d_hoff=ctx.to_device(hoff),
+                    d_rec=ctx.alloc(8 * (n + 1)), d_seg=ctx.alloc(20 * n), d_out=ctx.alloc(len(c.text)), cap=len(c.text))
+    A, B = prep(ca), prep(cb)
+    def tables(X):
+        p = ctx.qv_prescan(X["b"])
+        hist, tot = ctx.qv_hist(X["b"], p)
+        ctx.qv_set_coding(api.qv_build(hist, tot, p))
+    def args(X):
+        return (X["b"], X["d_hdr"], X["d_hoff"], X["d_seg"], X["d_rec"], X["d_out"], X["cap"])
+    want = {}
+    for name, X in (("A", A), ("B", B)):                            # the one-call encoder
+        tables(X)
+        t = ctx.qv_encode_onepass(*args(X))
+        want[name] = (t, X["d_out"].download(np.uint8, t).tobytes(), X["d_rec"].download(np.uint64).copy())
+        X["d_out"].upload(np.zeros(X["cap"], np.uint8))
+    with pytest.raises(L.DexGPUError):
+        ctx.qv_encode_onepass_end()                                # nothing has begun
+    tables(A)
+    ctx.qv_encode_onepass_begin(*args(A))
+    with pytest.raises(L.DexGPUError):
+        ctx.qv_encode_onepass_begin(*args(A))                      # one encode at a time
+    tables(B)                                                      # the next batch's scan beside A's last compaction
+    ta = ctx.qv_encode_onepass_end()
+    ctx.qv_encode_onepass_begin(*args(B))
+    tb = ctx.qv_encode_onepass_end()
+    for name, X, t in (("A", A, ta), ("B", B, tb)):
+        assert t == want[name][0]
+        assert X["d_out"].download(np.uint8, t).tobytes() == want[name][1]
+        assert (X["d_rec"].download(np.uint64) == want[name][2]).all()
+    assert ctx.dexqv(ca.text) == O.dexqv(ca.text)                   # (the file driver still works on this context)
+
+
 def test_record_offsets_beyond_4gib(ctx):
     """A few thousand huge entries (700 k symbols each, 17.5 GB of text generated on the device): the record
     stream grows past 4 GiB, so every 64-bit offset path is exercised (slot offsets, record offsets, the
