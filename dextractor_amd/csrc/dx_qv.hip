@@ -1834,7 +1834,7 @@ static int fast_grid(dx_ctx *ctx, uint64_t entries)
 #define ONEPASS_REGION_CAP ((uint64_t) 32 << 30)          // bytes of one of the two scratch regions of dx_qv_encode_onepass
 
 // side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
-static int onepass_side(dx_ctx *ctx, hipStream_t B, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
+static int onepass_side(dx_ctx *ctx, hipStream_t B, int waves_per_cu, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
                         uint64_t *d_rec_off, const uint64_t *base_in, uint64_t *base_out, const uint32_t *d_len,
                         const uint8_t *d_slots, const uint64_t *d_slot, const uint32_t *d_seg, const uint8_t *d_hdr,
                         const uint64_t *d_hdr_off, uint8_t *d_out, uint64_t out_cap, uint32_t *d_tick)
@@ -1843,7 +1843,7 @@ static int onepass_side(dx_ctx *ctx, hipStream_t B, const uint32_t *d_size, uint
   DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, mt, d_gran);
   DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_apply_base, (int) mt, DX_BLOCK, d_size, m, (const uint64_t *) d_tile, d_rec_off,
                (const uint64_t *) d_gran, base_in, base_out);
-  DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, COMPACT_WAVES_PER_CU), DX_BLOCK,
+  DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, waves_per_cu), DX_BLOCK,
             m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
             ctx->d_status, d_tick);
   return DX_OK;
@@ -2245,7 +2245,7 @@ layout:
       DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction
       DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g & 7], 0));
-      rc = onepass_side(ctx, B, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
+      rc = onepass_side(ctx, B, COMPACT_WAVES_PER_CU, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
                         b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp);
       (void) hipEventRecord(cmp_done[g & 7], B);
       ng += 1;
