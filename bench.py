@@ -46,8 +46,9 @@ def parse():
                     help=f"entries per GPU (default {ENTRIES_1GPU} at N=1, {ENTRIES_SHARD} per rank at N>1)")
     ap.add_argument("--mean", type=int, default=10_000)
     ap.add_argument("--dist", default="fixed", choices=["fixed", "lognormal"])
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="dexqv: every step ends its own encode (dx_qv_encode_onepass) instead of begin / end across steps")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="dexqv: the timed steps as consecutive batches of one job (dx_qv_encode_onepass_begin / _end: a step's "
+                         "last compaction runs beside the next step's scan) instead of every step ending its own encode")
     ap.add_argument("--with-index", action="store_true",
                     help="dexqv: the timed steps also write the group index (dx_qv_subindex) -- what it costs the encoder")
     ap.add_argument("--lossy", action="store_true")
@@ -242,7 +243,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
             state["p_out"] = Ptr(torch.empty(need + 4096, dtype=torch.uint8, device="cuda"))
             state["out_cap"] = need + 4096
         p_out, out_cap = state["p_out"], state["out_cap"]
-        if not args.twopass and not args.no_pipeline:
+        if not args.twopass and args.pipeline:
             # consecutive steps are consecutive batches of one job: the encode is queued (begin) and collected (end) just
             # before the next one starts, so that the last group's compaction runs beside the next batch's scan
             if state.get("begun"):
