@@ -110,14 +110,23 @@ static void *copy_slice(void *arg)
   return NULL;
 }
 
-static int write_image(FILE *f, const uint8_t *buf, size_t n)
+/* May the output be laid out directly in the file behind f (posix_fallocate / ftruncate / pwrite at absolute
+   offsets / a mapping)?  Only when the file is ours to lay out: a regular file that is empty, positioned at its
+   start and not opened for appending.  `tool -i <in >>all` (O_APPEND: pwrite appends whatever the offset, ftruncate
+   would cut what is there) and `1<>file` (existing bytes behind offset 0) go through fwrite like a pipe.           */
+static int file_is_ours(FILE *f)
 { struct stat st;
-  long cores = sysconf(_SC_NPROCESSORS_ONLN);
+  int fd = fileno(f), fl;
+  if (fflush(f) != 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size != 0) return 0;
+  if ((fl = fcntl(fd, F_GETFL)) < 0 || (fl & O_APPEND)) return 0;
+  return lseek(fd, 0, SEEK_CUR) == 0;
+}
+
+static int write_image(FILE *f, const uint8_t *buf, size_t n)
+{ long cores = sysconf(_SC_NPROCESSORS_ONLN);
   int  T = cores > 16 ? 16 : (int) cores, k, made = 0;
-  off_t base;
   uint8_t *map;
-  if (n < ((size_t) 32 << 20) || T < 2 || fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || fflush(f) != 0 ||
-      (base = lseek(fileno(f), 0, SEEK_CUR)) != 0 || posix_fallocate(fileno(f), 0, (off_t) n) != 0 ||
+  if (n < ((size_t) 32 << 20) || T < 2 || !file_is_ours(f) || posix_fallocate(fileno(f), 0, (off_t) n) != 0 ||
       ftruncate(fileno(f), (off_t) n) != 0)
     return (n > 0 && fwrite(buf, 1, n, f) != n) ? -1 : 0;
   map = mmap(NULL, n, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(f), 0);
@@ -430,11 +439,10 @@ int dex_tool_main(int tool, int argc, char *argv[])
              its size comes from the host walk over the record stream, which runs while the GPU context is
              still being opened, and so does the allocation of the file's pages. */
           dx_undexqv_plan *plan = NULL;
-          struct stat      os;
           int              rc = dx_file_undexqv_plan(in, n, &plan, &out_len), direct, fd = fileno(output);
           tmark("records walked");
           if (rc == DX_OK)
-            { direct = fflush(output) == 0 && fstat(fd, &os) == 0 && S_ISREG(os.st_mode) && lseek(fd, 0, SEEK_CUR) == 0 &&
+            { direct = file_is_ours(output) &&
                        (out_len == 0 || posix_fallocate(fd, 0, (off_t) out_len) == 0) && ftruncate(fd, (off_t) out_len) == 0;
               tmark("output file allocated");
               if (Opening)
@@ -476,10 +484,9 @@ int dex_tool_main(int tool, int argc, char *argv[])
           leave(1);
         }
       if ((tool == TOOL_DEXQV && Nctx <= 1) || tool == TOOL_UNDEXTA || tool == TOOL_UNDEXAR)
-        { /* the output goes from the GPU into the output file chunk by chunk, if that is a regular file */
-          struct stat os;
+        { /* the output goes from the GPU into the output file chunk by chunk, if that is a regular file of ours */
           int         fd = fileno(output);
-          if (fflush(output) == 0 && fstat(fd, &os) == 0 && S_ISREG(os.st_mode) && lseek(fd, 0, SEEK_CUR) == 0)
+          if (file_is_ours(output))
             { uint64_t line = 0;
               int      code = 0, rc;
               if (tool == TOOL_DEXQV)

@@ -145,3 +145,25 @@ def test_cli_pack2_on_several_contexts(tmp_path, tool, ext, kind):
     assert r.returncode == 0, r.stderr
     want = O.dexta(txt) if kind == "fasta" else O.dexar(txt)
     assert _read(tmp_path / f"m.{'dexta' if kind == 'fasta' else 'dexar'}") == want
+
+
+@pytest.mark.gpu
+def test_cli_pipe_mode_appends_to_an_existing_file(tmp_path):
+    """`tool -i <in >>all` (stdout a regular file opened O_APPEND, or one that already holds bytes) must append: the
+    direct-to-file output paths only lay out files that are empty, at offset 0 and not in append mode."""
+    fa = synth.make_seqfile("fasta", 6, seed=11, mean=500).text
+    dx = O.dexta(fa)
+    _write(tmp_path / "a.dexta", dx)
+    back = O.undexta(dx, True, 80)
+    out = tmp_path / "all"
+    _write(out, b"KEEP ME\n")
+    for _ in range(2):
+        r = subprocess.run(f"{os.path.join(BIN, 'undexta')} -i -U <a.dexta >>all", shell=True, cwd=str(tmp_path), capture_output=True)
+        assert r.returncode == 0, r.stderr
+    assert _read(out) == b"KEEP ME\n" + back + back
+    # a file that already holds bytes, opened read-write at offset 0: its bytes beyond the new text survive as with fwrite
+    out = tmp_path / "rw"
+    _write(out, b"x" * (len(back) + 10))
+    r = subprocess.run(f"{os.path.join(BIN, 'undexta')} -i -U <a.dexta 1<>rw", shell=True, cwd=str(tmp_path), capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert _read(out) == back + b"x" * 10
