@@ -64,6 +64,9 @@ def parse():
                     help="dexqv: dx_qv_sizes + dx_qv_encode instead of dx_qv_encode_onepass (scratch slots + compaction)")
     ap.add_argument("--no-verify", action="store_true",
                     help="dexqv: skip the (untimed) full-size on-device decode + compare after the timed steps")
+    ap.add_argument("--scratch-budget-gb", type=float, default=None,
+                    help="dexqv: memory the one-pass encoder may take for its scratch regions (dx_set_scratch_budget); default: "
+                         "none at N=1 (by free device memory), 64 at N>1 so that every rank of a sharded job takes the same route")
     ap.add_argument("--only-main", action="store_true",
                     help="N=1: only the headline workload, without the lognormal / dexta / dexar extras")
     return ap.parse_args()
@@ -178,6 +181,9 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
     from dextractor_amd import api, shard, synth
 
     ctx = api.Context(local)
+    budget_gb = args.scratch_budget_gb if args.scratch_budget_gb is not None else (64.0 if world > 1 else 0.0)
+    if budget_gb:
+        ctx.set_scratch_budget(int(budget_gb * 1e9))
     n = args.entries
     entry0 = rank * n
     movie = "m000_000"
@@ -262,6 +268,9 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
                 if not args.no_check:
                     raise
         state.update(total=total, coding=coding, params=p)
+        if not args.twopass:
+            state["route"] = ctx.qv_onepass_info()
+            state["mem_used_peak"] = max(state.get("mem_used_peak", 0), (lambda f, t: t - f)(*torch.cuda.mem_get_info()))
 
     def fence():
         if state.get("begun"):                # the job's last encode: its compaction belongs inside the timed region
@@ -448,6 +457,8 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         "roundtrip_bit_exact": roundtrip,
         "tables_identical_across_ranks": tables_same,
         "host_table_build_us": state.get("host_build_us"),
+        "encoder_route": dict(state.get("route") or {}, scratch_budget_bytes=int(budget_gb * 1e9) or None,
+                              device_bytes_in_use_after_step=state.get("mem_used_peak")),
         "decode": state.get("decode"),
         "decode_indexed": state.get("decode_indexed"),
         "text_front_end": fr,

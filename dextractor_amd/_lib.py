@@ -43,6 +43,12 @@ class QVCoding(C.Structure):
 HIST = (C.c_uint64 * 256) * 6
 
 
+class OnepassInfo(C.Structure):
+    _fields_ = [("groups", C.c_int32), ("direct", C.c_int32), ("tokens", C.c_int32), ("reserved", C.c_int32),
+                ("region_bytes", C.c_uint64), ("scratch_bytes", C.c_uint64), ("avail_bytes", C.c_uint64),
+                ("token_bytes", C.c_uint64)]
+
+
 class QVIndex(C.Structure):
     _fields_ = [("n", C.c_uint64), ("rec_off", C.POINTER(C.c_uint64)), ("hdr_off", C.POINTER(C.c_uint64)),
                 ("seg", C.POINTER(C.c_uint32)), ("len", C.POINTER(C.c_uint32)), ("hdr4", C.POINTER(C.c_int32)),
@@ -98,6 +104,8 @@ SIGNATURES = {
     "dx_qv_encode_onepass": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "dx_qv_encode_onepass_begin": (C.c_int, [_P, C.POINTER(QVBatch), _P, _P, _P, _P, _P, C.c_uint64]),
     "dx_qv_encode_onepass_end": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "dx_qv_onepass_info": (C.c_int, [_P, C.POINTER(OnepassInfo)]),
+    "dx_set_scratch_budget": (C.c_int, [_P, C.c_uint64]),
     "dx_qv_out_bound": (C.c_uint64, [C.POINTER(HIST), C.c_uint64, C.POINTER(QVCoding), C.c_int]),
     "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
     "dx_qv_walk": (C.c_int, [_P, C.c_size_t, _P]),

@@ -265,19 +265,48 @@ class Context:
     def qv_subindex(self, on=True):
         self._chk(self.lib.dx_qv_subindex(self.h, int(bool(on))))
 
+    def qv_onepass_info(self) -> dict:
+        """dx_qv_onepass_info: the route the last one-pass encode took (groups / direct, scratch, budget)."""
+        o = L.OnepassInfo()
+        self._chk(self.lib.dx_qv_onepass_info(self.h, C.byref(o)))
+        return {k: int(getattr(o, k)) for k, _ in L.OnepassInfo._fields_ if k != "reserved"}
+
+    def set_scratch_budget(self, nbytes: int):
+        self._chk(self.lib.dx_set_scratch_budget(self.h, int(nbytes)))
+
+    @staticmethod
+    def _sink(sink):
+        """ctypes callback around a Python sink.  An exception raised inside a ctypes callback is printed and
+        swallowed (the callback then returns 0 = go on), so it is caught here, the library is told to stop
+        (it returns DX_E_IO) and the caller re-raises it through `box`."""
+        box = []
+
+        def cb(user, data, n, at):
+            try:
+                return 1 if sink(C.string_at(data, n), at) else 0
+            except BaseException as e:                       # noqa: BLE001 -- re-raised by the caller
+                box.append(e)
+                return 1
+        return L.SINK_FN(cb), box
+
     def unpack2_stream(self, img: bytes, sink, mode=L.DX_LETTERS_LOWER, width=80) -> int:
         """dx_file_unpack2_to: sink(data: bytes, at: int) -> falsy to go on; returns the text's size."""
         total = C.c_size_t()
-        cb = L.SINK_FN(lambda user, data, n, at: 1 if sink(C.string_at(data, n), at) else 0)
-        self._chk(self.lib.dx_file_unpack2_to(self.h, int(mode), img, len(img), int(width), cb, None, C.byref(total)))
+        cb, box = self._sink(sink)
+        rc = self.lib.dx_file_unpack2_to(self.h, int(mode), img, len(img), int(width), cb, None, C.byref(total))
+        if box:
+            raise box[0]
+        self._chk(rc)
         return total.value
 
     def dexqv_stream(self, quiva: bytes, sink, lossy=False) -> int:
         """dx_file_dexqv_to: sink(data: bytes, at: int) -> falsy to go on; returns the image's size."""
         total, line, code = C.c_size_t(), C.c_uint64(), C.c_int()
-        cb = L.SINK_FN(lambda user, data, n, at: 1 if sink(C.string_at(data, n), at) else 0)
+        cb, box = self._sink(sink)
         rc = self.lib.dx_file_dexqv_to(self.h, quiva, len(quiva), int(lossy), cb, None, C.byref(total),
                                        C.byref(line), C.byref(code))
+        if box:
+            raise box[0]
         if rc != 0:
             raise L.DexGPUError(rc, f"line {line.value} (DX_IDX code {code.value}): " + (self.lib.dx_last_error(self.h) or b"").decode())
         return total.value
@@ -291,8 +320,11 @@ class Context:
         if rc != 0:
             raise L.DexGPUError(rc, "dx_file_undexqv_plan")
         try:
-            cb = L.SINK_FN(lambda user, data, n, at: 1 if sink(C.string_at(data, n), at) else 0)
-            self._chk(self.lib.dx_file_undexqv_run(self.h, plan, int(upper), cb, None))
+            cb, box = self._sink(sink)
+            rc = self.lib.dx_file_undexqv_run(self.h, plan, int(upper), cb, None)
+            if box:
+                raise box[0]
+            self._chk(rc)
         finally:
             self.lib.dx_file_undexqv_plan_free(plan)
         return total.value

@@ -66,6 +66,8 @@ extern "C" int dx_open(int device, dx_ctx **out)
   ctx->d_scan = NULL;
   ctx->scan_words = 0;
   ctx->onepass_min_groups = 0;
+  ctx->scratch_budget = 0;
+  memset(&ctx->route, 0, sizeof(ctx->route));
   memset(&ctx->sx, 0, sizeof(ctx->sx));
   ctx->h_stage[0] = ctx->h_stage[1] = NULL;
   ctx->d_hscr = NULL; ctx->hscr_bytes = 0;
@@ -145,8 +147,18 @@ extern "C" int dx_reset_stream(dx_ctx *ctx)
   return DX_OK;
 }
 
+// An encode that has begun (dx_qv_encode_onepass_begin) still has its last compaction on the side stream: a call that
+// reads what it writes makes the context's stream wait for it first (the contract of dexgpu.h).
+int dx_after_pending(dx_ctx *ctx)
+{ if (ctx->op.pending && !ctx->op.direct)
+    DX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev[16], 0));
+  return DX_OK;
+}
+
 extern "C" int dx_sync(dx_ctx *ctx)
 { if (ctx == NULL) return DX_E_ARG;
+  int e = dx_after_pending(ctx);
+  if (e) return e;
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return DX_OK;
 }
@@ -177,6 +189,8 @@ extern "C" int dx_h2d(dx_ctx *ctx, void *d_dst, const void *src, size_t bytes)
 extern "C" int dx_d2h(dx_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 { if (ctx == NULL) return DX_E_ARG;
   if (bytes == 0) return DX_OK;
+  int e = dx_after_pending(ctx);
+  if (e) return e;
   DX_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return DX_OK;
@@ -218,6 +232,9 @@ extern "C" int dx_d2h_stream(dx_ctx *ctx, const void *d_src, size_t bytes, dx_si
 { if (ctx == NULL || sink == NULL || (bytes && d_src == NULL)) return DX_E_ARG;
   if (bytes == 0) return DX_OK;
   DX_HIP(ctx, hipSetDevice(ctx->device));
+  { int e = dx_after_pending(ctx);
+    if (e) return e;
+  }
   if (ctx->h_stage[0] == NULL)
     { void *h = NULL;
       if (hipHostMalloc(&h, 2 * DX_STAGE_BYTES, hipHostMallocDefault) != hipSuccess)
@@ -273,16 +290,34 @@ extern "C" int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes)
   return DX_OK;
 }
 
+// the scratch budget in force: DEXGPU_SCRATCH_BUDGET, else dx_set_scratch_budget, else 0 (none)
+uint64_t dx_budget(const dx_ctx *ctx)
+{ const char *e = getenv("DEXGPU_SCRATCH_BUDGET");
+  if (e != NULL && *e) return strtoull(e, NULL, 10);
+  return ctx->scratch_budget;
+}
+
+extern "C" int dx_set_scratch_budget(dx_ctx *ctx, uint64_t bytes)
+{ if (ctx == NULL) return DX_E_ARG;
+  ctx->scratch_budget = bytes;
+  ctx->onepass_min_groups = 0;                             // (what an earlier budget forced no longer binds)
+  return DX_OK;
+}
+
 int dx_scratch(dx_ctx *ctx, size_t bytes, void **p)
 { if (ctx->op.pending && !ctx->op.direct)                  // an encode has begun: its last compaction reads this buffer
     DX_HIP(ctx, hipStreamSynchronize(ctx->side));
+  const uint64_t budget = dx_budget(ctx);
+  if (budget && bytes > budget && bytes > ((size_t) 64 << 20))          // (small bookkeeping requests always pass)
+    return dx_fail(ctx, DX_E_NOMEM, "scratch request of %zu bytes exceeds the budget of %llu", bytes, (unsigned long long) budget);
   if (bytes > ctx->scratch_bytes)
     { DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_scratch)
         DX_HIP(ctx, hipFree(ctx->d_scratch));
       ctx->d_scratch = NULL;
       ctx->scratch_bytes = 0;
-      size_t want = bytes + bytes / 4 + 4096;
+      size_t want = bytes + (bytes < ((size_t) 1 << 30) ? bytes / 4 : 0) + 4096;     // (head room only while it is cheap)
+      if (budget && want > budget && bytes <= budget) want = bytes;
       hipError_t e = hipMalloc(&ctx->d_scratch, want);
       if (e != hipSuccess)
         return dx_fail(ctx, DX_E_NOMEM, "scratch allocation of %zu bytes failed: %s", want,

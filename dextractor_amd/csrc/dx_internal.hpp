@@ -46,6 +46,8 @@ struct dx_ctx
   uint32_t  bps[4];            // upper bound of encoded bits per symbol of del/ins/mrg/sub (dx_qv_encode_onepass)
   uint32_t  pair_lo[2];        // ins, mrg: lowest coded byte value when the coded values span <= 64 (pair tables), else ~0
   int       onepass_min_groups;// dx_qv_encode_onepass: fewest groups whose scratch regions have fitted the device so far
+  uint64_t  scratch_budget;    // dx_set_scratch_budget (0: by hipMemGetInfo)
+  dx_onepass_info route;       // what the last dx_qv_encode_onepass did (dx_qv_onepass_info)
 
   // run-length tokens the histogram pass leaves for the encoder (dx_qv.hip: "token hand-over")
   struct
@@ -92,6 +94,8 @@ struct dx_ctx
 
 int  dx_fail(dx_ctx *ctx, int code, const char *fmt, ...);
 int  dx_scratch(dx_ctx *ctx, size_t bytes, void **p);
+uint64_t dx_budget(const dx_ctx *ctx);
+int  dx_after_pending(dx_ctx *ctx);
 void dx_prof_begin_on(dx_ctx *ctx, int kernel, hipStream_t stream);
 void dx_prof_end_on(dx_ctx *ctx, hipStream_t stream);
 static inline void dx_prof_begin(dx_ctx *ctx, int kernel) { dx_prof_begin_on(ctx, kernel, ctx->stream); }

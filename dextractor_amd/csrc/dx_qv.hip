@@ -1402,13 +1402,19 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 
 // per-entry slot size for the scratch mode: sum over the streams of the table-derived bound
 __global__ __launch_bounds__(DX_BLOCK)
-void k_qv_bounds(const uint32_t *len, uint64_t n, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t *bound)
+void k_qv_bounds(const uint32_t *len, uint64_t n, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t *bound,
+                 unsigned long long *too_long)
 { const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
   if (i >= n) return;
   const uint64_t L = len[i];
   const uint64_t bits = L * b0 + L * b1 + L * b2 + L * b3;
-  const uint64_t bytes = ((bits + 7) >> 3) + 4 * 20 + tag_room((uint32_t) L);     // + partial and pad words, trailing run tokens
-  bound[i] = (uint32_t) ((bytes + 15) & ~(uint64_t) 15);                          // (entries of < 2^27 symbols)
+  uint64_t bytes = ((bits + 7) >> 3) + 4 * 20 + tag_room((uint32_t) L);           // + partial and pad words, trailing run tokens
+  bytes = (bytes + 15) & ~(uint64_t) 15;
+  if (bytes >= (1ull << 32))                                                     // a slot is addressed in 32 bits: such an entry (some
+    { atomicMax(too_long, (unsigned long long) L);                               // 3.5e8 symbols at 96 bits per position) is refused, never
+      bytes = 16;                                                                // given a wrapped bound
+    }
+  bound[i] = (uint32_t) bytes;
 }
 
 // bytes [0, nbytes) from src to dst, both arbitrarily aligned, by one wave: a byte-wise head up to
@@ -1723,6 +1729,7 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
   ctx->delChar = c->delChar;
   ctx->subChar = c->subChar;
   ctx->sx.valid = 0;                                     // (a group index belongs to a stream of the tables before)
+  if (ctx->op.pending) ctx->op.sx_idx = NULL;            // ... also the one an encode that has begun would arm at its end
   return DX_OK;
 }
 
@@ -1759,6 +1766,8 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
 { int e = check_batch(ctx, b, "dx_qv_sizes");
   if (e) return e;
   if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_sizes: call dx_qv_set_coding first");
+  if (ctx->op.pending)
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_sizes: an encode has begun in this context: end it first (dx_qv_encode_onepass_end)");
   if (d_rec_off == NULL || (b->n && d_seg == NULL))
     return dx_fail(ctx, DX_E_ARG, "dx_qv_sizes: NULL d_seg / d_rec_off");
   DX_HIP(ctx, hipSetDevice(ctx->device));
@@ -1798,6 +1807,8 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
 { int e = check_batch(ctx, b, "dx_qv_encode");
   if (e) return e;
   if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: call dx_qv_set_coding first");
+  if (ctx->op.pending)
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: an encode has begun in this context: end it first (dx_qv_encode_onepass_end)");
   if ((d_hdr == NULL) != (d_hdr_off == NULL))
     return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: d_hdr and d_hdr_off must be given together");
   if (b->n == 0) return DX_OK;
@@ -2040,6 +2051,8 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       hipStreamSynchronize(A) != hipSuccess)
     return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
   if (total) *total = tot;
+  ctx->route.groups = 0; ctx->route.direct = 1; ctx->route.tokens = 1; ctx->route.region_bytes = 0;
+  ctx->route.scratch_bytes = ctx->scratch_bytes; ctx->route.token_bytes = 4ull * ctx->tk.cap_tokens;
   if (tot > out_cap || (st & 8u))
     return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
                    (unsigned long long) tot, (unsigned long long) out_cap);
@@ -2102,13 +2115,17 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
       { while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
         // ... and as the free device memory allows (the scratch that exists counts as free: it is replaced): more,
         // smaller groups when two big regions do not fit (a 125 GB shard leaves ~40 GB beside its tokens and output)
+        // (or the budget the caller set, dx_set_scratch_budget: the route is then a function of the batch and the budget)
         size_t free_b = 0, all_b = 0;
-        if (hipMemGetInfo(&free_b, &all_b) == hipSuccess)
-          { const uint64_t avail = (uint64_t) free_b + ctx->scratch_bytes;
-            while (G < ONEPASS_MAX_GROUPS &&
-                   (uint64_t) (G > 2 ? 3 : G) * ((n + G - 1) / G * per_entry) + 28 * n + (1ull << 30) > avail)
-              G++;
-          }
+        const uint64_t budget = dx_budget(ctx);
+        uint64_t avail = budget;
+        if (!budget && hipMemGetInfo(&free_b, &all_b) == hipSuccess)
+          avail = (uint64_t) free_b + ctx->scratch_bytes;
+        if (avail)
+          while (G < ONEPASS_MAX_GROUPS &&
+                 (uint64_t) (G > 2 ? 3 : G) * ((n + G - 1) / G * per_entry) + 28 * n + (budget ? 0 : 1ull << 30) > avail)
+            G++;
+        ctx->route.avail_bytes = avail;
       }
     else if (n >= 240000)
       G = (int) (n / 250000) > 2 ? (int) (n / 250000) : 2;
@@ -2176,15 +2193,21 @@ layout:
       d_slot  = (uint64_t *) (scr + 2 * a4);
       d_tile  = (uint64_t *) (scr + 2 * a4 + a8);
       d_gran  = d_tile + ntiles;
+      unsigned long long *d_long = (unsigned long long *) (ctx->d_u64 + 32), too_long = 0;
+      DX_HIP(ctx, hipMemsetAsync(d_long, 0, 8, ctx->stream));
       DX_LAUNCH(ctx, DX_K_SCAN, k_qv_bounds, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK,
-                (const uint32_t *) b->d_len, n, ctx->bps[0], ctx->bps[1], ctx->bps[2], ctx->bps[3], d_bound);
+                (const uint32_t *) b->d_len, n, ctx->bps[0], ctx->bps[1], ctx->bps[2], ctx->bps[3], d_bound, d_long);
       DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) ntiles, DX_BLOCK, (const uint32_t *) d_bound, n, d_tile);
       DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, ntiles, d_gran);
       DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, (const uint32_t *) d_bound, n,
                 (const uint64_t *) d_tile, d_slot, (const uint64_t *) d_gran);
       for (int g = 0; g <= G; g++)
         DX_HIP(ctx, hipMemcpyAsync(&gstart[g], d_slot + gb[g], 8, hipMemcpyDeviceToHost, ctx->stream));
+      DX_HIP(ctx, hipMemcpyAsync(&too_long, d_long, 8, hipMemcpyDeviceToHost, ctx->stream));
       DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (too_long)
+        return dx_fail(ctx, DX_E_UNSUPPORTED, "dx_qv_encode_onepass: an entry of %llu symbols needs a scratch slot of 4 GiB or more "
+                       "under these tables (use dx_qv_sizes + dx_qv_encode)", too_long);
       region = 0;
       for (int g = 0; g < G; g++)
         if (gstart[g + 1] - gstart[g] > region) region = gstart[g + 1] - gstart[g];
@@ -2255,6 +2278,9 @@ layout:
       return rc;
     }
   (void) hipEventRecord(done, B);
+  ctx->route.groups = ng; ctx->route.direct = 0; ctx->route.tokens = fast ? 1 : 0;
+  ctx->route.region_bytes = region; ctx->route.scratch_bytes = ctx->scratch_bytes;
+  ctx->route.token_bytes = fast ? 4ull * ctx->tk.cap_tokens : 0;
   ctx->op.pending = 1; ctx->op.direct = 0; ctx->op.d_total = d_base + (ng & 1); ctx->op.out_cap = out_cap; ctx->op.sx_idx = sx_idx;
   if (!wait) return DX_OK;                               // (the last compaction is still running on the side stream)
   return onepass_end(ctx, total);
@@ -2285,6 +2311,12 @@ static int onepass_end(dx_ctx *ctx, uint64_t *total)
     return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
                    (unsigned long long) tot, (unsigned long long) ctx->op.out_cap);
   ctx->sx.valid = ctx->op.sx_idx != NULL;
+  return DX_OK;
+}
+
+extern "C" int dx_qv_onepass_info(const dx_ctx *ctx, dx_onepass_info *out)
+{ if (ctx == NULL || out == NULL) return DX_E_ARG;
+  *out = ctx->route;
   return DX_OK;
 }
 

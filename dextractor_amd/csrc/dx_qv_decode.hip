@@ -1187,6 +1187,8 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
                             uint8_t *d_out, const uint64_t *d_out_off)
 { if (ctx == NULL) return DX_E_ARG;
   if (!ctx->coding_set) return dx_fail(ctx, DX_E_ARG, "dx_qv_decode: call dx_qv_set_coding first");
+  if (ctx->op.pending)                                   // (its verdict sits in d_status, its output may be d_in)
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_decode: an encode has begun in this context: end it first (dx_qv_encode_onepass_end)");
   if (n == 0) return DX_OK;
   if (n >= (1ull << 31))
     return dx_fail(ctx, DX_E_ARG, "dx_qv_decode: more than 2^31 - 1 entries in one batch");

@@ -268,12 +268,33 @@ int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr
  * last group's compaction is still running on the context's second stream; _end makes the context's stream wait
  * for it and hands back the stream's size and the verdict (DX_E_SPACE, ...).  Between the two, the NEXT batch's
  * dx_qv_prescan, dx_qv_hist, dx_qv_build and dx_qv_set_coding may run (in that order: they touch nothing the
- * compaction reads) -- the compaction then hides behind the histogram pass, 3 ms of a 31 ms step; every other call
- * of the context first waits for the compaction.  One encode at a time per context.  d_out, d_seg, d_rec_off are
- * complete once _end has returned.                                                                             */
+ * compaction reads) -- the compaction then hides behind the histogram pass, 3 ms of a 31 ms step.  Of the other calls,
+ * dx_sync, dx_d2h and dx_d2h_stream first make the context's stream wait for the compaction; dx_qv_sizes,
+ * dx_qv_encode, dx_qv_decode and a second dx_qv_encode_onepass[_begin] are refused (DX_E_ARG) until _end has been
+ * called.  A dx_qv_set_coding in between leaves the group index (dx_qv_subindex) of the ended encode unarmed.  One
+ * encode at a time per context.  d_out, d_seg, d_rec_off are complete once _end has returned.                   */
 int dx_qv_encode_onepass_begin(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                                uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap);
 int dx_qv_encode_onepass_end(dx_ctx *ctx, uint64_t *total);
+
+/* Which way the last dx_qv_encode_onepass / _begin of this context took (it depends on the memory left on the
+ * device), for logs and benchmarks: groups = scratch regions the batch was worked through in (0: none, see direct),
+ * direct = 1 when no scratch slots could be had and the sizes-first route ran (k_qv_sizes_fast, records written in
+ * place), tokens = 1 when the histogram pass's tokens fed the encoder; region_bytes = one scratch region,
+ * scratch_bytes = the context's scratch allocation after the call, avail_bytes = the memory the choice was made
+ * against (free device memory + the scratch that exists, or the budget below), token_bytes = the token slots.   */
+typedef struct
+  { int32_t  groups, direct, tokens, reserved;
+    uint64_t region_bytes, scratch_bytes, avail_bytes, token_bytes;
+  } dx_onepass_info;
+int dx_qv_onepass_info(const dx_ctx *ctx, dx_onepass_info *out);
+
+/* Memory the context may take for the scratch of dx_qv_encode_onepass (0, the default: whatever hipMemGetInfo
+ * reports free when the call is made -- which depends on what else holds memory in the process, e.g. a caching
+ * allocator).  With a budget the route a batch takes is a function of the batch and the budget alone: a job
+ * sharded over several GPUs gives every rank the same one.  The environment variable DEXGPU_SCRATCH_BUDGET (bytes)
+ * overrides both.                                                                                              */
+int dx_set_scratch_budget(dx_ctx *ctx, uint64_t bytes);
 
 /* Host helper sizing d_out for dx_qv_encode_onepass: an upper bound of the bytes the batch's n entries
  * encode to (framing bytes not included), from the batch's own raw histograms (what dx_qv_hist added

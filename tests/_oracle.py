@@ -63,8 +63,23 @@ def lib():
         L.ref_qv_encode_entry.restype = C.c_long
         L.ref_qv_encode_entry.argtypes = [C.POINTER(Coding), C.c_int, C.c_int] + [C.c_void_p] * 5 + \
                                          [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+        for name in ("ref_number_read", "ref_number_arrow"):
+            getattr(L, name).restype = None
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t]
+        L.ref_compress_read.restype = C.c_size_t
+        L.ref_compress_read.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
+
+
+def compress_read(seq: bytes, arrow=False) -> bytes:
+    """Number_Read / Number_Arrow + Compress_Read on one in-memory read (DB.c:393-441, 319-338): what dex2DB
+    writes to .bps / .arw (dex2DB.c:604-606, 643-644)."""
+    num = C.create_string_buffer(bytes(seq), len(seq) + 4)
+    (lib().ref_number_arrow if arrow else lib().ref_number_read)(num, len(seq))
+    out = C.create_string_buffer((len(seq) + 3) // 4 + 4)
+    n = lib().ref_compress_read(len(seq), num, out)
+    return out.raw[:n]
 
 
 def _call(fn, data, cap, *mid):
@@ -205,3 +220,39 @@ def byteswap_dexqv(dx, walk):
                     sw(p + w, 4)
             p += n
     return bytes(b)
+
+
+def rewrite_pack2(img, arrow=False, legacy=False, swap=False):
+    """A reference-written .dexta / .dexar image (key 0x55aa, int32 fields, this host's byte order) in the other
+    layouts the reference's readers accept: `legacy` = key 0x33cc with uint16 beg / end / qv (undexta.c:140-159,
+    211-240; .dexta only), `swap` = as a host of the other endianness would have written it (keys read back as
+    0xaa55 / 0xcc33; undexar.c:138-145).  Payload and well bytes are byte strings and stay as they are."""
+    import struct
+    assert img[:2] == b"\xaa\x55" and not (legacy and arrow)
+    e = ">" if swap else "<"
+    plen = struct.unpack("<i", img[2:6])[0]
+    out = bytearray(struct.pack(e + "H", 0x33cc if legacy else 0x55aa) + struct.pack(e + "i", plen) + img[6:6 + plen])
+    at = 6 + plen
+    while at < len(img):
+        w0 = at
+        while img[at] == 255:
+            at += 1
+        at += 1
+        out += img[w0:at]
+        beg, end = struct.unpack("<ii", img[at:at + 8])
+        at += 8
+        if arrow:
+            cnr = struct.unpack("<4H", img[at:at + 8])
+            at += 8
+            out += struct.pack(e + "ii4H", beg, end, *cnr)
+        else:
+            qv = struct.unpack("<i", img[at:at + 4])[0]
+            at += 4
+            if legacy:
+                assert 0 <= beg < 65536 and 0 <= end < 65536 and 0 <= qv < 65536
+            out += struct.pack(e + ("HHH" if legacy else "iii"), beg, end, qv)
+        clen = (end - beg + 3) >> 2
+        out += img[at:at + clen]
+        at += clen
+    assert at == len(img)
+    return bytes(out)

@@ -188,7 +188,25 @@ def quiva_runs():
 CASES = []
 
 
+def legacy_pack2(O):
+    """Older / other-endian .dexta and .dexar layouts (undexta.c:140-159, 211-240; undexar.c:138-145).  No current tool
+    writes them: the images are derived from the reference's own ta_small.dexta / ar_small.dexar (fields narrowed,
+    bytes swapped: O.rewrite_pack2) and the expected text is what the REAL reference undexta / undexar print."""
+    ta = O.golden("ta_small.dexta")
+    for tag, kw in (("legacy", dict(legacy=True)), ("swapped", dict(swap=True)), ("legacy_swapped", dict(legacy=True, swap=True))):
+        img = O.rewrite_pack2(ta, **kw)
+        store(f"ta_small.{tag}.dexta", img)
+        store(f"ta_small.{tag}.rt.fasta", run_tool("undexta", ["-U"], img, ".dexta", ".fasta"))
+    ar = O.rewrite_pack2(O.golden("ar_small.dexar"), arrow=True, swap=True)
+    store("ar_small.swapped.dexar", ar)
+    store("ar_small.swapped.rt.arrow", run_tool("undexar", [], ar, ".dexar", ".arrow"))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "legacy_pack2":          # (only these fixtures; the others stay as they are)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        return legacy_pack2(O)
     if not os.path.isdir(REF):
         sys.exit("oracle/_ref missing: run `make -C oracle ref` in the build container first")
     hashes = {}
@@ -254,6 +272,8 @@ def main():
     store("qv_tiny.legacy.dexqv", leg)
     store("qv_tiny.legacy.rt.quiva", run_tool("undexqv", ["-U"], leg, ".dexqv", ".quiva"))
     store("qv_tiny.legacy.rt_lower.quiva", run_tool("undexqv", [], leg, ".dexqv", ".quiva"))
+
+    legacy_pack2(O)
 
     # ---- BASELINE config 1: 1000 reads, mean 10 kb -- hashes only ----
     c1 = synth.make_seqfile("fasta", 1000, seed=20261003, mean=10000)

@@ -636,9 +636,13 @@ def test_undexta_legacy_and_byteswapped_keys(ctx):
         return out
     imgs = [build(0x55aa, False, True), build(0x55aa, True, True), build(0x33cc, False, False), build(0x33cc, True, False)]
     want = b">mv/5/0_7 RQ=0.851\nacgtacg\n>mv/300/3_5 RQ=0.7\ngt\n"
-    for img in imgs:
+    for k, img in enumerate(imgs):
         assert O.undexta(img) == want
         assert ctx.undexta(img) == want
+        if O.have_ref():                                              # ... and the real undexta says the same
+            import tempfile
+            with tempfile.TemporaryDirectory() as d:
+                assert O.run_ref("undexta", [], img, ".dexta", ".fasta", d) == want, k
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -1198,3 +1202,42 @@ def test_old_name_shims_like_dex2db(ctx, tmp_path):
         body, _ = O.qv_encode_entry(ref, False, np.stack([np.frombuffer(x, np.uint8) for x in lines]))
         want += body
     assert got == want
+
+
+@pytest.mark.parametrize("name,kind", [("ta_small.legacy", "dexta"), ("ta_small.swapped", "dexta"),
+                                       ("ta_small.legacy_swapped", "dexta"), ("ar_small.swapped", "dexar")])
+def test_unpack2_older_and_other_endian_layouts_golden(ctx, name, kind):
+    """.dexta with key 0x33cc (uint16 fields), byte-swapped 0xcc33 / 0xaa55, byte-swapped .dexar (undexta.c:140-159,
+    211-240; undexar.c:138-145) against what the REAL undexta / undexar print for these images (tests/golden)."""
+    img = O.golden(f"{name}.{kind}")
+    want = O.golden(name + (".rt.fasta" if kind == "dexta" else ".rt.arrow"))
+    if kind == "dexta":
+        assert ctx.undexta(img, True, 80) == want
+        assert ctx.undexta(img, False, 61) == O.undexta(img, False, 61)
+    else:
+        assert ctx.undexar(img, 80) == want
+        assert ctx.undexar(img, 7) == O.undexar(img, 7)
+
+
+@pytest.mark.parametrize("arrow", [False, True], ids=["bps", "arw"])
+def test_pack2_bare_payloads_like_dex2db(ctx, arrow):
+    """dx_pack2_encode with d_hdr == NULL: bare 2-bit payloads, read after read, no framing -- what dex2DB writes to
+    .bps / .arw through Compress_Read (dex2DB.c:604-606, 643-644) -- against Number_Read / Number_Arrow +
+    Compress_Read per read.  In-memory reads: no line ends, every length mod 4, empty reads, odd letters."""
+    rng = np.random.Generator(np.random.PCG64(77 + arrow))
+    lens = [0, 1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 1023, 1024, 1025, 4099, 20000, 0, 7] + [int(x) for x in rng.integers(1, 9000, 60)]
+    alpha = np.frombuffer(b"1234G05" if arrow else b"ACGTacgtNn", np.uint8)
+    reads = [alpha[rng.integers(0, len(alpha), L)].tobytes() for L in lens]
+    text = b"".join(reads)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    nsym = np.array(lens, np.uint32)
+    want = [O.compress_read(r, arrow) for r in reads]
+    out_off = np.concatenate([[0], np.cumsum([len(w) for w in want])]).astype(np.uint64)
+    d_text = ctx.to_device(np.frombuffer(text + b"\0" * 16, np.uint8))
+    d_off, d_n, d_oo = ctx.to_device(off), ctx.to_device(nsym), ctx.to_device(out_off)
+    total = int(out_off[-1])
+    d_out = ctx.to_device(np.full(total + 64, 0xEE, np.uint8))
+    ctx.pack2_encode(L.DX_ALPHA_ARROW if arrow else L.DX_ALPHA_BASES, d_text, d_off, d_n, d_n, len(lens), None, None, d_out, d_oo)
+    got = d_out.download(np.uint8, total + 64).tobytes()
+    assert got[:total] == b"".join(want)
+    assert got[total:] == b"\xee" * 64                                 # nothing written past the last payload

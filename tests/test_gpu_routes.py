@@ -1,0 +1,100 @@
+"""The routes dx_qv_encode_onepass takes under memory pressure, at a size where they matter (needs an MI355X).
+
+BASELINE configs[4] gives every GPU a 2.5 M-entry slice (125 GB of QV bytes): beside it, its output and its tokens
+there is room for only a fraction of the scratch a 1 M-entry batch gets, so the encoder works in more, smaller
+groups or, with no room at all, sizes first and in place.  Here the same pressure is put on a batch that fits a test
+(dx_set_scratch_budget scales the memory the encoder may assume down by the same factor): every route must write the
+same bytes, and those bytes are pinned to the oracle on a sample."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from dextractor_amd import _lib as L
+from dextractor_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+N, MEAN, SEED = 120_000, 10_000, 4242          # 6 GB of QV bytes; the scratch slots of the whole batch: ~5 GB
+
+
+class Corpus:
+    def __init__(self, ctx, n=N, mean=MEAN, seed=SEED, dist="lognormal"):
+        movie = "m000_000"
+        self.hlen = hlen = 1 + len(movie) + 1 + 8 + 1 + 7 + 1 + 7 + 6 + 3 + 1
+        self.lens = lens = synth.lengths(n, seed, dist, mean)
+        self.hdr4 = hdr4 = synth.headers(n, seed, lens, 0)
+        rec = hlen + 5 * (lens.astype(np.uint64) + 1)
+        self.off = off = (np.concatenate([[0], np.cumsum(rec)[:-1]]) + hlen).astype(np.uint64)
+        self.text_bytes = int(rec.sum())
+        prof = synth.pacbio_profile()
+        self.d_text = ctx.alloc(self.text_bytes + 64)
+        self.d_off, self.d_len = ctx.to_device(off), ctx.to_device(lens)
+        d_hdr4, d_lut = ctx.to_device(hdr4.reshape(-1)), ctx.to_device(prof.table().reshape(-1))
+        ctx.synth_quiva(seed, 0, n, self.d_off, self.d_len, d_hdr4, d_lut, prof.del_run, movie, self.d_text)
+        ctx.sync()
+        self.batch = ctx.qv_batch(self.d_text, self.d_off, self.d_len, n, text_bytes=self.text_bytes + 64)
+        blob, hoff, _ = api.frame_headers(hdr4, None, 0)
+        self.hoff = hoff
+        self.d_hdr, self.d_hoff = ctx.to_device(blob.copy()), ctx.to_device(hoff)
+        self.d_rec, self.d_seg = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n)
+        self.n = n
+
+    def encode(self, ctx, budget):
+        """scan + tables + one-pass encode under `budget` bytes of scratch; -> (stream bytes, route)"""
+        ctx.set_scratch_budget(budget)
+        p = ctx.qv_prescan(self.batch)
+        hist, tot = ctx.qv_hist(self.batch, p)
+        coding = api.qv_build(hist, tot, p, False)
+        ctx.qv_set_coding(coding, False)
+        cap = int(self.hoff[-1]) + api.qv_out_bound(hist, self.n, coding, False) + 4096
+        d_out = ctx.alloc(cap)
+        total = ctx.qv_encode_onepass(self.batch, self.d_hdr, self.d_hoff, self.d_seg, self.d_rec, d_out, cap)
+        info = ctx.qv_onepass_info()
+        out = d_out.download(np.uint8, total)
+        d_out.free()
+        return out, info, coding
+
+
+def test_onepass_routes_under_memory_pressure_write_the_same_stream():
+    with api.Context(0) as ctx:
+        c = Corpus(ctx)
+        ref, info0, coding = c.encode(ctx, 0)                       # no budget: by free device memory
+        assert info0["direct"] == 0 and info0["groups"] >= 1 and info0["tokens"] == 1
+        # the first 300 records against the oracle (the same entries as a small file give the same tables only if the
+        # whole corpus does: so compare record by record with the oracle's entry encoder under THESE tables)
+        rec = c.d_rec.download(np.uint64, c.n + 1)
+        text = c.d_text.download(np.uint8, int(c.off[300]))
+        oc = O.Coding()                                             # (same layout as dx_qv_coding)
+        C.memmove(C.byref(oc), C.byref(coding), C.sizeof(coding))
+        for i in range(299):
+            o, ln = int(c.off[i]), int(c.lens[i])
+            lines = np.stack([text[o + k * (ln + 1): o + k * (ln + 1) + ln] for k in range(5)])
+            want, _ = O.qv_encode_entry(oc, False, lines)
+            hl = int(c.hoff[i + 1] - c.hoff[i])
+            assert ref[int(rec[i]) + hl: int(rec[i + 1])].tobytes() == want, i
+        seen = {(info0["groups"], info0["direct"])}
+        # a half, an eighth, an eighteenth of what the slots of the whole batch take (three regions of a group's slots
+        # must fit: 6, 24, 54 groups), then nothing to speak of (no slots at all: sizes first, records in place)
+        whole = info0["groups"] * info0["region_bytes"]
+        for budget in (whole // 2 + 28 * c.n, whole // 8 + 28 * c.n, whole // 18 + 28 * c.n, 80 << 20):
+            got, info, _ = c.encode(ctx, budget)
+            assert info["avail_bytes"] == budget
+            assert len(got) == len(ref) and (got == ref).all(), info
+            seen.add((info["groups"], info["direct"]))
+        assert any(d == 1 for _, d in seen), seen                   # the sizes-first route ran ...
+        assert len({g for g, d in seen if d == 0}) >= 3, seen       # ... and three different groupings of the slot route
+        ctx.set_scratch_budget(0)
+
+
+def test_budget_env_overrides_and_route_is_reported(monkeypatch):
+    with api.Context(0) as ctx:
+        c = Corpus(ctx, n=3000, mean=4000)
+        a, info_a, _ = c.encode(ctx, 0)
+        monkeypatch.setenv("DEXGPU_SCRATCH_BUDGET", str(16 << 20))
+        b, info_b, _ = c.encode(ctx, 0)
+        assert info_b["avail_bytes"] == 16 << 20
+        assert (a == b).all()
+        small = synth.make_quiva(40, seed=5, mean=3000)
+        assert ctx.dexqv(small.text) == O.dexqv(small.text)         # the file driver under the same budget
