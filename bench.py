@@ -231,6 +231,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
             dC, dF, sC, sF = shard.agree_params(dist, (p.delChar, p.del_first), lens, entry0, sub_hist)
             p = L.QVParams(dC, sC, dF, sF)
         mine, tot = ctx.qv_hist(batch, p, entry0)
+        state["hist_mine"] = mine
         hist = mine
         if world > 1:                        # host-side sum of the 12 KB histograms (no RCCL)
             h = torch.from_numpy(np.concatenate([mine.reshape(-1), [tot]]).astype(np.int64))
@@ -306,12 +307,15 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         # writes only the five data lines of an entry; the chunk buffer is zero elsewhere and header bytes are
         # never zero, so the number of differing bytes must equal the number of header bytes exactly.
         trace("verify: decode + compare")
-        free_b = torch.cuda.mem_get_info()[0]                     # as few decode launches as the free memory allows:
-        chunk = max(1, min(n, int(max(6e9, 0.6 * free_b) // (5 * (args.mean + 1) + hlen))))   # (a launch = one pool of tasks)
         ends = np.concatenate([off[1:] - hlen, [text_bytes]]).astype(np.uint64)   # end of each entry's record
+        dec_parts = {}
+
         def decode_all():
           roundtrip, dec_ms = True, 0.0
-          chunk = max(1, min(n, int(max(6e9, 0.6 * torch.cuda.mem_get_info()[0]) // (5 * (args.mean + 1) + hlen))))
+          dec_parts.clear()
+          ctx.trim(1 | 2)                                         # the encoder's scratch and tokens go back to the device first
+          torch.cuda.empty_cache()                                # as few decode launches as the free memory allows
+          chunk = max(1, min(n, int(max(1e9, 0.5 * torch.cuda.mem_get_info()[0] - 4e9) // (5 * (args.mean + 1) + hlen))))   # (a launch = one pool of tasks)
           for a in range(0, n, chunk):
               b = min(n, a + chunk)
               lo, hi = int(off[a]) - hlen, int(ends[b - 1])
@@ -323,19 +327,23 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
                             Ptr(d_back), o_rel)
               ctx.sync(); torch.cuda.synchronize()
               kt = ctx.kernel_times()
-              dec_ms += kt.get("k_qv_decode", (0.0, 0))[0]
+              dec_ms += sum(kt.get(k, (0.0, 0))[0] for k in L.DECODE_KERNELS)
+              for k in L.DECODE_KERNELS:
+                  if k in kt:
+                      dec_parts[k] = round(dec_parts.get(k, 0.0) + kt[k][0], 3)
               ctx.profile(False)
               diff = 0
-              for c0 in range(0, hi - lo, 1 << 29):                 # compared in slices: no chunk-sized temporaries
-                  c1 = min(hi - lo, c0 + (1 << 29))
+              for c0 in range(0, hi - lo, 1 << 28):                 # compared in slices: no chunk-sized temporaries
+                  c1 = min(hi - lo, c0 + (1 << 28))
                   diff += int(torch.count_nonzero(d_back[c0:c1] != d_text[lo + c0: lo + c1]))
               roundtrip = roundtrip and diff == (b - a) * hlen
               del d_back, o_rel
           return roundtrip, dec_ms
 
         roundtrip, dec_ms = decode_all()                          # lane-per-line kernels (what a bare .dexqv gets too)
-        state["decode"] = {"kernel": "k_qv_decode_plain + k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2),
-                           "output_GBps": round(5.0 * bases / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None}
+        state["decode"] = {"kernel": "k_qv_decode_plain + k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2), "ms_by_kernel": dict(dec_parts),
+                           "output_GBps": round(5.0 * bases / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
+                           "frac_of_hbm_peak": round((5.0 * bases + float(state["total"])) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None}
         if not args.twopass:
             # ... and with the encoder's group index (dx_qv_subindex): one more, untimed, encode that leaves the index,
             # then the plain lines are decoded a wavefront per line (k_qv_decode_sub)
@@ -353,7 +361,8 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
                 roundtrip = roundtrip and ok2
                 L64 = lens.astype(np.int64)
                 words_ = 4 * ((((L64 + 15) >> 4) + 3) >> 2) + 3   # plain lines: a byte per 16 symbols; + a word per 8 tokens of the run-coded lines
-                state["decode_indexed"] = {"kernel": "k_qv_decode_sub + k_qv_decode_runs + k_qv_decode + k_qv_decode_tags", "ms": round(dec2_ms, 2),
+                state["decode_indexed"] = {"kernel": "k_qv_decode_sub + k_qv_decode_runs + k_qv_decode + k_qv_decode_tags", "ms": round(dec2_ms, 2), "ms_by_kernel": dict(dec_parts),
+                                           "frac_of_hbm_peak": round((5.0 * bases + float(state["total"])) / (dec2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec2_ms else None,
                                            "output_GBps": round(5.0 * bases / (dec2_ms * 1e-3) / 1e9, 1) if dec2_ms else None,
                                            "index_bytes_without_run_groups": int(4 * words_.sum()),
                                            "bit_exact": bool(ok2),
@@ -408,29 +417,64 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
 
     value = 5.0 * all_bases * args.steps / dt / 1e9
 
-    # ---- roofline of the dominant kernel (per-launch algorithmic bytes / measured launch time) -----
-    algo = {"k_qv_hist": 4.0 * bases, "k_qv_sizes": 4.0 * bases,
-            "k_qv_encode": 5.0 * bases + state["total"]}
-    kern = {k: {"ms_avg": ms / cnt, "launches": cnt} for k, (ms, cnt) in times.items()}
-    for k, b in algo.items():
-        if k in kern:
-            per_step = max(1, round(kern[k]["launches"] / args.steps))   # the one-pass encoder runs in groups
-            algo[k] = b / per_step
-            kern[k]["launches_per_step"] = per_step
-            kern[k]["algo_bytes"] = algo[k]
-            kern[k]["GBps"] = algo[k] / (kern[k]["ms_avg"] * 1e-3) / 1e9
-    dom = max(algo, key=lambda k: kern.get(k, {}).get("ms_avg", 0.0) * kern.get(k, {}).get("launches_per_step", 1))
-    traffic = read_traffic(args.traffic_file, "dexqv", dom, dict(entries=n, mean=args.mean, dist=args.dist),
-                           kern[dom]["launches_per_step"])
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": round(kern[dom]["GBps"], 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algo_bytes_per_launch": algo[dom]}
-    # whole pipeline against the same roofline: (4 + 5) B/base read + output written, over the step's
-    # wall time (kernels overlap in the one-pass encoder, so their durations do not add up)
+    # ---- roofline: the WHOLE STEP against HBM -- (4 B hist + 5 B encode) per base read + the output written,
+    # over the step's wall time -- with every kernel of the step beside it: its share of the 8(d) bytes, the bytes it
+    # must move IN THIS DESIGN (hist: 5 lines read + tokens written; fast encoder: tokens + plain lines read + output
+    # written; compaction: nothing -- it is pure overhead), its measured time and its PMC traffic (profiles/traffic.json).
     step_s = dt / args.steps
-    pipe = {"algo_bytes": 9.0 * bases + state["total"], "step_ms": round(step_s * 1e3, 3),
+    out_b = float(state["total"])
+    cd, prm = state["coding"], state["params"]
+    hist_mine = state.get("hist_mine")
+    tok = 0.0                                              # tokens of the run-coded lines (2 bytes each, written and read once)
+    if hist_mine is not None and not args.twopass and os.environ.get("DEXGPU_NO_TOKENS") is None:
+        if prm.delChar >= 0:
+            tok += float(hist_mine[0].sum() - hist_mine[0][prm.delChar])
+        if prm.subChar >= 0:
+            tok += float(hist_mine[3].sum() - hist_mine[3][prm.subChar])
+    tok_lines = (1 if prm.delChar >= 0 else 0) + (1 if cd.subChar >= 0 else 0)           # lines the encoder takes from tokens
+    text_lines_enc = 5 - (2 if prm.delChar >= 0 else 0) - (1 if cd.subChar >= 0 else 0) if tok else 5   # (del tokens carry the tags)
+    spec = {   # kernel id -> (8(d) bytes per step, design bytes per step)
+        "k_qv_hist": (4.0 * bases, (5.0 if tok and prm.delChar >= 0 else 4.0) * bases + 2.0 * tok),
+        "k_qv_encode": (5.0 * bases + out_b, 2.0 * tok + text_lines_enc * bases + out_b),
+        "k_qv_encode_text": ((5.0 * bases + out_b) if args.twopass or not tok else 0.0, (5.0 * bases + out_b) if args.twopass or not tok else 0.0),
+        "k_qv_sizes": (0.0, 0.0), "k_qv_compact": (0.0, 0.0), "k_scan": (0.0, 0.0), "k_qv_prescan": (0.0, 0.0),
+    }
+    if not tok and not args.twopass:                       # no tokens: the text-reading kernel is the encoder
+        spec["k_qv_encode"] = (0.0, 0.0)
+    kern, per_kernel = {}, {}
+    for k, (ms, cnt) in times.items():
+        kern[k] = {"ms_avg": ms / cnt, "launches": cnt}
+        if k not in spec:
+            continue
+        lps = max(1, round(cnt / args.steps))
+        ms_step = ms / args.steps
+        a8d, design = spec[k]
+        tr = read_traffic(args.traffic_file, "dexqv", k, dict(entries=n, mean=args.mean, dist=args.dist), lps, per_step=True)
+        per_kernel[k] = {"ms_per_step": round(ms_step, 3), "launches_per_step": lps, "ms_avg_launch": round(ms / cnt, 4),
+                         "algo_bytes_8d_per_step": a8d, "design_bytes_per_step": design, "traffic_bytes_per_step": tr,
+                         "design_GBps": round(design / (ms_step * 1e-3) / 1e9, 1) if ms_step and design else None,
+                         "traffic_GBps": round(tr / (ms_step * 1e-3) / 1e9, 1) if ms_step and tr else None}
+    step_algo = 9.0 * bases + out_b
+    step_traffic = None
+    if per_kernel and all(v["traffic_bytes_per_step"] is not None for k, v in per_kernel.items() if spec[k][1] or k == "k_qv_compact"):
+        step_traffic = sum(v["traffic_bytes_per_step"] or 0.0 for v in per_kernel.values())
+    dom = max((k for k in per_kernel if spec[k][0]), key=lambda k: per_kernel[k]["ms_per_step"])
+    dk = per_kernel[dom]
+    dom_ms_launch = dk["ms_per_step"] / dk["launches_per_step"]
+    roofline = {"kernel": "whole step (k_qv_prescan, k_qv_hist, host tables, k_qv_encode_fast + k_qv_compact per group)",
+                "bound": "hbm", "achieved": round(step_algo / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(step_algo / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
+                "algo_bytes_per_step": step_algo,
+                "formula": "SURVEY 8(d): (4 B/base histogram pass + 5 B/base encode pass + output bytes) / step wall time / 8 TB/s",
+                "dominant_kernel": {"kernel": dom, "ms_avg_launch": round(dom_ms_launch, 4),
+                                    "algo_bytes_8d_per_launch": dk["algo_bytes_8d_per_step"] / dk["launches_per_step"],
+                                    "achieved": round(dk["algo_bytes_8d_per_step"] / (dk["ms_per_step"] * 1e-3) / 1e9, 1),
+                                    "frac": round(dk["algo_bytes_8d_per_step"] / (dk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "traffic": (dk["traffic_bytes_per_step"] / dk["launches_per_step"]) if dk["traffic_bytes_per_step"] else None},
+                "per_kernel": per_kernel}
+    pipe = {"algo_bytes": step_algo, "step_ms": round(step_s * 1e3, 3),
             "kernel_ms_sum": round(sum(kern[k]["ms_avg"] * kern[k]["launches"] / args.steps for k in kern if k != "k_synth"), 3),
-            "GBps": round((9.0 * bases + state["total"]) / step_s / 1e9, 1),
+            "GBps": round(step_algo / step_s / 1e9, 1),
             "encoder": "two pass (sizes, encode)" if args.twopass else "one pass (scratch slots, compaction on a second stream)"}
     pipe["frac"] = round(pipe["GBps"] / HBM_PEAK_GBS, 4)
 
@@ -474,9 +518,9 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
     return line
 
 
-def read_traffic(path, workload, kernel, want, launches_per_step=1):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json), when it was
-    collected on the same workload shape; None otherwise."""
+def read_traffic(path, workload, kernel, want, launches_per_step=1, per_step=False):
+    """HBM bytes per launch (per_step: per bench step) of the kernels timed under bench id `kernel`, from the
+    committed PMC summary (profiles/traffic.json), when it was collected on the same workload shape; None otherwise."""
     try:
         tf = json.load(open(path))
         tf = tf.get("workloads", {}).get(workload, tf if workload == "dexqv" else {})
@@ -484,7 +528,8 @@ def read_traffic(path, workload, kernel, want, launches_per_step=1):
             return None
         if tf.get("launches_per_step", {}).get(kernel, 1) != launches_per_step:
             return None                                   # profile taken with another grouping
-        return tf["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+        v = tf["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
+        return None if v is None else (v * launches_per_step if per_step else v)
     except Exception:
         return None
 

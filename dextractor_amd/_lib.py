@@ -19,7 +19,9 @@ DX_ALPHA_BASES, DX_ALPHA_ARROW = 0, 1
 DX_LETTERS_LOWER, DX_LETTERS_UPPER, DX_LETTERS_ARROW = 0, 1, 2
 DX_DEL, DX_INS, DX_MRG, DX_SUB, DX_DRUN, DX_SRUN = range(6)
 KERNELS = ["k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
-           "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact"]
+           "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact", "k_qv_encode_text",
+           "k_qv_decode_sub", "k_qv_decode_runs", "k_qv_decode_plain", "k_qv_decode_tags"]
+DECODE_KERNELS = ["k_qv_decode", "k_qv_decode_sub", "k_qv_decode_runs", "k_qv_decode_plain", "k_qv_decode_tags"]
 
 
 class QVBatch(C.Structure):
@@ -106,6 +108,7 @@ SIGNATURES = {
     "dx_qv_encode_onepass_end": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "dx_qv_onepass_info": (C.c_int, [_P, C.POINTER(OnepassInfo)]),
     "dx_set_scratch_budget": (C.c_int, [_P, C.c_uint64]),
+    "dx_trim": (C.c_int, [_P, C.c_int]),
     "dx_qv_out_bound": (C.c_uint64, [C.POINTER(HIST), C.c_uint64, C.POINTER(QVCoding), C.c_int]),
     "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
     "dx_qv_walk": (C.c_int, [_P, C.c_size_t, _P]),

@@ -271,6 +271,10 @@ class Context:
         self._chk(self.lib.dx_qv_onepass_info(self.h, C.byref(o)))
         return {k: int(getattr(o, k)) for k, _ in L.OnepassInfo._fields_ if k != "reserved"}
 
+    def trim(self, what=7):
+        """dx_trim: give the context's scratch (1), token slots (2), group index (4) back to the device."""
+        self._chk(self.lib.dx_trim(self.h, int(what)))
+
     def set_scratch_budget(self, nbytes: int):
         self._chk(self.lib.dx_set_scratch_budget(self.h, int(nbytes)))
 

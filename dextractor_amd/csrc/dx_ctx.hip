@@ -135,6 +135,34 @@ extern "C" void dx_close(dx_ctx *ctx)
   delete ctx;
 }
 
+// Gives back what the context keeps between calls to save allocations: the scratch regions of the one-pass encoder,
+// the token slots of the histogram pass, the group index.  (The code tables and everything a later call needs to be
+// correct stay; the next call that wants one of the buffers allocates it again.)
+extern "C" int dx_trim(dx_ctx *ctx, int what)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (ctx->op.pending)
+    return dx_fail(ctx, DX_E_ARG, "dx_trim: an encode has begun in this context: end it first (dx_qv_encode_onepass_end)");
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->side));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (what & DX_TRIM_SCRATCH)
+    { (void) hipFree(ctx->d_scratch); ctx->d_scratch = NULL; ctx->scratch_bytes = 0;
+      (void) hipFree(ctx->d_hscr);    ctx->d_hscr = NULL;    ctx->hscr_bytes = 0;
+    }
+  if (what & DX_TRIM_TOKENS)
+    { (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info);
+      (void) hipFree(ctx->tk.count);
+      memset(&ctx->tk, 0, sizeof(ctx->tk));
+    }
+  if (what & DX_TRIM_INDEX)
+    { const int want = ctx->sx.want;
+      (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room); (void) hipFree(ctx->sx.none);
+      memset(&ctx->sx, 0, sizeof(ctx->sx));
+      ctx->sx.want = want;
+    }
+  return DX_OK;
+}
+
 extern "C" int dx_set_stream(dx_ctx *ctx, void *hip_stream)
 { if (ctx == NULL) return DX_E_ARG;
   ctx->stream = (hipStream_t) hip_stream;
@@ -341,7 +369,8 @@ int dx_grid_waves(dx_ctx *ctx, uint64_t n_units, int waves_per_cu)
 
 static const char *k_names[DX_K_COUNT] =
   { "k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
-    "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact" };
+    "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact", "k_qv_encode_text",
+    "k_qv_decode_sub", "k_qv_decode_runs", "k_qv_decode_plain", "k_qv_decode_tags" };
 
 extern "C" const char *dx_kernel_name(int kernel)
 { return (kernel >= 0 && kernel < DX_K_COUNT) ? k_names[kernel] : "?"; }

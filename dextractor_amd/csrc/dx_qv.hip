@@ -1819,7 +1819,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
-  DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
+  DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
             a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL },
             (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0,
             sub_sink{ NULL, NULL, NULL });
@@ -2027,7 +2027,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       dx_prof_end_on(ctx, A);
       if (odd)
         { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
-          dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
+          dx_prof_begin_on(ctx, DX_K_QV_ENCODE_TEXT, A);
           hipLaunchKernelGGL(k_qv_encode, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * ENC_WAVES)),
                              dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
                              (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
@@ -2258,7 +2258,7 @@ layout:
       if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
         { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode, dx_grid_waves(ctx, work, 4 * ENC_WAVES), DX_BLOCK,
+          DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, work, 4 * ENC_WAVES), DX_BLOCK,
                     ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) NULL, (const uint32_t *) NULL,
                     (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g,
                     fast ? (const uint32_t *) ctx->tk.list : (const uint32_t *) NULL,

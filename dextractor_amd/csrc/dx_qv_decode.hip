@@ -1230,7 +1230,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
           uint64_t sb = (n + DS_NWAVE - 1) / DS_NWAVE;
           if (sb > cap * (nk <= 2 ? 2 : 1)) sb = cap * (nk <= 2 ? 2 : 1);       // two workgroups per CU fit with <= 2 tables
 #define SUB_LAUNCH(NK)                                                                                        \
-          DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_sub<NK>, (int) sb, DS_BLOCK, a, (const uint16_t *) ctx->d_dec,   \
+          DX_LAUNCH(ctx, DX_K_QV_DEC_SUB, k_qv_decode_sub<NK>, (int) sb, DS_BLOCK, a, (const uint16_t *) ctx->d_dec,   \
                     (const uint32_t *) ctx->d_long, d_next3, plain, (const uint32_t *) ctx->sx.idx,            \
                     (const uint64_t *) (ctx->sx.off + first))
           if (nk == 1)      SUB_LAUNCH(1);
@@ -1250,11 +1250,11 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
               uint64_t rb = (n + DR_NWAVE - 1) / DR_NWAVE;
               if (rb > cap) rb = cap;
               if (runs == 9u)
-                DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_runs<2>, (int) rb, DR_BLOCK, a, (const uint16_t *) ctx->d_dec,
+                DX_LAUNCH(ctx, DX_K_QV_DEC_RUNS, k_qv_decode_runs<2>, (int) rb, DR_BLOCK, a, (const uint16_t *) ctx->d_dec,
                           (const uint32_t *) ctx->d_long, ctx->d_status, d_next4, runs, (const uint32_t *) ctx->sx.idx,
                           (const uint64_t *) (ctx->sx.off + first));
               else
-                DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_runs<1>, (int) rb, DR_BLOCK, a, (const uint16_t *) ctx->d_dec,
+                DX_LAUNCH(ctx, DX_K_QV_DEC_RUNS, k_qv_decode_runs<1>, (int) rb, DR_BLOCK, a, (const uint16_t *) ctx->d_dec,
                           (const uint32_t *) ctx->d_long, ctx->d_status, d_next4, runs, (const uint32_t *) ctx->sx.idx,
                           (const uint64_t *) (ctx->sx.off + first));
               skip_idx = ctx->sx.idx; skip_off = ctx->sx.off + first; skip_kinds = runs;
@@ -1264,7 +1264,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   if (plain)
     { uint64_t pb = (4 * ((n + 63) / 64) + DP_NWAVE - 1) / DP_NWAVE;
       if (pb > cap * DP_WG_PER_CU) pb = cap * DP_WG_PER_CU;
-      DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_plain, (int) pb, DP_BLOCK, a, (const uint16_t *) ctx->d_dec,
+      DX_LAUNCH(ctx, DX_K_QV_DEC_PLAIN, k_qv_decode_plain, (int) pb, DP_BLOCK, a, (const uint16_t *) ctx->d_dec,
                 (const uint32_t *) ctx->d_long, d_next2, plain);
     }
   if (plain_kinds != 15u)
@@ -1272,7 +1272,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
               (const uint32_t *) ctx->d_long, ctx->d_status, d_next, 15u & ~plain_kinds,
               (const uint32_t *) skip_idx, (const uint64_t *) skip_off, skip_kinds, (const uint32_t *) ctx->sx.none,
               ((15u & ~plain_kinds) & 6u) == 0u ? (uint32_t) (2 * ((n + 63) / 64)) : 0u);
-  DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a,
+  DX_LAUNCH(ctx, DX_K_QV_DEC_TAGS, k_qv_decode_tags, dx_grid_waves(ctx, n, 16), DX_BLOCK, a,
             (skip_kinds & 1u) ? (const uint32_t *) skip_idx : (const uint32_t *) NULL, (const uint64_t *) skip_off);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -69,7 +69,10 @@ int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes);
 /* Per-kernel device time, measured with HIP events on the context's stream around every launch
  * while profiling is enabled.  Kernel ids: */
 enum { DX_K_PACK2_ENC = 0, DX_K_PACK2_DEC, DX_K_QV_PRESCAN, DX_K_QV_HIST, DX_K_QV_SIZES, DX_K_SCAN,
-       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_INDEX, DX_K_QV_COMPACT, DX_K_COUNT };
+       DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_INDEX, DX_K_QV_COMPACT,
+       DX_K_QV_ENCODE_TEXT,                       /* the encoder that reads the text (two-pass path; entries without usable tokens) */
+       DX_K_QV_DEC_SUB, DX_K_QV_DEC_RUNS, DX_K_QV_DEC_PLAIN, DX_K_QV_DEC_TAGS,   /* DX_K_QV_DECODE: the generic lane-per-line decoder */
+       DX_K_COUNT };
 int         dx_profile(dx_ctx *ctx, int enable);                  /* enabling resets the counters */
 int         dx_profile_get(dx_ctx *ctx, int kernel, double *ms_total, uint64_t *launches);  /* syncs */
 const char *dx_kernel_name(int kernel);
@@ -295,6 +298,16 @@ int dx_qv_onepass_info(const dx_ctx *ctx, dx_onepass_info *out);
  * sharded over several GPUs gives every rank the same one.  The environment variable DEXGPU_SCRATCH_BUDGET (bytes)
  * overrides both.                                                                                              */
 int dx_set_scratch_budget(dx_ctx *ctx, uint64_t bytes);
+
+/* Gives device memory the context keeps between calls back to the device (it is allocated again when next needed):
+ * DX_TRIM_SCRATCH the scratch regions of dx_qv_encode_onepass and dx_qv_hist, DX_TRIM_TOKENS the token slots the
+ * histogram pass leaves for the encoder (the next encode without a fresh dx_qv_hist then reads the text),
+ * DX_TRIM_INDEX the group index of dx_qv_subindex (the next decode then takes the lane-per-line kernels).       */
+#define DX_TRIM_SCRATCH 1
+#define DX_TRIM_TOKENS  2
+#define DX_TRIM_INDEX   4
+#define DX_TRIM_ALL     7
+int dx_trim(dx_ctx *ctx, int what);
 
 /* Host helper sizing d_out for dx_qv_encode_onepass: an upper bound of the bytes the batch's n entries
  * encode to (framing bytes not included), from the batch's own raw histograms (what dx_qv_hist added

@@ -35,7 +35,14 @@ def test_bench_line_single_gpu():
     assert all(k in d for k in FIELDS)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "GB/s" and d["dtype"] == "u8"
     assert d["roundtrip_bit_exact"] is True and d["decode_indexed"]["bit_exact"] is True
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1
+    # the whole step -- (4 + 5) bytes per base read + the output written -- over the step's wall time
+    bases, out = 30000 * 10000, d["config"]["output_bytes"]
+    assert abs(r["algo_bytes_per_step"] - (9 * bases + out)) < 1 and abs(r["achieved"] - (9 * bases + out) / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * r["achieved"]
+    assert r["dominant_kernel"]["kernel"] in ("k_qv_hist", "k_qv_encode") and 0 < r["dominant_kernel"]["frac"] < 1
+    assert r["per_kernel"]["k_qv_compact"]["design_bytes_per_step"] == 0          # pure overhead, priced as such
+    assert d["encoder_route"]["groups"] >= 1 and d["encoder_route"]["direct"] == 0
     assert abs(d["value"] - 5 * 30000 * 10000 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]
 
 
