@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--with-index", action="store_true",
                     help="dexqv: the timed steps also write the group index (dx_qv_subindex) -- what it costs the encoder")
     ap.add_argument("--lossy", action="store_true")
+    ap.add_argument("--del-run-p", type=float, default=0.85, help="dexqv: share of the run character in the deletion QV line")
+    ap.add_argument("--sub-run-p", type=float, default=0.80, help="dexqv: share of the run character in the substitution QV line")
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--cpu-sample-entries", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -153,6 +155,22 @@ def main():
                                                               "roundtrip_bit_exact", "pipeline", "decode", "decode_indexed")}
         except Exception as e:                               # an extra must never cost the headline line
             extra["dexqv_" + a2.dist] = {"error": repr(e)}
+        # run density: the tokens of the run-coded lines hold runs up to 126 and longer ones by exception, so the
+        # encoder's route must not depend on how long the runs are (share of entries on the text-reading encoder reported)
+        sweep = {}
+        for pr in (0.95, 0.99):
+            a3 = argparse.Namespace(**vars(args))
+            a3.del_run_p, a3.sub_run_p, a3.steps, a3.warmup = pr, pr, 3, 1
+            trace(f"extra: dexqv, run density {pr}")
+            try:
+                l3 = dexqv_bench(a3, 0, 1, local, cpu=False, front=False, index_decode=False)
+                sweep[str(pr)] = {"value": l3["value"], "unit": "GB/s", "ms_per_step": l3["ms_per_step"], "ratio": l3["config"]["ratio"],
+                                  "roundtrip_bit_exact": l3["roundtrip_bit_exact"],
+                                  "entries_on_text_encoder": l3["encoder_route"].get("text_entries"),
+                                  "vs_default_density": round(l3["value"] / line["value"], 3)}
+            except Exception as e:
+                sweep[str(pr)] = {"error": repr(e)}
+        extra["dexqv_run_density"] = sweep
         for w in ("dexta", "dexar"):
             trace(f"extra: {w}")
             try:
@@ -166,7 +184,7 @@ def main():
 # ------------------------------------------------------------------------------------------------
 #  dexqv (BASELINE configs[3] at N=1, configs[4] at N>1)
 # ------------------------------------------------------------------------------------------------
-def dexqv_bench(args, rank, world, local, cpu=True, front=True):
+def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=True):
     import torch
     import torch.distributed as dist
     if world > 1 and not dist.is_initialized():
@@ -196,7 +214,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
     off = (np.concatenate([[0], np.cumsum(rec_bytes)[:-1]]) + hlen).astype(np.uint64)
     text_bytes = int(rec_bytes.sum())
     bases = int(lens.astype(np.uint64).sum())
-    prof = synth.pacbio_profile()
+    prof = synth.pacbio_profile(args.del_run_p, args.sub_run_p)
 
     d_text = torch.empty(text_bytes + 64, dtype=torch.uint8, device="cuda")
     t_off, t_len = torch.from_numpy(off.view(np.int64)).cuda(), torch.from_numpy(lens.view(np.int32)).cuda()
@@ -344,7 +362,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         state["decode"] = {"kernel": "k_qv_decode_plain + k_qv_decode + k_qv_decode_tags", "ms": round(dec_ms, 2), "ms_by_kernel": dict(dec_parts),
                            "output_GBps": round(5.0 * bases / (dec_ms * 1e-3) / 1e9, 1) if dec_ms else None,
                            "frac_of_hbm_peak": round((5.0 * bases + float(state["total"])) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_ms else None}
-        if not args.twopass:
+        if not args.twopass and index_decode:
             # ... and with the encoder's group index (dx_qv_subindex): one more, untimed, encode that leaves the index,
             # then the plain lines are decoded a wavefront per line (k_qv_decode_sub)
             try:
@@ -492,6 +510,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True):
         "config": {"workload": f"dexqv 5-stream Huffman encode, {n} x {args.mean} .quiva per GPU "
                                f"({args.dist} lengths, {which}), HBM-resident",
                    "entries_per_gpu": n, "mean_len": args.mean, "lossy": bool(args.lossy),
+                   "run_density": {"del": args.del_run_p, "sub": args.sub_run_p},
                    "input_bytes_per_gpu": 5 * bases, "text_image_bytes_per_gpu": text_bytes,
                    "output_bytes": all_out, "ratio": round(5.0 * all_bases / all_out, 3),
                    "sharding": "contiguous entry ranges of one file (host-side scan state + 12 KB histogram sum, gloo; no RCCL)"

@@ -271,11 +271,19 @@ __device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool 
 // each -- bits [0,2) the 2-bit code of the deletion tag under the symbol (Pack_Tag + Number_Read,
 // QV.c:810-819; 0 for the substitution line), [2,9) the symbol, [9,16) the run in front of it -- into a
 // slot of len/2 + 64 tokens per entry, with the token count and the run left open at the line's end.
-// k_qv_encode_fast then walks dense token arrays instead of the text.  An entry whose line has a symbol
-// >= 128, a run >= 127 or more tokens than its slot holds is marked unusable and encoded from the text
-// by the generic kernel, as is everything when the tokens were made for another batch or scan state.
-#define TOK_RUN_MAX  127u                      // run field saturates here: the entry goes to the generic kernel
+// k_qv_encode_fast then walks dense token arrays instead of the text.  A run of 127 or more does not fit
+// the token's 7 bits: the field then holds 127 and the run's length goes into the line's EXCEPTION LIST,
+// (token index, run length) pairs of 32-bit words in token order, growing backwards from the end of the
+// line's slot (record j at words [-2j - 2], [-2j - 1] from the slot's end).  At most 0.3 % of a line's
+// symbols can be such tokens (density d: (1 - d) d^127), so the list is short and searched by bisection.
+// An entry whose line has a symbol >= 128 or more tokens (and exceptions) than its slot holds is marked
+// unusable and encoded from the text by the generic kernel, as is everything when the tokens were made
+// for another batch or scan state.
+#define TOK_RUN_MAX  127u                      // run field 127: the run's length is in the exception list
 #define TOK_BAD      0x80000000u               // info word: the stream's tokens are unusable
+#define TOK_INFO     8u                        // info words per entry: tokens of del | TOK_BAD, of sub | TOK_BAD, run open at the end
+                                               // of del, of sub, exceptions of del, of sub, 2 spare
+#define TOK_XMARGIN  40u                       // token slots kept free for the exceptions one step can add (<= 9 runs of >= 127 in 1 KiB)
 
 struct tok_sink
 { uint16_t       *del, *sub;                   // NULL del: no tokens wanted
@@ -285,11 +293,21 @@ struct tok_sink
   uint32_t       *list;                        // ... and their indices in the batch (any order)
 };
 
-__host__ __device__ __forceinline__ uint32_t tok_room(uint32_t L) { return (((L >> 1) + 64u) + 7u) & ~7u; }
+__host__ __device__ __forceinline__ uint32_t tok_room(uint32_t L) { return (((L >> 1) + 64u + TOK_XMARGIN) + 7u) & ~7u; }
+
+// run length of exception token `idx` of a line: bisection over its nx records (ascending token index)
+__device__ __forceinline__ uint32_t tok_exception(const uint32_t *slot_end, uint32_t nx, uint32_t idx)
+{ uint32_t lo = 0, hi = nx;
+  while (lo < hi)
+    { const uint32_t mid = (lo + hi) >> 1;
+      if (*(slot_end - 2 * (int) mid - 2) < idx) lo = mid + 1; else hi = mid;
+    }
+  return *(slot_end - 2 * (int) lo - 1);
+}
 
 // does this entry have to be encoded from the text (generic kernel)?  info: the n x 4 words k_qv_hist left
 __device__ __forceinline__ bool tok_unusable(const uint32_t *info, uint64_t r, int delChar, int subChar)
-{ return (delChar >= 0 && (info[4 * r] & TOK_BAD)) || (subChar >= 0 && (info[4 * r + 1] & TOK_BAD)); }
+{ return (delChar >= 0 && (info[TOK_INFO * r] & TOK_BAD)) || (subChar >= 0 && (info[TOK_INFO * r + 1] & TOK_BAD)); }
 
 // one step of a run-coded stream: non-run symbols and the run before each (QV.c:709-724); the run
 // character itself is counted with popcounts instead of LDS atomics (it is 80-85 % of the stream).
@@ -298,7 +316,7 @@ __device__ __forceinline__ bool tok_unusable(const uint32_t *info, uint64_t r, i
 __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c, int valid, uint32_t sv, uint32_t rc,
                                                uint32_t &C, uint32_t &nrun, uint32_t (*hs)[HCOLS], uint32_t *slow_s,
                                                uint32_t (*hr)[HCOLS], uint32_t *slow_r, bool count,
-                                               uint16_t *tok, uint32_t &ntok, uint32_t cap, uint32_t &bad,
+                                               uint16_t *tok, uint32_t &ntok, uint32_t cap, uint32_t &bad, uint32_t &nexc,
                                                const uint8_t *tagchunk, const uint8_t *tagcode)
 { const int      lane  = lane_id();
   const uint32_t col   = (uint32_t) lane & (HCOLS - 1);
@@ -306,8 +324,8 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
   nrun += sv - total;                                            // wave-uniform
   bool emit = false;
   if (tok != NULL && !bad)
-    { emit = ntok + total <= cap;
-      if (!emit) bad = 1;                                        // more tokens than the slot holds
+    { emit = ntok + total + 4u * nexc + TOK_XMARGIN <= cap;
+      if (!emit) bad = 1;                                        // more tokens (and exceptions) than the slot holds
     }
   uint32_t odd = 0;
   // Two tokens per lane per round (i and i + 64): the look-ups of a token hang on each other (position ->
@@ -354,9 +372,23 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
             if (emit)
               { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9);
                 tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;
-                odd |= (x[k] >= 128u || run[k] >= TOK_RUN_MAX) ? 1u : 0u;
+                odd |= x[k] >= 128u ? 1u : 0u;
               }
           }
+      if (emit && !fastbins && __any((on[0] && run[0] >= TOK_RUN_MAX) || (on[1] && run[1] >= TOK_RUN_MAX)))   // rare: exception records, in token order
+        { uint32_t *xend = (uint32_t *) (tok + cap);
+          #pragma unroll
+          for (int k = 0; k < 2; k++)
+            { const bool     lg = on[k] && run[k] >= TOK_RUN_MAX;
+              const uint64_t m  = __ballot(lg);
+              if (lg)
+                { const uint32_t j = nexc + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+                  *(xend - 2 * (int) j - 2) = ntok + i0 + 64u * (uint32_t) k + (uint32_t) lane;
+                  *(xend - 2 * (int) j - 1) = run[k];
+                }
+              nexc += (uint32_t) __popcll(m);
+            }
+        }
     }
   if (emit)
     { ntok += total;
@@ -414,7 +446,7 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
       const bool over = can_overread(a, p4, L);       // p4 is the last line of the entry
       uint32_t C0 = 0, C4 = 0, n0 = 0, n4 = 0;
       uint16_t *tk0 = NULL, *tk4 = NULL;
-      uint32_t  nt0 = 0, nt4 = 0, cap = 0, bad0 = 0, bad4 = 0;
+      uint32_t  nt0 = 0, nt4 = 0, cap = 0, bad0 = 0, bad4 = 0, nx0 = 0, nx4 = 0;
       if (toks)
         { const uint64_t t0 = ts.off[r];
           cap = (uint32_t) (ts.off[r + 1] - t0);
@@ -442,11 +474,11 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           if (drun)
             { if (tags) *(u32x4 *) (tchunk + 16 * lane) = t1;    // (run_collect's barrier orders it before the look-ups)
               hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.sym[DX_DEL], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN],
-                             dcnt, tk0, nt0, cap, bad0, tags ? tchunk : (const uint8_t *) NULL, s_tagcode);
+                             dcnt, tk0, nt0, cap, bad0, nx0, tags ? tchunk : (const uint8_t *) NULL, s_tagcode);
             }
           else      hist_plain_step(c0, valid, full, H.sym[DX_DEL], H.slow[DX_DEL]);
           if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.sym[DX_SUB], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
-                                   scnt, tk4, nt4, cap, bad4, (const uint8_t *) NULL, s_tagcode);
+                                   scnt, tk4, nt4, cap, bad4, nx4, (const uint8_t *) NULL, s_tagcode);
           else      hist_plain_step(c4, valid, full, H.sym[DX_SUB], H.slow[DX_SUB]);
           hist_plain_step(c2, valid, full, H.sym[DX_INS], H.slow[DX_INS]);
           hist_plain_step(c3, valid, full, H.sym[DX_MRG], H.slow[DX_MRG]);
@@ -463,11 +495,13 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
         }
       if (toks)
         { if (lane == 0)
-            { uint32_t *w = ts.info + 4 * r;
+            { uint32_t *w = ts.info + TOK_INFO * r;
               w[0] = nt0 | ((bad0 || !drun) ? TOK_BAD : 0u);
               w[1] = nt4 | ((bad4 || !srun) ? TOK_BAD : 0u);
               w[2] = C0;
               w[3] = C4;
+              w[4] = nx0;
+              w[5] = nx4;
             }
           if (((drun && bad0) || (srun && bad4)) && lane == 0)      // rare: the generic kernel works through this list
             ts.list[atomicAdd(ts.unusable, 1ull)] = (uint32_t) r;
@@ -1547,7 +1581,7 @@ static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params
     { (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
       ctx->tk.off = NULL; ctx->tk.info = NULL; ctx->tk.count = NULL; ctx->tk.list = NULL; ctx->tk.cap_entries = 0;
       if (hipMalloc((void **) &ctx->tk.off, (n + 1) * 8) != hipSuccess ||
-          hipMalloc((void **) &ctx->tk.info, n * 16) != hipSuccess ||
+          hipMalloc((void **) &ctx->tk.info, n * 4 * TOK_INFO) != hipSuccess ||
           hipMalloc((void **) &ctx->tk.count, 8 + n * 4) != hipSuccess)
         { (void) hipGetLastError(); return false; }
       ctx->tk.list = (uint32_t *) (ctx->tk.count + 1);
@@ -1867,7 +1901,7 @@ void k_sub_rooms(const uint32_t *len, uint64_t n, const uint32_t *info /* token 
   if (i >= n) return;
   uint32_t passes = 0;                                   // group words only where k_qv_encode_fast will write them
   if (info != NULL)
-    { const uint32_t d = info[4 * i], s = info[4 * i + 1];
+    { const uint32_t d = info[TOK_INFO * i], s = info[TOK_INFO * i + 1];
       passes = ((d & TOK_BAD) ? 0u : run_passes(d)) + ((s & TOK_BAD) ? 0u : run_passes(s));
     }
   room[i] = run_base(len[i]) + 3u + 64u * passes;
@@ -1987,7 +2021,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
       const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL, ctx->sx.none };
-      const tok_src   tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
+      const tok_src   tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
       rc = DX_E_HIP;
       if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
       dx_prof_begin_on(ctx, DX_K_QV_SIZES, B);
@@ -2000,7 +2034,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
           hipLaunchKernelGGL(k_qv_sizes, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * SIZES_WAVES)),
                              dim3(DX_BLOCK), 0, B, ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz,
                              (const uint32_t *) ctx->tk.list, (const unsigned long long *) ctx->tk.count, g0,
-                             (const uint32_t *) (ctx->tk.info + 4 * g0));
+                             (const uint32_t *) (ctx->tk.info + TOK_INFO * g0));
           dx_prof_end_on(ctx, B);
         }
       dx_prof_begin_on(ctx, DX_K_SCAN, B);
@@ -2032,7 +2066,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
                              dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
                              (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
                              d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, (const uint32_t *) ctx->tk.list,
-                             (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + 4 * g0), out_cap, sx_g);
+                             (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), out_cap, sx_g);
           dx_prof_end_on(ctx, A);
         }
       if (hipGetLastError() != hipSuccess) break;
@@ -2053,6 +2087,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
   if (total) *total = tot;
   ctx->route.groups = 0; ctx->route.direct = 1; ctx->route.tokens = 1; ctx->route.region_bytes = 0;
   ctx->route.scratch_bytes = ctx->scratch_bytes; ctx->route.token_bytes = 4ull * ctx->tk.cap_tokens;
+  ctx->route.text_entries = ctx->tk.unusable;
   if (tot > out_cap || (st & 8u))
     return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
                    (unsigned long long) tot, (unsigned long long) out_cap);
@@ -2242,7 +2277,7 @@ layout:
         DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 3) & 7], 0));    // the region is free once its last tenant has been copied out
       const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 };
       if (fast)                                          // entries with usable tokens: walked from the tokens
-        { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + 4 * g0 };
+        { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
           if (sx_idx)
             DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast<true>, fast_grid(ctx, m), FAST_BLOCK,
@@ -2263,7 +2298,7 @@ layout:
                     (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g,
                     fast ? (const uint32_t *) ctx->tk.list : (const uint32_t *) NULL,
                     fast ? (const unsigned long long *) ctx->tk.count : (const unsigned long long *) NULL, g0,
-                    fast ? (const uint32_t *) (ctx->tk.info + 4 * g0) : (const uint32_t *) NULL, ~(uint64_t) 0, sx_g);
+                    fast ? (const uint32_t *) (ctx->tk.info + TOK_INFO * g0) : (const uint32_t *) NULL, ~(uint64_t) 0, sx_g);
         }
       DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction
@@ -2281,6 +2316,7 @@ layout:
   ctx->route.groups = ng; ctx->route.direct = 0; ctx->route.tokens = fast ? 1 : 0;
   ctx->route.region_bytes = region; ctx->route.scratch_bytes = ctx->scratch_bytes;
   ctx->route.token_bytes = fast ? 4ull * ctx->tk.cap_tokens : 0;
+  ctx->route.text_entries = fast ? ctx->tk.unusable : n;
   ctx->op.pending = 1; ctx->op.direct = 0; ctx->op.d_total = d_base + (ng & 1); ctx->op.out_cap = out_cap; ctx->op.sx_idx = sx_idx;
   if (!wait) return DX_OK;                               // (the last compaction is still running on the side stream)
   return onepass_end(ctx, total);

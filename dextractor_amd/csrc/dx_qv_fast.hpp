@@ -22,11 +22,15 @@ struct tok_src
 // into one string of <= 128 bits, and a single prefix sum + placement per pass puts the strings into
 // the window; with TAGS the lanes' 2-bit tag fields go into the tag window the same way.
 // gix (group index, dx_qv_subindex): the line's header word; groups: one word per lane and pass.
+// xend / nx: the line's exception list (runs of 127 and more: see "token hand-over"); nx is wave-uniform, and a line
+// without exceptions runs exactly the code it ran before there were any.  With exceptions a lane looks up the run of
+// its (one) exception token by bisection and swaps it in for the field's 127; a lane with two of them among its
+// tokens -- two runs of >= 127 within 8 tokens -- sends the pass to the token-by-token path.
 template <bool TAGS>
 __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, const uint16_t *tok, uint32_t cnt,
                                                   const uint32_t *ntab, const uint32_t *rtab,
                                                   const uint32_t *nstab, const uint32_t *rstab, uint32_t *gix, uint32_t *groups,
-                                                  uint32_t *none_count)
+                                                  uint32_t *none_count, const uint32_t *xend, uint32_t nx)
 { const uint32_t lane = (uint32_t) lane_id();
   uint32_t *g16 = gix ? groups + lane : (uint32_t *) NULL;
   uint32_t  wide = 0;                                              // a group that does not fit its 16 bits
@@ -45,16 +49,34 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           rt[k] = rstab[t16 >> 9];                                 // QV.c:479-487 (runs below TOK_RUN_MAX: no clamp needed)
           st[k] = *(const uint32_t *) ((const uint8_t *) nstab + (t16 & 0x1fcu));
         }
+      uint32_t xk = TOK_TP, xr = 0, xn = 0;                        // this lane's exception token: which, its run; how many it has
+      if (nx)                                                      // (wave-uniform)
+        {
+          #pragma unroll
+          for (int k = 0; k < (int) TOK_TP; k++)
+            { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
+              if ((uint32_t) k < c && (t16 >> 9) == TOK_RUN_MAX) { xk = (uint32_t) k; xn += 1u; }
+            }
+          if (xn)
+            { xr = tok_exception(xend, nx, first + xk);
+              const uint32_t e = rstab[xr > 255u ? 255u : xr];     // QV.c:479-482
+              #pragma unroll
+              for (int k = 0; k < (int) TOK_TP; k++)
+                if ((uint32_t) k == xk) rt[k] = e;
+            }
+        }
       uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, nb = 0, zor = 0, tacc = 0, span = 0;
       #pragma unroll
       for (int k = 0; k < (int) TOK_TP; k++)
         if ((uint32_t) k < c)
           { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
-            span += (t16 >> 9) + 1u;
+            const uint32_t run = (uint32_t) k == xk ? xr : t16 >> 9;
+            span += run + 1u;
             STOK_APPEND(rt[k])
             if (rt[k] & 0x80u)                                     // escaped run: its 16-bit literal follows (QV.c:486-487)
-              { const uint32_t lit = ((t16 >> 9) << 16) | 16u;
+              { const uint32_t lit = (run << 16) | 16u;
                 STOK_APPEND(lit)
+                w0 |= run & 0xffff0000u;                           // OCODE(16, run) with run >= 2^16 (QV.c:411, 420)
                 nb += 16u;
               }
             STOK_APPEND(st[k])
@@ -63,11 +85,22 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
             if (TAGS)
               tacc = (tacc << 2) | (t16 & 3u);
           }
+      if (xn > 1u)                                                 // two exception tokens in one lane: its bits counted token by token
+        { nb = 0; span = 0; zor |= 32u;                            // (and the pass placed token by token, below)
+          for (uint32_t j = 0; j < c; j++)
+            { const uint32_t t16 = tok[first + j];
+              uint32_t run = t16 >> 9;
+              if (run == TOK_RUN_MAX) run = tok_exception(xend, nx, first + j);
+              const uint32_t re = rtab[run > 255u ? 255u : run], se = ntab[(t16 >> 2) & 0x7fu];
+              nb   += TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u) + TOK_LEN(se);
+              span += run + 1u;
+            }
+        }
       const uint32_t incl = wave_incl_scan(nb);
       if (g16)
         { *g16 = nb | (span << 16);
           g16 += 64;
-          wide |= ((zor & 32u) || wave_total(incl) > RUN_PASSBITS) ? 1u : 0u;
+          wide |= ((zor & 32u) || span > 0xffffu || wave_total(incl) > RUN_PASSBITS) ? 1u : 0u;
         }
       if (!__any((int) ((zor & 32u) | (nb > 128u))))
         { FOR_EACH_ROUND(o, incl, nb,
@@ -80,8 +113,9 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
               _Pragma("unroll 1")
               for (uint32_t j = 0; j < c; j++)
                 { const uint32_t t16 = tok[first + j];
-                  const uint32_t run = t16 >> 9;
-                  const uint32_t re  = rtab[run];
+                  uint32_t run = t16 >> 9;
+                  if (nx && run == TOK_RUN_MAX) run = tok_exception(xend, nx, first + j);
+                  const uint32_t re  = rtab[run > 255u ? 255u : run];
                   const uint32_t se  = ntab[(t16 >> 2) & 0x7fu];
                   acc_put(s, o.win, TOK_ESC(re) ? ((TOK_BITS(re) << 16) | run) : TOK_BITS(re),
                           TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u));
@@ -222,7 +256,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
       // framing bytes, del words, tag bytes, ins, mrg, sub words (QV.c:1393-1423) -- and every size is checked.
       const bool      S      = sc.base != NULL;
       const uint32_t  L      = a.len[r];
-      const uint32_t *inf    = tk.info + 4 * r;
+      const uint32_t *inf    = tk.info + TOK_INFO * r;
       const uint64_t  toff   = tk.off[r];
       const uint32_t *sg     = seg + 5 * r;              // (direct mode)
       uint32_t       *sgw    = sc.seg_out + 5 * r;       // (scratch mode)
@@ -275,8 +309,10 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                   grp = base + 3u + (q == 0 ? 0u : 64u * pd);
                   if (lane == 0) base[2] = pd;
                 }
-              if (q == 0) encode_token_line<true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none);
-              else        encode_token_line<false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none);
+              const uint32_t *xend = (const uint32_t *) ((q == 0 ? tk.del : tk.sub) + tk.off[r + 1]);      // the slot's end
+              const uint32_t  nx   = inf[q == 0 ? 4 : 5];
+              if (q == 0) encode_token_line<true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx);
+              else        encode_token_line<false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx);
               uint32_t last;
               if (C > 0)
                 last = encode_trailing_run(o, C, rtab);
@@ -366,9 +402,15 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
 // table; both 256 B = conflict-free), per byte of the insertion / merge lines one; the pad rule QV.c:436-442 in
 // closed form.  Reads the tokens (~0.7 B per base) and the two plain lines (2 B per base): a memory-bound kernel
 // with a quarter of the encoder's instructions, run for group g + 1 beside the encoder of group g.
-__device__ __forceinline__ uint32_t token_bits(const uint16_t *tok, uint32_t cnt, const uint8_t *slen, const uint8_t *rlen)
+__device__ __forceinline__ uint32_t token_bits(const uint16_t *tok, uint32_t cnt, const uint8_t *slen, const uint8_t *rlen,
+                                               const uint32_t *xend, uint32_t nx)
 { const uint32_t lane = (uint32_t) lane_id();
   uint32_t acc = 0;
+  // exception tokens (runs of 127 and more) were priced as run 127 below: swap in the real run's price
+  for (uint32_t j = lane; j < nx; j += 64u)
+    { const uint32_t run = *(xend - 2 * (int) j - 1);
+      acc += (uint32_t) rlen[run > 255u ? 255u : run] - (uint32_t) rlen[TOK_RUN_MAX];
+    }
   for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
     { const uint32_t first = k0 + lane * TOK_TP;
       const uint32_t c     = first < cnt ? (cnt - first < TOK_TP ? cnt - first : TOK_TP) : 0u;
@@ -400,7 +442,7 @@ void k_qv_sizes_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, 
     { if (tok_unusable(tk.info, r, a.delChar, a.subChar))
         continue;                                        // k_qv_sizes (generic) has this entry
       const uint32_t  L    = a.len[r];
-      const uint32_t *inf  = tk.info + 4 * r;
+      const uint32_t *inf  = tk.info + TOK_INFO * r;
       const uint64_t  toff = tk.off[r];
       const bool      over = can_overread(a, line_ptr(a, r, L, 4), L);
       uint32_t s0 = 0, s2 = 0, s3 = 0, s4 = 0;
@@ -416,7 +458,8 @@ void k_qv_sizes_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, 
             { const int       rs  = q == 0 ? DX_DRUN : DX_SRUN;
               const uint16_t *tok = (q == 0 ? tk.del : tk.sub) + toff;
               const uint32_t  cnt = inf[q == 0 ? 0 : 1] & ~TOK_BAD, C = inf[q == 0 ? 2 : 3];
-              T = wave_sum(token_bits(tok, cnt, s_t.len[q], s_t.len[rs]));
+              T = wave_sum(token_bits(tok, cnt, s_t.len[q], s_t.len[rs],
+                                      (const uint32_t *) ((q == 0 ? tk.del : tk.sub) + tk.off[r + 1]), inf[q == 0 ? 4 : 5]));
               if (C > 0)                                 // run-only token at the line's end
                 { const uint32_t e = s_tok[rs][C > 255u ? 255u : C];
                   T   += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);

@@ -285,10 +285,12 @@ int dx_qv_encode_onepass_end(dx_ctx *ctx, uint64_t *total);
  * direct = 1 when no scratch slots could be had and the sizes-first route ran (k_qv_sizes_fast, records written in
  * place), tokens = 1 when the histogram pass's tokens fed the encoder; region_bytes = one scratch region,
  * scratch_bytes = the context's scratch allocation after the call, avail_bytes = the memory the choice was made
- * against (free device memory + the scratch that exists, or the budget below), token_bytes = the token slots.   */
+ * against (free device memory + the scratch that exists, or the budget below), token_bytes = the token slots,
+ * text_entries = entries the text-reading encoder took because their tokens could not be used (a byte >= 128 in a
+ * run-coded line, more tokens than the slot holds).                                                              */
 typedef struct
   { int32_t  groups, direct, tokens, reserved;
-    uint64_t region_bytes, scratch_bytes, avail_bytes, token_bytes;
+    uint64_t region_bytes, scratch_bytes, avail_bytes, token_bytes, text_entries;
   } dx_onepass_info;
 int dx_qv_onepass_info(const dx_ctx *ctx, dx_onepass_info *out);
 

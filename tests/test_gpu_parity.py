@@ -1242,3 +1242,61 @@ def test_pack2_bare_payloads_like_dex2db(ctx, arrow):
     got = d_out.download(np.uint8, total + 64).tobytes()
     assert got[:total] == b"".join(want)
     assert got[total:] == b"\xee" * 64                                 # nothing written past the last payload
+
+
+def _with_runs(c, entry, line, at, run_lens, run_char, gap=b"\x28"):
+    """Plants runs of run_char of the given lengths (separated by `gap` symbols) into one QV line of one entry; for the
+    deletion line the tag line gets 'N' under the run character and a letter under everything else (dextract.c:99-101)."""
+    txt = bytearray(c.text)
+    L, o = int(c.len[entry]), int(c.off[entry])
+    p = o + line * (L + 1) + at
+    for r in run_lens:
+        assert p + r + len(gap) <= o + line * (L + 1) + L
+        txt[p: p + r] = bytes([run_char]) * r
+        txt[p + r: p + r + len(gap)] = gap
+        if line == 0:
+            q = p + (L + 1)
+            txt[q: q + r] = b"N" * r
+            txt[q + r: q + r + len(gap)] = b"ACGT"[: len(gap)] if len(gap) <= 4 else b"A" * len(gap)
+        p += r + len(gap)
+    c.text = bytes(txt)
+
+
+def test_dexqv_long_runs_stay_on_the_token_path(ctx):
+    """Runs of 127 and more do not fit a token's 7-bit run field: they go by the line's exception list and the entry
+    stays with k_qv_encode_fast (round 2 sent such entries to the text-reading encoder).  One exception per lane
+    (patched in place), two and more within a lane's 8 tokens (token-by-token pass), runs across step boundaries,
+    255 / 256 (the code's cap, QV.c:479-482), > 65535 (16-bit literal overflow, QV.c:411, 420), at the line's end."""
+    lens = np.array([9000] * 10 + [200000, 9000, 9000], dtype=np.uint32)
+    c = synth.make_quiva(len(lens), seed=91, lens=lens)
+    st = O.qv_scan(c.text)
+    dch, sch = st.delChar, st.subChar
+    assert dch >= 0
+    sch = sch if sch >= 0 else ord("?")
+    _with_runs(c, 1, 0, 100, [127, 126, 128, 300, 5, 255, 256, 1000], dch)                # one exception here and there
+    _with_runs(c, 2, 0, 50, [130] * 20, dch)                                               # consecutive exception tokens: several per lane
+    _with_runs(c, 2, 4, 900, [127] * 12 + [2000, 127, 127], sch)
+    _with_runs(c, 3, 4, 0, [1023, 1, 1024, 2, 1025], sch)                                  # around the 1 KiB step
+    _with_runs(c, 4, 0, 9000 - 600, [599], dch, gap=b"")                                   # the line ENDS in a long run
+    _with_runs(c, 10, 0, 1000, [70000, 127, 66000], dch)                                   # beyond 16 bits
+    _with_runs(c, 10, 4, 5, [65535, 65536, 127], sch)
+    want = O.dexqv(c.text)
+    got = ctx.dexqv(c.text)
+    assert len(got) == len(want) and got == want
+    assert ctx.qv_onepass_info()["text_entries"] == 0                 # nobody went to the text-reading encoder
+    assert ctx.undexqv(got, upper=True) == O.undexqv(want, upper=True)
+    if O.have_ref():
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            assert O.run_ref("dexqv", [], c.text, ".quiva", ".dexqv", d) == got
+
+
+@pytest.mark.parametrize("run_p", [0.95, 0.99, 0.999])
+def test_dexqv_high_run_density_takes_no_text_entries(ctx, run_p):
+    prof = synth.pacbio_profile(del_run_p=run_p, sub_run_p=run_p)
+    c = synth.make_quiva(60, seed=78, mean=12000, prof=prof)
+    assert ctx.dexqv(c.text) == O.dexqv(c.text)
+    assert ctx.qv_onepass_info()["text_entries"] == 0
+    # the group index of such lines (decoder side) round-trips too
+    back = ctx.undexqv(ctx.dexqv(c.text), upper=True)
+    assert back == c.text
