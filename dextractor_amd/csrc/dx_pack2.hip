@@ -23,6 +23,14 @@
 #define P2_WIN_WORDS  448                // per-wave LDS window: flush threshold + one step (128 words) + slack
 #define P2_FLUSH_BITS 8192u
 #define P2_BATCH      16u                // reads a wave draws at a time (one same-address atomic costs ~11 ns chip-wide)
+#ifndef P2D_UNROLL
+#define P2D_UNROLL    1u                 // k_pack2_decode: 1 KiB steps whose loads go out together (measured, 10 M x 10 kb, ms per launch:
+                                         // 1: 32.8-35.5, 2: 33.8-35.9, 4: 39.0-39.3, 8: 41-42, 4 + non-temporal stores: 37.7-39.1 --
+                                         // profiles/r03_ab_pack2.txt; more stores in flight per wave do not help this write-bound kernel)
+#endif
+#ifndef P2D_NT
+#define P2D_NT        0                  // k_pack2_decode: non-temporal stores for the text
+#endif
 
 // ---------------------------------------------------------------------------------------------
 //  alphabet maps (computed, not tabulated)
@@ -229,40 +237,61 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
       const uint32_t T    = L + (L + width - 1u) / width;        // letters + newlines
       uint32_t line = line0, col = col0;
 
-      for (uint32_t base = 0; base < T; base += DX_STEP)
-        { const uint32_t q0 = base + 16u * lane;
-          const uint32_t i0 = q0 - line;                         // symbols before text byte q0
-          const uint32_t b0 = i0 >> 2;
-          if (q0 + 16u < T && b0 + 8u <= clen && !narrow)
-            { // 16 (or 15 + line end) letters from 8 packed bytes: symbol k of the chunk in bits 31-2k, 30-2k
-              const uint64_t raw = *(const u64_u *) (src + b0);
-              const uint64_t be  = ((uint64_t) __builtin_bswap32((uint32_t) raw) << 32) | __builtin_bswap32((uint32_t) (raw >> 32));
-              uint32_t cw = (uint32_t) ((be << (2u * (i0 & 3u))) >> 32);
-              const uint32_t nlpos = width - col;                // offset of the line end in this chunk (>= 16: none)
-              if (nlpos < 16u)
-                { const uint32_t K = 30u - 2u * nlpos;           // open a 2-bit hole at slot nlpos
-                  const uint32_t keep = ~((4u << K) - 1u);       // slots before it
-                  cw = (cw & keep) | ((cw & ~keep) >> 2);
-                }
-              u32x4 v;
-              v.x = s_quad[cw >> 24];
-              v.y = s_quad[(cw >> 16) & 0xffu];
-              v.z = s_quad[(cw >> 8) & 0xffu];
-              v.w = s_quad[cw & 0xffu];
-              if (nlpos < 16u)
-                { const uint32_t m = 0xffu << (8u * (nlpos & 3u)), j = nlpos >> 2;
-                  const uint32_t nl4 = 0x0a0a0a0au;
-                  v.x = j == 0u ? (v.x & ~m) | (nl4 & m) : v.x;
-                  v.y = j == 1u ? (v.y & ~m) | (nl4 & m) : v.y;
-                  v.z = j == 2u ? (v.z & ~m) | (nl4 & m) : v.z;
-                  v.w = j == 3u ? (v.w & ~m) | (nl4 & m) : v.w;
-                }
-              *(u32x4_u *) (dst + q0) = v;
+      // P2D_UNROLL steps of 1 KiB per iteration, their 8-byte loads issued together (a wave's loads and stores retire in
+      // issue order, so the wait for a step's load is also a wait for the stores before it); 1 measured best, see above
+      for (uint32_t base = 0; base < T; base += P2D_UNROLL * DX_STEP)
+        { uint64_t raw[P2D_UNROLL];
+          uint32_t i0k[P2D_UNROLL], nlk[P2D_UNROLL];
+          bool     fastk[P2D_UNROLL];
+          #pragma unroll
+          for (int k = 0; k < (int) P2D_UNROLL; k++)
+            { const uint32_t q0 = base + (uint32_t) k * DX_STEP + 16u * lane;
+              const uint32_t i0 = q0 - line;                     // symbols before text byte q0
+              const uint32_t b0 = i0 >> 2;
+              i0k[k]   = i0;
+              nlk[k]   = width - col;                            // offset of the line end in this chunk (>= 16: none)
+              fastk[k] = q0 + 16u < T && b0 + 8u <= clen && !narrow;
+              raw[k]   = 0;
+              if (fastk[k])
+                raw[k] = *(const u64_u *) (src + b0);
+              line += dline; col += dcol;
+              if (col >= W1) { col -= W1; line += 1u; }
             }
-          else if (q0 < T)
-            decode_chunk_generic<LETTERS>(src, dst, q0, T, clen, width);
-          line += dline; col += dcol;
-          if (col >= W1) { col -= W1; line += 1u; }
+          #pragma unroll
+          for (int k = 0; k < (int) P2D_UNROLL; k++)
+            { const uint32_t q0 = base + (uint32_t) k * DX_STEP + 16u * lane;
+              if (fastk[k])
+                { // 16 (or 15 + line end) letters from 8 packed bytes: symbol j of the chunk in bits 31-2j, 30-2j
+                  const uint64_t be = ((uint64_t) __builtin_bswap32((uint32_t) raw[k]) << 32) | __builtin_bswap32((uint32_t) (raw[k] >> 32));
+                  uint32_t cw = (uint32_t) ((be << (2u * (i0k[k] & 3u))) >> 32);
+                  const uint32_t nlpos = nlk[k];
+                  if (nlpos < 16u)
+                    { const uint32_t K = 30u - 2u * nlpos;       // open a 2-bit hole at slot nlpos
+                      const uint32_t keep = ~((4u << K) - 1u);   // slots before it
+                      cw = (cw & keep) | ((cw & ~keep) >> 2);
+                    }
+                  u32x4 v;
+                  v.x = s_quad[cw >> 24];
+                  v.y = s_quad[(cw >> 16) & 0xffu];
+                  v.z = s_quad[(cw >> 8) & 0xffu];
+                  v.w = s_quad[cw & 0xffu];
+                  if (nlpos < 16u)
+                    { const uint32_t m = 0xffu << (8u * (nlpos & 3u)), j = nlpos >> 2;
+                      const uint32_t nl4 = 0x0a0a0a0au;
+                      v.x = j == 0u ? (v.x & ~m) | (nl4 & m) : v.x;
+                      v.y = j == 1u ? (v.y & ~m) | (nl4 & m) : v.y;
+                      v.z = j == 2u ? (v.z & ~m) | (nl4 & m) : v.z;
+                      v.w = j == 3u ? (v.w & ~m) | (nl4 & m) : v.w;
+                    }
+#if P2D_NT
+                  __builtin_nontemporal_store(v, (u32x4_u *) (dst + q0));
+#else
+                  *(u32x4_u *) (dst + q0) = v;
+#endif
+                }
+              else if (q0 < T)
+                decode_chunk_generic<LETTERS>(src, dst, q0, T, clen, width);
+            }
         }
     }
   }

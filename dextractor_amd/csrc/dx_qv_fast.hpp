@@ -22,11 +22,11 @@ struct tok_src
 // into one string of <= 128 bits, and a single prefix sum + placement per pass puts the strings into
 // the window; with TAGS the lanes' 2-bit tag fields go into the tag window the same way.
 // gix (group index, dx_qv_subindex): the line's header word; groups: one word per lane and pass.
-// xend / nx: the line's exception list (runs of 127 and more: see "token hand-over"); nx is wave-uniform, and a line
-// without exceptions runs exactly the code it ran before there were any.  With exceptions a lane looks up the run of
+// xend / nx: the line's exception list (runs of 127 and more: see "token hand-over"); XC = the line has exceptions
+// (nx is wave-uniform: a line without any runs the instance without a single instruction for them).  With exceptions a lane looks up the run of
 // its (one) exception token by bisection and swaps it in for the field's 127; a lane with two of them among its
 // tokens -- two runs of >= 127 within 8 tokens -- sends the pass to the token-by-token path.
-template <bool TAGS>
+template <bool TAGS, bool XC>
 __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, const uint16_t *tok, uint32_t cnt,
                                                   const uint32_t *ntab, const uint32_t *rtab,
                                                   const uint32_t *nstab, const uint32_t *rstab, uint32_t *gix, uint32_t *groups,
@@ -50,7 +50,7 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           st[k] = *(const uint32_t *) ((const uint8_t *) nstab + (t16 & 0x1fcu));
         }
       uint32_t xk = TOK_TP, xr = 0, xn = 0;                        // this lane's exception token: which, its run; how many it has
-      if (nx)                                                      // (wave-uniform)
+      if (XC)
         {
           #pragma unroll
           for (int k = 0; k < (int) TOK_TP; k++)
@@ -70,7 +70,7 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
       for (int k = 0; k < (int) TOK_TP; k++)
         if ((uint32_t) k < c)
           { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
-            const uint32_t run = (uint32_t) k == xk ? xr : t16 >> 9;
+            const uint32_t run = XC && (uint32_t) k == xk ? xr : t16 >> 9;
             span += run + 1u;
             STOK_APPEND(rt[k])
             if (rt[k] & 0x80u)                                     // escaped run: its 16-bit literal follows (QV.c:486-487)
@@ -85,7 +85,7 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
             if (TAGS)
               tacc = (tacc << 2) | (t16 & 3u);
           }
-      if (xn > 1u)                                                 // two exception tokens in one lane: its bits counted token by token
+      if (XC && xn > 1u)                                           // two exception tokens in one lane: its bits counted token by token
         { nb = 0; span = 0; zor |= 32u;                            // (and the pass placed token by token, below)
           for (uint32_t j = 0; j < c; j++)
             { const uint32_t t16 = tok[first + j];
@@ -114,7 +114,7 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
               for (uint32_t j = 0; j < c; j++)
                 { const uint32_t t16 = tok[first + j];
                   uint32_t run = t16 >> 9;
-                  if (nx && run == TOK_RUN_MAX) run = tok_exception(xend, nx, first + j);
+                  if (XC && run == TOK_RUN_MAX) run = tok_exception(xend, nx, first + j);
                   const uint32_t re  = rtab[run > 255u ? 255u : run];
                   const uint32_t se  = ntab[(t16 >> 2) & 0x7fu];
                   acc_put(s, o.win, TOK_ESC(re) ? ((TOK_BITS(re) << 16) | run) : TOK_BITS(re),
@@ -157,13 +157,25 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
 // is built from the shift tokens by every workgroup at its start.  Pair index of bytes (b0, b1) in stream
 // order: (b0 - lo) + 64 * (b1 - lo).  A step with a byte outside the band, a pair without a token or a
 // lane string beyond 128 bits is handed to the one-symbol step.
+// LDS banks: a look-up is serviced 32 lanes at a time over 32 banks of 4 bytes, one cycle per distinct address on a
+// bank.  Laid out as (b0 - lo) + 64 * (b1 - lo), an entry's bank is (b0 - lo) mod 32 whatever b1 is: with the
+// insertion QVs' geometric distribution a quarter of the lanes have the same b0 and three or four different b1, and
+// nearly every look-up took three or four passes (round 2: 279 M conflict cycles on 159 M cycles of LDS work).  With a
+// row stride of 69 the bank is (b0 + 5 b1) mod 32: the thirty most frequent pairs sit in thirty different banks, and
+// lanes with the SAME pair read one address, which is a broadcast.  (69 * 63 + 63 < 65536: both 16-bit halves of a word
+// still index independently, by one multiply-add instead of the shift and the OR.)
 #define PAIR_NONE 0xffffffffu
+#ifndef PAIR_STRIDE
+#define PAIR_STRIDE 69u
+#endif
+#define PAIR_SIZE (((63u * PAIR_STRIDE + 64u) + 15u) & ~15u)
 
-__device__ __forceinline__ void build_pair_tables(uint32_t (*s_pair)[4096], const uint32_t (*s_stok)[256],
+__device__ __forceinline__ void build_pair_tables(uint32_t (*s_pair)[PAIR_SIZE], const uint32_t (*s_stok)[256],
                                                   uint32_t lo_ins, uint32_t lo_mrg)
 { for (uint32_t k = threadIdx.x; k < 2u * 4096u; k += blockDim.x)
-    { const uint32_t q = 1u + (k >> 12), idx = k & 4095u, lo = q == 1u ? lo_ins : lo_mrg;
-      const uint32_t a = lo + (idx & 63u), b = lo + (idx >> 6);
+    { const uint32_t q = 1u + (k >> 12), lo = q == 1u ? lo_ins : lo_mrg;
+      const uint32_t ia = k & 63u, ib = (k >> 6) & 63u, idx = (q - 1u) * PAIR_SIZE + ia + PAIR_STRIDE * ib;
+      const uint32_t a = lo + ia, b = lo + ib;
       uint32_t tok = 32u;                                            // "no code": the step goes to the one-symbol path
       if (lo != PAIR_NONE && a < 256u && b < 256u)
         { const uint32_t t1 = s_stok[q][a], t2 = s_stok[q][b];
@@ -171,7 +183,7 @@ __device__ __forceinline__ void build_pair_tables(uint32_t (*s_pair)[4096], cons
           if (s1 < 32u && s2 < 32u && s1 + s2 >= 40u)                // both coded, <= 24 bits together
             tok = (t1 & 0xffffff00u) | ((t2 & 0xffffff00u) >> (32u - s1)) | (s1 + s2 - 32u);
         }
-      (&s_pair[0][0])[k] = tok;
+      (&s_pair[0][0])[idx] = tok;
     }
   __syncthreads();
 }
@@ -184,7 +196,11 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
   #pragma unroll
   for (int w = 0; w < 4; w++)
     { const uint32_t x = (chunk_word(c, w) & m4) - lo4;              // bytes - lo: all < 64 in the band (no borrow then)
+#if PAIR_STRIDE == 64
       const uint32_t m = (x & 0x003f003fu) | ((x >> 2) & 0x0fc00fc0u);   // two 12-bit pair indices, one per half word
+#else
+      const uint32_t m = __umul24((x >> 8) & 0x003f003fu, PAIR_STRIDE) + (x & 0x003f003fu);   // two pair indices b0 + 69 b1, one per half word
+#endif
       bad |= x;
       tok[2 * w]     = ptab[m & 0xffffu];
       tok[2 * w + 1] = ptab[m >> 16];
@@ -230,7 +246,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                       sub_sink sx)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
-  __shared__ uint32_t s_pair[2][4096];
+  __shared__ uint32_t s_pair[2][PAIR_SIZE];
   __shared__ uint8_t  s_tagcode[256];
   __shared__ __attribute__((aligned(16))) uint32_t s_win[FAST_NWAVE][QV_WIN_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t s_tag[FAST_NWAVE][TAG_WIN_WORDS];
@@ -311,8 +327,14 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                 }
               const uint32_t *xend = (const uint32_t *) ((q == 0 ? tk.del : tk.sub) + tk.off[r + 1]);      // the slot's end
               const uint32_t  nx   = inf[q == 0 ? 4 : 5];
-              if (q == 0) encode_token_line<true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx);
-              else        encode_token_line<false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx);
+              if (nx == 0)
+                { if (q == 0) encode_token_line<true,  false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, 0u);
+                  else        encode_token_line<false, false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, 0u);
+                }
+              else
+                { if (q == 0) encode_token_line<true,  true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx);
+                  else        encode_token_line<false, true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx);
+                }
               uint32_t last;
               if (C > 0)
                 last = encode_trailing_run(o, C, rtab);
