@@ -48,7 +48,8 @@ HIST = (C.c_uint64 * 256) * 6
 class OnepassInfo(C.Structure):
     _fields_ = [("groups", C.c_int32), ("direct", C.c_int32), ("tokens", C.c_int32), ("reserved", C.c_int32),
                 ("region_bytes", C.c_uint64), ("scratch_bytes", C.c_uint64), ("avail_bytes", C.c_uint64),
-                ("token_bytes", C.c_uint64), ("text_entries", C.c_uint64)]
+                ("token_bytes", C.c_uint64), ("text_entries", C.c_uint64),
+                ("chain_waits", C.c_uint64 * 3)]
 
 
 class QVIndex(C.Structure):

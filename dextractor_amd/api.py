@@ -269,7 +269,9 @@ class Context:
         """dx_qv_onepass_info: the route the last one-pass encode took (groups / direct, scratch, budget)."""
         o = L.OnepassInfo()
         self._chk(self.lib.dx_qv_onepass_info(self.h, C.byref(o)))
-        return {k: int(getattr(o, k)) for k, _ in L.OnepassInfo._fields_ if k != "reserved"}
+        d = {k: int(getattr(o, k)) for k, _ in L.OnepassInfo._fields_ if k not in ("reserved", "chain_waits")}
+        d["chain_waits"] = [int(x) for x in o.chain_waits]
+        return d
 
     def trim(self, what=7):
         """dx_trim: give the context's scratch (1), token slots (2), group index (4) back to the device."""

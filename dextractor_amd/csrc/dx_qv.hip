@@ -1507,6 +1507,11 @@ void k_qv_compact(uint64_t n, const uint32_t *len, const uint8_t *scratch, const
 }
 
 #include "dx_qv_fast.hpp"
+// (template arguments hold commas, which a macro argument cannot: the instances go by these names)
+static constexpr auto FAST_K          = &k_qv_encode_fast<false, false>;
+static constexpr auto FAST_K_IX       = &k_qv_encode_fast<true, false>;
+static constexpr auto FAST_K_CHAIN    = &k_qv_encode_fast<false, true>;
+static constexpr auto FAST_K_IX_CHAIN = &k_qv_encode_fast<true, true>;
 
 // =============================================================================================
 //  C-ABI
@@ -2049,15 +2054,15 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       if (hipStreamWaitEvent(A, sz_done[g & 7], 0) != hipSuccess || hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
       dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
       if (sx_idx)
-        hipLaunchKernelGGL(k_qv_encode_fast<true>, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
+        hipLaunchKernelGGL(FAST_K_IX, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
                            ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
-                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
+                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
       else
-        hipLaunchKernelGGL(k_qv_encode_fast<false>, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
+        hipLaunchKernelGGL(FAST_K, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
                            ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
-                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
+                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
       dx_prof_end_on(ctx, A);
       if (odd)
         { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
@@ -2097,6 +2102,75 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
   return DX_OK;
 }
 
+// dx_qv_encode_onepass with chained placement (DEXGPU_CHAIN, or no memory for scratch slots): one launch of
+// k_qv_encode_fast<.., true> -- sizes, look-back, record in place -- between two list-mode launches of the generic
+// kernels for the entries whose tokens cannot be used.  Needs the token hand-over; 8 bytes of scratch per entry.
+static int onepass_chain(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                         uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total)
+{ const uint64_t n  = b->n;
+  const size_t   a8 = (n * 8 + 255) & ~(size_t) 255, a4 = (n * 4 + 255) & ~(size_t) 255;
+  uint8_t *scr;
+  int e;
+  if ((e = dx_scratch(ctx, a8 + a4 + 512, (void **) &scr))) return e;
+  unsigned long long *d_status64 = (unsigned long long *) scr;
+  uint32_t           *d_size     = (uint32_t *) (scr + a8);
+  unsigned long long *d_waits    = (unsigned long long *) (scr + a8 + a4);
+  uint32_t *sx_idx = NULL;
+  if ((e = subindex_prepare(ctx, b, d_out, d_seg, &sx_idx))) return e;
+  hipStream_t A = ctx->stream;
+  uint32_t *d_tick = (uint32_t *) (ctx->d_u64 + 19);
+  const qv_args a   = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
+  const bool    odd = ctx->tk.unusable > 0;
+  const tok_src tg  = { ctx->tk.del, ctx->tk.sub, ctx->tk.off, ctx->tk.info };
+  const sub_sink sx = { sx_idx, sx_idx ? (const uint64_t *) ctx->sx.off : (const uint64_t *) NULL, ctx->sx.none };
+  const lb_chain lb = { d_status64, d_rec_off, d_seg, d_size, d_waits };
+  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
+  DX_HIP(ctx, hipMemsetAsync(d_status64, 0, a8, A));
+  DX_HIP(ctx, hipMemsetAsync(d_waits, 0, 32, A));
+  if (odd)                                               // sizes of the entries the fast kernel leaves out: from the text
+    { DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
+      DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, ctx->tk.unusable < n ? ctx->tk.unusable : n, 4 * SIZES_WAVES), DX_BLOCK,
+                a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_seg, d_size, d_tick, (const uint32_t *) ctx->tk.list,
+                (const unsigned long long *) ctx->tk.count, (uint64_t) 0, (const uint32_t *) ctx->tk.info);
+    }
+  DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
+  if (sx_idx)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX_CHAIN, fast_grid(ctx, n), FAST_BLOCK,
+              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+              ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb);
+  else
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_CHAIN, fast_grid(ctx, n), FAST_BLOCK,
+              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+              ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb);
+  if (odd)                                               // ... and their records, in place
+    { DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
+      DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, ctx->tk.unusable < n ? ctx->tk.unusable : n, 4 * ENC_WAVES), DX_BLOCK,
+                a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, (const uint64_t *) d_rec_off, (const uint32_t *) d_seg, d_out,
+                ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL }, (const uint32_t *) ctx->tk.list,
+                (const unsigned long long *) ctx->tk.count, (uint64_t) 0, (const uint32_t *) ctx->tk.info, out_cap, sx);
+    }
+  uint64_t tot = 0, waits[4] = { 0, 0, 0, 0 };
+  uint32_t st  = 0;
+  DX_HIP(ctx, hipMemcpyAsync(&tot, d_rec_off + n, 8, hipMemcpyDeviceToHost, A));
+  DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A));
+  DX_HIP(ctx, hipMemcpyAsync(waits, d_waits, 24, hipMemcpyDeviceToHost, A));
+  DX_HIP(ctx, hipStreamSynchronize(A));
+  if (total) *total = tot;
+  ctx->route.groups = 0; ctx->route.direct = 2; ctx->route.tokens = 1; ctx->route.region_bytes = 0;
+  ctx->route.scratch_bytes = ctx->scratch_bytes; ctx->route.token_bytes = 4ull * ctx->tk.cap_tokens;
+  ctx->route.text_entries = ctx->tk.unusable;
+  ctx->route.chain_waits[0] = waits[0]; ctx->route.chain_waits[1] = waits[1]; ctx->route.chain_waits[2] = waits[2];
+  if (st & 32u)
+    return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: the placement chain did not close (an entry waited %u looks for its predecessors)", LB_SPIN_LIMIT);
+  if (tot > out_cap || (st & 8u))
+    return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
+                   (unsigned long long) tot, (unsigned long long) out_cap);
+  if (st & 2u)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an encoded segment differs in size from what the size phase computed");
+  ctx->sx.valid = sx_idx != NULL;
+  return DX_OK;
+}
+
 static int onepass_end(dx_ctx *ctx, uint64_t *total);
 
 // wait = false: everything is queued and the function returns; onepass_end collects the total and the status
@@ -2124,6 +2198,13 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // DEXGPU_DIRECT_ENCODE: sizes first, records written in place, no scratch slots (onepass_direct) -- what also runs
   // when the slots below cannot be allocated.  It is the slower of the two (34.5 ms against 31.0, 1 M x 10 kb): its
   // size kernel reads the 30 GB of plain lines once more, the compaction it saves moves 2 x 14 GB.
+  if (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_CHAIN") != NULL && getenv("DEXGPU_CHAIN")[0] != '0')
+    { uint64_t t = 0;
+      const int rc = onepass_chain(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
+      if (total) *total = t;
+      if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }
+      return rc;
+    }
   if (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_DIRECT_ENCODE") != NULL)
     { uint64_t t = 0;
       const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
@@ -2280,15 +2361,15 @@ layout:
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
           if (sx_idx)
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast<true>, fast_grid(ctx, m), FAST_BLOCK,
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX, fast_grid(ctx, m), FAST_BLOCK,
                       ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
                       ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g);
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
           else
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, k_qv_encode_fast<false>, fast_grid(ctx, m), FAST_BLOCK,
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K, fast_grid(ctx, m), FAST_BLOCK,
                       ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
                       ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g);
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
         }
       if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
         { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;

@@ -225,6 +225,155 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
   return true;
 }
 
+__device__ __forceinline__ uint32_t token_bits(const uint16_t *tok, uint32_t cnt, const uint8_t *slen, const uint8_t *rlen,
+                                               const uint32_t *xend, uint32_t nx)
+{ const uint32_t lane = (uint32_t) lane_id();
+  uint32_t acc = 0;
+  // exception tokens (runs of 127 and more) were priced as run 127 below: swap in the real run's price
+  for (uint32_t j = lane; j < nx; j += 64u)
+    { const uint32_t run = *(xend - 2 * (int) j - 1);
+      acc += (uint32_t) rlen[run > 255u ? 255u : run] - (uint32_t) rlen[TOK_RUN_MAX];
+    }
+  for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
+    { const uint32_t first = k0 + lane * TOK_TP;
+      const uint32_t c     = first < cnt ? (cnt - first < TOK_TP ? cnt - first : TOK_TP) : 0u;
+      u32x4 tw = { 0u, 0u, 0u, 0u };
+      if (c)
+        tw = *(const u32x4_u *) (tok + first);
+      #pragma unroll
+      for (int k = 0; k < (int) TOK_TP; k++)
+        { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
+          const uint32_t l   = (uint32_t) rlen[t16 >> 9] + (uint32_t) slen[(t16 >> 2) & 0x7fu];
+          acc += (uint32_t) k < c ? l : 0u;
+        }
+    }
+  return acc;                                            // (per lane; < 2^32 for entries of < 2^27 symbols)
+}
+
+
+// the five segment sizes of one entry from its tokens and its plain lines (what k_qv_sizes_fast stores; the chained
+// encoder computes them for itself): sz[0..4] = del words, tag bytes, ins, mrg, sub words
+__device__ __forceinline__ void entry_sizes_fast(const qv_args &a, uint64_t r, uint32_t L, const uint32_t *inf, uint64_t toff, uint64_t tend,
+                                                 const tok_src &tk, const uint32_t (*s_tok)[256], const uint8_t (*s_len)[256],
+                                                 bool over, uint32_t *sz)
+{ const int lane = lane_id();
+  sz[0] = sz[2] = sz[3] = sz[4] = 0;
+  sz[1] = (L + 3u) >> 2;                                 // all tags kept unless the deletion line is run-coded
+  #pragma unroll 1
+  for (int q = 0; q < 4; q++)
+    { const int       line = q ? q + 1 : 0;
+      const int       rci  = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
+      const uint32_t *tab  = s_tok[q];
+      uint64_t T;
+      uint32_t last;
+      if (rci >= 0)                                      // Encode_Run: token lengths (QV.c:475-497)
+        { const int       rs  = q == 0 ? DX_DRUN : DX_SRUN;
+          const uint16_t *tok = (q == 0 ? tk.del : tk.sub) + toff;
+          const uint32_t  cnt = inf[q == 0 ? 0 : 1] & ~TOK_BAD, C = inf[q == 0 ? 2 : 3];
+          T = wave_sum(token_bits(tok, cnt, s_len[q], s_len[rs],
+                                  (const uint32_t *) ((q == 0 ? tk.del : tk.sub) + tend), inf[q == 0 ? 4 : 5]));
+          if (C > 0)                                     // run-only token at the line's end
+            { const uint32_t e = s_tok[rs][C > 255u ? 255u : C];
+              T   += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
+              last = TOK_ESC(e) ? 16u : TOK_LEN(e);
+            }
+          else if (cnt > 0)
+            { const uint32_t e = tab[((uint32_t) tok[cnt - 1] >> 2) & 0x7fu];
+              last = TOK_ESC(e) ? 8u : TOK_LEN(e);
+            }
+          else
+            last = 0;
+          if (q == 0) sz[1] = (cnt + 3u) >> 2;           // Pack_Tag's count, QV.c:810-819
+        }
+      else                                               // Encode: code lengths of the line's bytes (QV.c:427-434)
+        { const uint8_t *p    = line_ptr(a, r, L, line);
+          const uint32_t mask = !a.lossy ? 0xffu : (q == 1 ? 0xfeu : (q == 2 ? 0xfcu : 0xffu));
+          const uint32_t m4   = mask * 0x01010101u;
+          uint32_t pos = 16u * lane, acc = 0;
+          u32x4 c = fetch(p, pos, L, over);
+          T = 0;
+          for (uint32_t base = 0; base < L; base += DX_STEP)
+            { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
+              acc += bits_syms_step(c, valid_of(pos, L), s_len[q], m4);
+              c = d;
+              pos += DX_STEP;
+              if ((base & 0x3ffffffu) == 0x3fffc00u)     // fold long before a 32-bit lane sum can wrap
+                { T += wave_sum(acc); acc = 0; }
+            }
+          T   += wave_sum(acc);
+          last = last_piece_plain(tab, p, L, mask);
+        }
+      sz[line] = seg_bytes(T, last);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  chained placement (decoupled look-back): no scratch slots, no compaction
+// ---------------------------------------------------------------------------------------------
+// The waves draw entries in file order.  A wave first computes its entry's five sizes (the cheap size code above:
+// token and symbol LENGTHS only), publishes the record's size in a 64-bit status word -- flag and value in one
+// store, so the word needs no ordering with anything else -- then sums the words of the entries before it back to
+// the nearest one that already holds its inclusive prefix, 64 predecessors per look, and publishes its own prefix.
+// Because sizes are published BEFORE the entry is encoded, nobody ever waits for an encode: the chain runs a size
+// phase ahead of the encoders however ragged the entry lengths are.  The record is then written in place.
+// Every drawn entry is published by a resident, running wave and no wave waits for a later entry, so the spin
+// below ends; it is bounded all the same (status bit 32: the host reports the failure).
+struct lb_chain
+{ unsigned long long *status;       // n words, zeroed: bits 63..62: 0 nothing yet, 1 the record's size, 2 its inclusive prefix; low 62 bits: the value
+  uint64_t           *rec_off;      // n + 1, written here
+  uint32_t           *seg;          // n x 5, written here
+  const uint32_t     *rec_size;     // record sizes of the entries on the unusable list (k_qv_sizes in list mode)
+  unsigned long long *waits;        // [0] looks that met a word not yet published, [1] entries with such a look, [2] most such looks of one entry
+};
+#define LB_SIZE   (1ull << 62)
+#define LB_PREFIX (2ull << 62)
+#define LB_VALUE  ((1ull << 62) - 1ull)
+#define LB_SPIN_LIMIT (1u << 22)
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
+{ for (int d = 32; d >= 1; d >>= 1)
+    v += __shfl_xor(v, d);
+  return v;
+}
+
+// publishes `own`, returns the sum of the records before entry r; *failed set when the spin gave up
+__device__ __forceinline__ uint64_t chain_place(const lb_chain &lb, uint64_t r, uint64_t own, uint32_t *status_flags)
+{ const int lane = lane_id();
+  if (lane == 0)
+    __hip_atomic_store(&lb.status[r], LB_SIZE | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint64_t excl = 0, j = r;                               // entries [j, r) are in excl
+  uint32_t polls = 0;
+  while (j > 0)
+    { unsigned long long v = LB_PREFIX;                   // before entry 0: prefix 0
+      if ((uint64_t) lane < j)
+        v = __hip_atomic_load(&lb.status[j - 1 - (uint64_t) lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t flag = (uint32_t) (v >> 62);
+      const uint64_t mP = __ballot(flag == 2u), mE = __ballot(flag == 0u);
+      const int firstP = mP ? __ffsll((unsigned long long) mP) - 1 : 64, firstE = mE ? __ffsll((unsigned long long) mE) - 1 : 64;
+      const int upto   = firstP < firstE ? firstP + 1 : firstE;       // lanes [0, upto) hold sizes (the last one a prefix)
+      excl += wave_sum64(lane < upto ? (uint64_t) (v & LB_VALUE) : 0ull);
+      if (firstP < firstE) break;                         // reached an inclusive prefix
+      j -= (uint64_t) upto;
+      if (upto == 0)
+        { polls += 1;
+          if (polls > LB_SPIN_LIMIT)
+            { if (lane == 0) atomicOr(status_flags, 32u);
+              break;
+            }
+          __builtin_amdgcn_s_sleep(4);
+        }
+    }
+  if (lane == 0)
+    { __hip_atomic_store(&lb.status[r], LB_PREFIX | (excl + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (polls && lb.waits)
+        { atomicAdd(&lb.waits[0], (unsigned long long) polls);
+          atomicAdd(&lb.waits[1], 1ull);
+          atomicMax(&lb.waits[2], (unsigned long long) polls);
+        }
+    }
+  return excl;
+}
+
 #ifndef FAST_WAVES
 #define FAST_WAVES 4                                     // waves per SIMD the register allocation leaves room for
 #endif
@@ -238,16 +387,26 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
 // whose four encoder waves leave 64 of the 512 registers, i.e. at <= 112 each.  The plain instance has 110; with the
 // index code compiled in it had 116 (-> 120 allocated) even when no index was asked for, the two kernels ran one
 // after the other, and a step took 32.7 ms instead of 31.0.
-template <bool SUB>
+// CHAIN: chained placement (lb): sizes first, record offset by look-back, record written in place.
+template <bool SUB, bool CHAIN>
 __global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
                       enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
                       const uint8_t *hdr, const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint64_t out_cap,
-                      sub_sink sx)
+                      sub_sink sx, lb_chain lb)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint32_t s_pair[2][PAIR_SIZE];
   __shared__ uint8_t  s_tagcode[256];
+  __shared__ uint8_t  s_len[CHAIN ? 6 : 1][256];           // code lengths per symbol / run value (the size phase)
+  if (CHAIN)
+    for (int k = threadIdx.x; k < 6 * 256; k += (int) blockDim.x)
+      { const uint32_t e = g_tok[k];
+        uint32_t l = TOK_LEN(e) + ((k >= 4 * 256 && TOK_ESC(e)) ? 16u : 0u);
+        if ((a.delChar >= 0 && k == DX_DEL * 256 + a.delChar) || (a.subChar >= 0 && k == DX_SUB * 256 + a.subChar))
+          l = 0;
+        (&s_len[0][0])[k] = (uint8_t) l;
+      }
   __shared__ __attribute__((aligned(16))) uint32_t s_win[FAST_NWAVE][QV_WIN_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t s_tag[FAST_NWAVE][TAG_WIN_WORDS];
   load_tables(s_tok, g_tok);
@@ -266,18 +425,52 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   for (uint64_t r = next_unit(ticket), nxt; r < a.n; r = nxt)
     { nxt = next_unit(ticket);
       if (tok_unusable(tk.info, r, a.delChar, a.subChar))
-        continue;                                        // the generic kernel encodes this entry from the text
+        { if (CHAIN)                                     // its size (k_qv_sizes, list mode) takes its place in the chain all the same
+            { const uint64_t own  = lb.rec_size[r];
+              const uint64_t excl = chain_place(lb, r, own, status);
+              if (lane == 0)
+                { lb.rec_off[r] = excl;
+                  if (r + 1 == a.n) lb.rec_off[a.n] = excl + own;
+                }
+            }
+          continue;                                      // the generic kernel encodes this entry from the text
+        }
       // Two modes.  Scratch (sc.base != NULL): the entry goes into its slot, the sizes it turns out to have are
       // recorded.  Direct: the sizes are known (k_qv_sizes_fast), the record is written where it belongs --
       // framing bytes, del words, tag bytes, ins, mrg, sub words (QV.c:1393-1423) -- and every size is checked.
-      const bool      S      = sc.base != NULL;
+      const bool      S      = !CHAIN && sc.base != NULL;
       const uint32_t  L      = a.len[r];
       const uint32_t *inf    = tk.info + TOK_INFO * r;
       const uint64_t  toff   = tk.off[r];
       const uint32_t *sg     = seg + 5 * r;              // (direct mode)
       uint32_t       *sgw    = sc.seg_out + 5 * r;       // (scratch mode)
       uint8_t        *dst, *tag_at;
-      if (S)
+      uint32_t        sz[5]  = { 0u, 0u, 0u, 0u, 0u };   // (chained mode: the sizes, wave-uniform)
+      if (CHAIN)
+        { entry_sizes_fast(a, r, L, inf, toff, tk.off[r + 1], tk, s_tok, s_len, can_overread(a, line_ptr(a, r, L, 4), L), sz);
+          const uint32_t hl   = hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u;
+          const uint64_t own  = (uint64_t) hl + sz[0] + sz[1] + sz[2] + sz[3] + sz[4];
+          const uint64_t excl = chain_place(lb, r, own, status);
+          if (lane == 0)
+            { lb.rec_off[r] = excl;
+              if (r + 1 == a.n) lb.rec_off[a.n] = excl + own;
+              uint32_t *w = lb.seg + 5 * r;
+              w[0] = sz[0]; w[1] = sz[1]; w[2] = sz[2]; w[3] = sz[3]; w[4] = sz[4];
+            }
+          if (excl + own > out_cap)                      // d_out is too small: report, never overrun
+            { if (lane == 0) atomicOr(status, 8u);
+              continue;
+            }
+          dst = out + excl;
+          if (hdr != NULL)                               // record framing (dexqv.c:128-139)
+            { const uint64_t h0 = hdr_off[r];
+              for (uint32_t k = (uint32_t) lane; k < hl; k += 64)
+                dst[k] = hdr[h0 + k];
+              dst += hl;
+            }
+          tag_at = dst + sz[0];
+        }
+      else if (S)
         { dst    = sc.base + sc.slot_off[r];
           tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
         }
@@ -348,7 +541,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               if (q == 0)
                 { const uint32_t tb = finish_tags(ot);
                   if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
-                  else   { bad |= tb ^ sg[1]; dst += sg[1]; }
+                  else   { const uint32_t w1 = CHAIN ? sz[1] : sg[1]; bad |= tb ^ w1; dst += w1; }
                 }
             }
           else                                           // Encode
@@ -393,7 +586,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                 { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
                   const uint32_t tb = encode_all_tags(ot, p1, L, over);
                   if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
-                  else   { bad |= tb ^ sg[1]; dst += sg[1]; }
+                  else   { const uint32_t w1 = CHAIN ? sz[1] : sg[1]; bad |= tb ^ w1; dst += w1; }
                 }
             }
           if (S)
@@ -401,7 +594,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               sum += got;
             }
           else
-            bad |= got ^ sg[line];
+            bad |= got ^ (CHAIN ? (q == 0 ? sz[0] : q == 1 ? sz[2] : q == 2 ? sz[3] : sz[4]) : sg[line]);
           dst += got;
         }
       if (S)
@@ -424,31 +617,6 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
 // table; both 256 B = conflict-free), per byte of the insertion / merge lines one; the pad rule QV.c:436-442 in
 // closed form.  Reads the tokens (~0.7 B per base) and the two plain lines (2 B per base): a memory-bound kernel
 // with a quarter of the encoder's instructions, run for group g + 1 beside the encoder of group g.
-__device__ __forceinline__ uint32_t token_bits(const uint16_t *tok, uint32_t cnt, const uint8_t *slen, const uint8_t *rlen,
-                                               const uint32_t *xend, uint32_t nx)
-{ const uint32_t lane = (uint32_t) lane_id();
-  uint32_t acc = 0;
-  // exception tokens (runs of 127 and more) were priced as run 127 below: swap in the real run's price
-  for (uint32_t j = lane; j < nx; j += 64u)
-    { const uint32_t run = *(xend - 2 * (int) j - 1);
-      acc += (uint32_t) rlen[run > 255u ? 255u : run] - (uint32_t) rlen[TOK_RUN_MAX];
-    }
-  for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
-    { const uint32_t first = k0 + lane * TOK_TP;
-      const uint32_t c     = first < cnt ? (cnt - first < TOK_TP ? cnt - first : TOK_TP) : 0u;
-      u32x4 tw = { 0u, 0u, 0u, 0u };
-      if (c)
-        tw = *(const u32x4_u *) (tok + first);
-      #pragma unroll
-      for (int k = 0; k < (int) TOK_TP; k++)
-        { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
-          const uint32_t l   = (uint32_t) rlen[t16 >> 9] + (uint32_t) slen[(t16 >> 2) & 0x7fu];
-          acc += (uint32_t) k < c ? l : 0u;
-        }
-    }
-  return acc;                                            // (per lane; < 2^32 for entries of < 2^27 symbols)
-}
-
 __global__ __launch_bounds__(FAST_BLOCK)
 void k_qv_sizes_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *seg /* n x 5 */, uint32_t *rec_size,
                      uint32_t *ticket, tok_src tk)
@@ -463,64 +631,15 @@ void k_qv_sizes_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, 
     for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
     { if (tok_unusable(tk.info, r, a.delChar, a.subChar))
         continue;                                        // k_qv_sizes (generic) has this entry
-      const uint32_t  L    = a.len[r];
-      const uint32_t *inf  = tk.info + TOK_INFO * r;
-      const uint64_t  toff = tk.off[r];
-      const bool      over = can_overread(a, line_ptr(a, r, L, 4), L);
-      uint32_t s0 = 0, s2 = 0, s3 = 0, s4 = 0;
-      uint32_t s1 = (L + 3u) >> 2;                       // all tags kept unless the deletion line is run-coded
-      #pragma unroll 1
-      for (int q = 0; q < 4; q++)
-        { const int       line = q ? q + 1 : 0;
-          const int       rci  = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
-          const uint32_t *tab  = s_tok[q];
-          uint64_t T;
-          uint32_t last;
-          if (rci >= 0)                                  // Encode_Run: token lengths (QV.c:475-497)
-            { const int       rs  = q == 0 ? DX_DRUN : DX_SRUN;
-              const uint16_t *tok = (q == 0 ? tk.del : tk.sub) + toff;
-              const uint32_t  cnt = inf[q == 0 ? 0 : 1] & ~TOK_BAD, C = inf[q == 0 ? 2 : 3];
-              T = wave_sum(token_bits(tok, cnt, s_t.len[q], s_t.len[rs],
-                                      (const uint32_t *) ((q == 0 ? tk.del : tk.sub) + tk.off[r + 1]), inf[q == 0 ? 4 : 5]));
-              if (C > 0)                                 // run-only token at the line's end
-                { const uint32_t e = s_tok[rs][C > 255u ? 255u : C];
-                  T   += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
-                  last = TOK_ESC(e) ? 16u : TOK_LEN(e);
-                }
-              else if (cnt > 0)
-                { const uint32_t e = tab[((uint32_t) tok[cnt - 1] >> 2) & 0x7fu];
-                  last = TOK_ESC(e) ? 8u : TOK_LEN(e);
-                }
-              else
-                last = 0;
-              if (q == 0) s1 = (cnt + 3u) >> 2;          // Pack_Tag's count, QV.c:810-819
-            }
-          else                                           // Encode: code lengths of the line's bytes (QV.c:427-434)
-            { const uint8_t *p    = line_ptr(a, r, L, line);
-              const uint32_t mask = !a.lossy ? 0xffu : (q == 1 ? 0xfeu : (q == 2 ? 0xfcu : 0xffu));
-              const uint32_t m4   = mask * 0x01010101u;
-              uint32_t pos = 16u * lane, acc = 0;
-              u32x4 c = fetch(p, pos, L, over);
-              T = 0;
-              for (uint32_t base = 0; base < L; base += DX_STEP)
-                { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
-                  acc += bits_syms_step(c, valid_of(pos, L), s_t.len[q], m4);
-                  c = d;
-                  pos += DX_STEP;
-                  if ((base & 0x3ffffffu) == 0x3fffc00u)           // fold long before a 32-bit lane sum can wrap
-                    { T += wave_sum(acc); acc = 0; }
-                }
-              T   += wave_sum(acc);
-              last = last_piece_plain(tab, p, L, mask);
-            }
-          const uint32_t bytes = seg_bytes(T, last);
-          if (q == 0) s0 = bytes; else if (q == 1) s2 = bytes; else if (q == 2) s3 = bytes; else s4 = bytes;
-        }
+      const uint32_t L = a.len[r];
+      uint32_t sz[5];
+      entry_sizes_fast(a, r, L, tk.info + TOK_INFO * r, tk.off[r], tk.off[r + 1], tk, s_tok, s_t.len,
+                       can_overread(a, line_ptr(a, r, L, 4), L), sz);
       if (lane == 0)
         { const uint32_t hl = hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u;
           uint32_t *sg = seg + 5 * r;
-          sg[0] = s0; sg[1] = s1; sg[2] = s2; sg[3] = s3; sg[4] = s4;
-          rec_size[r] = hl + s0 + s1 + s2 + s3 + s4;
+          sg[0] = sz[0]; sg[1] = sz[1]; sg[2] = sz[2]; sg[3] = sz[3]; sg[4] = sz[4];
+          rec_size[r] = hl + sz[0] + sz[1] + sz[2] + sz[3] + sz[4];
         }
     }
   }
