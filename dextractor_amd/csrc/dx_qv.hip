@@ -232,21 +232,42 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 #ifndef TICKET_BATCH
 #define TICKET_BATCH 2u                  // entries a wave of the histogram / size pass draws at a time
 #endif
-#define HIST_BLOCK   1024
+#ifndef HIST_BLOCK
+#define HIST_BLOCK   1024                // threads of a histogram workgroup ...
+#endif
+#ifndef HIST_PER_CU
+#define HIST_PER_CU  1                   // ... and how many of them a CU holds (LDS: the tables below + 4 KB per wave)
+#endif
 #define HIST_NWAVE   (HIST_BLOCK / 64)
-#define HCOLS        32
+// copies of every fast bin (copy = lane & (copies - 1)): 32 = no two lanes of a 32-lane group ever on one bank.  The plain
+// lines (ins, mrg; del and sub when they have no run character) take 16 updates per lane and step; the run-coded lines'
+// symbol and run bins only see the tokens (a sixth of the symbols, two per lane and round), so fewer copies cost little.
+#ifndef HC_PLAIN
+#define HC_PLAIN     32
+#endif
+#ifndef HC_RSYM
+#define HC_RSYM      32
+#endif
+#ifndef HC_RUN
+#define HC_RUN       32
+#endif
 #define HSYM_FAST    128
 #define HRUN_FAST    64
 
 struct hist_lds
-{ uint32_t sym[4][HSYM_FAST][HCOLS];     // 64 KB
-  uint32_t run[2][HRUN_FAST][HCOLS];     // 16 KB
-  uint32_t slow[6][256];                 //  6 KB
+{ uint32_t plain[2][HSYM_FAST][HC_PLAIN];   // ins, mrg
+  uint32_t rsym[2][HSYM_FAST][HC_RSYM];     // del, sub
+  uint32_t run[2][HRUN_FAST][HC_RUN];       // deletion runs, substitution runs
+  uint32_t slow[6][256];                    // bytes >= 128, runs >= 64, trailing runs, the run characters' own counts
 };
-#define HIST_FAST_WORDS (4 * HSYM_FAST * HCOLS + 2 * HRUN_FAST * HCOLS)
+#define HIST_W_PLAIN (2 * HSYM_FAST * HC_PLAIN)
+#define HIST_W_RSYM  (2 * HSYM_FAST * HC_RSYM)
+#define HIST_W_RUN   (2 * HRUN_FAST * HC_RUN)
+#define HIST_FAST_WORDS (HIST_W_PLAIN + HIST_W_RSYM + HIST_W_RUN)
 
-__device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool full, uint32_t (*h)[HCOLS], uint32_t *slow)
-{ const uint32_t col = (uint32_t) lane_id() & (HCOLS - 1);
+template <int COLS>
+__device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool full, uint32_t (*h)[COLS], uint32_t *slow)
+{ const uint32_t col = (uint32_t) lane_id() & (COLS - 1);
   const bool wide = __any((int) ((c.x | c.y | c.z | c.w) & 0x80808080u));
   if (full && !wide)
     {
@@ -314,12 +335,12 @@ __device__ __forceinline__ bool tok_unusable(const uint32_t *info, uint64_t r, i
 // `count`: the run histogram takes part (entries from del_first / sub_first on, QV.c:1003, 1016).
 // `tok` != NULL: the step's tokens are stored at tok[ntok ...] (tagchunk: this step's deletion tags).
 __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c, int valid, uint32_t sv, uint32_t rc,
-                                               uint32_t &C, uint32_t &nrun, uint32_t (*hs)[HCOLS], uint32_t *slow_s,
-                                               uint32_t (*hr)[HCOLS], uint32_t *slow_r, bool count,
+                                               uint32_t &C, uint32_t &nrun, uint32_t (*hs)[HC_RSYM], uint32_t *slow_s,
+                                               uint32_t (*hr)[HC_RUN], uint32_t *slow_r, bool count,
                                                uint16_t *tok, uint32_t &ntok, uint32_t cap, uint32_t &bad, uint32_t &nexc,
                                                const uint8_t *tagchunk, const uint8_t *tagcode)
 { const int      lane  = lane_id();
-  const uint32_t col   = (uint32_t) lane & (HCOLS - 1);
+  const uint32_t cols  = (uint32_t) lane & (HC_RSYM - 1), colr = (uint32_t) lane & (HC_RUN - 1);
   const uint32_t total = run_collect(R, c, valid, rc);
   nrun += sv - total;                                            // wave-uniform
   bool emit = false;
@@ -358,15 +379,15 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
       for (int k = 0; k < 2; k++)
         if (on[k])
           { if (fastbins)                                            // the usual case, decided once for the wave
-              { if (count) atomicAdd(&hr[run[k]][col], 1u);
-                atomicAdd(&hs[x[k]][col], 1u);
+              { if (count) atomicAdd(&hr[run[k]][colr], 1u);
+                atomicAdd(&hs[x[k]][cols], 1u);
               }
             else
               { if (count)
-                  { if (run[k] < HRUN_FAST) atomicAdd(&hr[run[k]][col], 1u);
+                  { if (run[k] < HRUN_FAST) atomicAdd(&hr[run[k]][colr], 1u);
                     else                    atomicAdd(&slow_r[run[k] > 255u ? 255u : run[k]], 1u);   // QV.c:717-720
                   }
-                if (x[k] < HSYM_FAST) atomicAdd(&hs[x[k]][col], 1u);
+                if (x[k] < HSYM_FAST) atomicAdd(&hs[x[k]][cols], 1u);
                 else                  atomicAdd(&slow_s[x[k]], 1u);
               }
             if (emit)
@@ -400,15 +421,22 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
 
 // bin of the histogram g_hist[6*256] that LDS word k (of the fast tables, then the slow ones) counts
 __device__ __forceinline__ uint32_t hist_bin_of(uint32_t k)
-{ if (k < 4 * HSYM_FAST * HCOLS)
-    return (k / (HSYM_FAST * HCOLS)) * 256u + (k / HCOLS) % HSYM_FAST;
-  k -= 4 * HSYM_FAST * HCOLS;
-  if (k < 2 * HRUN_FAST * HCOLS)
-    return (4u + k / (HRUN_FAST * HCOLS)) * 256u + (k / HCOLS) % HRUN_FAST;
-  return k - 2 * HRUN_FAST * HCOLS;
+{ if (k < HIST_W_PLAIN)                                          // ins, mrg
+    return (DX_INS + k / (HSYM_FAST * HC_PLAIN)) * 256u + (k / HC_PLAIN) % HSYM_FAST;
+  k -= HIST_W_PLAIN;
+  if (k < HIST_W_RSYM)                                           // del, sub
+    return (k / (HSYM_FAST * HC_RSYM) ? DX_SUB : DX_DEL) * 256u + (k / HC_RSYM) % HSYM_FAST;
+  k -= HIST_W_RSYM;
+  if (k < HIST_W_RUN)
+    return (4u + k / (HRUN_FAST * HC_RUN)) * 256u + (k / HC_RUN) % HRUN_FAST;
+  return k - HIST_W_RUN;
 }
 
-__global__ __launch_bounds__(HIST_BLOCK)
+// how many copies the fast bin holding LDS word k has (the words of one bin are consecutive)
+__device__ __forceinline__ uint32_t hist_copies_of(uint32_t k)
+{ return k < HIST_W_PLAIN ? HC_PLAIN : (k < HIST_W_PLAIN + HIST_W_RSYM ? HC_RSYM : HC_RUN); }
+
+__global__ __launch_bounds__(HIST_BLOCK, (HIST_NWAVE * HIST_PER_CU + 3) / 4)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
                unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts)
 { __shared__ hist_lds H;
@@ -420,7 +448,7 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   const int      tid   = threadIdx.x;
   const run_lds  R     = { s_chunk[tid >> 6], s_list[tid >> 6] };
   uint8_t *const tchunk = s_tchunk[tid >> 6];
-  uint32_t *const words = &H.sym[0][0][0];                      // the whole of H as words
+  uint32_t *const words = &H.plain[0][0][0];                    // the whole of H as words
   const uint32_t  nwords = sizeof(hist_lds) / 4;
   const bool      toks  = ts.del != NULL;
 
@@ -473,15 +501,15 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           // in before the step's end, where the wait for the prefetched chunks also waits for every older store.
           if (drun)
             { if (tags) *(u32x4 *) (tchunk + 16 * lane) = t1;    // (run_collect's barrier orders it before the look-ups)
-              hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.sym[DX_DEL], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN],
+              hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.rsym[0], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN],
                              dcnt, tk0, nt0, cap, bad0, nx0, tags ? tchunk : (const uint8_t *) NULL, s_tagcode);
             }
-          else      hist_plain_step(c0, valid, full, H.sym[DX_DEL], H.slow[DX_DEL]);
-          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.sym[DX_SUB], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
+          else      hist_plain_step<HC_RSYM>(c0, valid, full, H.rsym[0], H.slow[DX_DEL]);
+          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.rsym[1], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
                                    scnt, tk4, nt4, cap, bad4, nx4, (const uint8_t *) NULL, s_tagcode);
-          else      hist_plain_step(c4, valid, full, H.sym[DX_SUB], H.slow[DX_SUB]);
-          hist_plain_step(c2, valid, full, H.sym[DX_INS], H.slow[DX_INS]);
-          hist_plain_step(c3, valid, full, H.sym[DX_MRG], H.slow[DX_MRG]);
+          else      hist_plain_step<HC_RSYM>(c4, valid, full, H.rsym[1], H.slow[DX_SUB]);
+          hist_plain_step<HC_PLAIN>(c2, valid, full, H.plain[0], H.slow[DX_INS]);
+          hist_plain_step<HC_PLAIN>(c3, valid, full, H.plain[1], H.slow[DX_MRG]);
           c0 = d0; c2 = d2; c3 = d3; c4 = d4; t1 = u1;
           pos = np;
         }
@@ -520,12 +548,13 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   if (lane == 0 && tot)
     atomicAdd(g_tot, (unsigned long long) tot);
   __syncthreads();
-  // fold the 32 copies of every fast bin (rotated start: the lanes of a wave read distinct banks)
-  for (uint32_t bin = tid; bin < HIST_FAST_WORDS / HCOLS; bin += HIST_BLOCK)
+  // fold the copies of every fast bin (rotated start: the lanes of a wave read distinct banks); one thread per 8 words
+  // (8 divides every copy count), several threads per bin where it has more copies
+  for (uint32_t w8 = tid; w8 < HIST_FAST_WORDS / 8u; w8 += HIST_BLOCK)
     { uint32_t v = 0;
-      for (uint32_t j = 0; j < HCOLS; j++)
-        v += words[bin * HCOLS + ((j + (uint32_t) lane) & (HCOLS - 1))];
-      if (v) atomicAdd(&g_hist[hist_bin_of(bin * HCOLS)], (unsigned long long) v);
+      for (uint32_t j = 0; j < 8u; j++)
+        v += words[w8 * 8u + ((j + (uint32_t) lane) & 7u)];
+      if (v) atomicAdd(&g_hist[hist_bin_of(w8 * 8u)], (unsigned long long) v);
     }
   for (uint32_t k = tid; k < 6 * 256; k += HIST_BLOCK)
     { const uint32_t v = (&H.slow[0][0])[k];
@@ -1649,8 +1678,8 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
     { ts.del = ctx->tk.del; ts.sub = ctx->tk.sub; ts.off = ctx->tk.off; ts.info = ctx->tk.info; ts.list = ctx->tk.list; }
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
-  const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE;       // one 16-wave workgroup per CU
-  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, (int) (hist_blocks < (uint64_t) ctx->num_cu ? hist_blocks : (uint64_t) ctx->num_cu), HIST_BLOCK,
+  const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE, hist_room = (uint64_t) ctx->num_cu * HIST_PER_CU;   // HIST_PER_CU workgroups per CU
+  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
             a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts);
   uint64_t host[6 * 256 + 2];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));

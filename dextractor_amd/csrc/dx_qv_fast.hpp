@@ -422,8 +422,10 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   for (int j = lane; j < TAG_WIN_WORDS; j += 64) ot.win[j] = 0;
   wave_sync();
 
-  for (uint64_t r = next_unit(ticket), nxt; r < a.n; r = nxt)
-    { nxt = next_unit(ticket);
+  // (chained placement: an entry is drawn only when its wave is ready to size and publish it -- an entry held in
+  // reserve behind a whole encode keeps every later entry of the file waiting for its size: 97 ms instead of 14)
+  for (uint64_t r = next_unit(ticket), nxt = 0; r < a.n; r = CHAIN ? next_unit(ticket) : nxt)
+    { if (!CHAIN) nxt = next_unit(ticket);
       if (tok_unusable(tk.info, r, a.delChar, a.subChar))
         { if (CHAIN)                                     // its size (k_qv_sizes, list mode) takes its place in the chain all the same
             { const uint64_t own  = lb.rec_size[r];

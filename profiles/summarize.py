@@ -15,10 +15,15 @@ Writes, under profiles/:
 """
 import csv, glob, json, os, shutil, sys, collections
 
-BENCH_ID = {"k_qv_encode_fast": "k_qv_encode", "k_qv_encode": "k_qv_encode", "k_qv_hist": "k_qv_hist",
-            "k_qv_compact": "k_qv_compact", "k_qv_decode": "k_qv_decode", "k_qv_decode_tags": "k_qv_decode",
-            "k_qv_decode_plain": "k_qv_decode", "k_qv_decode_sub": "k_qv_decode", "k_qv_decode_runs": "k_qv_decode", "k_qv_sizes_fast": "k_qv_sizes",
-            "k_pack2_encode": "k_pack2_encode", "k_pack2_decode": "k_pack2_decode", "k_qv_sizes": "k_qv_sizes"}
+# device kernel -> the id bench.py times it under (dx_kernel_name)
+BENCH_ID = {"k_qv_encode_fast": "k_qv_encode", "k_qv_encode": "k_qv_encode_text", "k_qv_hist": "k_qv_hist",
+            "k_qv_compact": "k_qv_compact", "k_qv_decode": "k_qv_decode", "k_qv_decode_tags": "k_qv_decode_tags",
+            "k_qv_decode_plain": "k_qv_decode_plain", "k_qv_decode_sub": "k_qv_decode_sub", "k_qv_decode_runs": "k_qv_decode_runs",
+            "k_qv_sizes_fast": "k_qv_sizes", "k_qv_sizes": "k_qv_sizes",
+            "k_qv_prescan_del": "k_qv_prescan", "k_qv_prescan_sub": "k_qv_prescan",
+            "k_scan_tiles": "k_scan", "k_scan_sums": "k_scan", "k_scan_apply": "k_scan", "k_scan_apply_base": "k_scan",
+            "k_qv_bounds": "k_scan", "k_tok_rooms": "k_scan", "k_sub_rooms": "k_scan",
+            "k_pack2_encode": "k_pack2_encode", "k_pack2_decode": "k_pack2_decode"}
 
 
 def kname(full):
@@ -53,10 +58,9 @@ def traffic(src, suffix, steps):
                      "launches_sampled": len(f) or len(w)}
         out[name]["hbm_bytes_per_launch"] = (out[name]["fetch_bytes"] or 0) + (out[name]["write_bytes"] or 0)
         lps[name] = max(1, round(out[name]["launches_sampled"] / steps))
-    # per bench kernel id (bench.py lumps the fast and the generic encode kernel, and the two decode kernels)
-    # bench.py times the fast and the generic encode kernel under one id (and the two decode kernels): bytes and
-    # launches of an id are the sums over its kernels, so that bytes per launch there and ms per launch in bench.py
-    # average over the same launches
+    # per bench kernel id: bytes and launches of an id are the sums over its device kernels, so that bytes per launch
+    # there and ms per launch in bench.py average over the same launches (since round 3 every main kernel has an id of
+    # its own: the fast encoder "k_qv_encode", the text-reading one "k_qv_encode_text", each decode kernel its name)
     ids = collections.defaultdict(lambda: {"hbm_bytes_per_step": 0.0, "launches_per_step": 0})
     for name, v in out.items():
         b = BENCH_ID.get(name)
