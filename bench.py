@@ -539,16 +539,16 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
 
 def read_traffic(path, workload, kernel, want, launches_per_step=1, per_step=False):
     """HBM bytes per launch (per_step: per bench step) of the kernels timed under bench id `kernel`, from the
-    committed PMC summary (profiles/traffic.json), when it was collected on the same workload shape; None otherwise."""
+    committed PMC summary (profiles/traffic.json, "bench_ids"), when it was collected on the same workload shape and
+    with the same number of launches per step; None otherwise."""
     try:
-        tf = json.load(open(path))
-        tf = tf.get("workloads", {}).get(workload, tf if workload == "dexqv" else {})
+        tf = json.load(open(path))["workloads"][workload]
         if any(tf.get(k) != v for k, v in want.items()):
             return None
-        if tf.get("launches_per_step", {}).get(kernel, 1) != launches_per_step:
-            return None                                   # profile taken with another grouping
-        v = tf["kernels"].get(kernel, {}).get("hbm_bytes_per_launch")
-        return None if v is None else (v * launches_per_step if per_step else v)
+        e = tf["bench_ids"].get(kernel)
+        if e is None or e["launches_per_step"] != launches_per_step:
+            return None                                   # not profiled, or profiled with another grouping
+        return e["hbm_bytes_per_step"] if per_step else e["hbm_bytes_per_launch"]
     except Exception:
         return None
 

@@ -671,7 +671,18 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
 // plain lines (ins, mrg) two 12-wave workgroups share a CU (78 KB each), 6 waves per SIMD.
 #define DS_BLOCK 768
 #define DS_NWAVE (DS_BLOCK / 64)
+#ifndef DS_PAIR
+#define DS_PAIR  0                                         // 1: two symbols per look-up (pair tables, 16 KB per kind; 1.85 symbols per look-up on the
+                                                           // bench's lines).  Measured SLOWER: k_qv_decode_sub 15.3 ms against 13.4 (profiles/
+                                                           // r03_ab_decode_pair.txt) -- lanes need 8..16 look-ups per group of 16 symbols and the wave
+                                                           // runs to the longest, and a look-up costs more (which of the two, a 128-bit queue for the
+                                                           // output) than the 8 instructions of the fixed-position code below.  Kept for the record.
+#endif
+#if DS_PAIR
+#define DS_WIN   960                                       // words per wave: 3.75 KB (two workgroups per CU beside 2 x 16 KB of tables)
+#else
 #define DS_WIN   1280                                      // words per wave: 5 KB
+#endif
 #ifndef DS_STEPS
 #define DS_STEPS 4                                         // steps of 64 groups per round (one step always fits: <= 515 words)
 #endif
@@ -698,6 +709,29 @@ __device__ __forceinline__ uint32_t wr_symbol(winrd &r, const uint16_t *tab, con
   const uint32_t w = r.hi >> 16;
   const uint32_t e = tab[w >> (16 - DP_BITS)];
   uint32_t len = (e & 31u) ? 32u - (e & 31u) : 0u, sym = e >> 8;
+  if (len == 0)                                            // code longer than the primary index
+    { const uint32_t cnt = lng[0];
+      for (uint32_t k = 1; k <= cnt; k++)
+        { const uint32_t t = lng[k], l = (t >> 8) & 0xffu;
+          if ((w >> (16u - l)) == ((t >> 16) >> (16u - l)))
+            { len = l; sym = t & 0xffu;
+              break;
+            }
+        }
+      if (len == 0) len = 1;                               // no such code (corrupt stream): keep moving
+    }
+  r.hi  = __builtin_amdgcn_alignbit(r.hi, r.lo, 32u - len);
+  r.lo <<= len;
+  r.nb -= (int) len;
+  return sym;
+}
+
+// the same from a pair table (its entries also say what the FIRST code of the window is)
+__device__ __forceinline__ uint32_t wr_symbol2(winrd &r, const uint32_t *tab2, const uint32_t *lng)
+{ wr_fill(r);
+  const uint32_t w = r.hi >> 16;
+  const uint32_t e = tab2[w >> (16 - DP_BITS)];
+  uint32_t len = e ? 32u - (e >> 24) : 0u, sym = (e >> 8) & 0xffu;
   if (len == 0)                                            // code longer than the primary index
     { const uint32_t cnt = lng[0];
       for (uint32_t k = 1; k <= cnt; k++)
@@ -745,13 +779,73 @@ __device__ __forceinline__ void ds_block8(winrd &rd, const uint16_t *tab, const 
   o0 = w[0]; o1 = w[1];
 }
 
+// ---- two symbols per look-up ---------------------------------------------------------------------------------
+// The plain lines' codes are short (insertion QVs 3.2 bits on average, merge QVs 5): the next DP_BITS bits of the stream
+// mostly hold TWO whole codes.  Pair table, indexed by those 12 bits: bits [0,5) = 32 - (bits of what the entry
+// decodes) -- the shift v_alignbit wants, 20..31, so bit 4 is set in every real entry --, bit 5 = the entry holds two
+// symbols, [8,16) the first symbol, [16,24) the second, [24,29) = 32 - the first code's bits (to take only the first
+// when the group has room for one); 0 = the first code is longer than the index (the list of long codes has it).
+// A lane assembles its 16 symbols in a 128-bit queue that moves down by 8 or 16 bits per look-up.
+__device__ __forceinline__ void ds_queue(uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3, uint32_t syms, uint32_t s8)
+{ o0 = __builtin_amdgcn_alignbit(o1, o0, s8);
+  o1 = __builtin_amdgcn_alignbit(o2, o1, s8);
+  o2 = __builtin_amdgcn_alignbit(o3, o2, s8);
+  o3 = (o3 >> s8) | (syms << (32u - s8));
+}
+
+__device__ __forceinline__ u32x4 ds_group16_pair(winrd &rd, const uint32_t *tab2, const uint32_t *lng)
+{ uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, cnt = 0;
+  while (cnt < 16u)
+    { wr_fill(rd);                                         // >= 32 bits: two look-ups of <= 12
+      #pragma unroll
+      for (int h = 0; h < 2; h++)
+        if (cnt < 16u)
+          { const uint32_t e = tab2[rd.hi >> (32 - DP_BITS)];
+            if (e == 0u)                                   // a code longer than the index: by the list
+              { const uint32_t w = rd.hi >> 16, n = lng[0];
+                uint32_t len = 1u, sym = 0u;               // (no such code -- a corrupt stream --: keep moving)
+                for (uint32_t k = 1; k <= n; k++)
+                  { const uint32_t t = lng[k], l = (t >> 8) & 0xffu;
+                    if ((w >> (16u - l)) == ((t >> 16) >> (16u - l)))
+                      { len = l; sym = t & 0xffu;
+                        break;
+                      }
+                  }
+                wr_fill(rd);
+                rd.hi  = __builtin_amdgcn_alignbit(rd.hi, rd.lo, 32u - len);
+                rd.lo <<= len;
+                rd.nb -= (int) len;
+                ds_queue(o0, o1, o2, o3, sym, 8u);
+                cnt += 1u;
+                wr_fill(rd);
+              }
+            else
+              { const bool     two = (e & 32u) != 0u && cnt < 15u;
+                const uint32_t sh  = (e & 32u) != 0u && !two ? e >> 24 : e;
+                rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, sh);
+                rd.lo = __builtin_amdgcn_alignbit(rd.lo, 0u, sh);
+                rd.nb += (int) (sh & 31u) - 32;
+                ds_queue(o0, o1, o2, o3, two ? (e >> 8) & 0xffffu : (e >> 8) & 0xffu, two ? 16u : 8u);
+                cnt += two ? 2u : 1u;
+              }
+          }
+    }
+  const u32x4 v = { o0, o1, o2, o3 };
+  return v;
+}
+
 template <int NK>
 __global__ __launch_bounds__(DS_BLOCK)
 void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds,
                      const uint32_t *sub_idx, const uint64_t *sub_off)
-{ __shared__ uint16_t s_tab[NK][DP_SIZE];                  // 8 KB each
+{
+#if DS_PAIR
+  __shared__ uint32_t s_tab2[NK][DP_SIZE];                 // 16 KB each
+#else
+  __shared__ uint16_t s_tab[NK][DP_SIZE];                  // 8 KB each
+#endif
   __shared__ uint32_t s_long[NK][1 + DX_LONG_MAX];         // 1 KB each
-  __shared__ uint32_t s_win[DS_NWAVE][DS_WIN];             // 60 KB
+  __shared__ uint32_t s_win[DS_NWAVE][DS_WIN];             // 60 KB (45 KB beside pair tables)
   // tables of the kinds present, in the order of their bits (dp_build_tables for a subset)
   { int slot_of[4], nk = 0;
     for (int q = 0; q < 4; q++) slot_of[q] = ((kinds >> q) & 1u) ? nk++ : -1;
@@ -772,9 +866,29 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
                       { len = l; sym = t & 0xffu; }
                   }
               }
+#if DS_PAIR
+            s_tab2[slot_of[q]][i] = len ? (32u - len) | (sym << 8) | ((32u - len) << 24) : 0u;      // one symbol for now
+#else
             s_tab[slot_of[q]][i] = (uint16_t) ((len ? 32u - len : 0u) | (sym << 8));
+#endif
           }
     __syncthreads();
+#if DS_PAIR
+    // pair entries from the one-symbol ones, in place: what a thread reads of ANOTHER entry -- its first code's length
+    // (bits 24..) and symbol (byte 1) -- is the same before and after that entry's own upgrade
+    for (int sl = 0; sl < NK; sl++)
+      for (int i_ = threadIdx.x; i_ < DP_SIZE; i_ += DS_BLOCK)
+        { const uint32_t i = (uint32_t) i_, e1 = s_tab2[sl][i];
+          if (e1)
+            { const uint32_t l1 = 32u - (e1 >> 24);
+              const uint32_t e2 = s_tab2[sl][(i << l1) & (DP_SIZE - 1)];         // the bits behind the first code, zero-filled
+              const uint32_t l2 = e2 ? 32u - (e2 >> 24) : 0u;
+              if (l2 && l1 + l2 <= DP_BITS)                // (a code that ends inside the window did not see the fill)
+                s_tab2[sl][i] = (32u - (l1 + l2)) | 32u | (e1 & 0xff00u) | ((e2 & 0xff00u) << 8) | (e1 & 0xff000000u);
+            }
+        }
+    __syncthreads();
+#endif
   }
   uint32_t *const win  = s_win[threadIdx.x >> 6];
   const int       lane = lane_id();
@@ -802,7 +916,11 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
       uint8_t        *out    = a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u);
       const uint32_t  G      = sub_groups(L);
       const uint8_t  *at8    = (const uint8_t *) (sub_idx + sub_off[r] + (uint64_t) q * sub_words(L));
+#if DS_PAIR
+      const uint32_t *tab    = s_tab2[slot];
+#else
       const uint16_t *tab    = s_tab[slot];
+#endif
       const uint32_t *lng    = s_long[slot];
       const bool      serial = G > 0 && uniform((uint32_t) at8[0]) == SUB_NONE;
       uint32_t base = 0;                                   // bit at which the round's first group starts
@@ -848,15 +966,24 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
                     }
                     uint8_t *o = out + 16ull * g;
                     if (valid == 16u)
-                      { uint32_t x0, x1, x2, x3;
+                      {
+#if DS_PAIR
+                        *(u32x4_u *) o = ds_group16_pair(rd, tab, lng);
+#else
+                        uint32_t x0, x1, x2, x3;
                         ds_block8(rd, tab, lng, x0, x1);
                         ds_block8(rd, tab, lng, x2, x3);
                         const u32x4 v = { x0, x1, x2, x3 };
                         *(u32x4_u *) o = v;
+#endif
                       }
                     else
                       for (uint32_t j = 0; j < valid; j++)   // the ragged end of the line
+#if DS_PAIR
+                        o[j] = (uint8_t) wr_symbol2(rd, tab, lng);
+#else
                         o[j] = (uint8_t) wr_symbol(rd, tab, lng);
+#endif
                     used = 32u * (rd.wi - 1u - ((st[k] - 32u * w0) >> 5)) + (32u - ((st[k] - 32u * w0) & 31u)) - (uint32_t) rd.nb;
                   }
               }

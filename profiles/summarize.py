@@ -41,33 +41,47 @@ def counters(src, sub):
     return per
 
 
-def traffic(src, suffix, steps):
+def bench_launches(src, suffix):
+    """launches per step of every bench kernel id in the profiled run itself (its JSON line: launches over the timed steps)"""
+    try:
+        line = [ln for ln in open(os.path.join(src, "prof_fetch" + suffix + ".json")) if ln.startswith("{")][0]
+        d = json.loads(line)
+        return {k: max(1, round(v["launches"] / d["steps"])) for k, v in d.get("kernels", {}).items()}
+    except Exception:
+        return {}
+
+
+def traffic(src, suffix):
     fe, wr = counters(src, "prof_fetch" + suffix), counters(src, "prof_write" + suffix)
-    out, lps = {}, {}
+    out = {}
     for name in sorted(set(fe) | set(wr)):
         if not name.startswith("k_"):
             continue
         f = fe.get(name, {}).get("FETCH_SIZE", [])
         w = wr.get(name, {}).get("WRITE_SIZE", [])
         # the x2 is for wide coalesced streams (16 B per lane, consecutive lanes consecutive bytes): every kernel here
-        # but the lane-per-stream decoder, whose lanes each read their own line (raw request bytes kept for it)
+        # but the lane-per-stream decoders, whose lanes each read their own line (raw request bytes kept for them)
         scattered = name in ("k_qv_decode", "k_qv_decode_plain", "k_qv_decode_sub", "k_qv_decode_runs")
         out[name] = {"fetch_bytes": sum(f) / len(f) * 1024 * (1 if scattered else 2) if f else None,
                      "fetch_bytes_raw_counter": sum(f) / len(f) * 1024 if f else None,
                      "write_bytes": sum(w) / len(w) * 1024 if w else None,
-                     "launches_sampled": len(f) or len(w)}
+                     "rows_sampled": len(f) or len(w)}
         out[name]["hbm_bytes_per_launch"] = (out[name]["fetch_bytes"] or 0) + (out[name]["write_bytes"] or 0)
-        lps[name] = max(1, round(out[name]["launches_sampled"] / steps))
-    # per bench kernel id: bytes and launches of an id are the sums over its device kernels, so that bytes per launch
-    # there and ms per launch in bench.py average over the same launches (since round 3 every main kernel has an id of
-    # its own: the fast encoder "k_qv_encode", the text-reading one "k_qv_encode_text", each decode kernel its name)
-    ids = collections.defaultdict(lambda: {"hbm_bytes_per_step": 0.0, "launches_per_step": 0})
+    # per bench kernel id (dx_kernel_name: what bench.py times): bytes per launch = the average over the sampled launches
+    # of the id's device kernels; launches per step from the profiled run's own JSON line
+    lps = bench_launches(src, suffix)
+    acc = collections.defaultdict(lambda: [0.0, 0])
     for name, v in out.items():
         b = BENCH_ID.get(name)
         if b:
-            ids[b]["hbm_bytes_per_step"] += v["hbm_bytes_per_launch"] * lps[name]
-            ids[b]["launches_per_step"] += lps[name]
-    return out, lps, ids
+            acc[b][0] += v["hbm_bytes_per_launch"] * v["rows_sampled"]
+            acc[b][1] += v["rows_sampled"]
+    ids = {}
+    for b, (tot, rows) in acc.items():
+        if rows:                                           # (kernels outside the timed steps -- the decoders, the packers -- run once)
+            n = lps.get(b, 1)
+            ids[b] = {"hbm_bytes_per_launch": tot / rows, "launches_per_step": n, "hbm_bytes_per_step": tot / rows * n}
+    return out, ids
 
 
 def main():
@@ -78,21 +92,14 @@ def main():
         ks = glob.glob(os.path.join(src, "prof_stats" + suffix, "*", "*_kernel_stats.csv"))
         if ks:
             shutil.copy(ks[0], os.path.join(here, f"{tag}_kernel_stats{suffix}.csv"))
-    steps = 4                                            # PMC passes: warmup 1 + steps 3
     doc = {"tag": tag, "units": "bytes", "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count on 16 B/lane streams); WRITE_SIZE KiB x 1024",
            "workloads": {}}
-    k, lps, ids = traffic(src, "", steps)
-    dq = {"entries": 1000000, "mean": 10000, "dist": "fixed", "kernels": dict(k), "launches_per_step": dict(lps)}
-    for b, v in ids.items():                             # what bench.py looks up: bytes per launch of its kernel ids
-        n = v["launches_per_step"]
-        dq["kernels"].setdefault(b, {})
-        dq["kernels"][b] = dict(dq["kernels"][b], hbm_bytes_per_launch=v["hbm_bytes_per_step"] / n, hbm_bytes_per_step=v["hbm_bytes_per_step"])
-        dq["launches_per_step"][b] = n
-    doc["workloads"]["dexqv"] = dq
+    k, ids = traffic(src, "")
+    doc["workloads"]["dexqv"] = {"entries": 1000000, "mean": 10000, "dist": "fixed", "kernels": dict(k), "bench_ids": ids}
     for w in ("dexta", "dexar"):
-        k, lps, ids = traffic(src, "_" + w, steps)
+        k, ids = traffic(src, "_" + w)
         if k:
-            doc["workloads"][w] = {"reads": 10000000, "mean": 10000, "kernels": k, "launches_per_step": lps}
+            doc["workloads"][w] = {"reads": 10000000, "mean": 10000, "kernels": k, "bench_ids": ids}
     json.dump(doc, open(os.path.join(here, f"{tag}_traffic.json"), "w"), indent=1)
     json.dump(doc, open(os.path.join(here, "traffic.json"), "w"), indent=1)
     sq = {}
@@ -104,7 +111,7 @@ def main():
         if "SQ_INSTS_VALU" in c:
             c["VALU_per_5KiB_wave_step"] = round(c["SQ_INSTS_VALU"] / 2e6, 1)     # 200 k entries x 10 steps
     json.dump({"tag": tag, "batch": "200000 x 10000", "per_launch": sq}, open(os.path.join(here, f"{tag}_sq_counters.json"), "w"), indent=1)
-    print(json.dumps({w: {kk: round(vv["hbm_bytes_per_launch"] / 1e9, 3) for kk, vv in d["kernels"].items()} for w, d in doc["workloads"].items()}, indent=1))
+    print(json.dumps({w: {kk: round(vv["hbm_bytes_per_step"] / 1e9, 3) for kk, vv in d["bench_ids"].items()} for w, d in doc["workloads"].items()}, indent=1))
 
 
 if __name__ == "__main__":
