@@ -8,6 +8,22 @@
 
 static char g_open_err[512] = "";
 
+#undef hipMalloc
+hipError_t dx_hip_malloc(void **p, size_t bytes)
+{ static int poison = -2;                                   // -2: not looked up yet, -1: off
+  if (poison == -2)
+    { const char *e = getenv("DEXGPU_POISON");
+      poison = (e != NULL && e[0] != '\0') ? (int) (strtol(e, NULL, 0) & 0xff) : -1;
+    }
+  const hipError_t rc = hipMalloc(p, bytes);
+  if (rc == hipSuccess && poison >= 0 && bytes)
+    { (void) hipMemset(*p, poison, bytes);
+      (void) hipDeviceSynchronize();
+    }
+  return rc;
+}
+#define hipMalloc(p, n) dx_hip_malloc((void **) (p), (n))
+
 int dx_fail(dx_ctx *ctx, int code, const char *fmt, ...)
 { char *dst = ctx ? ctx->err : g_open_err;
   va_list ap;
@@ -344,6 +360,7 @@ int dx_scratch(dx_ctx *ctx, size_t bytes, void **p)
         DX_HIP(ctx, hipFree(ctx->d_scratch));
       ctx->d_scratch = NULL;
       ctx->scratch_bytes = 0;
+      ctx->scratch_gen += 1;
       size_t want = bytes + (bytes < ((size_t) 1 << 30) ? bytes / 4 : 0) + 4096;     // (head room only while it is cheap)
       if (budget && want > budget && bytes <= budget) want = bytes;
       hipError_t e = hipMalloc(&ctx->d_scratch, want);

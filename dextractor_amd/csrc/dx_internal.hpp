@@ -83,6 +83,8 @@ struct dx_ctx
   uint64_t *d_u64;             // small device scalars (prescan keys, totals, ...)
   void     *d_scratch;         // grow-only scratch (scan partials, histograms, sizes)
   size_t    scratch_bytes;
+  uint64_t  scratch_gen;       // counts its re-allocations: a new block may come back at the OLD address with other contents,
+                               //   so "did it move" must never be asked of the pointer
   uint64_t *d_scan;            // grow-only tile sums of dx_scan_u32 (its callers hold d_scratch)
   size_t    scan_words;
   uint8_t  *h_stage[2];        // pinned staging of dx_d2h_stream (made at its first call)
@@ -93,6 +95,11 @@ struct dx_ctx
 };
 
 int  dx_fail(dx_ctx *ctx, int code, const char *fmt, ...);
+// Every device allocation of the library goes through dx_hip_malloc: with DEXGPU_POISON=<byte value> in the environment
+// the new block is filled with that byte, so that a kernel reading memory nothing has written yet does so reproducibly
+// (a debugging aid; fresh device memory usually reads as zeros and hides such reads).
+hipError_t dx_hip_malloc(void **p, size_t bytes);
+#define hipMalloc(p, n) dx_hip_malloc((void **) (p), (n))
 int  dx_scratch(dx_ctx *ctx, size_t bytes, void **p);
 uint64_t dx_budget(const dx_ctx *ctx);
 int  dx_after_pending(dx_ctx *ctx);

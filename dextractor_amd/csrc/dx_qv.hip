@@ -87,6 +87,17 @@ __device__ __forceinline__ u32x4 fetch(const uint8_t *p, uint32_t pos, uint32_t 
 __device__ __forceinline__ int valid_of(uint32_t pos, uint32_t L)
 { return pos >= L ? 0 : (L - pos >= 16u ? 16 : (int) (L - pos)); }
 
+// the chunks of the step that starts at `base` (wave-uniform): when the whole step lies inside the line -- every step
+// but a line's last -- one scalar test sends all 64 lanes to a bare 16-byte load; fetch()'s per-lane bounds tests
+// (three branches on the execution mask and the clearing of the result registers, per line and step) are then paid
+// only at the line's end
+__device__ __forceinline__ u32x4 fetch_step(const uint8_t *p, uint32_t base, uint32_t L, bool over)
+{ const uint32_t pos = base + 16u * (uint32_t) lane_id();
+  if (base + DX_STEP <= L)
+    return *(const u32x4_u *) (p + pos);
+  return fetch(p, pos, L, over);
+}
+
 #define BYTE_OF(c, b) ((chunk_word(c, (b) >> 2) >> (8 * ((b) & 3))) & 0xffu)
 
 // ---------------------------------------------------------------------------------------------
@@ -253,6 +264,12 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 #endif
 #define HSYM_FAST    128
 #define HRUN_FAST    64
+#ifndef HIST_BARE_FETCH
+#define HIST_BARE_FETCH 1
+#endif
+#ifndef HIST_ADAPTIVE
+#define HIST_ADAPTIVE 1
+#endif
 
 struct hist_lds
 { uint32_t plain[2][HSYM_FAST][HC_PLAIN];   // ins, mrg
@@ -350,67 +367,87 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
     }
   uint32_t odd = 0;
   // Two tokens per lane per round (i and i + 64): the look-ups of a token hang on each other (position ->
-  // symbol and tag -> tag code), so the second token's chain runs in the shadow of the first one's.
-  for (uint32_t i0 = 0; i0 < total; i0 += 128u)
-    { uint32_t pos[2], x[2], run[2], tg[2];
-      bool     on[2];
-      #pragma unroll
-      for (int k = 0; k < 2; k++)
-        { const uint32_t i = i0 + 64u * k + (uint32_t) lane;
-          on[k]  = i < total;
-          pos[k] = on[k] ? (uint32_t) R.list[i] : 0u;
-          run[k] = on[k] && i ? (uint32_t) R.list[i - 1] + 1u : 0u - C;       // where the run in front of the token starts
-        }
-      #pragma unroll
-      for (int k = 0; k < 2; k++)
-        { x[k]   = R.chunk[pos[k]];
-          tg[k]  = tagchunk != NULL ? (uint32_t) tagchunk[pos[k]] : 0u;
-          run[k] = pos[k] - run[k];
-        }
-      if (emit && tagchunk != NULL)
-        {
-          #pragma unroll
-          for (int k = 0; k < 2; k++)
-            tg[k] = tagcode[tg[k]];
-        }
-      const bool fastbins = !__any((on[0] && (run[0] >= HRUN_FAST || x[0] >= HSYM_FAST)) ||
-                                   (on[1] && (run[1] >= HRUN_FAST || x[1] >= HSYM_FAST)));
-      #pragma unroll
-      for (int k = 0; k < 2; k++)
-        if (on[k])
-          { if (fastbins)                                            // the usual case, decided once for the wave
-              { if (count) atomicAdd(&hr[run[k]][colr], 1u);
-                atomicAdd(&hs[x[k]][cols], 1u);
-              }
-            else
-              { if (count)
-                  { if (run[k] < HRUN_FAST) atomicAdd(&hr[run[k]][colr], 1u);
-                    else                    atomicAdd(&slow_r[run[k] > 255u ? 255u : run[k]], 1u);   // QV.c:717-720
-                  }
-                if (x[k] < HSYM_FAST) atomicAdd(&hs[x[k]][cols], 1u);
-                else                  atomicAdd(&slow_s[x[k]], 1u);
-              }
-            if (emit)
-              { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9);
-                tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;
-                odd |= x[k] >= 128u ? 1u : 0u;
-              }
-          }
-      if (emit && !fastbins && __any((on[0] && run[0] >= TOK_RUN_MAX) || (on[1] && run[1] >= TOK_RUN_MAX)))   // rare: exception records, in token order
-        { uint32_t *xend = (uint32_t *) (tok + cap);
-          #pragma unroll
-          for (int k = 0; k < 2; k++)
-            { const bool     lg = on[k] && run[k] >= TOK_RUN_MAX;
-              const uint64_t m  = __ballot(lg);
-              if (lg)
-                { const uint32_t j = nexc + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-                  *(xend - 2 * (int) j - 2) = ntok + i0 + 64u * (uint32_t) k + (uint32_t) lane;
-                  *(xend - 2 * (int) j - 1) = run[k];
-                }
-              nexc += (uint32_t) __popcll(m);
-            }
-        }
+  // symbol and tag -> tag code), so the second token's chain runs in the shadow of the first one's.  When 64 or
+  // fewer tokens are left the round takes one per lane: a step of a line with 15 % non-run symbols has ~154 tokens,
+  // and the third token slot of every lane would be paid for 26 of them.
+#define RUNS_ROUND(NK)                                                                                          \
+    { uint32_t pos[NK], x[NK], run[NK], tg[NK];                                                                 \
+      bool     on[NK];                                                                                          \
+      _Pragma("unroll")                                                                                         \
+      for (int k = 0; k < NK; k++)                                                                              \
+        { const uint32_t i = i0 + 64u * k + (uint32_t) lane;                                                    \
+          on[k]  = i < total;                                                                                   \
+          pos[k] = on[k] ? (uint32_t) R.list[i] : 0u;                                                           \
+          run[k] = on[k] && i ? (uint32_t) R.list[i - 1] + 1u : 0u - C;       /* where the run in front of the token starts */ \
+        }                                                                                                       \
+      _Pragma("unroll")                                                                                         \
+      for (int k = 0; k < NK; k++)                                                                              \
+        { x[k]   = R.chunk[pos[k]];                                                                             \
+          tg[k]  = tagchunk != NULL ? (uint32_t) tagchunk[pos[k]] : 0u;                                         \
+          run[k] = pos[k] - run[k];                                                                             \
+        }                                                                                                       \
+      if (emit && tagchunk != NULL)                                                                             \
+        {                                                                                                       \
+          _Pragma("unroll")                                                                                     \
+          for (int k = 0; k < NK; k++)                                                                          \
+            tg[k] = tagcode[tg[k]];                                                                             \
+        }                                                                                                       \
+      bool slowbin = false;                                                                                     \
+      _Pragma("unroll")                                                                                         \
+      for (int k = 0; k < NK; k++)                                                                              \
+        slowbin = slowbin || (on[k] && (run[k] >= HRUN_FAST || x[k] >= HSYM_FAST));                             \
+      if (!__any(slowbin))                                         /* the usual case, decided once for the wave: */ \
+        {                                                          /* every run < 64 (no clamp), every symbol < 128 */ \
+          _Pragma("unroll")                                                                                     \
+          for (int k = 0; k < NK; k++)                                                                          \
+            if (on[k])                                                                                          \
+              { if (count) atomicAdd(&hr[run[k]][colr], 1u);                                                    \
+                atomicAdd(&hs[x[k]][cols], 1u);                                                                 \
+                if (emit)                                                                                       \
+                  tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) (tg[k] | (x[k] << 2) | (run[k] << 9)); \
+              }                                                                                                 \
+        }                                                                                                       \
+      else                                                                                                      \
+        {                                                                                                       \
+          _Pragma("unroll")                                                                                     \
+          for (int k = 0; k < NK; k++)                                                                          \
+            if (on[k])                                                                                          \
+              { if (count)                                                                                      \
+                  { if (run[k] < HRUN_FAST) atomicAdd(&hr[run[k]][colr], 1u);                                   \
+                    else                    atomicAdd(&slow_r[run[k] > 255u ? 255u : run[k]], 1u);   /* QV.c:717-720 */ \
+                  }                                                                                             \
+                if (x[k] < HSYM_FAST) atomicAdd(&hs[x[k]][cols], 1u);                                           \
+                else                  atomicAdd(&slow_s[x[k]], 1u);                                             \
+                if (emit)                                                                                       \
+                  { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9); \
+                    tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;                                  \
+                    odd |= x[k] >= 128u ? 1u : 0u;                                                              \
+                  }                                                                                             \
+              }                                                                                                 \
+          bool lng = false;                                                                                     \
+          _Pragma("unroll")                                                                                     \
+          for (int k = 0; k < NK; k++)                                                                          \
+            lng = lng || (on[k] && run[k] >= TOK_RUN_MAX);                                                      \
+          if (emit && __any(lng))                                  /* rare: exception records, in token order */ \
+            { uint32_t *xend = (uint32_t *) (tok + cap);                                                        \
+              _Pragma("unroll")                                                                                 \
+              for (int k = 0; k < NK; k++)                                                                      \
+                { const bool     lg = on[k] && run[k] >= TOK_RUN_MAX;                                           \
+                  const uint64_t m  = __ballot(lg);                                                             \
+                  if (lg)                                                                                       \
+                    { const uint32_t j = nexc + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));               \
+                      *(xend - 2 * (int) j - 2) = ntok + i0 + 64u * (uint32_t) k + (uint32_t) lane;             \
+                      *(xend - 2 * (int) j - 1) = run[k];                                                       \
+                    }                                                                                           \
+                  nexc += (uint32_t) __popcll(m);                                                               \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
     }
+  for (uint32_t i0 = 0; i0 < total; )
+    if (!HIST_ADAPTIVE || total - i0 > 64u) { RUNS_ROUND(2) i0 += 128u; }
+    else                                    { RUNS_ROUND(1) i0 += 64u; }
+#undef RUNS_ROUND
   if (emit)
     { ntok += total;
       if (__any((int) odd)) bad = 1;
@@ -490,10 +527,17 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
       if (tags) t1 = fetch(p1, pos, L, over);          // the deletion tags travel with the step's other chunks
       for (uint32_t base = 0; base < L; base += DX_STEP)
         { const uint32_t np = pos + DX_STEP;           // next step's chunks go in flight first
-          const u32x4 d0 = fetch(p0, np, L, over), d2 = fetch(p2, np, L, over);
-          const u32x4 d3 = fetch(p3, np, L, over), d4 = fetch(p4, np, L, over);
-          u32x4 u1 = d0;
-          if (tags) u1 = fetch(p1, np, L, over);
+          u32x4 d0, d2, d3, d4, u1 = { 0u, 0u, 0u, 0u };    // (u1 never a copy of d0: the copy would wait for d0's load right here)
+          if (HIST_BARE_FETCH && base + 2u * DX_STEP <= L)   // the whole next step is inside the lines: bare loads (see fetch_step)
+            { d0 = *(const u32x4_u *) (p0 + np); d2 = *(const u32x4_u *) (p2 + np);
+              d3 = *(const u32x4_u *) (p3 + np); d4 = *(const u32x4_u *) (p4 + np);
+              if (tags) u1 = *(const u32x4_u *) (p1 + np);
+            }
+          else
+            { d0 = fetch(p0, np, L, over); d2 = fetch(p2, np, L, over);
+              d3 = fetch(p3, np, L, over); d4 = fetch(p4, np, L, over);
+              if (tags) u1 = fetch(p1, np, L, over);
+            }
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
           const bool     full  = sv == DX_STEP;
           const int      valid = valid_of(pos, L);
@@ -1288,9 +1332,24 @@ struct enc_scratch
   const uint64_t *slot_off;    // n + 1
   uint32_t       *seg_out;     // n x 5
   uint32_t       *rec_size;    // n
+  uint64_t        lo, hi;      // the slot offsets this launch may use: [lo, hi) is its scratch region (see slot_sane)
 };
 
 __host__ __device__ __forceinline__ uint32_t tag_room(uint32_t L) { return (((L + 3u) >> 2) + 7u) & ~3u; }
+
+// The encoders form addresses from index arrays (entry offsets and lengths, slot offsets, token slots).  An index that
+// does not hold together is reported (status bit 6) and its entry skipped -- never followed into memory: a kernel that
+// faults takes the process, and possibly the node's GPUs, with it.  Wave-uniform tests on values the wave holds anyway.
+#define DX_ST_INDEX 64u
+__device__ __forceinline__ bool entry_sane(const qv_args &a, uint64_t r, uint32_t L)
+{ if (a.text_bytes == 0) return true;                    // extent of the text unknown to the library
+  const uint64_t o = a.off[r], span = 4ull * ((uint64_t) L + a.pad) + L;
+  return o <= a.text_bytes && span <= a.text_bytes - o;
+}
+__device__ __forceinline__ bool slot_sane(const enc_scratch &sc, uint64_t r, uint32_t L)
+{ const uint64_t s0 = sc.slot_off[r], s1 = sc.slot_off[r + 1];
+  return s0 >= sc.lo && s1 <= sc.hi && s1 >= s0 && s1 - s0 >= tag_room(L);
+}
 
 __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
@@ -1352,6 +1411,10 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
       uint32_t       *sgw = sc.seg_out + 5 * r;
       uint8_t        *dst, *tag_at = NULL;
       uint32_t        sum = 0;
+      if (!entry_sane(a, r, L) || (S && !slot_sane(sc, r, L)))
+        { if (lane == 0) atomicOr(status, DX_ST_INDEX);
+          continue;
+        }
       if (S)
         { dst    = sc.base + sc.slot_off[r];
           tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
@@ -1888,7 +1951,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL },
+            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 },
             (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0,
             sub_sink{ NULL, NULL, NULL });
   uint32_t st = 0;
@@ -2084,12 +2147,12 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
       if (sx_idx)
         hipLaunchKernelGGL(FAST_K_IX, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
                            (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
       else
         hipLaunchKernelGGL(FAST_K, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
                            (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
       dx_prof_end_on(ctx, A);
@@ -2099,7 +2162,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
           hipLaunchKernelGGL(k_qv_encode, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * ENC_WAVES)),
                              dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
                              (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
-                             d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL }, (const uint32_t *) ctx->tk.list,
+                             d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, (const uint32_t *) ctx->tk.list,
                              (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), out_cap, sx_g);
           dx_prof_end_on(ctx, A);
         }
@@ -2165,17 +2228,17 @@ static int onepass_chain(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr
   DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
   if (sx_idx)
     DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX_CHAIN, fast_grid(ctx, n), FAST_BLOCK,
-              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
               ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb);
   else
     DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_CHAIN, fast_grid(ctx, n), FAST_BLOCK,
-              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL }, tg,
+              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
               ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb);
   if (odd)                                               // ... and their records, in place
     { DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
       DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, ctx->tk.unusable < n ? ctx->tk.unusable : n, 4 * ENC_WAVES), DX_BLOCK,
                 a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, (const uint64_t *) d_rec_off, (const uint32_t *) d_seg, d_out,
-                ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL }, (const uint32_t *) ctx->tk.list,
+                ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, (const uint32_t *) ctx->tk.list,
                 (const unsigned long long *) ctx->tk.count, (uint64_t) 0, (const uint32_t *) ctx->tk.info, out_cap, sx);
     }
   uint64_t tot = 0, waits[4] = { 0, 0, 0, 0 };
@@ -2313,6 +2376,7 @@ layout:
   uint64_t      *d_slot = NULL, *d_tile = NULL, *d_gran = NULL;
   // the slot layout needs the scratch to exist and the scratch's size needs the layout: lay out, size,
   // and lay out again if the buffer had to move.  Three rotating regions hold the groups' slots.
+  uint64_t laid_gen = 0;                                 // the scratch generation the layout below was computed in
   for (int pass = 0; pass < 2; pass++)
     { void *base;
       if ((e = dx_scratch(ctx, small + (G > 2 ? 3 : G) * region + 512, &base)))
@@ -2331,7 +2395,10 @@ layout:
             }
           return e;
         }
-      if (pass == 1 && base == (void *) scr) break;
+      // (not "base == scr": a re-allocated block can come back at the old address, with whatever its pages held before --
+      // the layout of pass 0 gone, and the encoder sent after junk offsets)
+      if (pass == 1 && ctx->scratch_gen == laid_gen) break;
+      laid_gen = ctx->scratch_gen;
       scr     = (uint8_t *) base;
       d_bound = (uint32_t *) scr;
       d_size  = (uint32_t *) (scr + a4);
@@ -2385,7 +2452,7 @@ layout:
       const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL, ctx->sx.none };
       if (g >= 3)
         DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 3) & 7], 0));    // the region is free once its last tenant has been copied out
-      const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0 };
+      const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0, gstart[g], gstart[g] + region };
       if (fast)                                          // entries with usable tokens: walked from the tokens
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
@@ -2451,6 +2518,9 @@ static int onepass_end(dx_ctx *ctx, uint64_t *total)
       hipStreamSynchronize(A) != hipSuccess)
     return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
   if (total) *total = tot;
+  if (st & DX_ST_INDEX)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry's offsets, length or scratch / token slot do not hold together "
+                   "(d_off / d_len beyond text_bytes, or an internal index is corrupt)");
   if (st & 2u)
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry outgrew its scratch slot");
   if (tot > ctx->op.out_cap || (st & 8u))

@@ -293,7 +293,7 @@ __device__ __forceinline__ void entry_sizes_fast(const qv_args &a, uint64_t r, u
           u32x4 c = fetch(p, pos, L, over);
           T = 0;
           for (uint32_t base = 0; base < L; base += DX_STEP)
-            { const u32x4 d = fetch(p, pos + DX_STEP, L, over);
+            { const u32x4 d = fetch_step(p, base + DX_STEP, L, over);
               acc += bits_syms_step(c, valid_of(pos, L), s_len[q], m4);
               c = d;
               pos += DX_STEP;
@@ -374,6 +374,9 @@ __device__ __forceinline__ uint64_t chain_place(const lb_chain &lb, uint64_t r, 
   return excl;
 }
 
+#ifndef FAST_GUARDS
+#define FAST_GUARDS 0
+#endif
 #ifndef FAST_WAVES
 #define FAST_WAVES 4                                     // waves per SIMD the register allocation leaves room for
 #endif
@@ -444,6 +447,21 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
       const uint32_t  L      = a.len[r];
       const uint32_t *inf    = tk.info + TOK_INFO * r;
       const uint64_t  toff   = tk.off[r];
+#if FAST_GUARDS
+      { // the entry inside the text, its token slot as k_tok_rooms laid it out, the counts inside the slot, its scratch
+        // slot inside this launch's region: else report and skip (see entry_sane).  Off by default: the branch makes the
+        // wave wait for ALL of an entry's index words before its first data load goes out -- one more memory round trip
+        // per entry, 0.6 ms of the 13.7 a 1 M-entry batch takes (measured); the generic kernel (the odd entries) has them
+        const uint64_t room = tk.off[r + 1] - toff;
+        const bool ok = entry_sane(a, r, L) && room == tok_room(L) &&
+                        (inf[0] & ~TOK_BAD) <= room && (inf[1] & ~TOK_BAD) <= room && inf[4] <= room / 4u && inf[5] <= room / 4u &&
+                        (!S || slot_sane(sc, r, L));
+        if (!ok)
+          { if (lane == 0) atomicOr(status, DX_ST_INDEX);
+            continue;
+          }
+      }
+#endif
       const uint32_t *sg     = seg + 5 * r;              // (direct mode)
       uint32_t       *sgw    = sc.seg_out + 5 * r;       // (scratch mode)
       uint8_t        *dst, *tag_at;
@@ -554,7 +572,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               u32x4 c = fetch(p, pos, L, over);
 #define PLAIN_LOOP(STAB)                                                                        \
               for (uint32_t base = 0; base < L; base += DX_STEP)                                 \
-                { const u32x4 d = fetch(p, pos + DX_STEP, L, over);                              \
+                { const u32x4 d = fetch_step(p, base + DX_STEP, L, over);                        \
                   encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4, sm); \
                   c = d;                                                                         \
                   pos += DX_STEP;                                                                \
@@ -562,7 +580,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
 #define PAIR_LOOP(STAB, PTAB, LO)                                                               \
               { const uint32_t lo4 = (LO) * 0x01010101u;                                         \
                 for (uint32_t base = 0; base < L; base += DX_STEP)                               \
-                  { const u32x4 d = fetch(p, pos + DX_STEP, L, over);                            \
+                  { const u32x4 d = fetch_step(p, base + DX_STEP, L, over);                      \
                     const bool full = L - base >= DX_STEP;                                       \
                     if (!full || !encode_plain_step_pair(o, c, PTAB, lo4, m4, sm))               \
                       encode_plain_step(o, c, valid_of(pos, L), full, tab, STAB, m4, sm);        \

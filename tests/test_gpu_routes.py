@@ -148,3 +148,40 @@ def test_chained_placement_small_files_and_text_entries(monkeypatch):
         assert info["direct"] == 2 and info["text_entries"] == 4
         for case in O.cases("quiva"):                                   # the reference's own bytes
             assert ctx.dexqv(O.golden(case["input"] + ".quiva"), "-l" in case["flags"]) == O.golden(case["name"] + ".dexqv")
+
+
+_POISON_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import _oracle as O
+from dextractor_amd import api, synth
+with api.Context(0) as ctx:
+    # growing inputs: every internal buffer is re-allocated (and poisoned) again and again, the scratch among them
+    for n, mean, seed in [(3, 300, 1), (40, 8000, 3), (700, 900, 4), (24, 30000, 6), (2000, 1500, 9), (5, 200, 2)]:
+        c = synth.make_quiva(n, seed=seed, mean=mean)
+        for lossy in (0, 1):
+            dx = ctx.dexqv(c.text, lossy)
+            assert dx == O.dexqv(c.text, lossy), ("dexqv", n, mean, lossy)
+        assert ctx.undexqv(ctx.dexqv(c.text), upper=True) == c.text, ("undexqv", n, mean)
+    for kind, enc, dec in (("fasta", ctx.dexta, lambda x: ctx.undexta(x, upper=True)), ("arrow", ctx.dexar, ctx.undexar)):
+        for n, mean in [(5, 300), (300, 9000), (30, 40000)]:
+            f = synth.make_seqfile(kind, n, seed=n, mean=mean)
+            img = enc(f.text)
+            assert img == (O.dexta(f.text) if kind == "fasta" else O.dexar(f.text)), (kind, n)
+            if kind == "fasta":
+                assert dec(img) == f.text, (kind, n)
+print("POISON_OK")
+"""
+
+
+@pytest.mark.parametrize("poison", ["0xa5", "0xff"])
+def test_poisoned_allocations_change_nothing(poison):
+    """DEXGPU_POISON fills every device allocation of the library with a byte: a kernel that reads memory nothing has
+    written (fresh device memory usually reads as zeros and hides it) then fails here instead of in the field.  Found
+    this way: dx_qv_encode_onepass took a re-allocated scratch buffer that came back at its old address for the old
+    buffer and kept a slot layout that was gone (a GPU memory fault when the pages held another process's leftovers)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _POISON_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DEXGPU_POISON=poison), capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"POISON_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
