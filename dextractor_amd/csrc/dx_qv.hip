@@ -44,6 +44,12 @@
 #ifndef ENC_WAVES
 #define ENC_WAVES 4
 #endif
+// perturbation experiments (tools/microbench/hist_time.py): parts of k_qv_hist compiled out -- wrong results, a kernel
+// time that says what the part costs.  1: no token rounds, 2: no plain lines, 4: no position lists, 8: no token stores,
+// 16: no run-coded lines at all
+#ifndef HIST_SKIP
+#define HIST_SKIP 0
+#endif
 
 struct qv_args
 { const uint8_t  *text;
@@ -122,6 +128,7 @@ __device__ __forceinline__ uint32_t run_collect(const run_lds &R, const u32x4 &c
   uint32_t       idx  = incl - cnt;
   *(u32x4 *) (R.chunk + 16 * lane) = c;
   const uint32_t p16 = 16u * (uint32_t) lane;
+  if (HIST_SKIP & 4) nr = 0;
   while (nr)
     { R.list[idx++] = (uint16_t) (p16 + (uint32_t) __builtin_ctz(nr));
       nr &= nr - 1u;
@@ -267,9 +274,6 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 #ifndef HIST_BARE_FETCH
 #define HIST_BARE_FETCH 1
 #endif
-#ifndef HIST_ADAPTIVE
-#define HIST_ADAPTIVE 1
-#endif
 
 struct hist_lds
 { uint32_t plain[2][HSYM_FAST][HC_PLAIN];   // ins, mrg
@@ -367,87 +371,68 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
     }
   uint32_t odd = 0;
   // Two tokens per lane per round (i and i + 64): the look-ups of a token hang on each other (position ->
-  // symbol and tag -> tag code), so the second token's chain runs in the shadow of the first one's.  When 64 or
-  // fewer tokens are left the round takes one per lane: a step of a line with 15 % non-run symbols has ~154 tokens,
-  // and the third token slot of every lane would be paid for 26 of them.
-#define RUNS_ROUND(NK)                                                                                          \
-    { uint32_t pos[NK], x[NK], run[NK], tg[NK];                                                                 \
-      bool     on[NK];                                                                                          \
-      _Pragma("unroll")                                                                                         \
-      for (int k = 0; k < NK; k++)                                                                              \
-        { const uint32_t i = i0 + 64u * k + (uint32_t) lane;                                                    \
-          on[k]  = i < total;                                                                                   \
-          pos[k] = on[k] ? (uint32_t) R.list[i] : 0u;                                                           \
-          run[k] = on[k] && i ? (uint32_t) R.list[i - 1] + 1u : 0u - C;       /* where the run in front of the token starts */ \
-        }                                                                                                       \
-      _Pragma("unroll")                                                                                         \
-      for (int k = 0; k < NK; k++)                                                                              \
-        { x[k]   = R.chunk[pos[k]];                                                                             \
-          tg[k]  = tagchunk != NULL ? (uint32_t) tagchunk[pos[k]] : 0u;                                         \
-          run[k] = pos[k] - run[k];                                                                             \
-        }                                                                                                       \
-      if (emit && tagchunk != NULL)                                                                             \
-        {                                                                                                       \
-          _Pragma("unroll")                                                                                     \
-          for (int k = 0; k < NK; k++)                                                                          \
-            tg[k] = tagcode[tg[k]];                                                                             \
-        }                                                                                                       \
-      bool slowbin = false;                                                                                     \
-      _Pragma("unroll")                                                                                         \
-      for (int k = 0; k < NK; k++)                                                                              \
-        slowbin = slowbin || (on[k] && (run[k] >= HRUN_FAST || x[k] >= HSYM_FAST));                             \
-      if (!__any(slowbin))                                         /* the usual case, decided once for the wave: */ \
-        {                                                          /* every run < 64 (no clamp), every symbol < 128 */ \
-          _Pragma("unroll")                                                                                     \
-          for (int k = 0; k < NK; k++)                                                                          \
-            if (on[k])                                                                                          \
-              { if (count) atomicAdd(&hr[run[k]][colr], 1u);                                                    \
-                atomicAdd(&hs[x[k]][cols], 1u);                                                                 \
-                if (emit)                                                                                       \
-                  tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) (tg[k] | (x[k] << 2) | (run[k] << 9)); \
-              }                                                                                                 \
-        }                                                                                                       \
-      else                                                                                                      \
-        {                                                                                                       \
-          _Pragma("unroll")                                                                                     \
-          for (int k = 0; k < NK; k++)                                                                          \
-            if (on[k])                                                                                          \
-              { if (count)                                                                                      \
-                  { if (run[k] < HRUN_FAST) atomicAdd(&hr[run[k]][colr], 1u);                                   \
-                    else                    atomicAdd(&slow_r[run[k] > 255u ? 255u : run[k]], 1u);   /* QV.c:717-720 */ \
-                  }                                                                                             \
-                if (x[k] < HSYM_FAST) atomicAdd(&hs[x[k]][cols], 1u);                                           \
-                else                  atomicAdd(&slow_s[x[k]], 1u);                                             \
-                if (emit)                                                                                       \
-                  { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9); \
-                    tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;                                  \
-                    odd |= x[k] >= 128u ? 1u : 0u;                                                              \
-                  }                                                                                             \
-              }                                                                                                 \
-          bool lng = false;                                                                                     \
-          _Pragma("unroll")                                                                                     \
-          for (int k = 0; k < NK; k++)                                                                          \
-            lng = lng || (on[k] && run[k] >= TOK_RUN_MAX);                                                      \
-          if (emit && __any(lng))                                  /* rare: exception records, in token order */ \
-            { uint32_t *xend = (uint32_t *) (tok + cap);                                                        \
-              _Pragma("unroll")                                                                                 \
-              for (int k = 0; k < NK; k++)                                                                      \
-                { const bool     lg = on[k] && run[k] >= TOK_RUN_MAX;                                           \
-                  const uint64_t m  = __ballot(lg);                                                             \
-                  if (lg)                                                                                       \
-                    { const uint32_t j = nexc + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));               \
-                      *(xend - 2 * (int) j - 2) = ntok + i0 + 64u * (uint32_t) k + (uint32_t) lane;             \
-                      *(xend - 2 * (int) j - 1) = run[k];                                                       \
-                    }                                                                                           \
-                  nexc += (uint32_t) __popcll(m);                                                               \
-                }                                                                                               \
-            }                                                                                                   \
-        }                                                                                                       \
+  // symbol and tag -> tag code), so the second token's chain runs in the shadow of the first one's.
+  if (HIST_SKIP & 8) emit = false;
+  for (uint32_t i0 = 0; i0 < ((HIST_SKIP & 1) ? 0u : total); i0 += 128u)
+    { uint32_t pos[2], x[2], run[2], tg[2];
+      bool     on[2];
+      #pragma unroll
+      for (int k = 0; k < 2; k++)
+        { const uint32_t i = i0 + 64u * k + (uint32_t) lane;
+          on[k]  = i < total;
+          pos[k] = on[k] ? (uint32_t) R.list[i] : 0u;
+          run[k] = on[k] && i ? (uint32_t) R.list[i - 1] + 1u : 0u - C;       // where the run in front of the token starts
+        }
+      #pragma unroll
+      for (int k = 0; k < 2; k++)
+        { x[k]   = R.chunk[pos[k]];
+          tg[k]  = tagchunk != NULL ? (uint32_t) tagchunk[pos[k]] : 0u;
+          run[k] = pos[k] - run[k];
+        }
+      if (emit && tagchunk != NULL)
+        {
+          #pragma unroll
+          for (int k = 0; k < 2; k++)
+            tg[k] = tagcode[tg[k]];
+        }
+      const bool fastbins = !__any((on[0] && (run[0] >= HRUN_FAST || x[0] >= HSYM_FAST)) ||
+                                   (on[1] && (run[1] >= HRUN_FAST || x[1] >= HSYM_FAST)));
+      #pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (on[k])
+          { if (fastbins)                                            // the usual case, decided once for the wave
+              { if (count) atomicAdd(&hr[run[k]][colr], 1u);
+                atomicAdd(&hs[x[k]][cols], 1u);
+              }
+            else
+              { if (count)
+                  { if (run[k] < HRUN_FAST) atomicAdd(&hr[run[k]][colr], 1u);
+                    else                    atomicAdd(&slow_r[run[k] > 255u ? 255u : run[k]], 1u);   // QV.c:717-720
+                  }
+                if (x[k] < HSYM_FAST) atomicAdd(&hs[x[k]][cols], 1u);
+                else                  atomicAdd(&slow_s[x[k]], 1u);
+              }
+            if (emit)
+              { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9);
+                tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;
+                odd |= x[k] >= 128u ? 1u : 0u;
+              }
+          }
+      if (emit && !fastbins && __any((on[0] && run[0] >= TOK_RUN_MAX) || (on[1] && run[1] >= TOK_RUN_MAX)))   // rare: exception records, in token order
+        { uint32_t *xend = (uint32_t *) (tok + cap);
+          #pragma unroll
+          for (int k = 0; k < 2; k++)
+            { const bool     lg = on[k] && run[k] >= TOK_RUN_MAX;
+              const uint64_t m  = __ballot(lg);
+              if (lg)
+                { const uint32_t j = nexc + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+                  *(xend - 2 * (int) j - 2) = ntok + i0 + 64u * (uint32_t) k + (uint32_t) lane;
+                  *(xend - 2 * (int) j - 1) = run[k];
+                }
+              nexc += (uint32_t) __popcll(m);
+            }
+        }
     }
-  for (uint32_t i0 = 0; i0 < total; )
-    if (!HIST_ADAPTIVE || total - i0 > 64u) { RUNS_ROUND(2) i0 += 128u; }
-    else                                    { RUNS_ROUND(1) i0 += 64u; }
-#undef RUNS_ROUND
   if (emit)
     { ntok += total;
       if (__any((int) odd)) bad = 1;
@@ -527,7 +512,13 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
       if (tags) t1 = fetch(p1, pos, L, over);          // the deletion tags travel with the step's other chunks
       for (uint32_t base = 0; base < L; base += DX_STEP)
         { const uint32_t np = pos + DX_STEP;           // next step's chunks go in flight first
-          u32x4 d0, d2, d3, d4, u1 = { 0u, 0u, 0u, 0u };    // (u1 never a copy of d0: the copy would wait for d0's load right here)
+          // ... but behind an explicit wait for everything older.  vmcnt counts loads and stores alike and the number
+          // of token stores of a step is not known to the compiler, so every wait it inserts itself is vmcnt(0) -- and
+          // wherever in the step that falls, it then also waits for the chunks requested a moment ago: no prefetch at
+          // all.  With the wait HERE this step's chunks (requested a whole step ago) and the last step's token stores
+          // are complete, nothing in the step below needs another wait, and the new requests have the whole step.
+          __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+          u32x4 d0, d2, d3, d4, u1 = c0;               // (without tags u1 is never looked at; a copy of d0 would wait for d0's load)
           if (HIST_BARE_FETCH && base + 2u * DX_STEP <= L)   // the whole next step is inside the lines: bare loads (see fetch_step)
             { d0 = *(const u32x4_u *) (p0 + np); d2 = *(const u32x4_u *) (p2 + np);
               d3 = *(const u32x4_u *) (p3 + np); d4 = *(const u32x4_u *) (p4 + np);
@@ -543,17 +534,21 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           const int      valid = valid_of(pos, L);
           // The run-coded lines first: their token stores then have the two plain lines' worth of work to complete
           // in before the step's end, where the wait for the prefetched chunks also waits for every older store.
-          if (drun)
+          if (HIST_SKIP & 16) { }
+          else if (drun)
             { if (tags) *(u32x4 *) (tchunk + 16 * lane) = t1;    // (run_collect's barrier orders it before the look-ups)
               hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.rsym[0], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN],
                              dcnt, tk0, nt0, cap, bad0, nx0, tags ? tchunk : (const uint8_t *) NULL, s_tagcode);
             }
           else      hist_plain_step<HC_RSYM>(c0, valid, full, H.rsym[0], H.slow[DX_DEL]);
-          if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.rsym[1], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
+          if (HIST_SKIP & 16) { }
+          else if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.rsym[1], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
                                    scnt, tk4, nt4, cap, bad4, nx4, (const uint8_t *) NULL, s_tagcode);
           else      hist_plain_step<HC_RSYM>(c4, valid, full, H.rsym[1], H.slow[DX_SUB]);
-          hist_plain_step<HC_PLAIN>(c2, valid, full, H.plain[0], H.slow[DX_INS]);
-          hist_plain_step<HC_PLAIN>(c3, valid, full, H.plain[1], H.slow[DX_MRG]);
+          if (!(HIST_SKIP & 2))
+            { hist_plain_step<HC_PLAIN>(c2, valid, full, H.plain[0], H.slow[DX_INS]);
+              hist_plain_step<HC_PLAIN>(c3, valid, full, H.plain[1], H.slow[DX_MRG]);
+            }
           c0 = d0; c2 = d2; c3 = d3; c4 = d4; t1 = u1;
           pos = np;
         }
@@ -975,7 +970,13 @@ __device__ __forceinline__ uint32_t fsr(uint32_t hi, uint32_t lo, uint32_t s)
 // fits (one round); if the window is too full it is drained first, and with pathological code
 // tables a step is split at lane boundaries into several rounds.  `incl` = inclusive prefix sum
 // of the lanes' bit counts `nb`; the statement block receives `bit_`, this lane's bit offset.
-#define FOR_EACH_ROUND(o, incl, nb, ...)                                                         \
+// FOR_EACH_ROUND drains a well-filled window behind the step; FOR_EACH_ROUND_LATE leaves that to the caller's loop,
+// which does it at the START of its next step, behind the request for the chunk after: the drain's stores and that
+// load then have a whole step to complete in before anything waits for them (vmcnt counts both, and a wait the
+// compiler places is always for everything outstanding).
+#define FOR_EACH_ROUND(o, incl, nb, ...)       FOR_EACH_ROUND_(o, incl, nb, true, __VA_ARGS__)
+#define FOR_EACH_ROUND_LATE(o, incl, nb, ...)  FOR_EACH_ROUND_(o, incl, nb, false, __VA_ARGS__)
+#define FOR_EACH_ROUND_(o, incl, nb, DRAIN, ...)                                                 \
   { uint32_t done_ = 0, lo_ = 0;                                                                \
     const int lane_ = lane_id();                                                                \
     while (lo_ < 64u)                                                                           \
@@ -994,7 +995,7 @@ __device__ __forceinline__ uint32_t fsr(uint32_t hi, uint32_t lo, uint32_t s)
         done_ = upto_;                                                                          \
         lo_   = hi_;                                                                            \
       }                                                                                         \
-    if ((o).winbits >= QV_FLUSH_BITS)                                                           \
+    if ((DRAIN) && (o).winbits >= QV_FLUSH_BITS)                                                \
       flush_quads((o), false);                                                                  \
   }
 
@@ -1089,6 +1090,8 @@ __device__ __forceinline__ void sub_step(sub_mark &m, uint32_t nb, uint32_t vali
 struct sub_sink { uint32_t *idx; const uint64_t *off; uint32_t *none; };      // idx == NULL: none wanted; none: counts the RUN_NONE lines
 
 // one step of Encode (QV.c:427-434): 16 table look-ups per lane, prefix sum, bits into the window
+// (LATE: the caller drains the window, see FOR_EACH_ROUND_LATE)
+template <bool LATE = false>
 __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, int valid, bool full,
                                                   const uint32_t *tab, const uint32_t *stab, uint32_t m4, sub_mark &sm)
 { uint32_t tok[16];
@@ -1120,7 +1123,7 @@ __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, i
   if (fast)
     { // every token has 1..24 bits and the lane's string fits 128 bits: branch-free packing.  The
       // dummies of a ragged last chunk append one zero bit each, shifted out again at the end.
-      FOR_EACH_ROUND(o, incl, nb,
+      FOR_EACH_ROUND_(o, incl, nb, !LATE,
         { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
           _Pragma("unroll")
           for (int b = 0; b < 16; b++)
@@ -1133,7 +1136,7 @@ __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, i
         })
     }
   else
-    { FOR_EACH_ROUND(o, incl, nb,
+    { FOR_EACH_ROUND_(o, incl, nb, !LATE,
         { bit_acc s;
           acc_begin(s, bit_);
           _Pragma("unroll 1")

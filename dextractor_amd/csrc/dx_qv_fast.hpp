@@ -9,6 +9,12 @@
 // Entries are written into scratch slots exactly as the generic kernel's scratch mode does (del, ins,
 // mrg, sub compactly; tags at the slot's end) and their five sizes recorded; entries whose tokens are
 // marked unusable are left to the generic kernel.
+// perturbation experiments (tools/microbench/hist_time.py --encode): parts of k_qv_encode_fast compiled out -- wrong
+// output, a kernel time that says what the part costs.  1: no run-coded lines, 2: no plain lines, 4: bits are not placed
+// in the window (plain lines), 8: one-symbol steps instead of pair tables
+#ifndef FAST_SKIP
+#define FAST_SKIP 0
+#endif
 #define TOK_TP 8u                                        // tokens a lane takes per pass (one 16-byte load)
 
 struct tok_src
@@ -34,14 +40,27 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
 { const uint32_t lane = (uint32_t) lane_id();
   uint32_t *g16 = gix ? groups + lane : (uint32_t *) NULL;
   uint32_t  wide = 0;                                              // a group that does not fit its 16 bits
+  // a pass's tokens are requested a pass ahead, and the windows are drained at the start of a pass behind that request
+  // (see FOR_EACH_ROUND_LATE): loads and stores then have a pass to complete in
+#define TOK_PASS(K0, M_, T_, FIRST_, C_)                                                                   \
+      const uint32_t M_     = cnt - (K0) < 64u * TOK_TP ? cnt - (K0) : 64u * TOK_TP;                        \
+      const uint32_t T_     = (M_ + 63u) >> 6;                     /* tokens per lane in this pass (wave-uniform) */ \
+      const uint32_t FIRST_ = (K0) + lane * T_;                                                             \
+      const uint32_t C_     = FIRST_ < (K0) + M_ ? ((K0) + M_ - FIRST_ < T_ ? (K0) + M_ - FIRST_ : T_) : 0u;
+  u32x4 tw = { 0u, 0u, 0u, 0u };
+  if (cnt)
+    { TOK_PASS(0u, m0, T0, first0, c0)
+      if (c0) tw = *(const u32x4_u *) (tok + first0);              // (may read up to 7 tokens past the count: inside the padded buffer)
+    }
   for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
-    { const uint32_t m     = cnt - k0 < 64u * TOK_TP ? cnt - k0 : 64u * TOK_TP;
-      const uint32_t T     = (m + 63u) >> 6;                       // tokens per lane in this pass (wave-uniform)
-      const uint32_t first = k0 + lane * T;
-      const uint32_t c     = first < k0 + m ? (k0 + m - first < T ? k0 + m - first : T) : 0u;
-      u32x4 tw = { 0u, 0u, 0u, 0u };
-      if (c)
-        tw = *(const u32x4_u *) (tok + first);                    // (may read up to 7 tokens past the count: inside the padded buffer)
+    { TOK_PASS(k0, m, T, first, c)
+      u32x4 twn = { 0u, 0u, 0u, 0u };
+      if (k0 + 64u * TOK_TP < cnt)
+        { TOK_PASS(k0 + 64u * TOK_TP, mn, Tn, firstn, cn)
+          if (cn) twn = *(const u32x4_u *) (tok + firstn);
+        }
+      if (o.winbits >= QV_FLUSH_BITS) flush_quads(o, false);
+      if (TAGS && ot.winbits >= TAG_FLUSH_BITS) flush_quads(ot, true);
       uint32_t rt[TOK_TP], st[TOK_TP];
       #pragma unroll
       for (int k = 0; k < (int) TOK_TP; k++)                       // all look-ups first: one round of LDS waits per pass
@@ -103,11 +122,11 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           wide |= ((zor & 32u) || span > 0xffffu || wave_total(incl) > RUN_PASSBITS) ? 1u : 0u;
         }
       if (!__any((int) ((zor & 32u) | (nb > 128u))))
-        { FOR_EACH_ROUND(o, incl, nb,
+        { FOR_EACH_ROUND_LATE(o, incl, nb,
             { place_bits128(o.win, bit_, nb, w0, w1, w2, w3); })
         }
       else                                    // a symbol or run without a code, or a string > 128 bits
-        { FOR_EACH_ROUND(o, incl, nb,
+        { FOR_EACH_ROUND_LATE(o, incl, nb,
             { bit_acc s;
               acc_begin(s, bit_);
               _Pragma("unroll 1")
@@ -134,10 +153,10 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
                 atomicOr(&ot.win[w + 1], v << (32u - sh));
             }
           ot.winbits += 2u * m;
-          if (ot.winbits >= TAG_FLUSH_BITS)
-            flush_quads(ot, true);
         }
+      tw = twn;
     }
+#undef TOK_PASS
   if (gix)
     { const bool none = __any((int) wide) != 0;
       if (lane == 0)
@@ -215,12 +234,13 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
     return false;
   const uint32_t incl = wave_incl_scan(nb);
   sub_step(sm, nb, 16u, false);
-  FOR_EACH_ROUND(o, incl, nb,
+  FOR_EACH_ROUND_LATE(o, incl, nb,
     { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
       _Pragma("unroll")
       for (int k = 0; k < 8; k++)
         STOK_APPEND(tok[k])
-      place_bits128(o.win, bit_, nb, w0, w1, w2, w3);
+      if (!(FAST_SKIP & 4) || w3 == 0x12345u)
+        place_bits128(o.win, bit_, nb, w0, w1, w2, w3);
     })
   return true;
 }
@@ -377,6 +397,9 @@ __device__ __forceinline__ uint64_t chain_place(const lb_chain &lb, uint64_t r, 
 #ifndef FAST_GUARDS
 #define FAST_GUARDS 0
 #endif
+#ifndef FAST_TICKET
+#define FAST_TICKET 2u                                   // entries a wave draws at a time
+#endif
 #ifndef FAST_WAVES
 #define FAST_WAVES 4                                     // waves per SIMD the register allocation leaves room for
 #endif
@@ -427,8 +450,14 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
 
   // (chained placement: an entry is drawn only when its wave is ready to size and publish it -- an entry held in
   // reserve behind a whole encode keeps every later entry of the file waiting for its size: 97 ms instead of 14)
-  for (uint64_t r = next_unit(ticket), nxt = 0; r < a.n; r = CHAIN ? next_unit(ticket) : nxt)
-    { if (!CHAIN) nxt = next_unit(ticket);
+  // Entries are drawn FAST_TICKET at a time: every draw is an atomic on ONE address, ~11 ns each chip-wide whoever asks
+  // (a kernel doing nothing but drawing its 500 k tickets takes 5.8 ms), so a million single draws are 11 ms of the
+  // counter's time inside a 13.7 ms kernel.
+  const uint32_t TB = CHAIN ? 1u : FAST_TICKET;
+  for (uint64_t r0 = next_unit(ticket, TB), nxt = 0; r0 < a.n; r0 = CHAIN ? next_unit(ticket) : nxt)
+  { if (!CHAIN) nxt = next_unit(ticket, TB);
+  for (uint64_t r = r0; r < r0 + TB && r < a.n; r++)
+    {
       if (tok_unusable(tk.info, r, a.delChar, a.subChar))
         { if (CHAIN)                                     // its size (k_qv_sizes, list mode) takes its place in the chain all the same
             { const uint64_t own  = lb.rec_size[r];
@@ -523,6 +552,9 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
           o.seg = dst; o.wordbase = 0; o.winbits = 0;
           uint32_t got;
 
+          if ((FAST_SKIP & 1) && rci >= 0) { got = 0; }
+          else if ((FAST_SKIP & 2) && rci < 0) { got = 0; }
+          else
           if (rci >= 0)                                  // Encode_Run from the tokens; for del also the tags
             { const int       rs   = q == 0 ? DX_DRUN : DX_SRUN;
               const uint32_t *rtab = s_tok[rs];
@@ -573,7 +605,8 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
 #define PLAIN_LOOP(STAB)                                                                        \
               for (uint32_t base = 0; base < L; base += DX_STEP)                                 \
                 { const u32x4 d = fetch_step(p, base + DX_STEP, L, over);                        \
-                  encode_plain_step(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4, sm); \
+                  if (o.winbits >= QV_FLUSH_BITS) flush_quads(o, false);   /* behind the load: see FOR_EACH_ROUND_LATE */ \
+                  encode_plain_step<true>(o, c, valid_of(pos, L), L - base >= DX_STEP, tab, STAB, m4, sm); \
                   c = d;                                                                         \
                   pos += DX_STEP;                                                                \
                 }
@@ -582,8 +615,9 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                 for (uint32_t base = 0; base < L; base += DX_STEP)                               \
                   { const u32x4 d = fetch_step(p, base + DX_STEP, L, over);                      \
                     const bool full = L - base >= DX_STEP;                                       \
+                    if (o.winbits >= QV_FLUSH_BITS) flush_quads(o, false);   /* behind the load */ \
                     if (!full || !encode_plain_step_pair(o, c, PTAB, lo4, m4, sm))               \
-                      encode_plain_step(o, c, valid_of(pos, L), full, tab, STAB, m4, sm);        \
+                      encode_plain_step<true>(o, c, valid_of(pos, L), full, tab, STAB, m4, sm);  \
                     c = d;                                                                       \
                     pos += DX_STEP;                                                              \
                   }                                                                              \
@@ -591,11 +625,11 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               sub_mark sm;
               sub_begin(sm, SUB && sx.idx ? sx.idx + sx.off[r] + (uint64_t) q * sub_words(L) : (uint32_t *) NULL);
               if (q == 1)
-                { if (pair_lo_ins != PAIR_NONE) PAIR_LOOP(s_stok[1], s_pair[0], pair_lo_ins)
+                { if (!(FAST_SKIP & 8) && pair_lo_ins != PAIR_NONE) PAIR_LOOP(s_stok[1], s_pair[0], pair_lo_ins)
                   else                          { PLAIN_LOOP(s_stok[1]) }
                 }
               else if (q == 2)
-                { if (pair_lo_mrg != PAIR_NONE) PAIR_LOOP(s_stok[2], s_pair[1], pair_lo_mrg)
+                { if (!(FAST_SKIP & 8) && pair_lo_mrg != PAIR_NONE) PAIR_LOOP(s_stok[2], s_pair[1], pair_lo_mrg)
                   else                          { PLAIN_LOOP(s_stok[2]) }
                 }
               else             { PLAIN_LOOP(s_stok[q]) }
@@ -625,6 +659,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
       if (bad && lane == 0)
         atomicOr(status, 2u);                            // slot overflow / a size differs from what k_qv_sizes_fast computed
     }
+  }
 }
 
 
