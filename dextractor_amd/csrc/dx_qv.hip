@@ -1414,7 +1414,11 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
       uint32_t       *sgw = sc.seg_out + 5 * r;
       uint8_t        *dst, *tag_at = NULL;
       uint32_t        sum = 0;
-      if (!entry_sane(a, r, L) || (S && !slot_sane(sc, r, L)))
+      if (!entry_sane(a, r, L))                          // (two tests, not one: the joint condition costs four registers,
+        { if (lane == 0) atomicOr(status, DX_ST_INDEX);  //  and 112 is this kernel's budget beside the compaction)
+          continue;
+        }
+      if (S && !slot_sane(sc, r, L))
         { if (lane == 0) atomicOr(status, DX_ST_INDEX);
           continue;
         }
