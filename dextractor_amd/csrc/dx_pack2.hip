@@ -28,6 +28,9 @@
                                          // 1: 32.8-35.5, 2: 33.8-35.9, 4: 39.0-39.3, 8: 41-42, 4 + non-temporal stores: 37.7-39.1 --
                                          // profiles/r03_ab_pack2.txt; more stores in flight per wave do not help this write-bound kernel)
 #endif
+#ifndef P2D_PIPE
+#define P2D_PIPE      1                  // k_pack2_decode: hand-pipelined main loop (0: every step through the checked loop)
+#endif
 #ifndef P2D_NT
 #define P2D_NT        0                  // k_pack2_decode: non-temporal stores for the text
 #endif
@@ -136,8 +139,8 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
               if (x2) atomicOr(&o.win[w + 2], x2);
             }
           o.winbits += 2u * wave_total(incl);
-          if (o.winbits >= P2_FLUSH_BITS)
-            flush_quads(o, true);
+          if (o.winbits >= P2_FLUSH_BITS)                // (drained at the START of the next step, behind its requests -- what pays
+            flush_quads(o, true);                        //  in k_qv_encode_fast -- this kernel is slower: 29.5 ms against 28.3)
           cA = dA; cB = dB;
           pos += P2_STEP;
         }
@@ -237,9 +240,74 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
       const uint32_t T    = L + (L + width - 1u) / width;        // letters + newlines
       uint32_t line = line0, col = col0;
 
-      // P2D_UNROLL steps of 1 KiB per iteration, their 8-byte loads issued together (a wave's loads and stores retire in
-      // issue order, so the wait for a step's load is also a wait for the stores before it); 1 measured best, see above
-      for (uint32_t base = 0; base < T; base += P2D_UNROLL * DX_STEP)
+      // Main loop: the steps in which every lane takes the fast path (16 letters from one 8-byte load; all but a read's
+      // last one or two), software-pipelined by hand.  A wave's loads and stores are counted together (vmcnt) and retire
+      // in issue order, and left to itself the compiler follows each 8-byte load with a wait for EVERYTHING outstanding:
+      // the load's whole latency and the acknowledgement of the step before's store, every step.  Here the issue order
+      // per step is [wait vmcnt(1): this step's load is back, the last step's store may still be on its way] [request
+      // the next step's 8 bytes] [16 letters] [store]; two steps per iteration with the two loads in registers of their
+      // own (a copy of a requested register would wait for it).
+      uint32_t base = 0;
+#if P2D_PIPE
+#define P2D_ALLFAST(B) (!narrow && (B) + DX_STEP < T && (((B) + DX_STEP - 16u) >> 2) + 8u <= clen)
+#define P2D_ADVANCE(LN, CL) { LN += dline; CL += dcol; if (CL >= W1) { CL -= W1; LN += 1u; } }
+#define P2D_LOAD(B, LN) (*(const u64_u *) (src + (((B) + 16u * (uint32_t) lane - (LN)) >> 2)))
+#define P2D_STEP_FAST(RAW, B, LN, CL)                                                                        \
+          { const uint32_t q0 = (B) + 16u * (uint32_t) lane, i0 = q0 - (LN), nlpos = width - (CL);           \
+            const uint64_t be = ((uint64_t) __builtin_bswap32((uint32_t) (RAW)) << 32) | __builtin_bswap32((uint32_t) ((RAW) >> 32)); \
+            uint32_t cw = (uint32_t) ((be << (2u * (i0 & 3u))) >> 32);                                       \
+            if (nlpos < 16u)                                                                                 \
+              { const uint32_t K = 30u - 2u * nlpos;           /* open a 2-bit hole at slot nlpos */         \
+                const uint32_t keep = ~((4u << K) - 1u);       /* slots before it */                         \
+                cw = (cw & keep) | ((cw & ~keep) >> 2);                                                      \
+              }                                                                                              \
+            u32x4 v;                                                                                         \
+            v.x = s_quad[cw >> 24];                                                                          \
+            v.y = s_quad[(cw >> 16) & 0xffu];                                                                \
+            v.z = s_quad[(cw >> 8) & 0xffu];                                                                 \
+            v.w = s_quad[cw & 0xffu];                                                                        \
+            if (nlpos < 16u)                                                                                 \
+              { const uint32_t m = 0xffu << (8u * (nlpos & 3u)), j = nlpos >> 2;                             \
+                const uint32_t nl4 = 0x0a0a0a0au;                                                            \
+                v.x = j == 0u ? (v.x & ~m) | (nl4 & m) : v.x;                                                \
+                v.y = j == 1u ? (v.y & ~m) | (nl4 & m) : v.y;                                                \
+                v.z = j == 2u ? (v.z & ~m) | (nl4 & m) : v.z;                                                \
+                v.w = j == 3u ? (v.w & ~m) | (nl4 & m) : v.w;                                                \
+              }                                                                                              \
+            *(u32x4_u *) (dst + q0) = v;                                                                     \
+          }
+      if (P2D_ALLFAST(0u))
+        { uint32_t lineA = line, colA = col, lineB = line, colB = col;
+          uint64_t rawA = P2D_LOAD(0u, lineA), rawB = 0;
+          __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the first step has no store in front of it
+          for (;;)
+            { // (the waits stand at the head of each half, on every path into it: a wait on one branch only does not
+              // count for the compiler where the branches meet, and it adds one of its own, for everything)
+              __builtin_amdgcn_s_waitcnt(0x0F71);          // vmcnt(1): rawA is back (requested before the last store)
+              bool ok = P2D_ALLFAST(base + DX_STEP);       // wave-uniform
+              lineB = lineA; colB = colA;
+              P2D_ADVANCE(lineB, colB)
+              if (ok) rawB = P2D_LOAD(base + DX_STEP, lineB);
+              P2D_STEP_FAST(rawA, base, lineA, colA)
+              base += DX_STEP;
+              if (!ok) { line = lineB; col = colB; break; }
+              __builtin_amdgcn_s_waitcnt(0x0F71);          // vmcnt(1): rawB is back
+              ok = P2D_ALLFAST(base + DX_STEP);
+              lineA = lineB; colA = colB;
+              P2D_ADVANCE(lineA, colA)
+              if (ok) rawA = P2D_LOAD(base + DX_STEP, lineA);
+              P2D_STEP_FAST(rawB, base, lineB, colB)
+              base += DX_STEP;
+              if (!ok) { line = lineA; col = colA; break; }
+            }
+        }
+#undef P2D_STEP_FAST
+#undef P2D_LOAD
+#undef P2D_ADVANCE
+#undef P2D_ALLFAST
+#endif
+      // the rest (and everything, for narrow lines): P2D_UNROLL steps of 1 KiB per iteration, checked lane by lane
+      for (; base < T; base += P2D_UNROLL * DX_STEP)
         { uint64_t raw[P2D_UNROLL];
           uint32_t i0k[P2D_UNROLL], nlk[P2D_UNROLL];
           bool     fastk[P2D_UNROLL];
