@@ -1336,6 +1336,7 @@ struct enc_scratch
   uint32_t       *seg_out;     // n x 5
   uint32_t       *rec_size;    // n
   uint64_t        lo, hi;      // the slot offsets this launch may use: [lo, hi) is its scratch region (see slot_sane)
+  uint32_t        ready;       // ORed into every rec_size word written (FC_READY on the follow route, dx_qv_fast.hpp; else 0)
 };
 
 __host__ __device__ __forceinline__ uint32_t tag_room(uint32_t L) { return (((L + 3u) >> 2) + 7u) & ~3u; }
@@ -1526,7 +1527,8 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
       if (S)
         { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
           if (lane == 0)
-            sc.rec_size[r] = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
+            __hip_atomic_store(&sc.rec_size[r], (sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u)) | sc.ready,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       if (bad && lane == 0)
         atomicOr(status, 2u);                            // sizes disagree with k_qv_sizes / slot overflow
@@ -1611,6 +1613,8 @@ static constexpr auto FAST_K          = &k_qv_encode_fast<false, false>;
 static constexpr auto FAST_K_IX       = &k_qv_encode_fast<true, false>;
 static constexpr auto FAST_K_CHAIN    = &k_qv_encode_fast<false, true>;
 static constexpr auto FAST_K_IX_CHAIN = &k_qv_encode_fast<true, true>;
+static constexpr auto FAST_K_FOLLOW   = &k_qv_encode_fast<false, false, true>;
+static constexpr auto FAST_K_IX_FOLLOW = &k_qv_encode_fast<true, false, true>;
 
 // =============================================================================================
 //  C-ABI
@@ -1958,7 +1962,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 },
+            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 },
             (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0,
             sub_sink{ NULL, NULL, NULL });
   uint32_t st = 0;
@@ -2154,14 +2158,14 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
       if (sx_idx)
         hipLaunchKernelGGL(FAST_K_IX, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
-                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
+                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
       else
         hipLaunchKernelGGL(FAST_K, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
-                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
+                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
       dx_prof_end_on(ctx, A);
       if (odd)
         { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
@@ -2169,7 +2173,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
           hipLaunchKernelGGL(k_qv_encode, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * ENC_WAVES)),
                              dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
                              (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
-                             d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, (const uint32_t *) ctx->tk.list,
+                             d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, (const uint32_t *) ctx->tk.list,
                              (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), out_cap, sx_g);
           dx_prof_end_on(ctx, A);
         }
@@ -2235,17 +2239,17 @@ static int onepass_chain(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr
   DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
   if (sx_idx)
     DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX_CHAIN, fast_grid(ctx, n), FAST_BLOCK,
-              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
-              ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb);
+              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, tg,
+              ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb, follow_copy{});
   else
     DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_CHAIN, fast_grid(ctx, n), FAST_BLOCK,
-              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
-              ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb);
+              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, tg,
+              ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb, follow_copy{});
   if (odd)                                               // ... and their records, in place
     { DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
       DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, ctx->tk.unusable < n ? ctx->tk.unusable : n, 4 * ENC_WAVES), DX_BLOCK,
                 a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, (const uint64_t *) d_rec_off, (const uint32_t *) d_seg, d_out,
-                ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, (const uint32_t *) ctx->tk.list,
+                ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, (const uint32_t *) ctx->tk.list,
                 (const unsigned long long *) ctx->tk.count, (uint64_t) 0, (const uint32_t *) ctx->tk.info, out_cap, sx);
     }
   uint64_t tot = 0, waits[4] = { 0, 0, 0, 0 };
@@ -2320,12 +2324,16 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // table-derived slot bounds), two from 240 k entries on so that half of the compaction is hidden.
   // Measured, 1 M x 10 kb, ms per step: 2 equal groups 31.0, 4: 31.3, 8: 32.9, 16: 35.0, 64: 46.7;
   // 40 % / 30 % / 30 % in three regions: 31.4; 7 groups with a halving tail: 32.7.
+  // DEXGPU_FOLLOW: the encoder moves every record to its place itself (follow_copy, dx_qv_fast.hpp): no compaction kernel,
+  // no overlap to arrange -- one group if its slots fit the memory, else groups one after the other in ONE region
+  const bool follow = getenv("DEXGPU_FOLLOW") != NULL && getenv("DEXGPU_FOLLOW")[0] != '0' && onepass_tokens_ok(ctx, b);
+  const int  regions_max = follow ? 1 : 3;
   uint64_t gb[ONEPASS_MAX_GROUPS + 1];
   int      G = 1;
   { const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
     const uint64_t syms = b->text_bytes ? b->text_bytes / 5 / n : 0;   // per entry (a file image: five lines each)
     const uint64_t per_entry = syms ? syms * bits / 8 + syms / 4 + 128 : 0;       // mean slot bound
-    if (n >= 240000) G = 2;
+    if (n >= 240000 && !follow) G = 2;
     if (per_entry)
       { while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
         // ... and as the free device memory allows (the scratch that exists counts as free: it is replaced): more,
@@ -2338,11 +2346,11 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
           avail = (uint64_t) free_b + ctx->scratch_bytes;
         if (avail)
           while (G < ONEPASS_MAX_GROUPS &&
-                 (uint64_t) (G > 2 ? 3 : G) * ((n + G - 1) / G * per_entry) + 28 * n + (budget ? 0 : 1ull << 30) > avail)
+                 (uint64_t) (G > regions_max ? regions_max : G) * ((n + G - 1) / G * per_entry) + 28 * n + (budget ? 0 : 1ull << 30) > avail)
             G++;
         ctx->route.avail_bytes = avail;
       }
-    else if (n >= 240000)
+    else if (n >= 240000 && !follow)
       G = (int) (n / 250000) > 2 ? (int) (n / 250000) : 2;
     if (G < ctx->onepass_min_groups) G = ctx->onepass_min_groups;      // (what an earlier call had to fall back to)
     if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
@@ -2376,17 +2384,19 @@ layout:
   }
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
-  const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255);
+  const size_t   ftile  = (((n + 63) / 64 + 2) * 8 + 255) & ~(size_t) 255;             // follow route: a status word per 64 entries
+  const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255) + ftile;
   uint64_t       region = 0, gstart[ONEPASS_MAX_GROUPS + 1] = { 0 };   // slot offset at which each group starts; largest group's extent
   uint8_t       *scr    = NULL;
   uint32_t      *d_bound = NULL, *d_size = NULL;
   uint64_t      *d_slot = NULL, *d_tile = NULL, *d_gran = NULL;
+  unsigned long long *d_ftile = NULL;
   // the slot layout needs the scratch to exist and the scratch's size needs the layout: lay out, size,
   // and lay out again if the buffer had to move.  Three rotating regions hold the groups' slots.
   uint64_t laid_gen = 0;                                 // the scratch generation the layout below was computed in
   for (int pass = 0; pass < 2; pass++)
     { void *base;
-      if ((e = dx_scratch(ctx, small + (G > 2 ? 3 : G) * region + 512, &base)))
+      if ((e = dx_scratch(ctx, small + (uint64_t) (G > regions_max ? regions_max : G) * region + 512, &base)))
         { (void) hipGetLastError();                      // (the failed allocation's error is dealt with here)
           if (pass == 1 && G >= 2 && 2 * G <= ONEPASS_MAX_GROUPS && getenv("DEXGPU_ONEPASS_GROUPS") == NULL)
             { G = G < 3 ? 4 : 2 * G;                     // no room for regions this big: more, smaller groups
@@ -2412,6 +2422,7 @@ layout:
       d_slot  = (uint64_t *) (scr + 2 * a4);
       d_tile  = (uint64_t *) (scr + 2 * a4 + a8);
       d_gran  = d_tile + ntiles;
+      d_ftile = (unsigned long long *) (scr + small - ftile);
       unsigned long long *d_long = (unsigned long long *) (ctx->d_u64 + 32), too_long = 0;
       DX_HIP(ctx, hipMemsetAsync(d_long, 0, 8, ctx->stream));
       DX_LAUNCH(ctx, DX_K_SCAN, k_qv_bounds, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK,
@@ -2452,14 +2463,45 @@ layout:
       if (g0 >= g1) continue;
       const uint64_t m = g1 - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
       // this group's slots live in region g % 3: slot_off[r] is file-wide, so shift the base
-      uint8_t *slots_g = d_slots + (uint64_t) (g % 3) * region - gstart[g];
+      uint8_t *slots_g = d_slots + (uint64_t) (follow ? 0 : g % 3) * region - gstart[g];
       qv_args ag = a;
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
       const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL, ctx->sx.none };
-      if (g >= 3)
+      if (g >= 3 && !follow)
         DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 3) & 7], 0));    // the region is free once its last tenant has been copied out
-      const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0, gstart[g], gstart[g] + region };
+      const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0, gstart[g], gstart[g] + region, follow ? 0x80000000u : 0u };
+      if (follow)
+        { // the odd entries first (into their slots, sizes published), then the encoder that also places every record
+          unsigned long long *d_waits = (unsigned long long *) (ctx->d_u64 + 40);
+          const follow_copy fc = { d_size + g0, d_ftile, d_rec_off + g0, d_base + (ng & 1), (unsigned long long *) (d_base + ((ng + 1) & 1)),
+                                   d_hdr, d_out, out_cap, d_waits };
+          const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
+          DX_HIP(ctx, hipMemsetAsync(d_size + g0, 0, m * 4, A));
+          DX_HIP(ctx, hipMemsetAsync(d_ftile, 0, ((m + 63) / 64 + 1) * 8, A));
+          if (g == 0) DX_HIP(ctx, hipMemsetAsync(d_waits, 0, 32, A));
+          if (ctx->tk.unusable > 0)
+            { const uint64_t work = ctx->tk.unusable < m ? ctx->tk.unusable : m;
+              DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
+              DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, work, 4 * ENC_WAVES), DX_BLOCK,
+                        ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) NULL, (const uint32_t *) NULL,
+                        (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g, (const uint32_t *) ctx->tk.list,
+                        (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), ~(uint64_t) 0, sx_g);
+            }
+          DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
+          if (sx_idx)
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX_FOLLOW, fast_grid(ctx, m), FAST_BLOCK,
+                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
+                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, fc);
+          else
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_FOLLOW, fast_grid(ctx, m), FAST_BLOCK,
+                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
+                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, fc);
+          ng += 1;
+          continue;
+        }
       if (fast)                                          // entries with usable tokens: walked from the tokens
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
@@ -2467,12 +2509,12 @@ layout:
             DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX, fast_grid(ctx, m), FAST_BLOCK,
                       ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
                       ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
           else
             DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K, fast_grid(ctx, m), FAST_BLOCK,
                       ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
                       ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL });
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
         }
       if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
         { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;
@@ -2496,8 +2538,8 @@ layout:
     { (void) hipStreamSynchronize(B);
       return rc;
     }
-  (void) hipEventRecord(done, B);
-  ctx->route.groups = ng; ctx->route.direct = 0; ctx->route.tokens = fast ? 1 : 0;
+  (void) hipEventRecord(done, follow ? A : B);
+  ctx->route.groups = ng; ctx->route.direct = follow ? 3 : 0; ctx->route.tokens = fast ? 1 : 0;
   ctx->route.region_bytes = region; ctx->route.scratch_bytes = ctx->scratch_bytes;
   ctx->route.token_bytes = fast ? 4ull * ctx->tk.cap_tokens : 0;
   ctx->route.text_entries = fast ? ctx->tk.unusable : n;

@@ -394,6 +394,143 @@ __device__ __forceinline__ uint64_t chain_place(const lb_chain &lb, uint64_t r, 
   return excl;
 }
 
+// ---------------------------------------------------------------------------------------------
+//  compaction inside the encoder ("follow"): no second kernel, no groups, no tail
+// ---------------------------------------------------------------------------------------------
+// The scratch route as above -- an entry is coded into its slot, its five sizes turn out -- but the wave that coded
+// an entry also moves it to its place in the record stream, one entry LATER: when it has coded its next entry.  By
+// then the entries before it (drawn before it, so coded at about the same time) have published their sizes, and the
+// record's offset is the sum of those: of the sizes of its own tile of 64 entries (one load per lane) and of the
+// tiles before, whose sums and prefixes are kept in one status word per tile exactly as in lb_chain -- whoever sees a
+// tile complete publishes its sum, whoever has worked out a prefix publishes it.  Every word (a size with its READY
+// bit, a tile's flag and value) is stored by ONE atomic store and means the same whoever wrote it: no ordering between
+// words is needed, so no release fence -- which at agent scope writes back the L2's dirty lines, the slots among them.
+// The slot is read back by the wave that wrote it (no other wave ever looks at it): program order, no fence either.
+// No wave waits before it has published what it coded, and a wave placing entry P only waits for entries below P, which
+// other waves are coding or have coded: the lowest unpublished entry is always being coded, the waits end (they are
+// bounded all the same: status bit 5).
+struct follow_copy
+{ uint32_t           *size;       // n words: record size | FC_READY once the entry's slot is complete (zeroed before the launch)
+  unsigned long long *tile;       // a word per 64 entries: LB_SIZE | their sizes added, or LB_PREFIX | all records up to the tile's end
+  uint64_t           *rec_off;    // n + 1, written here (absolute)
+  const uint64_t     *base;       // *base: where this launch's first record starts in d_out
+  unsigned long long *total;      // *total = *base + the records of this launch (the wave that places the last entry writes it)
+  const uint8_t      *hdr;        // framing bytes
+  uint8_t            *out;
+  uint64_t            out_cap;
+  unsigned long long *waits;      // as lb_chain.waits
+};
+#define FC_READY 0x80000000u
+
+// sizes of the 64 entries of tile t, a lane each (beyond n: 0, ready)
+__device__ __forceinline__ uint32_t fc_tile_sizes(const follow_copy &fc, uint64_t t, uint64_t n)
+{ const uint64_t e = 64ull * t + (uint64_t) lane_id();
+  return e < n ? __hip_atomic_load(&fc.size[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FC_READY;
+}
+
+// bytes of the launch's records before entry r; false: gave up waiting (status bit 5)
+__device__ __forceinline__ bool fc_offset(const follow_copy &fc, uint64_t r, uint64_t n, uint32_t *status, uint64_t &excl)
+{ const int      lane = lane_id();
+  const uint64_t t = r >> 6;
+  const uint32_t j = (uint32_t) (r & 63u);
+  uint32_t polls = 0;
+  uint64_t inner = 0;
+  for (;;)                                               // the entries of r's own tile before r
+    { const uint32_t v     = fc_tile_sizes(fc, t, n);
+      const uint64_t ready = __ballot((v & FC_READY) != 0u);
+      const uint64_t need  = j ? (~0ull >> (64u - j)) : 0ull;
+      if ((ready & need) == need)
+        { inner = wave_sum64(lane < (int) j ? (uint64_t) (v & ~FC_READY) : 0ull);
+          if (ready == ~0ull)                            // the whole tile is complete: its sum, for whoever comes looking
+            { const uint64_t s = wave_sum64((uint64_t) (v & ~FC_READY));
+              if (lane == 0)
+                { unsigned long long none = 0ull;
+                  __hip_atomic_compare_exchange_strong(&fc.tile[t], &none, LB_SIZE | s, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+          break;
+        }
+      if (++polls > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(status, 32u); return false; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  uint64_t P = 0, u = t;                                 // tiles [u, t) are in P
+  while (u > 0)
+    { unsigned long long w = LB_PREFIX;                  // before tile 0: prefix 0
+      if ((uint64_t) lane < u)
+        w = __hip_atomic_load(&fc.tile[u - 1 - (uint64_t) lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t flag = (uint32_t) (w >> 62);
+      const uint64_t mP = __ballot(flag == 2u), mE = __ballot(flag == 0u);
+      const int firstP = mP ? __ffsll((unsigned long long) mP) - 1 : 64, firstE = mE ? __ffsll((unsigned long long) mE) - 1 : 64;
+      const int upto   = firstP < firstE ? firstP + 1 : firstE;       // lanes [0, upto) hold sums (the last one a prefix)
+      P += wave_sum64(lane < upto ? (uint64_t) (w & LB_VALUE) : 0ull);
+      if (firstP < firstE) break;                        // reached an inclusive prefix
+      u -= (uint64_t) upto;
+      if (upto == 0)                                     // tile u - 1 has no sum yet: add its sizes up ourselves, if they are all there
+        { const uint32_t v = fc_tile_sizes(fc, u - 1, n);
+          if (__ballot((v & FC_READY) != 0u) == ~0ull)
+            { const uint64_t s = wave_sum64((uint64_t) (v & ~FC_READY));
+              if (lane == 0)
+                { unsigned long long none = 0ull;
+                  __hip_atomic_compare_exchange_strong(&fc.tile[u - 1], &none, LB_SIZE | s, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              P += s;
+              u -= 1;
+            }
+          else
+            { if (++polls > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(status, 32u); return false; }
+              __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
+  if (lane == 0)
+    { if (t > 0)                                         // everything before tile t: tile t - 1's inclusive prefix
+        __hip_atomic_store(&fc.tile[t - 1], LB_PREFIX | P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (polls && fc.waits)
+        { atomicAdd(&fc.waits[0], (unsigned long long) polls);
+          atomicAdd(&fc.waits[1], 1ull);
+          atomicMax(&fc.waits[2], (unsigned long long) polls);
+        }
+    }
+  excl = P + inner;
+  return true;
+}
+
+// entry r (its slot complete, its size published) to its place in the record stream: what k_qv_compact does for it
+__device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a, const enc_scratch &sc, const uint64_t *hdr_off,
+                                         uint64_t r, uint32_t *status)
+{ const int lane = lane_id();
+  uint64_t excl = 0;
+  if (!fc_offset(fc, r, a.n, status, excl))
+    return;
+  const uint64_t own = (uint64_t) (__hip_atomic_load(&fc.size[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~FC_READY);
+  const uint64_t at  = *fc.base + excl;
+  if (lane == 0)
+    { fc.rec_off[r] = at;
+      if (r + 1 == a.n)
+        { fc.rec_off[a.n] = at + own;
+          *fc.total = at + own;
+        }
+    }
+  if (at + own > fc.out_cap)                             // d_out is too small: report, never overrun
+    { if (lane == 0) atomicOr(status, 8u);
+      return;
+    }
+  const uint32_t *sg  = sc.seg_out + 5 * r;
+  const uint8_t  *src = sc.base + sc.slot_off[r];
+  uint8_t        *dst = fc.out + at;
+  if (fc.hdr != NULL)
+    { const uint64_t h0 = hdr_off[r];
+      const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
+      for (uint32_t k = (uint32_t) lane; k < hl; k += 64)
+        dst[k] = fc.hdr[h0 + k];
+      dst += hl;
+    }
+  const uint32_t s0 = sg[0], s1 = sg[1], s234 = sg[2] + sg[3] + sg[4];
+  wave_copy(dst, src, s0);
+  wave_copy(dst + s0, sc.base + sc.slot_off[r + 1] - tag_room(a.len[r]), s1);
+  wave_copy(dst + s0 + s1, src + s0, s234);
+}
+
 #ifndef FAST_GUARDS
 #define FAST_GUARDS 0
 #endif
@@ -414,12 +551,13 @@ __device__ __forceinline__ uint64_t chain_place(const lb_chain &lb, uint64_t r, 
 // index code compiled in it had 116 (-> 120 allocated) even when no index was asked for, the two kernels ran one
 // after the other, and a step took 32.7 ms instead of 31.0.
 // CHAIN: chained placement (lb): sizes first, record offset by look-back, record written in place.
-template <bool SUB, bool CHAIN>
+// FOLLOW: scratch route with the compaction inside (fc): see follow_copy.
+template <bool SUB, bool CHAIN, bool FOLLOW = false>
 __global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
                       enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
                       const uint8_t *hdr, const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint64_t out_cap,
-                      sub_sink sx, lb_chain lb)
+                      sub_sink sx, lb_chain lb, follow_copy fc)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint32_t s_pair[2][PAIR_SIZE];
@@ -454,6 +592,8 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   // (a kernel doing nothing but drawing its 500 k tickets takes 5.8 ms), so a million single draws are 11 ms of the
   // counter's time inside a 13.7 ms kernel.
   const uint32_t TB = CHAIN ? 1u : FAST_TICKET;
+  uint64_t pend = ~0ull;                                 // (FOLLOW) the entry coded before this one: placed once this one is coded
+#define FOLLOW_NEXT(x) { if (pend != ~0ull) fc_place(fc, a, sc, hdr_off, pend, status); pend = (x); }
   for (uint64_t r0 = next_unit(ticket, TB), nxt = 0; r0 < a.n; r0 = CHAIN ? next_unit(ticket) : nxt)
   { if (!CHAIN) nxt = next_unit(ticket, TB);
   for (uint64_t r = r0; r < r0 + TB && r < a.n; r++)
@@ -467,6 +607,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                   if (r + 1 == a.n) lb.rec_off[a.n] = excl + own;
                 }
             }
+          if (FOLLOW) FOLLOW_NEXT(r)                     // (the generic kernel has coded it into its slot BEFORE this launch)
           continue;                                      // the generic kernel encodes this entry from the text
         }
       // Two modes.  Scratch (sc.base != NULL): the entry goes into its slot, the sizes it turns out to have are
@@ -653,13 +794,20 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
         }
       if (S)
         { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
+          const uint32_t rec = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
           if (lane == 0)
-            sc.rec_size[r] = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
+            { if (FOLLOW) __hip_atomic_store(&sc.rec_size[r], rec | FC_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else        sc.rec_size[r] = rec;
+            }
         }
       if (bad && lane == 0)
         atomicOr(status, 2u);                            // slot overflow / a size differs from what k_qv_sizes_fast computed
+      if (FOLLOW) FOLLOW_NEXT(r)
     }
   }
+  if (FOLLOW && pend != ~0ull)
+    fc_place(fc, a, sc, hdr_off, pend, status);
+#undef FOLLOW_NEXT
 }
 
 
