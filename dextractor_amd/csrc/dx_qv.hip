@@ -2562,11 +2562,17 @@ static int onepass_end(dx_ctx *ctx, uint64_t *total)
   uint32_t st  = 0;
   DX_HIP(ctx, hipSetDevice(ctx->device));
   (void) hipStreamWaitEvent(A, ctx->ev[16], 0);          // the caller's stream sees the finished output
+  uint64_t waits[3] = { 0, 0, 0 };
+  if (ctx->route.direct == 3)                            // follow route: what its placements had to wait for
+    (void) hipMemcpyAsync(waits, ctx->d_u64 + 40, 24, hipMemcpyDeviceToHost, A);
   if (hipMemcpyAsync(&tot, ctx->op.d_total, 8, hipMemcpyDeviceToHost, A) != hipSuccess ||
       hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A) != hipSuccess ||
       hipStreamSynchronize(A) != hipSuccess)
     return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
   if (total) *total = tot;
+  ctx->route.chain_waits[0] = waits[0]; ctx->route.chain_waits[1] = waits[1]; ctx->route.chain_waits[2] = waits[2];
+  if (st & 32u)
+    return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: a record's predecessors never all reported their sizes (follow route, %u looks)", LB_SPIN_LIMIT);
   if (st & DX_ST_INDEX)
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry's offsets, length or scratch / token slot do not hold together "
                    "(d_off / d_len beyond text_bytes, or an internal index is corrupt)");

@@ -15,6 +15,9 @@
 #ifndef FAST_SKIP
 #define FAST_SKIP 0
 #endif
+#ifndef FOLLOW_SKIP
+#define FOLLOW_SKIP 0                                    // (experiments on the follow route: 1 no copy, 2 no look-back)
+#endif
 #define TOK_TP 8u                                        // tokens a lane takes per pass (one 16-byte load)
 
 struct tok_src
@@ -428,7 +431,12 @@ __device__ __forceinline__ uint32_t fc_tile_sizes(const follow_copy &fc, uint64_
   return e < n ? __hip_atomic_load(&fc.size[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FC_READY;
 }
 
-// bytes of the launch's records before entry r; false: gave up waiting (status bit 5)
+// bytes of the launch's records before entry r; false: gave up waiting (status bit 5).
+// Atomics on one address -- and on neighbouring words, which share a memory channel -- retire one every ~11 ns chip-wide:
+// a first version in which every wave published its tile's sum (compare-and-swap) and the prefix before it (store) spent
+// 20 ms per 500 k entries on those two million operations.  Now a tile's word is stored by the wave that places the
+// tile's LAST entry (the inclusive prefix) and, while it is still empty, by the few waves that had to work the prefix
+// out for themselves; everybody else only loads.
 __device__ __forceinline__ bool fc_offset(const follow_copy &fc, uint64_t r, uint64_t n, uint32_t *status, uint64_t &excl)
 { const int      lane = lane_id();
   const uint64_t t = r >> 6;
@@ -441,49 +449,41 @@ __device__ __forceinline__ bool fc_offset(const follow_copy &fc, uint64_t r, uin
       const uint64_t need  = j ? (~0ull >> (64u - j)) : 0ull;
       if ((ready & need) == need)
         { inner = wave_sum64(lane < (int) j ? (uint64_t) (v & ~FC_READY) : 0ull);
-          if (ready == ~0ull)                            // the whole tile is complete: its sum, for whoever comes looking
-            { const uint64_t s = wave_sum64((uint64_t) (v & ~FC_READY));
-              if (lane == 0)
-                { unsigned long long none = 0ull;
-                  __hip_atomic_compare_exchange_strong(&fc.tile[t], &none, LB_SIZE | s, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
           break;
         }
       if (++polls > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(status, 32u); return false; }
       __builtin_amdgcn_s_sleep(8);
     }
-  uint64_t P = 0, u = t;                                 // tiles [u, t) are in P
+  uint64_t P = 0, u = t;                                 // the records of tiles [u, t) are in P
+  bool     first_empty = false;                          // tile t - 1's word was empty when we looked
   while (u > 0)
     { unsigned long long w = LB_PREFIX;                  // before tile 0: prefix 0
-      if ((uint64_t) lane < u)
+      if ((uint64_t) lane < u && lane < 16)              // the sixteen tiles before u
         w = __hip_atomic_load(&fc.tile[u - 1 - (uint64_t) lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t flag = (uint32_t) (w >> 62);
-      const uint64_t mP = __ballot(flag == 2u), mE = __ballot(flag == 0u);
-      const int firstP = mP ? __ffsll((unsigned long long) mP) - 1 : 64, firstE = mE ? __ffsll((unsigned long long) mE) - 1 : 64;
-      const int upto   = firstP < firstE ? firstP + 1 : firstE;       // lanes [0, upto) hold sums (the last one a prefix)
-      P += wave_sum64(lane < upto ? (uint64_t) (w & LB_VALUE) : 0ull);
-      if (firstP < firstE) break;                        // reached an inclusive prefix
-      u -= (uint64_t) upto;
-      if (upto == 0)                                     // tile u - 1 has no sum yet: add its sizes up ourselves, if they are all there
-        { const uint32_t v = fc_tile_sizes(fc, u - 1, n);
+      else if (lane >= 16)
+        w = 0ull;
+      const uint64_t mP = __ballot((uint32_t) (w >> 62) == 2u) & 0xffffull;
+      const int      d  = mP ? __ffsll((unsigned long long) mP) - 1 : 16;       // nearest tile with a prefix: u - 1 - d
+      if (u == t) first_empty = d != 0;
+      if (d < 16)
+        P += __shfl(w & LB_VALUE, d);
+      const uint64_t upto = d < 16 ? (uint64_t) d : (u < 16 ? u : 16);          // tiles u - 1 ... u - upto go by their sizes
+      for (uint64_t k = 0; k < upto; )
+        { const uint32_t v = fc_tile_sizes(fc, u - 1 - k, n);
           if (__ballot((v & FC_READY) != 0u) == ~0ull)
-            { const uint64_t s = wave_sum64((uint64_t) (v & ~FC_READY));
-              if (lane == 0)
-                { unsigned long long none = 0ull;
-                  __hip_atomic_compare_exchange_strong(&fc.tile[u - 1], &none, LB_SIZE | s, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-              P += s;
-              u -= 1;
+            { P += wave_sum64((uint64_t) (v & ~FC_READY));
+              k += 1;
             }
           else
             { if (++polls > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(status, 32u); return false; }
               __builtin_amdgcn_s_sleep(8);
             }
         }
+      if (d < 16) break;
+      u -= upto;
     }
   if (lane == 0)
-    { if (t > 0)                                         // everything before tile t: tile t - 1's inclusive prefix
+    { if (t > 0 && first_empty)                          // everything before tile t: tile t - 1's inclusive prefix
         __hip_atomic_store(&fc.tile[t - 1], LB_PREFIX | P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (polls && fc.waits)
         { atomicAdd(&fc.waits[0], (unsigned long long) polls);
@@ -496,16 +496,22 @@ __device__ __forceinline__ bool fc_offset(const follow_copy &fc, uint64_t r, uin
 }
 
 // entry r (its slot complete, its size published) to its place in the record stream: what k_qv_compact does for it
+// (base0 = *fc.base, read ONCE per wave: the word shares its 128-byte line with the ticket counter, and a load of a line
+// the whole chip is drawing tickets from waits behind those atomics -- read per entry it made the kernel four times slower)
 __device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a, const enc_scratch &sc, const uint64_t *hdr_off,
-                                         uint64_t r, uint32_t *status)
+                                         uint64_t r, uint32_t *status, uint64_t base0)
 { const int lane = lane_id();
   uint64_t excl = 0;
+  if (FOLLOW_SKIP & 2) excl = 0;                         // (experiments: no look-back; 1: no copy)
+  else
   if (!fc_offset(fc, r, a.n, status, excl))
     return;
   const uint64_t own = (uint64_t) (__hip_atomic_load(&fc.size[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~FC_READY);
-  const uint64_t at  = *fc.base + excl;
+  const uint64_t at  = base0 + excl;
   if (lane == 0)
-    { fc.rec_off[r] = at;
+    { if ((r & 63u) == 63u)                              // the tile's last entry: its inclusive prefix
+        __hip_atomic_store(&fc.tile[r >> 6], LB_PREFIX | (excl + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fc.rec_off[r] = at;
       if (r + 1 == a.n)
         { fc.rec_off[a.n] = at + own;
           *fc.total = at + own;
@@ -515,6 +521,7 @@ __device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a
     { if (lane == 0) atomicOr(status, 8u);
       return;
     }
+  if (FOLLOW_SKIP & 1) return;
   const uint32_t *sg  = sc.seg_out + 5 * r;
   const uint8_t  *src = sc.base + sc.slot_off[r];
   uint8_t        *dst = fc.out + at;
@@ -536,6 +543,9 @@ __device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a
 #endif
 #ifndef FAST_TICKET
 #define FAST_TICKET 2u                                   // entries a wave draws at a time
+#endif
+#ifndef FOLLOW_TICKET
+#define FOLLOW_TICKET 1u                                 // ... on the follow route
 #endif
 #ifndef FAST_WAVES
 #define FAST_WAVES 4                                     // waves per SIMD the register allocation leaves room for
@@ -591,9 +601,10 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   // Entries are drawn FAST_TICKET at a time: every draw is an atomic on ONE address, ~11 ns each chip-wide whoever asks
   // (a kernel doing nothing but drawing its 500 k tickets takes 5.8 ms), so a million single draws are 11 ms of the
   // counter's time inside a 13.7 ms kernel.
-  const uint32_t TB = CHAIN ? 1u : FAST_TICKET;
+  const uint32_t TB = CHAIN ? 1u : (FOLLOW ? FOLLOW_TICKET : FAST_TICKET);
   uint64_t pend = ~0ull;                                 // (FOLLOW) the entry coded before this one: placed once this one is coded
-#define FOLLOW_NEXT(x) { if (pend != ~0ull) fc_place(fc, a, sc, hdr_off, pend, status); pend = (x); }
+  const uint64_t base0 = FOLLOW ? uniform64(*fc.base) : 0ull;
+#define FOLLOW_NEXT(x) { if (!(FOLLOW_SKIP & 4) && pend != ~0ull) fc_place(fc, a, sc, hdr_off, pend, status, base0); pend = (x); }
   for (uint64_t r0 = next_unit(ticket, TB), nxt = 0; r0 < a.n; r0 = CHAIN ? next_unit(ticket) : nxt)
   { if (!CHAIN) nxt = next_unit(ticket, TB);
   for (uint64_t r = r0; r < r0 + TB && r < a.n; r++)
@@ -796,7 +807,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
         { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
           const uint32_t rec = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
           if (lane == 0)
-            { if (FOLLOW) __hip_atomic_store(&sc.rec_size[r], rec | FC_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            { if (FOLLOW && !(FOLLOW_SKIP & 8)) __hip_atomic_store(&sc.rec_size[r], rec | FC_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               else        sc.rec_size[r] = rec;
             }
         }
@@ -805,8 +816,8 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
       if (FOLLOW) FOLLOW_NEXT(r)
     }
   }
-  if (FOLLOW && pend != ~0ull)
-    fc_place(fc, a, sc, hdr_off, pend, status);
+  if (FOLLOW && !(FOLLOW_SKIP & 4) && pend != ~0ull)
+    fc_place(fc, a, sc, hdr_off, pend, status, base0);
 #undef FOLLOW_NEXT
 }
 
