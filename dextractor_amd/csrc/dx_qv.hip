@@ -1007,7 +1007,9 @@ __device__ __forceinline__ uint32_t finish_words(wave_out &o, uint32_t last)
   if (lane_id() == 0)
     { const uint32_t w = o.win[0];
       for (uint32_t k = 0; k < tailw; k++)
-        store32_u(o.seg + 4ull * (o.wordbase + k), w);
+        { if (o.wt) store4_wt(o.seg + 4ull * (o.wordbase + k), w);
+          else      store32_u(o.seg + 4ull * (o.wordbase + k), w);
+        }
       o.win[0] = 0;
     }
   wave_sync();
@@ -1306,7 +1308,9 @@ __device__ __forceinline__ uint32_t finish_tags(wave_out &o)
   if (lane_id() == 0)
     { const uint32_t w = __builtin_bswap32(o.win[0]);
       for (uint32_t k = 0; 8u * k < o.winbits; k++)
-        o.seg[4ull * o.wordbase + k] = (uint8_t) (w >> (8 * k));
+        { if (o.wt) store1_wt(o.seg + 4ull * o.wordbase + k, (w >> (8 * k)) & 0xffu);
+          else      o.seg[4ull * o.wordbase + k] = (uint8_t) (w >> (8 * k));
+        }
       o.win[0] = 0;
     }
   wave_sync();
@@ -1375,6 +1379,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 
   const run_lds R = { s_chunk[wid], s_list[wid] };
   wave_out o, ot;
+  o.wt = ot.wt = false;
   o.win  = s_win[wid];
   ot.win = s_tag[wid];
   for (int j = lane; j < QV_WIN_WORDS; j += 64)  o.win[j]  = 0;
@@ -1544,7 +1549,8 @@ void k_qv_bounds(const uint32_t *len, uint64_t n, uint32_t b0, uint32_t b1, uint
   const uint64_t L = len[i];
   const uint64_t bits = L * b0 + L * b1 + L * b2 + L * b3;
   uint64_t bytes = ((bits + 7) >> 3) + 4 * 20 + tag_room((uint32_t) L);           // + partial and pad words, trailing run tokens
-  bytes = (bytes + 15) & ~(uint64_t) 15;
+  bytes = (bytes + 127) & ~(uint64_t) 127;                                       // (whole 128-byte lines: no cache line holds two entries' slots,
+                                                                                 //  so a line a follower wave has read never goes stale under it)
   if (bytes >= (1ull << 32))                                                     // a slot is addressed in 32 bits: such an entry (some
     { atomicMax(too_long, (unsigned long long) L);                               // 3.5e8 symbols at 96 bits per position) is refused, never
       bytes = 16;                                                                // given a wrapped bound
@@ -1574,6 +1580,9 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
     dst[t] = src[t];
 }
 
+#ifndef FOLLOW_WAVES_PER_CU
+#define FOLLOW_WAVES_PER_CU 8                           // waves of k_qv_follow per CU (beside the encoder's sixteen)
+#endif
 #define COMPACT_BATCH 8u
 #ifndef COMPACT_WAVES_PER_CU
 #define COMPACT_WAVES_PER_CU 16                         // (a copy kernel: few registers, no LDS)
@@ -1613,8 +1622,10 @@ static constexpr auto FAST_K          = &k_qv_encode_fast<false, false>;
 static constexpr auto FAST_K_IX       = &k_qv_encode_fast<true, false>;
 static constexpr auto FAST_K_CHAIN    = &k_qv_encode_fast<false, true>;
 static constexpr auto FAST_K_IX_CHAIN = &k_qv_encode_fast<true, true>;
-static constexpr auto FAST_K_FOLLOW   = &k_qv_encode_fast<false, false, true>;
-static constexpr auto FAST_K_IX_FOLLOW = &k_qv_encode_fast<true, false, true>;
+static constexpr auto FAST_K_FOLLOW   = &k_qv_encode_fast<false, false, 1>;
+static constexpr auto FAST_K_IX_FOLLOW = &k_qv_encode_fast<true, false, 1>;
+static constexpr auto FAST_K_FWD      = &k_qv_encode_fast<false, false, 2>;
+static constexpr auto FAST_K_IX_FWD   = &k_qv_encode_fast<true, false, 2>;
 
 // =============================================================================================
 //  C-ABI
@@ -2326,8 +2337,12 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // 40 % / 30 % / 30 % in three regions: 31.4; 7 groups with a halving tail: 32.7.
   // DEXGPU_FOLLOW: the encoder moves every record to its place itself (follow_copy, dx_qv_fast.hpp): no compaction kernel,
   // no overlap to arrange -- one group if its slots fit the memory, else groups one after the other in ONE region
+  // DEXGPU_FOLLOW=2: the encoder only forwards (slots written through, sizes published) and k_qv_follow, started beside it
+  // on the side stream, places the records as they come: two regions, so that a group's encoder need not wait for the
+  // group before's follower
   const bool follow = getenv("DEXGPU_FOLLOW") != NULL && getenv("DEXGPU_FOLLOW")[0] != '0' && onepass_tokens_ok(ctx, b);
-  const int  regions_max = follow ? 1 : 3;
+  const bool beside = follow && getenv("DEXGPU_FOLLOW")[0] == '2';
+  const int  regions_max = follow ? (beside ? 2 : 1) : 3;
   uint64_t gb[ONEPASS_MAX_GROUPS + 1];
   int      G = 1;
   { const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
@@ -2385,7 +2400,7 @@ layout:
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
   const size_t   ftile  = (((n + 63) / 64 + 2) * 8 + 255) & ~(size_t) 255;             // follow route: a status word per 64 entries
-  const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255) + ftile;
+  const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255) + 2 * ftile;
   uint64_t       region = 0, gstart[ONEPASS_MAX_GROUPS + 1] = { 0 };   // slot offset at which each group starts; largest group's extent
   uint8_t       *scr    = NULL;
   uint32_t      *d_bound = NULL, *d_size = NULL;
@@ -2422,7 +2437,7 @@ layout:
       d_slot  = (uint64_t *) (scr + 2 * a4);
       d_tile  = (uint64_t *) (scr + 2 * a4 + a8);
       d_gran  = d_tile + ntiles;
-      d_ftile = (unsigned long long *) (scr + small - ftile);
+      d_ftile = (unsigned long long *) (scr + small - 2 * ftile);                    // (two: consecutive groups' followers may overlap)
       unsigned long long *d_long = (unsigned long long *) (ctx->d_u64 + 32), too_long = 0;
       DX_HIP(ctx, hipMemsetAsync(d_long, 0, 8, ctx->stream));
       DX_LAUNCH(ctx, DX_K_SCAN, k_qv_bounds, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK,
@@ -2463,7 +2478,7 @@ layout:
       if (g0 >= g1) continue;
       const uint64_t m = g1 - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
       // this group's slots live in region g % 3: slot_off[r] is file-wide, so shift the base
-      uint8_t *slots_g = d_slots + (uint64_t) (follow ? 0 : g % 3) * region - gstart[g];
+      uint8_t *slots_g = d_slots + (uint64_t) (follow ? (beside ? g % 2 : 0) : g % 3) * region - gstart[g];
       qv_args ag = a;
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
@@ -2473,12 +2488,18 @@ layout:
       const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0, gstart[g], gstart[g] + region, follow ? 0x80000000u : 0u };
       if (follow)
         { // the odd entries first (into their slots, sizes published), then the encoder that also places every record
+          // (beside: that only forwards, with k_qv_follow on the side stream)
           unsigned long long *d_waits = (unsigned long long *) (ctx->d_u64 + 40);
-          const follow_copy fc = { d_size + g0, d_ftile, d_rec_off + g0, d_base + (ng & 1), (unsigned long long *) (d_base + ((ng + 1) & 1)),
-                                   d_hdr, d_out, out_cap, d_waits };
+          unsigned long long *ft_g    = d_ftile + (beside ? (size_t) (g & 1) * (ftile / 8) : 0);
+          const follow_copy fc_all = { d_size + g0, ft_g, d_rec_off + g0, d_base + (ng & 1), (unsigned long long *) (d_base + ((ng + 1) & 1)),
+                                       d_hdr, d_out, out_cap, d_waits };
+          follow_copy fc = fc_all;
+          if (beside) { fc.out = NULL; fc.rec_off = NULL; }
           const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
+          if (beside && g >= 2)
+            DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 2) & 7], 0));    // the region (and the tile words) are free once their follower is through
           DX_HIP(ctx, hipMemsetAsync(d_size + g0, 0, m * 4, A));
-          DX_HIP(ctx, hipMemsetAsync(d_ftile, 0, ((m + 63) / 64 + 1) * 8, A));
+          DX_HIP(ctx, hipMemsetAsync(ft_g, 0, ((m + 63) / 64 + 1) * 8, A));
           if (g == 0) DX_HIP(ctx, hipMemsetAsync(d_waits, 0, 32, A));
           if (ctx->tk.unusable > 0)
             { const uint64_t work = ctx->tk.unusable < m ? ctx->tk.unusable : m;
@@ -2489,16 +2510,23 @@ layout:
                         (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), ~(uint64_t) 0, sx_g);
             }
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          if (sx_idx)
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX_FOLLOW, fast_grid(ctx, m), FAST_BLOCK,
-                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
-                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, fc);
-          else
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_FOLLOW, fast_grid(ctx, m), FAST_BLOCK,
-                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
-                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, fc);
+          const int fw = getenv("DEXGPU_FOLLOW_WAVES") ? atoi(getenv("DEXGPU_FOLLOW_WAVES")) : FOLLOW_WAVES_PER_CU;   // (experiments; 0: no follower)
+          if (beside && fw > 0)                          // the follower starts when the encoder does
+            { DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
+              DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g & 7], 0));
+              DX_HIP(ctx, hipMemsetAsync(d_tick_cmp, 0, 4, B));
+              DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_follow, ctx->num_cu * fw / DX_WAVES_PER_BLK, DX_BLOCK,
+                           ag, sc_g, hoff_g, fc_all, ctx->d_status, d_tick_cmp);
+              (void) hipEventRecord(cmp_done[g & 7], B);
+            }
+#define FOLLOW_LAUNCH(K)                                                                                              \
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, K, fast_grid(ctx, m), FAST_BLOCK,                                            \
+                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,                   \
+                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL, \
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, fc)
+          if (beside) { if (sx_idx) FOLLOW_LAUNCH(FAST_K_IX_FWD);    else FOLLOW_LAUNCH(FAST_K_FWD); }
+          else        { if (sx_idx) FOLLOW_LAUNCH(FAST_K_IX_FOLLOW); else FOLLOW_LAUNCH(FAST_K_FOLLOW); }
+#undef FOLLOW_LAUNCH
           ng += 1;
           continue;
         }
@@ -2538,7 +2566,7 @@ layout:
     { (void) hipStreamSynchronize(B);
       return rc;
     }
-  (void) hipEventRecord(done, follow ? A : B);
+  (void) hipEventRecord(done, follow && !beside ? A : B);
   ctx->route.groups = ng; ctx->route.direct = follow ? 3 : 0; ctx->route.tokens = fast ? 1 : 0;
   ctx->route.region_bytes = region; ctx->route.scratch_bytes = ctx->scratch_bytes;
   ctx->route.token_bytes = fast ? 4ull * ctx->tk.cap_tokens : 0;

@@ -522,7 +522,13 @@ __device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a
       return;
     }
   if (FOLLOW_SKIP & 1) return;
-  const uint32_t *sg  = sc.seg_out + 5 * r;
+  // (the five sizes by agent-scope loads: on the forwarding route another XCD's wave wrote them, and their line also
+  // holds the neighbouring entries' sizes, which a cached copy of it would show as they were)
+  uint32_t sg[5];
+  { uint32_t v = 0;
+    if (lane < 5) v = __hip_atomic_load(sc.seg_out + 5 * r + (uint64_t) lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < 5; k++) sg[k] = __builtin_amdgcn_readlane(v, k);
+  }
   const uint8_t  *src = sc.base + sc.slot_off[r];
   uint8_t        *dst = fc.out + at;
   if (fc.hdr != NULL)
@@ -544,6 +550,9 @@ __device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a
 #ifndef FAST_TICKET
 #define FAST_TICKET 2u                                   // entries a wave draws at a time
 #endif
+#ifndef FOLLOW_BATCH
+#define FOLLOW_BATCH 4u                                  // entries a wave of k_qv_follow draws at a time
+#endif
 #ifndef FOLLOW_TICKET
 #define FOLLOW_TICKET 1u                                 // ... on the follow route
 #endif
@@ -562,7 +571,7 @@ __device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a
 // after the other, and a step took 32.7 ms instead of 31.0.
 // CHAIN: chained placement (lb): sizes first, record offset by look-back, record written in place.
 // FOLLOW: scratch route with the compaction inside (fc): see follow_copy.
-template <bool SUB, bool CHAIN, bool FOLLOW = false>
+template <bool SUB, bool CHAIN, int FOLLOW = 0>          // FOLLOW: 0 off, 1 this kernel's waves place the records, 2 forwarding (k_qv_follow does)
 __global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
                       enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
@@ -589,7 +598,11 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   const int lane = lane_id();
   const int wid  = threadIdx.x >> 6;
 
+  // FOLLOW, fc.out == NULL: forwarding -- the slots are written through to memory and the sizes published once they are
+  // there; k_qv_follow, started beside this kernel, places the records (fc.out given: this kernel's waves do, fc_place)
+  const bool FWD = FOLLOW == 2;
   wave_out o, ot;
+  o.wt = ot.wt = FWD;
   o.win  = s_win[wid];
   ot.win = s_tag[wid];
   for (int j = lane; j < QV_WIN_WORDS; j += 64)  o.win[j]  = 0;
@@ -601,10 +614,10 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   // Entries are drawn FAST_TICKET at a time: every draw is an atomic on ONE address, ~11 ns each chip-wide whoever asks
   // (a kernel doing nothing but drawing its 500 k tickets takes 5.8 ms), so a million single draws are 11 ms of the
   // counter's time inside a 13.7 ms kernel.
-  const uint32_t TB = CHAIN ? 1u : (FOLLOW ? FOLLOW_TICKET : FAST_TICKET);
+  const uint32_t TB = CHAIN ? 1u : (FOLLOW && !FWD ? FOLLOW_TICKET : FAST_TICKET);
   uint64_t pend = ~0ull;                                 // (FOLLOW) the entry coded before this one: placed once this one is coded
-  const uint64_t base0 = FOLLOW ? uniform64(*fc.base) : 0ull;
-#define FOLLOW_NEXT(x) { if (!(FOLLOW_SKIP & 4) && pend != ~0ull) fc_place(fc, a, sc, hdr_off, pend, status, base0); pend = (x); }
+  const uint64_t base0 = FOLLOW == 1 ? uniform64(*fc.base) : 0ull;
+#define FOLLOW_NEXT(x) { if (FOLLOW == 1) { if (!(FOLLOW_SKIP & 4) && pend != ~0ull) fc_place(fc, a, sc, hdr_off, pend, status, base0); pend = (x); } }
   for (uint64_t r0 = next_unit(ticket, TB), nxt = 0; r0 < a.n; r0 = CHAIN ? next_unit(ticket) : nxt)
   { if (!CHAIN) nxt = next_unit(ticket, TB);
   for (uint64_t r = r0; r < r0 + TB && r < a.n; r++)
@@ -624,6 +637,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
       // Two modes.  Scratch (sc.base != NULL): the entry goes into its slot, the sizes it turns out to have are
       // recorded.  Direct: the sizes are known (k_qv_sizes_fast), the record is written where it belongs --
       // framing bytes, del words, tag bytes, ins, mrg, sub words (QV.c:1393-1423) -- and every size is checked.
+#define SEG_OUT(k, v) { if (FWD) __hip_atomic_store(sgw + (k), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else sgw[k] = (v); }
       const bool      S      = !CHAIN && sc.base != NULL;
       const uint32_t  L      = a.len[r];
       const uint32_t *inf    = tk.info + TOK_INFO * r;
@@ -744,7 +758,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               got = finish_words(o, last);
               if (q == 0)
                 { const uint32_t tb = finish_tags(ot);
-                  if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
+                  if (S) { if (lane == 0) SEG_OUT(1, tb) sum += tb; }
                   else   { const uint32_t w1 = CHAIN ? sz[1] : sg[1]; bad |= tb ^ w1; dst += w1; }
                 }
             }
@@ -791,12 +805,12 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               if (q == 0)                                // no delChar: the whole tag line is packed
                 { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
                   const uint32_t tb = encode_all_tags(ot, p1, L, over);
-                  if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
+                  if (S) { if (lane == 0) SEG_OUT(1, tb) sum += tb; }
                   else   { const uint32_t w1 = CHAIN ? sz[1] : sg[1]; bad |= tb ^ w1; dst += w1; }
                 }
             }
           if (S)
-            { if (lane == 0) sgw[line] = got;
+            { if (lane == 0) SEG_OUT(line, got)
               sum += got;
             }
           else
@@ -807,7 +821,8 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
         { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
           const uint32_t rec = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
           if (lane == 0)
-            { if (FOLLOW && !(FOLLOW_SKIP & 8)) __hip_atomic_store(&sc.rec_size[r], rec | FC_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            { if (FWD) __builtin_amdgcn_s_waitcnt(0x0F70);     // every byte of the slot and its five sizes is in memory: only then the word that says so
+              if (FOLLOW && !(FOLLOW_SKIP & 8)) __hip_atomic_store(&sc.rec_size[r], rec | FC_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               else        sc.rec_size[r] = rec;
             }
         }
@@ -816,11 +831,39 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
       if (FOLLOW) FOLLOW_NEXT(r)
     }
   }
-  if (FOLLOW && !(FOLLOW_SKIP & 4) && pend != ~0ull)
+  if (FOLLOW == 1 && !(FOLLOW_SKIP & 4) && pend != ~0ull)
     fc_place(fc, a, sc, hdr_off, pend, status, base0);
 #undef FOLLOW_NEXT
+#undef SEG_OUT
 }
 
+
+// ---------------------------------------------------------------------------------------------
+//  k_qv_follow: the compaction BESIDE the encoder, entry by entry as the sizes come in
+// ---------------------------------------------------------------------------------------------
+// Started on the side stream together with the forwarding encoder (see FWD above).  Its waves draw entries in file order,
+// wait for an entry's size word -- and, in fc_offset, for those of the entries before it -- and move the record from its
+// slot to its place.  What makes that safe without a fence: the encoder writes a slot through to memory (sc1 stores),
+// waits until they have all arrived, and only then stores the size word; slots are whole 128-byte lines, so no line this
+// kernel has read before holds bytes of an entry it has yet to read; sizes and tile words are read past the caches.
+// The waves of this kernel never hold up an encoder wave, whatever they wait for; the encoder waits for nobody.
+__global__ __launch_bounds__(DX_BLOCK, 8)               // (64 registers: room beside four encoder waves of 112)
+void k_qv_follow(qv_args a, enc_scratch sc, const uint64_t *hdr_off, follow_copy fc, uint32_t *status, uint32_t *ticket)
+{ const uint64_t base0 = uniform64(*fc.base);
+  for (uint64_t r0 = next_unit(ticket, FOLLOW_BATCH), nxt; r0 < a.n; r0 = nxt)
+  { nxt = next_unit(ticket, FOLLOW_BATCH);
+    for (uint64_t r = r0; r < r0 + FOLLOW_BATCH && r < a.n; r++)
+      { uint32_t polls = 0;
+        for (;;)                                           // the entry itself
+          { const uint32_t v = uniform(__hip_atomic_load(&fc.size[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (v & FC_READY) break;
+            if (++polls > LB_SPIN_LIMIT) { if (lane_id() == 0) atomicOr(status, 32u); return; }
+            __builtin_amdgcn_s_sleep(100);
+          }
+        fc_place(fc, a, sc, hdr_off, r, status, base0);
+      }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 //  k_qv_sizes_fast: the five segment sizes of every entry, from the tokens and the two plain lines

@@ -187,7 +187,8 @@ def test_poisoned_allocations_change_nothing(poison):
     assert r.returncode == 0 and b"POISON_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_follow_route_writes_the_same_stream(monkeypatch):
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_follow_route_writes_the_same_stream(monkeypatch, mode):
     """DEXGPU_FOLLOW: the encoder moves every record from its scratch slot to its place itself, one entry behind its
     coding (follow_copy, dx_qv_fast.hpp) -- no compaction kernel.  Same bytes, same index beside them, as the route with
     the compaction kernel: ragged lengths, several groups in one region (a scratch budget), entries that come by the
@@ -197,8 +198,8 @@ def test_follow_route_writes_the_same_stream(monkeypatch):
         ref, info0, _ = c.encode(ctx, 0)
         rec_ref = c.d_rec.download(np.uint64, c.n + 1)
         seg_ref = c.d_seg.download(np.uint32, 5 * c.n)
-        monkeypatch.setenv("DEXGPU_FOLLOW", "1")
-        for budget in (0, 600 << 20):
+        monkeypatch.setenv("DEXGPU_FOLLOW", mode)           # 1: the encoder's waves place the records, 2: k_qv_follow beside the encoder
+        for budget in (0, 600 << 20 if mode == "1" else 1200 << 20):
             got, info, _ = c.encode(ctx, budget)
             assert info["direct"] == 3 and (info["groups"] == 1 if budget == 0 else info["groups"] > 1), info
             assert len(got) == len(ref) and (got == ref).all()
@@ -216,8 +217,9 @@ def test_follow_route_writes_the_same_stream(monkeypatch):
         assert (d_out.download(np.uint8, 4096, offset=cap) == 0xEE).all()
 
 
-def test_follow_route_small_files_and_text_entries(monkeypatch):
-    monkeypatch.setenv("DEXGPU_FOLLOW", "1")
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_follow_route_small_files_and_text_entries(monkeypatch, mode):
+    monkeypatch.setenv("DEXGPU_FOLLOW", mode)
     with api.Context(0) as ctx:
         for seed, n, mean in ((3, 1, 50), (4, 7, 3000), (5, 300, 900), (6, 65, 100), (7, 129, 2000)):
             c = synth.make_quiva(n, seed=seed, mean=mean)

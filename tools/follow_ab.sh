@@ -1,5 +1,5 @@
 for rep in 1 2; do
-for f in 0 1; do
+for f in 0 2; do
   for dist in fixed lognormal; do
   DEXGPU_FOLLOW=$f python bench.py --no-cpu-baseline --only-main --steps 8 --warmup 2 --dist $dist 2>/dev/null | python -c "
 import json,sys
