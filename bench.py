@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--scratch-budget-gb", type=float, default=None,
                     help="dexqv: memory the one-pass encoder may take for its scratch regions (dx_set_scratch_budget); default: "
                          "none at N=1 (by free device memory), 64 at N>1 so that every rank of a sharded job takes the same route")
+    ap.add_argument("--no-walk-index", action="store_true",
+                    help="dexqv: skip the decode of the batch with the HOST walk's group index (brings the 14 GB stream to the host and walks it)")
     ap.add_argument("--only-main", action="store_true",
                     help="N=1: only the headline workload, without the lognormal / dexta / dexar extras")
     return ap.parse_args()
@@ -392,6 +394,44 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                 ctx.profile(False)
                 torch.cuda.empty_cache()
                 state["decode_indexed"] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
+        if not args.twopass and index_decode and not args.no_walk_index and world == 1:
+            # ... and as a bare file gets it: the record stream goes to the host as a .dexqv image, dx_qv_walk_indexed finds the
+            # segment boundaries AND leaves the group index (host threads; it passes every code anyway), dx_qv_use_index hands
+            # it to the decoder: the wave-per-line kernels on a stream no encoder of this context has seen
+            try:
+                trace("verify: decode with the host walk's group index")
+                t_w = time.perf_counter()
+                head = b"\xaa\x55" + api.qv_write_coding(state["coding"], ("@" + movie).encode())
+                img = np.empty(len(head) + int(state["total"]), np.uint8)
+                img[: len(head)] = np.frombuffer(head, np.uint8)
+                torch.from_numpy(img[len(head):]).copy_(p_out.t[: int(state["total"])])
+                t_w1 = time.perf_counter()
+                w = api.qv_walk(img, index=True)
+                t_w2 = time.perf_counter()
+                del img
+                assert int(w["n"]) == n and (w["seg"].reshape(-1) == p_seg.t[: 5 * n].cpu().numpy().view(np.uint32)).all()
+                d_gidx = torch.from_numpy(w["gidx"].view(np.int32)).cuda()
+                d_goff = torch.from_numpy(w["gidx_off"].view(np.int64)).cuda()
+                ctx.qv_use_index(p_out, p_seg, n, Ptr(d_gidx), Ptr(d_goff), w["gidx_none"])
+                ok3, dec3_ms = decode_all()
+                ctx.qv_use_index(None, None, 0, None, None)
+                roundtrip = roundtrip and ok3
+                state["decode_walk_indexed"] = {"kernel": "k_qv_decode_sub + k_qv_decode_runs + k_qv_decode + k_qv_decode_tags", "ms": round(dec3_ms, 2),
+                                                "ms_by_kernel": dict(dec_parts), "bit_exact": bool(ok3),
+                                                "frac_of_hbm_peak": round((5.0 * bases + float(state["total"])) / (dec3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec3_ms else None,
+                                                "output_GBps": round(5.0 * bases / (dec3_ms * 1e-3) / 1e9, 1) if dec3_ms else None,
+                                                "index_bytes": int(4 * len(w["gidx"])), "lines_without_index": int(w["gidx_none"]),
+                                                "host_walk_s": round(t_w2 - t_w1, 2), "download_s": round(t_w1 - t_w, 2),
+                                                "note": "group index made by the host walk of the bare stream (dx_qv_walk_indexed), not by the encoder"}
+                del d_gidx, d_goff, w
+            except Exception as e:
+                try:
+                    ctx.qv_use_index(None, None, 0, None, None)
+                except Exception:
+                    pass
+                ctx.profile(False)
+                torch.cuda.empty_cache()
+                state["decode_walk_indexed"] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
     # GPU text front end on the same resident image (untimed extra): newline scan -> entry index
     fr = None
     if front and not args.no_verify:
@@ -524,6 +564,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                               device_bytes_in_use_after_step=state.get("mem_used_peak")),
         "decode": state.get("decode"),
         "decode_indexed": state.get("decode_indexed"),
+        "decode_walk_indexed": state.get("decode_walk_indexed"),
         "text_front_end": fr,
         "pipeline": pipe,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}

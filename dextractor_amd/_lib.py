@@ -55,7 +55,9 @@ class OnepassInfo(C.Structure):
 class QVIndex(C.Structure):
     _fields_ = [("n", C.c_uint64), ("rec_off", C.POINTER(C.c_uint64)), ("hdr_off", C.POINTER(C.c_uint64)),
                 ("seg", C.POINTER(C.c_uint32)), ("len", C.POINTER(C.c_uint32)), ("hdr4", C.POINTER(C.c_int32)),
-                ("coding", QVCoding), ("prefix", C.c_char_p), ("newv", C.c_int), ("flip", C.c_int)]
+                ("coding", QVCoding), ("prefix", C.c_char_p), ("newv", C.c_int), ("flip", C.c_int),
+                ("gidx", C.POINTER(C.c_uint32)), ("gidx_off", C.POINTER(C.c_uint64)), ("gidx_words", C.c_uint64),
+                ("gidx_none", C.c_uint64)]
 
 # name -> (restype, argtypes); every symbol include/dexgpu.h declares
 _P = C.c_void_p
@@ -113,6 +115,8 @@ SIGNATURES = {
     "dx_qv_out_bound": (C.c_uint64, [C.POINTER(HIST), C.c_uint64, C.POINTER(QVCoding), C.c_int]),
     "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
     "dx_qv_walk": (C.c_int, [_P, C.c_size_t, _P]),
+    "dx_qv_walk_indexed": (C.c_int, [_P, C.c_size_t, _P, C.c_int]),
+    "dx_qv_use_index": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64]),
     "dx_qv_index_free": (None, [_P]),
     "dx_file_pack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),
                                 C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),

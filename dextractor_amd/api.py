@@ -259,6 +259,11 @@ class Context:
     def dexqv(self, quiva: bytes, lossy=False) -> bytes:
         return self._file_call(self.lib.dx_file_dexqv, quiva, len(quiva), int(lossy))
 
+    def qv_use_index(self, d_in, d_seg, n, d_gidx, d_gidx_off, none=0):
+        """dx_qv_use_index: a group index made elsewhere (qv_walk(index=True)) for the stream at d_in / d_seg; d_gidx None: take it back"""
+        self._chk(self.lib.dx_qv_use_index(self.h, d_in.ptr if d_in else None, d_seg.ptr if d_seg else None, n,
+                                           d_gidx.ptr if d_gidx else None, d_gidx_off.ptr if d_gidx_off else None, none))
+
     def undexqv(self, img: bytes, upper=False) -> bytes:
         return self._file_call(self.lib.dx_file_undexqv, img, len(img), int(upper))
 
@@ -410,16 +415,26 @@ def qv_read_coding(img: bytes):
     return c, flip.value, pre.value, used.value
 
 
-def qv_walk(img: bytes):
-    """Host boundary walk of a bare .dexqv image -> dict of numpy arrays + coding (QVIndex copy)."""
+def qv_walk(img: bytes, index=False):
+    """Host boundary walk of a bare .dexqv image -> dict of numpy arrays + coding (QVIndex copy); index=True: with the
+    group index of dx_qv_walk_indexed (gidx words, gidx_off, gidx_none)."""
     lib = L.load()
     x = L.QVIndex()
-    rc = lib.dx_qv_walk(img, len(img), C.byref(x))
+    if isinstance(img, np.ndarray):                       # (a big image: no copy into a bytes object)
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rc = lib.dx_qv_walk_indexed(img.ctypes.data_as(C.c_void_p), img.size, C.byref(x), int(bool(index)))
+    else:
+        rc = lib.dx_qv_walk_indexed(img, len(img), C.byref(x), int(bool(index)))
     if rc != 0:
         raise L.DexGPUError(rc, "dx_qv_walk")
     try:
         n = x.n
-        return {"n": n,
+        extra = {}
+        if index:
+            w = int(x.gidx_words)
+            extra = {"gidx": np.ctypeslib.as_array(x.gidx, (max(w, 1),))[:w].copy(),
+                     "gidx_off": np.ctypeslib.as_array(x.gidx_off, (n + 1,)).copy(), "gidx_none": int(x.gidx_none)}
+        return {**extra, "n": n,
                 "rec_off": np.ctypeslib.as_array(x.rec_off, (n + 1,)).copy(),
                 "hdr_off": np.ctypeslib.as_array(x.hdr_off, (n + 1,)).copy(),
                 "seg": np.ctypeslib.as_array(x.seg, (max(n, 1), 5))[:n].copy(),

@@ -24,6 +24,13 @@ hipError_t dx_hip_malloc(void **p, size_t bytes)
 }
 #define hipMalloc(p, n) dx_hip_malloc((void **) (p), (n))
 
+void dx_sx_drop_external(dx_ctx *ctx)
+{ if (!ctx->sx.external) return;
+  ctx->sx.idx = NULL; ctx->sx.off = NULL; ctx->sx.cap_idx = 0;
+  (void) hipFree(ctx->sx.room); ctx->sx.room = NULL; ctx->sx.cap_entries = 0;
+  ctx->sx.external = 0; ctx->sx.valid = 0;
+}
+
 int dx_fail(dx_ctx *ctx, int code, const char *fmt, ...)
 { char *dst = ctx ? ctx->err : g_open_err;
   va_list ap;
@@ -142,6 +149,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->d_scratch);
   (void) hipFree(ctx->d_scan);
   (void) hipFree(ctx->d_hscr);
+  dx_sx_drop_external(ctx);
   (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room); (void) hipFree(ctx->sx.none);
   if (ctx->h_stage[0]) (void) hipHostFree(ctx->h_stage[0]);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
@@ -172,6 +180,7 @@ extern "C" int dx_trim(dx_ctx *ctx, int what)
     }
   if (what & DX_TRIM_INDEX)
     { const int want = ctx->sx.want;
+      dx_sx_drop_external(ctx);
       (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room); (void) hipFree(ctx->sx.none);
       memset(&ctx->sx, 0, sizeof(ctx->sx));
       ctx->sx.want = want;

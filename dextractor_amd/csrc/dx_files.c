@@ -642,7 +642,8 @@ int dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, s
   *plan = NULL; *out_len = 0;
   p = calloc(1, sizeof(*p));
   if (p == NULL) return DX_E_NOMEM;
-  rc = dx_qv_walk(img, n, &p->x);                         /* boundary walk (host) */
+  /* boundary walk (host); it also leaves the group index the wave-per-line decoders take, unless told not to */
+  rc = dx_qv_walk_indexed(img, n, &p->x, getenv("DEXGPU_NO_WALK_INDEX") == NULL);
   if (rc != DX_OK) { free(p); return rc; }
   p->img = img; p->n = n;
   plen = strlen(p->x.prefix);
@@ -673,7 +674,7 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
 { dpool     pool = { {0}, 0, ctx };
   void     *d_in, *d_rec, *d_hoff, *d_seg, *d_len, *d_out, *d_ooff;
   hdr_patch h;
-  int       rc = DX_OK;
+  int       rc = DX_OK, indexed = 0;
 
   if (ctx == NULL || p == NULL || sink == NULL) return DX_E_ARG;
   h.n = p->x.n; h.ooff = p->ooff; h.hat = p->hat; h.hd = p->hd.p; h.sink = sink; h.user = user;
@@ -686,11 +687,19 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
       TRY(dupload(&pool, p->x.len, p->x.n * 4, &d_len));
       TRY(dupload(&pool, p->ooff, p->x.n * 8, &d_ooff));
       TRY(dalloc(&pool, p->total, &d_out));
+      if (p->x.gidx != NULL && !p->x.flip)               /* the walk's group index: a wavefront per line (dx_qv_use_index) */
+        { void *d_gidx, *d_goff;
+          TRY(dupload(&pool, p->x.gidx, (size_t) p->x.gidx_words * 4, &d_gidx));
+          TRY(dupload(&pool, p->x.gidx_off, (p->x.n + 1) * 8, &d_goff));
+          TRY(dx_qv_use_index(ctx, d_in, d_seg, p->x.n, d_gidx, d_goff, p->x.gidx_none));
+          indexed = 1;
+        }
       TRY(dx_qv_decode(ctx, d_in, d_rec, d_hoff, d_seg, d_len, p->x.n,
                        (upper ? DX_DECODE_UPPER : 0) | (p->x.flip ? DX_DECODE_FLIP : 0), d_out, d_ooff));
       TRY(dx_d2h_stream(ctx, d_out, p->total, patch_and_pass, &h));
     }
 done:
+  if (indexed) (void) dx_qv_use_index(ctx, NULL, NULL, 0, NULL, NULL, 0);     /* (the index lives in the pool freed below) */
   dfree_all(&pool);
   return rc;
 }

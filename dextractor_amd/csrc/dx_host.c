@@ -743,9 +743,121 @@ static int64_t walk_runs(const uint8_t *p, const uint8_t *end, uint32_t rlen, co
   return (p + bytes <= end) ? bytes : -1;
 }
 
+/* ---- the same walks, leaving the GROUP INDEX the wave-per-line decoders take (dx_layout.h; device side: dx_device.hpp,
+ * k_qv_encode_fast writes it, k_qv_decode_sub / k_qv_decode_runs read it).  The walk passes every code anyway; with the
+ * index a bare file decodes on the kernels that otherwise only serve a stream the same context has just encoded.
+ * One look-up per symbol here (the several-codes-per-look-up tables above do not stop at group boundaries). ---------- */
+#include "dx_layout.h"
+
+/* plain line: one byte per group of 16 symbols = the group's code bits minus its symbols.  Several codes per look-up
+   (mwlut) while they stay inside the group, one code at a time across its boundary. */
+static int64_t walk_plain_ix(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *t, const mwlut *m, int esc, int flip,
+                             uint8_t *share)
+{ wrd r = { p, end, 0, 0, 0, flip };
+  uint32_t j = 0, last = 0, gbits = 0, none = 0;
+  int64_t bytes;
+  while (j < rlen)
+    { uint32_t w = w_peek(&r);
+      const mwent g = m->e[w >> (16 - MW_BITS)];
+      if (r.nb < 0) return -1;
+      if (g.nsym && (j & 15u) + g.nsym <= 16u && j + g.nsym <= rlen)
+        { w_skip(&r, g.nbits);
+          j += g.nsym; gbits += g.nbits; last = g.last;
+        }
+      else
+        { uint32_t e = t->e[w];
+          last = e >> 8;
+          if (last == 0) return -1;
+          w_skip(&r, (int) last);
+          gbits += last;
+          if (esc && (e & 0xff) == 255)
+            { w_peek(&r); w_skip(&r, 8); last = 8; gbits += 8; }
+          j += 1;
+        }
+      if ((j & 15u) == 0 || j == rlen)
+        { const uint32_t valid = (j & 15u) ? (j & 15u) : 16u;
+          if (gbits - valid > 254u) none = 1;               /* does not fit the byte (escape schemes): no index for this line */
+          share[(j - 1) >> 4] = (uint8_t) (gbits - valid);
+          gbits = 0;
+        }
+    }
+  if ((none || esc) && rlen) share[0] = (uint8_t) DXL_SUB_NONE;
+  bytes = 4 * (int64_t) pad_words(r.T, last);
+  return (p + bytes <= end) ? bytes : -1;
+}
+
+/* run-coded line: per token its bits and the positions it covers (run + 1), into tb / ts (room for rlen tokens) */
+static int64_t walk_runs_ix(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *nt, int esc,
+                            const wlut *rt, const rwlut *pair, uint32_t *nonrun, int flip, uint16_t *tb, uint32_t *ts)
+{ wrd r = { p, end, 0, 0, 0, flip };
+  uint32_t j = 0, last = 0, nn = 0;
+  int64_t bytes;
+  while (j < rlen)
+    { uint32_t w = w_peek(&r), e, c, bits;
+      const rwent g = pair->e[w >> (16 - MW_BITS)];
+      if (r.nb < 0) return -1;
+      if (g.ok && j + g.run < rlen)
+        { w_skip(&r, g.nbits);
+          tb[nn] = g.nbits; ts[nn] = (uint32_t) g.run + 1u;
+          j   += (uint32_t) g.run + 1u;
+          nn  += 1;
+          last = g.last;
+          continue;
+        }
+      e = rt->e[w]; c = e & 0xff;
+      last = e >> 8;
+      if (last == 0) return -1;
+      w_skip(&r, (int) last);
+      bits = last;
+      if (c == 255)
+        { c = w_peek(&r); w_skip(&r, 16); last = 16; bits += 16; }
+      if (c > rlen - j) return -1;
+      j += c;
+      if (j < rlen)
+        { e = nt->e[w_peek(&r)];
+          last = e >> 8;
+          if (last == 0) return -1;
+          w_skip(&r, (int) last);
+          bits += last;
+          if (esc && (e & 0xff) == 255)
+            { w_peek(&r); w_skip(&r, 8); last = 8; bits += 8; }
+          tb[nn] = (uint16_t) bits; ts[nn] = c + 1u;
+          j  += 1;
+          nn += 1;
+        }
+    }
+  *nonrun = nn;
+  bytes = 4 * (int64_t) pad_words(r.T, last);
+  return (p + bytes <= end) ? bytes : -1;
+}
+
+/* the group words of a run-coded line from its tokens, as k_qv_encode_fast cuts them: passes of 512 tokens, in a pass
+   of m tokens lane l holds the (m + 63) / 64 tokens from l times that on; word = bits | positions << 16.  Returns the
+   header word: the token count, or DXL_RUN_NONE when a group does not fit (positions > 65535, a pass > RUN_PASSBITS). */
+static uint32_t run_groups(const uint16_t *tb, const uint32_t *ts, uint32_t cnt, uint32_t L, uint32_t *grp)
+{ uint32_t k0, none = 0;
+  if (cnt > ((((L >> 1) + 64u) + 7u) & ~7u)) none = 1;    /* more tokens than the encoder's token slots hold: such a line never has an
+                                                             index (k_qv_decode_runs refuses one), the lane-per-line kernel takes it */
+  for (k0 = 0; k0 < cnt; k0 += DXL_RUN_PASS, grp += 64)
+    { const uint32_t m = cnt - k0 < DXL_RUN_PASS ? cnt - k0 : DXL_RUN_PASS, T = (m + 63u) >> 6;
+      uint32_t lane, total = 0;
+      for (lane = 0; lane < 64; lane++)
+        { const uint32_t first = lane * T, c = first < m ? (m - first < T ? m - first : T) : 0u;
+          uint32_t nb = 0, span = 0, k;
+          for (k = 0; k < c; k++) { nb += tb[k0 + first + k]; span += ts[k0 + first + k]; }
+          if (span > 0xffffu || nb > 0xffffu) none = 1;
+          grp[lane] = nb | (span << 16);
+          total += nb;
+        }
+      if (total > DXL_RUN_PASSBITS) none = 1;
+    }
+  return none ? DXL_RUN_NONE : cnt;
+}
+
 void dx_qv_index_free(dx_qv_index *x)
 { if (x == NULL) return;
   free(x->rec_off); free(x->hdr_off); free(x->seg); free(x->len); free(x->hdr4); free(x->prefix);
+  free(x->gidx); free(x->gidx_off);
   memset(x, 0, sizeof(*x));
 }
 
@@ -756,19 +868,37 @@ typedef struct
     rwlut *rlut[2];
     const dx_qv_coding *cd;
     int    newv, flip;
+    int    want_index;                /* leave the group index too (dx_qv_walk_indexed) */
   } walk_tabs;
 
-typedef struct { uint32_t hdr_bytes, len, seg[5]; int32_t dwell, beg, end, qv; } walk_rec;
+typedef struct { uint32_t hdr_bytes, len, seg[5]; int32_t dwell, beg, end, qv; uint64_t gx_at, gx_words; uint32_t gx_none; } walk_rec;
+
+/* index words of the records a thread walks (in the order it walks them) + its token scratch */
+typedef struct { uint32_t *w; uint64_t n, cap; uint16_t *tb; uint32_t *ts; uint32_t tcap; } gx_buf;
+
+static uint32_t *gx_room(gx_buf *g, uint64_t words)        /* `words` more zeroed words; NULL: out of memory */
+{ if (g->n + words > g->cap)
+    { uint64_t nc = g->cap ? g->cap : (1u << 16);
+      uint32_t *q;
+      while (nc < g->n + words) nc *= 2;
+      q = realloc(g->w, nc * sizeof(*q));
+      if (q == NULL) return NULL;
+      g->w = q; g->cap = nc;
+    }
+  memset(g->w + g->n, 0, words * sizeof(uint32_t));
+  g->n += words;
+  return g->w + g->n - words;
+}
 
 /* One record at img + at (undexqv.c:119-208): the framing fields, then the five segments walked code by
    code.  Returns the offset behind the record; 0 if there is no well-formed record here.            */
-static size_t walk_record(const walk_tabs *t, const uint8_t *img, size_t n, size_t at, walk_rec *r)
-{ const uint8_t *end = img + n;
-  const size_t   h0  = at;
-  const dx_qv_coding *cd = t->cd;
+static size_t walk_record_ix(const walk_tabs *t, const uint8_t *img, size_t n, size_t at, walk_rec *r, gx_buf *g);
+
+/* the framing fields of a record (undexqv.c:119-180); returns the offset of its first segment, 0: no plausible record here */
+static size_t walk_framing(const walk_tabs *t, const uint8_t *img, size_t n, size_t at, walk_rec *r)
+{ const size_t h0 = at;
   int32_t  beg, end_, qv, dw = 0;
-  uint32_t rlen, clen;
-  int64_t  b;
+  uint32_t rlen;
 
   while (at < n && img[at] == 255) { dw += 255; at += 1; }
   if (at >= n) return 0;
@@ -794,6 +924,18 @@ static size_t walk_record(const walk_tabs *t, const uint8_t *img, size_t n, size
     return 0;
   r->hdr_bytes = (uint32_t) (at - h0);
   r->len = rlen; r->dwell = dw; r->beg = beg; r->end = end_; r->qv = qv;
+  return at;
+}
+
+static size_t walk_record(const walk_tabs *t, const uint8_t *img, size_t n, size_t at, walk_rec *r)
+{ const uint8_t *end = img + n;
+  const dx_qv_coding *cd = t->cd;
+  uint32_t rlen, clen;
+  int64_t  b;
+
+  at = walk_framing(t, img, n, at, r);
+  if (at == 0) return 0;
+  rlen = r->len;
 
   clen = rlen;                                            /* QV.c:1433-1462 */
   if (cd->delChar < 0)
@@ -822,9 +964,86 @@ static size_t walk_record(const walk_tabs *t, const uint8_t *img, size_t n, size
   return at;
 }
 
+/* the same record, with its share of the group index appended to g (walk_tabs.want_index); on failure g is as it was */
+static size_t walk_record_ix(const walk_tabs *t, const uint8_t *img, size_t n, size_t at, walk_rec *r, gx_buf *g)
+{ const uint8_t *end = img + n;
+  const dx_qv_coding *cd = t->cd;
+  const uint64_t at0_words = g->n;
+  uint32_t rlen, clen, nd = 0, ns = 0, pd, sw, rb;
+  uint32_t *blk;
+  int64_t  b;
+
+  at = walk_framing(t, img, n, at, r);
+  if (at == 0) return 0;
+  rlen = r->len;
+  if (rlen > g->tcap)
+    { uint16_t *tb = realloc(g->tb, ((size_t) rlen + 1) * sizeof(*tb));
+      uint32_t *ts;
+      if (tb == NULL) return 0;
+      g->tb = tb;
+      ts = realloc(g->ts, ((size_t) rlen + 1) * sizeof(*ts));
+      if (ts == NULL) return 0;
+      g->ts = ts; g->tcap = rlen;
+    }
+  sw = dxl_sub_words(rlen); rb = dxl_run_base(rlen);
+  if (gx_room(g, (uint64_t) rb + 3u) == NULL) return 0;
+  r->gx_at = at0_words; r->gx_none = 0;
+#define BLK (g->w + at0_words)
+#define FAIL { g->n = at0_words; return 0; }
+  BLK[rb + 0] = DXL_RUN_NONE; BLK[rb + 1] = DXL_RUN_NONE;
+  clen = rlen;
+  if (cd->delChar < 0)
+    b = walk_plain_ix(img + at, end, rlen, t->lut[DX_DEL], t->mlut[DX_DEL], cd->s[DX_DEL].type == 2, t->flip, (uint8_t *) BLK);
+  else
+    { b = walk_runs_ix(img + at, end, rlen, t->lut[DX_DEL], cd->s[DX_DEL].type == 2, t->lut[DX_DRUN], t->rlut[0], &clen, t->flip, g->tb, g->ts);
+      nd = clen;
+    }
+  if (b < 0) FAIL
+  r->seg[0] = (uint32_t) b; at += (size_t) b;
+  pd = cd->delChar < 0 ? 0u : dxl_run_passes(nd);
+  if (pd)
+    { if ((blk = gx_room(g, 64ull * pd)) == NULL) FAIL
+      BLK[rb + 0] = run_groups(g->tb, g->ts, nd, rlen, blk);
+    }
+  else if (cd->delChar >= 0)
+    BLK[rb + 0] = 0;                                      /* a line of run characters only: no tokens, indexed */
+  BLK[rb + 2] = pd;
+  if (cd->delChar >= 0 && BLK[rb + 0] == DXL_RUN_NONE) r->gx_none += 1;
+  r->seg[1] = (clen + 3) >> 2;
+  if (at + r->seg[1] > n) FAIL
+  at += r->seg[1];
+  b = walk_plain_ix(img + at, end, rlen, t->lut[DX_INS], t->mlut[DX_INS], cd->s[DX_INS].type == 2, t->flip, (uint8_t *) (BLK + sw));
+  if (b < 0) FAIL
+  r->seg[2] = (uint32_t) b; at += (size_t) b;
+  b = walk_plain_ix(img + at, end, rlen, t->lut[DX_MRG], t->mlut[DX_MRG], cd->s[DX_MRG].type == 2, t->flip, (uint8_t *) (BLK + 2 * sw));
+  if (b < 0) FAIL
+  r->seg[3] = (uint32_t) b; at += (size_t) b;
+  if (cd->subChar < 0)
+    b = walk_plain_ix(img + at, end, rlen, t->lut[DX_SUB], t->mlut[DX_SUB], cd->s[DX_SUB].type == 2, t->flip, (uint8_t *) (BLK + 3 * sw));
+  else
+    { b = walk_runs_ix(img + at, end, rlen, t->lut[DX_SUB], cd->s[DX_SUB].type == 2, t->lut[DX_SRUN], t->rlut[1], &ns, t->flip, g->tb, g->ts);
+      if (b >= 0)
+        { const uint32_t ps = dxl_run_passes(ns);
+          if (ps)
+            { if ((blk = gx_room(g, 64ull * ps)) == NULL) FAIL
+              BLK[rb + 1] = run_groups(g->tb, g->ts, ns, rlen, blk);
+            }
+          else
+            BLK[rb + 1] = 0;
+          if (BLK[rb + 1] == DXL_RUN_NONE) r->gx_none += 1;
+        }
+    }
+  if (b < 0) FAIL
+  r->seg[4] = (uint32_t) b; at += (size_t) b;
+#undef FAIL
+#undef BLK
+  r->gx_words = g->n - at0_words;
+  return at;
+}
+
 /* records of img[from, to) appended to a growing list; stops at `to` exactly (returns it), behind it
    (a record straddles `to`: returns that offset) or 0 on a malformed record / out of memory (*rc says which) */
-typedef struct { walk_rec *r; uint64_t n, cap; } rec_list;
+typedef struct { walk_rec *r; uint64_t n, cap; gx_buf gx; } rec_list;
 
 static size_t walk_span(const walk_tabs *t, const uint8_t *img, size_t n, size_t from, size_t to, rec_list *L, int *rc)
 { size_t at = from;
@@ -836,7 +1055,7 @@ static size_t walk_span(const walk_tabs *t, const uint8_t *img, size_t n, size_t
           if (q == NULL) { *rc = DX_E_NOMEM; return 0; }
           L->r = q; L->cap = nc;
         }
-      nx = walk_record(t, img, n, at, &L->r[L->n]);
+      nx = t->want_index ? walk_record_ix(t, img, n, at, &L->r[L->n], &L->gx) : walk_record(t, img, n, at, &L->r[L->n]);
       if (nx == 0) { *rc = DX_E_FORMAT; return 0; }
       L->n += 1;
       at = nx;
@@ -968,25 +1187,34 @@ static int walk_parallel(const walk_tabs *t, const uint8_t *img, size_t n, size_
     if (job[k].rc == DX_E_NOMEM) rc = DX_E_NOMEM;
     else if (job[k].rc != DX_OK || job[k].landed != job[k].stop) rc = DX_E_MISMATCH;   /* a wrong guess (or a damaged file): walk it front to back */
   if (rc == DX_OK)
-    { uint64_t tot = 0, at = 0;
-      for (k = 0; k < T; k++) tot += job[k].L.n;
+    { uint64_t tot = 0, at = 0, gw = 0, gat = 0, i;
+      for (k = 0; k < T; k++) { tot += job[k].L.n; gw += job[k].L.gx.n; }
       out->r = malloc((tot + 1) * sizeof(walk_rec));
-      if (out->r == NULL) rc = DX_E_NOMEM;
+      if (t->want_index) out->gx.w = malloc((gw + 1) * sizeof(uint32_t));
+      if (out->r == NULL || (t->want_index && out->gx.w == NULL)) rc = DX_E_NOMEM;
       else
         { for (k = 0; k < T; k++)
             { memcpy(out->r + at, job[k].L.r, job[k].L.n * sizeof(walk_rec));
+              if (t->want_index)
+                { memcpy(out->gx.w + gat, job[k].L.gx.w, job[k].L.gx.n * sizeof(uint32_t));
+                  for (i = 0; i < job[k].L.n; i++) out->r[at + i].gx_at += gat;    /* (offsets were into the thread's own words) */
+                  gat += job[k].L.gx.n;
+                }
               at += job[k].L.n;
             }
           out->n = out->cap = tot;
+          out->gx.n = out->gx.cap = gw;
         }
     }
-  for (k = 0; k < T; k++) free(job[k].L.r);
+  for (k = 0; k < T; k++) { free(job[k].L.r); free(job[k].L.gx.w); free(job[k].L.gx.tb); free(job[k].L.gx.ts); }
   return rc;
 }
 
-int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
+int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x) { return dx_qv_walk_indexed(img, n, x, 0); }
+
+int dx_qv_walk_indexed(const uint8_t *img, size_t n, dx_qv_index *x, int want_index)
 { walk_tabs t;
-  rec_list  L = { NULL, 0, 0 };
+  rec_list  L;
   size_t    at = 0, used = 0;
   uint64_t  hat = 0, i;
   uint16_t  key;
@@ -995,6 +1223,8 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   if (img == NULL || x == NULL) return DX_E_ARG;
   memset(x, 0, sizeof(*x));
   memset(&t, 0, sizeof(t));
+  memset(&L, 0, sizeof(L));
+  t.want_index = want_index != 0;
   if (n < 2) return DX_E_FORMAT;
   memcpy(&key, img, 2);                                   /* undexqv.c:103-110 */
   if (key == 0x55aa || key == 0xaa55) { x->newv = 1; at = 2; }
@@ -1045,7 +1275,8 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   if (rc == DX_E_MISMATCH && getenv("DEXGPU_WALK_REQUIRE_PARALLEL") != NULL)
     goto fail;                                            /* (tests: no silent front-to-back walk) */
   if (rc == DX_E_MISMATCH)
-    { L.r = NULL; L.n = L.cap = 0;
+    { free(L.r); free(L.gx.w); free(L.gx.tb); free(L.gx.ts);
+      memset(&L, 0, sizeof(L));
       rc = DX_OK;
       if (walk_span(&t, img, n, at, n, &L, &rc) == 0 && rc == DX_OK && at < n) rc = DX_E_FORMAT;
     }
@@ -1058,6 +1289,17 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   x->len     = malloc((L.n + 1) * sizeof(uint32_t));
   x->hdr4    = malloc((L.n + 1) * 4 * sizeof(int32_t));
   if (!x->rec_off || !x->hdr_off || !x->seg || !x->len || !x->hdr4) { rc = DX_E_NOMEM; goto fail; }
+  if (t.want_index)                                       /* the group index: the threads' words are already in record order */
+    { x->gidx_off = malloc((L.n + 1) * sizeof(uint64_t));
+      if (!x->gidx_off) { rc = DX_E_NOMEM; goto fail; }
+      x->gidx = L.gx.w; L.gx.w = NULL;
+      for (i = 0; i < L.n; i++)
+        { x->gidx_off[i] = L.r[i].gx_at;
+          x->gidx_none  += L.r[i].gx_none;
+        }
+      x->gidx_off[L.n] = L.gx.n;
+      x->gidx_words    = L.gx.n;
+    }
   for (i = 0; i < L.n; i++)
     { const walk_rec *r = &L.r[i];
       x->rec_off[i] = at;
@@ -1072,14 +1314,14 @@ int dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *x)
   x->rec_off[L.n] = at;
   x->hdr_off[L.n] = hat;
   walk_mark("index assembled");
-  free(L.r);
+  free(L.r); free(L.gx.w); free(L.gx.tb); free(L.gx.ts);
   for (s = 0; s < 6; s++) free(t.lut[s]);
   for (s = 0; s < 4; s++) free(t.mlut[s]);
   free(t.rlut[0]); free(t.rlut[1]);
   return DX_OK;
 
 fail:
-  free(L.r);
+  free(L.r); free(L.gx.w); free(L.gx.tb); free(L.gx.ts);
   for (s = 0; s < 6; s++) free(t.lut[s]);
   for (s = 0; s < 4; s++) free(t.mlut[s]);
   free(t.rlut[0]); free(t.rlut[1]);

@@ -69,6 +69,7 @@ struct dx_ctx
   // group index of the plain lines, left by dx_qv_encode_onepass for dx_qv_decode when dx_qv_subindex is on
   struct
   { int       want, valid;
+    int       external;          // idx / off are the caller's (dx_qv_use_index): never freed here, dropped before the context makes its own
     uint32_t *idx;               // one byte per group of 16 symbols, 4 * sub_words(len) words per entry
     uint64_t *off;               // n + 1: where each entry's words start
     uint32_t *room;              // n: scratch of the offsets' scan
@@ -101,6 +102,7 @@ int  dx_fail(dx_ctx *ctx, int code, const char *fmt, ...);
 hipError_t dx_hip_malloc(void **p, size_t bytes);
 #define hipMalloc(p, n) dx_hip_malloc((void **) (p), (n))
 int  dx_scratch(dx_ctx *ctx, size_t bytes, void **p);
+void dx_sx_drop_external(dx_ctx *ctx);      // forget a caller's group index (dx_qv_use_index) before the context's own buffers are touched
 uint64_t dx_budget(const dx_ctx *ctx);
 int  dx_after_pending(dx_ctx *ctx);
 void dx_prof_begin_on(dx_ctx *ctx, int kernel, hipStream_t stream);

@@ -2037,6 +2037,7 @@ extern "C" int dx_qv_subindex(dx_ctx *ctx, int on)
 static bool onepass_tokens_ok(const dx_ctx *ctx, const dx_qv_batch *b);
 static int subindex_prepare(dx_ctx *ctx, const dx_qv_batch *b, const void *d_out, const void *d_seg, uint32_t **idx)
 { *idx = NULL;
+  dx_sx_drop_external(ctx);                              // (a caller's index belongs to another stream)
   ctx->sx.valid = 0;
   if (!ctx->sx.want || b->n == 0) return DX_OK;
   const uint64_t n = b->n;

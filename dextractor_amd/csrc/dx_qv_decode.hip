@@ -1309,6 +1309,37 @@ void k_qv_decode_tags(dec_args a, const uint32_t *skip_idx, const uint64_t *skip
     }
 }
 
+// A group index made elsewhere (the host walk of a bare file, dx_qv_walk_indexed) for the stream at d_in / d_seg.
+extern "C" int dx_qv_use_index(dx_ctx *ctx, const uint8_t *d_in, const uint32_t *d_seg, uint64_t n,
+                               const uint32_t *d_gidx, const uint64_t *d_gidx_off, uint64_t none)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (ctx->op.pending)
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_use_index: an encode has begun in this context: end it first (dx_qv_encode_onepass_end)");
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  if (d_gidx == NULL)                                    // take it back
+    { dx_sx_drop_external(ctx);
+      return DX_OK;
+    }
+  if (!d_in || !d_seg || !d_gidx_off || n == 0)
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_use_index: NULL device pointer or no entries");
+  if (!ctx->sx.external)                                 // the context's own index buffers go: one index at a time
+    { DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room);
+      ctx->sx.idx = NULL; ctx->sx.off = NULL; ctx->sx.room = NULL; ctx->sx.cap_idx = 0; ctx->sx.cap_entries = 0;
+    }
+  if (ctx->sx.none == NULL && hipMalloc((void **) &ctx->sx.none, 64) != hipSuccess)
+    { (void) hipGetLastError();
+      return dx_fail(ctx, DX_E_NOMEM, "dx_qv_use_index: no memory");
+    }
+  const uint32_t none32 = none > 0xffffffffull ? 0xffffffffu : (uint32_t) none;
+  DX_HIP(ctx, hipMemcpyAsync(ctx->sx.none, &none32, 4, hipMemcpyHostToDevice, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->sx.idx = (uint32_t *) d_gidx; ctx->sx.off = (uint64_t *) d_gidx_off;
+  ctx->sx.out = d_in; ctx->sx.seg = d_seg; ctx->sx.n = n;
+  ctx->sx.external = 1; ctx->sx.valid = 1;
+  return DX_OK;
+}
+
 extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_rec_off, const uint64_t *d_hdr_off,
                             const uint32_t *d_seg, const uint32_t *d_len, uint64_t n, int flags,
                             uint8_t *d_out, const uint64_t *d_out_off)

@@ -847,7 +847,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
 // waits until they have all arrived, and only then stores the size word; slots are whole 128-byte lines, so no line this
 // kernel has read before holds bytes of an entry it has yet to read; sizes and tile words are read past the caches.
 // The waves of this kernel never hold up an encoder wave, whatever they wait for; the encoder waits for nobody.
-__global__ __launch_bounds__(DX_BLOCK, 8)               // (64 registers: room beside four encoder waves of 112)
+__global__ __launch_bounds__(DX_BLOCK, 7)               // (72 registers: room beside four forwarding-encoder waves of 104)
 void k_qv_follow(qv_args a, enc_scratch sc, const uint64_t *hdr_off, follow_copy fc, uint32_t *status, uint32_t *ticket)
 { const uint64_t base0 = uniform64(*fc.base);
   for (uint64_t r0 = next_unit(ticket, FOLLOW_BATCH), nxt; r0 < a.n; r0 = nxt)

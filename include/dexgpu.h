@@ -348,8 +348,23 @@ typedef struct
     dx_qv_coding  coding;
     char         *prefix;       /* header prefix (QV.c:1256-1265) */
     int           newv, flip;   /* 0x55aa-keyed file (int32 fields) / byte-swapped writer */
+    /* dx_qv_walk_indexed(want_index != 0): the group index of dx_qv_subindex, made by the walk (it passes every code anyway) */
+    uint32_t     *gidx;         /* gidx_words words: per entry the plain lines' group bytes, three header words, the run lines' group words */
+    uint64_t     *gidx_off;     /* n+1: where each entry's words start */
+    uint64_t      gidx_words;
+    uint64_t      gidx_none;    /* run-coded lines left without an index (a group that does not fit its word) */
   } dx_qv_index;
 int  dx_qv_walk(const uint8_t *img, size_t n, dx_qv_index *idx);
+/* The same, and with want_index != 0 also the group index (layout: csrc/dx_layout.h) that lets dx_qv_decode take a
+ * wavefront per line instead of a lane: hand it over with dx_qv_use_index.  The walk then takes one table look-up per
+ * symbol instead of one per several.                                                                         */
+int  dx_qv_walk_indexed(const uint8_t *img, size_t n, dx_qv_index *idx, int want_index);
+/* A group index for the stream at d_in with the segment index d_seg (n entries), uploaded by the caller (d_gidx: the
+ * words, d_gidx_off: n + 1 offsets; none: dx_qv_index.gidx_none).  dx_qv_decode of that stream -- all of it or a
+ * contiguous part, same d_in and d_seg -- then decodes with it.  The memory stays the caller's and must outlive the
+ * decodes; d_gidx == NULL takes the index back.  An index the context made itself (dx_qv_subindex) is dropped.   */
+int  dx_qv_use_index(dx_ctx *ctx, const uint8_t *d_in, const uint32_t *d_seg, uint64_t n,
+                     const uint32_t *d_gidx, const uint64_t *d_gidx_off, uint64_t none);
 void dx_qv_index_free(dx_qv_index *idx);
 
 /* Group index (on = 1): dx_qv_encode_onepass also leaves, in the context, where the codes are: one byte per group of

@@ -22,10 +22,19 @@ static uint8_t *slurp(const char *path, size_t *n)
 static unsigned long long checksum = 0;
 
 static void try_walk(const uint8_t *img, size_t n)
-{ dx_qv_index x;
-  if (dx_qv_walk(img, n, &x) == DX_OK)
-    { checksum += x.n + x.rec_off[x.n];
-      dx_qv_index_free(&x);
+{ dx_qv_index x, y;
+  int a = dx_qv_walk(img, n, &x), b = dx_qv_walk_indexed(img, n, &y, 1);     /* the same records with and without the group index */
+  if ((a == DX_OK) != (b == DX_OK)) { fprintf(stderr, "walk %d but indexed walk %d\n", a, b); exit(3); }
+  if (a == DX_OK)
+    { uint64_t i, w = 0;
+      if (x.n != y.n || x.rec_off[x.n] != y.rec_off[y.n] || y.gidx_off[y.n] != y.gidx_words) { fprintf(stderr, "indexed walk differs\n"); exit(3); }
+      for (i = 0; i < y.n; i++)
+        { if (x.len[i] != y.len[i] || x.seg[5*i] != y.seg[5*i] || x.seg[5*i+4] != y.seg[5*i+4]) { fprintf(stderr, "indexed walk differs at %llu\n", (unsigned long long) i); exit(3); }
+          w += y.gidx_off[i+1] - y.gidx_off[i];
+        }
+      for (i = 0; i < y.gidx_words; i++) checksum += y.gidx[i];           /* every word of the index is read: all of it initialised */
+      checksum += x.n + x.rec_off[x.n] + w;
+      dx_qv_index_free(&x); dx_qv_index_free(&y);
     }
 }
 

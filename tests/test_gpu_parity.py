@@ -1303,3 +1303,61 @@ def test_dexqv_high_run_density_takes_no_text_entries(ctx, run_p):
     # the group index of such lines (decoder side) round-trips too
     back = ctx.undexqv(ctx.dexqv(c.text), upper=True)
     assert back == c.text
+
+
+def test_undexqv_of_a_bare_file_decodes_with_the_walks_group_index(ctx, monkeypatch):
+    """dx_qv_walk_indexed: the host walk of a bare .dexqv leaves the group index the encoder would have left
+    (csrc/dx_layout.h), and dx_file_undexqv hands it to the decoder (dx_qv_use_index): the wave-per-line kernels decode a
+    file from disk.  Same text as the oracle's, with and without the index; the kernels that ran say which route it was."""
+    cases = [synth.make_quiva(n, seed=s, mean=m).text for n, s, m in ((3, 1, 300), (60, 2, 9000), (700, 3, 900), (24, 4, 30000))]
+    cases.append(synth.make_quiva(30, seed=5, mean=9000, prof=synth.pacbio_profile(del_run_p=0.999, sub_run_p=0.97)).text)   # long runs
+    cases += [O.golden(c["input"] + ".quiva") for c in O.cases("quiva") if "-l" not in c["flags"]]
+    for text in cases:
+        dx = O.dexqv(text)
+        want = O.undexqv(dx, upper=True)
+        ctx.profile(True)
+        got = ctx.undexqv(dx, upper=True)
+        used = ctx.kernel_times()
+        ctx.profile(False)
+        assert got == want
+        w = api.qv_walk(dx, index=True)
+        if w["delChar"] >= 0 or w["subChar"] >= 0:
+            assert "k_qv_decode_runs" in used, used.keys()
+        assert "k_qv_decode_sub" in used or "k_qv_decode" in used
+        monkeypatch.setenv("DEXGPU_NO_WALK_INDEX", "1")
+        ctx.profile(True)
+        assert ctx.undexqv(dx, upper=True) == want
+        assert "k_qv_decode_sub" not in ctx.kernel_times() and "k_qv_decode_runs" not in ctx.kernel_times()
+        ctx.profile(False)
+        monkeypatch.delenv("DEXGPU_NO_WALK_INDEX")
+
+
+def test_decode_with_a_host_made_index_equals_the_encoders(ctx):
+    """The same stream decoded three ways -- with the encoder's own group index, with the host walk's (dx_qv_use_index),
+    without any -- gives the same text; the host walk's index has the size the device layout reserves."""
+    c = synth.make_quiva(300, seed=21, mean=7000)
+    dx = O.dexqv(c.text)
+    w = api.qv_walk(dx, index=True)
+    sw = lambda L: (((L + 15) >> 4) + 3) >> 2
+    assert int(w["gidx_off"][-1]) == len(w["gidx"]) and w["gidx_none"] == 0
+    d_in = ctx.to_device(np.frombuffer(dx, np.uint8).copy())
+    d_rec, d_hoff = ctx.to_device(w["rec_off"]), ctx.to_device(w["hdr_off"])
+    d_seg, d_len = ctx.to_device(w["seg"].reshape(-1).copy()), ctx.to_device(w["len"])
+    lens = w["len"].astype(np.uint64)
+    ooff = np.concatenate([[0], np.cumsum(5 * (lens + 1))]).astype(np.uint64)
+    d_ooff, d_out = ctx.to_device(ooff[:-1].copy()), ctx.alloc(int(ooff[-1]) + 64)
+    coding, _, _, _ = api.qv_read_coding(dx[2:])
+    ctx.qv_set_coding(coding, False)
+    ctx.qv_decode(d_in, d_rec, d_hoff, d_seg, d_len, w["n"], True, d_out, d_ooff)
+    plain = d_out.download(np.uint8, int(ooff[-1]))
+    d_gidx, d_goff = ctx.to_device(w["gidx"]), ctx.to_device(w["gidx_off"])
+    ctx.qv_use_index(d_in, d_seg, w["n"], d_gidx, d_goff, w["gidx_none"])
+    ctx.profile(True)
+    ctx.qv_decode(d_in, d_rec, d_hoff, d_seg, d_len, w["n"], True, d_out, d_ooff)
+    used = ctx.kernel_times()
+    ctx.profile(False)
+    ctx.qv_use_index(None, None, 0, None, None)
+    assert "k_qv_decode_sub" in used and "k_qv_decode_runs" in used
+    assert (d_out.download(np.uint8, int(ooff[-1])) == plain).all()
+    body = b"".join(c.text[int(o):int(o) + 5 * (int(l) + 1)] for o, l in zip(c.off, c.len))
+    assert bytes(plain) == body
