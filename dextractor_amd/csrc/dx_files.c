@@ -642,8 +642,13 @@ int dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, s
   *plan = NULL; *out_len = 0;
   p = calloc(1, sizeof(*p));
   if (p == NULL) return DX_E_NOMEM;
-  /* boundary walk (host); it also leaves the group index the wave-per-line decoders take, unless told not to */
-  rc = dx_qv_walk_indexed(img, n, &p->x, getenv("DEXGPU_NO_WALK_INDEX") == NULL);
+  /* boundary walk (host).  With DEXGPU_WALK_INDEX set it also leaves the group index the wave-per-line decoders take
+     (dx_qv_use_index below): 31 instead of 50 ms of kernels per 14 GB of records -- but the walk is 45 % longer with it
+     and the index is another 30 % to upload, and from file to file that costs more than it saves (undexqv of a 1 GB
+     .quiva: 0.54-0.59 s with, 0.44-0.48 s without; profiles/r03c_cli_timing.txt), so it is off unless asked for */
+  { const char *e = getenv("DEXGPU_WALK_INDEX");
+    rc = dx_qv_walk_indexed(img, n, &p->x, e != NULL && e[0] != '\0' && e[0] != '0');
+  }
   if (rc != DX_OK) { free(p); return rc; }
   p->img = img; p->n = n;
   plen = strlen(p->x.prefix);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# end-to-end CLI timing on a 1 GB .quiva in tmpfs
+# end-to-end CLI timing on a 1 GB .quiva in tmpfs; undexqv with and without the walk's group index
 R=$PWD
 D=/dev/shm/clit; rm -rf $D; mkdir -p $D
 python3 - <<PY
@@ -10,6 +10,11 @@ open('$D/s.quiva','wb').write(c.text)
 PY
 ls -la $D
 cd $D
-for i in 1 2; do DEXGPU_TIMING=1 $R/dextractor_amd/bin/dexqv -k s; done
-for i in 1 2; do DEXGPU_TIMING=1 $R/dextractor_amd/bin/undexqv -k s; done
+T() { local a=$(date +%s%N); "$@"; local b=$(date +%s%N); echo "   wall $(( (b - a) / 1000000 )) ms: $*"; }
+for i in 1 2 3; do DEXGPU_TIMING=1 T $R/dextractor_amd/bin/dexqv -k s; done
+cp s.quiva s0.quiva
+echo "== undexqv -U with the walk's group index (DEXGPU_WALK_INDEX=1)"
+for i in 1 2 3; do DEXGPU_WALK_INDEX=1 DEXGPU_TIMING=1 T $R/dextractor_amd/bin/undexqv -k -U s; cmp s.quiva s0.quiva && echo "   identical to the input"; done
+echo "== undexqv -U without (the default)"
+for i in 1 2 3; do DEXGPU_TIMING=1 T $R/dextractor_amd/bin/undexqv -k -U s; cmp s.quiva s0.quiva && echo "   identical to the input"; done
 rm -rf $D

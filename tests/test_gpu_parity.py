@@ -1315,6 +1315,7 @@ def test_undexqv_of_a_bare_file_decodes_with_the_walks_group_index(ctx, monkeypa
     for text in cases:
         dx = O.dexqv(text)
         want = O.undexqv(dx, upper=True)
+        monkeypatch.setenv("DEXGPU_WALK_INDEX", "1")          # (off by default in the file drivers: it costs the CLI more than it saves)
         ctx.profile(True)
         got = ctx.undexqv(dx, upper=True)
         used = ctx.kernel_times()
@@ -1324,12 +1325,11 @@ def test_undexqv_of_a_bare_file_decodes_with_the_walks_group_index(ctx, monkeypa
         if w["delChar"] >= 0 or w["subChar"] >= 0:
             assert "k_qv_decode_runs" in used, used.keys()
         assert "k_qv_decode_sub" in used or "k_qv_decode" in used
-        monkeypatch.setenv("DEXGPU_NO_WALK_INDEX", "1")
+        monkeypatch.delenv("DEXGPU_WALK_INDEX")
         ctx.profile(True)
         assert ctx.undexqv(dx, upper=True) == want
         assert "k_qv_decode_sub" not in ctx.kernel_times() and "k_qv_decode_runs" not in ctx.kernel_times()
         ctx.profile(False)
-        monkeypatch.delenv("DEXGPU_NO_WALK_INDEX")
 
 
 def test_decode_with_a_host_made_index_equals_the_encoders(ctx):
