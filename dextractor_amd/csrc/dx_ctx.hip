@@ -115,7 +115,7 @@ extern "C" int dx_open(int device, dx_ctx **out)
   OPEN_HIP(hipStreamCreateWithFlags(&ctx->own, hipStreamNonBlocking));
   OPEN_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
   open_mark("streams");
-  for (int k = 0; k < 17; k++)
+  for (int k = 0; k < 19; k++)
     OPEN_HIP(hipEventCreateWithFlags(&ctx->ev[k], hipEventDisableTiming));
   open_mark("events");
   ctx->stream = ctx->own;
@@ -155,7 +155,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
-  for (int k = 0; k < 17; k++) (void) hipEventDestroy(ctx->ev[k]);
+  for (int k = 0; k < 19; k++) (void) hipEventDestroy(ctx->ev[k]);
   delete ctx;
 }
 

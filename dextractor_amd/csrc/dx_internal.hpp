@@ -25,7 +25,7 @@ struct dx_ctx
 { int          device;
   hipStream_t  own, stream;
   hipStream_t  side;             // second stream: compaction beside the next group's encode (dx_qv_encode_onepass)
-  hipEvent_t   ev[17];           // ordering between the two streams (no timing): 8 + 8 + 1
+  hipEvent_t   ev[19];           // ordering between the two streams (no timing): 8 + 8 + 1, + 2 of the hybrid route
   int          num_cu;
   char         err[512];
 

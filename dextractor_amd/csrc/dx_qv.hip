@@ -1998,15 +1998,27 @@ static int fast_grid(dx_ctx *ctx, uint64_t entries)
 #define ONEPASS_REGION_CAP ((uint64_t) 32 << 30)          // bytes of one of the two scratch regions of dx_qv_encode_onepass
 
 // side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
+// (next_*: the group after this one goes the direct way -- its sizes are known, its record offsets follow from this group's
+// end: scanned here, in front of the compaction, so that its encoder can start beside it; next_ev says when)
 static int onepass_side(dx_ctx *ctx, hipStream_t B, int waves_per_cu, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
                         uint64_t *d_rec_off, const uint64_t *base_in, uint64_t *base_out, const uint32_t *d_len,
                         const uint8_t *d_slots, const uint64_t *d_slot, const uint32_t *d_seg, const uint8_t *d_hdr,
-                        const uint64_t *d_hdr_off, uint8_t *d_out, uint64_t out_cap, uint32_t *d_tick)
+                        const uint64_t *d_hdr_off, uint8_t *d_out, uint64_t out_cap, uint32_t *d_tick,
+                        const uint32_t *next_size = NULL, uint64_t next_m = 0, uint64_t *next_rec_off = NULL, uint64_t *next_base_out = NULL,
+                        hipEvent_t next_ev = NULL)
 { DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, B));
   DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_tiles, (int) mt, DX_BLOCK, d_size, m, d_tile);
   DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, mt, d_gran);
   DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_apply_base, (int) mt, DX_BLOCK, d_size, m, (const uint64_t *) d_tile, d_rec_off,
                (const uint64_t *) d_gran, base_in, base_out);
+  if (next_size != NULL)
+    { const uint64_t nt = (next_m + SCAN_TILE - 1) / SCAN_TILE;
+      DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_tiles, (int) nt, DX_BLOCK, next_size, next_m, d_tile);
+      DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, nt, d_gran);
+      DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_apply_base, (int) nt, DX_BLOCK, next_size, next_m, (const uint64_t *) d_tile, next_rec_off,
+                   (const uint64_t *) d_gran, (const uint64_t *) base_out, next_base_out);
+      DX_HIP(ctx, hipEventRecord(next_ev, B));
+    }
   DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, waves_per_cu), DX_BLOCK,
             m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
             ctx->d_status, d_tick);
@@ -2474,6 +2486,33 @@ layout:
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
   DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
   int rc = DX_OK, ng = 0;                                // ng: groups run so far (selects the ping-pong base)
+  // Hybrid (DEXGPU_HYBRID): the LAST group goes the direct way.  Its sizes (k_qv_sizes_fast: tokens and plain lines read
+  // once more) are computed on the side stream while the FIRST group is being encoded, its record offsets follow from the
+  // group before's end (onepass_side), and its encoder writes the records in place beside that group's compaction: no
+  // compaction is left over at the end of the batch.
+  const bool hybrid = fast && !follow && G >= 2 && getenv("DEXGPU_HYBRID") != NULL && getenv("DEXGPU_HYBRID")[0] != '0';
+  hipEvent_t off_done = ctx->ev[17], hyb_fork = ctx->ev[18];
+  if (hybrid)
+    { const uint64_t g0 = gb[G - 1], m = gb[G] - g0;
+      qv_args ag = a;
+      ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
+      const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
+      const tok_src   tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
+      uint32_t *d_tick_sz = (uint32_t *) (ctx->d_u64 + 44);         // (a line of its own: away from the other tickets)
+      DX_HIP(ctx, hipEventRecord(hyb_fork, A));
+      DX_HIP(ctx, hipStreamWaitEvent(B, hyb_fork, 0));
+      DX_HIP(ctx, hipMemsetAsync(d_tick_sz, 0, 4, B));
+      // 256-thread workgroups: one wave per SIMD is what fits beside four encoder waves (64 of the 512 registers are left)
+      DX_LAUNCH_ON(ctx, B, DX_K_QV_SIZES, k_qv_sizes_fast, ctx->num_cu * 2, DX_BLOCK,
+                   ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz, tg);
+      if (ctx->tk.unusable > 0)
+        { DX_HIP(ctx, hipMemsetAsync(d_tick_sz, 0, 4, B));
+          DX_LAUNCH_ON(ctx, B, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * SIZES_WAVES), DX_BLOCK,
+                       ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz,
+                       (const uint32_t *) ctx->tk.list, (const unsigned long long *) ctx->tk.count, g0,
+                       (const uint32_t *) (ctx->tk.info + TOK_INFO * g0));
+        }
+    }
   for (int g = 0; g < G && rc == DX_OK; g++)
     { const uint64_t g0 = gb[g], g1 = gb[g + 1];
       if (g0 >= g1) continue;
@@ -2531,6 +2570,32 @@ layout:
           ng += 1;
           continue;
         }
+      if (hybrid && g == G - 1)                          // the last group: sizes and offsets are there, records in place
+        { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
+          const enc_scratch none = { NULL, NULL, NULL, NULL, 0, 0, 0 };
+          DX_HIP(ctx, hipStreamWaitEvent(A, off_done, 0));
+          DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
+          if (sx_idx)
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX, fast_grid(ctx, m), FAST_BLOCK,
+                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, none, tg,
+                      ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0),
+                      d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
+          else
+            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K, fast_grid(ctx, m), FAST_BLOCK,
+                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, none, tg,
+                      ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0),
+                      d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
+          if (ctx->tk.unusable > 0)
+            { const uint64_t work = ctx->tk.unusable < m ? ctx->tk.unusable : m;
+              DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
+              DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, work, 4 * ENC_WAVES), DX_BLOCK,
+                        ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0),
+                        d_out, ctx->d_status, d_tick_enc, none, (const uint32_t *) ctx->tk.list,
+                        (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), out_cap, sx_g);
+            }
+          ng += 1;
+          continue;
+        }
       if (fast)                                          // entries with usable tokens: walked from the tokens
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
@@ -2558,6 +2623,11 @@ layout:
       DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction
       DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g & 7], 0));
+      if (hybrid && g == G - 2)                          // ... and the offsets of the direct group after this one
+        rc = onepass_side(ctx, B, COMPACT_WAVES_PER_CU, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
+                          b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp,
+                          d_size + gb[G - 1], gb[G] - gb[G - 1], d_rec_off + gb[G - 1], d_base + (ng & 1), off_done);
+      else
       rc = onepass_side(ctx, B, COMPACT_WAVES_PER_CU, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
                         b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp);
       (void) hipEventRecord(cmp_done[g & 7], B);

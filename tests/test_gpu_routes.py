@@ -235,3 +235,21 @@ def test_follow_route_small_files_and_text_entries(monkeypatch, mode):
         assert info["direct"] == 3 and info["text_entries"] == 4
         for case in O.cases("quiva"):                                   # the reference's own bytes
             assert ctx.dexqv(O.golden(case["input"] + ".quiva"), "-l" in case["flags"]) == O.golden(case["name"] + ".dexqv")
+
+
+def test_hybrid_route_writes_the_same_stream(monkeypatch):
+    """DEXGPU_HYBRID: the last group goes the direct way (sizes on the side stream beside the first group's encode, records
+    written in place beside its compaction).  Same bytes and the same index beside them, also in more than two groups."""
+    with api.Context(0) as ctx:
+        c = Corpus(ctx, n=60_000, mean=6000)
+        ref, info0, _ = c.encode(ctx, 0)
+        rec_ref = c.d_rec.download(np.uint64, c.n + 1)
+        seg_ref = c.d_seg.download(np.uint32, 5 * c.n)
+        monkeypatch.setenv("DEXGPU_HYBRID", "1")
+        for groups in ("2", "5"):
+            monkeypatch.setenv("DEXGPU_ONEPASS_GROUPS", groups)
+            got, info, _ = c.encode(ctx, 0)
+            assert info["groups"] == int(groups)
+            assert len(got) == len(ref) and (got == ref).all()
+            assert (c.d_rec.download(np.uint64, c.n + 1) == rec_ref).all()
+            assert (c.d_seg.download(np.uint32, 5 * c.n) == seg_ref).all()
