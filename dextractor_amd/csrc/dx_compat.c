@@ -14,6 +14,7 @@
 static dx_ctx       *Ctx     = NULL;
 static dx_entries   *Batch   = NULL;      /* entries gathered by QVcoding_Scan1 */
 static uint32_t     *Lens    = NULL;      /* their lengths: the second pass is checked against them */
+static uint64_t     *Sums    = NULL;      /* ... and a checksum of each entry's five lines: the second pass hands the same bytes, or dies */
 static uint64_t      Nent = 0, LensCap = 0;
 static dx_qv_coding  Tables;              /* what Create_QVcoding built */
 static uint8_t      *Records = NULL;      /* every entry already compressed (Create_QVcoding) */
@@ -24,6 +25,18 @@ static QVcoding      Coding;              /* the object handed to the caller (QV
 static void die(const char *msg)
 { fprintf(stderr, "libdexgpu: %s\n", msg);          /* batch error convention, DB.h:45-47 */
   exit(1);
+}
+
+/* FNV-1a over the five lines of an entry (64 bits: a second pass that hands other bytes of the same length is caught) */
+static uint64_t entry_sum(int rlen, const char *const line[5])
+{ uint64_t h = 0xcbf29ce484222325ull;
+  int k, j;
+  for (k = 0; k < 5; k++)
+    for (j = 0; j < rlen; j++)
+      { h ^= (uint8_t) line[k][j];
+        h *= 0x100000001b3ull;
+      }
+  return h;
 }
 
 static void drop_results(void)
@@ -49,9 +62,16 @@ void QVcoding_Scan1(int rlen, char *del, char *tag, char *ins, char *mrg, char *
   if (Nent == LensCap)
     { uint64_t  nc = LensCap ? 2 * LensCap : 1024;
       uint32_t *t  = realloc(Lens, nc * sizeof(*t));
+      uint64_t *u;
       if (t == NULL) die("Out of memory (QVcoding_Scan1)");
-      Lens = t; LensCap = nc;
+      Lens = t;
+      u = realloc(Sums, nc * sizeof(*u));
+      if (u == NULL) die("Out of memory (QVcoding_Scan1)");
+      Sums = u; LensCap = nc;
     }
+  { const char *const line[5] = { del, tag, ins, mrg, sub };
+    Sums[Nent] = entry_sum(rlen, line);
+  }
   Lens[Nent++] = (uint32_t) rlen;
 }
 
@@ -102,11 +122,15 @@ void Write_QVcoding(FILE *output, QVcoding *coding)
 void Compress_Next_QVentry1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub,
                             FILE *output, QVcoding *coding, int lossy)
 { size_t k;
-  (void) del; (void) tag; (void) ins; (void) mrg; (void) sub; (void) lossy;
+  (void) lossy;                                     /* (the records were made with Create_QVcoding's `lossy`, as in dex2DB.c) */
   if (coding == NULL || coding->delScheme != (void *) &Tables || Records == NULL)
     die("Compress_Next_QVentry1: call Create_QVcoding first");
   if (Next >= Nent || (uint32_t) rlen != Lens[Next])
     die("Compress_Next_QVentry1: the entries must come in the order they were scanned in");
+  { const char *const line[5] = { del, tag, ins, mrg, sub };      /* the reference encodes what it is handed here (QV.c:1343-1379): */
+    if (entry_sum(rlen, line) != Sums[Next])                       /* other bytes than were scanned must not pass silently */
+      die("Compress_Next_QVentry1: this entry's lines are not the ones QVcoding_Scan1 was given for it");
+  }
   k = (size_t) (Coff[Next + 1] - Coff[Next]);
   if (k && fwrite(Records + Coff[Next], 1, k, output) != k)
     die("Compress_Next_QVentry1: write failed");
@@ -119,5 +143,5 @@ void Free_QVcoding(QVcoding *coding)                /* QV.c:1324-1334: the auxil
       coding->prefix = NULL;
     }
   drop_results();
-  free(Lens); Lens = NULL; LensCap = 0; Nent = 0;
+  free(Lens); Lens = NULL; free(Sums); Sums = NULL; LensCap = 0; Nent = 0;
 }

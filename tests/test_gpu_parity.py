@@ -1361,3 +1361,38 @@ def test_decode_with_a_host_made_index_equals_the_encoders(ctx):
     assert (d_out.download(np.uint8, int(ooff[-1])) == plain).all()
     body = b"".join(c.text[int(o):int(o) + 5 * (int(l) + 1)] for o, l in zip(c.off, c.len))
     assert bytes(plain) == body
+
+
+def test_old_name_shim_refuses_other_bytes_in_the_second_pass(tmp_path):
+    """Compress_Next_QVentry1 (dexcompat.h) writes the record Create_QVcoding made from what QVcoding_Scan1 was given; the
+    reference encodes what it is handed in the second pass (QV.c:1343-1379), so other bytes of the same length must not
+    pass silently: the shim checks a checksum of the five lines per entry and dies like on an order mismatch."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, ctypes as C
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+import numpy as np
+from dextractor_amd import _lib as L, synth
+lib = L.load(); libc = C.CDLL(None)
+libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+lib.Create_QVcoding.restype = C.c_void_p
+lib.QVcoding_Scan1.argtypes = [C.c_int] + [C.c_char_p] * 5
+lib.Compress_Next_QVentry1.argtypes = [C.c_int] + [C.c_char_p] * 5 + [C.c_void_p, C.c_void_p, C.c_int]
+c = synth.make_quiva(6, seed=3, mean=3000)
+t = np.frombuffer(c.text, np.uint8)
+ents = [[t[int(o) + k * (int(n) + 1): int(o) + k * (int(n) + 1) + int(n)].tobytes() for k in range(5)] for o, n in zip(c.off, c.len)]
+lib.QVcoding_Scan1(0, None, None, None, None, None)
+for e in ents: lib.QVcoding_Scan1(len(e[0]), *e)
+coding = lib.Create_QVcoding(0)
+f = libc.fopen({str(tmp_path / 'x.qvs')!r}.encode(), b"wb")
+lib.Compress_Next_QVentry1(len(ents[0][0]), *ents[0], f, coding, 0)
+bad = list(ents[1]); bad[2] = bytes([bad[2][0] ^ 1]) + bad[2][1:]
+print("SECOND", flush=True)
+lib.Compress_Next_QVentry1(len(bad[0]), *bad, f, coding, 0)
+print("NOT REACHED", flush=True)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stderr[-500:])
+    assert b"SECOND" in r.stdout and b"NOT REACHED" not in r.stdout
+    assert b"not the ones QVcoding_Scan1 was given" in r.stderr
