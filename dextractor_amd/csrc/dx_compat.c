@@ -137,10 +137,97 @@ void Compress_Next_QVentry1(int rlen, char *del, char *tag, char *ins, char *mrg
   Next += 1;
 }
 
+/* ---- decode side (undexqv.c:112-208) ------------------------------------------------------------------------ */
+static uint8_t     *DImg   = NULL;        /* the whole .dexqv file */
+static size_t       DImgN  = 0;
+static dx_qv_index  DWalk;                /* its records (host walk) */
+static int          DHave  = 0;
+static uint8_t     *DText  = NULL;        /* every entry decoded: the .quiva text dx_file_undexqv makes */
+static size_t       DTextN = 0, DAt = 0;  /* DAt: where the next entry's header line starts in DText */
+static uint64_t     DNext  = 0;
+static QVcoding     DCoding;
+
+static void drop_decode(void)
+{ free(DImg); DImg = NULL; DImgN = 0;
+  if (DHave) dx_qv_index_free(&DWalk);
+  DHave = 0;
+  dx_file_free(DText); DText = NULL; DTextN = 0; DAt = 0; DNext = 0;
+}
+
+static void open_gpu(const char *who)
+{ if (Ctx == NULL)
+    { const char *d = getenv("DEXGPU_DEVICE");
+      if (dx_open(d ? atoi(d) : 0, &Ctx) != DX_OK)
+        { fprintf(stderr, "libdexgpu: %s: cannot open a GPU (%s)\n", who, dx_last_error(NULL));
+          exit(1);
+        }
+    }
+}
+
+QVcoding *Read_QVcoding(FILE *input)
+{ long   end;
+  size_t plen;
+  drop_decode();
+  if (input == NULL || fseek(input, 0, SEEK_END) != 0 || (end = ftell(input)) < 0 || fseek(input, 0, SEEK_SET) != 0)
+    die("Read_QVcoding: the input must be a seekable file (the whole of it is decoded at once)");
+  DImgN = (size_t) end;
+  DImg  = malloc(DImgN ? DImgN : 1);
+  if (DImg == NULL) die("Out of memory (Read_QVcoding)");
+  if (DImgN && fread(DImg, 1, DImgN, input) != DImgN) die("Read_QVcoding: read failed");
+  if (dx_qv_walk(DImg, DImgN, &DWalk) != DX_OK) die("Read_QVcoding: not a .dexqv file, or a damaged one");
+  DHave = 1;
+  open_gpu("Read_QVcoding");
+  if (dx_file_undexqv(Ctx, DImg, DImgN, /*upper*/ 0, &DText, &DTextN) != DX_OK)
+    { fprintf(stderr, "libdexgpu: Read_QVcoding: %s\n", dx_last_error(Ctx));
+      exit(1);
+    }
+  if (fseek(input, (long) DWalk.rec_off[0], SEEK_SET) != 0) die("Read_QVcoding: seek failed");   /* behind the coding, as QV.c:1214-1320 leaves it */
+  memset(&DCoding, 0, sizeof(DCoding));
+  DCoding.delScheme = &DWalk;                           /* opaque to the caller */
+  DCoding.delChar   = DWalk.coding.delChar;
+  DCoding.subChar   = DWalk.coding.subChar;
+  DCoding.flip      = DWalk.flip;
+  plen = strlen(DWalk.prefix);
+  DCoding.prefix = malloc(plen + 1);                    /* the caller's to keep until Free_QVcoding, QV.c:1256-1265 */
+  if (DCoding.prefix == NULL) die("Out of memory (Read_QVcoding)");
+  memcpy(DCoding.prefix, DWalk.prefix, plen + 1);
+  return &DCoding;
+}
+
+int Uncompress_Next_QVentry(FILE *input, char **entry, QVcoding *coding, int rlen)
+{ const uint64_t k = DNext;
+  const uint8_t *nl;
+  size_t at;
+  long   pos;
+  int    e;
+  if (coding == NULL || coding->delScheme != (void *) &DWalk || !DHave)
+    die("Uncompress_Next_QVentry: call Read_QVcoding first");
+  if (k >= DWalk.n) die("Uncompress_Next_QVentry: no more entries in this file");
+  if ((uint32_t) rlen != DWalk.len[k])
+    die("Uncompress_Next_QVentry: rlen is not the length of the entry that stands here");
+  pos = ftell(input);                                   /* the caller has read this record's framing bytes, no more, no less */
+  if (pos < 0 || (uint64_t) pos != DWalk.rec_off[k] + (DWalk.hdr_off[k + 1] - DWalk.hdr_off[k]))
+    die("Uncompress_Next_QVentry: the stream does not stand at the start of the next entry's segments");
+  nl = memchr(DText + DAt, '\n', DTextN - DAt);          /* the entry's header line, then its five lines */
+  if (nl == NULL) die("Uncompress_Next_QVentry: internal: decoded text ends early");
+  at = (size_t) (nl - DText) + 1;
+  if (at + 5 * ((size_t) rlen + 1) > DTextN) die("Uncompress_Next_QVentry: internal: decoded text ends early");
+  for (e = 0; e < 5; e++)
+    memcpy(entry[e], DText + at + (size_t) e * ((size_t) rlen + 1), (size_t) rlen);
+  DAt   = at + 5 * ((size_t) rlen + 1);
+  DNext = k + 1;
+  if (fseek(input, (long) DWalk.rec_off[k + 1], SEEK_SET) != 0) die("Uncompress_Next_QVentry: seek failed");
+  return 0;
+}
+
 void Free_QVcoding(QVcoding *coding)                /* QV.c:1324-1334: the auxiliary storage, not the object */
 { if (coding != NULL)
     { free(coding->prefix);
       coding->prefix = NULL;
+    }
+  if (coding == &DCoding)                           /* a coding Read_QVcoding made: the decode side's state goes */
+    { drop_decode();
+      return;
     }
   drop_results();
   free(Lens); Lens = NULL; free(Sums); Sums = NULL; LensCap = 0; Nent = 0;

@@ -41,6 +41,16 @@ void      Compress_Next_QVentry1(int rlen, char *del, char *tag, char *ins, char
                                  FILE *output, QVcoding *coding, int lossy);                 /* QV.c:1343-1379 */
 void      Free_QVcoding(QVcoding *coding);                                                   /* QV.c:1324-1334 */
 
+/* The decode side, as undexqv.c:112-208 uses it: Read_QVcoding after the caller has read (or not found) the 0x55aa key,
+ * then per entry the caller's own reads of the framing bytes and one Uncompress_Next_QVentry.  A GPU cannot be fed an
+ * entry at a time here either: Read_QVcoding takes the WHOLE file from `input` (which must be seekable), walks it and
+ * decodes every entry on the GPU at once (dx_qv_walk + the decode kernels); Uncompress_Next_QVentry hands out the next
+ * entry's five lines (tags in lower case, as the reference leaves them) and leaves `input` at the next record's framing
+ * bytes, exactly where the reference's reads would have left it.  It checks that the stream stands where this entry's
+ * segments start and that rlen is the entry's length; one file at a time per process.                          */
+QVcoding *Read_QVcoding(FILE *input);                                                        /* QV.c:1214-1320 */
+int       Uncompress_Next_QVentry(FILE *input, char **entry, QVcoding *coding, int rlen);    /* QV.c:1428-1481 */
+
 #ifdef __cplusplus
 }
 #endif

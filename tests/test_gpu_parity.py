@@ -1396,3 +1396,60 @@ print("NOT REACHED", flush=True)
     assert r.returncode == 1, (r.returncode, r.stderr[-500:])
     assert b"SECOND" in r.stdout and b"NOT REACHED" not in r.stdout
     assert b"not the ones QVcoding_Scan1 was given" in r.stderr
+
+
+def test_old_name_decode_shims_like_undexqv(ctx, tmp_path):
+    """include/dexcompat.h: Read_QVcoding / Uncompress_Next_QVentry driven the way undexqv.c:101-208 drives them -- the
+    caller reads the 0x55aa key and, per entry, the framing bytes itself through the same FILE*, the shim hands out the
+    five lines (lower-case tags) and leaves the stream at the next record.  The text put together that way is the
+    reference's `undexqv` output."""
+    import struct
+    lib = L.load()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.fread.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    libc.fread.restype = C.c_size_t
+
+    class QVcoding(C.Structure):
+        _fields_ = [(k, C.c_void_p) for k in ("delScheme", "insScheme", "mrgScheme", "subScheme", "dRunScheme", "sRunScheme")] + \
+                   [("delChar", C.c_int), ("subChar", C.c_int), ("flip", C.c_int), ("prefix", C.c_char_p)]
+    lib.Read_QVcoding.restype = C.POINTER(QVcoding)
+    lib.Read_QVcoding.argtypes = [C.c_void_p]
+    lib.Uncompress_Next_QVentry.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(QVcoding), C.c_int]
+    lib.Free_QVcoding.argtypes = [C.POINTER(QVcoding)]
+
+    def rd(f, n):
+        b = C.create_string_buffer(n)
+        got = libc.fread(b, 1, n, f)
+        return b.raw[:got]
+
+    for text in (synth.make_quiva(17, seed=41, mean=4000).text, O.golden("qv_runs.quiva"), O.golden("qv_full.quiva")):
+        dx = O.dexqv(text)
+        want = O.undexqv(dx, upper=False)
+        path = tmp_path / "x.dexqv"
+        path.write_bytes(dx)
+        f = libc.fopen(str(path).encode(), b"rb")
+        assert rd(f, 2) == b"\xaa\x55"                                  # undexqv.c:103-110
+        coding = lib.Read_QVcoding(f)                                   # undexqv.c:112
+        prefix = coding.contents.prefix
+        out, well = [], 0
+        while True:                                                     # undexqv.c:119-208
+            b = rd(f, 1)
+            if not b:
+                break
+            while b[0] == 255:
+                well += 255
+                b = rd(f, 1)
+            well += b[0]
+            beg, end, qv = struct.unpack("<iii", rd(f, 12))
+            rlen = end - beg
+            bufs = [C.create_string_buffer(rlen + 1) for _ in range(5)]
+            entry = (C.c_char_p * 5)(*[C.cast(x, C.c_char_p) for x in bufs])
+            assert lib.Uncompress_Next_QVentry(f, entry, coding, rlen) == 0
+            out.append(b"%s/%d/%d_%d RQ=0.%d\n" % (prefix, well, beg, end, qv))
+            out += [x.raw[:rlen] + b"\n" for x in bufs]
+        lib.Free_QVcoding(coding)
+        libc.fclose(f)
+        assert b"".join(out) == want

@@ -27,7 +27,8 @@ def test_library_exports_every_declared_symbol():
     compat = open(os.path.join(ROOT, "include", "dexcompat.h")).read()
     compat = re.sub(r"/\*.*?\*/", "", compat, flags=re.S)
     old_names = set(re.findall(r"\b([A-Z][A-Za-z_]+_QV[a-z]+1?|QVcoding_Scan1)\s*\(", compat))
-    assert old_names == {"QVcoding_Scan1", "Create_QVcoding", "Write_QVcoding", "Compress_Next_QVentry1", "Free_QVcoding"}
+    assert old_names == {"QVcoding_Scan1", "Create_QVcoding", "Write_QVcoding", "Compress_Next_QVentry1", "Free_QVcoding",
+                         "Read_QVcoding", "Uncompress_Next_QVentry"}
     for name in old_names:
         assert hasattr(lib, name), f"{name} declared in dexcompat.h but not exported"
 
