@@ -33,7 +33,9 @@
 
 #define QV_WIN_WORDS  512                          // per-wave LDS bit window (2 KiB)
 #define QV_WIN_BITS   (32u * (QV_WIN_WORDS - 32))  // usable: one lane's worst case (896 bits) always fits
+#ifndef QV_FLUSH_BITS
 #define QV_FLUSH_BITS 8192u                        // drain the window once it holds this much
+#endif
 #define TAG_WIN_WORDS 128                          // per-wave window of the tag segment
 #define TAG_FLUSH_BITS 1024u
 
