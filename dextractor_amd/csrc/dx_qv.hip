@@ -47,8 +47,8 @@
 #define ENC_WAVES 4
 #endif
 // perturbation experiments (tools/microbench/hist_time.py): parts of k_qv_hist compiled out -- wrong results, a kernel
-// time that says what the part costs.  1: no token rounds, 2: no plain lines, 4: no position lists, 8: no token stores,
-// 16: no run-coded lines at all
+// time that says what the part costs.  1: no token rounds, 2: no plain lines, 4: no position lists, 8: no tokens (no tag
+// look-up, no assembly, no store), 16: no run-coded lines at all, 32: tokens made but not stored to memory
 #ifndef HIST_SKIP
 #define HIST_SKIP 0
 #endif
@@ -416,7 +416,8 @@ __device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c,
               }
             if (emit)
               { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9);
-                tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;
+                if (HIST_SKIP & 32) R.chunk[2u * (i0 + 64u * k + (uint32_t) lane) & 1023u] = (uint8_t) (t ^ (t >> 8));   // (experiment: the token made, not stored)
+                else tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;
                 odd |= x[k] >= 128u ? 1u : 0u;
               }
           }
