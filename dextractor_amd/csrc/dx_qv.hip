@@ -222,11 +222,17 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
     }
 
   const int lane = lane_id(), wid = tid >> 6;
-  for (long long r = wid; r <= first; r += DX_WAVES_PER_BLK)
-    { const uint32_t L   = a.len[r];
-      const uint8_t *sub = line_ptr(a, (uint64_t) r, L, 4);
-      for (uint32_t pos = lane; pos < L; pos += 64)
-        atomicAdd(&s_hist[sub[pos]], 1u);
+  for (long long r = wid; r <= first; r += DX_WAVES_PER_BLK)      // (a dozen entries: 16 bytes per lane and load, as everywhere)
+    { const uint32_t L    = a.len[r];
+      const uint8_t *sub  = line_ptr(a, (uint64_t) r, L, 4);
+      const bool     over = can_overread(a, sub, L);
+      for (uint32_t base = 0; base < L; base += DX_STEP)
+        { const uint32_t pos   = base + 16u * (uint32_t) lane;
+          const u32x4    c     = fetch(sub, pos, L, over);
+          const int      valid = valid_of(pos, L);
+          for (int b = 0; b < valid; b++)
+            atomicAdd(&s_hist[chunk_byte(c, b)], 1u);
+        }
     }
   __syncthreads();
   if (tid == 0)
