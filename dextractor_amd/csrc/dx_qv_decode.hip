@@ -683,6 +683,9 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
 #else
 #define DS_WIN   1280                                      // words per wave: 5 KB
 #endif
+#ifndef DS_DUAL
+#define DS_DUAL  1                                         // two groups per lane decoded side by side (two look-up chains in flight)
+#endif
 #ifndef DS_STEPS
 #define DS_STEPS 4                                         // steps of 64 groups per round (one step always fits: <= 515 words)
 #endif
@@ -777,6 +780,48 @@ __device__ __forceinline__ void ds_block8(winrd &rd, const uint16_t *tab, const 
         }
     }
   o0 = w[0]; o1 = w[1];
+}
+
+// the same for two groups at once: the look-up -> shift -> look-up chains of the two are independent, so a lane has two
+// LDS reads in flight where one group alone leaves it waiting for each (DS_DUAL)
+__device__ __forceinline__ void ds_block8_dual(winrd &ra, winrd &rb, const uint16_t *tab, const uint32_t *lng,
+                                               uint32_t &a0, uint32_t &a1, uint32_t &b0, uint32_t &b1)
+{ const winrd sa = ra, sb = rb;
+  uint32_t wa[2] = { 0u, 0u }, wb[2] = { 0u, 0u }, zand = 31u;
+  #pragma unroll
+  for (int k = 0; k < 8; k += 2)
+    { wr_fill(ra);
+      wr_fill(rb);
+      #pragma unroll
+      for (int h = 0; h < 2; h++)
+        { const uint32_t ea = tab[ra.hi >> (32 - DP_BITS)], eb = tab[rb.hi >> (32 - DP_BITS)];
+          const uint32_t sel = ((k + h) & 3) == 0 ? 0x03020105u : ((k + h) & 3) == 1 ? 0x03020500u :
+                               ((k + h) & 3) == 2 ? 0x03050100u : 0x05020100u;
+          zand &= ea & eb;
+          ra.hi = __builtin_amdgcn_alignbit(ra.hi, ra.lo, ea);
+          ra.lo = __builtin_amdgcn_alignbit(ra.lo, 0u, ea);
+          ra.nb += (int) (ea & 31u) - 32;
+          rb.hi = __builtin_amdgcn_alignbit(rb.hi, rb.lo, eb);
+          rb.lo = __builtin_amdgcn_alignbit(rb.lo, 0u, eb);
+          rb.nb += (int) (eb & 31u) - 32;
+          wa[(k + h) >> 2] = __builtin_amdgcn_perm(ea, wa[(k + h) >> 2], sel);
+          wb[(k + h) >> 2] = __builtin_amdgcn_perm(eb, wb[(k + h) >> 2], sel);
+        }
+    }
+  if (__any((int) (~zand & 16u)))                          // a long code somewhere: both blocks again, code by code
+    { ra = sa; rb = sb;
+      #pragma unroll 1
+      for (int k = 0; k < 8; k++)
+        { const uint32_t c = wr_symbol(ra, tab, lng);
+          wa[k >> 2] = (k & 3) ? (wa[k >> 2] | (c << (8 * (k & 3)))) : c;
+        }
+      #pragma unroll 1
+      for (int k = 0; k < 8; k++)
+        { const uint32_t c = wr_symbol(rb, tab, lng);
+          wb[k >> 2] = (k & 3) ? (wb[k >> 2] | (c << (8 * (k & 3)))) : c;
+        }
+    }
+  a0 = wa[0]; a1 = wa[1]; b0 = wb[0]; b1 = wb[1];
 }
 
 // ---- two symbols per look-up ---------------------------------------------------------------------------------
@@ -952,9 +997,35 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
             }
           wave_sync();
           uint32_t used = 0;                               // serial mode: bits the group really took
+          int kdone = 0;
+#if DS_DUAL && !DS_PAIR
+          // pairs of steps whose 128 groups are all whole (every round but a line's last): two groups per lane side by side
+          #pragma unroll
+          for (int k = 0; k + 1 < DS_STEPS; k += 2)
+            if (kdone == k && (uint32_t) k + 2u <= steps && !serial && 16u * (g0 + 64u * (k + 2)) <= L)
+              { const uint32_t ga = g0 + 64u * k + (uint32_t) lane, gb = ga + 64u;
+                winrd ra, rb;
+                ra.win = win; rb.win = win;
+                { const uint32_t sb = st[k] - 32u * w0, off = sb & 31u;
+                  ra.wi = (sb >> 5) + 1u;
+                  ra.hi = win[sb >> 5] << off; ra.lo = 0u; ra.nb = 32 - (int) off;
+                }
+                { const uint32_t sb = st[k + 1] - 32u * w0, off = sb & 31u;
+                  rb.wi = (sb >> 5) + 1u;
+                  rb.hi = win[sb >> 5] << off; rb.lo = 0u; rb.nb = 32 - (int) off;
+                }
+                uint32_t x0, x1, x2, x3, y0, y1, y2, y3;
+                ds_block8_dual(ra, rb, tab, lng, x0, x1, y0, y1);
+                ds_block8_dual(ra, rb, tab, lng, x2, x3, y2, y3);
+                const u32x4 va = { x0, x1, x2, x3 }, vb = { y0, y1, y2, y3 };
+                *(u32x4_u *) (out + 16ull * ga) = va;
+                *(u32x4_u *) (out + 16ull * gb) = vb;
+                kdone = k + 2;
+              }
+#endif
           #pragma unroll
           for (int k = 0; k < DS_STEPS; k++)
-            if ((uint32_t) k < steps)
+            if ((uint32_t) k < steps && k >= kdone)
               { const uint32_t g = g0 + 64u * k + (uint32_t) lane;
                 const uint32_t valid = g < G && (!serial || lane == 0) ? (L - 16u * g < 16u ? L - 16u * g : 16u) : 0u;
                 if (valid)
@@ -1010,6 +1081,12 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 #define DR_BLOCK 1024                                      // 16 waves: tables 36 KB + 16 x (1.75 + 5) KB = 144 KB
 #define DR_NWAVE (DR_BLOCK / 64)
 #define DR_WIN   448                                       // words per wave: a pass's bits (<= RUN_PASSBITS, the encoder saw to it) + slack
+#ifndef DR_AHEAD
+#define DR_AHEAD 1                                         // the next pass's group word and window, the tag bytes: requested early
+#endif
+#ifndef DR_FAST
+#define DR_FAST  1                                         // the sound pass without a bit buffer (see the kernel)
+#endif
 #define DR_STRETCH (RUN_STRETCH / 4)                       // words per wave for a pass's piece of the line (the encoder saw to it that it fits)
 
 template <int NK>                                          // run-coded kinds in the launch: 1 or 2 (del, sub)
@@ -1018,8 +1095,8 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                       uint32_t kinds, const uint32_t *sub_idx, const uint64_t *sub_off)
 { __shared__ uint16_t s_tab[2 * NK][DP_SIZE];              // per kind: symbols, runs (8 KB each)
   __shared__ uint32_t s_long[2 * NK][1 + DX_LONG_MAX];
-  __shared__ uint32_t s_win[DR_NWAVE][DR_WIN];             // 52 KB
-  __shared__ uint32_t s_str[DR_NWAVE][DR_STRETCH];         // (see DR_BLOCK)
+  __shared__ uint32_t s_win[DR_NWAVE][DR_WIN];             // 52 KB; [0] is a lead word (the positioned reads look one word back)
+  __shared__ __attribute__((aligned(16))) uint32_t s_str[DR_NWAVE][DR_STRETCH];       // (see DR_BLOCK)
   { int nk = 0;
     for (int q = 0; q < 4; q++)
       if ((kinds >> q) & 1u)
@@ -1051,44 +1128,82 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
         }
     __syncthreads();
   }
-  uint32_t *const win  = s_win[threadIdx.x >> 6], *const stretch = s_str[threadIdx.x >> 6];
+  uint32_t *const win  = s_win[threadIdx.x >> 6] + 1, *const stretch = s_str[threadIdx.x >> 6];
   const int       lane = lane_id();
+  if (lane == 0) win[-1] = 0u;
 
-  for (;;)                                                 // a task = the run-coded lines of one entry
-    { uint32_t t = 0;
-      if (lane == 0)
-        t = atomicAdd(next_task, 1u);
-      t = uniform(t);
-      if ((uint64_t) t >= a.n) break;
-      const uint64_t r = t;
+  // A task = the run-coded lines of one entry.  What says where an entry's lines are -- its length, record, segment
+  // sizes, share of the index: 18 words from six arrays -- is ONE load whose lanes fetch a word each, requested while the
+  // entry before it is decoded and taken apart with v_readlane when its turn comes; so are the three header words of its
+  // share (asked for between the two lines) and the ticket (drawn two entries ahead).  Otherwise an entry begins with five
+  // dependent memory round trips per line, at four waves per SIMD.
+  struct dr_entry { uint32_t L, hl, sg[5]; uint64_t so, so1, rec, oo; };
+#define DR_RL(V, K)  ((uint32_t) __builtin_amdgcn_readlane((int) (V), K))
+#define DR_DESC(V, R)                                                                                                   \
+  { const uint32_t *p_ = a.len + (R);                                                                                   \
+    if (lane >= 1  && lane <= 4)  p_ = (const uint32_t *) (sub_off + (R)) + (lane - 1);                                 \
+    if (lane >= 5  && lane <= 6)  p_ = (const uint32_t *) (a.rec_off + (R)) + (lane - 5);                               \
+    if (lane >= 7  && lane <= 8)  p_ = (const uint32_t *) (a.out_off + (R)) + (lane - 7);                               \
+    if (lane >= 9  && lane <= 12 && a.hdr_off) p_ = (const uint32_t *) (a.hdr_off + (R)) + (lane - 9);                  \
+    if (lane >= 13 && lane <= 17) p_ = a.seg + 5 * (R) + (lane - 13);                                                   \
+    V = *p_;                                                                                                            \
+  }
+#define DR_TAKE(E, V)                                                                                                   \
+  { E.L   = DR_RL(V, 0);                                                                                                \
+    E.so  = (uint64_t) DR_RL(V, 1) | ((uint64_t) DR_RL(V, 2) << 32);                                                    \
+    E.so1 = (uint64_t) DR_RL(V, 3) | ((uint64_t) DR_RL(V, 4) << 32);                                                    \
+    E.rec = (uint64_t) DR_RL(V, 5) | ((uint64_t) DR_RL(V, 6) << 32);                                                    \
+    E.oo  = (uint64_t) DR_RL(V, 7) | ((uint64_t) DR_RL(V, 8) << 32);                                                    \
+    E.hl  = a.hdr_off ? DR_RL(V, 11) - DR_RL(V, 9) : 0u;         /* (a header is far below 4 GB: low words do) */       \
+    E.sg[0] = DR_RL(V, 13); E.sg[1] = DR_RL(V, 14); E.sg[2] = DR_RL(V, 15); E.sg[3] = DR_RL(V, 16); E.sg[4] = DR_RL(V, 17); \
+  }
+#define DR_HEADV(V, E) { V = 0u; if (lane < 3) V = (sub_idx + E.so + run_base(E.L))[lane]; }
+  uint32_t t = 0, t1 = 0, t2v = 0, dv = 0, dv_nx = 0, hv = 0, hv_nx = 0;
+  if (lane == 0) { t = atomicAdd(next_task, 1u); t1 = atomicAdd(next_task, 1u); }
+  t = uniform(t); t1 = uniform(t1);
+  if ((uint64_t) t < a.n)
+    { dr_entry e0;
+      DR_DESC(dv, (uint64_t) t)
+      DR_TAKE(e0, dv)
+      DR_HEADV(hv, e0)
+    }
+  for (; (uint64_t) t < a.n; t = t1, t1 = uniform(t2v), dv = dv_nx, hv = hv_nx)       // (every wave gets past the end: the counter only grows)
+    { dr_entry cur, nx;
+      uint32_t head[3];
+      DR_TAKE(cur, dv)
+      head[0] = DR_RL(hv, 0); head[1] = DR_RL(hv, 1); head[2] = DR_RL(hv, 2);
+      const bool more = (uint64_t) t1 < a.n;
+      if (more) DR_DESC(dv_nx, (uint64_t) t1)
+      if (lane == 0) t2v = atomicAdd(next_task, 1u);
       int slot = -1;
       #pragma unroll 1
       for (uint32_t q = 0; q < 4; q += 3)                  // del (0), sub (3)
-      { if (!((kinds >> q) & 1u)) continue;
+      { if (q == 3 && more) { DR_TAKE(nx, dv_nx) DR_HEADV(hv_nx, nx) }             // (the next entry's numbers are here by now)
+        if (!((kinds >> q) & 1u)) continue;
         slot += 1;
-        const uint32_t  L   = a.len[r];
-        const uint32_t *hdr = sub_idx + sub_off[r] + run_base(L);         // three header words, then the groups
-        const uint32_t  cnt = uniform(hdr[q == 0 ? 0 : 1]);
+        const uint32_t  L   = cur.L;
+        const uint32_t *hdr = sub_idx + cur.so + run_base(L);             // three header words, then the groups
+        const uint32_t  cnt = head[q == 0 ? 0 : 1];
         if (cnt == RUN_NONE) continue;                     // not indexed: k_qv_decode takes this line
-        { const uint64_t share = sub_off[r + 1] - sub_off[r];              // words of this entry in the index
-          const uint64_t need  = (uint64_t) run_base(L) + 3u + 64ull * ((q == 0 ? 0u : uniform(hdr[2])) + run_passes(cnt));
+        { const uint64_t share = cur.so1 - cur.so;                        // words of this entry in the index
+          const uint64_t need  = (uint64_t) run_base(L) + 3u + 64ull * ((q == 0 ? 0u : head[2]) + run_passes(cnt));
           if (cnt > ((((L >> 1) + 64u) + 7u) & ~7u) || need > share)       // not an index this entry can have: never follow it
             { if (lane == 0) atomicOr(status, 4u);
               continue;
             }
         }
         const int       line = q == 0 ? 0 : 4;
-        const uint32_t *sg   = a.seg + 5 * r;
-        uint64_t at = a.rec_off[r] + (a.hdr_off ? a.hdr_off[r + 1] - a.hdr_off[r] : 0);
+        const uint32_t *sg   = cur.sg;
+        uint64_t at = cur.rec + cur.hl;
         for (int k = 0; k < line; k++)
           at += sg[k];
         const uint8_t  *seg    = a.in + at;
         const uint32_t  sbytes = sg[line];
-        uint8_t        *out    = a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u);
+        uint8_t        *out    = a.out + cur.oo + (uint64_t) line * ((uint64_t) L + 1u);
         const uint32_t  rc     = (uint32_t) (q == 0 ? a.delChar : a.subChar);
         const uint16_t *stab   = s_tab[2 * slot], *rtab = s_tab[2 * slot + 1];
         const uint32_t *slng   = s_long[2 * slot], *rlng = s_long[2 * slot + 1];
-        const uint32_t *g16    = hdr + 3 + (q == 0 ? 0u : 64u * uniform(hdr[2]));
+        const uint32_t *g16    = hdr + 3 + (q == 0 ? 0u : 64u * head[2]);
 
         uint32_t base_bit = 0, base_pos = 0, bad = 0;
         const uint32_t pat = rc * 0x01010101u;
@@ -1099,12 +1214,30 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
         const uint32_t tbytes = sg[1];
         uint8_t       *tout  = out + (uint64_t) L + 1u;
         const uint32_t fold  = a.upper ? 32u : 0u, tpat = ('n' - fold) * 0x01010101u;
+#if DR_AHEAD
+        // requested a pass ahead, so that a pass does not begin with two memory round trips in a row: its group word and
+        // the first 128 words of its window (a pass of the bench's lines takes ~115)
+#define DR_WORD(W) (4ull * (W) + 4u <= sbytes ? *(const u32_u *) (seg + 4ull * (W)) : 0u)
+        uint32_t gw_nx = cnt ? g16[lane] : 0u;
+        uint32_t pre0 = DR_WORD((uint64_t) lane), pre1 = DR_WORD(64ull + (uint64_t) lane);
+#endif
         for (uint32_t k0 = 0; k0 < cnt; k0 += 512u)
           { const uint32_t m     = cnt - k0 < 512u ? cnt - k0 : 512u;
             const uint32_t T     = (m + 63u) >> 6;         // tokens per lane in this pass (as the encoder cut them)
             const uint32_t first = (uint32_t) lane * T;
             const uint32_t c     = first < m ? (m - first < T ? m - first : T) : 0u;
+#if DR_AHEAD
+            const uint32_t gw    = gw_nx;
+            uint32_t tg0 = 0, tg1 = 0, tg2 = 0;            // the tag bytes of this lane's tokens: wanted late, asked for now
+            if (tags && c)
+              { const uint32_t b0 = (k0 + first) >> 2;
+                tg0 = b0      < tbytes ? (uint32_t) tsrc[b0]      : 0u;
+                tg1 = b0 + 1u < tbytes ? (uint32_t) tsrc[b0 + 1u] : 0u;
+                tg2 = b0 + 2u < tbytes ? (uint32_t) tsrc[b0 + 2u] : 0u;
+              }
+#else
             const uint32_t gw    = g16[(k0 >> 3) + (uint32_t) lane];      // (64 groups per pass)
+#endif
             const uint32_t bits  = c ? gw & 0xffffu : 0u, span = c ? gw >> 16 : 0u;
             const uint32_t ib = wave_incl_scan(bits), ip = wave_incl_scan(span);
             const uint32_t sb = base_bit + ib - bits;
@@ -1115,14 +1248,28 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             const bool staged = tp <= RUN_STRETCH;         // (long runs: the pass covers more than the buffer holds)
             const uint32_t w0 = base_bit >> 5;
             uint32_t nw = ((base_bit + tb + 31u) >> 5) + 2u - w0;
-            if (nw > DR_WIN) { nw = DR_WIN; bad = 1; }     // (cannot happen with a sound index)
+            if (nw > DR_WIN - 1u) { nw = DR_WIN - 1u; bad = 1; }            // (cannot happen with a sound index)
+#if DR_AHEAD
+            win[lane] = pre0; win[64 + lane] = pre1;
+            for (uint32_t i = 128u + (uint32_t) lane; i < nw; i += 64)
+              win[i] = DR_WORD((uint64_t) w0 + i);
+            if (k0 + 512u < cnt)
+              { const uint64_t w0n = (base_bit + tb) >> 5;
+                gw_nx = g16[((k0 + 512u) >> 3) + (uint32_t) lane];
+                pre0  = DR_WORD(w0n + (uint64_t) lane);
+                pre1  = DR_WORD(w0n + 64ull + (uint64_t) lane);
+              }
+#else
             for (uint32_t i = (uint32_t) lane; i < nw; i += 64)
               { const uint64_t byte = 4ull * (w0 + i);
                 win[i] = byte + 4u <= sbytes ? *(const u32_u *) (seg + byte) : 0u;
               }
+#endif
             if (staged)
-              for (uint32_t i = (uint32_t) lane; i < (tp + 3u) >> 2; i += 64)    // the pass's stretch of the line: run characters
-                stretch[i] = pat;
+              { const u32x4 v = { pat, pat, pat, pat };
+                for (uint32_t i = (uint32_t) lane; i < (tp + 15u) >> 4; i += 64)  // the pass's stretch of the line: run characters
+                  ((u32x4 *) stretch)[i] = v;
+              }
             else                                           // ... in memory, and done before the symbols go over them
               { uint8_t *o = out + base_pos;
                 for (uint32_t k = 16u * (uint32_t) lane; k < tp; k += 1024u)
@@ -1133,7 +1280,42 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
               }
             wave_sync();
             uint32_t posk[8];                              // where this lane's symbols went (the tag letters go to the same places)
-            if (c)
+            // The pass as it nearly always is (its piece of the line staged, no code longer than the tables' index, no
+            // literal run): per token one positioned 32-bit read of the window -- a token's two codes take <= 24 bits --,
+            // two look-ups, no bit buffer and no branch; the tokens' places and symbols stay in registers until every lane
+            // has found its pass sound, then go to the staging buffer.  Anything else: the code-by-code path below.
+            bool fast = false;
+#if DR_FAST
+            if (staged && tp)
+              { uint32_t p = sb - 32u * w0, at1 = pos, zand = 31u, rmax = 0u, pk[8];
+                #pragma unroll
+                for (uint32_t k = 0; k < 8; k++)
+                  if (k < c)
+                    { const uint32_t  e  = p + 31u;                   // the last of the 32 bits from p on
+                      const uint32_t *wp = win + (e >> 5);
+                      const uint32_t  x  = __builtin_amdgcn_alignbit(wp[-1], wp[0], ~e);
+                      const uint32_t  er = rtab[x >> (32 - DP_BITS)];
+                      const uint32_t  y  = __builtin_amdgcn_alignbit(x, 0u, er);          // x << the run code's bits
+                      const uint32_t  es = stab[y >> (32 - DP_BITS)];
+                      zand &= er & es;                                 // bit 4: set in every entry of a code within the index
+                      rmax  = rmax > (er >> 8) ? rmax : er >> 8;
+                      p    += 64u - (er & 31u) - (es & 31u);
+                      at1  += (er >> 8) + 1u;                          // one past the symbol's place
+                      pk[k] = __builtin_amdgcn_perm(es, at1, 0x0c050100u);                 // place + 1 | symbol << 16
+                    }
+                fast = !__any((int) ((~zand & 16u) | (uint32_t) (rmax >= 255u) | (uint32_t) (c && at1 > tp)));
+                if (fast)
+                  { uint8_t *sm1 = (uint8_t *) stretch - 1;
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 8; k++)
+                      if (k < c)
+                        { sm1[pk[k] & 0xffffu] = (uint8_t) (pk[k] >> 16);
+                          posk[k] = (pk[k] & 0xffffu) - 1u;
+                        }
+                  }
+              }
+#endif
+            if (c && !fast)
               { winrd rd;
                 rd.win = win;
                 { const uint32_t s0 = sb - 32u * w0, off = s0 & 31u;
@@ -1167,7 +1349,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             { uint8_t *o = out + base_pos;                 // the stretch leaves in 16-byte pieces, its last bytes one by one
               for (uint32_t i = (uint32_t) lane; 16u * i < tp; i += 64)
                 if (16u * i + 16u <= tp)
-                  { const u32x4 v = { stretch[4 * i], stretch[4 * i + 1], stretch[4 * i + 2], stretch[4 * i + 3] };
+                  { const u32x4 v = ((const u32x4 *) stretch)[i];
                     *(u32x4_u *) (o + 16u * i) = v;
                   }
                 else
@@ -1177,8 +1359,10 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             if (tags)                                      // the same piece of the tag line: 'n', letters at the tokens' places
               { uint8_t *o = tout + base_pos;
                 if (staged)
-                  for (uint32_t i = (uint32_t) lane; i < (tp + 3u) >> 2; i += 64)
-                    stretch[i] = tpat;
+                  { const u32x4 v = { tpat, tpat, tpat, tpat };
+                    for (uint32_t i = (uint32_t) lane; i < (tp + 15u) >> 4; i += 64)
+                      ((u32x4 *) stretch)[i] = v;
+                  }
                 else
                   { for (uint32_t k = 16u * (uint32_t) lane; k < tp; k += 1024u)
                       if (k + 16u <= tp) { const u32x4 v = { tpat, tpat, tpat, tpat }; *(u32x4_u *) (o + k) = v; }
@@ -1190,9 +1374,14 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 if (c && tp)
                   { const uint32_t tix = k0 + first, b0 = tix >> 2;             // this lane's first token and its tag byte
                     uint32_t W = 0;                                               // the next 3 tag bytes, first code in the top bits
+#if DR_AHEAD
+                    W = (tg0 << 24) | (tg1 << 16) | (tg2 << 8);
+                    (void) b0;
+#else
                     #pragma unroll
                     for (uint32_t j = 0; j < 3; j++)
                       W |= (b0 + j < tbytes ? (uint32_t) tsrc[b0 + j] : 0u) << (24u - 8u * j);
+#endif
                     W <<= 2u * (tix & 3u);
                     #pragma unroll
                     for (uint32_t k = 0; k < 8; k++)
@@ -1207,7 +1396,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 if (staged)
                   { for (uint32_t i = (uint32_t) lane; 16u * i < tp; i += 64)
                       if (16u * i + 16u <= tp)
-                        { const u32x4 v = { stretch[4 * i], stretch[4 * i + 1], stretch[4 * i + 2], stretch[4 * i + 3] };
+                        { const u32x4 v = ((const u32x4 *) stretch)[i];
                           *(u32x4_u *) (o + 16u * i) = v;
                         }
                       else

@@ -12,6 +12,6 @@ for rep in 1 2; do
 import json,sys
 d=json.loads(sys.stdin.read())
 pk=d['roofline']['per_kernel']
-print('$v', d['value'], d['ms_per_step'], d.get('roundtrip_bit_exact'), {k:v['ms_per_step'] for k,v in pk.items() if v['ms_per_step']>0.5}, (d.get('decode') or {}).get('ms'), (d.get('decode_indexed') or {}).get('ms'))"
+print('$v', d['value'], d['ms_per_step'], d.get('roundtrip_bit_exact'), {k:v['ms_per_step'] for k,v in pk.items() if v['ms_per_step']>0.5}, (d.get('decode') or {}).get('ms'), (d.get('decode_indexed') or {}).get('ms'), (d.get('decode_indexed') or {}).get('ms_by_kernel'))"
   done
 done
