@@ -657,6 +657,33 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
 }
 
 // ---------------------------------------------------------------------------------------------
+//  an entry's whereabouts in one load (the wave-per-line kernels)
+// ---------------------------------------------------------------------------------------------
+// What says where an entry's lines are -- its length, record, segment sizes, place in the output, share of the index:
+// 18 words from six arrays -- is ONE load whose lanes fetch a word each (DR_DESC), requested while the entry before it
+// is decoded and taken apart with v_readlane when its turn comes (DR_TAKE).  The macros use the kernel's a, sub_off, lane.
+struct dr_entry { uint32_t L, hl, sg[5]; uint64_t so, so1, rec, oo; };
+#define DR_RL(V, K)  ((uint32_t) __builtin_amdgcn_readlane((int) (V), K))
+#define DR_DESC(V, R)                                                                                                   \
+  { const uint32_t *p_ = a.len + (R);                                                                                   \
+    if (lane >= 1  && lane <= 4)  p_ = (const uint32_t *) (sub_off + (R)) + (lane - 1);                                 \
+    if (lane >= 5  && lane <= 6)  p_ = (const uint32_t *) (a.rec_off + (R)) + (lane - 5);                               \
+    if (lane >= 7  && lane <= 8)  p_ = (const uint32_t *) (a.out_off + (R)) + (lane - 7);                               \
+    if (lane >= 9  && lane <= 12 && a.hdr_off) p_ = (const uint32_t *) (a.hdr_off + (R)) + (lane - 9);                  \
+    if (lane >= 13 && lane <= 17) p_ = a.seg + 5 * (R) + (lane - 13);                                                   \
+    V = *p_;                                                                                                            \
+  }
+#define DR_TAKE(E, V)                                                                                                   \
+  { E.L   = DR_RL(V, 0);                                                                                                \
+    E.so  = (uint64_t) DR_RL(V, 1) | ((uint64_t) DR_RL(V, 2) << 32);                                                    \
+    E.so1 = (uint64_t) DR_RL(V, 3) | ((uint64_t) DR_RL(V, 4) << 32);                                                    \
+    E.rec = (uint64_t) DR_RL(V, 5) | ((uint64_t) DR_RL(V, 6) << 32);                                                    \
+    E.oo  = (uint64_t) DR_RL(V, 7) | ((uint64_t) DR_RL(V, 8) << 32);                                                    \
+    E.hl  = a.hdr_off ? DR_RL(V, 11) - DR_RL(V, 9) : 0u;         /* (a header is far below 4 GB: low words do) */       \
+    E.sg[0] = DR_RL(V, 13); E.sg[1] = DR_RL(V, 14); E.sg[2] = DR_RL(V, 15); E.sg[3] = DR_RL(V, 16); E.sg[4] = DR_RL(V, 17); \
+  }
+
+// ---------------------------------------------------------------------------------------------
 //  plain lines with the encoder's group index (dx_qv_subindex): k_qv_decode_sub
 // ---------------------------------------------------------------------------------------------
 // A wavefront per (entry, plain line).  The index holds the code bits of every group of 16 symbols; per round the
@@ -671,23 +698,18 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
 // plain lines (ins, mrg) two 12-wave workgroups share a CU (78 KB each), 6 waves per SIMD.
 #define DS_BLOCK 768
 #define DS_NWAVE (DS_BLOCK / 64)
-#ifndef DS_PAIR
-#define DS_PAIR  0                                         // 1: two symbols per look-up (pair tables, 16 KB per kind; 1.85 symbols per look-up on the
-                                                           // bench's lines).  Measured SLOWER: k_qv_decode_sub 15.3 ms against 13.4 (profiles/
-                                                           // r03_ab_decode_pair.txt) -- lanes need 8..16 look-ups per group of 16 symbols and the wave
-                                                           // runs to the longest, and a look-up costs more (which of the two, a 128-bit queue for the
-                                                           // output) than the 8 instructions of the fixed-position code below.  Kept for the record.
+#define DS_WIN   1280                                       // words per wave: 5 KB
+#ifndef DS_WG_PER_CU
+#define DS_WG_PER_CU 6                                      // (waves per SIMD, HIP's second launch bound: two 12-wave workgroups per CU with the usual two tables, <= 80 VGPRs)
 #endif
-#if DS_PAIR
-#define DS_WIN   960                                       // words per wave: 3.75 KB (two workgroups per CU beside 2 x 16 KB of tables)
-#else
-#define DS_WIN   1280                                      // words per wave: 5 KB
+#ifndef DS_NPRE
+#define DS_NPRE  5                                          // words per lane of the coming round's window requested a round ahead
 #endif
 #ifndef DS_DUAL
-#define DS_DUAL  1                                         // two groups per lane decoded side by side (two look-up chains in flight)
+#define DS_DUAL  0                                         // two groups per lane decoded side by side (two look-up chains in flight)
 #endif
 #ifndef DS_STEPS
-#define DS_STEPS 4                                         // steps of 64 groups per round (one step always fits: <= 515 words)
+#define DS_STEPS 2                                         // steps of 64 groups per round (one step always fits: <= 515 words)
 #endif
 
 struct winrd
@@ -712,29 +734,6 @@ __device__ __forceinline__ uint32_t wr_symbol(winrd &r, const uint16_t *tab, con
   const uint32_t w = r.hi >> 16;
   const uint32_t e = tab[w >> (16 - DP_BITS)];
   uint32_t len = (e & 31u) ? 32u - (e & 31u) : 0u, sym = e >> 8;
-  if (len == 0)                                            // code longer than the primary index
-    { const uint32_t cnt = lng[0];
-      for (uint32_t k = 1; k <= cnt; k++)
-        { const uint32_t t = lng[k], l = (t >> 8) & 0xffu;
-          if ((w >> (16u - l)) == ((t >> 16) >> (16u - l)))
-            { len = l; sym = t & 0xffu;
-              break;
-            }
-        }
-      if (len == 0) len = 1;                               // no such code (corrupt stream): keep moving
-    }
-  r.hi  = __builtin_amdgcn_alignbit(r.hi, r.lo, 32u - len);
-  r.lo <<= len;
-  r.nb -= (int) len;
-  return sym;
-}
-
-// the same from a pair table (its entries also say what the FIRST code of the window is)
-__device__ __forceinline__ uint32_t wr_symbol2(winrd &r, const uint32_t *tab2, const uint32_t *lng)
-{ wr_fill(r);
-  const uint32_t w = r.hi >> 16;
-  const uint32_t e = tab2[w >> (16 - DP_BITS)];
-  uint32_t len = e ? 32u - (e >> 24) : 0u, sym = (e >> 8) & 0xffu;
   if (len == 0)                                            // code longer than the primary index
     { const uint32_t cnt = lng[0];
       for (uint32_t k = 1; k <= cnt; k++)
@@ -824,73 +823,44 @@ __device__ __forceinline__ void ds_block8_dual(winrd &ra, winrd &rb, const uint1
   a0 = wa[0]; a1 = wa[1]; b0 = wb[0]; b1 = wb[1];
 }
 
-// ---- two symbols per look-up ---------------------------------------------------------------------------------
-// The plain lines' codes are short (insertion QVs 3.2 bits on average, merge QVs 5): the next DP_BITS bits of the stream
-// mostly hold TWO whole codes.  Pair table, indexed by those 12 bits: bits [0,5) = 32 - (bits of what the entry
-// decodes) -- the shift v_alignbit wants, 20..31, so bit 4 is set in every real entry --, bit 5 = the entry holds two
-// symbols, [8,16) the first symbol, [16,24) the second, [24,29) = 32 - the first code's bits (to take only the first
-// when the group has room for one); 0 = the first code is longer than the index (the list of long codes has it).
-// A lane assembles its 16 symbols in a 128-bit queue that moves down by 8 or 16 bits per look-up.
-__device__ __forceinline__ void ds_queue(uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3, uint32_t syms, uint32_t s8)
-{ o0 = __builtin_amdgcn_alignbit(o1, o0, s8);
-  o1 = __builtin_amdgcn_alignbit(o2, o1, s8);
-  o2 = __builtin_amdgcn_alignbit(o3, o2, s8);
-  o3 = (o3 >> s8) | (syms << (32u - s8));
+struct ds_line { const uint8_t *seg, *at8; uint8_t *out; uint32_t sbytes, G, L; };
+
+__device__ __forceinline__ ds_line ds_line_of(const dec_args &a, const dr_entry &e, uint32_t q, const uint32_t *sub_idx)
+{ ds_line ln;
+  const uint32_t line = q == 0 ? 0u : q + 1u;              // output line / segment index
+  uint64_t at = e.rec + e.hl;
+  for (uint32_t k = 0; k < 5; k++)
+    if (k < line) at += e.sg[k];
+  ln.seg    = a.in + at;
+  ln.sbytes = line == 0 ? e.sg[0] : line == 2 ? e.sg[2] : line == 3 ? e.sg[3] : e.sg[4];
+  ln.out    = a.out + e.oo + (uint64_t) line * ((uint64_t) e.L + 1u);
+  ln.L      = e.L;
+  ln.G      = sub_groups(e.L);
+  ln.at8    = (const uint8_t *) (sub_idx + e.so + (uint64_t) q * sub_words(e.L));
+  return ln;
 }
 
-__device__ __forceinline__ u32x4 ds_group16_pair(winrd &rd, const uint32_t *tab2, const uint32_t *lng)
-{ uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, cnt = 0;
-  while (cnt < 16u)
-    { wr_fill(rd);                                         // >= 32 bits: two look-ups of <= 12
-      #pragma unroll
-      for (int h = 0; h < 2; h++)
-        if (cnt < 16u)
-          { const uint32_t e = tab2[rd.hi >> (32 - DP_BITS)];
-            if (e == 0u)                                   // a code longer than the index: by the list
-              { const uint32_t w = rd.hi >> 16, n = lng[0];
-                uint32_t len = 1u, sym = 0u;               // (no such code -- a corrupt stream --: keep moving)
-                for (uint32_t k = 1; k <= n; k++)
-                  { const uint32_t t = lng[k], l = (t >> 8) & 0xffu;
-                    if ((w >> (16u - l)) == ((t >> 16) >> (16u - l)))
-                      { len = l; sym = t & 0xffu;
-                        break;
-                      }
-                  }
-                wr_fill(rd);
-                rd.hi  = __builtin_amdgcn_alignbit(rd.hi, rd.lo, 32u - len);
-                rd.lo <<= len;
-                rd.nb -= (int) len;
-                ds_queue(o0, o1, o2, o3, sym, 8u);
-                cnt += 1u;
-                wr_fill(rd);
-              }
-            else
-              { const bool     two = (e & 32u) != 0u && cnt < 15u;
-                const uint32_t sh  = (e & 32u) != 0u && !two ? e >> 24 : e;
-                rd.hi = __builtin_amdgcn_alignbit(rd.hi, rd.lo, sh);
-                rd.lo = __builtin_amdgcn_alignbit(rd.lo, 0u, sh);
-                rd.nb += (int) (sh & 31u) - 32;
-                ds_queue(o0, o1, o2, o3, two ? (e >> 8) & 0xffffu : (e >> 8) & 0xffu, two ? 16u : 8u);
-                cnt += two ? 2u : 1u;
-              }
-          }
-    }
-  const u32x4 v = { o0, o1, o2, o3 };
-  return v;
-}
+// a round's requests: the index bytes of its DS_STEPS x 64 groups and the first 64 x DS_NPRE words of its window
+#define DS_ASK(LN, G0, BASE)                                                                                            \
+  { _Pragma("unroll")                                                                                                   \
+    for (int k_ = 0; k_ < DS_STEPS; k_++)                                                                               \
+      { const uint32_t g_ = (G0) + 64u * k_ + (uint32_t) lane;                                                          \
+        draw[k_] = g_ < (LN).G ? (uint32_t) (LN).at8[g_] : 0u;                                                          \
+      }                                                                                                                 \
+    _Pragma("unroll")                                                                                                   \
+    for (int j_ = 0; j_ < DS_NPRE; j_++)                                                                                \
+      { const uint64_t b_ = 4ull * (((BASE) >> 5) + 64u * j_ + (uint32_t) lane);                                        \
+        pre[j_] = b_ + 4u <= (LN).sbytes ? *(const u32_u *) ((LN).seg + b_) : 0u;                                       \
+      }                                                                                                                 \
+  }
 
 template <int NK>
-__global__ __launch_bounds__(DS_BLOCK)
+__global__ __launch_bounds__(DS_BLOCK, NK <= 2 ? DS_WG_PER_CU : 3)
 void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds,
                      const uint32_t *sub_idx, const uint64_t *sub_off)
-{
-#if DS_PAIR
-  __shared__ uint32_t s_tab2[NK][DP_SIZE];                 // 16 KB each
-#else
-  __shared__ uint16_t s_tab[NK][DP_SIZE];                  // 8 KB each
-#endif
+{ __shared__ uint16_t s_tab[NK][DP_SIZE];                  // 8 KB each
   __shared__ uint32_t s_long[NK][1 + DX_LONG_MAX];         // 1 KB each
-  __shared__ uint32_t s_win[DS_NWAVE][DS_WIN];             // 60 KB (45 KB beside pair tables)
+  __shared__ uint32_t s_win[DS_NWAVE][DS_WIN];             // 60 KB
   // tables of the kinds present, in the order of their bits (dp_build_tables for a subset)
   { int slot_of[4], nk = 0;
     for (int q = 0; q < 4; q++) slot_of[q] = ((kinds >> q) & 1u) ? nk++ : -1;
@@ -911,74 +881,57 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
                       { len = l; sym = t & 0xffu; }
                   }
               }
-#if DS_PAIR
-            s_tab2[slot_of[q]][i] = len ? (32u - len) | (sym << 8) | ((32u - len) << 24) : 0u;      // one symbol for now
-#else
             s_tab[slot_of[q]][i] = (uint16_t) ((len ? 32u - len : 0u) | (sym << 8));
-#endif
           }
     __syncthreads();
-#if DS_PAIR
-    // pair entries from the one-symbol ones, in place: what a thread reads of ANOTHER entry -- its first code's length
-    // (bits 24..) and symbol (byte 1) -- is the same before and after that entry's own upgrade
-    for (int sl = 0; sl < NK; sl++)
-      for (int i_ = threadIdx.x; i_ < DP_SIZE; i_ += DS_BLOCK)
-        { const uint32_t i = (uint32_t) i_, e1 = s_tab2[sl][i];
-          if (e1)
-            { const uint32_t l1 = 32u - (e1 >> 24);
-              const uint32_t e2 = s_tab2[sl][(i << l1) & (DP_SIZE - 1)];         // the bits behind the first code, zero-filled
-              const uint32_t l2 = e2 ? 32u - (e2 >> 24) : 0u;
-              if (l2 && l1 + l2 <= DP_BITS)                // (a code that ends inside the window did not see the fill)
-                s_tab2[sl][i] = (32u - (l1 + l2)) | 32u | (e1 & 0xff00u) | ((e2 & 0xff00u) << 8) | (e1 & 0xff000000u);
-            }
-        }
-    __syncthreads();
-#endif
   }
   uint32_t *const win  = s_win[threadIdx.x >> 6];
   const int       lane = lane_id();
+  const uint32_t  first_kind = (uint32_t) __builtin_ctz(kinds | 16u);
 
-  for (;;)                                                 // a task = the plain lines of one entry (n < 2^31)
-    { uint32_t t = 0;
-      if (lane == 0)
-        t = atomicAdd(next_task, 1u);
-      t = uniform(t);
-      if ((uint64_t) t >= a.n) break;                      // every wave gets here: the counter only grows
-      const uint64_t r = t;
+  // A task = the plain lines of one entry (n < 2^31), a round = DS_STEPS x 64 groups of one line.  Every round asks for
+  // what the round AFTER it will need -- the next groups of the line, the first of the entry's next line or of the next
+  // entry's first line -- before it decodes: the index bytes and (from the bit position the prefix sums have just
+  // given) the window's words stay in registers until that round begins.  Without this a round starts with two
+  // dependent memory round trips (index, then window) and an entry with three more (ticket, length and offsets).
+  uint32_t t = 0, t1 = 0, t2v = 0, dv = 0, dv_nx = 0;
+  uint32_t draw[DS_STEPS], pre[DS_NPRE];
+  bool     ready = false;                                  // draw / pre hold the coming round's requests
+  if (lane == 0) { t = atomicAdd(next_task, 1u); t1 = atomicAdd(next_task, 1u); }
+  t = uniform(t); t1 = uniform(t1);
+  if ((uint64_t) t < a.n) DR_DESC(dv, (uint64_t) t)
+  for (; (uint64_t) t < a.n; t = t1, t1 = uniform(t2v), dv = dv_nx)       // (every wave gets past the end: the counter only grows)
+    { dr_entry cur;
+      DR_TAKE(cur, dv)
+      const bool more = (uint64_t) t1 < a.n;
+      if (more) DR_DESC(dv_nx, (uint64_t) t1)
+      if (lane == 0) t2v = atomicAdd(next_task, 1u);
       int slot = -1;
       #pragma unroll 1
       for (uint32_t q = 0; q < 4; q++)
       { if (!((kinds >> q) & 1u)) continue;
         slot += 1;
-      const int       line = q == 0 ? 0 : (int) q + 1;     // output line / segment index
-      const uint32_t  L    = a.len[r];
-      const uint32_t *sg   = a.seg + 5 * r;
-      uint64_t at = a.rec_off[r] + (a.hdr_off ? a.hdr_off[r + 1] - a.hdr_off[r] : 0);
-      for (int k = 0; k < line; k++)
-        at += sg[k];
-      const uint8_t  *seg    = a.in + at;
-      const uint32_t  sbytes = sg[line];
-      uint8_t        *out    = a.out + a.out_off[r] + (uint64_t) line * ((uint64_t) L + 1u);
-      const uint32_t  G      = sub_groups(L);
-      const uint8_t  *at8    = (const uint8_t *) (sub_idx + sub_off[r] + (uint64_t) q * sub_words(L));
-#if DS_PAIR
-      const uint32_t *tab    = s_tab2[slot];
-#else
+      const ds_line   ln     = ds_line_of(a, cur, q, sub_idx);
+      const uint32_t  L      = ln.L, G = ln.G, sbytes = ln.sbytes;
+      const uint8_t  *seg    = ln.seg;
+      uint8_t        *out    = ln.out;
       const uint16_t *tab    = s_tab[slot];
-#endif
       const uint32_t *lng    = s_long[slot];
-      const bool      serial = G > 0 && uniform((uint32_t) at8[0]) == SUB_NONE;
+      bool            serial = false;                      // SUB_NONE: a symbol without a code in the line (hand-made tables only)
       uint32_t base = 0;                                   // bit at which the round's first group starts
 
       for (uint32_t g0 = 0; g0 < G; )
-        { // bit counts of up to DS_STEPS x 64 groups, their starts, and how many steps the window holds
+        { if (!ready) DS_ASK(ln, g0, base)
+          ready = false;
+          if (g0 == 0) serial = DR_RL(draw[0], 0) == SUB_NONE;
+          // bit counts of up to DS_STEPS x 64 groups, their starts, and how many steps the window holds
           uint32_t d[DS_STEPS], st[DS_STEPS], upto[DS_STEPS];
           uint32_t run = base, steps = 0;
           #pragma unroll
           for (int k = 0; k < DS_STEPS; k++)
             { const uint32_t g = g0 + 64u * k + (uint32_t) lane;
               const uint32_t valid = g < G ? (L - 16u * g < 16u ? L - 16u * g : 16u) : 0u;
-              d[k] = valid ? (uint32_t) at8[g] + valid : 0u;
+              d[k] = valid ? draw[k] + valid : 0u;
               if (serial) d[k] = valid && lane == 0 && k == 0 ? 16u * valid : 0u;      // (an upper bound: one group at a time)
             }
           #pragma unroll
@@ -991,14 +944,42 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
             }
           const uint32_t w0 = base >> 5;
           const uint32_t nw = ((upto[steps - 1] + 31u) >> 5) + 2u - w0;
-          for (uint32_t i = (uint32_t) lane; i < nw; i += 64)
+          #pragma unroll
+          for (int j = 0; j < DS_NPRE; j++)
+            win[64 * j + lane] = pre[j];
+          for (uint32_t i = 64u * DS_NPRE + (uint32_t) lane; i < nw; i += 64)
             { const uint64_t byte = 4ull * (w0 + i);
               win[i] = byte + 4u <= sbytes ? *(const u32_u *) (seg + byte) : 0u;     // (segments are whole words, QV.c:436-442)
+            }
+          // the round after this one
+          if (!serial)
+            { if (g0 + 64u * steps < G)
+                { DS_ASK(ln, g0 + 64u * steps, upto[steps - 1])
+                  ready = true;
+                }
+              else
+                { uint32_t q2 = q + 1u;
+                  while (q2 < 4u && !((kinds >> q2) & 1u)) q2 += 1u;
+                  if (q2 < 4u)
+                    { const ds_line l2 = ds_line_of(a, cur, q2, sub_idx);
+                      DS_ASK(l2, 0u, 0u)
+                      ready = true;
+                    }
+                  else if (more)
+                    { dr_entry nx;
+                      DR_TAKE(nx, dv_nx)
+                      if (nx.L)
+                        { const ds_line l2 = ds_line_of(a, nx, first_kind, sub_idx);
+                          DS_ASK(l2, 0u, 0u)
+                          ready = true;
+                        }
+                    }
+                }
             }
           wave_sync();
           uint32_t used = 0;                               // serial mode: bits the group really took
           int kdone = 0;
-#if DS_DUAL && !DS_PAIR
+#if DS_DUAL
           // pairs of steps whose 128 groups are all whole (every round but a line's last): two groups per lane side by side
           #pragma unroll
           for (int k = 0; k + 1 < DS_STEPS; k += 2)
@@ -1037,24 +1018,15 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
                     }
                     uint8_t *o = out + 16ull * g;
                     if (valid == 16u)
-                      {
-#if DS_PAIR
-                        *(u32x4_u *) o = ds_group16_pair(rd, tab, lng);
-#else
-                        uint32_t x0, x1, x2, x3;
+                      { uint32_t x0, x1, x2, x3;
                         ds_block8(rd, tab, lng, x0, x1);
                         ds_block8(rd, tab, lng, x2, x3);
                         const u32x4 v = { x0, x1, x2, x3 };
                         *(u32x4_u *) o = v;
-#endif
                       }
                     else
                       for (uint32_t j = 0; j < valid; j++)   // the ragged end of the line
-#if DS_PAIR
-                        o[j] = (uint8_t) wr_symbol2(rd, tab, lng);
-#else
                         o[j] = (uint8_t) wr_symbol(rd, tab, lng);
-#endif
                     used = 32u * (rd.wi - 1u - ((st[k] - 32u * w0) >> 5)) + (32u - ((st[k] - 32u * w0) & 31u)) - (uint32_t) rd.nb;
                   }
               }
@@ -1067,6 +1039,7 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
       }
     }
 }
+#undef DS_ASK
 
 // ---------------------------------------------------------------------------------------------
 //  run-coded lines with the encoder's group index: k_qv_decode_runs
@@ -1081,13 +1054,26 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 #define DR_BLOCK 1024                                      // 16 waves: tables 36 KB + 16 x (1.75 + 5) KB = 144 KB
 #define DR_NWAVE (DR_BLOCK / 64)
 #define DR_WIN   448                                       // words per wave: a pass's bits (<= RUN_PASSBITS, the encoder saw to it) + slack
-#ifndef DR_AHEAD
-#define DR_AHEAD 1                                         // the next pass's group word and window, the tag bytes: requested early
-#endif
 #ifndef DR_FAST
 #define DR_FAST  1                                         // the sound pass without a bit buffer (see the kernel)
 #endif
 #define DR_STRETCH (RUN_STRETCH / 4)                       // words per wave for a pass's piece of the line (the encoder saw to it that it fits)
+
+// where a run-coded line of an entry is, and whether its share of the index is one the entry can have
+struct dr_line { const uint8_t *seg; const uint32_t *g16; uint32_t sbytes, cnt; bool ok; };
+
+__device__ __forceinline__ dr_line dr_line_of(const dec_args &a, const dr_entry &e, const uint32_t head[3], uint32_t q, const uint32_t *sub_idx)
+{ dr_line ln;
+  const uint32_t L = e.L;
+  ln.cnt = head[q == 0 ? 0 : 1];                           // tokens (RUN_NONE: not indexed)
+  const uint64_t share = e.so1 - e.so;                     // words of this entry in the index
+  const uint64_t need  = (uint64_t) run_base(L) + 3u + 64ull * ((q == 0 ? 0u : head[2]) + run_passes(ln.cnt));
+  ln.ok     = ln.cnt != RUN_NONE && ln.cnt <= ((((L >> 1) + 64u) + 7u) & ~7u) && need <= share;
+  ln.seg    = a.in + e.rec + e.hl + (q == 0 ? 0ull : (uint64_t) e.sg[0] + e.sg[1] + e.sg[2] + e.sg[3]);
+  ln.sbytes = q == 0 ? e.sg[0] : e.sg[4];
+  ln.g16    = sub_idx + e.so + run_base(L) + 3u + (q == 0 ? 0u : 64u * head[2]);      // three header words, then the groups
+  return ln;
+}
 
 template <int NK>                                          // run-coded kinds in the launch: 1 or 2 (del, sub)
 __global__ __launch_bounds__(DR_BLOCK)
@@ -1137,28 +1123,10 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
   // entry before it is decoded and taken apart with v_readlane when its turn comes; so are the three header words of its
   // share (asked for between the two lines) and the ticket (drawn two entries ahead).  Otherwise an entry begins with five
   // dependent memory round trips per line, at four waves per SIMD.
-  struct dr_entry { uint32_t L, hl, sg[5]; uint64_t so, so1, rec, oo; };
-#define DR_RL(V, K)  ((uint32_t) __builtin_amdgcn_readlane((int) (V), K))
-#define DR_DESC(V, R)                                                                                                   \
-  { const uint32_t *p_ = a.len + (R);                                                                                   \
-    if (lane >= 1  && lane <= 4)  p_ = (const uint32_t *) (sub_off + (R)) + (lane - 1);                                 \
-    if (lane >= 5  && lane <= 6)  p_ = (const uint32_t *) (a.rec_off + (R)) + (lane - 5);                               \
-    if (lane >= 7  && lane <= 8)  p_ = (const uint32_t *) (a.out_off + (R)) + (lane - 7);                               \
-    if (lane >= 9  && lane <= 12 && a.hdr_off) p_ = (const uint32_t *) (a.hdr_off + (R)) + (lane - 9);                  \
-    if (lane >= 13 && lane <= 17) p_ = a.seg + 5 * (R) + (lane - 13);                                                   \
-    V = *p_;                                                                                                            \
-  }
-#define DR_TAKE(E, V)                                                                                                   \
-  { E.L   = DR_RL(V, 0);                                                                                                \
-    E.so  = (uint64_t) DR_RL(V, 1) | ((uint64_t) DR_RL(V, 2) << 32);                                                    \
-    E.so1 = (uint64_t) DR_RL(V, 3) | ((uint64_t) DR_RL(V, 4) << 32);                                                    \
-    E.rec = (uint64_t) DR_RL(V, 5) | ((uint64_t) DR_RL(V, 6) << 32);                                                    \
-    E.oo  = (uint64_t) DR_RL(V, 7) | ((uint64_t) DR_RL(V, 8) << 32);                                                    \
-    E.hl  = a.hdr_off ? DR_RL(V, 11) - DR_RL(V, 9) : 0u;         /* (a header is far below 4 GB: low words do) */       \
-    E.sg[0] = DR_RL(V, 13); E.sg[1] = DR_RL(V, 14); E.sg[2] = DR_RL(V, 15); E.sg[3] = DR_RL(V, 16); E.sg[4] = DR_RL(V, 17); \
-  }
 #define DR_HEADV(V, E) { V = 0u; if (lane < 3) V = (sub_idx + E.so + run_base(E.L))[lane]; }
   uint32_t t = 0, t1 = 0, t2v = 0, dv = 0, dv_nx = 0, hv = 0, hv_nx = 0;
+  uint32_t gw_nx = 0, pre0 = 0, pre1 = 0;                  // a pass's group word and the first 128 words of its window ...
+  bool     ready = false;                                  // ... requested for the next line that has passes (by the line before it)
   if (lane == 0) { t = atomicAdd(next_task, 1u); t1 = atomicAdd(next_task, 1u); }
   t = uniform(t); t1 = uniform(t1);
   if ((uint64_t) t < a.n)
@@ -1168,42 +1136,36 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
       DR_HEADV(hv, e0)
     }
   for (; (uint64_t) t < a.n; t = t1, t1 = uniform(t2v), dv = dv_nx, hv = hv_nx)       // (every wave gets past the end: the counter only grows)
-    { dr_entry cur, nx;
+    { dr_entry cur, nx = {};
       uint32_t head[3];
       DR_TAKE(cur, dv)
       head[0] = DR_RL(hv, 0); head[1] = DR_RL(hv, 1); head[2] = DR_RL(hv, 2);
       const bool more = (uint64_t) t1 < a.n;
+      bool asked = false;                                  // the next entry's header words are on their way
       if (more) DR_DESC(dv_nx, (uint64_t) t1)
       if (lane == 0) t2v = atomicAdd(next_task, 1u);
       int slot = -1;
       #pragma unroll 1
       for (uint32_t q = 0; q < 4; q += 3)                  // del (0), sub (3)
-      { if (q == 3 && more) { DR_TAKE(nx, dv_nx) DR_HEADV(hv_nx, nx) }             // (the next entry's numbers are here by now)
-        if (!((kinds >> q) & 1u)) continue;
+      { if (!((kinds >> q) & 1u)) continue;
         slot += 1;
         const uint32_t  L   = cur.L;
-        const uint32_t *hdr = sub_idx + cur.so + run_base(L);             // three header words, then the groups
-        const uint32_t  cnt = head[q == 0 ? 0 : 1];
+        const dr_line   ln  = dr_line_of(a, cur, head, q, sub_idx);
+        const uint32_t  cnt = ln.cnt;
         if (cnt == RUN_NONE) continue;                     // not indexed: k_qv_decode takes this line
-        { const uint64_t share = cur.so1 - cur.so;                        // words of this entry in the index
-          const uint64_t need  = (uint64_t) run_base(L) + 3u + 64ull * ((q == 0 ? 0u : head[2]) + run_passes(cnt));
-          if (cnt > ((((L >> 1) + 64u) + 7u) & ~7u) || need > share)       // not an index this entry can have: never follow it
-            { if (lane == 0) atomicOr(status, 4u);
-              continue;
-            }
-        }
+        if (!ln.ok)                                        // not an index this entry can have: never follow it
+          { if (lane == 0) atomicOr(status, 4u);
+            continue;
+          }
         const int       line = q == 0 ? 0 : 4;
         const uint32_t *sg   = cur.sg;
-        uint64_t at = cur.rec + cur.hl;
-        for (int k = 0; k < line; k++)
-          at += sg[k];
-        const uint8_t  *seg    = a.in + at;
-        const uint32_t  sbytes = sg[line];
+        const uint8_t  *seg    = ln.seg;
+        const uint32_t  sbytes = ln.sbytes;
         uint8_t        *out    = a.out + cur.oo + (uint64_t) line * ((uint64_t) L + 1u);
         const uint32_t  rc     = (uint32_t) (q == 0 ? a.delChar : a.subChar);
         const uint16_t *stab   = s_tab[2 * slot], *rtab = s_tab[2 * slot + 1];
         const uint32_t *slng   = s_long[2 * slot], *rlng = s_long[2 * slot + 1];
-        const uint32_t *g16    = hdr + 3 + (q == 0 ? 0u : 64u * head[2]);
+        const uint32_t *g16    = ln.g16;
 
         uint32_t base_bit = 0, base_pos = 0, bad = 0;
         const uint32_t pat = rc * 0x01010101u;
@@ -1214,19 +1176,20 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
         const uint32_t tbytes = sg[1];
         uint8_t       *tout  = out + (uint64_t) L + 1u;
         const uint32_t fold  = a.upper ? 32u : 0u, tpat = ('n' - fold) * 0x01010101u;
-#if DR_AHEAD
         // requested a pass ahead, so that a pass does not begin with two memory round trips in a row: its group word and
         // the first 128 words of its window (a pass of the bench's lines takes ~115)
 #define DR_WORD(W) (4ull * (W) + 4u <= sbytes ? *(const u32_u *) (seg + 4ull * (W)) : 0u)
-        uint32_t gw_nx = cnt ? g16[lane] : 0u;
-        uint32_t pre0 = DR_WORD((uint64_t) lane), pre1 = DR_WORD(64ull + (uint64_t) lane);
-#endif
+        if (!ready && cnt)
+          { gw_nx = g16[lane];
+            pre0  = DR_WORD((uint64_t) lane);
+            pre1  = DR_WORD(64ull + (uint64_t) lane);
+          }
+        if (cnt) ready = false;                            // (this line's first pass takes them)
         for (uint32_t k0 = 0; k0 < cnt; k0 += 512u)
           { const uint32_t m     = cnt - k0 < 512u ? cnt - k0 : 512u;
             const uint32_t T     = (m + 63u) >> 6;         // tokens per lane in this pass (as the encoder cut them)
             const uint32_t first = (uint32_t) lane * T;
             const uint32_t c     = first < m ? (m - first < T ? m - first : T) : 0u;
-#if DR_AHEAD
             const uint32_t gw    = gw_nx;
             uint32_t tg0 = 0, tg1 = 0, tg2 = 0;            // the tag bytes of this lane's tokens: wanted late, asked for now
             if (tags && c)
@@ -1235,9 +1198,6 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 tg1 = b0 + 1u < tbytes ? (uint32_t) tsrc[b0 + 1u] : 0u;
                 tg2 = b0 + 2u < tbytes ? (uint32_t) tsrc[b0 + 2u] : 0u;
               }
-#else
-            const uint32_t gw    = g16[(k0 >> 3) + (uint32_t) lane];      // (64 groups per pass)
-#endif
             const uint32_t bits  = c ? gw & 0xffffu : 0u, span = c ? gw >> 16 : 0u;
             const uint32_t ib = wave_incl_scan(bits), ip = wave_incl_scan(span);
             const uint32_t sb = base_bit + ib - bits;
@@ -1249,22 +1209,36 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             const uint32_t w0 = base_bit >> 5;
             uint32_t nw = ((base_bit + tb + 31u) >> 5) + 2u - w0;
             if (nw > DR_WIN - 1u) { nw = DR_WIN - 1u; bad = 1; }            // (cannot happen with a sound index)
-#if DR_AHEAD
             win[lane] = pre0; win[64 + lane] = pre1;
             for (uint32_t i = 128u + (uint32_t) lane; i < nw; i += 64)
               win[i] = DR_WORD((uint64_t) w0 + i);
+            if (more && !asked)                            // (the next entry's numbers are here by now: a pass has gone by)
+              { DR_TAKE(nx, dv_nx)
+                DR_HEADV(hv_nx, nx)
+                asked = true;
+              }
             if (k0 + 512u < cnt)
               { const uint64_t w0n = (base_bit + tb) >> 5;
                 gw_nx = g16[((k0 + 512u) >> 3) + (uint32_t) lane];
                 pre0  = DR_WORD(w0n + (uint64_t) lane);
                 pre1  = DR_WORD(w0n + 64ull + (uint64_t) lane);
               }
-#else
-            for (uint32_t i = (uint32_t) lane; i < nw; i += 64)
-              { const uint64_t byte = 4ull * (w0 + i);
-                win[i] = byte + 4u <= sbytes ? *(const u32_u *) (seg + byte) : 0u;
+            else                                           // the line's last pass: the first pass of the line that comes next
+              { dr_line nl = { NULL, NULL, 0u, 0u, false };
+                if (q == 0 && ((kinds >> 3) & 1u)) nl = dr_line_of(a, cur, head, 3u, sub_idx);
+                if (!(nl.ok && nl.cnt) && more)
+                  { uint32_t hn[3];
+                    hn[0] = DR_RL(hv_nx, 0); hn[1] = DR_RL(hv_nx, 1); hn[2] = DR_RL(hv_nx, 2);
+                    if (kinds & 1u) nl = dr_line_of(a, nx, hn, 0u, sub_idx);
+                    if (!(nl.ok && nl.cnt) && ((kinds >> 3) & 1u)) nl = dr_line_of(a, nx, hn, 3u, sub_idx);
+                  }
+                if (nl.ok && nl.cnt)
+                  { gw_nx = nl.g16[lane];
+                    pre0  = 4ull * (uint64_t) lane + 4u <= nl.sbytes ? *(const u32_u *) (nl.seg + 4ull * (uint64_t) lane) : 0u;
+                    pre1  = 4ull * (64ull + (uint64_t) lane) + 4u <= nl.sbytes ? *(const u32_u *) (nl.seg + 4ull * (64ull + (uint64_t) lane)) : 0u;
+                    ready = true;
+                  }
               }
-#endif
             if (staged)
               { const u32x4 v = { pat, pat, pat, pat };
                 for (uint32_t i = (uint32_t) lane; i < (tp + 15u) >> 4; i += 64)  // the pass's stretch of the line: run characters
@@ -1374,14 +1348,8 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 if (c && tp)
                   { const uint32_t tix = k0 + first, b0 = tix >> 2;             // this lane's first token and its tag byte
                     uint32_t W = 0;                                               // the next 3 tag bytes, first code in the top bits
-#if DR_AHEAD
                     W = (tg0 << 24) | (tg1 << 16) | (tg2 << 8);
                     (void) b0;
-#else
-                    #pragma unroll
-                    for (uint32_t j = 0; j < 3; j++)
-                      W |= (b0 + j < tbytes ? (uint32_t) tsrc[b0 + j] : 0u) << (24u - 8u * j);
-#endif
                     W <<= 2u * (tix & 3u);
                     #pragma unroll
                     for (uint32_t k = 0; k < 8; k++)
@@ -1420,6 +1388,10 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
           }
         if (__any((int) bad) && lane == 0) atomicOr(status, 4u);
       }
+      if (more && !asked)                                  // (an entry without a pass)
+        { DR_TAKE(nx, dv_nx)
+          DR_HEADV(hv_nx, nx)
+        }
     }
 }
 
