@@ -663,6 +663,25 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
 // 18 words from six arrays -- is ONE load whose lanes fetch a word each (DR_DESC), requested while the entry before it
 // is decoded and taken apart with v_readlane when its turn comes (DR_TAKE).  The macros use the kernel's a, sub_off, lane.
 struct dr_entry { uint32_t L, hl, sg[5]; uint64_t so, so1, rec, oo; };
+// Entries are drawn DEC_TICKET at a time: an atomic on one address completes every ~11 ns chip-wide, so a ticket per
+// entry is an 11 ms floor under a kernel over a million entries, whatever else it does.  A wave knows the entry after
+// the current one a whole entry ahead: the next of its ticket, or the first of the ticket it drew when this one began.
+#ifndef DEC_TICKET
+#define DEC_TICKET 4u
+#endif
+#define DT_FIRST(R, R_END, TKV)                                                                                         \
+  { uint32_t t0_ = 0;                                                                                                   \
+    if (lane == 0) { t0_ = atomicAdd(next_task, 1u); TKV = atomicAdd(next_task, 1u); }                                  \
+    R = (uint64_t) uniform(t0_) * DEC_TICKET; R_END = R + DEC_TICKET;                                                   \
+  }
+#define DT_NEXT(R1, FRESH, R, R_END, TKV)                                                                               \
+  { FRESH = (R) + 1u >= (R_END);                                                                                        \
+    R1    = (R) + 1u;                                                                                                   \
+    if (FRESH)                                                                                                          \
+      { R1 = (uint64_t) uniform(TKV) * DEC_TICKET;                                                                      \
+        if (lane == 0) TKV = atomicAdd(next_task, 1u);                                                                  \
+      }                                                                                                                 \
+  }
 #define DR_RL(V, K)  ((uint32_t) __builtin_amdgcn_readlane((int) (V), K))
 #define DR_DESC(V, R)                                                                                                   \
   { const uint32_t *p_ = a.len + (R);                                                                                   \
@@ -894,18 +913,18 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
   // entry's first line -- before it decodes: the index bytes and (from the bit position the prefix sums have just
   // given) the window's words stay in registers until that round begins.  Without this a round starts with two
   // dependent memory round trips (index, then window) and an entry with three more (ticket, length and offsets).
-  uint32_t t = 0, t1 = 0, t2v = 0, dv = 0, dv_nx = 0;
+  uint64_t r, r_end, r1;
+  uint32_t tkv = 0, dv = 0, dv_nx = 0;
   uint32_t draw[DS_STEPS], pre[DS_NPRE];
-  bool     ready = false;                                  // draw / pre hold the coming round's requests
-  if (lane == 0) { t = atomicAdd(next_task, 1u); t1 = atomicAdd(next_task, 1u); }
-  t = uniform(t); t1 = uniform(t1);
-  if ((uint64_t) t < a.n) DR_DESC(dv, (uint64_t) t)
-  for (; (uint64_t) t < a.n; t = t1, t1 = uniform(t2v), dv = dv_nx)       // (every wave gets past the end: the counter only grows)
+  bool     ready = false, fresh;                           // draw / pre hold the coming round's requests
+  DT_FIRST(r, r_end, tkv)
+  if (r < a.n) DR_DESC(dv, r)
+  for (; r < a.n; r = r1, r_end = fresh ? r1 + DEC_TICKET : r_end, dv = dv_nx)       // (every wave gets past the end: the counter only grows)
     { dr_entry cur;
       DR_TAKE(cur, dv)
-      const bool more = (uint64_t) t1 < a.n;
-      if (more) DR_DESC(dv_nx, (uint64_t) t1)
-      if (lane == 0) t2v = atomicAdd(next_task, 1u);
+      DT_NEXT(r1, fresh, r, r_end, tkv)
+      const bool more = r1 < a.n;
+      if (more) DR_DESC(dv_nx, r1)
       int slot = -1;
       #pragma unroll 1
       for (uint32_t q = 0; q < 4; q++)
@@ -1054,6 +1073,9 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 #define DR_BLOCK 1024                                      // 16 waves: tables 36 KB + 16 x (1.75 + 5) KB = 144 KB
 #define DR_NWAVE (DR_BLOCK / 64)
 #define DR_WIN   448                                       // words per wave: a pass's bits (<= RUN_PASSBITS, the encoder saw to it) + slack
+#ifndef DR_SKIP
+#define DR_SKIP  0                                         // timing experiments: 1 no tag line, 2 no tokens, 4 the line's piece stays in LDS
+#endif
 #ifndef DR_FAST
 #define DR_FAST  1                                         // the sound pass without a bit buffer (see the kernel)
 #endif
@@ -1124,26 +1146,26 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
   // share (asked for between the two lines) and the ticket (drawn two entries ahead).  Otherwise an entry begins with five
   // dependent memory round trips per line, at four waves per SIMD.
 #define DR_HEADV(V, E) { V = 0u; if (lane < 3) V = (sub_idx + E.so + run_base(E.L))[lane]; }
-  uint32_t t = 0, t1 = 0, t2v = 0, dv = 0, dv_nx = 0, hv = 0, hv_nx = 0;
+  uint64_t r, r_end, r1;
+  uint32_t tkv = 0, dv = 0, dv_nx = 0, hv = 0, hv_nx = 0;
   uint32_t gw_nx = 0, pre0 = 0, pre1 = 0;                  // a pass's group word and the first 128 words of its window ...
-  bool     ready = false;                                  // ... requested for the next line that has passes (by the line before it)
-  if (lane == 0) { t = atomicAdd(next_task, 1u); t1 = atomicAdd(next_task, 1u); }
-  t = uniform(t); t1 = uniform(t1);
-  if ((uint64_t) t < a.n)
+  bool     ready = false, fresh;                           // ... requested for the next line that has passes (by the line before it)
+  DT_FIRST(r, r_end, tkv)
+  if (r < a.n)
     { dr_entry e0;
-      DR_DESC(dv, (uint64_t) t)
+      DR_DESC(dv, r)
       DR_TAKE(e0, dv)
       DR_HEADV(hv, e0)
     }
-  for (; (uint64_t) t < a.n; t = t1, t1 = uniform(t2v), dv = dv_nx, hv = hv_nx)       // (every wave gets past the end: the counter only grows)
+  for (; r < a.n; r = r1, r_end = fresh ? r1 + DEC_TICKET : r_end, dv = dv_nx, hv = hv_nx)       // (every wave gets past the end: the counter only grows)
     { dr_entry cur, nx = {};
       uint32_t head[3];
       DR_TAKE(cur, dv)
       head[0] = DR_RL(hv, 0); head[1] = DR_RL(hv, 1); head[2] = DR_RL(hv, 2);
-      const bool more = (uint64_t) t1 < a.n;
+      DT_NEXT(r1, fresh, r, r_end, tkv)
+      const bool more = r1 < a.n;
       bool asked = false;                                  // the next entry's header words are on their way
-      if (more) DR_DESC(dv_nx, (uint64_t) t1)
-      if (lane == 0) t2v = atomicAdd(next_task, 1u);
+      if (more) DR_DESC(dv_nx, r1)
       int slot = -1;
       #pragma unroll 1
       for (uint32_t q = 0; q < 4; q += 3)                  // del (0), sub (3)
@@ -1185,7 +1207,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             pre1  = DR_WORD(64ull + (uint64_t) lane);
           }
         if (cnt) ready = false;                            // (this line's first pass takes them)
-        for (uint32_t k0 = 0; k0 < cnt; k0 += 512u)
+        for (uint32_t k0 = 0; k0 < ((DR_SKIP & 32) ? 0u : cnt); k0 += 512u)
           { const uint32_t m     = cnt - k0 < 512u ? cnt - k0 : 512u;
             const uint32_t T     = (m + 63u) >> 6;         // tokens per lane in this pass (as the encoder cut them)
             const uint32_t first = (uint32_t) lane * T;
@@ -1209,9 +1231,11 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             const uint32_t w0 = base_bit >> 5;
             uint32_t nw = ((base_bit + tb + 31u) >> 5) + 2u - w0;
             if (nw > DR_WIN - 1u) { nw = DR_WIN - 1u; bad = 1; }            // (cannot happen with a sound index)
-            win[lane] = pre0; win[64 + lane] = pre1;
+            if (!(DR_SKIP & 16))
+            { win[lane] = pre0; win[64 + lane] = pre1;
             for (uint32_t i = 128u + (uint32_t) lane; i < nw; i += 64)
               win[i] = DR_WORD((uint64_t) w0 + i);
+            }
             if (more && !asked)                            // (the next entry's numbers are here by now: a pass has gone by)
               { DR_TAKE(nx, dv_nx)
                 DR_HEADV(hv_nx, nx)
@@ -1239,7 +1263,8 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                     ready = true;
                   }
               }
-            if (staged)
+            if (staged && (DR_SKIP & 8)) { }
+            else if (staged)
               { const u32x4 v = { pat, pat, pat, pat };
                 for (uint32_t i = (uint32_t) lane; i < (tp + 15u) >> 4; i += 64)  // the pass's stretch of the line: run characters
                   ((u32x4 *) stretch)[i] = v;
@@ -1260,7 +1285,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             // has found its pass sound, then go to the staging buffer.  Anything else: the code-by-code path below.
             bool fast = false;
 #if DR_FAST
-            if (staged && tp)
+            if (staged && tp && !(DR_SKIP & 2))
               { uint32_t p = sb - 32u * w0, at1 = pos, zand = 31u, rmax = 0u, pk[8];
                 #pragma unroll
                 for (uint32_t k = 0; k < 8; k++)
@@ -1289,7 +1314,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                   }
               }
 #endif
-            if (c && !fast)
+            if (c && !fast && !(DR_SKIP & 2))
               { winrd rd;
                 rd.win = win;
                 { const uint32_t s0 = sb - 32u * w0, off = s0 & 31u;
@@ -1319,7 +1344,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                     }
               }
             wave_sync();
-            if (staged)
+            if (staged && !(DR_SKIP & 4))
             { uint8_t *o = out + base_pos;                 // the stretch leaves in 16-byte pieces, its last bytes one by one
               for (uint32_t i = (uint32_t) lane; 16u * i < tp; i += 64)
                 if (16u * i + 16u <= tp)
@@ -1330,7 +1355,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                   for (uint32_t j = 16u * i; j < tp; j++) o[j] = ((const uint8_t *) stretch)[j];
             }
             wave_sync();
-            if (tags)                                      // the same piece of the tag line: 'n', letters at the tokens' places
+            if (tags && !(DR_SKIP & 1))                    // the same piece of the tag line: 'n', letters at the tokens' places
               { uint8_t *o = tout + base_pos;
                 if (staged)
                   { const u32x4 v = { tpat, tpat, tpat, tpat };
