@@ -643,6 +643,12 @@ __device__ __forceinline__ uint32_t last_piece_plain(const uint32_t *tab, const 
   return TOK_ESC(e) ? 8u : TOK_LEN(e);
 }
 
+__device__ __forceinline__ uint32_t last_piece_byte(const uint32_t *tab, uint32_t last_byte, uint32_t L, uint32_t mask)
+{ if (L == 0) return 0;
+  const uint32_t e = tab[last_byte & mask];
+  return TOK_ESC(e) ? 8u : TOK_LEN(e);
+}
+
 __device__ __forceinline__ uint32_t seg_bytes(uint64_t T, uint32_t last)
 { return 4u * ((uint32_t) (T >> 5) + (((uint32_t) T & 31u) ? 1u : 0u) + pad_extra(T, last)); }
 
