@@ -768,7 +768,9 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               const uint32_t m4   = mask * 0x01010101u;
               uint32_t pos = 16u * lane;
               u32x4 c = fetch(p, pos, L, over);
-              const uint32_t lastb = L ? (uint32_t) p[L - 1] : 0u;   // wanted at the line's end, requested now: a memory round trip less per line
+              // (wanted at the line's end, requested now: a memory round trip less per line; not in the forwarding instance, which
+              //  has no register to spare beside k_qv_follow)
+              const uint32_t lastb = !FWD && L ? (uint32_t) p[L - 1] : 0u;
 #define PLAIN_LOOP(STAB)                                                                        \
               for (uint32_t base = 0; base < L; base += DX_STEP)                                 \
                 { const u32x4 d = fetch_step(p, base + DX_STEP, L, over);                        \
@@ -802,7 +804,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               else             { PLAIN_LOOP(s_stok[q]) }
 #undef PAIR_LOOP
 #undef PLAIN_LOOP
-              got = finish_words(o, last_piece_byte(tab, lastb, L, mask));
+              got = finish_words(o, FWD ? last_piece_plain(tab, p, L, mask) : last_piece_byte(tab, lastb, L, mask));
               if (q == 0)                                // no delChar: the whole tag line is packed
                 { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
                   const uint32_t tb = encode_all_tags(ot, p1, L, over);
