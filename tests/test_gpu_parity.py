@@ -541,6 +541,47 @@ def test_decode_with_the_encoders_group_index(ctx, case, route, monkeypatch):
         ctx.qv_subindex(False)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 9, 13])
+def test_indexed_decode_of_small_batches(ctx, n):
+    """The wave-per-line decoders draw four entries per ticket and request every entry's whereabouts, header words and
+    first round an entry ahead: batches smaller than a ticket, not a multiple of one, with empty entries in between and
+    at either end, and every contiguous part of them."""
+    lens = np.array([(0, 5000, 17, 0, 2500, 1, 1024, 16, 0, 3333, 15, 4096, 0)[i % 13] if n > 2 else (700, 0)[i % 2]
+                     for i in range(n)], np.uint32)
+    c = synth.make_quiva(n, seed=50 + n, lens=lens)
+    b, keep = _upload_quiva(ctx, c)
+    p = ctx.qv_prescan(b)
+    hist, tot = ctx.qv_hist(b, p)
+    coding = api.qv_build(hist, tot, p, False)
+    ctx.qv_set_coding(coding, False)
+    blob, hoff, _ = api.frame_headers(c.hdr)
+    d_hdr, d_hoff = ctx.to_device(blob), ctx.to_device(hoff)
+    d_rec, d_seg = ctx.alloc(8 * (n + 1)), ctx.alloc(20 * n)
+    cap = len(c.text) + 4096 * n + 4096
+    d_out = ctx.alloc(cap)
+    ctx.qv_subindex(True)
+    try:
+        ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg, d_rec, d_out, cap)
+        for first in range(n):
+            for count in range(1, n - first + 1):
+                img = np.frombuffer(c.text, np.uint8).copy()
+                for i in range(n):
+                    img[int(c.off[i]): int(c.off[i]) + 5 * (int(c.len[i]) + 1)] = 0
+                d_txt = ctx.to_device(img)
+                ctx.profile(True)
+                ctx.qv_decode(d_out, d_rec.offset(8 * first), d_hoff.offset(8 * first), d_seg.offset(20 * first),
+                              keep[2].offset(4 * first), count, True, d_txt, keep[1].offset(8 * first))
+                ran = ctx.kernel_times()
+                ctx.profile(False)
+                assert ran["k_qv_decode_sub"][1] == 1 and "k_qv_decode_plain" not in ran
+                got = d_txt.download(np.uint8, len(c.text)).tobytes()
+                lo, hi = int(c.off[first]), int(c.off[first + count - 1]) + 5 * (int(c.len[first + count - 1]) + 1)
+                assert got[lo:hi] == c.text[lo:hi], (first, count)
+                assert got[:lo] == img[:lo].tobytes() and got[hi:] == img[hi:].tobytes(), (first, count)   # nothing outside the part
+    finally:
+        ctx.qv_subindex(False)
+
+
 def test_undexqv_no_delchar_and_type2(ctx, decoder):
     for name in ("qv_nodel", "qv_type2", "qv_runs"):
         dx = O.golden(name + ".dexqv")
