@@ -724,6 +724,9 @@ struct dr_entry { uint32_t L, hl, sg[5]; uint64_t so, so1, rec, oo; };
 #ifndef DS_NPRE
 #define DS_NPRE  5                                          // words per lane of the coming round's window requested a round ahead
 #endif
+#ifndef DS_POS
+#define DS_POS   1                                         // whole groups decoded by positioned reads, no bit buffer (ds_block8_pos)
+#endif
 #ifndef DS_DUAL
 #define DS_DUAL  0                                         // two groups per lane decoded side by side (two look-up chains in flight)
 #endif
@@ -798,6 +801,33 @@ __device__ __forceinline__ void ds_block8(winrd &rd, const uint16_t *tab, const 
         }
     }
   o0 = w[0]; o1 = w[1];
+}
+
+// 8 codes into two output words WITHOUT a bit buffer (DS_POS): per pair of codes one positioned 32-bit read of the window
+// -- two words and a v_alignbit; two codes within the tables' index take <= 24 bits --, the second code looked up in the
+// first one's word shifted.  The entries' low bytes (32 - length each, <= 31) are summed as they come: eight of them stay
+// below 256, so the bits used so far are 32 x codes - (sum & 255).  No refill test, no branch: ~9 instructions per code
+// against ~12.  p: the bit (from win[0]'s top bit) at which the block starts; win[-1] must exist.  Returns bit 4 clear if
+// some code was longer than the index (the caller decodes the group again, code by code).
+__device__ __forceinline__ uint32_t ds_block8_pos(const uint32_t *win, uint32_t &p, const uint16_t *tab, uint32_t &o0, uint32_t &o1)
+{ uint32_t w[2] = { 0u, 0u }, zand = 31u, acc = 0u;
+  const uint32_t e0 = p + 31u;
+  #pragma unroll
+  for (int k = 0; k < 8; k += 2)
+    { const uint32_t  e  = e0 + 32u * k - (acc & 255u);    // the last of the 32 bits from the pair's first on
+      const uint32_t *wp = win + (e >> 5);
+      const uint32_t  x  = __builtin_amdgcn_alignbit(wp[-1], wp[0], ~e);
+      const uint32_t  ea = tab[x >> (32 - DP_BITS)];
+      const uint32_t  y  = __builtin_amdgcn_alignbit(x, 0u, ea);         // x << the first code's bits
+      const uint32_t  eb = tab[y >> (32 - DP_BITS)];
+      zand &= ea & eb;
+      acc  += ea + eb;
+      w[k >> 2] = __builtin_amdgcn_perm(ea, w[k >> 2], (k & 3) == 0 ? 0x03020105u : 0x03050100u);
+      w[k >> 2] = __builtin_amdgcn_perm(eb, w[k >> 2], (k & 3) == 0 ? 0x03020500u : 0x05020100u);
+    }
+  p += 256u - (acc & 255u);
+  o0 = w[0]; o1 = w[1];
+  return zand;
 }
 
 // the same for two groups at once: the look-up -> shift -> look-up chains of the two are independent, so a lane has two
@@ -904,8 +934,9 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
           }
     __syncthreads();
   }
-  uint32_t *const win  = s_win[threadIdx.x >> 6];
+  uint32_t *const win  = s_win[threadIdx.x >> 6] + 1;      // ([-1]: the positioned reads look one word back)
   const int       lane = lane_id();
+  if (lane == 0) win[-1] = 0u;
   const uint32_t  first_kind = (uint32_t) __builtin_ctz(kinds | 16u);
 
   // A task = the plain lines of one entry (n < 2^31), a round = DS_STEPS x 64 groups of one line.  Every round asks for
@@ -959,7 +990,7 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
               st[k]   = run + incl - d[k];
               run    += wave_total(incl);
               upto[k] = run;
-              if (((upto[k] + 31u) >> 5) + 2u - (base >> 5) <= DS_WIN && g0 + 64u * k < G && (!serial || k == 0)) steps = k + 1;
+              if (((upto[k] + 31u) >> 5) + 2u - (base >> 5) <= DS_WIN - 1u && g0 + 64u * k < G && (!serial || k == 0)) steps = k + 1;
             }
           const uint32_t w0 = base >> 5;
           const uint32_t nw = ((upto[steps - 1] + 31u) >> 5) + 2u - w0;
@@ -1038,8 +1069,15 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
                     uint8_t *o = out + 16ull * g;
                     if (valid == 16u)
                       { uint32_t x0, x1, x2, x3;
-                        ds_block8(rd, tab, lng, x0, x1);
-                        ds_block8(rd, tab, lng, x2, x3);
+#if DS_POS
+                        uint32_t pp = st[k] - 32u * w0;
+                        uint32_t z  = ds_block8_pos(win, pp, tab, x0, x1);
+                        z &= ds_block8_pos(win, pp, tab, x2, x3);
+                        if (__any((int) (~z & 16u)))       // a long code somewhere in the wave's groups: this group again, code by code
+#endif
+                        { ds_block8(rd, tab, lng, x0, x1);
+                          ds_block8(rd, tab, lng, x2, x3);
+                        }
                         const u32x4 v = { x0, x1, x2, x3 };
                         *(u32x4_u *) o = v;
                       }
