@@ -31,6 +31,12 @@
 #ifndef P2D_PIPE
 #define P2D_PIPE      1                  // k_pack2_decode: hand-pipelined main loop (0: every step through the checked loop)
 #endif
+#ifndef P2D_SKIP
+#define P2D_SKIP      0                  // timing experiments: 1 the pipelined steps store nothing, 2 no per-byte path (wrong results on purpose).
+                                         // 10 M x 10 kb (profiles/r03d_perturb_pack2_decode.txt): 32.3 ms; 1: 15.2; 2: 29.0; 3: 9.5 -- the parts ADD UP: the
+                                         // loads and the letters of one wave do not run beside the stores of another.  Loads issued three steps ahead
+                                         // (three stores in flight per wave, vmcnt(5)): 31.7-32.4 against 32.1-33.6, and 73 registers -- not kept.
+#endif
 #ifndef P2D_NT
 #define P2D_NT        0                  // k_pack2_decode: non-temporal stores for the text
 #endif
@@ -275,7 +281,8 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
                 v.z = j == 2u ? (v.z & ~m) | (nl4 & m) : v.z;                                                \
                 v.w = j == 3u ? (v.w & ~m) | (nl4 & m) : v.w;                                                \
               }                                                                                              \
-            *(u32x4_u *) (dst + q0) = v;                                                                     \
+            if (!(P2D_SKIP & 1)) *(u32x4_u *) (dst + q0) = v;                                                \
+            else if (v.x == 0x12345678u) dst[q0] = 1;                                                        \
           }
       if (P2D_ALLFAST(0u))
         { uint32_t lineA = line, colA = col, lineB = line, colB = col;
@@ -358,7 +365,7 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
                   *(u32x4_u *) (dst + q0) = v;
 #endif
                 }
-              else if (q0 < T)
+              else if (q0 < T && !(P2D_SKIP & 2))
                 decode_chunk_generic<LETTERS>(src, dst, q0, T, clen, width);
             }
         }
