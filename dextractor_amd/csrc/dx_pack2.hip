@@ -31,6 +31,9 @@
 #ifndef P2D_PIPE
 #define P2D_PIPE      1                  // k_pack2_decode: hand-pipelined main loop (0: every step through the checked loop)
 #endif
+#ifndef P2D_ENDS
+#define P2D_ENDS      1                  // a read's last chunks through the 16-letters-per-lane code as well (0: byte by byte, divisions and all)
+#endif
 #ifndef P2D_SKIP
 #define P2D_SKIP      0                  // timing experiments: 1 the pipelined steps store nothing, 2 no per-byte path (wrong results on purpose).
                                          // 10 M x 10 kb (profiles/r03d_perturb_pack2_decode.txt): 32.3 ms; 1: 15.2; 2: 29.0; 3: 9.5 -- the parts ADD UP: the
@@ -326,10 +329,20 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
               const uint32_t b0 = i0 >> 2;
               i0k[k]   = i0;
               nlk[k]   = width - col;                            // offset of the line end in this chunk (>= 16: none)
-              fastk[k] = q0 + 16u < T && b0 + 8u <= clen && !narrow;
+              // every chunk of the text but those of narrow lines and of reads shorter than 8 packed bytes: the read's last
+              // chunks too (P2D_ENDS) -- their 8 bytes taken from the last 8 of the read and shifted when they would reach
+              // past its end, a second hole for the text's last line end, a byte-wise store when the chunk is not whole
+              fastk[k] = P2D_ENDS ? (q0 < T && clen >= 8u && !narrow) : (q0 + 16u < T && b0 + 8u <= clen && !narrow);
               raw[k]   = 0;
               if (fastk[k])
-                raw[k] = *(const u64_u *) (src + b0);
+                { if (b0 + 8u <= clen)
+                    raw[k] = *(const u64_u *) (src + b0);
+                  else
+                    { const uint32_t sh = 8u * (b0 + 8u - clen);
+                      const uint64_t ld = *(const u64_u *) (src + clen - 8u);
+                      raw[k] = sh < 64u ? ld >> sh : 0ull;
+                    }
+                }
               line += dline; col += dcol;
               if (col >= W1) { col -= W1; line += 1u; }
             }
@@ -341,9 +354,15 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
                   const uint64_t be = ((uint64_t) __builtin_bswap32((uint32_t) raw[k]) << 32) | __builtin_bswap32((uint32_t) (raw[k] >> 32));
                   uint32_t cw = (uint32_t) ((be << (2u * (i0k[k] & 3u))) >> 32);
                   const uint32_t nlpos = nlk[k];
+                  const uint32_t fpos  = P2D_ENDS ? T - 1u - q0 : 16u;   // the text's last byte (a line end) in this chunk (>= 16: not here)
                   if (nlpos < 16u)
                     { const uint32_t K = 30u - 2u * nlpos;       // open a 2-bit hole at slot nlpos
                       const uint32_t keep = ~((4u << K) - 1u);   // slots before it
+                      cw = (cw & keep) | ((cw & ~keep) >> 2);
+                    }
+                  if (fpos < 16u && fpos != nlpos)               // (a short last line: its end is not where the width puts one)
+                    { const uint32_t K = 30u - 2u * fpos;
+                      const uint32_t keep = ~((4u << K) - 1u);
                       cw = (cw & keep) | ((cw & ~keep) >> 2);
                     }
                   u32x4 v;
@@ -359,6 +378,20 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
                       v.z = j == 2u ? (v.z & ~m) | (nl4 & m) : v.z;
                       v.w = j == 3u ? (v.w & ~m) | (nl4 & m) : v.w;
                     }
+                  if (fpos < 16u && fpos != nlpos)
+                    { const uint32_t m = 0xffu << (8u * (fpos & 3u)), j = fpos >> 2;
+                      const uint32_t nl4 = 0x0a0a0a0au;
+                      v.x = j == 0u ? (v.x & ~m) | (nl4 & m) : v.x;
+                      v.y = j == 1u ? (v.y & ~m) | (nl4 & m) : v.y;
+                      v.z = j == 2u ? (v.z & ~m) | (nl4 & m) : v.z;
+                      v.w = j == 3u ? (v.w & ~m) | (nl4 & m) : v.w;
+                    }
+                  if (fpos < 15u)                                // the text ends inside this chunk: its bytes one by one
+                    { const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+                      for (uint32_t b = 0; b <= fpos; b++)
+                        dst[q0 + b] = (uint8_t) ((b < 4u ? w4[0] : b < 8u ? w4[1] : b < 12u ? w4[2] : w4[3]) >> (8u * (b & 3u)));
+                    }
+                  else
 #if P2D_NT
                   __builtin_nontemporal_store(v, (u32x4_u *) (dst + q0));
 #else
