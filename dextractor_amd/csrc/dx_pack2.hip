@@ -31,6 +31,9 @@
 #ifndef P2D_PIPE
 #define P2D_PIPE      1                  // k_pack2_decode: hand-pipelined main loop (0: every step through the checked loop)
 #endif
+#ifndef P2E_OVER
+#define P2E_OVER      1                  // k_pack2_encode: a read's last, partial chunk by one 16-byte load when text follows it in the buffer
+#endif
 #ifndef P2D_ENDS
 #define P2D_ENDS      1                  // a read's last chunks through the 16-letters-per-lane code as well (0: byte by byte, divisions and all)
 #endif
@@ -59,8 +62,21 @@ __device__ __forceinline__ uint32_t sym_code(uint32_t x)
 
 #define BYTE_AT(c, b) ((chunk_word(c, (b) >> 2) >> (8 * ((b) & 3))) & 0xffu)
 
-__device__ __forceinline__ u32x4 p2_fetch(const uint8_t *p, uint32_t pos, uint32_t T)
-{ return load_chunk(p + pos, pos >= T ? 0 : (T - pos >= 16u ? 16 : (int) (T - pos))); }
+// this lane's 16 bytes of a read's text at p + pos: bytes past the text's end read as 0.  over: 16 bytes may be read
+// at any position of this read (what follows it in the buffer is more text) -- the read's last, partial chunk is then one
+// load and four masks instead of up to 15 byte loads by one lane, which the whole wave waits for
+__device__ __forceinline__ u32x4 p2_fetch(const uint8_t *p, uint32_t pos, uint32_t T, bool over)
+{ if (!over || pos >= T || T - pos >= 16u)
+    return load_chunk(p + pos, pos >= T ? 0 : (T - pos >= 16u ? 16 : (int) (T - pos)));
+  const uint32_t left = T - pos;
+  u32x4 v = *(const u32x4_u *) (p + pos);
+  const uint32_t m0 = left >= 4u  ? ~0u : ~(~0u << (8u * left));
+  const uint32_t m1 = left >= 8u  ? ~0u : (left > 4u  ? ~(~0u << (8u * (left - 4u)))  : 0u);
+  const uint32_t m2 = left >= 12u ? ~0u : (left > 8u  ? ~(~0u << (8u * (left - 8u)))  : 0u);
+  const uint32_t m3 =                     (left > 12u ? ~(~0u << (8u * (left - 12u))) : 0u);
+  v.x &= m0; v.y &= m1; v.z &= m2; v.w &= m3;
+  return v;
+}
 
 template <int ALPHA>
 __global__ __launch_bounds__(DX_BLOCK)
@@ -84,11 +100,13 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
     o.win[j] = 0;
   __syncthreads();
 
+  const uint64_t text_end = off[n - 1] + tlen[n - 1];    // (the reads lie one behind the other: the last one's end is the buffer's)
   for (uint64_t r0 = next_unit(ticket, P2_BATCH), nxt; r0 < n; r0 = nxt)
   { nxt = next_unit(ticket, P2_BATCH);                   // drawn early: hidden behind these reads
     for (uint64_t r = r0; r < r0 + P2_BATCH && r < n; r++)
     { const uint8_t *src = text + off[r];
       const uint32_t T   = tlen[r];
+      const bool     over = P2E_OVER && off[r] + T + 16u <= text_end;
       uint8_t       *dst = out + out_off[r];
 
       if (hdr != NULL)                                   // record framing bytes (dexta.c:187-198)
@@ -103,9 +121,9 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
       // 32 consecutive bytes per lane and step (two chunks): the prefix sum, the window bookkeeping
       // and the drain are paid once per 2 KiB
       uint32_t pos = 32u * lane;
-      u32x4 cA = p2_fetch(src, pos, T), cB = p2_fetch(src, pos + 16u, T);
+      u32x4 cA = p2_fetch(src, pos, T, over), cB = p2_fetch(src, pos + 16u, T, over);
       for (uint32_t base = 0; base < T; base += P2_STEP)
-        { const u32x4 dA = p2_fetch(src, pos + P2_STEP, T), dB = p2_fetch(src, pos + P2_STEP + 16u, T);   // next step in flight
+        { const u32x4 dA = p2_fetch(src, pos + P2_STEP, T, over), dB = p2_fetch(src, pos + P2_STEP + 16u, T, over);   // next step in flight
           const uint32_t left   = pos >= T ? 0u : T - pos;
           const uint32_t validA = left >= 16u ? 16u : left, validB = left >= 32u ? 16u : (left > 16u ? left - 16u : 0u);
           // the bytes' codes, first one in the top bits, as if there were no line ends

@@ -1081,9 +1081,25 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
                         const u32x4 v = { x0, x1, x2, x3 };
                         *(u32x4_u *) o = v;
                       }
-                    else
-                      for (uint32_t j = 0; j < valid; j++)   // the ragged end of the line
-                        o[j] = (uint8_t) wr_symbol(rd, tab, lng);
+                    else                                   // the ragged end of the line (one lane of the wave, but the whole wave's time:
+                      {                                    //  sixteen codes at once here too, those past the end thrown away)
+#if DS_POS
+                        uint32_t x0, x1, x2, x3, pp = st[k] - 32u * w0;
+                        uint32_t z = ds_block8_pos(win, pp, tab, x0, x1);
+                        z &= ds_block8_pos(win, pp, tab, x2, x3);
+                        if (!serial && (z & 16u))          // (a code beyond the index, real or among those thrown away: code by code)
+                          { if (valid >= 4u)  *(u32_u *) o        = x0;
+                            if (valid >= 8u)  *(u32_u *) (o + 4)  = x1;
+                            if (valid >= 12u) *(u32_u *) (o + 8)  = x2;
+                            const uint32_t w = valid >= 12u ? x3 : valid >= 8u ? x2 : valid >= 4u ? x1 : x0;
+                            for (uint32_t j = 0; j < (valid & 3u); j++)
+                              o[(valid & ~3u) + j] = (uint8_t) (w >> (8u * j));
+                          }
+                        else
+#endif
+                        for (uint32_t j = 0; j < valid; j++)
+                          o[j] = (uint8_t) wr_symbol(rd, tab, lng);
+                      }
                     used = 32u * (rd.wi - 1u - ((st[k] - 32u * w0) >> 5)) + (32u - ((st[k] - 32u * w0) & 31u)) - (uint32_t) rd.nb;
                   }
               }

@@ -1137,7 +1137,11 @@ def test_record_offsets_beyond_4gib(ctx):
     increasing with the segment index adding up, the on-device decode of the first and last entries equal to
     the text, and the LAST two records (offsets > 4 GiB) decoded by the oracle with the batch's own tables."""
     torch = pytest.importorskip("torch")
-    if torch.cuda.mem_get_info()[0] < 60 * 2**30:
+    try:                                                            # (torch only lends this test its device memory)
+        free = torch.cuda.mem_get_info()[0]
+    except RuntimeError as e:
+        pytest.skip("torch cannot open the GPU in this process: %s" % e)
+    if free < 60 * 2**30:
         pytest.skip("needs ~60 GB of free device memory")
     n, Ln, seed, movie = 5000, 700_000, 11, "m000_000"
     hlen = 1 + len(movie) + 1 + 8 + 1 + 7 + 1 + 7 + 6 + 3 + 1
