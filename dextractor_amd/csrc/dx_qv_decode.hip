@@ -1127,6 +1127,7 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 #define DR_BLOCK 1024                                      // 16 waves: tables 36 KB + 16 x (1.75 + 5) KB = 144 KB
 #define DR_NWAVE (DR_BLOCK / 64)
 #define DR_WIN   448                                       // words per wave: a pass's bits (<= RUN_PASSBITS, the encoder saw to it) + slack
+#define DR_MAXPIECE 65534u                                 // positions of a pass whose places (+ 1) still fit 16 bits beside the symbol
 #ifndef DR_SKIP
 #define DR_SKIP  0                                         // timing experiments: 1 no tag line, 2 no tokens, 4 the line's piece stays in LDS
 #endif
@@ -1281,7 +1282,8 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             const uint32_t tb = wave_total(ib);
             uint32_t       tp = wave_total(ip);
             if (base_pos + tp > L) { tp = L - base_pos; bad = 1; }        // corrupt index: never past the line
-            const bool staged = tp <= RUN_STRETCH;         // (long runs: the pass covers more than the buffer holds)
+            const bool staged = tp <= DR_MAXPIECE;         // the pass's piece of the line goes through the staging buffer, RUN_STRETCH
+                                                           // positions at a time (else, runs of thousands: straight to memory, byte by byte)
             const uint32_t w0 = base_bit >> 5;
             uint32_t nw = ((base_bit + tb + 31u) >> 5) + 2u - w0;
             if (nw > DR_WIN - 1u) { nw = DR_WIN - 1u; bad = 1; }            // (cannot happen with a sound index)
@@ -1317,13 +1319,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                     ready = true;
                   }
               }
-            if (staged && (DR_SKIP & 8)) { }
-            else if (staged)
-              { const u32x4 v = { pat, pat, pat, pat };
-                for (uint32_t i = (uint32_t) lane; i < (tp + 15u) >> 4; i += 64)  // the pass's stretch of the line: run characters
-                  ((u32x4 *) stretch)[i] = v;
-              }
-            else                                           // ... in memory, and done before the symbols go over them
+            if (!staged)                                   // the piece as run characters in memory, and there before the symbols go over them
               { uint8_t *o = out + base_pos;
                 for (uint32_t k = 16u * (uint32_t) lane; k < tp; k += 1024u)
                   if (k + 16u <= tp) { const u32x4 v = { pat, pat, pat, pat }; *(u32x4_u *) (o + k) = v; }
@@ -1332,18 +1328,20 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 __builtin_amdgcn_s_waitcnt(0);
               }
             wave_sync();
-            uint32_t posk[8];                              // where this lane's symbols went (the tag letters go to the same places)
-            // The pass as it nearly always is (its piece of the line staged, no code longer than the tables' index, no
-            // literal run): per token one positioned 32-bit read of the window -- a token's two codes take <= 24 bits --,
-            // two look-ups, no bit buffer and no branch; the tokens' places and symbols stay in registers until every lane
-            // has found its pass sound, then go to the staging buffer.  Anything else: the code-by-code path below.
+            // Tokens first, bytes afterwards: every lane works out where its <= 8 symbols go (one past the place | symbol << 16)
+            // and only then are they put into the piece, RUN_STRETCH positions at a time.
+            // The pass as it nearly always is (no code longer than the tables' index, no literal run): per token one
+            // positioned 32-bit read of the window -- a token's two codes take <= 24 bits --, two look-ups, no bit buffer and
+            // no branch.  Anything else: code by code.
+            uint32_t posk[8];
             bool fast = false;
 #if DR_FAST
             if (staged && tp && !(DR_SKIP & 2))
-              { uint32_t p = sb - 32u * w0, at1 = pos, zand = 31u, rmax = 0u, pk[8];
+              { uint32_t p = sb - 32u * w0, at1 = pos, zand = 31u, rmax = 0u;
                 #pragma unroll
                 for (uint32_t k = 0; k < 8; k++)
-                  if (k < c)
+                  { posk[k] = 0u;
+                    if (k < c)
                     { const uint32_t  e  = p + 31u;                   // the last of the 32 bits from p on
                       const uint32_t *wp = win + (e >> 5);
                       const uint32_t  x  = __builtin_amdgcn_alignbit(wp[-1], wp[0], ~e);
@@ -1354,18 +1352,10 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                       rmax  = rmax > (er >> 8) ? rmax : er >> 8;
                       p    += 64u - (er & 31u) - (es & 31u);
                       at1  += (er >> 8) + 1u;                          // one past the symbol's place
-                      pk[k] = __builtin_amdgcn_perm(es, at1, 0x0c050100u);                 // place + 1 | symbol << 16
+                      posk[k] = __builtin_amdgcn_perm(es, at1, 0x0c050100u);               // place + 1 | symbol << 16
                     }
-                fast = !__any((int) ((~zand & 16u) | (uint32_t) (rmax >= 255u) | (uint32_t) (c && at1 > tp)));
-                if (fast)
-                  { uint8_t *sm1 = (uint8_t *) stretch - 1;
-                    #pragma unroll
-                    for (uint32_t k = 0; k < 8; k++)
-                      if (k < c)
-                        { sm1[pk[k] & 0xffffu] = (uint8_t) (pk[k] >> 16);
-                          posk[k] = (pk[k] & 0xffffu) - 1u;
-                        }
                   }
+                fast = !__any((int) ((~zand & 16u) | (uint32_t) (rmax >= 255u) | (uint32_t) (c && at1 > tp)));
               }
 #endif
             if (c && !fast && !(DR_SKIP & 2))
@@ -1377,7 +1367,8 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 }
                 #pragma unroll
                 for (uint32_t k = 0; k < 8; k++)
-                  if (k < c)
+                  { posk[k] = 0u;
+                    if (k < c)
                     { uint32_t run = wr_symbol(rd, rtab, rlng);      // (fills first: >= 32 bits)
                       if (run == 255u)                               // 16-bit literal, QV.c:670-676
                         { wr_fill(rd);
@@ -1389,65 +1380,90 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                       pos += run;
                       const uint32_t x = wr_symbol(rd, stab, slng);
                       if (pos >= tp)   { bad = 1; pos = tp ? tp - 1u : 0u; }   // corrupt stream / index: stay inside
-                      if (tp)
-                        { if (staged) ((uint8_t *) stretch)[pos] = (uint8_t) x;
-                          else        out[base_pos + pos] = (uint8_t) x;
+                      if (staged) posk[k] = (pos + 1u) | (x << 16);           // (pos < tp <= DR_MAXPIECE: 16 bits do)
+                      else
+                        { if (tp) out[base_pos + pos] = (uint8_t) x;
+                          posk[k] = pos + 1u;
                         }
-                      posk[k] = pos;
                       pos += 1;
                     }
+                  }
               }
-            wave_sync();
-            if (staged && !(DR_SKIP & 4))
-            { uint8_t *o = out + base_pos;                 // the stretch leaves in 16-byte pieces, its last bytes one by one
-              for (uint32_t i = (uint32_t) lane; 16u * i < tp; i += 64)
-                if (16u * i + 16u <= tp)
-                  { const u32x4 v = ((const u32x4 *) stretch)[i];
-                    *(u32x4_u *) (o + 16u * i) = v;
-                  }
-                else
-                  for (uint32_t j = 16u * i; j < tp; j++) o[j] = ((const uint8_t *) stretch)[j];
-            }
-            wave_sync();
-            if (tags && !(DR_SKIP & 1))                    // the same piece of the tag line: 'n', letters at the tokens' places
+            else if (!fast)
+              {
+                #pragma unroll
+                for (uint32_t k = 0; k < 8; k++) posk[k] = 0u;
+              }
+            const uint32_t Wtag = ((tg0 << 24) | (tg1 << 16) | (tg2 << 8)) << (2u * ((k0 + first) & 3u));   // this lane's tag codes, first one on top
+            if (staged)
+              for (uint32_t w = 0; w < tp; w += RUN_STRETCH)
+                { const uint32_t wl = tp - w < RUN_STRETCH ? tp - w : RUN_STRETCH;
+                  uint8_t *const s8 = (uint8_t *) stretch;
+                  if (!(DR_SKIP & 8))
+                    { const u32x4 v = { pat, pat, pat, pat };
+                      for (uint32_t i = (uint32_t) lane; i < (wl + 15u) >> 4; i += 64)    // this stretch of the line: run characters
+                        ((u32x4 *) stretch)[i] = v;
+                    }
+                  wave_sync();
+                  #pragma unroll
+                  for (uint32_t k = 0; k < 8; k++)
+                    { const uint32_t pl = (posk[k] & 0xffffu) - 1u - w;                  // (no token: a huge number)
+                      if (k < c && pl < wl) s8[pl] = (uint8_t) (posk[k] >> 16);
+                    }
+                  wave_sync();
+                  if (!(DR_SKIP & 4))
+                    { uint8_t *o = out + base_pos + w;         // the stretch leaves in 16-byte pieces, its last bytes one by one
+                      for (uint32_t i = (uint32_t) lane; 16u * i < wl; i += 64)
+                        if (16u * i + 16u <= wl)
+                          { const u32x4 v = ((const u32x4 *) stretch)[i];
+                            *(u32x4_u *) (o + 16u * i) = v;
+                          }
+                        else
+                          for (uint32_t j = 16u * i; j < wl; j++) o[j] = s8[j];
+                    }
+                  wave_sync();
+                  if (tags && !(DR_SKIP & 1))                  // the same stretch of the tag line: 'n', letters at the tokens' places
+                    { uint8_t *o = tout + base_pos + w;
+                      const u32x4 v = { tpat, tpat, tpat, tpat };
+                      for (uint32_t i = (uint32_t) lane; i < (wl + 15u) >> 4; i += 64)
+                        ((u32x4 *) stretch)[i] = v;
+                      wave_sync();
+                      uint32_t W = Wtag;
+                      #pragma unroll
+                      for (uint32_t k = 0; k < 8; k++)
+                        { const uint32_t ch = ((0x74676361u >> (8u * (W >> 30))) & 0xffu) - fold;   // "acgt", Lower_Read DB.c:367
+                          const uint32_t pl = (posk[k] & 0xffffu) - 1u - w;
+                          W <<= 2;
+                          if (k < c && pl < wl) s8[pl] = (uint8_t) ch;
+                        }
+                      wave_sync();
+                      for (uint32_t i = (uint32_t) lane; 16u * i < wl; i += 64)
+                        if (16u * i + 16u <= wl)
+                          { const u32x4 v2 = ((const u32x4 *) stretch)[i];
+                            *(u32x4_u *) (o + 16u * i) = v2;
+                          }
+                        else
+                          for (uint32_t j = 16u * i; j < wl; j++) o[j] = s8[j];
+                      wave_sync();
+                    }
+                }
+            else if (tags && !(DR_SKIP & 1))               // (a piece too long for 16-bit places: the tag line's straight to memory as well)
               { uint8_t *o = tout + base_pos;
-                if (staged)
-                  { const u32x4 v = { tpat, tpat, tpat, tpat };
-                    for (uint32_t i = (uint32_t) lane; i < (tp + 15u) >> 4; i += 64)
-                      ((u32x4 *) stretch)[i] = v;
-                  }
-                else
-                  { for (uint32_t k = 16u * (uint32_t) lane; k < tp; k += 1024u)
-                      if (k + 16u <= tp) { const u32x4 v = { tpat, tpat, tpat, tpat }; *(u32x4_u *) (o + k) = v; }
-                      else for (uint32_t j = k; j < tp; j++) o[j] = (uint8_t) tpat;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __builtin_amdgcn_s_waitcnt(0);
-                  }
+                for (uint32_t k = 16u * (uint32_t) lane; k < tp; k += 1024u)
+                  if (k + 16u <= tp) { const u32x4 v = { tpat, tpat, tpat, tpat }; *(u32x4_u *) (o + k) = v; }
+                  else for (uint32_t j = k; j < tp; j++) o[j] = (uint8_t) tpat;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_s_waitcnt(0);
                 wave_sync();
                 if (c && tp)
-                  { const uint32_t tix = k0 + first, b0 = tix >> 2;             // this lane's first token and its tag byte
-                    uint32_t W = 0;                                               // the next 3 tag bytes, first code in the top bits
-                    W = (tg0 << 24) | (tg1 << 16) | (tg2 << 8);
-                    (void) b0;
-                    W <<= 2u * (tix & 3u);
+                  { uint32_t W = Wtag;
                     #pragma unroll
                     for (uint32_t k = 0; k < 8; k++)
                       if (k < c)
-                        { const uint32_t ch = ((0x74676361u >> (8u * (W >> 30))) & 0xffu) - fold;   // "acgt", Lower_Read DB.c:367
+                        { const uint32_t ch = ((0x74676361u >> (8u * (W >> 30))) & 0xffu) - fold;
                           W <<= 2;
-                          if (staged) ((uint8_t *) stretch)[posk[k]] = (uint8_t) ch;
-                          else        o[posk[k]] = (uint8_t) ch;
+                          (o - 1)[posk[k]] = (uint8_t) ch;
                         }
-                  }
-                wave_sync();
-                if (staged)
-                  { for (uint32_t i = (uint32_t) lane; 16u * i < tp; i += 64)
-                      if (16u * i + 16u <= tp)
-                        { const u32x4 v = ((const u32x4 *) stretch)[i];
-                          *(u32x4_u *) (o + 16u * i) = v;
-                        }
-                      else
-                        for (uint32_t j = 16u * i; j < tp; j++) o[j] = ((const uint8_t *) stretch)[j];
                   }
                 wave_sync();
               }

@@ -108,7 +108,8 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
               tacc = (tacc << 2) | (t16 & 3u);
           }
       if (XC && xn > 1u)                                           // two exception tokens in one lane: its bits counted token by token
-        { nb = 0; span = 0; zor |= 32u;                            // (and the pass placed token by token, below)
+        { nb = 0; span = 0; zor |= 64u;                            // (and the pass placed token by token, below; bit 6 is free in every
+                                                                   //  token: unlike bit 5 -- something has no code -- it leaves the line its index)
           for (uint32_t j = 0; j < c; j++)
             { const uint32_t t16 = tok[first + j];
               uint32_t run = t16 >> 9;
@@ -124,7 +125,7 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           g16 += 64;
           wide |= ((zor & 32u) || span > 0xffffu || wave_total(incl) > RUN_PASSBITS) ? 1u : 0u;
         }
-      if (!__any((int) ((zor & 32u) | (nb > 128u))))
+      if (!__any((int) ((zor & 96u) | (nb > 128u))))
         { FOR_EACH_ROUND_LATE(o, incl, nb,
             { place_bits128(o.win, bit_, nb, w0, w1, w2, w3); })
         }

@@ -438,7 +438,8 @@ def test_device_round_trip_with_encoder_index(ctx):
 
 
 @pytest.mark.parametrize("route", ["scratch", "direct", "text"])
-@pytest.mark.parametrize("case", ["ragged", "long_codes", "no_runs", "lossy", "long_entries", "odd_entries", "long_runs"])
+@pytest.mark.parametrize("case", ["ragged", "long_codes", "no_runs", "lossy", "long_entries", "odd_entries", "long_runs",
+                                  "dense_runs_90", "dense_runs_97", "dense_runs_99"])
 def test_decode_with_the_encoders_group_index(ctx, case, route, monkeypatch):
     """dx_qv_subindex: the one-pass encoder (each of its routes) leaves the code bits of every group of 16 symbols of the
     plain lines; dx_qv_decode of that stream in the same context then runs k_qv_decode_sub, a wavefront per line.  Same text
@@ -465,6 +466,10 @@ def test_decode_with_the_encoders_group_index(ctx, case, route, monkeypatch):
             txt[o_ + 100: o_ + 100 + 101 * k] = unit_d * k
             txt[o_ + (Le + 1) + 100: o_ + (Le + 1) + 100 + 101 * k] = unit_t * k
         c.text = bytes(txt)
+    elif case.startswith("dense_runs"):                           # run characters 90 / 97 / 99 % of the two lines: a pass of 512 tokens covers 5 k,
+        rp = int(case[-2:]) / 100.0                               # 17 k, 51 k positions -- through the staging buffer 5120 at a time --, runs of
+        c = synth.make_quiva(40, seed=36, mean=30000,             # 127 and more in most lanes (exception tokens: the line keeps its index),
+                             prof=synth.pacbio_profile(del_run_p=rp, sub_run_p=rp))   # runs of 255 and more (16-bit literals: code by code)
     elif case == "ragged":                                        # every group shape: 0, < 16, multiples of 16, around a step (1024) and a round
         lens = np.array(list(range(0, 70)) + [255, 256, 257, 1023, 1024, 1025, 1040, 2047, 2048, 2049, 4097, 9999, 10000,
                                               16383, 16384, 16385, 16400] + [7000] * 30, np.uint32)
