@@ -35,6 +35,25 @@ __device__ __forceinline__ uint64_t next_unit(uint32_t *counter, uint32_t batch 
   return (uint64_t) uniform(t);
 }
 
+// Units per ticket where only the device knows how many bytes a batch holds: one thread, in front of the kernel, leaves
+// the number in the word BEHIND the kernel's ticket counter (ticket[1]; the host zeroes only ticket[0]) -- about `target`
+// bytes' worth per ticket, `least` units at least.  bytes = *hi + *extra - *lo.  (Every draw is an atomic on one address,
+// ~11 ns each chip-wide: a fixed few units per ticket bind a batch of many short units to its counter -- 50 M reads of
+// 1 kb, 16 per ticket: 34 ms of draws for 13 ms of work.)
+static __global__ void k_ticket_units(const uint64_t *lo, const uint64_t *hi, const uint32_t *extra, uint64_t n,
+                                      uint32_t target, uint32_t least, uint32_t *ticket)
+{ const uint64_t bytes = *hi + (extra ? (uint64_t) *extra : 0ull) - *lo;
+  const uint64_t mean  = n ? bytes / n + 1u : 1u;
+  uint64_t u = ((uint64_t) target + mean - 1u) / mean;
+  ticket[1] = (uint32_t) (u < least ? least : (u > 4096u ? 4096u : u));
+}
+
+// what the kernel makes of that word (never less than `least`, whatever is there)
+__device__ __forceinline__ uint32_t ticket_units_of(const uint32_t *ticket, uint32_t least)
+{ const uint32_t u = uniform(ticket[1]);
+  return u < least || u > 4096u ? least : u;
+}
+
 // Orders this wave's LDS traffic: everything before is complete and visible to the other lanes
 // of the wave before anything after starts.  (LDS instructions of one wave execute in order;
 // this pins the compiler and waits for outstanding returns.)

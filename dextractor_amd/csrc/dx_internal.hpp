@@ -84,6 +84,7 @@ struct dx_ctx
   uint64_t *d_u64;             // small device scalars (prescan keys, totals, ...)
   void     *d_scratch;         // grow-only scratch (scan partials, histograms, sizes)
   size_t    scratch_bytes;
+  uint32_t  compact_units;     // records per ticket of k_qv_compact for the batch being encoded (onepass_impl sets it)
   uint64_t  scratch_gen;       // counts its re-allocations: a new block may come back at the OLD address with other contents,
                                //   so "did it move" must never be asked of the pointer
   uint64_t *d_scan;            // grow-only tile sums of dx_scan_u32 (its callers hold d_scratch)

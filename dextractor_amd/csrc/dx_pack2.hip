@@ -101,9 +101,10 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
   __syncthreads();
 
   const uint64_t text_end = off[n - 1] + tlen[n - 1];    // (the reads lie one behind the other: the last one's end is the buffer's)
-  for (uint64_t r0 = next_unit(ticket, P2_BATCH), nxt; r0 < n; r0 = nxt)
-  { nxt = next_unit(ticket, P2_BATCH);                   // drawn early: hidden behind these reads
-    for (uint64_t r = r0; r < r0 + P2_BATCH && r < n; r++)
+  const uint32_t TB = ticket_units_of(ticket, P2_BATCH);  // (k_ticket_units in front of the launch: 16 reads of 10 kb, more of shorter ones)
+  for (uint64_t r0 = next_unit(ticket, TB), nxt; r0 < n; r0 = nxt)
+  { nxt = next_unit(ticket, TB);                         // drawn early: hidden behind these reads
+    for (uint64_t r = r0; r < r0 + TB && r < n; r++)
     { const uint8_t *src = text + off[r];
       const uint32_t T   = tlen[r];
       const bool     over = P2E_OVER && off[r] + T + 16u <= text_end;
@@ -258,9 +259,10 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
   const uint32_t dline  = DX_STEP / W1, dcol = DX_STEP - dline * W1;
   const bool     narrow = width < 16u;   // several line ends may fall into 16 bytes: generic path only
 
-  for (uint64_t r0 = next_unit(ticket, P2_BATCH), nxt; r0 < n; r0 = nxt)
-  { nxt = next_unit(ticket, P2_BATCH);
-    for (uint64_t r = r0; r < r0 + P2_BATCH && r < n; r++)
+  const uint32_t TB = ticket_units_of(ticket, P2_BATCH);
+  for (uint64_t r0 = next_unit(ticket, TB), nxt; r0 < n; r0 = nxt)
+  { nxt = next_unit(ticket, TB);
+    for (uint64_t r = r0; r < r0 + TB && r < n; r++)
     { const uint8_t *src  = in + in_off[r];
       uint8_t       *dst  = out + out_off[r];
       const uint32_t L    = nsym[r];
@@ -446,6 +448,8 @@ extern "C" int dx_pack2_encode(dx_ctx *ctx, int alphabet,
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 20);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, d_off, d_off + (n - 1), d_tlen + (n - 1), n,
+                     P2_BATCH * 10000u, P2_BATCH, d_ticket);
   const int grid = dx_grid_waves(ctx, n, 32);
   if (alphabet == DX_ALPHA_BASES)
     DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_BASES>, grid, DX_BLOCK,
@@ -478,6 +482,8 @@ extern "C" int dx_pack2_decode(dx_ctx *ctx, int letters,
   DX_HIP(ctx, hipSetDevice(ctx->device));
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 21);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, d_out_off, d_out_off + (n - 1), d_nsym + (n - 1), n,
+                     P2_BATCH * 10000u, P2_BATCH, d_ticket);
   const int grid = dx_grid_waves(ctx, n, 32);
   switch (letters)
     { case DX_LETTERS_LOWER:

@@ -62,7 +62,18 @@ struct qv_args
   uint32_t        pad;          // line_pad
   int             delChar, subChar;
   int             lossy;
+  uint32_t        units;        // entries per ticket (ticket_units on the host: 2 of 10 kb, more of shorter ones)
 };
+
+// Units per ticket for a batch whose n units hold `bytes` bytes in all: about `target` bytes' worth, `least` at least.
+// Every draw is an atomic on ONE address, ~11 ns each chip-wide: with a fixed few units per ticket a batch of many short
+// entries or reads is bound by its counter (4 M entries of 300, two per ticket: 22 ms of draws under every kernel).
+static uint32_t ticket_units(uint64_t bytes, uint64_t n, uint32_t target, uint32_t least)
+{ if (n == 0 || bytes == 0) return least;
+  const uint64_t mean = bytes / n + 1u;
+  uint64_t u = ((uint64_t) target + mean - 1u) / mean;
+  return (uint32_t) (u < least ? least : (u > 4096u ? 4096u : u));
+}
 
 __device__ __forceinline__ const uint8_t *line_ptr(const qv_args &a, uint64_t r, uint32_t L, int k)
 { return a.text + a.off[r] + (uint64_t) k * ((uint64_t) L + a.pad); }
@@ -491,9 +502,9 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   __syncthreads();
 
   uint64_t tot = 0, since = 0;
-  for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
-  { nxt = next_unit(ticket, TICKET_BATCH);             // drawn early: the atomic's latency hides behind these entries
-    for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
+  for (uint64_t r0 = next_unit(ticket, a.units), nxt; r0 < a.n; r0 = nxt)
+  { nxt = next_unit(ticket, a.units);                  // drawn early: the atomic's latency hides behind these entries
+    for (uint64_t r = r0; r < r0 + a.units && r < a.n; r++)
     { const uint32_t  L = a.len[r];
       const long long g = (long long) (entry0 + r);
       const bool drun = a.delChar >= 0 && (toks || g >= del_first);      // tokenised (and, from del_first on, run-histogrammed)
@@ -759,12 +770,12 @@ void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint3
   const uint64_t listed = only_list ? (uint64_t) *only_count : 0;
   uint64_t pend = 0;
   uint32_t mine = 0;
-  for (uint64_t r0 = only_list ? 0 : next_unit(ticket, TICKET_BATCH), nxt = 0; ; r0 = nxt)
+  for (uint64_t r0 = only_list ? 0 : next_unit(ticket, a.units), nxt = 0; ; r0 = nxt)
   { uint64_t rlo, rhi;
     if (only_list == NULL)
       { if (r0 >= a.n) break;
-        nxt = next_unit(ticket, TICKET_BATCH);
-        rlo = r0; rhi = r0 + TICKET_BATCH < a.n ? r0 + TICKET_BATCH : a.n;
+        nxt = next_unit(ticket, a.units);
+        rlo = r0; rhi = r0 + a.units < a.n ? r0 + a.units : a.n;
       }
     else
       { while (pend == 0)
@@ -1406,14 +1417,18 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
   // (batch-wide indices, any order; this launch takes the ones in [first_entry, first_entry + n)).  The
   // list is drawn 64 indices at a time, a lane each.
   const uint64_t listed = only_list ? (uint64_t) *only_count : 0;
-  uint64_t pend = 0, nxt = only_list ? 0 : next_unit(ticket);
+  uint64_t pend = 0, nxt = only_list ? 0 : next_unit(ticket, a.units), cur = 0, cur_end = 0;
   uint32_t mine = 0;
   for (;;)
     { uint64_t r;
-      if (only_list == NULL)
-        { r = nxt;
+      if (only_list == NULL)                             // (a.units entries per ticket, like everywhere)
+        { if (cur >= cur_end)
+            { cur = nxt; cur_end = nxt + a.units;
+              if (cur >= a.n) break;
+              nxt = next_unit(ticket, a.units);
+            }
+          r = cur++;
           if (r >= a.n) break;
-          nxt = next_unit(ticket);
         }
       else
         { while (pend == 0)
@@ -1606,10 +1621,10 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
 __global__ __launch_bounds__(DX_BLOCK)
 void k_qv_compact(uint64_t n, const uint32_t *len, const uint8_t *scratch, const uint64_t *slot_off, const uint32_t *seg,
                   const uint64_t *rec_off, const uint8_t *hdr, const uint64_t *hdr_off, uint8_t *out, uint64_t out_cap,
-                  uint32_t *status, uint32_t *ticket)
-{ for (uint64_t r0 = next_unit(ticket, COMPACT_BATCH), nxt; r0 < n; r0 = nxt)
-  { nxt = next_unit(ticket, COMPACT_BATCH);              // (one same-address atomic costs ~11 ns chip-wide)
-    for (uint64_t r = r0; r < r0 + COMPACT_BATCH && r < n; r++)
+                  uint32_t *status, uint32_t *ticket, uint32_t units)
+{ for (uint64_t r0 = next_unit(ticket, units), nxt; r0 < n; r0 = nxt)
+  { nxt = next_unit(ticket, units);                      // (one same-address atomic costs ~11 ns chip-wide; units: 8 of 10 kb)
+    for (uint64_t r = r0; r < r0 + units && r < n; r++)
     { const uint32_t *sg  = seg + 5 * r;
       const uint8_t  *src = scratch + slot_off[r];
       uint8_t        *dst = out + rec_off[r];
@@ -1660,6 +1675,7 @@ static qv_args make_args(const dx_qv_batch *b, int delChar, int subChar, int los
   a.text = b->d_text; a.off = b->d_off; a.len = b->d_len; a.n = b->n; a.pad = b->line_pad;
   a.text_bytes = b->text_bytes;
   a.delChar = delChar; a.subChar = subChar; a.lossy = lossy;
+  a.units = ticket_units(b->text_bytes, b->n, TICKET_BATCH * 50000u, TICKET_BATCH);
   return a;
 }
 
@@ -2036,7 +2052,7 @@ static int onepass_side(dx_ctx *ctx, hipStream_t B, int waves_per_cu, const uint
     }
   DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, waves_per_cu), DX_BLOCK,
             m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
-            ctx->d_status, d_tick);
+            ctx->d_status, d_tick, ctx->compact_units ? ctx->compact_units : COMPACT_BATCH);
   return DX_OK;
 }
 
@@ -2495,6 +2511,7 @@ layout:
   uint64_t      *d_base = ctx->d_u64 + 24;               // [0], [1]: running record offset, ping-pong
   uint32_t      *d_tick_enc = (uint32_t *) (ctx->d_u64 + 19), *d_tick_cmp = (uint32_t *) (ctx->d_u64 + 22);
   qv_args        a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
+  ctx->compact_units = COMPACT_BATCH / TICKET_BATCH * a.units;      // (8 records of a 10 kb entry; more of shorter ones)
   // the token hand-over applies when k_qv_hist made its tokens for exactly this batch under the run characters now in force
   // (a substitution run character dropped by Create_QVcoding, QV.c:1044, just leaves its tokens unused)
   const bool fast = onepass_tokens_ok(ctx, b);

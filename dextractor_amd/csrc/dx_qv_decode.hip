@@ -670,15 +670,16 @@ struct dr_entry { uint32_t L, hl, sg[5]; uint64_t so, so1, rec, oo; };
 #define DEC_TICKET 4u
 #endif
 #define DT_FIRST(R, R_END, TKV)                                                                                         \
+  const uint32_t dec_ticket = ticket_units_of(next_task, DEC_TICKET);       /* (k_ticket_units in front of the launch) */ \
   { uint32_t t0_ = 0;                                                                                                   \
     if (lane == 0) { t0_ = atomicAdd(next_task, 1u); TKV = atomicAdd(next_task, 1u); }                                  \
-    R = (uint64_t) uniform(t0_) * DEC_TICKET; R_END = R + DEC_TICKET;                                                   \
+    R = (uint64_t) uniform(t0_) * dec_ticket; R_END = R + dec_ticket;                                                   \
   }
 #define DT_NEXT(R1, FRESH, R, R_END, TKV)                                                                               \
   { FRESH = (R) + 1u >= (R_END);                                                                                        \
     R1    = (R) + 1u;                                                                                                   \
     if (FRESH)                                                                                                          \
-      { R1 = (uint64_t) uniform(TKV) * DEC_TICKET;                                                                      \
+      { R1 = (uint64_t) uniform(TKV) * dec_ticket;                                                                      \
         if (lane == 0) TKV = atomicAdd(next_task, 1u);                                                                  \
       }                                                                                                                 \
   }
@@ -950,7 +951,7 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
   bool     ready = false, fresh;                           // draw / pre hold the coming round's requests
   DT_FIRST(r, r_end, tkv)
   if (r < a.n) DR_DESC(dv, r)
-  for (; r < a.n; r = r1, r_end = fresh ? r1 + DEC_TICKET : r_end, dv = dv_nx)       // (every wave gets past the end: the counter only grows)
+  for (; r < a.n; r = r1, r_end = fresh ? r1 + dec_ticket : r_end, dv = dv_nx)       // (every wave gets past the end: the counter only grows)
     { dr_entry cur;
       DR_TAKE(cur, dv)
       DT_NEXT(r1, fresh, r, r_end, tkv)
@@ -1212,7 +1213,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
       DR_TAKE(e0, dv)
       DR_HEADV(hv, e0)
     }
-  for (; r < a.n; r = r1, r_end = fresh ? r1 + DEC_TICKET : r_end, dv = dv_nx, hv = hv_nx)       // (every wave gets past the end: the counter only grows)
+  for (; r < a.n; r = r1, r_end = fresh ? r1 + dec_ticket : r_end, dv = dv_nx, hv = hv_nx)       // (every wave gets past the end: the counter only grows)
     { dr_entry cur, nx = {};
       uint32_t head[3];
       DR_TAKE(cur, dv)
@@ -1640,6 +1641,8 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
       if (first + n <= ctx->sx.n)
         { uint32_t *d_next3 = (uint32_t *) (ctx->d_u64 + 30);
           DX_HIP(ctx, hipMemsetAsync(d_next3, 0, 4, ctx->stream));
+          hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, a.rec_off, a.rec_off + n, (const uint32_t *) NULL, n,
+                             DEC_TICKET * 14000u, DEC_TICKET, d_next3);         // (4 entries of 10 kb per ticket; more of shorter ones)
           const int nk = __builtin_popcount(plain);
           uint64_t sb = (n + DS_NWAVE - 1) / DS_NWAVE;
           if (sb > cap * (nk <= 2 ? 2 : 1)) sb = cap * (nk <= 2 ? 2 : 1);       // two workgroups per CU fit with <= 2 tables
@@ -1661,6 +1664,8 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
           if (runs && getenv("DEXGPU_NO_RUNINDEX") == NULL)
             { uint32_t *d_next4 = (uint32_t *) (ctx->d_u64 + 29);
               DX_HIP(ctx, hipMemsetAsync(d_next4, 0, 4, ctx->stream));
+              hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, a.rec_off, a.rec_off + n, (const uint32_t *) NULL, n,
+                                 DEC_TICKET * 14000u, DEC_TICKET, d_next4);
               uint64_t rb = (n + DR_NWAVE - 1) / DR_NWAVE;
               if (rb > cap) rb = cap;
               if (runs == 9u)

@@ -615,7 +615,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   // Entries are drawn FAST_TICKET at a time: every draw is an atomic on ONE address, ~11 ns each chip-wide whoever asks
   // (a kernel doing nothing but drawing its 500 k tickets takes 5.8 ms), so a million single draws are 11 ms of the
   // counter's time inside a 13.7 ms kernel.
-  const uint32_t TB = CHAIN ? 1u : (FOLLOW && !FWD ? FOLLOW_TICKET : FAST_TICKET);
+  const uint32_t TB = CHAIN ? 1u : (FOLLOW ? (FWD ? FAST_TICKET : FOLLOW_TICKET) : a.units);
   uint64_t pend = ~0ull;                                 // (FOLLOW) the entry coded before this one: placed once this one is coded
   const uint64_t base0 = FOLLOW == 1 ? uniform64(*fc.base) : 0ull;
 #define FOLLOW_NEXT(x) { if (FOLLOW == 1) { if (!(FOLLOW_SKIP & 4) && pend != ~0ull) fc_place(fc, a, sc, hdr_off, pend, status, base0); pend = (x); } }
@@ -887,9 +887,9 @@ void k_qv_sizes_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, 
   load_size_tables(s_t, g_tok, a.delChar, a.subChar);
   const int lane = lane_id();
 
-  for (uint64_t r0 = next_unit(ticket, TICKET_BATCH), nxt; r0 < a.n; r0 = nxt)
-  { nxt = next_unit(ticket, TICKET_BATCH);
-    for (uint64_t r = r0; r < r0 + TICKET_BATCH && r < a.n; r++)
+  for (uint64_t r0 = next_unit(ticket, a.units), nxt; r0 < a.n; r0 = nxt)
+  { nxt = next_unit(ticket, a.units);
+    for (uint64_t r = r0; r < r0 + a.units && r < a.n; r++)
     { if (tok_unusable(tk.info, r, a.delChar, a.subChar))
         continue;                                        // k_qv_sizes (generic) has this entry
       const uint32_t L = a.len[r];
