@@ -707,13 +707,15 @@ struct dr_entry { uint32_t L, hl, sg[5]; uint64_t so, so1, rec, oo; };
 //  plain lines with the encoder's group index (dx_qv_subindex): k_qv_decode_sub
 // ---------------------------------------------------------------------------------------------
 // A wavefront per (entry, plain line).  The index holds the code bits of every group of 16 symbols; per round the
-// wave takes the next 4 x 64 groups, turns the bit counts into start offsets with four prefix sums, copies the
+// wave takes the next DS_STEPS x 64 groups, turns the bit counts into start offsets with prefix sums, puts the
 // words they span into its LDS window (coalesced dwords, the stream's word alignment restored on the way) and
-// lane b decodes groups b, 64 + b, 128 + b, 192 + b of the round: the 64 lanes' 16-byte stores of one step are
-// 1 KiB of consecutive addresses -- whole lines leave the L2 once -- where a lane per line touches 64 different
-// lines per access.  The lanes run the same code sequence as k_qv_decode_plain's blocks (12-bit look-up, two
-// v_alignbit, one v_perm per code) with refills that are plain LDS reads: no ring, no fetch.  A line marked
-// SUB_NONE (a symbol without a code: hand-made tables only) is decoded group after group by one lane.
+// lane b decodes groups b, 64 + b, ... of the round: the 64 lanes' 16-byte stores of one step are 1 KiB of
+// consecutive addresses -- whole lines leave the L2 once -- where a lane per line touches 64 different lines per
+// access.  A whole group is decoded by positioned reads of the window, two codes per read (ds_block8_pos); a group
+// with a code beyond the tables' 12-bit index, and what the positioned path cannot take, by the code sequence of
+// k_qv_decode_plain's blocks (bit buffer, refills that are plain LDS reads).  A line marked SUB_NONE (a symbol
+// without a code: hand-made tables only) is decoded group after group by one lane.  Every round requests what the
+// NEXT round needs (see the kernel).
 // LDS: only the tables of the NK plain kinds present (9 KB each) + a 5 KB window per wave; with the usual two
 // plain lines (ins, mrg) two 12-wave workgroups share a CU (78 KB each), 6 waves per SIMD.
 #define DS_BLOCK 768
