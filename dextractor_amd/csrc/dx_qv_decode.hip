@@ -1122,11 +1122,14 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 // ---------------------------------------------------------------------------------------------
 // A wavefront per (entry, run-coded line).  The index holds, for every group of <= 8 consecutive (run, symbol)
 // tokens -- what a lane of the encoder coded in a pass -- the bits they take and the positions they cover.  The
-// wave first stores the whole line as run characters (coalesced), then goes through the passes of 512 tokens the
-// way the encoder did: two prefix sums turn the groups' bits and spans into where each lane starts reading and
-// writing, the words are staged in the LDS window, and every lane decodes its tokens -- run code (+ 16-bit literal),
-// symbol code -- advancing by the run and storing only the symbol's byte.  All lanes hold the same number of
-// tokens (the line's last pass aside), so the wave runs in step; the stores of a pass fall into about 1 KB.
+// wave goes through the passes of 512 tokens the way the encoder did: two prefix sums turn the groups' bits and
+// spans into where each lane starts reading and writing, the pass's words are staged in the LDS window, every lane
+// decodes its tokens -- run code (+ 16-bit literal), symbol code -- into registers (one past the symbol's place |
+// symbol << 16), and the pass's piece of the line then goes through a staging buffer RUN_STRETCH positions at a
+// time: run characters everywhere, the symbols of the tokens that fall into it at their places, out in 16-byte
+// stores; for the deletion line the same stretch of the TAG line follows.  All lanes hold the same number of tokens
+// (the line's last pass aside), so the wave runs in step.  What is left of the line behind its last token is run
+// characters.  Everything a pass, a line and an entry begin with is requested ahead (see the kernel).
 #define DR_BLOCK 1024                                      // 16 waves: tables 36 KB + 16 x (1.75 + 5) KB = 144 KB
 #define DR_NWAVE (DR_BLOCK / 64)
 #define DR_WIN   448                                       // words per wave: a pass's bits (<= RUN_PASSBITS, the encoder saw to it) + slack
