@@ -163,11 +163,17 @@ def main():
         for pr in (0.95, 0.99):
             a3 = argparse.Namespace(**vars(args))
             a3.del_run_p, a3.sub_run_p, a3.steps, a3.warmup = pr, pr, 3, 1
+            a3.no_walk_index = True
             trace(f"extra: dexqv, run density {pr}")
             try:
-                l3 = dexqv_bench(a3, 0, 1, local, cpu=False, front=False, index_decode=False)
+                # (decode with the encoder's group index too: a pass of 512 tokens covers 10 k positions at 0.95 and 51 k at
+                #  0.99 -- more than the decoder stages at a time --, and most lanes hold runs of 127 and more at 0.99)
+                l3 = dexqv_bench(a3, 0, 1, local, cpu=False, front=False, index_decode=True)
                 sweep[str(pr)] = {"value": l3["value"], "unit": "GB/s", "ms_per_step": l3["ms_per_step"], "ratio": l3["config"]["ratio"],
                                   "roundtrip_bit_exact": l3["roundtrip_bit_exact"],
+                                  "decode_ms": (l3.get("decode") or {}).get("ms"),
+                                  "decode_indexed_ms": (l3.get("decode_indexed") or {}).get("ms"),
+                                  "decode_indexed_bit_exact": (l3.get("decode_indexed") or {}).get("bit_exact"),
                                   "entries_on_text_encoder": l3["encoder_route"].get("text_entries"),
                                   "vs_default_density": round(l3["value"] / line["value"], 3)}
             except Exception as e:
