@@ -1130,7 +1130,19 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 // stores; for the deletion line the same stretch of the TAG line follows.  All lanes hold the same number of tokens
 // (the line's last pass aside), so the wave runs in step.  What is left of the line behind its last token is run
 // characters.  Everything a pass, a line and an entry begin with is requested ahead (see the kernel).
+#ifndef DR_BLOCK
 #define DR_BLOCK 1024                                      // 16 waves: tables 36 KB + 16 x (1.75 + 5) KB = 144 KB
+#endif
+#ifndef DR_POS
+#define DR_POS   RUN_STRETCH                               // positions of the staging buffer
+#endif
+#ifndef DR_WAVES
+#define DR_WAVES 4                                         // waves per SIMD the kernel is compiled for (two 10-wave workgroups with half the
+                                                           // staging buffer each -- 5 per SIMD, 96 registers -- measured 19.5 ms against 14.2)
+#endif
+#ifndef DR_WG_PER_CU
+#define DR_WG_PER_CU 1
+#endif
 #define DR_NWAVE (DR_BLOCK / 64)
 #define DR_WIN   448                                       // words per wave: a pass's bits (<= RUN_PASSBITS, the encoder saw to it) + slack
 #define DR_MAXPIECE 65534u                                 // positions of a pass whose places (+ 1) still fit 16 bits beside the symbol
@@ -1140,7 +1152,7 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 #ifndef DR_FAST
 #define DR_FAST  1                                         // the sound pass without a bit buffer (see the kernel)
 #endif
-#define DR_STRETCH (RUN_STRETCH / 4)                       // words per wave for a pass's piece of the line (the encoder saw to it that it fits)
+#define DR_STRETCH (DR_POS / 4)                       // words per wave for a pass's piece of the line (the encoder saw to it that it fits)
 
 // where a run-coded line of an entry is, and whether its share of the index is one the entry can have
 struct dr_line { const uint8_t *seg; const uint32_t *g16; uint32_t sbytes, cnt; bool ok; };
@@ -1159,7 +1171,7 @@ __device__ __forceinline__ dr_line dr_line_of(const dec_args &a, const dr_entry 
 }
 
 template <int NK>                                          // run-coded kinds in the launch: 1 or 2 (del, sub)
-__global__ __launch_bounds__(DR_BLOCK)
+__global__ __launch_bounds__(DR_BLOCK, DR_WAVES)
 void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *status, uint32_t *next_task,
                       uint32_t kinds, const uint32_t *sub_idx, const uint64_t *sub_off)
 { __shared__ uint16_t s_tab[2 * NK][DP_SIZE];              // per kind: symbols, runs (8 KB each)
@@ -1402,8 +1414,8 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
               }
             const uint32_t Wtag = ((tg0 << 24) | (tg1 << 16) | (tg2 << 8)) << (2u * ((k0 + first) & 3u));   // this lane's tag codes, first one on top
             if (staged)
-              for (uint32_t w = 0; w < tp; w += RUN_STRETCH)
-                { const uint32_t wl = tp - w < RUN_STRETCH ? tp - w : RUN_STRETCH;
+              for (uint32_t w = 0; w < tp; w += DR_POS)
+                { const uint32_t wl = tp - w < DR_POS ? tp - w : DR_POS;
                   uint8_t *const s8 = (uint8_t *) stretch;
                   if (!(DR_SKIP & 8))
                     { const u32x4 v = { pat, pat, pat, pat };
@@ -1672,7 +1684,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
               hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, a.rec_off, a.rec_off + n, (const uint32_t *) NULL, n,
                                  DEC_TICKET * 14000u, DEC_TICKET, d_next4);
               uint64_t rb = (n + DR_NWAVE - 1) / DR_NWAVE;
-              if (rb > cap) rb = cap;
+              if (rb > cap * DR_WG_PER_CU) rb = cap * DR_WG_PER_CU;
               if (runs == 9u)
                 DX_LAUNCH(ctx, DX_K_QV_DEC_RUNS, k_qv_decode_runs<2>, (int) rb, DR_BLOCK, a, (const uint16_t *) ctx->d_dec,
                           (const uint32_t *) ctx->d_long, ctx->d_status, d_next4, runs, (const uint32_t *) ctx->sx.idx,
