@@ -198,7 +198,18 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # (gloo announces its connections on the C-level stdout -- "[Gloo] Rank 0 is connected to ..." --: stdout is for the
+        #  ONE JSON line, so while the group forms, file descriptor 1 is pointed at stderr)
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     if os.environ.get("DEXGPU_BENCH_ONE_DEVICE"):      # (testing the N > 1 path on a one-GPU box: every rank on device 0)
         local = 0
     torch.cuda.set_device(local)
