@@ -1345,6 +1345,12 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __builtin_amdgcn_s_waitcnt(0);
               }
+            else if (!(DR_SKIP & 8))                       // the first stretch of the piece as run characters: under way while the tokens are decoded
+              { const uint32_t wl0 = tp < DR_POS ? tp : DR_POS;
+                const u32x4 v = { pat, pat, pat, pat };
+                for (uint32_t i = (uint32_t) lane; i < (wl0 + 15u) >> 4; i += 64)
+                  ((u32x4 *) stretch)[i] = v;
+              }
             wave_sync();
             // Tokens first, bytes afterwards: every lane works out where its <= 8 symbols go (one past the place | symbol << 16)
             // and only then are they put into the piece, RUN_STRETCH positions at a time.
@@ -1417,12 +1423,14 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
               for (uint32_t w = 0; w < tp; w += DR_POS)
                 { const uint32_t wl = tp - w < DR_POS ? tp - w : DR_POS;
                   uint8_t *const s8 = (uint8_t *) stretch;
-                  if (!(DR_SKIP & 8))
-                    { const u32x4 v = { pat, pat, pat, pat };
-                      for (uint32_t i = (uint32_t) lane; i < (wl + 15u) >> 4; i += 64)    // this stretch of the line: run characters
-                        ((u32x4 *) stretch)[i] = v;
+                  if (w)                                       // (the first stretch was filled before the tokens were decoded)
+                    { if (!(DR_SKIP & 8))
+                        { const u32x4 v = { pat, pat, pat, pat };
+                          for (uint32_t i = (uint32_t) lane; i < (wl + 15u) >> 4; i += 64)    // this stretch of the line: run characters
+                            ((u32x4 *) stretch)[i] = v;
+                        }
+                      wave_sync();
                     }
-                  wave_sync();
                   #pragma unroll
                   for (uint32_t k = 0; k < 8; k++)
                     { const uint32_t pl = (posk[k] & 0xffffu) - 1u - w;                  // (no token: a huge number)
