@@ -37,6 +37,18 @@ struct dec_args
   int             flip;         // words were written by a host of the other endianness (GETFLIP, QV.c:553-568)
 };
 
+// A code that is in no table -- a corrupt stream, or a line whose scheme holds a single symbol (its code has no bits:
+// the reference writes such a file and its own undexqv then stops with "Could not read more bits (Decode)") -- cannot be
+// decoded.  The readers keep moving (one bit) so that every loop ends, and leave a mark: one LDS word per workgroup,
+// raised into the status word when the workgroup is done (DEC_ST_NOCODE), so that dx_qv_decode fails like the reference.
+#define DEC_ST_NOCODE 16u
+__shared__ uint32_t s_nocode;
+__device__ __forceinline__ void nocode_begin() { if (threadIdx.x == 0) s_nocode = 0u; }             // (in front of the kernel's first barrier)
+__device__ __forceinline__ void nocode_end(uint32_t *status)
+{ __syncthreads();
+  if (threadIdx.x == 0 && s_nocode) atomicOr(status, DEC_ST_NOCODE);
+}
+
 // MSB-first bit reader over little-endian 32-bit words; never reads past `end`.
 //
 // A wave waits on ALL of its outstanding global loads at once (one vmcnt per wave), so a lane that
@@ -135,6 +147,10 @@ __device__ __forceinline__ uint32_t dec_symbol_nofill(bitrd &r, const uint16_t *
             { e = (l << 8) | (t & 0xffu);
               break;
             }
+        }
+      if ((e >> 8) == 0)                                   // no such code (see DEC_ST_NOCODE): keep moving, leave a mark
+        { e |= 0x100u;
+          s_nocode = 1u;
         }
     }
   br_skip(r, (int) (e >> 8));
@@ -254,6 +270,7 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
   __shared__ __attribute__((aligned(8))) uint32_t s_ring[DEC_BLOCK][DEC_RING_STRIDE]; // 72 KB
   if (skip_idx != NULL && (kinds & ~skip_kinds) == 0u && *none_count == 0u)
     return;                                                // every line of this launch had its index: nothing left
+  nocode_begin();
   for (int k = threadIdx.x; k < 6 * DX_DEC_SIZE; k += DEC_BLOCK)          (&s_dec[0][0])[k]  = g_dec[k];
   for (int k = threadIdx.x; k < 6 * (1 + DX_LONG_MAX); k += DEC_BLOCK)    (&s_long[0][0])[k] = g_long[k];
   __syncthreads();
@@ -386,6 +403,7 @@ void k_qv_decode(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint
       if (bad) atomicOr(status, 4u);
       }
     }
+  nocode_end(status);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,7 +532,7 @@ __device__ __forceinline__ uint32_t lr_symbol(linerd &r, const uint16_t *tab, co
               break;
             }
         }
-      if (len == 0) len = 1;                               // no such code (corrupt stream): keep moving
+      if (len == 0) { len = 1; s_nocode = 1u; }            // no such code (see DEC_ST_NOCODE): keep moving, leave a mark
     }
   r.hi  = __builtin_amdgcn_alignbit(r.hi, r.lo, 32u - len);
   r.lo <<= len;
@@ -582,10 +600,12 @@ __device__ __forceinline__ void dp_build_tables(uint16_t (*s_tab)[DP_SIZE], uint
 }
 
 __global__ __launch_bounds__(DP_BLOCK)
-void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds)
+void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds,
+                       uint32_t *status)
 { __shared__ uint16_t s_tab[4][DP_SIZE];                   // 32 KB: 32 - len | symbol << 8 (low bits 0: longer than DP_BITS)
   __shared__ uint32_t s_long[4][1 + DX_LONG_MAX];          //  4 KB
   __shared__ uint32_t s_ring[DP_BLOCK][DP_STRIDE];         // 100 KB
+  nocode_begin();
   dp_build_tables(s_tab, s_long, g_dec, g_long);
 
   const uint64_t ngroup = (a.n + 63) / 64;
@@ -654,6 +674,7 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
           out[L] = '\n';
         }
     }
+  nocode_end(status);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -768,7 +789,7 @@ __device__ __forceinline__ uint32_t wr_symbol(winrd &r, const uint16_t *tab, con
               break;
             }
         }
-      if (len == 0) len = 1;                               // no such code (corrupt stream): keep moving
+      if (len == 0) { len = 1; s_nocode = 1u; }            // no such code (see DEC_ST_NOCODE): keep moving, leave a mark
     }
   r.hi  = __builtin_amdgcn_alignbit(r.hi, r.lo, 32u - len);
   r.lo <<= len;
@@ -909,11 +930,12 @@ __device__ __forceinline__ ds_line ds_line_of(const dec_args &a, const dr_entry 
 template <int NK>
 __global__ __launch_bounds__(DS_BLOCK, NK <= 2 ? DS_WG_PER_CU : 3)
 void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds,
-                     const uint32_t *sub_idx, const uint64_t *sub_off)
+                     const uint32_t *sub_idx, const uint64_t *sub_off, uint32_t *status)
 { __shared__ uint16_t s_tab[NK][DP_SIZE];                  // 8 KB each
   __shared__ uint32_t s_long[NK][1 + DX_LONG_MAX];         // 1 KB each
   __shared__ uint32_t s_win[DS_NWAVE][DS_WIN];             // 60 KB
   // tables of the kinds present, in the order of their bits (dp_build_tables for a subset)
+  nocode_begin();
   { int slot_of[4], nk = 0;
     for (int q = 0; q < 4; q++) slot_of[q] = ((kinds >> q) & 1u) ? nk++ : -1;
     for (int q = 0; q < 4; q++)
@@ -1114,6 +1136,7 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
         out[L] = '\n';
       }
     }
+  nocode_end(status);
 }
 #undef DS_ASK
 
@@ -1178,6 +1201,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
   __shared__ uint32_t s_long[2 * NK][1 + DX_LONG_MAX];
   __shared__ uint32_t s_win[DR_NWAVE][DR_WIN];             // 52 KB; [0] is a lead word (the positioned reads look one word back)
   __shared__ __attribute__((aligned(16))) uint32_t s_str[DR_NWAVE][DR_STRETCH];       // (see DR_BLOCK)
+  nocode_begin();
   { int nk = 0;
     for (int q = 0; q < 4; q++)
       if ((kinds >> q) & 1u)
@@ -1514,6 +1538,7 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
           DR_HEADV(hv_nx, nx)
         }
     }
+  nocode_end(status);
 }
 
 // Tag line of each entry (QV.c:1437-1461): tag[p] = 'n' where del[p] is the run character, else
@@ -1674,7 +1699,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
 #define SUB_LAUNCH(NK)                                                                                        \
           DX_LAUNCH(ctx, DX_K_QV_DEC_SUB, k_qv_decode_sub<NK>, (int) sb, DS_BLOCK, a, (const uint16_t *) ctx->d_dec,   \
                     (const uint32_t *) ctx->d_long, d_next3, plain, (const uint32_t *) ctx->sx.idx,            \
-                    (const uint64_t *) (ctx->sx.off + first))
+                    (const uint64_t *) (ctx->sx.off + first), ctx->d_status)
           if (nk == 1)      SUB_LAUNCH(1);
           else if (nk == 2) SUB_LAUNCH(2);
           else if (nk == 3) SUB_LAUNCH(3);
@@ -1709,7 +1734,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
     { uint64_t pb = (4 * ((n + 63) / 64) + DP_NWAVE - 1) / DP_NWAVE;
       if (pb > cap * DP_WG_PER_CU) pb = cap * DP_WG_PER_CU;
       DX_LAUNCH(ctx, DX_K_QV_DEC_PLAIN, k_qv_decode_plain, (int) pb, DP_BLOCK, a, (const uint16_t *) ctx->d_dec,
-                (const uint32_t *) ctx->d_long, d_next2, plain);
+                (const uint32_t *) ctx->d_long, d_next2, plain, ctx->d_status);
     }
   if (plain_kinds != 15u)
     DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,
@@ -1723,5 +1748,8 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (st & 4u)
     return dx_fail(ctx, DX_E_FORMAT, "dx_qv_decode: a run overruns its entry (corrupt stream or wrong index)");
+  if (st & DEC_ST_NOCODE)
+    return dx_fail(ctx, DX_E_FORMAT, "dx_qv_decode: a code that is in no table (a corrupt stream, or a line whose scheme holds a single "
+                                     "symbol, which has no bits: the reference stops with \"Could not read more bits (Decode)\")");
   return DX_OK;
 }

@@ -602,6 +602,76 @@ def _quiva(ents, movie=b"m7"):
     return b"".join(out)
 
 
+SINGLE_SYMBOL_QUIVA = b"""@m000_000/1/1588_1590 RQ=0.797
+&2
+CN
+%#
+"E
+??
+@m000_000/22/4851_4865 RQ=0.777
+$22,22222.%22)
+CNNGNNNNNTCNNA
+""%!""%#!!1$"!
++"!6219,(17(91
+??????????????
+@m000_000/54/1742_1747 RQ=0.774
+"22)2
+ANNAN
+""#"#
+?J*,.
+?????
+"""
+
+
+@pytest.mark.parametrize("index", [False, True], ids=["walk", "walk_indexed"])
+def test_a_line_of_one_symbol_is_written_like_the_reference_and_refused_like_it(ctx, tmp_path, index, monkeypatch):
+    """A file too short for a substitution run character whose substitution lines hold one value only: the Huffman tree
+    of that stream is a single leaf, its code has no bits (QV.c:136-147).  The reference writes the file -- and its own
+    undexqv then stops with "Could not read more bits (Decode)", exit 1.  Same bytes here, and a loud refusal instead of
+    a text of zeros (found by tools/stress_decode.py)."""
+    if index:
+        monkeypatch.setenv("DEXGPU_WALK_INDEX", "1")
+    dx = ctx.dexqv(SINGLE_SYMBOL_QUIVA)
+    assert dx == O.dexqv(SINGLE_SYMBOL_QUIVA)
+    if O.have_ref():
+        assert dx == O.run_ref("dexqv", [], SINGLE_SYMBOL_QUIVA, ".quiva", ".dexqv", tmp_path)
+        with pytest.raises(RuntimeError) as e:
+            O.run_ref("undexqv", [], dx, ".dexqv", ".quiva", tmp_path)
+        assert "Could not read more bits" in str(e.value)
+    with pytest.raises(L.DexGPUError) as e:                          # (the host walk of the records stops at the first such code)
+        ctx.undexqv(dx, upper=True)
+    assert e.value.code == -3                                        # DX_E_FORMAT
+    # the same stream decoded on the device with the encoder's own record boundaries: no walk in front of it, the kernels
+    # themselves must notice (they used to return a text with zeros in it)
+    lens = np.array([2, 14, 5], np.uint32)
+    offs, at = [], 0
+    for ln in SINGLE_SYMBOL_QUIVA.split(b"@")[1:]:
+        h = ln.index(b"\n") + 2
+        offs.append(at + h)
+        at += len(ln) + 1
+    d_text = ctx.to_device(np.frombuffer(SINGLE_SYMBOL_QUIVA, np.uint8))
+    d_off, d_len = ctx.to_device(np.array(offs, np.uint64)), ctx.to_device(lens)
+    b = ctx.qv_batch(d_text, d_off, d_len, 3, text_bytes=len(SINGLE_SYMBOL_QUIVA))
+    p = ctx.qv_prescan(b)
+    hist, tot = ctx.qv_hist(b, p)
+    coding = api.qv_build(hist, tot, p, False)
+    ctx.qv_set_coding(coding, False)
+    d_hoff = ctx.to_device(np.zeros(4, np.uint64))
+    d_hdr = ctx.alloc(16)
+    d_rec, d_seg, d_out = ctx.alloc(8 * 4), ctx.alloc(20 * 3), ctx.alloc(1 << 16)
+    ctx.qv_subindex(index)
+    try:
+        ctx.qv_encode_onepass(b, d_hdr, d_hoff, d_seg, d_rec, d_out, 1 << 16)
+        d_back = ctx.to_device(np.zeros(len(SINGLE_SYMBOL_QUIVA), np.uint8))
+        with pytest.raises(L.DexGPUError) as e:
+            ctx.qv_decode(d_out, d_rec, d_hoff, d_seg, d_len, 3, True, d_back, d_off)
+        assert e.value.code == -3 and "in no table" in str(e.value)
+    finally:
+        ctx.qv_subindex(False)
+    c = synth.make_quiva(20, seed=3, mean=500)                      # (the context is as good as before)
+    assert ctx.undexqv(ctx.dexqv(c.text), upper=True) == c.text
+
+
 def test_dexqv_zero_length_entries(ctx):
     """Entries with no symbols at all (five empty lines) between normal ones."""
     prof = synth.pacbio_profile()
