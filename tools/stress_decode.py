@@ -11,8 +11,9 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = refused = 0
 with api.Context(0) as ctx:
     for it in range(rounds):
-        n = int(rng.choice([1, 2, 3, 5, 8, 17, 40, 130, 400]))
-        shape = rng.choice(["short", "mixed", "long", "tiny", "zeros"])
+        big = bool(os.environ.get("STRESS_BIG"))                    # thousands of entries: many units per ticket, every wave busy
+        n = int(rng.choice([3000, 7000, 12000])) if big else int(rng.choice([1, 2, 3, 5, 8, 17, 40, 130, 400]))
+        shape = rng.choice(["short", "tiny", "zeros"]) if big else rng.choice(["short", "mixed", "long", "tiny", "zeros"])
         if shape == "short":   lens = rng.integers(0, 600, n)
         elif shape == "mixed": lens = np.where(rng.random(n) < 0.3, rng.integers(0, 40, n), rng.integers(500, 30000, n))
         elif shape == "long":  lens = rng.integers(20000, 90000, n)
