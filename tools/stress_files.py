@@ -76,6 +76,16 @@ with api.Context(0) as ctx:
                 w = int(rng.choice([1, 7, 15, 16, 17, 60, 80, 100, 1000]))
                 both(tag2 + f" unpack w={w}", (lambda: ctx.undexar(px, w)) if arrow else (lambda: ctx.undexta(px, False, w)),
                      (lambda: O.undexar(px, w)) if arrow else (lambda: O.undexta(px, False, w)))
+        if os.environ.get("STRESS_SHARDS") and it % 3 == 0:          # the same through 2 .. 4 contexts of this device (entry / read ranges)
+            k = int(rng.integers(2, 5))
+            ctxs = [ctx] + [api.Context(0) for _ in range(k - 1)]
+            try:
+                both(tag + f" dexqv over {k} contexts", lambda: api.dexqv_sharded(ctxs, c.text, lossy), lambda: O.dexqv(c.text, lossy), c.text)
+                t = synth.make_seqfile("fasta", n, seed=seed, lens=lens, width=80)
+                both(f"round {it} fasta over {k} contexts", lambda: api.pack2_sharded(ctxs, t.text), lambda: O.dexta(t.text))
+            finally:
+                for x in ctxs[1:]:
+                    x.close()
         if it % 10 == 9:
             print(f"{it + 1} rounds, {bad} mismatches, {agree_refusals} refused by both", flush=True)
 print("stress_files:", "OK" if bad == 0 else f"{bad} MISMATCHES")
