@@ -203,7 +203,9 @@ static void report_text_error(int tool, uint64_t line, int code)
     switch (code)
       { case DX_IDX_TOO_LONG:
         case DX_IDX_NO_NEWLINE:
-        case DX_IDX_EMPTY:     fprintf(stderr, "Line %llu: %s line is too long (> %d chars)\n", (unsigned long long) line, t->what, 99998); break;   /* dexta.c:110,168 */
+        case DX_IDX_EMPTY:     fprintf(stderr, "Line %llu: %s line is too long (> %d chars)\n", (unsigned long long) line,
+                                       tool == TOOL_DEXAR && line != 1 ? "Fasta" : t->what, 99998); break;   /* dexta.c:110,168; dexar.c says "Arrow" for line 1
+                                                                                                                 (dexar.c:109) and "Fasta" for every other (dexar.c:175) */
         case DX_IDX_NO_HEADER: fprintf(stderr, "Line 1: First header in %s file is missing\n", tool == TOOL_DEXTA ? "fasta" : "arrow"); break;   /* dexta.c:114 */
         default:               fprintf(stderr, "%s: Header line incorrectly formatted ?\n", Prog); break;                                        /* dexta.c:120,148,154 */
       }

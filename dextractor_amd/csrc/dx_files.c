@@ -60,6 +60,16 @@ static void dfree_all(dpool *pool)
 /* ==========================================================================================
  *  dexta / dexar
  * ========================================================================================== */
+
+/* A header line with the end of the file right behind it is an error for the reference unless it is the file's only line
+   (dx_index_seq has the story): such a text goes to the host index, which knows; the device front end takes the empty read. */
+static int ends_with_a_header(const uint8_t *text, size_t n)
+{ size_t at;
+  if (n < 2 || text[n - 1] != '\n') return 0;
+  for (at = n - 1; at > 0 && text[at - 1] != '\n'; at--) ;
+  return at > 0 && text[at] == '>';
+}
+
 int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
                   uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
 { dpool     pool = { {0}, 0, ctx };
@@ -78,7 +88,7 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
   /* index: on the GPU for large images (newline scan, record extents there; only header lines come
      back), on the host for small ones and for anything the GPU front end rejects (exact message) */
   if (n > 0) TRY(dupload(&pool, text, n, &d_text));
-  if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL)
+  if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL && !ends_with_a_header(text, n))
     { uint64_t *go = NULL; uint32_t *gt = NULL, *gs = NULL;
       rc = dx_index_seq_device(ctx, arrow, d_text, n, &go, &gt, &gs, &cnt, &hdr4, &cnr4, &plen, errline, errcode);
       if (rc == DX_OK)

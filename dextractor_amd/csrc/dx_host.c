@@ -430,8 +430,12 @@ static int get_line(tsrc *t, const uint8_t **s, size_t *len)
     return 0;
   t->line += 1;
   nl = memchr(t->p + t->at, '\n', t->n - t->at);
-  if (nl == NULL)
-    return -1;
+  if (nl == NULL)                                        /* the text's last line, unterminated: all of it */
+    { *s   = t->p + t->at;
+      *len = t->n - t->at;
+      t->at = t->n;
+      return -1;
+    }
   *s   = t->p + t->at;
   *len = (size_t) (nl - *s);
   t->at += *len + 1;
@@ -496,7 +500,15 @@ int dx_index_quiva(const uint8_t *text, size_t n, uint64_t cap,
       for (j = 0; j < 5; j++)                             /* QV.c:973-978, 785-796 */
         { r = get_line(&t, &s, &sl);
           if (r == 0) return idx_fail(t.line + 1, DX_IDX_INCOMPLETE, errline, errcode);
-          if (r < 0) return idx_fail(t.line, DX_IDX_NO_NEWLINE, errline, errcode);
+          if (r < 0)                                      /* the file's last line has no newline.  The reference grows its buffer
+                                                             only for an entry's FIRST line and says so (QV.c:771-781); lines 2-5 it
+                                                             reads with fgets and compares strlen -- newline included -- with the first
+                                                             line's (QV.c:786-795): one character more than the others passes (the
+                                                             last character stands where the newline would), anything else is ragged */
+            { if (j == 0) return idx_fail(t.line, DX_IDX_NO_NEWLINE, errline, errcode);
+              if (sl != first + 1) return idx_fail(t.line, DX_IDX_RAGGED, errline, errcode);
+              sl = first;
+            }
           if (j == 0)
             { first = sl;
               if (off != NULL && k < cap) off[k] = (uint64_t) (s - text);
@@ -560,6 +572,12 @@ int dx_index_seq(int arrow, const uint8_t *text, size_t n, uint64_t cap,
       end   = t.at;
       for (;;)
         { r = get_line(&t, &s, &sl);
+          if (r == 0 && k > 0 && t.at == start)           /* a header -- not the file's first -- with the end of the file right behind
+                                                             it: the reference's fgets leaves its buffer as the header's parse left it,
+                                                             finds no newline where it looks for one and says the NEXT line is too
+                                                             long (dexta.c:163-172; a file of one header alone passes, as do empty
+                                                             lines behind the header: checked against the binaries, tools/stress_cli.py) */
+            return idx_fail(t.line + 1, DX_IDX_TOO_LONG, errline, errcode);
           if (r == 0) break;
           if (r < 0 || sl + 1 >= DX_LINE_LIMIT) return idx_fail(t.line, DX_IDX_TOO_LONG, errline, errcode);
           if (sl > 0 && s[0] == '>')

@@ -159,7 +159,11 @@ extern "C" int dx_index_quiva_device(dx_ctx *ctx, const uint8_t *d_text, uint64_
   CK(dx_scan_u32(ctx, d_cnt, ntiles, d_toff, &nl));
   CKH(hipMemcpyAsync(&last, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, ctx->stream));
   CKH(hipStreamSynchronize(ctx->stream));
-  if (last != '\n') FMT(nl + 1, DX_IDX_NO_NEWLINE);                 // QV.c:771-781
+  // The last line without a newline: a header or an entry's first line, "Last line does not end with a newline" (QV.c:771-781);
+  // one of its lines 2-5, "not the same length" (QV.c:792: strlen, newline included, against the first line's) -- unless it is
+  // ONE character longer than the others, which the reference takes: the host index (dx_index_quiva), which the file driver
+  // asks after any refusal here, has that case.
+  if (last != '\n') FMT(nl + 1, nl % 6 >= 2 ? DX_IDX_RAGGED : DX_IDX_NO_NEWLINE);
   CKH(hipMalloc((void **) &d_line, (nl + 2) * 8));
   dx_prof_begin(ctx, DX_K_INDEX);
   hipLaunchKernelGGL(k_nl_fill, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream,

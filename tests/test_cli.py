@@ -105,6 +105,11 @@ def test_cli_pipe_mode_and_verbose(tmp_path):
     ("dexta", ".fasta", b"m/1/0_3 RQ=0.8\nACG\n"),
     ("dexta", ".fasta", b">m 1 0_3 RQ=0.8\nACG\n"),
     ("dexar", ".arrow", b">m/1/0_3 SN=1.0,2.0\n123\n"),
+    ("dexqv", ".quiva", b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc"),              # no newline behind an entry's LAST line: "not the same length"
+    ("dexqv", ".quiva", b"@m/1/0_3 RQ=0.8\nabc"),                                  # ... behind its first line: "Last line does not end ..."
+    ("dexar", ".arrow", b">m/1/0_3 SN=1.00,2.00,3.00,4.00\n123\n>m/2/0_3 SN=1.00,2.00,3.00,4.00\n12"),   # dexar's "Fasta line is too long"
+    ("dexta", ".fasta", b">m/1/0_3 RQ=0.8\nACG\n>m/2/0_3 RQ=0.8\n"),               # a later header with the end of the file behind it
+    ("dexar", ".arrow", b">m/1/0_3 SN=1.00,2.00,3.00,4.00\n123\n>m/2/0_3 SN=1.00,2.00,3.00,4.00\n"),
     ("undexta", ".dexta", b"\x01\x02\x03\x04\x05\x06"),
     ("undexar", ".dexar", b"\xcc\x33\x03\x04\x05\x06"),
 ])

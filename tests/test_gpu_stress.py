@@ -4,7 +4,9 @@ tools/stress_files.py   the six file drivers against the oracle (lengths 0 .. 90
                         line widths 1 .. 1000): identical bytes, identical refusals
 tools/stress_decode.py  encode with the group index -> decode on the device, whole batches and random contiguous parts:
                         the text that went in, nothing written outside the part
-Both found what the hand-made cases had not: files with a stream of ONE symbol (its Huffman code has no bits), which the
+tools/stress_cli.py     malformed text inputs through the packing tools and the reference's own binaries: exit code, message, output
+                        (found: the message for a last line without a newline, dexar's "Fasta line", a header with the file's end behind it)
+The first two found what the hand-made cases had not: files with a stream of ONE symbol (its Huffman code has no bits), which the
 reference writes and cannot read back -- dx_qv_decode used to return a text with zeros in it and now refuses them."""
 import os
 import subprocess
@@ -16,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,rounds,seed", [("stress_files.py", 60, 5), ("stress_decode.py", 80, 11)])
+@pytest.mark.parametrize("tool,rounds,seed", [("stress_files.py", 60, 5), ("stress_decode.py", 80, 11), ("stress_cli.py", 40, 3)])
 def test_random_shapes(tool, rounds, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(rounds), str(seed)], capture_output=True, timeout=600)
     assert r.returncode == 0, (r.stdout.decode()[-2000:], r.stderr.decode()[-2000:])

@@ -138,7 +138,11 @@ def test_index_quiva_matches_generator():
 
 
 @pytest.mark.parametrize("bad,code", [
-    (b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc", 1),            # no final newline
+    (b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc", 5),            # no final newline after an entry's LAST line: the reference reads lines 2-5
+                                                                    # with fgets and compares strlen, newline included (QV.c:786-795): "not the same
+                                                                    # length" (found against the real binary by tools/stress_cli.py; this said 1 before)
+    (b"@m/1/0_3 RQ=0.8\nabc", 1),                                    # ... after an entry's FIRST line: "Last line does not end with a newline" (QV.c:779)
+    (b"@m/1/0_3 RQ=0.8", 1),                                         # ... after a header line: the same
     (b"m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n", 2),           # header missing
     (b"@m 1 0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabc\n", 3),          # no slash
     (b"@m/1/0_3\nabc\nabc\nabc\nabc\nabc\n", 3),                 # RQ field required (QV.c:964)
@@ -152,6 +156,18 @@ def test_index_quiva_rejects(bad, code):
     assert rc == -3 and ec.value == code
     with pytest.raises(ValueError):
         O.dexqv(bad)                                               # the oracle rejects it too
+
+
+def test_index_quiva_takes_a_last_line_one_character_longer_like_the_reference():
+    """An unterminated last line with ONE character more than the entry's other lines has the strlen the reference compares
+    (QV.c:792): it passes, its last character standing where the newline would."""
+    lib = L.load()
+    good = b"@m/1/0_3 RQ=0.8\nabc\nabc\nabc\nabc\nabcd"
+    off, ln = (C.c_uint64 * 1)(), (C.c_uint32 * 1)()
+    hdr = (C.c_int32 * 4)()
+    cnt, pl, line, ec = C.c_uint64(), C.c_size_t(), C.c_uint64(), C.c_int()
+    rc = lib.dx_index_quiva(good, len(good), 1, off, ln, hdr, C.byref(cnt), C.byref(pl), C.byref(line), C.byref(ec))
+    assert rc == 0 and cnt.value == 1 and ln[0] == 3 and off[0] == 16
 
 
 @pytest.mark.parametrize("kind", ["fasta", "arrow"])
