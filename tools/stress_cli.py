@@ -60,6 +60,25 @@ for it in range(rounds):
         open(os.path.join(ROOT, "gpurun_out", "stress", "cli_%d%s" % (bad, ext)), "wb").write(data)
         print(f"MISMATCH round {it} {tool} edit={what}: mine rc={res[0][0]} {res[0][1][:120]!r} out={None if res[0][2] is None else len(res[0][2])} | "
               f"ref rc={res[1][0]} {res[1][1][:120]!r} out={None if res[1][2] is None else len(res[1][2])}", flush=True)
+    if it % 4 == 0:                                    # and the way back, with the unpacking tools' options, on the UNEDITED file
+        flags = {"quiva": [["-k"], ["-k", "-U"]], "fasta": [["-k"], ["-k", "-U"], ["-k", "-w%d" % int(rng.choice([1, 17, 60, 100, 9999]))]],
+                 "arrow": [["-k"], ["-k", "-w%d" % int(rng.choice([1, 17, 60, 100, 9999]))]]}[kind]
+        fl = flags[int(rng.integers(0, len(flags)))]
+        lossy = ["-l"] if kind == "quiva" and rng.random() < 0.3 else []
+        res = []
+        with tempfile.TemporaryDirectory() as d:
+            for sub, bdir in (("mine", BIN), ("ref", REF)):
+                dd = os.path.join(d, sub); os.mkdir(dd)
+                open(os.path.join(dd, "x" + ext), "wb").write(txt)
+                r1 = subprocess.run([os.path.join(bdir, tool), *lossy, "x"], cwd=dd, capture_output=True, timeout=120)       # (source removed: no -k)
+                r2 = subprocess.run([os.path.join(bdir, "un" + tool), *fl, "x"], cwd=dd, capture_output=True, timeout=120)
+                names = sorted(os.listdir(dd))
+                res.append((r1.returncode, r1.stderr, r2.returncode, r2.stderr, names,
+                            [open(os.path.join(dd, nm), "rb").read() for nm in names]))
+        if res[0] != res[1]:
+            bad += 1
+            print(f"MISMATCH round {it} {tool} {lossy} / un{tool} {fl}: mine rc={res[0][0]},{res[0][2]} {res[0][1][:80]!r} {res[0][3][:80]!r} files={res[0][4]} | "
+                  f"ref rc={res[1][0]},{res[1][2]} {res[1][1][:80]!r} {res[1][3][:80]!r} files={res[1][4]} same bytes: {res[0][5] == res[1][5]}", flush=True)
     if it % 20 == 19:
         print(f"{it + 1} rounds, {bad} mismatches", flush=True)
 print("stress_cli:", "OK" if bad == 0 else f"{bad} MISMATCHES")
