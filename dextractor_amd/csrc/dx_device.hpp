@@ -74,6 +74,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
   return v;
 }
 
+// inclusive running maximum over the 64 lanes (values >= 0)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{ v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false));
+  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false));
+  return v;
+}
+
 __device__ __forceinline__ uint32_t wave_total(uint32_t incl)
 { return __builtin_amdgcn_readlane(incl, 63); }
 

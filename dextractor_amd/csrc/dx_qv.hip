@@ -283,13 +283,13 @@ void k_qv_prescan_sub(qv_args a, long long *out /* [0]=entry index or -1, [1]=su
 #define HC_PLAIN     32
 #endif
 #ifndef HC_RSYM
-#define HC_RSYM      32
+#define HC_RSYM      8
 #endif
 #ifndef HC_RUN
-#define HC_RUN       32
+#define HC_RUN       8
 #endif
 #define HSYM_FAST    128
-#define HRUN_FAST    64
+#define HRUN_FAST    128                 // runs 0..126, and 127 for every longer one until hist_runs_step has looked again
 #ifndef HIST_BARE_FETCH
 #define HIST_BARE_FETCH 1
 #endif
@@ -370,95 +370,189 @@ __device__ __forceinline__ uint32_t tok_exception(const uint32_t *slot_end, uint
 __device__ __forceinline__ bool tok_unusable(const uint32_t *info, uint64_t r, int delChar, int subChar)
 { return (delChar >= 0 && (info[TOK_INFO * r] & TOK_BAD)) || (subChar >= 0 && (info[TOK_INFO * r + 1] & TOK_BAD)); }
 
-// one step of a run-coded stream: non-run symbols and the run before each (QV.c:709-724); the run
-// character itself is counted with popcounts instead of LDS atomics (it is 80-85 % of the stream).
-// `count`: the run histogram takes part (entries from del_first / sub_first on, QV.c:1003, 1016).
-// `tok` != NULL: the step's tokens are stored at tok[ntok ...] (tagchunk: this step's deletion tags).
-__device__ __forceinline__ void hist_runs_step(const run_lds &R, const u32x4 &c, int valid, uint32_t sv, uint32_t rc,
-                                               uint32_t &C, uint32_t &nrun, uint32_t (*hs)[HC_RSYM], uint32_t *slow_s,
-                                               uint32_t (*hr)[HC_RUN], uint32_t *slow_r, bool count,
-                                               uint16_t *tok, uint32_t &ntok, uint32_t cap, uint32_t &bad, uint32_t &nexc,
-                                               const uint8_t *tagchunk, const uint8_t *tagcode)
-{ const int      lane  = lane_id();
-  const uint32_t cols  = (uint32_t) lane & (HC_RSYM - 1), colr = (uint32_t) lane & (HC_RUN - 1);
-  const uint32_t total = run_collect(R, c, valid, rc);
+// 16-bit mask: bit b set iff byte b of the chunk differs from c.  Per word: the nonzero-byte flags of w ^ cccc at bits 7, 15,
+// 23, 31 (exact per byte: the add cannot carry out of a byte), lined up at bits 28..31 by one multiplication (the partial
+// products fall on distinct bits: 7 14 21 28 | 15 22 29 36 | 23 30 37 44 | 31 38 45 52), so the product's top byte is the
+// word's nibble << 4 over four zero bits; two byte permutes and a shift put the four nibbles side by side.
+__device__ __forceinline__ uint32_t chunk_ne_mask(const u32x4 &v, uint32_t c4 /* c * 0x01010101 */)
+{ uint32_t p[4];
+  #pragma unroll
+  for (int i = 0; i < 4; i++)
+    { const uint32_t w = chunk_word(v, i) ^ c4;
+      p[i] = ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u) * 0x00204081u;
+    }
+  const uint32_t even = __builtin_amdgcn_perm(p[2], p[0], 0x0c0c0703u);     // n0 << 4 | n2 << 12
+  const uint32_t odd  = __builtin_amdgcn_perm(p[3], p[1], 0x0c0c0703u);     // n1 << 4 | n3 << 12
+  return (even >> 4) | odd;
+}
+
+// byte b (0..15) of a chunk by three byte permutes, no compare and no select: selA = (b & 7) | 0x0c0c0c00 picks the byte
+// out of each half of the chunk (the other result bytes zero), selB = ((b >> 1) & 4) | 0x0c0c0c00 picks the half
+__device__ __forceinline__ uint32_t chunk_byte_sel(const u32x4 &v, uint32_t selA, uint32_t selB)
+{ return __builtin_amdgcn_perm(__builtin_amdgcn_perm(v.w, v.z, selA), __builtin_amdgcn_perm(v.y, v.x, selA), selB); }
+
+// the value of lane - 1 (lane 0: 0)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v)
+{ return (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true); }      // wave_shr:1
+
+// One step of a run-coded line: its non-run symbols and the run before each (QV.c:709-724); the run character itself is
+// counted with popcounts instead of LDS atomics (it is 80-85 % of the line).
+//
+// Every lane walks the non-run symbols of ITS OWN 16 bytes, everything in registers: the symbol (and the deletion tag
+// under it) by byte permutes of the chunk, the run in front of it as the distance to the lane's previous one -- for a
+// lane's first, to the end of the last token of any lane before it (an exclusive running maximum over the lanes, the run
+// open at the step's start folded in) -- one conflict-poor ds_add for the symbol, one for the run, the finished 16-bit
+// token into the wave's LDS list at the place a prefix sum of the lanes' counts gives it; the list then leaves in 8-byte
+// pieces.  No look-up hangs on another (round 3: position list -> symbol and tag -> tag code, three LDS round trips per
+// 128 tokens at four waves per SIMD; and 150 KB of LDS: chunk copies, position lists, 32 copies of every bin).
+//
+// The fast bins take symbol & 127 and min(run, 127); a step in which some token has a symbol >= 127 or a run >= 127
+// (never, in a .quiva file's printable QVs at usual run densities) is gone over once more: those tokens' counts move to
+// the 256-bin tables, their runs get exception records, a symbol >= 128 makes the entry's tokens unusable.
+// inc: 1 when the run histogram takes part (entries from del_first / sub_first on, QV.c:1003, 1016), else 0.
+// `tok` != NULL: the step's tokens are stored at tok[ntok ...] (t: this step's deletion tags where TAGS).
+// A step's tokens on their way out: lane l holds tokens 4 l .. 4 l + 3 of the n that belong at tok[at ...].  They are
+// stored at the head of the NEXT step, in front of its requests for chunks: a step ends with a wait for the chunks
+// requested at its head, vmcnt counts loads and stores alike, in order, and a store issued in the middle of the step is
+// far from complete at its end (k_qv_hist without the stores: - 1.5 ms of 12) -- issued at the head, it has the whole
+// step, like the chunks behind it.
+struct tok_pend { uint64_t v; uint32_t n, at; };
+
+__device__ __forceinline__ void tok_flush(tok_pend &p, uint16_t *tok)
+{ if (4u * (uint32_t) lane_id() < p.n)                           // (up to three slots past the last token are written too: inside
+    *(u64_u *) (tok + p.at + 4u * (uint32_t) lane_id()) = p.v;   //  TOK_XMARGIN, and the next step's tokens go over them)
+  p.n = 0;
+}
+
+// Number_Read's letter -> 2-bit code (DB.c:393-416: a c g t, either case; anything else 0) without a table: the letters
+// fold to 'A' + {0, 2, 6, 19}, and a 64-bit constant holds the code of 'A' + i at bits 2 i, 2 i + 1 for i < 32
+__device__ __forceinline__ uint32_t tag_code(uint32_t letter)
+{ const uint32_t i = min((letter & 0xdfu) - 0x41u, 31u);
+  return (uint32_t) (((1ull << 4) | (2ull << 12) | (3ull << 38)) >> (2u * i)) & 3u;
+}
+
+// LDS of one wave for the run-coded lines: a copy of the step's chunk and of its deletion tags (a lane reads back the
+// bytes under ITS OWN tokens: one address and two byte reads per token where picking byte b of a chunk in registers takes
+// nine byte permutes and masks) and the step's token list
+struct hist_wave_lds
+{ uint8_t  chunk[DX_STEP], tags[DX_STEP];
+  uint16_t list[DX_STEP];
+};
+
+template <bool TAGS>
+__device__ __forceinline__ void hist_runs_step(hist_wave_lds &W, const u32x4 &c, const u32x4 &t, uint32_t vmask, uint32_t sv, uint32_t rc4,
+                                               uint32_t &C, uint32_t &nrun, uint32_t *hs, uint32_t *slow_s,
+                                               uint32_t *hr, uint32_t *slow_r, uint32_t inc,
+                                               uint16_t *tok, uint32_t &ntok, uint32_t room, uint32_t &bad, uint32_t &nexc,
+                                               tok_pend &pend_out)
+{ const uint32_t lane  = (uint32_t) lane_id();
+  const uint32_t nr0   = chunk_ne_mask(c, rc4) & vmask;
+  const uint32_t cnt   = __popc(nr0);
+  const uint32_t incl  = wave_incl_scan(cnt);
+  const uint32_t total = wave_total(incl);
   nrun += sv - total;                                            // wave-uniform
-  bool emit = false;
-  if (tok != NULL && !bad)
-    { emit = ntok + total + 4u * nexc + TOK_XMARGIN <= cap;
-      if (!emit) bad = 1;                                        // more tokens (and exceptions) than the slot holds
+  *(u32x4 *) (W.chunk + 16u * lane) = c;
+  if (TAGS) *(u32x4 *) (W.tags + 16u * lane) = t;
+  // room: what the slot holds less TOK_XMARGIN (0: no tokens wanted)
+  const bool emit = !(HIST_SKIP & 8) && !bad && ntok + total + 4u * nexc <= room;
+  if (!emit) bad = 1;                                            // more tokens (and exceptions) than the slot holds
+  // where the last token of this lane ends (position + 1), the run open at the step's start added; 0: the lane has none
+  const uint32_t tend  = cnt ? 16u * lane + 32u - (uint32_t) __clz(nr0) + C : 0u;
+  const uint32_t imax  = wave_incl_max(tend);
+  const uint32_t gmax  = __builtin_amdgcn_readlane(imax, 63);
+  const uint32_t s0    = wave_shr1(imax) - (16u * lane + C);     // the run in front of the lane's token at byte b: b - s
+  const uint32_t li0   = incl - cnt;                             // the lane's first token in the step's list
+  uint32_t nr = (HIST_SKIP & 1) ? 0u : nr0, s = s0, acc = 0;
+  uint16_t      *lp = W.list + li0;
+  const uint8_t *cp = W.chunk + 16u * lane;
+  while (nr)
+    { const uint32_t b   = (uint32_t) __builtin_ctz(nr);
+      nr &= nr - 1u;
+      const uint32_t x   = cp[b];
+      const uint32_t tg  = TAGS ? cp[b + DX_STEP] : 0u;          // (both reads in front of the atomics: one wait for the two)
+      const uint32_t run = b - s;
+      const uint32_t r7  = run < TOK_RUN_MAX ? run : TOK_RUN_MAX;
+      s   = b + 1u;
+      acc = max(acc, max(run, x));
+      atomicAdd(&hs[(x & (HSYM_FAST - 1)) * HC_RSYM], 1u);
+      atomicAdd(&hr[r7 * HC_RUN], inc);
+      uint32_t tk = x | (r7 << 7);
+      if (TAGS) tk = (tk << 2) | tag_code(tg);
+      else      tk <<= 2;
+      *lp++ = (uint16_t) tk;
     }
   uint32_t odd = 0;
-  // Two tokens per lane per round (i and i + 64): the look-ups of a token hang on each other (position ->
-  // symbol and tag -> tag code), so the second token's chain runs in the shadow of the first one's.
-  if (HIST_SKIP & 8) emit = false;
-  for (uint32_t i0 = 0; i0 < ((HIST_SKIP & 1) ? 0u : total); i0 += 128u)
-    { uint32_t pos[2], x[2], run[2], tg[2];
-      bool     on[2];
-      #pragma unroll
-      for (int k = 0; k < 2; k++)
-        { const uint32_t i = i0 + 64u * k + (uint32_t) lane;
-          on[k]  = i < total;
-          pos[k] = on[k] ? (uint32_t) R.list[i] : 0u;
-          run[k] = on[k] && i ? (uint32_t) R.list[i - 1] + 1u : 0u - C;       // where the run in front of the token starts
-        }
-      #pragma unroll
-      for (int k = 0; k < 2; k++)
-        { x[k]   = R.chunk[pos[k]];
-          tg[k]  = tagchunk != NULL ? (uint32_t) tagchunk[pos[k]] : 0u;
-          run[k] = pos[k] - run[k];
-        }
-      if (emit && tagchunk != NULL)
-        {
-          #pragma unroll
-          for (int k = 0; k < 2; k++)
-            tg[k] = tagcode[tg[k]];
-        }
-      const bool fastbins = !__any((on[0] && (run[0] >= HRUN_FAST || x[0] >= HSYM_FAST)) ||
-                                   (on[1] && (run[1] >= HRUN_FAST || x[1] >= HSYM_FAST)));
-      #pragma unroll
-      for (int k = 0; k < 2; k++)
-        if (on[k])
-          { if (fastbins)                                            // the usual case, decided once for the wave
-              { if (count) atomicAdd(&hr[run[k]][colr], 1u);
-                atomicAdd(&hs[x[k]][cols], 1u);
-              }
-            else
-              { if (count)
-                  { if (run[k] < HRUN_FAST) atomicAdd(&hr[run[k]][colr], 1u);
-                    else                    atomicAdd(&slow_r[run[k] > 255u ? 255u : run[k]], 1u);   // QV.c:717-720
-                  }
-                if (x[k] < HSYM_FAST) atomicAdd(&hs[x[k]][cols], 1u);
-                else                  atomicAdd(&slow_s[x[k]], 1u);
-              }
-            if (emit)
-              { const uint32_t t = tg[k] | (x[k] << 2) | ((run[k] < TOK_RUN_MAX ? run[k] : TOK_RUN_MAX) << 9);
-                if (HIST_SKIP & 32) R.chunk[2u * (i0 + 64u * k + (uint32_t) lane) & 1023u] = (uint8_t) (t ^ (t >> 8));   // (experiment: the token made, not stored)
-                else tok[ntok + i0 + 64u * k + (uint32_t) lane] = (uint16_t) t;
-                odd |= x[k] >= 128u ? 1u : 0u;
-              }
-          }
-      if (emit && !fastbins && __any((on[0] && run[0] >= TOK_RUN_MAX) || (on[1] && run[1] >= TOK_RUN_MAX)))   // rare: exception records, in token order
-        { uint32_t *xend = (uint32_t *) (tok + cap);
-          #pragma unroll
-          for (int k = 0; k < 2; k++)
-            { const bool     lg = on[k] && run[k] >= TOK_RUN_MAX;
-              const uint64_t m  = __ballot(lg);
-              if (lg)
-                { const uint32_t j = nexc + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-                  *(xend - 2 * (int) j - 2) = ntok + i0 + 64u * (uint32_t) k + (uint32_t) lane;
-                  *(xend - 2 * (int) j - 1) = run[k];
-                }
-              nexc += (uint32_t) __popcll(m);
+  if (__any((int) (acc >= TOK_RUN_MAX)))                        // rare (see above): once more over the step
+    { uint32_t m = nr0, ne = 0;
+      s = s0;
+      while (m)
+        { const uint32_t b   = (uint32_t) __builtin_ctz(m);
+          m &= m - 1u;
+          const uint32_t x   = cp[b];
+          const uint32_t run = b - s;
+          s = b + 1u;
+          if (run >= TOK_RUN_MAX)
+            { atomicSub(&hr[TOK_RUN_MAX * HC_RUN], inc);
+              atomicAdd(&slow_r[run > 255u ? 255u : run], inc);                                   // QV.c:717-720
+              ne++;
             }
+          if (x >= HSYM_FAST)
+            { atomicSub(&hs[(x & (HSYM_FAST - 1)) * HC_RSYM], 1u);
+              atomicAdd(&slow_s[x], 1u);
+              odd = 1;
+            }
+        }
+      if (emit && __any((int) ne))                              // exception records, in token order
+        { const uint32_t ince = wave_incl_scan(ne);
+          uint32_t  j    = nexc + ince - ne, i = ntok + li0;
+          uint32_t *xend = (uint32_t *) (tok + room + TOK_XMARGIN);
+          m = nr0; s = s0;
+          while (m)
+            { const uint32_t b   = (uint32_t) __builtin_ctz(m);
+              m &= m - 1u;
+              const uint32_t run = b - s;
+              s = b + 1u;
+              if (run >= TOK_RUN_MAX)
+                { *(xend - 2 * (int) j - 2) = i;
+                  *(xend - 2 * (int) j - 1) = run;
+                  j++;
+                }
+              i++;
+            }
+          nexc += wave_total(ince);
         }
     }
   if (emit)
-    { ntok += total;
+    { __builtin_amdgcn_wave_barrier();                           // the list is complete: a wave's LDS instructions execute in order,
+      if (HIST_SKIP & 32) { }                                    //   only the compiler has to be kept from moving them
+      else if (total <= 256u)
+        { pend_out.v = *(const uint64_t *) (W.list + 4u * lane); pend_out.n = total; pend_out.at = ntok; }
+      else                                                       // (more than a quarter of the step's symbols: straight out)
+        for (uint32_t i = 4u * lane; i < total; i += 256u)
+          *(u64_u *) (tok + ntok + i) = *(const uint64_t *) (W.list + i);
+      ntok += total;
       if (__any((int) odd)) bad = 1;
     }
-  C = run_after(R, total, sv, C);
-  wave_sync();
+  C = sv + C - gmax;                                             // total ? sv - (end of the last token) : C + sv
+  __builtin_amdgcn_wave_barrier();
+}
+
+// the two lines that are always plain (ins, mrg), one test of "a whole step and no byte >= 128" for both
+__device__ __forceinline__ void hist_plain_pair(const u32x4 &c2, const u32x4 &c3, int valid, bool full, hist_lds &H)
+{ const uint32_t col = (uint32_t) lane_id() & (HC_PLAIN - 1);
+  if (full && !__any((int) ((c2.x | c2.y | c2.z | c2.w | c3.x | c3.y | c3.z | c3.w) & 0x80808080u)))
+    {
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        atomicAdd(&H.plain[0][BYTE_OF(c2, b)][col], 1u);
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        atomicAdd(&H.plain[1][BYTE_OF(c3, b)][col], 1u);
+    }
+  else
+    { hist_plain_step<HC_PLAIN>(c2, valid, full, H.plain[0], H.slow[DX_INS]);
+      hist_plain_step<HC_PLAIN>(c3, valid, full, H.plain[1], H.slow[DX_MRG]);
+    }
 }
 
 // bin of the histogram g_hist[6*256] that LDS word k (of the fast tables, then the slow ones) counts
@@ -478,27 +572,26 @@ __device__ __forceinline__ uint32_t hist_bin_of(uint32_t k)
 __device__ __forceinline__ uint32_t hist_copies_of(uint32_t k)
 { return k < HIST_W_PLAIN ? HC_PLAIN : (k < HIST_W_PLAIN + HIST_W_RSYM ? HC_RSYM : HC_RUN); }
 
+// FAST: tokens wanted and both run characters known -- the usual launch: both lines are run-coded in every entry, the tag
+// line travels with them, and none of that is asked per entry and step; !FAST: everything decided at run time.
+template <bool FAST>
 __global__ __launch_bounds__(HIST_BLOCK, (HIST_NWAVE * HIST_PER_CU + 3) / 4)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
                unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts)
 { __shared__ hist_lds H;
-  __shared__ __attribute__((aligned(16))) uint8_t s_chunk[HIST_NWAVE][DX_STEP];
-  __shared__ __attribute__((aligned(16))) uint8_t s_tchunk[HIST_NWAVE][DX_STEP];
-  __shared__ uint16_t s_list[HIST_NWAVE][DX_STEP];
-  __shared__ uint8_t  s_tagcode[256];
+  __shared__ __attribute__((aligned(16))) hist_wave_lds s_wave[HIST_NWAVE];
   const int      lane  = lane_id();
   const int      tid   = threadIdx.x;
-  const run_lds  R     = { s_chunk[tid >> 6], s_list[tid >> 6] };
-  uint8_t *const tchunk = s_tchunk[tid >> 6];
+  hist_wave_lds &W     = s_wave[tid >> 6];
   uint32_t *const words = &H.plain[0][0][0];                    // the whole of H as words
   const uint32_t  nwords = sizeof(hist_lds) / 4;
-  const bool      toks  = ts.del != NULL;
+  const bool      toks  = FAST || ts.del != NULL;
+  // this lane's copy of the run-coded lines' fast bins
+  uint32_t *const hs0 = &H.rsym[0][0][(uint32_t) lane & (HC_RSYM - 1)], *const hs4 = &H.rsym[1][0][(uint32_t) lane & (HC_RSYM - 1)];
+  uint32_t *const hr0 = &H.run[0][0][(uint32_t) lane & (HC_RUN - 1)],   *const hr4 = &H.run[1][0][(uint32_t) lane & (HC_RUN - 1)];
+  const uint32_t  rc0 = (uint32_t) (a.delChar & 0xff) * 0x01010101u, rc4 = (uint32_t) (a.subChar & 0xff) * 0x01010101u;
 
   for (uint32_t k = tid; k < nwords; k += HIST_BLOCK) words[k] = 0;
-  if (tid < 256)
-    { const int u = tid & 0xdf;                                  // Number_Read's letter -> 2-bit code (DB.c:393-416)
-      s_tagcode[tid] = (uint8_t) (u == 'C' ? 1 : (u == 'G' ? 2 : (u == 'T' ? 3 : 0)));
-    }
   __syncthreads();
 
   uint64_t tot = 0, since = 0;
@@ -507,23 +600,24 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
     for (uint64_t r = r0; r < r0 + a.units && r < a.n; r++)
     { const uint32_t  L = a.len[r];
       const long long g = (long long) (entry0 + r);
-      const bool drun = a.delChar >= 0 && (toks || g >= del_first);      // tokenised (and, from del_first on, run-histogrammed)
-      const bool srun = a.subChar >= 0 && (toks || g >= sub_first);
-      const bool dcnt = a.delChar >= 0 && g >= del_first, scnt = a.subChar >= 0 && g >= sub_first;
+      const bool drun = FAST || (a.delChar >= 0 && (toks || g >= del_first));      // tokenised (and, from del_first on, run-histogrammed)
+      const bool srun = FAST || (a.subChar >= 0 && (toks || g >= sub_first));
+      const uint32_t dinc = (a.delChar >= 0 && g >= del_first) ? 1u : 0u, sinc = (a.subChar >= 0 && g >= sub_first) ? 1u : 0u;
       const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2);
       const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
       const uint8_t *p1 = line_ptr(a, r, L, 1);
       const bool over = can_overread(a, p4, L);       // p4 is the last line of the entry
       uint32_t C0 = 0, C4 = 0, n0 = 0, n4 = 0;
       uint16_t *tk0 = NULL, *tk4 = NULL;
-      uint32_t  nt0 = 0, nt4 = 0, cap = 0, bad0 = 0, bad4 = 0, nx0 = 0, nx4 = 0;
+      uint32_t  nt0 = 0, nt4 = 0, room = 0, bad0 = 0, bad4 = 0, nx0 = 0, nx4 = 0;
+      tok_pend  pd0 = { 0ull, 0u, 0u }, pd4 = { 0ull, 0u, 0u };
       if (toks)
         { const uint64_t t0 = ts.off[r];
-          cap = (uint32_t) (ts.off[r + 1] - t0);
+          room = (uint32_t) (ts.off[r + 1] - t0) - TOK_XMARGIN;
           if (drun) tk0 = ts.del + t0;
           if (srun) tk4 = ts.sub + t0;
         }
-      const bool tags = tk0 != NULL;
+      const bool tags = FAST || tk0 != NULL;
 
       uint32_t pos = 16u * lane;
       u32x4 c0 = fetch(p0, pos, L, over), c2 = fetch(p2, pos, L, over);
@@ -531,13 +625,18 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
       u32x4 t1 = c0;
       if (tags) t1 = fetch(p1, pos, L, over);          // the deletion tags travel with the step's other chunks
       for (uint32_t base = 0; base < L; base += DX_STEP)
-        { const uint32_t np = pos + DX_STEP;           // next step's chunks go in flight first
-          // ... but behind an explicit wait for everything older.  vmcnt counts loads and stores alike and the number
-          // of token stores of a step is not known to the compiler, so every wait it inserts itself is vmcnt(0) -- and
-          // wherever in the step that falls, it then also waits for the chunks requested a moment ago: no prefetch at
-          // all.  With the wait HERE this step's chunks (requested a whole step ago) and the last step's token stores
-          // are complete, nothing in the step below needs another wait, and the new requests have the whole step.
+        { const uint32_t np = pos + DX_STEP;
+          // The last step's tokens leave first (tok_pend), then the next step's chunks are requested: the step ends with
+          // the wait for them -- the copies c = d below; with token stores in the loop every wait the compiler places
+          // is vmcnt(0) -- and by then both have had the whole step.  The explicit wait tells the compiler that nothing
+          // older is outstanding here (true but for an entry's first step, whose chunks were requested just before the
+          // loop): without it it waits for "everything" at the first use of a chunk in the step -- i.e. for the
+          // requests made a moment ago.
           __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+          if (toks)
+            { tok_flush(pd0, tk0);
+              tok_flush(pd4, tk4);
+            }
           u32x4 d0, d2, d3, d4, u1 = c0;               // (without tags u1 is never looked at; a copy of d0 would wait for d0's load)
           if (HIST_BARE_FETCH && base + 2u * DX_STEP <= L)   // the whole next step is inside the lines: bare loads (see fetch_step)
             { d0 = *(const u32x4_u *) (p0 + np); d2 = *(const u32x4_u *) (p2 + np);
@@ -552,32 +651,28 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
           const bool     full  = sv == DX_STEP;
           const int      valid = valid_of(pos, L);
-          // The run-coded lines first: their token stores then have the two plain lines' worth of work to complete
-          // in before the step's end, where the wait for the prefetched chunks also waits for every older store.
+          const uint32_t vmask = (1u << valid) - 1u;
           if (HIST_SKIP & 16) { }
-          else if (drun)
-            { if (tags) *(u32x4 *) (tchunk + 16 * lane) = t1;    // (run_collect's barrier orders it before the look-ups)
-              hist_runs_step(R, c0, valid, sv, (uint32_t) a.delChar, C0, n0, H.rsym[0], H.slow[DX_DEL], H.run[0], H.slow[DX_DRUN],
-                             dcnt, tk0, nt0, cap, bad0, nx0, tags ? tchunk : (const uint8_t *) NULL, s_tagcode);
-            }
+          else if (drun) hist_runs_step<true>(W, c0, t1, vmask, sv, rc0, C0, n0, hs0, H.slow[DX_DEL], hr0, H.slow[DX_DRUN],
+                                              dinc, tk0, nt0, tk0 != NULL ? room : 0u, bad0, nx0, pd0);   // (no tags wanted: t1 = c0, never stored)
           else      hist_plain_step<HC_RSYM>(c0, valid, full, H.rsym[0], H.slow[DX_DEL]);
           if (HIST_SKIP & 16) { }
-          else if (srun) hist_runs_step(R, c4, valid, sv, (uint32_t) a.subChar, C4, n4, H.rsym[1], H.slow[DX_SUB], H.run[1], H.slow[DX_SRUN],
-                                   scnt, tk4, nt4, cap, bad4, nx4, (const uint8_t *) NULL, s_tagcode);
+          else if (srun) hist_runs_step<false>(W, c4, c4, vmask, sv, rc4, C4, n4, hs4, H.slow[DX_SUB], hr4, H.slow[DX_SRUN],
+                                               sinc, tk4, nt4, tk4 != NULL ? room : 0u, bad4, nx4, pd4);
           else      hist_plain_step<HC_RSYM>(c4, valid, full, H.rsym[1], H.slow[DX_SUB]);
           if (!(HIST_SKIP & 2))
-            { hist_plain_step<HC_PLAIN>(c2, valid, full, H.plain[0], H.slow[DX_INS]);
-              hist_plain_step<HC_PLAIN>(c3, valid, full, H.plain[1], H.slow[DX_MRG]);
-            }
+            hist_plain_pair(c2, c3, valid, full, H);
           c0 = d0; c2 = d2; c3 = d3; c4 = d4; t1 = u1;
           pos = np;
         }
+      tok_flush(pd0, tk0);
+      tok_flush(pd4, tk4);
       if (drun)                                        // trailing run + the run character's own count
-        { if (dcnt && C0 > 0 && lane == 0) atomicAdd(&H.slow[DX_DRUN][C0 > 255u ? 255u : C0], 1u);
+        { if (dinc && C0 > 0 && lane == 0) atomicAdd(&H.slow[DX_DRUN][C0 > 255u ? 255u : C0], 1u);
           if (lane == 0 && n0) atomicAdd(&H.slow[DX_DEL][a.delChar], n0);
         }
       if (srun)
-        { if (scnt && C4 > 0 && lane == 0) atomicAdd(&H.slow[DX_SRUN][C4 > 255u ? 255u : C4], 1u);
+        { if (sinc && C4 > 0 && lane == 0) atomicAdd(&H.slow[DX_SRUN][C4 > 255u ? 255u : C4], 1u);
           if (lane == 0 && n4) atomicAdd(&H.slow[DX_SUB][a.subChar], n4);
         }
       if (toks)
@@ -707,17 +802,6 @@ __device__ __forceinline__ void load_size_tables(size_tabs &t, const uint32_t *g
       (&t.inner[0][0])[k] = (uint16_t) sum;
     }
   __syncthreads();
-}
-
-// inclusive running maximum over the 64 lanes (values >= 0)
-__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
-{ v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true));
-  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true));
-  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true));
-  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true));
-  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false));
-  v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false));
-  return v;
 }
 
 // sum of the symbol-code lengths of a lane's bytes [0, valid)
@@ -1795,8 +1879,12 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE, hist_room = (uint64_t) ctx->num_cu * HIST_PER_CU;   // HIST_PER_CU workgroups per CU
-  DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist, (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
-            a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts);
+  if (ts.del != NULL && p->delChar >= 0 && p->subChar >= 0)
+    DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist<true>, (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
+              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts);
+  else
+    DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist<false>, (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
+              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts);
   uint64_t host[6 * 256 + 2];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
