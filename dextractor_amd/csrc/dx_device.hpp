@@ -158,20 +158,7 @@ struct wave_out
   uint8_t  *seg;          // byte address of the current segment's first word
   uint32_t  wordbase;     // words of this segment already stored
   uint32_t  winbits;      // bits in the window
-  bool      wt;           // stores go straight to memory (sc1): what another XCD's waves may read within this kernel's time
 };
-
-// Stores that another XCD's waves can read while this kernel runs: `sc1` writes through the XCD's L2 (a plain store stays
-// there, dirty, invisible to the other seven L2s until the kernel ends).  MI355X_MICROARCH.md: a 16-byte sc1 store costs
-// what a plain one does.  (Inline assembly: no builtin gives a 16-byte store this flavour.  The trailing s_nop covers
-// the wait state between a store of more than 8 bytes and a write of its data registers, which the compiler would
-// otherwise see to.)
-__device__ __forceinline__ void store16_wt(uint8_t *p, const u32x4 &v)
-{ asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void store4_wt(uint8_t *p, uint32_t v)
-{ asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void store1_wt(uint8_t *p, uint32_t v)
-{ asm volatile("global_store_byte %0, %1, off sc1" : : "v"(p), "v"(v) : "memory"); }
 
 // The same in 16-byte units, for the periodic drain of a well-filled window (16-byte aligned):
 // whole groups of four words leave with one ds_read_b128 + one (unaligned) 16-byte store per
@@ -187,8 +174,7 @@ __device__ __forceinline__ void flush_quads(wave_out &o, bool swap)
         { v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y);
           v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
         }
-      if (o.wt) store16_wt(o.seg + 4ull * o.wordbase + 16ull * j, v);
-      else      *(u32x4_u *) (o.seg + 4ull * o.wordbase + 16ull * j) = v;
+      *(u32x4_u *) (o.seg + 4ull * o.wordbase + 16ull * j) = v;
     }
   const u32x4 rest = win4[nq];
   const u32x4 zero = { 0u, 0u, 0u, 0u };
@@ -207,8 +193,7 @@ __device__ __forceinline__ void flush_words(wave_out &o, bool swap)
   wave_sync();
   for (uint32_t j = lane; j < nfull; j += 64)
     { const uint32_t w = o.win[j];
-      if (o.wt) store4_wt(o.seg + 4ull * (o.wordbase + j), swap ? __builtin_bswap32(w) : w);
-      else      store32_u(o.seg + 4ull * (o.wordbase + j), swap ? __builtin_bswap32(w) : w);
+      store32_u(o.seg + 4ull * (o.wordbase + j), swap ? __builtin_bswap32(w) : w);
     }
   const uint32_t part = o.win[nfull];
   wave_sync();

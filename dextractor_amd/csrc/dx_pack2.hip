@@ -94,7 +94,6 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
   for (int k = threadIdx.x; k < 256; k += DX_BLOCK)
     s_code[k] = (uint8_t) sym_code<ALPHA>((uint32_t) k);
   wave_out o;
-  o.wt  = false;
   o.win = s_win[wid];
   for (int j = lane; j < P2_WIN_WORDS; j += 64)
     o.win[j] = 0;

@@ -1117,9 +1117,7 @@ __device__ __forceinline__ uint32_t finish_words(wave_out &o, uint32_t last)
   if (lane_id() == 0)
     { const uint32_t w = o.win[0];
       for (uint32_t k = 0; k < tailw; k++)
-        { if (o.wt) store4_wt(o.seg + 4ull * (o.wordbase + k), w);
-          else      store32_u(o.seg + 4ull * (o.wordbase + k), w);
-        }
+        store32_u(o.seg + 4ull * (o.wordbase + k), w);
       o.win[0] = 0;
     }
   wave_sync();
@@ -1418,9 +1416,7 @@ __device__ __forceinline__ uint32_t finish_tags(wave_out &o)
   if (lane_id() == 0)
     { const uint32_t w = __builtin_bswap32(o.win[0]);
       for (uint32_t k = 0; 8u * k < o.winbits; k++)
-        { if (o.wt) store1_wt(o.seg + 4ull * o.wordbase + k, (w >> (8 * k)) & 0xffu);
-          else      o.seg[4ull * o.wordbase + k] = (uint8_t) (w >> (8 * k));
-        }
+        o.seg[4ull * o.wordbase + k] = (uint8_t) (w >> (8 * k));
       o.win[0] = 0;
     }
   wave_sync();
@@ -1450,7 +1446,6 @@ struct enc_scratch
   uint32_t       *seg_out;     // n x 5
   uint32_t       *rec_size;    // n
   uint64_t        lo, hi;      // the slot offsets this launch may use: [lo, hi) is its scratch region (see slot_sane)
-  uint32_t        ready;       // ORed into every rec_size word written (FC_READY on the follow route, dx_qv_fast.hpp; else 0)
 };
 
 __host__ __device__ __forceinline__ uint32_t tag_room(uint32_t L) { return (((L + 3u) >> 2) + 7u) & ~3u; }
@@ -1489,7 +1484,6 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 
   const run_lds R = { s_chunk[wid], s_list[wid] };
   wave_out o, ot;
-  o.wt = ot.wt = false;
   o.win  = s_win[wid];
   ot.win = s_tag[wid];
   for (int j = lane; j < QV_WIN_WORDS; j += 64)  o.win[j]  = 0;
@@ -1646,8 +1640,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
       if (S)
         { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
           if (lane == 0)
-            __hip_atomic_store(&sc.rec_size[r], (sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u)) | sc.ready,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sc.rec_size[r] = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
         }
       if (bad && lane == 0)
         atomicOr(status, 2u);                            // sizes disagree with k_qv_sizes / slot overflow
@@ -1664,7 +1657,7 @@ void k_qv_bounds(const uint32_t *len, uint64_t n, uint32_t b0, uint32_t b1, uint
   const uint64_t bits = L * b0 + L * b1 + L * b2 + L * b3;
   uint64_t bytes = ((bits + 7) >> 3) + 4 * 20 + tag_room((uint32_t) L);           // + partial and pad words, trailing run tokens
   bytes = (bytes + 127) & ~(uint64_t) 127;                                       // (whole 128-byte lines: no cache line holds two entries' slots,
-                                                                                 //  so a line a follower wave has read never goes stale under it)
+                                                                                 //  and the compaction's 16-byte loads of a slot start on a line)
   if (bytes >= (1ull << 32))                                                     // a slot is addressed in 32 bits: such an entry (some
     { atomicMax(too_long, (unsigned long long) L);                               // 3.5e8 symbols at 96 bits per position) is refused, never
       bytes = 16;                                                                // given a wrapped bound
@@ -1694,9 +1687,6 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
     dst[t] = src[t];
 }
 
-#ifndef FOLLOW_WAVES_PER_CU
-#define FOLLOW_WAVES_PER_CU 8                           // waves of k_qv_follow per CU (beside the encoder's sixteen)
-#endif
 #define COMPACT_BATCH 8u
 #ifndef COMPACT_WAVES_PER_CU
 #define COMPACT_WAVES_PER_CU 16                         // (a copy kernel: few registers, no LDS)
@@ -1731,15 +1721,8 @@ void k_qv_compact(uint64_t n, const uint32_t *len, const uint8_t *scratch, const
 }
 
 #include "dx_qv_fast.hpp"
-// (template arguments hold commas, which a macro argument cannot: the instances go by these names)
-static constexpr auto FAST_K          = &k_qv_encode_fast<false, false>;
-static constexpr auto FAST_K_IX       = &k_qv_encode_fast<true, false>;
-static constexpr auto FAST_K_CHAIN    = &k_qv_encode_fast<false, true>;
-static constexpr auto FAST_K_IX_CHAIN = &k_qv_encode_fast<true, true>;
-static constexpr auto FAST_K_FOLLOW   = &k_qv_encode_fast<false, false, 1>;
-static constexpr auto FAST_K_IX_FOLLOW = &k_qv_encode_fast<true, false, 1>;
-static constexpr auto FAST_K_FWD      = &k_qv_encode_fast<false, false, 2>;
-static constexpr auto FAST_K_IX_FWD   = &k_qv_encode_fast<true, false, 2>;
+static constexpr auto FAST_K    = &k_qv_encode_fast<false>;
+static constexpr auto FAST_K_IX = &k_qv_encode_fast<true>;
 
 // =============================================================================================
 //  C-ABI
@@ -2092,7 +2075,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 },
+            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 },
             (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0,
             sub_sink{ NULL, NULL, NULL });
   uint32_t st = 0;
@@ -2117,27 +2100,15 @@ static int fast_grid(dx_ctx *ctx, uint64_t entries)
 #define ONEPASS_REGION_CAP ((uint64_t) 32 << 30)          // bytes of one of the two scratch regions of dx_qv_encode_onepass
 
 // side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
-// (next_*: the group after this one goes the direct way -- its sizes are known, its record offsets follow from this group's
-// end: scanned here, in front of the compaction, so that its encoder can start beside it; next_ev says when)
 static int onepass_side(dx_ctx *ctx, hipStream_t B, int waves_per_cu, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
                         uint64_t *d_rec_off, const uint64_t *base_in, uint64_t *base_out, const uint32_t *d_len,
                         const uint8_t *d_slots, const uint64_t *d_slot, const uint32_t *d_seg, const uint8_t *d_hdr,
-                        const uint64_t *d_hdr_off, uint8_t *d_out, uint64_t out_cap, uint32_t *d_tick,
-                        const uint32_t *next_size = NULL, uint64_t next_m = 0, uint64_t *next_rec_off = NULL, uint64_t *next_base_out = NULL,
-                        hipEvent_t next_ev = NULL)
+                        const uint64_t *d_hdr_off, uint8_t *d_out, uint64_t out_cap, uint32_t *d_tick)
 { DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, B));
   DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_tiles, (int) mt, DX_BLOCK, d_size, m, d_tile);
   DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, mt, d_gran);
   DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_apply_base, (int) mt, DX_BLOCK, d_size, m, (const uint64_t *) d_tile, d_rec_off,
                (const uint64_t *) d_gran, base_in, base_out);
-  if (next_size != NULL)
-    { const uint64_t nt = (next_m + SCAN_TILE - 1) / SCAN_TILE;
-      DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_tiles, (int) nt, DX_BLOCK, next_size, next_m, d_tile);
-      DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, nt, d_gran);
-      DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_apply_base, (int) nt, DX_BLOCK, next_size, next_m, (const uint64_t *) d_tile, next_rec_off,
-                   (const uint64_t *) d_gran, (const uint64_t *) base_out, next_base_out);
-      DX_HIP(ctx, hipEventRecord(next_ev, B));
-    }
   DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, waves_per_cu), DX_BLOCK,
             m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
             ctx->d_status, d_tick, ctx->compact_units ? ctx->compact_units : COMPACT_BATCH);
@@ -2301,14 +2272,14 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
       if (sx_idx)
         hipLaunchKernelGGL(FAST_K_IX, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, tg,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
-                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
+                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
       else
         hipLaunchKernelGGL(FAST_K, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, tg,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
-                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
+                           (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
       dx_prof_end_on(ctx, A);
       if (odd)
         { if (hipMemsetAsync(d_tick_enc, 0, 4, A) != hipSuccess) break;
@@ -2316,7 +2287,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
           hipLaunchKernelGGL(k_qv_encode, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * ENC_WAVES)),
                              dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
                              (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
-                             d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, (const uint32_t *) ctx->tk.list,
+                             d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, (const uint32_t *) ctx->tk.list,
                              (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), out_cap, sx_g);
           dx_prof_end_on(ctx, A);
         }
@@ -2348,75 +2319,6 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
   return DX_OK;
 }
 
-// dx_qv_encode_onepass with chained placement (DEXGPU_CHAIN, or no memory for scratch slots): one launch of
-// k_qv_encode_fast<.., true> -- sizes, look-back, record in place -- between two list-mode launches of the generic
-// kernels for the entries whose tokens cannot be used.  Needs the token hand-over; 8 bytes of scratch per entry.
-static int onepass_chain(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
-                         uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total)
-{ const uint64_t n  = b->n;
-  const size_t   a8 = (n * 8 + 255) & ~(size_t) 255, a4 = (n * 4 + 255) & ~(size_t) 255;
-  uint8_t *scr;
-  int e;
-  if ((e = dx_scratch(ctx, a8 + a4 + 512, (void **) &scr))) return e;
-  unsigned long long *d_status64 = (unsigned long long *) scr;
-  uint32_t           *d_size     = (uint32_t *) (scr + a8);
-  unsigned long long *d_waits    = (unsigned long long *) (scr + a8 + a4);
-  uint32_t *sx_idx = NULL;
-  if ((e = subindex_prepare(ctx, b, d_out, d_seg, &sx_idx))) return e;
-  hipStream_t A = ctx->stream;
-  uint32_t *d_tick = (uint32_t *) (ctx->d_u64 + 19);
-  const qv_args a   = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
-  const bool    odd = ctx->tk.unusable > 0;
-  const tok_src tg  = { ctx->tk.del, ctx->tk.sub, ctx->tk.off, ctx->tk.info };
-  const sub_sink sx = { sx_idx, sx_idx ? (const uint64_t *) ctx->sx.off : (const uint64_t *) NULL, ctx->sx.none };
-  const lb_chain lb = { d_status64, d_rec_off, d_seg, d_size, d_waits };
-  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
-  DX_HIP(ctx, hipMemsetAsync(d_status64, 0, a8, A));
-  DX_HIP(ctx, hipMemsetAsync(d_waits, 0, 32, A));
-  if (odd)                                               // sizes of the entries the fast kernel leaves out: from the text
-    { DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
-      DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, ctx->tk.unusable < n ? ctx->tk.unusable : n, 4 * SIZES_WAVES), DX_BLOCK,
-                a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_seg, d_size, d_tick, (const uint32_t *) ctx->tk.list,
-                (const unsigned long long *) ctx->tk.count, (uint64_t) 0, (const uint32_t *) ctx->tk.info);
-    }
-  DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
-  if (sx_idx)
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX_CHAIN, fast_grid(ctx, n), FAST_BLOCK,
-              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, tg,
-              ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb, follow_copy{});
-  else
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_CHAIN, fast_grid(ctx, n), FAST_BLOCK,
-              a, (const uint32_t *) ctx->d_tok, d_hdr_off, ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, tg,
-              ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) NULL, (const uint32_t *) NULL, d_out, out_cap, sx, lb, follow_copy{});
-  if (odd)                                               // ... and their records, in place
-    { DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, A));
-      DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, ctx->tk.unusable < n ? ctx->tk.unusable : n, 4 * ENC_WAVES), DX_BLOCK,
-                a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, (const uint64_t *) d_rec_off, (const uint32_t *) d_seg, d_out,
-                ctx->d_status, d_tick, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0, 0 }, (const uint32_t *) ctx->tk.list,
-                (const unsigned long long *) ctx->tk.count, (uint64_t) 0, (const uint32_t *) ctx->tk.info, out_cap, sx);
-    }
-  uint64_t tot = 0, waits[4] = { 0, 0, 0, 0 };
-  uint32_t st  = 0;
-  DX_HIP(ctx, hipMemcpyAsync(&tot, d_rec_off + n, 8, hipMemcpyDeviceToHost, A));
-  DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A));
-  DX_HIP(ctx, hipMemcpyAsync(waits, d_waits, 24, hipMemcpyDeviceToHost, A));
-  DX_HIP(ctx, hipStreamSynchronize(A));
-  if (total) *total = tot;
-  ctx->route.groups = 0; ctx->route.direct = 2; ctx->route.tokens = 1; ctx->route.region_bytes = 0;
-  ctx->route.scratch_bytes = ctx->scratch_bytes; ctx->route.token_bytes = 4ull * ctx->tk.cap_tokens;
-  ctx->route.text_entries = ctx->tk.unusable;
-  ctx->route.chain_waits[0] = waits[0]; ctx->route.chain_waits[1] = waits[1]; ctx->route.chain_waits[2] = waits[2];
-  if (st & 32u)
-    return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: the placement chain did not close (an entry waited %u looks for its predecessors)", LB_SPIN_LIMIT);
-  if (tot > out_cap || (st & 8u))
-    return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
-                   (unsigned long long) tot, (unsigned long long) out_cap);
-  if (st & 2u)
-    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an encoded segment differs in size from what the size phase computed");
-  ctx->sx.valid = sx_idx != NULL;
-  return DX_OK;
-}
-
 static int onepass_end(dx_ctx *ctx, uint64_t *total);
 
 // wait = false: everything is queued and the function returns; onepass_end collects the total and the status
@@ -2444,13 +2346,6 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // DEXGPU_DIRECT_ENCODE: sizes first, records written in place, no scratch slots (onepass_direct) -- what also runs
   // when the slots below cannot be allocated.  It is the slower of the two (34.5 ms against 31.0, 1 M x 10 kb): its
   // size kernel reads the 30 GB of plain lines once more, the compaction it saves moves 2 x 14 GB.
-  if (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_CHAIN") != NULL && getenv("DEXGPU_CHAIN")[0] != '0')
-    { uint64_t t = 0;
-      const int rc = onepass_chain(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
-      if (total) *total = t;
-      if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }
-      return rc;
-    }
   if (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_DIRECT_ENCODE") != NULL)
     { uint64_t t = 0;
       const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
@@ -2467,20 +2362,13 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // table-derived slot bounds), two from 240 k entries on so that half of the compaction is hidden.
   // Measured, 1 M x 10 kb, ms per step: 2 equal groups 31.0, 4: 31.3, 8: 32.9, 16: 35.0, 64: 46.7;
   // 40 % / 30 % / 30 % in three regions: 31.4; 7 groups with a halving tail: 32.7.
-  // DEXGPU_FOLLOW: the encoder moves every record to its place itself (follow_copy, dx_qv_fast.hpp): no compaction kernel,
-  // no overlap to arrange -- one group if its slots fit the memory, else groups one after the other in ONE region
-  // DEXGPU_FOLLOW=2: the encoder only forwards (slots written through, sizes published) and k_qv_follow, started beside it
-  // on the side stream, places the records as they come: two regions, so that a group's encoder need not wait for the
-  // group before's follower
-  const bool follow = getenv("DEXGPU_FOLLOW") != NULL && getenv("DEXGPU_FOLLOW")[0] != '0' && onepass_tokens_ok(ctx, b);
-  const bool beside = follow && getenv("DEXGPU_FOLLOW")[0] == '2';
-  const int  regions_max = follow ? (beside ? 2 : 1) : 3;
+  const int regions_max = 3;
   uint64_t gb[ONEPASS_MAX_GROUPS + 1];
   int      G = 1;
   { const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
     const uint64_t syms = b->text_bytes ? b->text_bytes / 5 / n : 0;   // per entry (a file image: five lines each)
     const uint64_t per_entry = syms ? syms * bits / 8 + syms / 4 + 128 : 0;       // mean slot bound
-    if (n >= 240000 && !follow) G = 2;
+    if (n >= 240000) G = 2;
     if (per_entry)
       { while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
         // ... and as the free device memory allows (the scratch that exists counts as free: it is replaced): more,
@@ -2497,7 +2385,7 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
             G++;
         ctx->route.avail_bytes = avail;
       }
-    else if (n >= 240000 && !follow)
+    else if (n >= 240000)
       G = (int) (n / 250000) > 2 ? (int) (n / 250000) : 2;
     if (G < ctx->onepass_min_groups) G = ctx->onepass_min_groups;      // (what an earlier call had to fall back to)
     if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
@@ -2531,13 +2419,11 @@ layout:
   }
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
-  const size_t   ftile  = (((n + 63) / 64 + 2) * 8 + 255) & ~(size_t) 255;             // follow route: a status word per 64 entries
-  const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255) + 2 * ftile;
+  const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255);
   uint64_t       region = 0, gstart[ONEPASS_MAX_GROUPS + 1] = { 0 };   // slot offset at which each group starts; largest group's extent
   uint8_t       *scr    = NULL;
   uint32_t      *d_bound = NULL, *d_size = NULL;
   uint64_t      *d_slot = NULL, *d_tile = NULL, *d_gran = NULL;
-  unsigned long long *d_ftile = NULL;
   // the slot layout needs the scratch to exist and the scratch's size needs the layout: lay out, size,
   // and lay out again if the buffer had to move.  Three rotating regions hold the groups' slots.
   uint64_t laid_gen = 0;                                 // the scratch generation the layout below was computed in
@@ -2569,7 +2455,6 @@ layout:
       d_slot  = (uint64_t *) (scr + 2 * a4);
       d_tile  = (uint64_t *) (scr + 2 * a4 + a8);
       d_gran  = d_tile + ntiles;
-      d_ftile = (unsigned long long *) (scr + small - 2 * ftile);                    // (two: consecutive groups' followers may overlap)
       unsigned long long *d_long = (unsigned long long *) (ctx->d_u64 + 32), too_long = 0;
       DX_HIP(ctx, hipMemsetAsync(d_long, 0, 8, ctx->stream));
       DX_LAUNCH(ctx, DX_K_SCAN, k_qv_bounds, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK,
@@ -2606,116 +2491,19 @@ layout:
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
   DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
   int rc = DX_OK, ng = 0;                                // ng: groups run so far (selects the ping-pong base)
-  // Hybrid (DEXGPU_HYBRID): the LAST group goes the direct way.  Its sizes (k_qv_sizes_fast: tokens and plain lines read
-  // once more) are computed on the side stream while the FIRST group is being encoded, its record offsets follow from the
-  // group before's end (onepass_side), and its encoder writes the records in place beside that group's compaction: no
-  // compaction is left over at the end of the batch.
-  const bool hybrid = fast && !follow && G >= 2 && getenv("DEXGPU_HYBRID") != NULL && getenv("DEXGPU_HYBRID")[0] != '0';
-  hipEvent_t off_done = ctx->ev[17], hyb_fork = ctx->ev[18];
-  if (hybrid)
-    { const uint64_t g0 = gb[G - 1], m = gb[G] - g0;
-      qv_args ag = a;
-      ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
-      const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
-      const tok_src   tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
-      uint32_t *d_tick_sz = (uint32_t *) (ctx->d_u64 + 44);         // (a line of its own: away from the other tickets)
-      DX_HIP(ctx, hipEventRecord(hyb_fork, A));
-      DX_HIP(ctx, hipStreamWaitEvent(B, hyb_fork, 0));
-      DX_HIP(ctx, hipMemsetAsync(d_tick_sz, 0, 4, B));
-      // 256-thread workgroups: one wave per SIMD is what fits beside four encoder waves (64 of the 512 registers are left)
-      DX_LAUNCH_ON(ctx, B, DX_K_QV_SIZES, k_qv_sizes_fast, ctx->num_cu * 2, DX_BLOCK,
-                   ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz, tg);
-      if (ctx->tk.unusable > 0)
-        { DX_HIP(ctx, hipMemsetAsync(d_tick_sz, 0, 4, B));
-          DX_LAUNCH_ON(ctx, B, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * SIZES_WAVES), DX_BLOCK,
-                       ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz,
-                       (const uint32_t *) ctx->tk.list, (const unsigned long long *) ctx->tk.count, g0,
-                       (const uint32_t *) (ctx->tk.info + TOK_INFO * g0));
-        }
-    }
   for (int g = 0; g < G && rc == DX_OK; g++)
     { const uint64_t g0 = gb[g], g1 = gb[g + 1];
       if (g0 >= g1) continue;
       const uint64_t m = g1 - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
       // this group's slots live in region g % 3: slot_off[r] is file-wide, so shift the base
-      uint8_t *slots_g = d_slots + (uint64_t) (follow ? (beside ? g % 2 : 0) : g % 3) * region - gstart[g];
+      uint8_t *slots_g = d_slots + (uint64_t) (g % 3) * region - gstart[g];
       qv_args ag = a;
       ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
       const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
       const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL, ctx->sx.none };
-      if (g >= 3 && !follow)
+      if (g >= 3)
         DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 3) & 7], 0));    // the region is free once its last tenant has been copied out
-      const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0, gstart[g], gstart[g] + region, follow ? 0x80000000u : 0u };
-      if (follow)
-        { // the odd entries first (into their slots, sizes published), then the encoder that also places every record
-          // (beside: that only forwards, with k_qv_follow on the side stream)
-          unsigned long long *d_waits = (unsigned long long *) (ctx->d_u64 + 40);
-          unsigned long long *ft_g    = d_ftile + (beside ? (size_t) (g & 1) * (ftile / 8) : 0);
-          const follow_copy fc_all = { d_size + g0, ft_g, d_rec_off + g0, d_base + (ng & 1), (unsigned long long *) (d_base + ((ng + 1) & 1)),
-                                       d_hdr, d_out, out_cap, d_waits };
-          follow_copy fc = fc_all;
-          if (beside) { fc.out = NULL; fc.rec_off = NULL; }
-          const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
-          if (beside && g >= 2)
-            DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 2) & 7], 0));    // the region (and the tile words) are free once their follower is through
-          DX_HIP(ctx, hipMemsetAsync(d_size + g0, 0, m * 4, A));
-          DX_HIP(ctx, hipMemsetAsync(ft_g, 0, ((m + 63) / 64 + 1) * 8, A));
-          if (g == 0) DX_HIP(ctx, hipMemsetAsync(d_waits, 0, 32, A));
-          if (ctx->tk.unusable > 0)
-            { const uint64_t work = ctx->tk.unusable < m ? ctx->tk.unusable : m;
-              DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-              DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, work, 4 * ENC_WAVES), DX_BLOCK,
-                        ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                        (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g, (const uint32_t *) ctx->tk.list,
-                        (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), ~(uint64_t) 0, sx_g);
-            }
-          DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          const int fw = getenv("DEXGPU_FOLLOW_WAVES") ? atoi(getenv("DEXGPU_FOLLOW_WAVES")) : FOLLOW_WAVES_PER_CU;   // (experiments; 0: no follower)
-          if (beside && fw > 0)                          // the follower starts when the encoder does
-            { DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
-              DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g & 7], 0));
-              DX_HIP(ctx, hipMemsetAsync(d_tick_cmp, 0, 4, B));
-              DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_follow, ctx->num_cu * fw / DX_WAVES_PER_BLK, DX_BLOCK,
-                           ag, sc_g, hoff_g, fc_all, ctx->d_status, d_tick_cmp);
-              (void) hipEventRecord(cmp_done[g & 7], B);
-            }
-#define FOLLOW_LAUNCH(K)                                                                                              \
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, K, fast_grid(ctx, m), FAST_BLOCK,                                            \
-                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,                   \
-                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL, \
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, fc)
-          if (beside) { if (sx_idx) FOLLOW_LAUNCH(FAST_K_IX_FWD);    else FOLLOW_LAUNCH(FAST_K_FWD); }
-          else        { if (sx_idx) FOLLOW_LAUNCH(FAST_K_IX_FOLLOW); else FOLLOW_LAUNCH(FAST_K_FOLLOW); }
-#undef FOLLOW_LAUNCH
-          ng += 1;
-          continue;
-        }
-      if (hybrid && g == G - 1)                          // the last group: sizes and offsets are there, records in place
-        { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
-          const enc_scratch none = { NULL, NULL, NULL, NULL, 0, 0, 0 };
-          DX_HIP(ctx, hipStreamWaitEvent(A, off_done, 0));
-          DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          if (sx_idx)
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX, fast_grid(ctx, m), FAST_BLOCK,
-                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, none, tg,
-                      ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0),
-                      d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
-          else
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K, fast_grid(ctx, m), FAST_BLOCK,
-                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, none, tg,
-                      ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0),
-                      d_out, out_cap, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
-          if (ctx->tk.unusable > 0)
-            { const uint64_t work = ctx->tk.unusable < m ? ctx->tk.unusable : m;
-              DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-              DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, work, 4 * ENC_WAVES), DX_BLOCK,
-                        ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0),
-                        d_out, ctx->d_status, d_tick_enc, none, (const uint32_t *) ctx->tk.list,
-                        (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), out_cap, sx_g);
-            }
-          ng += 1;
-          continue;
-        }
+      const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0, gstart[g], gstart[g] + region };
       if (fast)                                          // entries with usable tokens: walked from the tokens
         { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
           DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
@@ -2723,12 +2511,12 @@ layout:
             DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX, fast_grid(ctx, m), FAST_BLOCK,
                       ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
                       ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g);
           else
             DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K, fast_grid(ctx, m), FAST_BLOCK,
                       ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
                       ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g, lb_chain{ NULL, NULL, NULL, NULL, NULL }, follow_copy{});
+                      (uint8_t *) NULL, (uint64_t) 0, sx_g);
         }
       if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
         { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;
@@ -2743,11 +2531,6 @@ layout:
       DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
       // side stream: offsets of this group (continuing where the last one ended), then its compaction
       DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g & 7], 0));
-      if (hybrid && g == G - 2)                          // ... and the offsets of the direct group after this one
-        rc = onepass_side(ctx, B, COMPACT_WAVES_PER_CU, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
-                          b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp,
-                          d_size + gb[G - 1], gb[G] - gb[G - 1], d_rec_off + gb[G - 1], d_base + (ng & 1), off_done);
-      else
       rc = onepass_side(ctx, B, COMPACT_WAVES_PER_CU, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
                         b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp);
       (void) hipEventRecord(cmp_done[g & 7], B);
@@ -2757,8 +2540,8 @@ layout:
     { (void) hipStreamSynchronize(B);
       return rc;
     }
-  (void) hipEventRecord(done, follow && !beside ? A : B);
-  ctx->route.groups = ng; ctx->route.direct = follow ? 3 : 0; ctx->route.tokens = fast ? 1 : 0;
+  (void) hipEventRecord(done, B);
+  ctx->route.groups = ng; ctx->route.direct = 0; ctx->route.tokens = fast ? 1 : 0;
   ctx->route.region_bytes = region; ctx->route.scratch_bytes = ctx->scratch_bytes;
   ctx->route.token_bytes = fast ? 4ull * ctx->tk.cap_tokens : 0;
   ctx->route.text_entries = fast ? ctx->tk.unusable : n;
@@ -2781,17 +2564,12 @@ static int onepass_end(dx_ctx *ctx, uint64_t *total)
   uint32_t st  = 0;
   DX_HIP(ctx, hipSetDevice(ctx->device));
   (void) hipStreamWaitEvent(A, ctx->ev[16], 0);          // the caller's stream sees the finished output
-  uint64_t waits[3] = { 0, 0, 0 };
-  if (ctx->route.direct == 3)                            // follow route: what its placements had to wait for
-    (void) hipMemcpyAsync(waits, ctx->d_u64 + 40, 24, hipMemcpyDeviceToHost, A);
   if (hipMemcpyAsync(&tot, ctx->op.d_total, 8, hipMemcpyDeviceToHost, A) != hipSuccess ||
       hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A) != hipSuccess ||
       hipStreamSynchronize(A) != hipSuccess)
     return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
   if (total) *total = tot;
-  ctx->route.chain_waits[0] = waits[0]; ctx->route.chain_waits[1] = waits[1]; ctx->route.chain_waits[2] = waits[2];
-  if (st & 32u)
-    return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: a record's predecessors never all reported their sizes (follow route, %u looks)", LB_SPIN_LIMIT);
+  ctx->route.chain_waits[0] = ctx->route.chain_waits[1] = ctx->route.chain_waits[2] = 0;
   if (st & DX_ST_INDEX)
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry's offsets, length or scratch / token slot do not hold together "
                    "(d_off / d_len beyond text_bytes, or an internal index is corrupt)");

@@ -15,9 +15,6 @@
 #ifndef FAST_SKIP
 #define FAST_SKIP 0
 #endif
-#ifndef FOLLOW_SKIP
-#define FOLLOW_SKIP 0                                    // (experiments on the follow route: 1 no copy, 2 no look-back)
-#endif
 #define TOK_TP 8u                                        // tokens a lane takes per pass (one 16-byte load)
 
 struct tok_src
@@ -275,8 +272,7 @@ __device__ __forceinline__ uint32_t token_bits(const uint16_t *tok, uint32_t cnt
 }
 
 
-// the five segment sizes of one entry from its tokens and its plain lines (what k_qv_sizes_fast stores; the chained
-// encoder computes them for itself): sz[0..4] = del words, tag bytes, ins, mrg, sub words
+// the five segment sizes of one entry from its tokens and its plain lines (what k_qv_sizes_fast stores): sz[0..4] = del words, tag bytes, ins, mrg, sub words
 __device__ __forceinline__ void entry_sizes_fast(const qv_args &a, uint64_t r, uint32_t L, const uint32_t *inf, uint64_t toff, uint64_t tend,
                                                  const tok_src &tk, const uint32_t (*s_tok)[256], const uint8_t (*s_len)[256],
                                                  bool over, uint32_t *sz)
@@ -331,231 +327,11 @@ __device__ __forceinline__ void entry_sizes_fast(const qv_args &a, uint64_t r, u
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-//  chained placement (decoupled look-back): no scratch slots, no compaction
-// ---------------------------------------------------------------------------------------------
-// The waves draw entries in file order.  A wave first computes its entry's five sizes (the cheap size code above:
-// token and symbol LENGTHS only), publishes the record's size in a 64-bit status word -- flag and value in one
-// store, so the word needs no ordering with anything else -- then sums the words of the entries before it back to
-// the nearest one that already holds its inclusive prefix, 64 predecessors per look, and publishes its own prefix.
-// Because sizes are published BEFORE the entry is encoded, nobody ever waits for an encode: the chain runs a size
-// phase ahead of the encoders however ragged the entry lengths are.  The record is then written in place.
-// Every drawn entry is published by a resident, running wave and no wave waits for a later entry, so the spin
-// below ends; it is bounded all the same (status bit 32: the host reports the failure).
-struct lb_chain
-{ unsigned long long *status;       // n words, zeroed: bits 63..62: 0 nothing yet, 1 the record's size, 2 its inclusive prefix; low 62 bits: the value
-  uint64_t           *rec_off;      // n + 1, written here
-  uint32_t           *seg;          // n x 5, written here
-  const uint32_t     *rec_size;     // record sizes of the entries on the unusable list (k_qv_sizes in list mode)
-  unsigned long long *waits;        // [0] looks that met a word not yet published, [1] entries with such a look, [2] most such looks of one entry
-};
-#define LB_SIZE   (1ull << 62)
-#define LB_PREFIX (2ull << 62)
-#define LB_VALUE  ((1ull << 62) - 1ull)
-#define LB_SPIN_LIMIT (1u << 22)
-
-__device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
-{ for (int d = 32; d >= 1; d >>= 1)
-    v += __shfl_xor(v, d);
-  return v;
-}
-
-// publishes `own`, returns the sum of the records before entry r; *failed set when the spin gave up
-__device__ __forceinline__ uint64_t chain_place(const lb_chain &lb, uint64_t r, uint64_t own, uint32_t *status_flags)
-{ const int lane = lane_id();
-  if (lane == 0)
-    __hip_atomic_store(&lb.status[r], LB_SIZE | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint64_t excl = 0, j = r;                               // entries [j, r) are in excl
-  uint32_t polls = 0;
-  while (j > 0)
-    { unsigned long long v = LB_PREFIX;                   // before entry 0: prefix 0
-      if ((uint64_t) lane < j)
-        v = __hip_atomic_load(&lb.status[j - 1 - (uint64_t) lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t flag = (uint32_t) (v >> 62);
-      const uint64_t mP = __ballot(flag == 2u), mE = __ballot(flag == 0u);
-      const int firstP = mP ? __ffsll((unsigned long long) mP) - 1 : 64, firstE = mE ? __ffsll((unsigned long long) mE) - 1 : 64;
-      const int upto   = firstP < firstE ? firstP + 1 : firstE;       // lanes [0, upto) hold sizes (the last one a prefix)
-      excl += wave_sum64(lane < upto ? (uint64_t) (v & LB_VALUE) : 0ull);
-      if (firstP < firstE) break;                         // reached an inclusive prefix
-      j -= (uint64_t) upto;
-      if (upto == 0)
-        { polls += 1;
-          if (polls > LB_SPIN_LIMIT)
-            { if (lane == 0) atomicOr(status_flags, 32u);
-              break;
-            }
-          __builtin_amdgcn_s_sleep(4);
-        }
-    }
-  if (lane == 0)
-    { __hip_atomic_store(&lb.status[r], LB_PREFIX | (excl + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (polls && lb.waits)
-        { atomicAdd(&lb.waits[0], (unsigned long long) polls);
-          atomicAdd(&lb.waits[1], 1ull);
-          atomicMax(&lb.waits[2], (unsigned long long) polls);
-        }
-    }
-  return excl;
-}
-
-// ---------------------------------------------------------------------------------------------
-//  compaction inside the encoder ("follow"): no second kernel, no groups, no tail
-// ---------------------------------------------------------------------------------------------
-// The scratch route as above -- an entry is coded into its slot, its five sizes turn out -- but the wave that coded
-// an entry also moves it to its place in the record stream, one entry LATER: when it has coded its next entry.  By
-// then the entries before it (drawn before it, so coded at about the same time) have published their sizes, and the
-// record's offset is the sum of those: of the sizes of its own tile of 64 entries (one load per lane) and of the
-// tiles before, whose sums and prefixes are kept in one status word per tile exactly as in lb_chain -- whoever sees a
-// tile complete publishes its sum, whoever has worked out a prefix publishes it.  Every word (a size with its READY
-// bit, a tile's flag and value) is stored by ONE atomic store and means the same whoever wrote it: no ordering between
-// words is needed, so no release fence -- which at agent scope writes back the L2's dirty lines, the slots among them.
-// The slot is read back by the wave that wrote it (no other wave ever looks at it): program order, no fence either.
-// No wave waits before it has published what it coded, and a wave placing entry P only waits for entries below P, which
-// other waves are coding or have coded: the lowest unpublished entry is always being coded, the waits end (they are
-// bounded all the same: status bit 5).
-struct follow_copy
-{ uint32_t           *size;       // n words: record size | FC_READY once the entry's slot is complete (zeroed before the launch)
-  unsigned long long *tile;       // a word per 64 entries: LB_SIZE | their sizes added, or LB_PREFIX | all records up to the tile's end
-  uint64_t           *rec_off;    // n + 1, written here (absolute)
-  const uint64_t     *base;       // *base: where this launch's first record starts in d_out
-  unsigned long long *total;      // *total = *base + the records of this launch (the wave that places the last entry writes it)
-  const uint8_t      *hdr;        // framing bytes
-  uint8_t            *out;
-  uint64_t            out_cap;
-  unsigned long long *waits;      // as lb_chain.waits
-};
-#define FC_READY 0x80000000u
-
-// sizes of the 64 entries of tile t, a lane each (beyond n: 0, ready)
-__device__ __forceinline__ uint32_t fc_tile_sizes(const follow_copy &fc, uint64_t t, uint64_t n)
-{ const uint64_t e = 64ull * t + (uint64_t) lane_id();
-  return e < n ? __hip_atomic_load(&fc.size[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FC_READY;
-}
-
-// bytes of the launch's records before entry r; false: gave up waiting (status bit 5).
-// Atomics on one address -- and on neighbouring words, which share a memory channel -- retire one every ~11 ns chip-wide:
-// a first version in which every wave published its tile's sum (compare-and-swap) and the prefix before it (store) spent
-// 20 ms per 500 k entries on those two million operations.  Now a tile's word is stored by the wave that places the
-// tile's LAST entry (the inclusive prefix) and, while it is still empty, by the few waves that had to work the prefix
-// out for themselves; everybody else only loads.
-__device__ __forceinline__ bool fc_offset(const follow_copy &fc, uint64_t r, uint64_t n, uint32_t *status, uint64_t &excl)
-{ const int      lane = lane_id();
-  const uint64_t t = r >> 6;
-  const uint32_t j = (uint32_t) (r & 63u);
-  uint32_t polls = 0;
-  uint64_t inner = 0;
-  for (;;)                                               // the entries of r's own tile before r
-    { const uint32_t v     = fc_tile_sizes(fc, t, n);
-      const uint64_t ready = __ballot((v & FC_READY) != 0u);
-      const uint64_t need  = j ? (~0ull >> (64u - j)) : 0ull;
-      if ((ready & need) == need)
-        { inner = wave_sum64(lane < (int) j ? (uint64_t) (v & ~FC_READY) : 0ull);
-          break;
-        }
-      if (++polls > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(status, 32u); return false; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-  uint64_t P = 0, u = t;                                 // the records of tiles [u, t) are in P
-  bool     first_empty = false;                          // tile t - 1's word was empty when we looked
-  while (u > 0)
-    { unsigned long long w = LB_PREFIX;                  // before tile 0: prefix 0
-      if ((uint64_t) lane < u && lane < 16)              // the sixteen tiles before u
-        w = __hip_atomic_load(&fc.tile[u - 1 - (uint64_t) lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (lane >= 16)
-        w = 0ull;
-      const uint64_t mP = __ballot((uint32_t) (w >> 62) == 2u) & 0xffffull;
-      const int      d  = mP ? __ffsll((unsigned long long) mP) - 1 : 16;       // nearest tile with a prefix: u - 1 - d
-      if (u == t) first_empty = d != 0;
-      if (d < 16)
-        P += __shfl(w & LB_VALUE, d);
-      const uint64_t upto = d < 16 ? (uint64_t) d : (u < 16 ? u : 16);          // tiles u - 1 ... u - upto go by their sizes
-      for (uint64_t k = 0; k < upto; )
-        { const uint32_t v = fc_tile_sizes(fc, u - 1 - k, n);
-          if (__ballot((v & FC_READY) != 0u) == ~0ull)
-            { P += wave_sum64((uint64_t) (v & ~FC_READY));
-              k += 1;
-            }
-          else
-            { if (++polls > LB_SPIN_LIMIT) { if (lane == 0) atomicOr(status, 32u); return false; }
-              __builtin_amdgcn_s_sleep(8);
-            }
-        }
-      if (d < 16) break;
-      u -= upto;
-    }
-  if (lane == 0)
-    { if (t > 0 && first_empty)                          // everything before tile t: tile t - 1's inclusive prefix
-        __hip_atomic_store(&fc.tile[t - 1], LB_PREFIX | P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (polls && fc.waits)
-        { atomicAdd(&fc.waits[0], (unsigned long long) polls);
-          atomicAdd(&fc.waits[1], 1ull);
-          atomicMax(&fc.waits[2], (unsigned long long) polls);
-        }
-    }
-  excl = P + inner;
-  return true;
-}
-
-// entry r (its slot complete, its size published) to its place in the record stream: what k_qv_compact does for it
-// (base0 = *fc.base, read ONCE per wave: the word shares its 128-byte line with the ticket counter, and a load of a line
-// the whole chip is drawing tickets from waits behind those atomics -- read per entry it made the kernel four times slower)
-__device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a, const enc_scratch &sc, const uint64_t *hdr_off,
-                                         uint64_t r, uint32_t *status, uint64_t base0)
-{ const int lane = lane_id();
-  uint64_t excl = 0;
-  if (FOLLOW_SKIP & 2) excl = 0;                         // (experiments: no look-back; 1: no copy)
-  else
-  if (!fc_offset(fc, r, a.n, status, excl))
-    return;
-  const uint64_t own = (uint64_t) (__hip_atomic_load(&fc.size[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~FC_READY);
-  const uint64_t at  = base0 + excl;
-  if (lane == 0)
-    { if ((r & 63u) == 63u)                              // the tile's last entry: its inclusive prefix
-        __hip_atomic_store(&fc.tile[r >> 6], LB_PREFIX | (excl + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      fc.rec_off[r] = at;
-      if (r + 1 == a.n)
-        { fc.rec_off[a.n] = at + own;
-          *fc.total = at + own;
-        }
-    }
-  if (at + own > fc.out_cap)                             // d_out is too small: report, never overrun
-    { if (lane == 0) atomicOr(status, 8u);
-      return;
-    }
-  if (FOLLOW_SKIP & 1) return;
-  // (the five sizes by agent-scope loads: on the forwarding route another XCD's wave wrote them, and their line also
-  // holds the neighbouring entries' sizes, which a cached copy of it would show as they were)
-  uint32_t sg[5];
-  { uint32_t v = 0;
-    if (lane < 5) v = __hip_atomic_load(sc.seg_out + 5 * r + (uint64_t) lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int k = 0; k < 5; k++) sg[k] = __builtin_amdgcn_readlane(v, k);
-  }
-  const uint8_t  *src = sc.base + sc.slot_off[r];
-  uint8_t        *dst = fc.out + at;
-  if (fc.hdr != NULL)
-    { const uint64_t h0 = hdr_off[r];
-      const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
-      for (uint32_t k = (uint32_t) lane; k < hl; k += 64)
-        dst[k] = fc.hdr[h0 + k];
-      dst += hl;
-    }
-  const uint32_t s0 = sg[0], s1 = sg[1], s234 = sg[2] + sg[3] + sg[4];
-  wave_copy(dst, src, s0);
-  wave_copy(dst + s0, sc.base + sc.slot_off[r + 1] - tag_room(a.len[r]), s1);
-  wave_copy(dst + s0 + s1, src + s0, s234);
-}
-
 #ifndef FAST_GUARDS
 #define FAST_GUARDS 0
 #endif
 #ifndef FAST_TICKET
 #define FAST_TICKET 2u                                   // entries a wave draws at a time
-#endif
-#ifndef FOLLOW_BATCH
-#define FOLLOW_BATCH 4u                                  // entries a wave of k_qv_follow draws at a time
-#endif
-#ifndef FOLLOW_TICKET
-#define FOLLOW_TICKET 1u                                 // ... on the follow route
 #endif
 #ifndef FAST_WAVES
 #define FAST_WAVES 4                                     // waves per SIMD the register allocation leaves room for
@@ -570,27 +346,16 @@ __device__ __forceinline__ void fc_place(const follow_copy &fc, const qv_args &a
 // whose four encoder waves leave 64 of the 512 registers, i.e. at <= 112 each.  The plain instance has 110; with the
 // index code compiled in it had 116 (-> 120 allocated) even when no index was asked for, the two kernels ran one
 // after the other, and a step took 32.7 ms instead of 31.0.
-// CHAIN: chained placement (lb): sizes first, record offset by look-back, record written in place.
-// FOLLOW: scratch route with the compaction inside (fc): see follow_copy.
-template <bool SUB, bool CHAIN, int FOLLOW = 0>          // FOLLOW: 0 off, 1 this kernel's waves place the records, 2 forwarding (k_qv_follow does)
+template <bool SUB>
 __global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
                       enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
                       const uint8_t *hdr, const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint64_t out_cap,
-                      sub_sink sx, lb_chain lb, follow_copy fc)
+                      sub_sink sx)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint32_t s_pair[2][PAIR_SIZE];
   __shared__ uint8_t  s_tagcode[256];
-  __shared__ uint8_t  s_len[CHAIN ? 6 : 1][256];           // code lengths per symbol / run value (the size phase)
-  if (CHAIN)
-    for (int k = threadIdx.x; k < 6 * 256; k += (int) blockDim.x)
-      { const uint32_t e = g_tok[k];
-        uint32_t l = TOK_LEN(e) + ((k >= 4 * 256 && TOK_ESC(e)) ? 16u : 0u);
-        if ((a.delChar >= 0 && k == DX_DEL * 256 + a.delChar) || (a.subChar >= 0 && k == DX_SUB * 256 + a.subChar))
-          l = 0;
-        (&s_len[0][0])[k] = (uint8_t) l;
-      }
   __shared__ __attribute__((aligned(16))) uint32_t s_win[FAST_NWAVE][QV_WIN_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t s_tag[FAST_NWAVE][TAG_WIN_WORDS];
   load_tables(s_tok, g_tok);
@@ -599,47 +364,28 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   const int lane = lane_id();
   const int wid  = threadIdx.x >> 6;
 
-  // FOLLOW, fc.out == NULL: forwarding -- the slots are written through to memory and the sizes published once they are
-  // there; k_qv_follow, started beside this kernel, places the records (fc.out given: this kernel's waves do, fc_place)
-  const bool FWD = FOLLOW == 2;
   wave_out o, ot;
-  o.wt = ot.wt = FWD;
   o.win  = s_win[wid];
   ot.win = s_tag[wid];
   for (int j = lane; j < QV_WIN_WORDS; j += 64)  o.win[j]  = 0;
   for (int j = lane; j < TAG_WIN_WORDS; j += 64) ot.win[j] = 0;
   wave_sync();
 
-  // (chained placement: an entry is drawn only when its wave is ready to size and publish it -- an entry held in
-  // reserve behind a whole encode keeps every later entry of the file waiting for its size: 97 ms instead of 14)
-  // Entries are drawn FAST_TICKET at a time: every draw is an atomic on ONE address, ~11 ns each chip-wide whoever asks
+  // Entries are drawn a few at a time (a.units): every draw is an atomic on ONE address, ~11 ns each chip-wide whoever asks
   // (a kernel doing nothing but drawing its 500 k tickets takes 5.8 ms), so a million single draws are 11 ms of the
   // counter's time inside a 13.7 ms kernel.
-  const uint32_t TB = CHAIN ? 1u : (FOLLOW ? (FWD ? FAST_TICKET : FOLLOW_TICKET) : a.units);
-  uint64_t pend = ~0ull;                                 // (FOLLOW) the entry coded before this one: placed once this one is coded
-  const uint64_t base0 = FOLLOW == 1 ? uniform64(*fc.base) : 0ull;
-#define FOLLOW_NEXT(x) { if (FOLLOW == 1) { if (!(FOLLOW_SKIP & 4) && pend != ~0ull) fc_place(fc, a, sc, hdr_off, pend, status, base0); pend = (x); } }
-  for (uint64_t r0 = next_unit(ticket, TB), nxt = 0; r0 < a.n; r0 = CHAIN ? next_unit(ticket) : nxt)
-  { if (!CHAIN) nxt = next_unit(ticket, TB);
+  const uint32_t TB = a.units;
+  for (uint64_t r0 = next_unit(ticket, TB), nxt = 0; r0 < a.n; r0 = nxt)
+  { nxt = next_unit(ticket, TB);
   for (uint64_t r = r0; r < r0 + TB && r < a.n; r++)
     {
       if (tok_unusable(tk.info, r, a.delChar, a.subChar))
-        { if (CHAIN)                                     // its size (k_qv_sizes, list mode) takes its place in the chain all the same
-            { const uint64_t own  = lb.rec_size[r];
-              const uint64_t excl = chain_place(lb, r, own, status);
-              if (lane == 0)
-                { lb.rec_off[r] = excl;
-                  if (r + 1 == a.n) lb.rec_off[a.n] = excl + own;
-                }
-            }
-          if (FOLLOW) FOLLOW_NEXT(r)                     // (the generic kernel has coded it into its slot BEFORE this launch)
-          continue;                                      // the generic kernel encodes this entry from the text
-        }
+        continue;                                        // the generic kernel encodes this entry from the text
       // Two modes.  Scratch (sc.base != NULL): the entry goes into its slot, the sizes it turns out to have are
       // recorded.  Direct: the sizes are known (k_qv_sizes_fast), the record is written where it belongs --
       // framing bytes, del words, tag bytes, ins, mrg, sub words (QV.c:1393-1423) -- and every size is checked.
-#define SEG_OUT(k, v) { if (FWD) __hip_atomic_store(sgw + (k), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else sgw[k] = (v); }
-      const bool      S      = !CHAIN && sc.base != NULL;
+#define SEG_OUT(k, v) { sgw[k] = (v); }
+      const bool      S      = sc.base != NULL;
       const uint32_t  L      = a.len[r];
       const uint32_t *inf    = tk.info + TOK_INFO * r;
       const uint64_t  toff   = tk.off[r];
@@ -661,32 +407,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
       const uint32_t *sg     = seg + 5 * r;              // (direct mode)
       uint32_t       *sgw    = sc.seg_out + 5 * r;       // (scratch mode)
       uint8_t        *dst, *tag_at;
-      uint32_t        sz[5]  = { 0u, 0u, 0u, 0u, 0u };   // (chained mode: the sizes, wave-uniform)
-      if (CHAIN)
-        { entry_sizes_fast(a, r, L, inf, toff, tk.off[r + 1], tk, s_tok, s_len, can_overread(a, line_ptr(a, r, L, 4), L), sz);
-          const uint32_t hl   = hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u;
-          const uint64_t own  = (uint64_t) hl + sz[0] + sz[1] + sz[2] + sz[3] + sz[4];
-          const uint64_t excl = chain_place(lb, r, own, status);
-          if (lane == 0)
-            { lb.rec_off[r] = excl;
-              if (r + 1 == a.n) lb.rec_off[a.n] = excl + own;
-              uint32_t *w = lb.seg + 5 * r;
-              w[0] = sz[0]; w[1] = sz[1]; w[2] = sz[2]; w[3] = sz[3]; w[4] = sz[4];
-            }
-          if (excl + own > out_cap)                      // d_out is too small: report, never overrun
-            { if (lane == 0) atomicOr(status, 8u);
-              continue;
-            }
-          dst = out + excl;
-          if (hdr != NULL)                               // record framing (dexqv.c:128-139)
-            { const uint64_t h0 = hdr_off[r];
-              for (uint32_t k = (uint32_t) lane; k < hl; k += 64)
-                dst[k] = hdr[h0 + k];
-              dst += hl;
-            }
-          tag_at = dst + sz[0];
-        }
-      else if (S)
+      if (S)
         { dst    = sc.base + sc.slot_off[r];
           tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
         }
@@ -760,7 +481,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               if (q == 0)
                 { const uint32_t tb = finish_tags(ot);
                   if (S) { if (lane == 0) SEG_OUT(1, tb) sum += tb; }
-                  else   { const uint32_t w1 = CHAIN ? sz[1] : sg[1]; bad |= tb ^ w1; dst += w1; }
+                  else   { const uint32_t w1 = sg[1]; bad |= tb ^ w1; dst += w1; }
                 }
             }
           else                                           // Encode
@@ -769,9 +490,8 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               const uint32_t m4   = mask * 0x01010101u;
               uint32_t pos = 16u * lane;
               u32x4 c = fetch(p, pos, L, over);
-              // (wanted at the line's end, requested now: a memory round trip less per line; not in the forwarding instance, which
-              //  has no register to spare beside k_qv_follow)
-              const uint32_t lastb = !FWD && L ? (uint32_t) p[L - 1] : 0u;
+              // (wanted at the line's end, requested now: a memory round trip less per line)
+              const uint32_t lastb = L ? (uint32_t) p[L - 1] : 0u;
 #define PLAIN_LOOP(STAB)                                                                        \
               for (uint32_t base = 0; base < L; base += DX_STEP)                                 \
                 { const u32x4 d = fetch_step(p, base + DX_STEP, L, over);                        \
@@ -805,12 +525,12 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               else             { PLAIN_LOOP(s_stok[q]) }
 #undef PAIR_LOOP
 #undef PLAIN_LOOP
-              got = finish_words(o, FWD ? last_piece_plain(tab, p, L, mask) : last_piece_byte(tab, lastb, L, mask));
+              got = finish_words(o, last_piece_byte(tab, lastb, L, mask));
               if (q == 0)                                // no delChar: the whole tag line is packed
                 { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
                   const uint32_t tb = encode_all_tags(ot, p1, L, over);
                   if (S) { if (lane == 0) SEG_OUT(1, tb) sum += tb; }
-                  else   { const uint32_t w1 = CHAIN ? sz[1] : sg[1]; bad |= tb ^ w1; dst += w1; }
+                  else   { const uint32_t w1 = sg[1]; bad |= tb ^ w1; dst += w1; }
                 }
             }
           if (S)
@@ -818,56 +538,22 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               sum += got;
             }
           else
-            bad |= got ^ (CHAIN ? (q == 0 ? sz[0] : q == 1 ? sz[2] : q == 2 ? sz[3] : sz[4]) : sg[line]);
+            bad |= got ^ sg[line];
           dst += got;
         }
       if (S)
         { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
           const uint32_t rec = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
           if (lane == 0)
-            { if (FWD) __builtin_amdgcn_s_waitcnt(0x0F70);     // every byte of the slot and its five sizes is in memory: only then the word that says so
-              if (FOLLOW && !(FOLLOW_SKIP & 8)) __hip_atomic_store(&sc.rec_size[r], rec | FC_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              else        sc.rec_size[r] = rec;
-            }
+            sc.rec_size[r] = rec;
         }
       if (bad && lane == 0)
         atomicOr(status, 2u);                            // slot overflow / a size differs from what k_qv_sizes_fast computed
-      if (FOLLOW) FOLLOW_NEXT(r)
     }
   }
-  if (FOLLOW == 1 && !(FOLLOW_SKIP & 4) && pend != ~0ull)
-    fc_place(fc, a, sc, hdr_off, pend, status, base0);
-#undef FOLLOW_NEXT
 #undef SEG_OUT
 }
 
-
-// ---------------------------------------------------------------------------------------------
-//  k_qv_follow: the compaction BESIDE the encoder, entry by entry as the sizes come in
-// ---------------------------------------------------------------------------------------------
-// Started on the side stream together with the forwarding encoder (see FWD above).  Its waves draw entries in file order,
-// wait for an entry's size word -- and, in fc_offset, for those of the entries before it -- and move the record from its
-// slot to its place.  What makes that safe without a fence: the encoder writes a slot through to memory (sc1 stores),
-// waits until they have all arrived, and only then stores the size word; slots are whole 128-byte lines, so no line this
-// kernel has read before holds bytes of an entry it has yet to read; sizes and tile words are read past the caches.
-// The waves of this kernel never hold up an encoder wave, whatever they wait for; the encoder waits for nobody.
-__global__ __launch_bounds__(DX_BLOCK, 7)               // (72 registers: room beside four forwarding-encoder waves of 104)
-void k_qv_follow(qv_args a, enc_scratch sc, const uint64_t *hdr_off, follow_copy fc, uint32_t *status, uint32_t *ticket)
-{ const uint64_t base0 = uniform64(*fc.base);
-  for (uint64_t r0 = next_unit(ticket, FOLLOW_BATCH), nxt; r0 < a.n; r0 = nxt)
-  { nxt = next_unit(ticket, FOLLOW_BATCH);
-    for (uint64_t r = r0; r < r0 + FOLLOW_BATCH && r < a.n; r++)
-      { uint32_t polls = 0;
-        for (;;)                                           // the entry itself
-          { const uint32_t v = uniform(__hip_atomic_load(&fc.size[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (v & FC_READY) break;
-            if (++polls > LB_SPIN_LIMIT) { if (lane_id() == 0) atomicOr(status, 32u); return; }
-            __builtin_amdgcn_s_sleep(100);
-          }
-        fc_place(fc, a, sc, hdr_off, r, status, base0);
-      }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 //  k_qv_sizes_fast: the five segment sizes of every entry, from the tokens and the two plain lines

@@ -289,9 +289,9 @@ int dx_qv_encode_onepass_end(dx_ctx *ctx, uint64_t *total);
  * text_entries = entries the text-reading encoder took because their tokens could not be used (a byte >= 128 in a
  * run-coded line, more tokens than the slot holds).                                                              */
 typedef struct
-  { int32_t  groups, direct, tokens, reserved;        /* direct: 0 slots + compaction, 1 sizes first (own kernel), 2 chained placement */
+  { int32_t  groups, direct, tokens, reserved;        /* direct: 0 slots + compaction, 1 sizes first (own kernel) */
     uint64_t region_bytes, scratch_bytes, avail_bytes, token_bytes, text_entries;
-    uint64_t chain_waits[3];                          /* chained placement: looks that met an unpublished word, entries with one, most of one entry */
+    uint64_t chain_waits[3];                          /* always 0 (the routes that reported here are gone; kept for the layout) */
   } dx_onepass_info;
 int dx_qv_onepass_info(const dx_ctx *ctx, dx_onepass_info *out);
 

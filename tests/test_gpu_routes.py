@@ -100,56 +100,6 @@ def test_budget_env_overrides_and_route_is_reported(monkeypatch):
         assert ctx.dexqv(small.text) == O.dexqv(small.text)         # the file driver under the same budget
 
 
-def test_chained_placement_writes_the_same_stream(monkeypatch):
-    """DEXGPU_CHAIN: sizes first, record offsets by a decoupled look-back over per-entry status words, records written in
-    place -- no scratch slots, no compaction.  Same bytes as the slot route, on ragged lengths, with entries whose
-    tokens cannot be used in the chain (bytes >= 128 in a run-coded line: their sizes and records come from the
-    text-reading kernels) and with a d_out that is too small (DX_E_SPACE, nothing overrun)."""
-    with api.Context(0) as ctx:
-        c = Corpus(ctx, n=60_000, mean=6000)
-        ref, info0, _ = c.encode(ctx, 0)
-        monkeypatch.setenv("DEXGPU_CHAIN", "1")
-        got, info, _ = c.encode(ctx, 0)
-        assert info["direct"] == 2 and info["groups"] == 0
-        assert len(got) == len(ref) and (got == ref).all()
-        rec_chain = c.d_rec.download(np.uint64, c.n + 1)
-        seg_chain = c.d_seg.download(np.uint32, 5 * c.n)
-        monkeypatch.delenv("DEXGPU_CHAIN")
-        c.encode(ctx, 0)
-        assert (c.d_rec.download(np.uint64, c.n + 1) == rec_chain).all()       # the same index beside the stream
-        assert (c.d_seg.download(np.uint32, 5 * c.n) == seg_chain).all()
-        # a too small d_out: reported, nothing beyond it touched
-        monkeypatch.setenv("DEXGPU_CHAIN", "1")
-        p = ctx.qv_prescan(c.batch)
-        hist, tot = ctx.qv_hist(c.batch, p)
-        ctx.qv_set_coding(api.qv_build(hist, tot, p, False), False)
-        cap = len(ref) // 2
-        d_out = ctx.to_device(np.full(cap + 4096, 0xEE, np.uint8))
-        with pytest.raises(L.DexGPUError) as e:
-            ctx.qv_encode_onepass(c.batch, c.d_hdr, c.d_hoff, c.d_seg, c.d_rec, d_out, cap)
-        assert e.value.code == -8
-        assert (d_out.download(np.uint8, 4096, offset=cap) == 0xEE).all()
-
-
-def test_chained_placement_small_files_and_text_entries(monkeypatch):
-    monkeypatch.setenv("DEXGPU_CHAIN", "1")
-    with api.Context(0) as ctx:
-        for seed, n, mean in ((3, 1, 50), (4, 7, 3000), (5, 300, 900)):
-            c = synth.make_quiva(n, seed=seed, mean=mean)
-            assert ctx.dexqv(c.text) == O.dexqv(c.text)
-        c = synth.make_quiva(120, seed=9, mean=5000)                    # bytes >= 128: those entries go by the text-reading kernels
-        txt = bytearray(c.text)
-        for i in (3, 50, 51, 119):
-            L_, o = int(c.len[i]), int(c.off[i])
-            txt[o + 4 * (L_ + 1) + 7] = 200                            # substitution line
-        got = ctx.dexqv(bytes(txt))
-        assert got == O.dexqv(bytes(txt))
-        info = ctx.qv_onepass_info()
-        assert info["direct"] == 2 and info["text_entries"] == 4
-        for case in O.cases("quiva"):                                   # the reference's own bytes
-            assert ctx.dexqv(O.golden(case["input"] + ".quiva"), "-l" in case["flags"]) == O.golden(case["name"] + ".dexqv")
-
-
 _POISON_SCRIPT = r"""
 import sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
@@ -185,71 +135,3 @@ def test_poisoned_allocations_change_nothing(poison):
     code = _POISON_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DEXGPU_POISON=poison), capture_output=True, timeout=600)
     assert r.returncode == 0 and b"POISON_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
-
-
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_follow_route_writes_the_same_stream(monkeypatch, mode):
-    """DEXGPU_FOLLOW: the encoder moves every record from its scratch slot to its place itself, one entry behind its
-    coding (follow_copy, dx_qv_fast.hpp) -- no compaction kernel.  Same bytes, same index beside them, as the route with
-    the compaction kernel: ragged lengths, several groups in one region (a scratch budget), entries that come by the
-    text-reading kernel, a d_out that is too small."""
-    with api.Context(0) as ctx:
-        c = Corpus(ctx, n=60_000, mean=6000)
-        ref, info0, _ = c.encode(ctx, 0)
-        rec_ref = c.d_rec.download(np.uint64, c.n + 1)
-        seg_ref = c.d_seg.download(np.uint32, 5 * c.n)
-        monkeypatch.setenv("DEXGPU_FOLLOW", mode)           # 1: the encoder's waves place the records, 2: k_qv_follow beside the encoder
-        for budget in (0, 600 << 20 if mode == "1" else 1200 << 20):
-            got, info, _ = c.encode(ctx, budget)
-            assert info["direct"] == 3 and (info["groups"] == 1 if budget == 0 else info["groups"] > 1), info
-            assert len(got) == len(ref) and (got == ref).all()
-            assert (c.d_rec.download(np.uint64, c.n + 1) == rec_ref).all()
-            assert (c.d_seg.download(np.uint32, 5 * c.n) == seg_ref).all()
-        ctx.set_scratch_budget(0)
-        p = ctx.qv_prescan(c.batch)
-        hist, tot = ctx.qv_hist(c.batch, p)
-        ctx.qv_set_coding(api.qv_build(hist, tot, p, False), False)
-        cap = len(ref) // 2
-        d_out = ctx.to_device(np.full(cap + 4096, 0xEE, np.uint8))
-        with pytest.raises(L.DexGPUError) as e:
-            ctx.qv_encode_onepass(c.batch, c.d_hdr, c.d_hoff, c.d_seg, c.d_rec, d_out, cap)
-        assert e.value.code == -8
-        assert (d_out.download(np.uint8, 4096, offset=cap) == 0xEE).all()
-
-
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_follow_route_small_files_and_text_entries(monkeypatch, mode):
-    monkeypatch.setenv("DEXGPU_FOLLOW", mode)
-    with api.Context(0) as ctx:
-        for seed, n, mean in ((3, 1, 50), (4, 7, 3000), (5, 300, 900), (6, 65, 100), (7, 129, 2000)):
-            c = synth.make_quiva(n, seed=seed, mean=mean)
-            assert ctx.dexqv(c.text) == O.dexqv(c.text)
-        c = synth.make_quiva(120, seed=9, mean=5000)                    # bytes >= 128: those entries go by the text-reading kernel
-        txt = bytearray(c.text)
-        for i in (3, 50, 51, 119):
-            L_, o = int(c.len[i]), int(c.off[i])
-            txt[o + 4 * (L_ + 1) + 7] = 200                            # substitution line
-        got = ctx.dexqv(bytes(txt))
-        assert got == O.dexqv(bytes(txt))
-        info = ctx.qv_onepass_info()
-        assert info["direct"] == 3 and info["text_entries"] == 4
-        for case in O.cases("quiva"):                                   # the reference's own bytes
-            assert ctx.dexqv(O.golden(case["input"] + ".quiva"), "-l" in case["flags"]) == O.golden(case["name"] + ".dexqv")
-
-
-def test_hybrid_route_writes_the_same_stream(monkeypatch):
-    """DEXGPU_HYBRID: the last group goes the direct way (sizes on the side stream beside the first group's encode, records
-    written in place beside its compaction).  Same bytes and the same index beside them, also in more than two groups."""
-    with api.Context(0) as ctx:
-        c = Corpus(ctx, n=60_000, mean=6000)
-        ref, info0, _ = c.encode(ctx, 0)
-        rec_ref = c.d_rec.download(np.uint64, c.n + 1)
-        seg_ref = c.d_seg.download(np.uint32, 5 * c.n)
-        monkeypatch.setenv("DEXGPU_HYBRID", "1")
-        for groups in ("2", "5"):
-            monkeypatch.setenv("DEXGPU_ONEPASS_GROUPS", groups)
-            got, info, _ = c.encode(ctx, 0)
-            assert info["groups"] == int(groups)
-            assert len(got) == len(ref) and (got == ref).all()
-            assert (c.d_rec.download(np.uint64, c.n + 1) == rec_ref).all()
-            assert (c.d_seg.download(np.uint32, 5 * c.n) == seg_ref).all()
