@@ -33,6 +33,7 @@
 
 #define QV_WIN_WORDS  512                          // per-wave LDS bit window (2 KiB)
 #define QV_WIN_BITS   (32u * (QV_WIN_WORDS - 32))  // usable: one lane's worst case (896 bits) always fits
+#define QV_WIN_PAD    4                            // words in front of a window that place_bits128 may name (with a zero)
 #ifndef QV_FLUSH_BITS
 #define QV_FLUSH_BITS 8192u                        // drain the window once it holds this much
 #endif
@@ -1109,6 +1110,19 @@ __device__ __forceinline__ uint32_t fsr(uint32_t hi, uint32_t lo, uint32_t s)
       flush_quads((o), false);                                                                  \
   }
 
+// The same for steps in which every lane's string has at most 128 bits (the branch-free packing paths): a step is then at most
+// 8192 bits, which a drained window (< 32 bits left) always holds -- one round, no lane ranges, no ballots.  The drain,
+// when one is needed, is of whole words (flush_words); the periodic 16-byte drains stay with the caller as in _LATE.
+#define FOR_ONE_ROUND(o, incl, nb, ...)                                                         \
+  { const uint32_t all_ = wave_total(incl);                                                     \
+    if ((o).winbits + all_ > QV_WIN_BITS) flush_words((o), false);                              \
+    if (nb)                                                                                     \
+      { const uint32_t bit_ = (o).winbits + ((incl) - (nb));                                    \
+        __VA_ARGS__                                                                             \
+      }                                                                                         \
+    (o).winbits += all_;                                                                        \
+  }
+
 // write the partial word and the pad word (QV.c:436-442); returns the segment's byte size
 __device__ __forceinline__ uint32_t finish_words(wave_out &o, uint32_t last)
 { flush_words(o, false);
@@ -1164,11 +1178,14 @@ __device__ __forceinline__ void place_bits128(uint32_t *win, uint32_t bit, uint3
   const uint32_t we = (e - 1u) >> 5;
   const uint32_t x0 = w0 << sl;
   const uint32_t x1 = fsr(w1, w0, sr), x2 = fsr(w2, w1, sr), x3 = fsr(w3, w2, sr), x4 = fsr(0u, w3, sr);
+  // x1 .. x4 are zero where the string does not reach: ORed all the same -- five LDS operations instead of up to four
+  // branches on the execution mask (the kernels are bound by instruction issue, not by the LDS).  A word in front of the
+  // window (we < 4) may be named with a zero: that is what the QV_WIN_PAD words in front of every window are for.
   atomicOr(&win[we], x0);
-  if (x1) atomicOr(&win[we - 1], x1);
-  if (x2) atomicOr(&win[we - 2], x2);
-  if (x3) atomicOr(&win[we - 3], x3);
-  if (x4) atomicOr(&win[we - 4], x4);
+  atomicOr(&win[(int) we - 1], x1);
+  atomicOr(&win[(int) we - 2], x2);
+  atomicOr(&win[(int) we - 3], x3);
+  atomicOr(&win[(int) we - 4], x4);
 }
 
 // ---- group index of the plain lines (decoder side: k_qv_decode_sub, dx_qv_decode.hip) -----------------------
@@ -1233,7 +1250,7 @@ __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, i
   if (fast)
     { // every token has 1..24 bits and the lane's string fits 128 bits: branch-free packing.  The
       // dummies of a ragged last chunk append one zero bit each, shifted out again at the end.
-      FOR_EACH_ROUND_(o, incl, nb, !LATE,
+      FOR_ONE_ROUND(o, incl, nb,
         { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
           _Pragma("unroll")
           for (int b = 0; b < 16; b++)
@@ -1244,6 +1261,7 @@ __device__ __forceinline__ void encode_plain_step(wave_out &o, const u32x4 &c, i
           w3 >>= k;
           place_bits128(o.win, bit_, nb, w0, w1, w2, w3);
         })
+      if (!LATE && o.winbits >= QV_FLUSH_BITS) flush_quads(o, false);
     }
   else
     { FOR_EACH_ROUND_(o, incl, nb, !LATE,
@@ -1472,7 +1490,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint8_t  s_tagcode[256];
-  __shared__ __attribute__((aligned(16))) uint32_t s_win[DX_WAVES_PER_BLK][QV_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_win[DX_WAVES_PER_BLK][QV_WIN_PAD + QV_WIN_WORDS];   // (the pad: see place_bits128)
   __shared__ __attribute__((aligned(16))) uint32_t s_tag[DX_WAVES_PER_BLK][TAG_WIN_WORDS];
   __shared__ __attribute__((aligned(16))) uint8_t s_chunk[DX_WAVES_PER_BLK][DX_STEP];
   __shared__ __attribute__((aligned(16))) uint8_t s_tchunk[DX_WAVES_PER_BLK][DX_STEP];
@@ -1484,7 +1502,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 
   const run_lds R = { s_chunk[wid], s_list[wid] };
   wave_out o, ot;
-  o.win  = s_win[wid];
+  o.win  = s_win[wid] + QV_WIN_PAD;
   ot.win = s_tag[wid];
   for (int j = lane; j < QV_WIN_WORDS; j += 64)  o.win[j]  = 0;
   for (int j = lane; j < TAG_WIN_WORDS; j += 64) ot.win[j] = 0;

@@ -123,7 +123,7 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           wide |= ((zor & 32u) || span > 0xffffu || wave_total(incl) > RUN_PASSBITS) ? 1u : 0u;
         }
       if (!__any((int) ((zor & 96u) | (nb > 128u))))
-        { FOR_EACH_ROUND_LATE(o, incl, nb,
+        { FOR_ONE_ROUND(o, incl, nb,
             { place_bits128(o.win, bit_, nb, w0, w1, w2, w3); })
         }
       else                                    // a symbol or run without a code, or a string > 128 bits
@@ -235,7 +235,7 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
     return false;
   const uint32_t incl = wave_incl_scan(nb);
   sub_step(sm, nb, 16u, false);
-  FOR_EACH_ROUND_LATE(o, incl, nb,
+  FOR_ONE_ROUND(o, incl, nb,
     { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
       _Pragma("unroll")
       for (int k = 0; k < 8; k++)
@@ -347,7 +347,7 @@ __device__ __forceinline__ void entry_sizes_fast(const qv_args &a, uint64_t r, u
 // index code compiled in it had 116 (-> 120 allocated) even when no index was asked for, the two kernels ran one
 // after the other, and a step took 32.7 ms instead of 31.0.
 template <bool SUB>
-__global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES)
+__global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES) __attribute__((amdgpu_num_vgpr(112)))
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
                       enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
                       const uint8_t *hdr, const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint64_t out_cap,
@@ -356,7 +356,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   __shared__ uint32_t s_stok[6][256];
   __shared__ uint32_t s_pair[2][PAIR_SIZE];
   __shared__ uint8_t  s_tagcode[256];
-  __shared__ __attribute__((aligned(16))) uint32_t s_win[FAST_NWAVE][QV_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_win[FAST_NWAVE][QV_WIN_PAD + QV_WIN_WORDS];   // (the pad: see place_bits128)
   __shared__ __attribute__((aligned(16))) uint32_t s_tag[FAST_NWAVE][TAG_WIN_WORDS];
   load_tables(s_tok, g_tok);
   load_shift_tables(s_stok, s_tagcode, g_tok);
@@ -365,7 +365,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   const int wid  = threadIdx.x >> 6;
 
   wave_out o, ot;
-  o.win  = s_win[wid];
+  o.win  = s_win[wid] + QV_WIN_PAD;
   ot.win = s_tag[wid];
   for (int j = lane; j < QV_WIN_WORDS; j += 64)  o.win[j]  = 0;
   for (int j = lane; j < TAG_WIN_WORDS; j += 64) ot.win[j] = 0;
