@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--workload", default="dexqv", choices=["dexqv", "dexta", "dexar"],
                     help="dexqv = BASELINE metric (default); dexta/dexar = configs[1]/[2] (2-bit pack + unpack)")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU for dexta/dexar")
+    ap.add_argument("--p2-align", type=int, default=0,
+                    help="dexta/dexar experiment: unpack every read's text to an offset that is a multiple of this (0: back into the "
+                         "file image's own, arbitrarily aligned places; the round trip is then not checked)")
     ap.add_argument("--twopass", action="store_true",
                     help="dexqv: dx_qv_sizes + dx_qv_encode instead of dx_qv_encode_onepass (scratch slots + compaction)")
     ap.add_argument("--no-verify", action="store_true",
@@ -179,6 +182,25 @@ def main():
             except Exception as e:
                 sweep[str(pr)] = {"error": repr(e)}
         extra["dexqv_run_density"] = sweep
+        # BASELINE configs[4]: the slice ONE GPU of the 8-GPU job holds (2.5 M entries, 125 GB of QV bytes), under the scratch
+        # budget every rank of that job runs with -- so that the per-GPU work of configs[4] is timed wherever this line is
+        if args.entries == ENTRIES_1GPU and args.mean == 10_000:
+            a4 = argparse.Namespace(**vars(args))
+            a4.entries, a4.steps, a4.warmup, a4.no_walk_index = ENTRIES_SHARD, 3, 1, True
+            a4.scratch_budget_gb = 64.0 if args.scratch_budget_gb is None else args.scratch_budget_gb
+            trace("extra: dexqv, the configs[4] slice of one GPU")
+            try:
+                import torch
+                torch.cuda.empty_cache()
+                free_b = torch.cuda.mem_get_info()[0]
+                if free_b < 262e9:
+                    extra["config4_slice"] = {"skipped": f"{free_b / 1e9:.0f} GB of device memory free, the slice wants 262"}
+                else:
+                    l4 = dexqv_bench(a4, 0, 1, local, cpu=False, front=False, index_decode=False)
+                    extra["config4_slice"] = {k: l4[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "roundtrip_bit_exact",
+                                                                   "encoder_route", "kernels")}
+            except Exception as e:
+                extra["config4_slice"] = {"error": repr(e)}
         for w in ("dexta", "dexar"):
             trace(f"extra: {w}")
             try:
@@ -344,6 +366,9 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
         # writes only the five data lines of an entry; the chunk buffer is zero elsewhere and header bytes are
         # never zero, so the number of differing bytes must equal the number of header bytes exactly.
         trace("verify: decode + compare")
+        if args.lossy:                                            # what a lossy stream decodes back to: the text with QV.c:1355-1372's
+            ctx.qv_lossy_text(batch)                              # rounding applied (in place: the timed steps are over, and the
+            ctx.sync()                                            # rounding is idempotent -- every later encode of it gives the same stream)
         ends = np.concatenate([off[1:] - hlen, [text_bytes]]).astype(np.uint64)   # end of each entry's record
         dec_parts = {}
 
@@ -402,7 +427,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                                            "frac_of_hbm_peak": round((5.0 * bases + float(state["total"])) / (dec2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec2_ms else None,
                                            "output_GBps": round(5.0 * bases / (dec2_ms * 1e-3) / 1e9, 1) if dec2_ms else None,
                                            "index_bytes_without_run_groups": int(4 * words_.sum()),
-                                           "bit_exact": None if args.lossy else bool(ok2),   # (lossy: the text that comes back is not the text that went in)
+                                           "bit_exact": bool(ok2),                           # (lossy: against the text with the reference's rounding applied)
                                            "note": "index written by one extra untimed step of the same encoder; kernels of that step: "
                                                    + str(round(enc_ix_ms, 2)) + " ms"}
 
@@ -434,7 +459,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                 ctx.qv_use_index(None, None, 0, None, None)
                 roundtrip = roundtrip and ok3
                 state["decode_walk_indexed"] = {"kernel": "k_qv_decode_sub + k_qv_decode_runs + k_qv_decode + k_qv_decode_tags", "ms": round(dec3_ms, 2),
-                                                "ms_by_kernel": dict(dec_parts), "bit_exact": None if args.lossy else bool(ok3),
+                                                "ms_by_kernel": dict(dec_parts), "bit_exact": bool(ok3),
                                                 "frac_of_hbm_peak": round((5.0 * bases + float(state["total"])) / (dec3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec3_ms else None,
                                                 "output_GBps": round(5.0 * bases / (dec3_ms * 1e-3) / 1e9, 1) if dec3_ms else None,
                                                 "index_bytes": int(4 * len(w["gidx"])), "lines_without_index": int(w["gidx_none"]),
@@ -574,7 +599,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                                if world > 1 else "single GPU"},
         "roofline": roofline,
         "cpu_baseline": cpu_res,
-        "roundtrip_bit_exact": None if args.lossy else roundtrip,
+        "roundtrip_bit_exact": roundtrip,                         # (lossy: against the text with QV.c:1355-1372's rounding applied)
         "tables_identical_across_ranks": tables_same,
         "host_table_build_us": state.get("host_build_us"),
         "encoder_route": dict(state.get("route") or {}, scratch_budget_bytes=int(budget_gb * 1e9) or None,
@@ -765,13 +790,21 @@ def pack2_bench(args, arrow):
     # decode side: packed bytes sit after each record's framing; text goes back in 80-column lines
     ioff = (ooff + (hoff[1:] - hoff[:-1])).astype(np.uint64)
     p_ioff = up(ioff, np.int64)
-    p_back = Ptr(torch.zeros(n * tb // n0 + 64, dtype=torch.uint8, device="cuda"))
+    p_boff = p_off
+    if not args.p2_align:
+        p_back = Ptr(torch.zeros(n * tb // n0 + 64, dtype=torch.uint8, device="cuda"))
+    else:                                             # (experiment: what misaligned 16-byte stores cost the unpack kernel)
+        A = np.uint64(args.p2_align)
+        tl = tlen.astype(np.uint64)
+        boff = np.concatenate([[0], np.cumsum((tl + A - np.uint64(1)) // A * A)[:-1]]).astype(np.uint64)
+        p_back = Ptr(torch.zeros(int(boff[-1] + tl[-1]) + 4096, dtype=torch.uint8, device="cuda"))
+        p_boff = up(boff, np.int64)
     alpha = L.DX_ALPHA_ARROW if arrow else L.DX_ALPHA_BASES
     letters = L.DX_LETTERS_ARROW if arrow else L.DX_LETTERS_UPPER
 
     def step():
         ctx.pack2_encode(alpha, p_text, p_off, p_tlen, p_nsym, n, p_hdr, p_hoff, p_out, p_ooff)
-        ctx.pack2_decode(letters, p_out, p_ioff, p_nsym, n, 80, p_back, p_off)
+        ctx.pack2_decode(letters, p_out, p_ioff, p_nsym, n, 80, p_back, p_boff)
 
     for _ in range(args.warmup):
         step()
@@ -790,7 +823,7 @@ def pack2_bench(args, arrow):
     for o_, t_ in zip(tile.off, tile.tlen):
         seqmask[int(o_): int(o_) + int(t_)] = True
     same = True
-    for t in sorted({0, reps - 1}):
+    for t in sorted({0, reps - 1} if not args.p2_align else set()):
         a = d_text[t * tb: (t + 1) * tb].cpu().numpy()
         b = p_back.t[t * tb: (t + 1) * tb].cpu().numpy()
         same = same and bool(np.array_equal(a[seqmask], b[seqmask]))

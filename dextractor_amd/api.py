@@ -124,6 +124,10 @@ class Context:
     def qv_batch(d_text, d_off, d_len, n, line_pad=1, text_bytes=0) -> L.QVBatch:
         return L.QVBatch(d_text.ptr, d_off.ptr, d_len.ptr, n, text_bytes, line_pad)
 
+    def qv_lossy_text(self, batch):
+        """QV.c:1355-1372's rounding of the insertion / merge QVs, in place on the batch's device text."""
+        self._chk(self.lib.dx_qv_lossy_text(self.h, C.byref(batch)))
+
     def qv_prescan(self, batch, entry0=0, params=None) -> L.QVParams:
         p = params or L.QVParams(-1, -1, -1, -1)
         self._chk(self.lib.dx_qv_prescan(self.h, C.byref(batch), entry0, C.byref(p)))
@@ -432,7 +436,7 @@ def qv_walk(img: bytes, index=False):
         extra = {}
         if index:
             w = int(x.gidx_words)
-            extra = {"gidx": np.ctypeslib.as_array(x.gidx, (max(w, 1),))[:w].copy(),
+            extra = {"gidx": (np.ctypeslib.as_array(x.gidx, (w,)).copy() if w and x.gidx else np.zeros(0, np.uint32)),   # (an image without records: NULL)
                      "gidx_off": np.ctypeslib.as_array(x.gidx_off, (n + 1,)).copy(), "gidx_none": int(x.gidx_none)}
         return {**extra, "n": n,
                 "rec_off": np.ctypeslib.as_array(x.rec_off, (n + 1,)).copy(),

@@ -44,16 +44,25 @@ static void drop_results(void)
   Records = NULL; Coff = NULL; Next = 0;
 }
 
+static void scan_reset(void)
+{ dx_entries_free(Batch);
+  Batch = dx_entries_new();
+  if (Batch == NULL) die("Out of memory (QVcoding_Scan1)");
+  Nent = 0;
+  drop_results();
+}
+
+static void scan_add(int rlen, const char *del, const char *tag, const char *ins, const char *mrg, const char *sub);
+
 void QVcoding_Scan1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub)
 { if (rlen == 0)                                    /* reset: QV.c:871-886 */
-    { dx_entries_free(Batch);
-      Batch = dx_entries_new();
-      if (Batch == NULL) die("Out of memory (QVcoding_Scan1)");
-      Nent = 0;
-      drop_results();
-      return;
-    }
-  if (Batch == NULL)
+    scan_reset();
+  else
+    scan_add(rlen, del, tag, ins, mrg, sub);
+}
+
+static void scan_add(int rlen, const char *del, const char *tag, const char *ins, const char *mrg, const char *sub)
+{ if (Batch == NULL)
     { Batch = dx_entries_new();
       if (Batch == NULL) die("Out of memory (QVcoding_Scan1)");
     }
@@ -119,6 +128,110 @@ void Write_QVcoding(FILE *output, QVcoding *coding)
   free(buf);
 }
 
+/* ---- the FILE * entry points (dexqv.c:81-141) ------------------------------------------------------------------
+ * Read_Lines / QVentry / Set_QV_Line / Get_QV_Line (QV.c:733-798): a line reader with the reference's contract -- line j
+ * of a call at QVentry() + j * (its row stride), the common length returned without the line end, -1 at the end of the
+ * input, -2 (and the reference's message) on an error.  QVcoding_Scan reads entries with it and GATHERS them exactly as
+ * QVcoding_Scan1 does; Compress_Next_QVentry reads the next five lines and writes the record Create_QVcoding made of
+ * them.  Host code only: text intake, as in cli/.                                                                */
+static char *RLbuf = NULL;               /* five rows of RLmax bytes */
+static int   RLmax = 0;
+static int   RLline = 0;
+
+char *QVentry(void) { return RLbuf; }
+void  Set_QV_Line(int line) { RLline = line; }
+int   Get_QV_Line(void) { return RLline; }
+
+static int rl_grow(void)                 /* rows wider; row 0 keeps what it holds */
+{ int   nmax = RLmax + RLmax / 2 + 10000;
+  char *t    = realloc(RLbuf, 5 * (size_t) nmax);
+  if (t == NULL)
+    { fprintf(stderr, "libdexgpu: Out of memory (Reallocating QV entry read buffer)\n");
+      return -1;
+    }
+  RLbuf = t; RLmax = nmax;
+  return 0;
+}
+
+int Read_Lines(FILE *input, int nlines)
+{ int rlen, i;
+  if (RLbuf == NULL)
+    { RLmax = 0;
+      if (rl_grow()) return -2;
+    }
+  RLline += 1;
+  if (fgets(RLbuf, RLmax, input) == NULL)
+    return -1;
+  rlen = (int) strlen(RLbuf);
+  while (RLbuf[rlen - 1] != '\n')
+    { if (rl_grow()) return -2;
+      if (fgets(RLbuf + rlen, RLmax - rlen, input) == NULL)
+        { fprintf(stderr, "Line %d: Last line does not end with a newline !\n", RLline);
+          return -2;
+        }
+      rlen += (int) strlen(RLbuf + rlen);
+    }
+  for (i = 1; i < nlines; i++)
+    { char *other = RLbuf + (size_t) i * RLmax;
+      RLline += 1;
+      if (fgets(other, RLmax, input) == NULL)
+        { fprintf(stderr, "Line %d: incomplete last entry of .quiv file\n", RLline);
+          return -2;
+        }
+      if (rlen != (int) strlen(other))
+        { fprintf(stderr, "Line %d: Lines for an entry are not the same length\n", RLline);
+          return -2;
+        }
+    }
+  return rlen - 1;
+}
+
+int QVcoding_Scan(FILE *input, int num, FILE *temp)
+{ int i, r = 0;
+  scan_reset();                                             /* a scan starts afresh: QV.c:931-942 zeroes its histograms */
+  for (i = 0; i < num; i++)
+    { int   well, beg, end, qv, rlen, k;
+      char *slash;
+      rlen = Read_Lines(input, 1);
+      if (rlen == -2) return -1;
+      if (rlen < 0) break;
+      if (rlen == 0 || RLbuf[0] != '@')
+        { fprintf(stderr, "Line %d: Header in quiva file is missing\n", RLline);
+          return -1;
+        }
+      slash = strchr(RLbuf + 1, '/');
+      if (slash == NULL || sscanf(slash + 1, "%d/%d_%d RQ=0.%d\n", &well, &beg, &end, &qv) != 4)
+        { fprintf(stderr, "libdexgpu: Line %d: Header line incorrectly formatted ?\n", RLline);
+          return -1;
+        }
+      if (temp != NULL) fputs(RLbuf, temp);
+      rlen = Read_Lines(input, 5);
+      if (rlen < 0)
+        { if (rlen == -1) fprintf(stderr, "Line %d: incomplete last entry of .quiv file\n", RLline);
+          return -1;
+        }
+      if (temp != NULL)
+        for (k = 0; k < 5; k++) fputs(RLbuf + (size_t) k * RLmax, temp);
+      scan_add(rlen, RLbuf, RLbuf + RLmax, RLbuf + 2 * (size_t) RLmax, RLbuf + 3 * (size_t) RLmax, RLbuf + 4 * (size_t) RLmax);
+      r += 1;
+    }
+  return r;
+}
+
+void Compress_Next_QVentry1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub,
+                            FILE *output, QVcoding *coding, int lossy);
+
+int Compress_Next_QVentry(FILE *input, FILE *output, QVcoding *coding, int lossy)
+{ const int rlen = Read_Lines(input, 5);
+  if (rlen < 0)
+    { if (rlen == -1) fprintf(stderr, "Line %d: incomplete last entry of .quiv file\n", RLline);
+      exit(1);                                              /* (the reference's batch convention: EXIT(-1), DB.h:45-47) */
+    }
+  Compress_Next_QVentry1(rlen, RLbuf, RLbuf + RLmax, RLbuf + 2 * (size_t) RLmax, RLbuf + 3 * (size_t) RLmax, RLbuf + 4 * (size_t) RLmax,
+                         output, coding, lossy);
+  return rlen;
+}
+
 void Compress_Next_QVentry1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub,
                             FILE *output, QVcoding *coding, int lossy)
 { size_t k;
@@ -165,10 +278,20 @@ static void open_gpu(const char *who)
 }
 
 QVcoding *Read_QVcoding(FILE *input)
-{ long   end;
+{ long   end, at;
   size_t plen;
+  /* The reference reads ONE coding at the stream's position and keeps one static coding object (QV.c:1214-1320); a caller
+   * that reads codings from the middle of a file (DB.c:2450-2502 does, for .qvs tracks) or keeps two alive must not get
+   * another file's state silently: the stream must stand at the start of a .dexqv file -- at 0, or at 2 behind the
+   * 0x55aa key undexqv.c:112-118 has read -- and a second coding while one is live is refused. */
+  if (DHave)
+    die("Read_QVcoding: a coding of this process is still live (Free_QVcoding it first): one file at a time");
+  if (input == NULL || (at = ftell(input)) < 0)
+    die("Read_QVcoding: the input must be a seekable file (the whole of it is decoded at once)");
+  if (at != 0 && at != 2)
+    die("Read_QVcoding: the stream must stand at the start of a .dexqv file (offset 0, or 2 behind its key); codings inside other files are not supported");
   drop_decode();
-  if (input == NULL || fseek(input, 0, SEEK_END) != 0 || (end = ftell(input)) < 0 || fseek(input, 0, SEEK_SET) != 0)
+  if (fseek(input, 0, SEEK_END) != 0 || (end = ftell(input)) < 0 || fseek(input, 0, SEEK_SET) != 0)
     die("Read_QVcoding: the input must be a seekable file (the whole of it is decoded at once)");
   DImgN = (size_t) end;
   DImg  = malloc(DImgN ? DImgN : 1);

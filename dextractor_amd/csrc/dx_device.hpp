@@ -134,20 +134,21 @@ __device__ __forceinline__ uint32_t chunk_eq_mask(const u32x4 &v, uint32_t c)
 
 __device__ __forceinline__ void store32_u(uint8_t *p, uint32_t v) { *(u32_u *) p = v; }
 
-// group index of the plain QV lines (dx_qv.hip writes it, dx_qv_decode.hip reads it): one byte per group of 16
-// symbols = the group's code bits minus its symbols; sub_words(L) 32-bit words per line
-__host__ __device__ __forceinline__ uint32_t sub_groups(uint32_t L) { return (L + 15u) >> 4; }
-__host__ __device__ __forceinline__ uint32_t sub_words(uint32_t L)  { return (sub_groups(L) + 3u) >> 2; }
-#define SUB_NONE 255u                                       // first byte of a line: no index (a symbol without a code)
-// ... and of the run-coded lines, after the four plain shares of the entry: three header words -- the deletion line's
-// token count or RUN_NONE, the same for the substitution line, the passes reserved for the deletion line -- then one
-// word per group of <= 8 tokens (the tokens a lane of k_qv_encode_fast codes in a pass of 512): bits | span << 16
-// (span = positions the group's runs and symbols cover), 64 per pass, deletion line first.
-#define RUN_NONE 0xffffffffu
-#define RUN_STRETCH 5120u                                   // positions of a pass the decoder stages in LDS (a longer pass goes byte by byte)
-#define RUN_PASSBITS 13312u                                 // bits the 64 groups of a pass may take together (416 words of the decoder's window; else: no index)
-__host__ __device__ __forceinline__ uint32_t run_passes(uint32_t tokens) { return (tokens + 511u) >> 9; }
-__host__ __device__ __forceinline__ uint32_t run_base(uint32_t L) { return 4u * sub_words(L); }    // words before the three header words
+// group index of the plain QV lines (dx_qv.hip writes it, dx_qv_decode.hip reads it): one byte per group of 16 symbols =
+// the group's code bits minus its symbols; sub_words(L) 32-bit words per line -- and of the run-coded lines, after the four
+// plain shares of the entry: three header words (the deletion line's token count or RUN_NONE, the same for the substitution
+// line, the passes reserved for the deletion line), then one word per group of <= 8 tokens (the tokens a lane of
+// k_qv_encode_fast codes in a pass of 512): bits | span << 16 (span = positions the group's runs and symbols cover), 64 per
+// pass, deletion line first.  The layout is defined ONCE, in dx_layout.h (the host walk of a bare file writes it too):
+#include "dx_layout.h"
+#define SUB_NONE     DXL_SUB_NONE                           // first byte of a line: no index (a symbol without a code)
+#define RUN_NONE     DXL_RUN_NONE
+#define RUN_STRETCH  DXL_RUN_STRETCH                        // positions of a pass the decoder stages in LDS (a longer pass goes byte by byte)
+#define RUN_PASSBITS DXL_RUN_PASSBITS                       // bits the 64 groups of a pass may take together (416 words of the decoder's window; else: no index)
+__host__ __device__ __forceinline__ uint32_t sub_groups(uint32_t L) { return dxl_sub_groups(L); }
+__host__ __device__ __forceinline__ uint32_t sub_words(uint32_t L)  { return dxl_sub_words(L); }
+__host__ __device__ __forceinline__ uint32_t run_passes(uint32_t tokens) { return dxl_run_passes(tokens); }
+__host__ __device__ __forceinline__ uint32_t run_base(uint32_t L) { return dxl_run_base(L); }    // words before the three header words
 
 // ---------------------------------------------------------------------------------------------
 //  per-wave output window: bits are ORed into a zeroed LDS word window (MSB-first within 32-bit

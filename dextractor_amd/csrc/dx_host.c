@@ -854,7 +854,7 @@ static int64_t walk_runs_ix(const uint8_t *p, const uint8_t *end, uint32_t rlen,
    header word: the token count, or DXL_RUN_NONE when a group does not fit (positions > 65535, a pass > RUN_PASSBITS). */
 static uint32_t run_groups(const uint16_t *tb, const uint32_t *ts, uint32_t cnt, uint32_t L, uint32_t *grp)
 { uint32_t k0, none = 0;
-  if (cnt > ((((L >> 1) + 64u) + 7u) & ~7u)) none = 1;    /* more tokens than the encoder's token slots hold: such a line never has an
+  if (cnt > dxl_tok_limit(L)) none = 1;    /* more tokens than the encoder's token slots hold: such a line never has an
                                                              index (k_qv_decode_runs refuses one), the lane-per-line kernel takes it */
   for (k0 = 0; k0 < cnt; k0 += DXL_RUN_PASS, grp += 64)
     { const uint32_t m = cnt - k0 < DXL_RUN_PASS ? cnt - k0 : DXL_RUN_PASS, T = (m + 63u) >> 6;

@@ -1,20 +1,28 @@
-/* dx_layout.h -- layout of the group index (dx_qv_subindex), shared by the device code that writes and reads it and
- * the host walk that can produce it for a bare file.  Plain C.  (dx_device.hpp has the device-side twins of these
- * functions; tests/test_host.py checks that the two agree through the host walk's output.)                       */
+/* dx_layout.h -- layout of the group index (dx_qv_subindex): the ONE definition, shared by the device code that writes
+ * and reads it (dx_device.hpp includes this file; the functions are __host__ __device__ there) and the host walk that can
+ * produce it for a bare file (plain C).                                                                            */
 #ifndef DX_LAYOUT_H
 #define DX_LAYOUT_H
 #include <stdint.h>
+#ifdef __HIPCC__
+#define DXL_FN __host__ __device__ __forceinline__
+#else
+#define DXL_FN static inline
+#endif
 
 #define DXL_SUB_NONE     255u                 /* first byte of a plain line's share: no index for it */
 #define DXL_RUN_NONE     0xffffffffu          /* header word of a run-coded line: no index for it */
 #define DXL_RUN_PASSBITS 13312u               /* bits the 64 groups of a pass may take together */
 #define DXL_RUN_PASS     512u                 /* tokens of a pass: 64 groups of up to 8 */
+#define DXL_RUN_STRETCH  5120u                /* positions of a pass the decoder stages in LDS at a time */
 
-static inline uint32_t dxl_sub_groups(uint32_t L) { return (L + 15u) >> 4; }
-static inline uint32_t dxl_sub_words(uint32_t L)  { return (dxl_sub_groups(L) + 3u) >> 2; }
-static inline uint32_t dxl_run_passes(uint32_t tokens) { return (tokens + 511u) >> 9; }
-static inline uint32_t dxl_run_base(uint32_t L)   { return 4u * dxl_sub_words(L); }
+DXL_FN uint32_t dxl_sub_groups(uint32_t L) { return (L + 15u) >> 4; }
+DXL_FN uint32_t dxl_sub_words(uint32_t L)  { return (dxl_sub_groups(L) + 3u) >> 2; }
+DXL_FN uint32_t dxl_run_passes(uint32_t tokens) { return (tokens + 511u) >> 9; }
+DXL_FN uint32_t dxl_run_base(uint32_t L)   { return 4u * dxl_sub_words(L); }
 /* words of an entry: the four plain shares, three header words, 64 group words per pass of either run-coded line */
-static inline uint64_t dxl_entry_words(uint32_t L, uint32_t passes_del, uint32_t passes_sub)
+DXL_FN uint64_t dxl_entry_words(uint32_t L, uint32_t passes_del, uint32_t passes_sub)
 { return (uint64_t) dxl_run_base(L) + 3u + 64ull * ((uint64_t) passes_del + passes_sub); }
+/* tokens a run-coded line's slot holds (k_qv_hist's token hand-over; the host walk bounds its groups by the same figure) */
+DXL_FN uint32_t dxl_tok_limit(uint32_t L) { return (((L >> 1) + 64u) + 7u) & ~7u; }
 #endif

@@ -1800,6 +1800,34 @@ extern "C" int dx_qv_prescan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0,
   return DX_OK;
 }
 
+// The lossy rounding of Compress_Next_QVentry (QV.c:1355-1372: insertion QVs to even values, merge QVs to multiples of four)
+// applied in place to the text of a batch: what a lossy .dexqv decodes back to.  One wave per entry, 16 bytes per lane.
+__global__ __launch_bounds__(DX_BLOCK)
+void k_qv_lossy_text(qv_args a, uint8_t *text)
+{ const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
+  const uint64_t nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  for (uint64_t r = wave0; r < a.n; r += nwave)
+    { const uint32_t L = a.len[r];
+      for (int k = 2; k <= 3; k++)
+        { uint8_t *p = text + (line_ptr(a, r, L, k) - a.text);
+          const uint8_t m = k == 2 ? 0xfeu : 0xfcu;
+          for (uint32_t j = (uint32_t) lane_id(); j < L; j += 64u)
+            p[j] &= m;
+        }
+    }
+}
+
+extern "C" int dx_qv_lossy_text(dx_ctx *ctx, const dx_qv_batch *b)
+{ int e = check_batch(ctx, b, "dx_qv_lossy_text");
+  if (e) return e;
+  if (b->n == 0) return DX_OK;
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  const qv_args a = make_args(b, -1, -1, 1);
+  hipLaunchKernelGGL(k_qv_lossy_text, dim3(dx_grid_waves(ctx, b->n, 32)), dim3(DX_BLOCK), 0, ctx->stream, a, (uint8_t *) b->d_text);
+  DX_HIP(ctx, hipGetLastError());
+  return DX_OK;
+}
+
 // Token slots for the batch: offsets by a scan of the per-entry rooms, buffers grown as needed.  Returns
 // false (and leaves the hand-over off) when tokens are not wanted or the memory is not to be had.
 static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params *p, uint8_t *scr, size_t scr_at)

@@ -1186,7 +1186,7 @@ __device__ __forceinline__ dr_line dr_line_of(const dec_args &a, const dr_entry 
   ln.cnt = head[q == 0 ? 0 : 1];                           // tokens (RUN_NONE: not indexed)
   const uint64_t share = e.so1 - e.so;                     // words of this entry in the index
   const uint64_t need  = (uint64_t) run_base(L) + 3u + 64ull * ((q == 0 ? 0u : head[2]) + run_passes(ln.cnt));
-  ln.ok     = ln.cnt != RUN_NONE && ln.cnt <= ((((L >> 1) + 64u) + 7u) & ~7u) && need <= share;
+  ln.ok     = ln.cnt != RUN_NONE && ln.cnt <= dxl_tok_limit(L) && need <= share;
   ln.seg    = a.in + e.rec + e.hl + (q == 0 ? 0ull : (uint64_t) e.sg[0] + e.sg[1] + e.sg[2] + e.sg[3]);
   ln.sbytes = q == 0 ? e.sg[0] : e.sg[4];
   ln.g16    = sub_idx + e.so + run_base(L) + 3u + (q == 0 ? 0u : 64u * head[2]);      // three header words, then the groups

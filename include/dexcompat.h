@@ -34,6 +34,22 @@ typedef struct                 /* QV.h:31-42, field for field (the scheme pointe
     char    *prefix;
   } QVcoding;
 
+/* The FILE * entry points as dexqv.c:81-141 calls them: QVcoding_Scan reads up to num entries (copying them to temp if
+ * given) and gathers them the way QVcoding_Scan1 does; Compress_Next_QVentry reads the next entry's five lines and writes
+ * the record Create_QVcoding made of them (the second pass presents the entries of the first, in the same order: else
+ * it dies).  Read_Lines / QVentry / Set_QV_Line / Get_QV_Line: the reference's line reader, line j of a call at
+ * QVentry() + j * stride; -1 at the end of the input, -2 (message on stderr) on an error.                          */
+int       Read_Lines(FILE *input, int nlines);                                               /* QV.c:751-798 */
+char     *QVentry(void);                                                                     /* QV.c:737 */
+void      Set_QV_Line(int line);                                                             /* QV.c:740 */
+int       Get_QV_Line(void);                                                                 /* QV.c:743 */
+int       QVcoding_Scan(FILE *input, int num, FILE *temp);                                   /* QV.c:922-1023 */
+int       Compress_Next_QVentry(FILE *input, FILE *output, QVcoding *coding, int lossy);     /* QV.c:1381-1426 */
+
+/* Differences in side effects (the reference's own callers do not depend on them): the reference's compress calls rewrite the
+ * caller's buffers in place -- tag becomes the packed 2-bit codes (Number_Read / Compress_Read), ins / mrg are rounded when
+ * lossy (QV.c:1355-1372) -- these leave them untouched; Read_QVcoding wants the stream at offset 0 or 2 of a .dexqv file
+ * and refuses a second coding while one is live (the reference reads a coding wherever the stream stands).           */
 void      QVcoding_Scan1(int rlen, char *del, char *tag, char *ins, char *mrg, char *sub);   /* QV.c:866-920; rlen == 0: reset */
 QVcoding *Create_QVcoding(int lossy);                                                        /* QV.c:1029-1169 */
 void      Write_QVcoding(FILE *output, QVcoding *coding);                                    /* QV.c:1173-1210 */

@@ -198,6 +198,10 @@ typedef struct
     int64_t del_first, sub_first;
   } dx_qv_params;
 
+/* The lossy rounding of Compress_Next_QVentry (QV.c:1355-1372: insertion QVs >> 1 << 1, merge QVs >> 2 << 2) applied IN PLACE
+ * to the batch's text on the device: the text a lossy .dexqv decodes back to (what a lossy round trip is compared with). */
+int dx_qv_lossy_text(dx_ctx *ctx, const dx_qv_batch *b);
+
 /* Finds delChar (deletion QV under the first 'n'/'N' tag, QV.c:993-1002) and the provisional
  * subChar (argmax of the substitution histogram of the entries up to the one where the running
  * symbol count first reaches 100000, ties to the smallest value, QV.c:1006-1015), on the device.

@@ -54,3 +54,17 @@ def test_bench_line_two_ranks_on_one_device():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["tables_identical_across_ranks"] is True and d["roundtrip_bit_exact"] is True
     assert abs(d["value"] - 2 * 5 * 20000 * 10000 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]     # whole job
+
+
+@pytest.mark.gpu
+def test_bench_line_four_ranks_on_one_device():
+    """The N = 4 launch of the driver's scaling run, rehearsed with every rank on device 0 (a GPU box admits six processes on
+    its card at once, so the N = 8 launch cannot be rehearsed there: its sharding logic runs under gloo in
+    tests/test_shard_gloo.py::test_eight_rank_sharded_dexqv_equals_single): one JSON line, n_gpus 4, identical tables on
+    every rank, value = the whole job's bytes over the slowest rank's time."""
+    d = _run(["--gpus", "4", "--entries", "8000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+             env={"DEXGPU_BENCH_ONE_DEVICE": "1"})
+    assert all(k in d for k in FIELDS)
+    assert d["n_gpus"] == 4 and d["scaling"] == "weak" and d["config"]["sharding"] != "single GPU"
+    assert d["tables_identical_across_ranks"] is True and d["roundtrip_bit_exact"] is True
+    assert abs(d["value"] - 4 * 5 * 8000 * 10000 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]     # whole job

@@ -891,6 +891,30 @@ def test_file_dexqv_sharded_over_contexts(ctx, nctx, lossy):
             x.close()
 
 
+def test_sharded_file_drivers_over_every_physical_device():
+    """dx_file_dexqv_sharded / dx_file_pack2_sharded with ONE context on EVERY device hipGetDeviceCount reports: the
+    hipSetDevice-per-thread path of csrc/dx_files.c on real multi-GPU hardware (BASELINE configs[4]'s layout: contiguous
+    entry ranges per GPU, host-side histogram sum, outputs concatenated), against the oracle.  Skips on a one-GPU box --
+    there the same drivers run over several contexts of device 0 (the tests around this one)."""
+    ndev = L.load().dx_device_count()
+    if ndev < 2:
+        pytest.skip("one GPU visible (%d): the multi-device path needs at least two" % ndev)
+    cs = [api.Context(k) for k in range(ndev)]
+    try:
+        assert sorted(x.device for x in cs) == list(range(ndev))
+        for lossy in (0, 1):
+            c = synth.make_quiva(40 * ndev + 3, seed=91, mean=6000)        # ~250 k symbols per device: the 100000-symbol cut lies in shard 0
+            assert api.dexqv_sharded(cs, c.text, lossy) == O.dexqv(c.text, lossy)
+        small = synth.make_quiva(2 * ndev, seed=92, mean=4000)              # ... and beyond shard 0 here
+        assert api.dexqv_sharded(cs, small.text, 0) == O.dexqv(small.text, 0)
+        for kind in ("fasta", "arrow"):
+            f = synth.make_seqfile(kind, 50 * ndev + 1, seed=93, mean=5000)
+            assert api.pack2_sharded(cs, f.text, arrow=(kind == "arrow")) == (O.dexta(f.text) if kind == "fasta" else O.dexar(f.text))
+    finally:
+        for x in cs:
+            x.close()
+
+
 @pytest.mark.parametrize("nctx", [2, 5])
 @pytest.mark.parametrize("kind", ["fasta", "arrow"])
 def test_file_pack2_sharded_over_contexts(ctx, nctx, kind):
@@ -1323,6 +1347,31 @@ def test_old_name_shims_like_dex2db(ctx, tmp_path):
         body, _ = O.qv_encode_entry(ref, False, np.stack([np.frombuffer(x, np.uint8) for x in lines]))
         want += body
     assert got == want
+
+
+def test_file_pointer_shims_in_the_order_of_dexqv(tmp_path):
+    """include/dexcompat.h: QVcoding_Scan(FILE *) / Create_QVcoding / Write_QVcoding / Read_Lines + QVentry / Compress_Next_QVentry(FILE *)
+    / Free_QVcoding, called by a driver written for this test (tests/compat_driver/dexqv_like.c) in the order of dexqv.c:81-141:
+    the file it writes is the REAL dexqv's, byte for byte, for every .quiva golden (lossy ones too, L = 0, no delChar, ...)."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dexqv_like")
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tests", "compat_driver", "dexqv_like.c"),
+                           "-L" + libdir, "-ldexgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    ran = 0
+    for case in O.cases("quiva"):
+        if case.get("expect_error"):
+            continue
+        src = tmp_path / (case["input"] + ".quiva")
+        src.write_bytes(O.golden(case["input"] + ".quiva"))
+        out = tmp_path / (case["name"] + ".dexqv")
+        r = subprocess.run([exe] + (["-l"] if "-l" in case["flags"] else []) + [str(src), str(out)], capture_output=True, timeout=120)
+        assert r.returncode == 0, (case["name"], r.stderr[-500:])
+        assert out.read_bytes() == O.golden(case["name"] + ".dexqv"), case["name"]
+        ran += 1
+    assert ran >= 5
 
 
 @pytest.mark.parametrize("name,kind", [("ta_small.legacy", "dexta"), ("ta_small.swapped", "dexta"),

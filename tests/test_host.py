@@ -26,9 +26,10 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     compat = open(os.path.join(ROOT, "include", "dexcompat.h")).read()
     compat = re.sub(r"/\*.*?\*/", "", compat, flags=re.S)
-    old_names = set(re.findall(r"\b([A-Z][A-Za-z_]+_QV[a-z]+1?|QVcoding_Scan1)\s*\(", compat))
+    old_names = set(re.findall(r"\b([A-Z][A-Za-z]*_[A-Za-z_]*[a-z]1?|QVentry)\s*\(", compat))
     assert old_names == {"QVcoding_Scan1", "Create_QVcoding", "Write_QVcoding", "Compress_Next_QVentry1", "Free_QVcoding",
-                         "Read_QVcoding", "Uncompress_Next_QVentry"}
+                         "Read_QVcoding", "Uncompress_Next_QVentry",
+                         "QVcoding_Scan", "Compress_Next_QVentry", "Read_Lines", "QVentry", "Set_QV_Line", "Get_QV_Line"}, old_names
     for name in old_names:
         assert hasattr(lib, name), f"{name} declared in dexcompat.h but not exported"
 
@@ -224,6 +225,19 @@ def test_undexqv_plan_knows_the_text_size_without_a_gpu(case):
     with pytest.raises(L.DexGPUError) as e:
         api.undexqv_plan_size(dx[: len(dx) // 2])
     assert e.value.code == -3
+
+
+def test_walk_of_an_image_without_records_with_and_without_index():
+    """A .dexqv image that holds a coding but no records (cut at rec_off[0]): the walk finds zero entries either way, and
+    the group index of dx_qv_walk_indexed is empty -- not a NULL pointer handed to numpy."""
+    img = O.golden("qv_nodel.dexqv")
+    w = api.qv_walk(img)
+    head = img[: int(w["rec_off"][0])]
+    for index in (False, True):
+        e = api.qv_walk(head, index=index)
+        assert e["n"] == 0 and len(e["rec_off"]) == 1 and len(e["len"]) == 0
+        if index:
+            assert e["gidx"].dtype == np.uint32 and len(e["gidx"]) == 0 and len(e["gidx_off"]) == 1
 
 
 def test_walk_rejects_garbage():

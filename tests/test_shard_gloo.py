@@ -125,6 +125,16 @@ def test_four_rank_cut_beyond_rank0():
     assert _run_sharded(c, 4, False) == want
 
 
+def test_eight_rank_sharded_dexqv_equals_single():
+    """BASELINE configs[4]'s world size: eight ranks, contiguous entry ranges, the 100000-symbol cut in rank 2's slice,
+    -- the concatenation is the single-process file."""
+    c = synth.make_quiva(41, seed=23, mean=9000)
+    cum = np.cumsum(c.len.astype(np.uint64))
+    cut_rank = next(k for k in range(8) if int(cum[shard.entry_range(41, k, 8)[1] - 1]) >= 100000)
+    assert cut_rank >= 1                                      # the cut lies beyond rank 0
+    assert _run_sharded(c, 8, False) == O.dexqv(c.text, False)
+
+
 def test_three_rank_short_file_has_no_subchar():
     c = synth.make_quiva(9, seed=5, mean=6000)                # < 100000 symbols in all: no subChar anywhere
     assert int(c.len.astype(np.uint64).sum()) < 100000
