@@ -97,6 +97,7 @@ SIGNATURES = {
     "dx_parse_seq_headers": (C.c_int, [C.c_int, _P, _P, C.c_uint64, _P, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]),
     "dx_qv_prescan": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams)]),
     "dx_qv_lossy_text": (C.c_int, [_P, C.POINTER(QVBatch)]),
+    "dx_mem_info": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "dx_qv_hist": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams), C.POINTER(HIST),
                              C.POINTER(C.c_uint64)]),
     "dx_qv_build": (C.c_int, [C.POINTER(HIST), C.c_uint64, C.POINTER(QVParams), C.c_int, C.POINTER(QVCoding)]),

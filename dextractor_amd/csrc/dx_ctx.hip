@@ -159,6 +159,16 @@ extern "C" void dx_close(dx_ctx *ctx)
   delete ctx;
 }
 
+extern "C" int dx_mem_info(dx_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes)
+{ if (ctx == NULL) return DX_E_ARG;
+  size_t f = 0, t = 0;
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  DX_HIP(ctx, hipMemGetInfo(&f, &t));
+  if (free_bytes)  *free_bytes  = f;
+  if (total_bytes) *total_bytes = t;
+  return DX_OK;
+}
+
 // Gives back what the context keeps between calls to save allocations: the scratch regions of the one-pass encoder,
 // the token slots of the histogram pass, the group index.  (The code tables and everything a later call needs to be
 // correct stay; the next call that wants one of the buffers allocates it again.)

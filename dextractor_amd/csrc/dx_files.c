@@ -496,6 +496,162 @@ static int pass_shifted(void *arg, uint8_t *data, size_t len, size_t at)
   return h->sink(h->user, data, len, at + h->shift);
 }
 
+
+/* ---- a .quiva image larger than the device (or than DEXGPU_TEXT_BUDGET): slices of whole entries -------------------
+ * The reference streams a file of any size through two passes (dexqv.c:81-82, 112-143).  Here: the host index of the
+ * whole image (line structure, header fields), then per slice of at most `cap` bytes of text
+ *   pass 1: upload, dx_qv_prescan (the scan state carried from slice to slice, entry0 = the slice's first entry),
+ *           dx_qv_hist (adds into the file's histograms);
+ *   tables, the file's head (key + coding) out;
+ *   pass 2: upload again, dx_qv_hist once more (for the tokens of THIS slice under the final scan state; its counts go
+ *           nowhere), dx_qv_encode_onepass, the slice's records out behind the last slice's.
+ * A slice is bound by the host link (two uploads of the text at ~50 GB/s against kernels at ~1.7 TB/s), so the second
+ * histogram pass costs nothing that shows.  The well chain of the framing bytes runs through the slices.          */
+typedef struct { uint8_t *p; size_t n, cap; } grow_sink;
+static int grow_take(void *arg, uint8_t *data, size_t len, size_t at)
+{ grow_sink *g = arg;
+  if (at + len > g->cap)
+    { size_t nc = 2 * g->cap + at + len + 4096;
+      uint8_t *t = realloc(g->p, nc);
+      if (t == NULL) return 1;
+      g->p = t; g->cap = nc;
+    }
+  memcpy(g->p + at, data, len);
+  if (at + len > g->n) g->n = at + len;
+  return 0;
+}
+
+static int dexqv_sliced(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, size_t cap, uint8_t **out, dx_sink_fn sink, void *user,
+                        size_t *out_len, uint64_t *errline, int *errcode)
+{ dpool        pool = { {0}, 0, ctx };
+  uint64_t     cnt = 0, *off = NULL, *hoff = NULL, *rel = NULL, tot = 0, e0, at;
+  uint32_t    *len = NULL;
+  int32_t     *hdr4 = NULL, lwell = 0;
+  uint8_t     *blob = NULL, *head_img = NULL;
+  size_t       plen = 0, clen = 0, head = 0, maxent = 0, slice_bytes = 0;
+  dx_qv_params p = { -1, -1, -1, -1 };
+  dx_qv_coding *cd = NULL;
+  uint64_t   (*hist)[256] = NULL, (*junk)[256] = NULL;
+  void        *d_text = NULL, *d_off = NULL, *d_len = NULL, *d_hdr = NULL, *d_hoff = NULL, *d_rec = NULL, *d_seg = NULL, *d_out = NULL;
+  size_t       out_cap = 0;
+  grow_sink    grow = { NULL, 0, 0 };
+  int          rc, pass;
+
+  if (out) { sink = grow_take; user = &grow; }
+  cd = malloc(sizeof(*cd)); hist = calloc(6, sizeof(*hist)); junk = calloc(6, sizeof(*junk));
+  if (!cd || !hist || !junk) { rc = DX_E_NOMEM; goto done; }
+  TRY(dx_index_quiva(text, n, 0, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
+  if (cnt == 0) { rc = DX_E_DEGENERATE; goto done; }
+  off = malloc((cnt + 1) * sizeof(*off)); len = malloc((cnt + 1) * sizeof(*len)); hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+  if (!off || !len || !hdr4) { rc = DX_E_NOMEM; goto done; }
+  TRY(dx_index_quiva(text, n, cnt, off, len, hdr4, &cnt, &plen, errline, errcode));
+  /* the widest slice in entries and bytes under the cap (an entry larger than the cap is a slice of its own) */
+  for (e0 = 0; e0 < cnt; )
+    { const uint64_t s0 = e0 ? off[e0 - 1] + 5 * ((uint64_t) len[e0 - 1] + 1) : 0;
+      uint64_t e1 = e0 + 1;
+      while (e1 < cnt && off[e1] + 5 * ((uint64_t) len[e1] + 1) - s0 <= cap) e1++;
+      if (e1 - e0 > maxent) maxent = (size_t) (e1 - e0);
+      if (off[e1 - 1] + 5 * ((uint64_t) len[e1 - 1] + 1) - s0 > slice_bytes) slice_bytes = (size_t) (off[e1 - 1] + 5 * ((uint64_t) len[e1 - 1] + 1) - s0);
+      e0 = e1;
+    }
+  hoff = malloc((maxent + 1) * sizeof(*hoff)); rel = malloc((maxent + 1) * sizeof(*rel));
+  if (!hoff || !rel) { rc = DX_E_NOMEM; goto done; }
+  TRY(dalloc(&pool, slice_bytes, &d_text));
+  TRY(dalloc(&pool, (maxent + 1) * 8, &d_off));
+  TRY(dalloc(&pool, (maxent + 1) * 4, &d_len));
+  TRY(dalloc(&pool, (maxent + 1) * 8, &d_hoff));
+  TRY(dalloc(&pool, (maxent + 1) * 8, &d_rec));
+  TRY(dalloc(&pool, maxent * 5 * 4 + 64, &d_seg));
+
+  at = 0;
+  for (pass = 1; pass <= 2; pass++)
+    { if (pass == 2)
+        { TRY(dx_qv_build((const uint64_t (*)[256]) hist, tot, &p, lossy, cd));          /* Create_QVcoding, dexqv.c:86 */
+          TRY(dx_qv_set_coding(ctx, cd, lossy));
+          rc = dx_qv_write_coding(cd, (const char *) text, plen, NULL, 0, &clen);
+          if (rc != DX_OK && rc != DX_E_SPACE) goto done;
+          head = 2 + clen;
+          head_img = malloc(head + 16);
+          if (!head_img) { rc = DX_E_NOMEM; goto done; }
+          { uint16_t key = 0x55aa;                                                       /* dexqv.c:105-108 */
+            memcpy(head_img, &key, 2);
+            TRY(dx_qv_write_coding(cd, (const char *) text, plen, head_img + 2, clen, &clen));
+          }
+          if (sink(user, head_img, head, 0)) { rc = DX_E_IO; goto done; }
+          at = head;
+        }
+      for (e0 = 0; e0 < cnt; )
+        { const uint64_t s0 = e0 ? off[e0 - 1] + 5 * ((uint64_t) len[e0 - 1] + 1) : 0;
+          uint64_t e1 = e0 + 1, s1, k, m, total = 0;
+          dx_qv_batch b;
+          while (e1 < cnt && off[e1] + 5 * ((uint64_t) len[e1] + 1) - s0 <= cap) e1++;
+          s1 = off[e1 - 1] + 5 * ((uint64_t) len[e1 - 1] + 1);
+          m  = e1 - e0;
+          for (k = 0; k < m; k++) rel[k] = off[e0 + k] - s0;
+          TRY(dx_h2d(ctx, d_text, text + s0, (size_t) (s1 - s0)));
+          TRY(dx_h2d(ctx, d_off, rel, (size_t) m * 8));
+          TRY(dx_h2d(ctx, d_len, len + e0, (size_t) m * 4));
+          b.d_text = d_text; b.d_off = d_off; b.d_len = d_len; b.n = m; b.line_pad = 1; b.text_bytes = s1 - s0;
+          if (pass == 1)
+            { TRY(dx_qv_prescan(ctx, &b, e0, &p));                                       /* QV.c:993-1015, state carried along */
+              TRY(dx_qv_hist(ctx, &b, e0, &p, hist, &tot));
+            }
+          else
+            { uint64_t t2 = 0, bound;
+              size_t   bb;
+              memset(junk, 0, 6 * sizeof(*junk));
+              TRY(dx_qv_hist(ctx, &b, e0, &p, junk, &t2));                               /* this slice's tokens (and its own counts, for the bound) */
+              bb = dx_frame_bound(hdr4 + 4 * e0, m, lwell, 0) + 16;
+              { uint8_t *nb = realloc(blob, bb);
+                if (nb == NULL) { rc = DX_E_NOMEM; goto done; }
+                blob = nb;
+              }
+              TRY(dx_frame_headers(hdr4 + 4 * e0, NULL, m, 0, &lwell, blob, hoff));
+              if (d_hdr) { dx_free(ctx, d_hdr); d_hdr = NULL; }
+              TRY(dx_malloc(ctx, (size_t) hoff[m] + 64, &d_hdr));
+              TRY(dx_h2d(ctx, d_hdr, blob, (size_t) hoff[m]));
+              TRY(dx_h2d(ctx, d_hoff, hoff, (size_t) (m + 1) * 8));
+              bound = hoff[m] + dx_qv_out_bound((const uint64_t (*)[256]) junk, m, cd, lossy);
+              if (bound > out_cap)
+                { if (d_out) { dx_free(ctx, d_out); d_out = NULL; }
+                  TRY(dx_malloc(ctx, (size_t) bound + 64, &d_out));
+                  out_cap = (size_t) bound;
+                }
+              TRY(dx_qv_encode_onepass(ctx, &b, d_hdr, d_hoff, d_seg, d_rec, d_out, out_cap, &total));
+              { shifted_sink h = { sink, user, (size_t) at };
+                TRY(dx_d2h_stream(ctx, d_out, total, pass_shifted, &h));
+              }
+              at += total;
+            }
+          e0 = e1;
+        }
+    }
+  *out_len = (size_t) at;
+  if (out) { *out = grow.p; grow.p = NULL; }
+  rc = DX_OK;
+
+done:
+  if (d_hdr) dx_free(ctx, d_hdr);
+  if (d_out) dx_free(ctx, d_out);
+  dfree_all(&pool);
+  (void) dx_trim(ctx, DX_TRIM_TOKENS);                     /* (a slice's tokens must not meet another batch that looks like it) */
+  free(off); free(hoff); free(rel); free(len); free(hdr4); free(blob); free(cd); free(hist); free(junk); free(head_img); free(grow.p);
+  return rc;
+}
+
+/* how much text the device takes at once: DEXGPU_TEXT_BUDGET (bytes) when set, else what fits beside the tokens, the scratch
+   regions and the output (about 2.5 bytes of device memory per byte of text), 0 = all of it */
+static size_t text_cap(dx_ctx *ctx, size_t n)
+{ const char *e = getenv("DEXGPU_TEXT_BUDGET");
+  uint64_t fr = 0, all = 0;
+  if (e != NULL && *e)
+    { const unsigned long long v = strtoull(e, NULL, 10);
+      return v && v < n ? (size_t) (v < (4u << 20) ? (4u << 20) : v) : 0;
+    }
+  if (dx_mem_info(ctx, &fr, &all) != DX_OK || fr == 0) return 0;
+  return (double) n * 2.5 > (double) fr ? (size_t) (fr / 3) : 0;
+}
+
 /* out != NULL: the image in memory; else through the sink, in order, nothing before all of it is known to exist */
 static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uint8_t **out, dx_sink_fn sink, void *user,
                       size_t *out_len, uint64_t *errline, int *errcode)
@@ -515,6 +671,10 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uin
   if (ctx == NULL || (out == NULL && sink == NULL) || out_len == NULL) return DX_E_ARG;
   if (out) *out = NULL;
   *out_len = 0;
+  { const size_t cap = text_cap(ctx, n);
+    if (cap)
+      return dexqv_sliced(ctx, text, n, lossy, cap, out, sink, user, out_len, errline, errcode);
+  }
 
   /* pass 1 of the reference (QVcoding_Scan, dexqv.c:81-82): validate + index.  Large images are
    * indexed on the GPU (newline scan + structure checks there, only the header lines come back);

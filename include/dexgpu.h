@@ -306,6 +306,9 @@ int dx_qv_onepass_info(const dx_ctx *ctx, dx_onepass_info *out);
  * overrides both.                                                                                              */
 int dx_set_scratch_budget(dx_ctx *ctx, uint64_t bytes);
 
+/* Device memory free / in all on the context's GPU right now (hipMemGetInfo). */
+int dx_mem_info(dx_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
+
 /* Gives device memory the context keeps between calls back to the device (it is allocated again when next needed):
  * DX_TRIM_SCRATCH the scratch regions of dx_qv_encode_onepass and dx_qv_hist, DX_TRIM_TOKENS the token slots the
  * histogram pass leaves for the encoder (the next encode without a fresh dx_qv_hist then reads the text),
@@ -402,6 +405,10 @@ int  dx_file_unpack2_to(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uin
 /* dx_file_dexqv with the .dexqv image delivered through a sink instead (the file's head, then the record stream
  * in chunks: dx_d2h_stream), for a caller that writes it straight to a file.  The sink sees nothing unless the
  * whole input was valid and encoded.                                                                       */
+/* (dx_file_dexqv / _to: a .quiva image that does not fit the device beside its tokens, scratch and output -- or is larger than
+ *  DEXGPU_TEXT_BUDGET bytes when that is set -- is worked through in SLICES of whole entries, like the reference streams a
+ *  file of any size (dexqv.c:112-143): the scan pass over every slice (histograms added up on the host, the scan state
+ *  carried along), the tables, then slice by slice again -- upload, tokens, encode, records out.  Same bytes.)          */
 int  dx_file_dexqv_to(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, dx_sink_fn sink, void *user,
                       size_t *out_len, uint64_t *errline, int *errcode);
 /* dexqv of ONE file on several GPUs (one context each; contiguous entry ranges, one host thread per

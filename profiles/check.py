@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""profiles/check.py -- is the committed evidence set a function of the tree?  (run by tests/test_profiles.py, no GPU needed)
+
+  1. profiles/MANIFEST.json names the set (tag, commit, files) and the SHA-256 of the device sources (dextractor_amd/csrc/*.hip,
+     *.hpp, dx_layout.h) it was measured on: a kernel edited after the set was made fails the check until the set is made again
+     (gpurun -- bash tools/evidence.sh; python tools/evidence_collect.py <tag>).
+  2. Every kernel's rocprofv3 average (<tag>_kernel_stats*.csv, `--kernel-trace --stats`) must agree
+       - within 3 % with the per-kernel times the PROFILED run itself reported (<tag>_profiled_bench*.json: same launches,
+         HIP events against the profiler's timestamps), and
+       - within 7 % with the un-profiled bench line of the set (<tag>_bench*.json; profiled runs clock a little lower),
+     kernel by kernel: the `frac` figures of DESIGN.md section 5 are (bytes in the bench line) / (these times)."""
+import csv, glob, hashlib, json, os, sys
+
+BENCH_ID = {"k_qv_encode_fast": "k_qv_encode", "k_qv_encode": "k_qv_encode_text", "k_qv_hist": "k_qv_hist", "k_qv_compact": "k_qv_compact"}
+
+
+def device_sources_hash(root):
+    h = hashlib.sha256()
+    base = os.path.join(root, "dextractor_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.hpp")) + [os.path.join(base, "dx_layout.h")]):
+        h.update(os.path.basename(p).encode() + b"\0")
+        h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
+def stats_avg_ms(path):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        name = r["Name"].split("(")[0].strip()
+        if name.startswith("void "):
+            name = name[5:]
+        name = name.split("<")[0]
+        calls, total = int(r["Calls"]), float(r["TotalDurationNs"])
+        a = out.setdefault(name, [0, 0.0])
+        a[0] += calls; a[1] += total
+    return {k: (v[1] / v[0] / 1e6, v[0], v[1] / 1e6) for k, v in out.items()}          # avg ms, calls, total ms
+
+
+def rel(a, b):
+    return abs(a - b) / max(a, b)
+
+
+def check(root):
+    prof = os.path.join(root, "profiles")
+    mpath = os.path.join(prof, "MANIFEST.json")
+    if not os.path.isfile(mpath):
+        return ["profiles/MANIFEST.json is missing"]
+    m = json.load(open(mpath))
+    problems = []
+    if m["device_sources_sha256"] != device_sources_hash(root):
+        problems.append(f"the device sources have changed since the evidence set {m['tag']} was made (commit {m['head'][:10]}): "
+                        "run tools/evidence.sh on the GPU box and tools/evidence_collect.py again")
+    f = lambda k: os.path.join(prof, m["files"][k]) if k in m["files"] else None
+    load = lambda k: json.load(open(f(k))) if f(k) and os.path.isfile(f(k)) else None
+
+    def compare(what, rocprof_ms, bench_ms, tol):
+        if rocprof_ms is None or bench_ms is None or bench_ms < 0.05:
+            return
+        if rel(rocprof_ms, bench_ms) > tol:
+            problems.append(f"{what}: rocprofv3 average {rocprof_ms:.3f} ms, bench line {bench_ms:.3f} ms (> {int(tol * 100)} % apart)")
+
+    # dexqv: encode-path kernels, per launch
+    if f("kernel_stats.csv"):
+        st = stats_avg_ms(f("kernel_stats.csv"))
+        for which, tol in (("profiled_bench.json", 0.03), ("bench.json", 0.07)):
+            d = load(which)
+            if d is None:
+                problems.append(f"{which} of the set is missing"); continue
+            for dev, bid in BENCH_ID.items():
+                if dev in st and bid in d.get("kernels", {}) and d["kernels"][bid]["launches"]:
+                    # (the stats run also holds the one untimed step that writes the group index: same kernels, same work)
+                    compare(f"{dev} [{which}]", st[dev][0], d["kernels"][bid]["ms_avg"], tol)
+            # the decoders: totals over the passes of the verification (launch counts differ from pass to pass)
+            if which == "profiled_bench.json":
+                tot = {}
+                for key in ("decode", "decode_indexed", "decode_walk_indexed"):
+                    for k, v in ((d.get(key) or {}).get("ms_by_kernel") or {}).items():
+                        tot[k] = tot.get(k, 0.0) + v
+                for k, v in tot.items():
+                    if k in st:
+                        compare(f"{k} (all passes) [{which}]", st[k][2], v, 0.05)
+            else:
+                for key, kernels in (("decode_indexed", ("k_qv_decode_sub", "k_qv_decode_runs")), ("decode", ("k_qv_decode_plain",))):
+                    for k in kernels:
+                        v = ((d.get(key) or {}).get("ms_by_kernel") or {}).get(k)
+                        if v and k in st:
+                            compare(f"{k} [{which}: {key}]", st[k][0] * (1 if key == "decode" else 1), v, 0.07)
+    for w in ("dexta", "dexar"):
+        if f(f"kernel_stats_{w}.csv"):
+            st = stats_avg_ms(f(f"kernel_stats_{w}.csv"))
+            for which, tol in ((f"profiled_bench_{w}.json", 0.03), (f"bench_{w}.json", 0.07)):
+                d = load(which)
+                if d is None:
+                    problems.append(f"{which} of the set is missing"); continue
+                compare(f"k_pack2_encode [{which}]", st.get("k_pack2_encode", (None,))[0], d.get("encode_ms"), tol)
+                compare(f"k_pack2_decode [{which}]", st.get("k_pack2_decode", (None,))[0], (d.get("decode") or {}).get("ms"), tol)
+    return problems
+
+
+if __name__ == "__main__":
+    p = check(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    print("ok" if not p else "\n".join(p))
+    sys.exit(1 if p else 0)

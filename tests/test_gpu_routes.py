@@ -135,3 +135,36 @@ def test_poisoned_allocations_change_nothing(poison):
     code = _POISON_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DEXGPU_POISON=poison), capture_output=True, timeout=600)
     assert r.returncode == 0 and b"POISON_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_file_larger_than_the_text_budget_goes_in_slices(monkeypatch, tmp_path):
+    """dx_file_dexqv / dx_file_dexqv_to on a .quiva image 1.5 to 6 times the text the device may hold at once (DEXGPU_TEXT_BUDGET):
+    the scan pass slice by slice (histograms summed on the host, delChar / subChar and their first entries carried along), the
+    tables, then every slice again -- upload, tokens, encode, records out -- under a scratch budget as well.  The bytes are
+    those of the one-shot driver and of the oracle; through the CLI too (the sink writes the slices at their offsets)."""
+    import os, subprocess
+    with api.Context(0) as ctx:
+        c = synth.make_quiva(700, seed=77, mean=9000, dist="lognormal")           # ~32 MB of text, entries of 2 .. 40 kb
+        whole = ctx.dexqv(c.text)
+        assert whole == O.dexqv(c.text)
+        for budget in (len(c.text) * 2 // 3, 5 << 20):                            # 2 slices; 7 slices of 5 MiB
+            monkeypatch.setenv("DEXGPU_TEXT_BUDGET", str(budget))
+            ctx.set_scratch_budget(64 << 20)
+            assert ctx.dexqv(c.text) == whole
+            assert ctx.dexqv(c.text, True) == O.dexqv(c.text, True)
+            ctx.set_scratch_budget(0)
+        late = synth.make_quiva(300, seed=78, mean=9000)                          # the first 'N' tag far into the file: delChar found
+        t = bytearray(late.text)                                                 # in a later slice than the first
+        for i in range(200):
+            L_, o = int(late.len[i]), int(late.off[i])
+            t[o + L_ + 1: o + 2 * L_ + 1] = bytes(t[o + L_ + 1: o + 2 * L_ + 1]).replace(b"N", b"A").replace(b"n", b"a")
+        t = bytes(t)
+        monkeypatch.setenv("DEXGPU_TEXT_BUDGET", str(5 << 20))
+        assert ctx.dexqv(t) == O.dexqv(t)
+    src = tmp_path / "big.quiva"
+    src.write_bytes(c.text)
+    tool = os.path.join(os.path.dirname(L.LIB_PATH), "bin", "dexqv")
+    if os.path.isfile(tool):
+        r = subprocess.run([tool, "-k", str(src)], env=dict(os.environ, DEXGPU_TEXT_BUDGET=str(5 << 20)), capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert (tmp_path / "big.dexqv").read_bytes() == whole
