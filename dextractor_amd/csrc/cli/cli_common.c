@@ -272,7 +272,15 @@ static int report_failure(dx_ctx *ctx, int tool, const uint8_t *in, size_t n, in
     { fprintf(stderr, "%s: System error, read failed!\n", Prog);                                 /* DB.h:136-139 */
       return 2;
     }
-  fprintf(stderr, "%s: %s (libdexgpu error %d)\n", Prog, dx_last_error(ctx), rc);
+  { const char *why = dx_last_error(ctx);
+    if (why == NULL || why[0] == '\0')                    /* (host-side failures carry a code only) */
+      why = rc == DX_E_DEGENERATE ? "a stream that needs a Huffman scheme holds no symbols (e.g. a deletion line of nothing but its run "
+                                    "character, or an empty file): the reference reads out of bounds there (QV.c:201), nothing is written"
+          : rc == DX_E_NOMEM      ? "out of memory"
+          : rc == DX_E_UNSUPPORTED ? "a code longer than 16 bits: the reference would write a file its own decoder cannot read"
+          : "failed";
+    fprintf(stderr, "%s: %s (libdexgpu error %d)\n", Prog, why, rc);
+  }
   return 1;
 }
 

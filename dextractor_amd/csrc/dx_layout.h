@@ -23,6 +23,6 @@ DXL_FN uint32_t dxl_run_base(uint32_t L)   { return 4u * dxl_sub_words(L); }
 /* words of an entry: the four plain shares, three header words, 64 group words per pass of either run-coded line */
 DXL_FN uint64_t dxl_entry_words(uint32_t L, uint32_t passes_del, uint32_t passes_sub)
 { return (uint64_t) dxl_run_base(L) + 3u + 64ull * ((uint64_t) passes_del + passes_sub); }
-/* tokens a run-coded line's slot holds (k_qv_hist's token hand-over; the host walk bounds its groups by the same figure) */
-DXL_FN uint32_t dxl_tok_limit(uint32_t L) { return (((L >> 1) + 64u) + 7u) & ~7u; }
+/* tokens a run-coded line can have at most (one per symbol; the slots of k_qv_hist's token hand-over are sized per batch) */
+DXL_FN uint32_t dxl_tok_limit(uint32_t L) { return L + 8u; }
 #endif

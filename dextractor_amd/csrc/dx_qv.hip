@@ -355,7 +355,10 @@ struct tok_sink
   uint32_t       *list;                        // ... and their indices in the batch (any order)
 };
 
-__host__ __device__ __forceinline__ uint32_t tok_room(uint32_t L) { return (((L >> 1) + 64u + TOK_XMARGIN) + 7u) & ~7u; }
+// tokens an entry's slot holds: the share fr8 / 256 of its symbols (see k_qv_density: what the batch's run density asks for;
+// 128 = half, the fixed share of rounds 2 and 3), 64 on top, the margin of the exception records
+__host__ __device__ __forceinline__ uint32_t tok_room(uint32_t L, uint32_t fr8)
+{ return (((uint32_t) (((uint64_t) L * fr8) >> 8) + 64u + TOK_XMARGIN) + 7u) & ~7u; }
 
 // run length of exception token `idx` of a line: bisection over its nx records (ascending token index)
 __device__ __forceinline__ uint32_t tok_exception(const uint32_t *slot_end, uint32_t nx, uint32_t idx)
@@ -717,11 +720,49 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
     }
 }
 
-// slot sizes of the token hand-over (tokens per entry)
+// How many of a run-coded line's symbols are tokens (not the run character)?  Counted on a sample -- up to 1024 entries spread
+// evenly over the batch, the first 4 KiB of their deletion and substitution lines -- so that the token slots can be sized for
+// the batch at hand: half a slot per symbol (rounds 2 and 3) sends every entry of a batch with run density 0.3 to the
+// text-reading encoder and wastes two thirds of the slots at 0.85.  cnt[0..3]: symbols seen / tokens among them, del then sub.
 __global__ __launch_bounds__(DX_BLOCK)
-void k_tok_rooms(const uint32_t *len, uint64_t n, uint32_t *room)
+void k_qv_density(qv_args a, uint64_t stride, unsigned long long *cnt)
+{ const int      lane = lane_id();
+  const uint64_t w    = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
+  const uint64_t r    = w * stride;
+  if (r >= a.n) return;
+  const uint32_t L = a.len[r], S = L < 4096u ? L : 4096u;
+  #pragma unroll 1
+  for (int k = 0; k < 2; k++)
+    { const int rc = k == 0 ? a.delChar : a.subChar;
+      if (rc < 0) continue;
+      const uint8_t *p = line_ptr(a, r, L, k == 0 ? 0 : 4);
+      uint32_t tokens = 0;
+      for (uint32_t j = (uint32_t) lane; j < S; j += 64u)
+        tokens += p[j] != (uint8_t) rc ? 1u : 0u;
+      tokens = wave_sum(tokens);
+      if (lane == 0)
+        { atomicAdd(&cnt[2 * k], (unsigned long long) S);
+          atomicAdd(&cnt[2 * k + 1], (unsigned long long) tokens);
+        }
+    }
+}
+
+// the slot share (in 256ths) the sample asks for: one and a half times the denser line's token share and a twentieth on top,
+// a quarter at least (entries differ), everything at most
+__device__ __forceinline__ uint32_t tok_share_of(const unsigned long long *cnt)
+{ const double fd = cnt[0] ? (double) cnt[1] / (double) cnt[0] : 0.0, fs = cnt[2] ? (double) cnt[3] / (double) cnt[2] : 0.0;
+  const double f  = 1.5 * (fd > fs ? fd : fs) + 0.05;
+  const uint32_t fr8 = (uint32_t) (256.0 * f + 0.999);
+  return fr8 < 64u ? 64u : (fr8 > 256u ? 256u : fr8);
+}
+
+// slot sizes of the token hand-over (tokens per entry); the share it used goes to cnt[4] for the host's records
+__global__ __launch_bounds__(DX_BLOCK)
+void k_tok_rooms(const uint32_t *len, uint64_t n, unsigned long long *cnt, uint32_t *room)
 { const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
-  if (i < n) room[i] = tok_room(len[i]);
+  const uint32_t fr8 = tok_share_of(cnt);
+  if (i == 0) cnt[4] = fr8;
+  if (i < n) room[i] = tok_room(len[i], fr8);
 }
 
 // =============================================================================================
@@ -1850,8 +1891,15 @@ static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params
       ctx->tk.list = (uint32_t *) (ctx->tk.count + 1);
       ctx->tk.cap_entries = n;
     }
-  hipLaunchKernelGGL(k_tok_rooms, dim3((unsigned) ((n + DX_BLOCK - 1) / DX_BLOCK)), dim3(DX_BLOCK), 0, ctx->stream,
-                     (const uint32_t *) b->d_len, n, d_room);
+  { unsigned long long *d_cnt = (unsigned long long *) (ctx->d_u64 + 48);          // (5 words: k_qv_density's four, the share chosen)
+    const uint64_t sample = n < 1024 ? n : 1024, stride = n / sample;
+    if (hipMemsetAsync(d_cnt, 0, 40, ctx->stream) != hipSuccess) { (void) hipGetLastError(); return false; }
+    qv_args a = make_args(b, p->delChar, p->subChar, 0);
+    hipLaunchKernelGGL(k_qv_density, dim3((unsigned) ((sample + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream,
+                       a, stride, d_cnt);
+    hipLaunchKernelGGL(k_tok_rooms, dim3((unsigned) ((n + DX_BLOCK - 1) / DX_BLOCK)), dim3(DX_BLOCK), 0, ctx->stream,
+                       (const uint32_t *) b->d_len, n, d_cnt, d_room);
+  }
   hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, (const uint32_t *) d_room, n, d_tile);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(DX_BLOCK), 0, ctx->stream, d_tile, ntiles, d_gran);
   hipLaunchKernelGGL(k_scan_apply, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, (const uint32_t *) d_room, n,

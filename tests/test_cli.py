@@ -172,3 +172,25 @@ def test_cli_pipe_mode_appends_to_an_existing_file(tmp_path):
     r = subprocess.run(f"{os.path.join(BIN, 'undexta')} -i -U <a.dexta 1<>rw", shell=True, cwd=str(tmp_path), capture_output=True)
     assert r.returncode == 0, r.stderr
     assert _read(out) == back + b"x" * 10
+
+
+@pytest.mark.gpu
+def test_cli_degenerate_file_is_refused_loudly_where_the_reference_reads_out_of_bounds(tmp_path):
+    """A file whose deletion line holds nothing but the run character leaves the deletion scheme an EMPTY histogram: the
+    reference builds a Huffman tree of no leaves and reads node[-1] (QV.c:201) -- undefined behaviour that happens to write a
+    file.  Documented deviation: dexqv here says so and exits 1, its output file left empty and the source
+    kept (as after any failure: the output is opened first, dexqv.c:70-72); what the compiled reference does with the same file
+    is recorded beside it, not asserted (it is not defined)."""
+    L_ = 40
+    text = b"@m/1/0_%d RQ=0.850\n" % L_ + b"5" * L_ + b"\n" + b"N" * L_ + b"\n" + b"3" * L_ + b"\n" + b"7" * L_ + b"\n" + b"9" * L_ + b"\n"
+    mine = tmp_path / "mine"; mine.mkdir()
+    _write(mine / "d.quiva", text)
+    r = run("dexqv", ["-k", "d.quiva"], mine)
+    assert r.returncode == 1, (r.returncode, r.stderr)
+    assert b"holds no symbols" in r.stderr and b"libdexgpu error -4" in r.stderr, r.stderr
+    assert (mine / "d.dexqv").read_bytes() == b"" and (mine / "d.quiva").exists()
+    if O.have_ref():
+        ref = tmp_path / "ref"; ref.mkdir()
+        _write(ref / "d.quiva", text)
+        q = run("dexqv", ["-k", "d.quiva"], ref, ref=True)
+        print("reference on the degenerate file: exit code", q.returncode, "stderr", q.stderr[:200], "wrote a file:", (ref / "d.dexqv").exists())
