@@ -33,9 +33,15 @@ def kname(full):
     return n.split("<")[0]
 
 
+def newest(paths):
+    """gpurun merges a call's files into gpurun_out/ and never removes older ones: of several runs' files, the last one's"""
+    paths = sorted(paths, key=os.path.getmtime)
+    return paths[-1:] if paths else []
+
+
 def counters(src, sub):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    for f in newest(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))):
         for r in csv.DictReader(open(f)):
             per[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return per
@@ -89,7 +95,7 @@ def main():
     src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
     here = os.path.dirname(os.path.abspath(__file__))
     for suffix in ("", "_dexta", "_dexar"):
-        ks = glob.glob(os.path.join(src, "prof_stats" + suffix, "*", "*_kernel_stats.csv"))
+        ks = newest(glob.glob(os.path.join(src, "prof_stats" + suffix, "*", "*_kernel_stats.csv")))
         if ks:
             shutil.copy(ks[0], os.path.join(here, f"{tag}_kernel_stats{suffix}.csv"))
     doc = {"tag": tag, "units": "bytes", "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count on 16 B/lane streams); WRITE_SIZE KiB x 1024",
