@@ -531,13 +531,14 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
             tok += float(hist_mine[0].sum() - hist_mine[0][prm.delChar])
         if prm.subChar >= 0:
             tok += float(hist_mine[3].sum() - hist_mine[3][prm.subChar])
+    by_hist = (state.get("route") or {}).get("direct") == 2     # sizes from the entries' own histograms, records written in place
     tok_lines = (1 if prm.delChar >= 0 else 0) + (1 if cd.subChar >= 0 else 0)           # lines the encoder takes from tokens
     text_lines_enc = 5 - (2 if prm.delChar >= 0 else 0) - (1 if cd.subChar >= 0 else 0) if tok else 5   # (del tokens carry the tags)
     spec = {   # kernel id -> (8(d) bytes per step, design bytes per step)
-        "k_qv_hist": (4.0 * bases, (5.0 if tok and prm.delChar >= 0 else 4.0) * bases + 2.0 * tok),
+        "k_qv_hist": (4.0 * bases, (5.0 if tok and prm.delChar >= 0 else 4.0) * bases + 2.0 * tok + (1536.0 * n if by_hist else 0.0)),
         "k_qv_encode": (5.0 * bases + out_b, 2.0 * tok + text_lines_enc * bases + out_b),
         "k_qv_encode_text": ((5.0 * bases + out_b) if args.twopass or not tok else 0.0, (5.0 * bases + out_b) if args.twopass or not tok else 0.0),
-        "k_qv_sizes": (0.0, 0.0), "k_qv_compact": (0.0, 0.0), "k_scan": (0.0, 0.0), "k_qv_prescan": (0.0, 0.0),
+        "k_qv_sizes": (0.0, 1536.0 * n if by_hist else 0.0), "k_qv_compact": (0.0, 0.0), "k_scan": (0.0, 0.0), "k_qv_prescan": (0.0, 0.0),
     }
     if not tok and not args.twopass:                       # no tokens: the text-reading kernel is the encoder
         spec["k_qv_encode"] = (0.0, 0.0)
@@ -561,7 +562,8 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
     dom = max((k for k in per_kernel if spec[k][0]), key=lambda k: per_kernel[k]["ms_per_step"])
     dk = per_kernel[dom]
     dom_ms_launch = dk["ms_per_step"] / dk["launches_per_step"]
-    roofline = {"kernel": "whole step (k_qv_prescan, k_qv_hist, host tables, k_qv_encode_fast + k_qv_compact per group)",
+    roofline = {"kernel": "whole step (k_qv_prescan, k_qv_hist, host tables, k_qv_sizes_hist, k_qv_encode_fast in place)" if by_hist else
+                          "whole step (k_qv_prescan, k_qv_hist, host tables, k_qv_encode_fast + k_qv_compact per group)",
                 "bound": "hbm", "achieved": round(step_algo / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(step_algo / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
                 "algo_bytes_per_step": step_algo,
@@ -575,7 +577,9 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
     pipe = {"algo_bytes": step_algo, "step_ms": round(step_s * 1e3, 3),
             "kernel_ms_sum": round(sum(kern[k]["ms_avg"] * kern[k]["launches"] / args.steps for k in kern if k != "k_synth"), 3),
             "GBps": round(step_algo / step_s / 1e9, 1),
-            "encoder": "two pass (sizes, encode)" if args.twopass else "one pass (scratch slots, compaction on a second stream)"}
+            "encoder": "two pass (sizes, encode)" if args.twopass else
+                       ("one pass (sizes from the entries' own histograms, records written in place)" if by_hist else
+                        "one pass (scratch slots, compaction on a second stream)")}
     pipe["frac"] = round(pipe["GBps"] / HBM_PEAK_GBS, 4)
 
     cpu_res = None

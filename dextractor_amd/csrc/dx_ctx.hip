@@ -153,6 +153,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   (void) hipFree(ctx->sx.idx); (void) hipFree(ctx->sx.off); (void) hipFree(ctx->sx.room); (void) hipFree(ctx->sx.none);
   if (ctx->h_stage[0]) (void) hipHostFree(ctx->h_stage[0]);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
+  (void) hipFree(ctx->tk.eh);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
   for (int k = 0; k < 19; k++) (void) hipEventDestroy(ctx->ev[k]);
@@ -185,7 +186,7 @@ extern "C" int dx_trim(dx_ctx *ctx, int what)
     }
   if (what & DX_TRIM_TOKENS)
     { (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info);
-      (void) hipFree(ctx->tk.count);
+      (void) hipFree(ctx->tk.count); (void) hipFree(ctx->tk.eh);
       memset(&ctx->tk, 0, sizeof(ctx->tk));
     }
   if (what & DX_TRIM_INDEX)

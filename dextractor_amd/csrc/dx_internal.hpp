@@ -54,6 +54,10 @@ struct dx_ctx
   { uint16_t *del, *sub;       // token slots of the deletion / substitution stream, tok_off[r] .. tok_off[r+1]
     uint64_t *off;             // n + 1 slot offsets, in tokens
     uint32_t *info;            // n x 4: tokens of del | bit 31 unusable, of sub | bit 31, open run at the end of del, of sub
+    uint32_t *eh;              // n x 384 words: every entry's own histograms as 768 counters of 16 bits (k_qv_hist<true>; see hist_wave_own)
+    size_t    cap_eh;          // entries eh holds
+    int       eh_valid;        // eh belongs to the tokens (the FAST instance made them)
+    uint32_t  share8;          // the slot share k_tok_rooms chose for the batch (256ths of an entry's symbols; from the sampled run density)
     unsigned long long *count; // device copy of `unusable`, followed in the same allocation by ...
     uint32_t *list;            // ... the indices of those entries (any order)
     size_t    cap_tokens, cap_entries;        // what the buffers above hold

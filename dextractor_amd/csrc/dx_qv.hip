@@ -344,7 +344,7 @@ __device__ __forceinline__ void hist_plain_step(const u32x4 &c, int valid, bool 
 #define TOK_RUN_MAX  127u                      // run field 127: the run's length is in the exception list
 #define TOK_BAD      0x80000000u               // info word: the stream's tokens are unusable
 #define TOK_INFO     8u                        // info words per entry: tokens of del | TOK_BAD, of sub | TOK_BAD, run open at the end
-                                               // of del, of sub, exceptions of del, of sub, 2 spare
+                                               // of del, of sub, exceptions of del, of sub, "no counters" (hist_wave_own), 1 spare
 #define TOK_XMARGIN  40u                       // token slots kept free for the exceptions one step can add (<= 9 runs of >= 127 in 1 KiB)
 
 struct tok_sink
@@ -435,28 +435,47 @@ __device__ __forceinline__ uint32_t tag_code(uint32_t letter)
   return (uint32_t) (((1ull << 4) | (2ull << 12) | (3ull << 38)) >> (2u * i)) & 3u;
 }
 
-// LDS of one wave for the run-coded lines: a copy of the step's chunk and of its deletion tags (a lane reads back the
-// bytes under ITS OWN tokens: one address and two byte reads per token where picking byte b of a chunk in registers takes
-// nine byte permutes and masks) and the step's token list
+// LDS of one wave.  !FAST (everything decided at run time): a copy of the step's chunk and of its deletion tags (a lane
+// reads back the bytes under ITS OWN tokens: one address and two byte reads per token) and the step's token list; the
+// histograms are the workgroup's (hist_lds).  FAST: the wave's OWN histograms of the entry it is working on --
+//   pp: the two plain lines, every counter kept 4 times (copy = lane & 3): [line][symbol][copy];
+//   ps, pr: the token lines: symbols of del, of sub (two copies), runs of del, of sub, 128 counters each --
+// which at the entry's end go to the workgroup's 256-bin tables AND, as 768 counters of 16 bits, to memory: with the code
+// lengths known (after the tables have been built) an entry's five segment sizes are then a dot product away
+// (k_qv_sizes_hist), the encoder writes every record where it belongs, and the scratch slots and their compaction -- 30 of
+// the 133 GB a step moved in round 3 -- are gone.
 struct hist_wave_lds
 { uint8_t  chunk[DX_STEP], tags[DX_STEP];
   uint16_t list[DX_STEP];
 };
+struct hist_wave_own
+{ uint32_t pp[2][128][4];                               // (16 bits packed two to a word, eight copies: the same time, 3 instructions more per byte)
+  uint32_t ps[2][128][2];                               // token symbols of del, of sub: two copies (copy = lane & 1)
+  uint32_t pr[2][128];                                  // runs of del, of sub
+  uint16_t list[DX_STEP];
+};
+#define EH_WORDS 384u                                   // an entry's counters in memory: 768 x 16 bits: ins, mrg, del, sub, del runs, sub runs
 
-template <bool TAGS>
-__device__ __forceinline__ void hist_runs_step(hist_wave_lds &W, const u32x4 &c, const u32x4 &t, uint32_t vmask, uint32_t sv, uint32_t rc4,
+// OWN: the fast bins are the wave's own (the symbols' in two copies, the runs' in one; the run bins count whatever `inc` says
+// for the workgroup's tables -- the entry's sizes need every token); LDSX: symbol and tag are read back from the LDS copy of
+// the chunk (else they come out of the chunk in registers: no room for the copies beside a wave's own counters).
+template <bool TAGS, bool OWN, bool LDSX>
+__device__ __forceinline__ void hist_runs_step(hist_wave_lds *W, uint16_t *wlist, const u32x4 &c, const u32x4 &t, uint32_t vmask, uint32_t sv, uint32_t rc4,
                                                uint32_t &C, uint32_t &nrun, uint32_t *hs, uint32_t *slow_s,
                                                uint32_t *hr, uint32_t *slow_r, uint32_t inc,
                                                uint16_t *tok, uint32_t &ntok, uint32_t room, uint32_t &bad, uint32_t &nexc,
                                                tok_pend &pend_out)
-{ const uint32_t lane  = (uint32_t) lane_id();
+{ constexpr uint32_t HCS = OWN ? 2u : HC_RSYM, HCR = OWN ? 1u : HC_RUN;
+  const uint32_t lane  = (uint32_t) lane_id();
   const uint32_t nr0   = chunk_ne_mask(c, rc4) & vmask;
   const uint32_t cnt   = __popc(nr0);
   const uint32_t incl  = wave_incl_scan(cnt);
   const uint32_t total = wave_total(incl);
   nrun += sv - total;                                            // wave-uniform
-  *(u32x4 *) (W.chunk + 16u * lane) = c;
-  if (TAGS) *(u32x4 *) (W.tags + 16u * lane) = t;
+  if (LDSX)
+    { *(u32x4 *) (W->chunk + 16u * lane) = c;
+      if (TAGS) *(u32x4 *) (W->tags + 16u * lane) = t;
+    }
   // room: what the slot holds less TOK_XMARGIN (0: no tokens wanted)
   const bool emit = !(HIST_SKIP & 8) && !bad && ntok + total + 4u * nexc <= room;
   if (!emit) bad = 1;                                            // more tokens (and exceptions) than the slot holds
@@ -467,19 +486,28 @@ __device__ __forceinline__ void hist_runs_step(hist_wave_lds &W, const u32x4 &c,
   const uint32_t s0    = wave_shr1(imax) - (16u * lane + C);     // the run in front of the lane's token at byte b: b - s
   const uint32_t li0   = incl - cnt;                             // the lane's first token in the step's list
   uint32_t nr = (HIST_SKIP & 1) ? 0u : nr0, s = s0, acc = 0;
-  uint16_t      *lp = W.list + li0;
-  const uint8_t *cp = W.chunk + 16u * lane;
+  uint16_t      *lp = wlist + li0;
+  const uint8_t *cp = LDSX ? W->chunk + 16u * lane : (const uint8_t *) NULL;
+  const uint32_t pinc = OWN ? 1u : inc;                          // what the fast run bins count
   while (nr)
     { const uint32_t b   = (uint32_t) __builtin_ctz(nr);
       nr &= nr - 1u;
-      const uint32_t x   = cp[b];
-      const uint32_t tg  = TAGS ? cp[b + DX_STEP] : 0u;          // (both reads in front of the atomics: one wait for the two)
+      uint32_t x, tg = 0;
+      if (!LDSX)
+        { const uint32_t selA = (b & 7u) | 0x0c0c0c00u, selB = ((b >> 1) & 4u) | 0x0c0c0c00u;
+          x = chunk_byte_sel(c, selA, selB);
+          if (TAGS) tg = chunk_byte_sel(t, selA, selB);
+        }
+      else
+        { x = cp[b];
+          if (TAGS) tg = cp[b + DX_STEP];                        // (both reads in front of the atomics: one wait for the two)
+        }
       const uint32_t run = b - s;
       const uint32_t r7  = run < TOK_RUN_MAX ? run : TOK_RUN_MAX;
       s   = b + 1u;
       acc = max(acc, max(run, x));
-      atomicAdd(&hs[(x & (HSYM_FAST - 1)) * HC_RSYM], 1u);
-      atomicAdd(&hr[r7 * HC_RUN], inc);
+      atomicAdd(&hs[(x & (HSYM_FAST - 1)) * HCS], 1u);
+      atomicAdd(&hr[r7 * HCR], pinc);
       uint32_t tk = x | (r7 << 7);
       if (TAGS) tk = (tk << 2) | tag_code(tg);
       else      tk <<= 2;
@@ -492,16 +520,16 @@ __device__ __forceinline__ void hist_runs_step(hist_wave_lds &W, const u32x4 &c,
       while (m)
         { const uint32_t b   = (uint32_t) __builtin_ctz(m);
           m &= m - 1u;
-          const uint32_t x   = cp[b];
+          const uint32_t x   = LDSX ? (uint32_t) cp[b] : chunk_byte(c, (int) b);
           const uint32_t run = b - s;
           s = b + 1u;
           if (run >= TOK_RUN_MAX)
-            { atomicSub(&hr[TOK_RUN_MAX * HC_RUN], inc);
+            { atomicSub(&hr[TOK_RUN_MAX * HCR], pinc);
               atomicAdd(&slow_r[run > 255u ? 255u : run], inc);                                   // QV.c:717-720
               ne++;
             }
           if (x >= HSYM_FAST)
-            { atomicSub(&hs[(x & (HSYM_FAST - 1)) * HC_RSYM], 1u);
+            { atomicSub(&hs[(x & (HSYM_FAST - 1)) * HCS], 1u);
               atomicAdd(&slow_s[x], 1u);
               odd = 1;
             }
@@ -525,15 +553,17 @@ __device__ __forceinline__ void hist_runs_step(hist_wave_lds &W, const u32x4 &c,
             }
           nexc += wave_total(ince);
         }
+      else if (OWN && __any((int) ne))                          // (no record of these runs: the entry's sizes cannot be had from its counters)
+        bad = 1;
     }
   if (emit)
     { __builtin_amdgcn_wave_barrier();                           // the list is complete: a wave's LDS instructions execute in order,
       if (HIST_SKIP & 32) { }                                    //   only the compiler has to be kept from moving them
       else if (total <= 256u)
-        { pend_out.v = *(const uint64_t *) (W.list + 4u * lane); pend_out.n = total; pend_out.at = ntok; }
+        { pend_out.v = *(const uint64_t *) (wlist + 4u * lane); pend_out.n = total; pend_out.at = ntok; }
       else                                                       // (more than a quarter of the step's symbols: straight out)
         for (uint32_t i = 4u * lane; i < total; i += 256u)
-          *(u64_u *) (tok + ntok + i) = *(const uint64_t *) (W.list + i);
+          *(u64_u *) (tok + ntok + i) = *(const uint64_t *) (wlist + i);
       ntok += total;
       if (__any((int) odd)) bad = 1;
     }
@@ -559,6 +589,35 @@ __device__ __forceinline__ void hist_plain_pair(const u32x4 &c2, const u32x4 &c3
     }
 }
 
+// ... and into the wave's own packed counters (hist_wave_own.pp); a byte >= 128 goes to the workgroup's 256-bin table and
+// is reported (the entry's counters then do not hold all of it)
+__device__ __forceinline__ uint32_t hist_plain_pair_own(const u32x4 &c2, const u32x4 &c3, int valid, bool full, uint32_t (*pp)[128][4],
+                                                        uint32_t *slow_ins, uint32_t *slow_mrg)
+{ const uint32_t col = (uint32_t) lane_id() & 3u;
+  uint32_t *const q0 = &pp[0][0][col], *const q1 = &pp[1][0][col];
+#define OWN_ADD(q, x) atomicAdd(&(q)[4u * (x)], 1u)
+  uint32_t wide = 0;
+  if (full && !__any((int) ((c2.x | c2.y | c2.z | c2.w | c3.x | c3.y | c3.z | c3.w) & 0x80808080u)))
+    {
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        OWN_ADD(q0, BYTE_OF(c2, b));
+      #pragma unroll
+      for (int b = 0; b < 16; b++)
+        OWN_ADD(q1, BYTE_OF(c3, b));
+    }
+  else
+    for (int b = 0; b < valid; b++)
+      { const uint32_t x = chunk_byte(c2, b), y = chunk_byte(c3, b);
+        if (x < 128u) OWN_ADD(q0, x);
+        else          { atomicAdd(&slow_ins[x], 1u); wide = 1; }
+        if (y < 128u) OWN_ADD(q1, y);
+        else          { atomicAdd(&slow_mrg[y], 1u); wide = 1; }
+      }
+#undef OWN_ADD
+  return wide;
+}
+
 // bin of the histogram g_hist[6*256] that LDS word k (of the fast tables, then the slow ones) counts
 __device__ __forceinline__ uint32_t hist_bin_of(uint32_t k)
 { if (k < HIST_W_PLAIN)                                          // ins, mrg
@@ -577,22 +636,51 @@ __device__ __forceinline__ uint32_t hist_copies_of(uint32_t k)
 { return k < HIST_W_PLAIN ? HC_PLAIN : (k < HIST_W_PLAIN + HIST_W_RSYM ? HC_RSYM : HC_RUN); }
 
 // FAST: tokens wanted and both run characters known -- the usual launch: both lines are run-coded in every entry, the tag
-// line travels with them, and none of that is asked per entry and step; !FAST: everything decided at run time.
-template <bool FAST>
+// line travels with them, none of that is asked per entry and step, and the histograms are first the wave's own, per
+// entry (hist_wave_own); !FAST: everything decided at run time, the workgroup's replicated bins.
+// OWNTOK (with FAST): the token lines' counters are the wave's own too -- at the usual run densities.  Where more than about a
+// quarter of a run-coded line's symbols are tokens (k_qv_density), half of them have the same run in front (run 0) and the
+// lanes of a wave queue up at one counter: those batches take the instance whose token lines count in the workgroup's
+// replicated bins, and the size kernel reads their tokens instead of counters.
+template <bool FAST, bool OWNTOK> struct hist_smem;
+template <> struct hist_smem<false, false> { hist_lds H; hist_wave_lds W[HIST_NWAVE]; };
+template <> struct hist_smem<true, true>   { uint32_t slow[6][256]; hist_wave_own W[HIST_NWAVE]; };
+struct hist_wave_plain { uint32_t pp[2][128][4]; uint16_t list[DX_STEP]; };
+template <> struct hist_smem<true, false>
+{ uint32_t slow[6][256];
+  uint32_t rsym[2][HSYM_FAST][HC_RSYM], run[2][HRUN_FAST][HC_RUN];
+  hist_wave_plain W[HIST_NWAVE];
+};
+
+template <bool FAST, bool OWNTOK>
 __global__ __launch_bounds__(HIST_BLOCK, (HIST_NWAVE * HIST_PER_CU + 3) / 4)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
-               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts)
-{ __shared__ hist_lds H;
-  __shared__ __attribute__((aligned(16))) hist_wave_lds s_wave[HIST_NWAVE];
+               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts, uint32_t *eh /* n x EH_WORDS (FAST) */)
+{ __shared__ __attribute__((aligned(16))) hist_smem<FAST, OWNTOK> S;
+  typedef hist_smem<false, false> smem_g;
+  typedef hist_smem<true, true>   smem_a;
+  typedef hist_smem<true, false>  smem_b;
   const int      lane  = lane_id();
   const int      tid   = threadIdx.x;
-  hist_wave_lds &W     = s_wave[tid >> 6];
-  uint32_t *const words = &H.plain[0][0][0];                    // the whole of H as words
-  const uint32_t  nwords = sizeof(hist_lds) / 4;
+  const int      wid   = tid >> 6;
+  uint32_t (*const slow)[256] = !FAST ? ((smem_g *) (void *) &S)->H.slow : (OWNTOK ? ((smem_a *) (void *) &S)->slow : ((smem_b *) (void *) &S)->slow);
+  hist_lds      *const Hp = FAST ? (hist_lds *) NULL : &((smem_g *) (void *) &S)->H;
+  hist_wave_lds *const Wl = FAST ? (hist_wave_lds *) NULL : &((smem_g *) (void *) &S)->W[wid];
+  hist_wave_own *const Wo = FAST && OWNTOK ? &((smem_a *) (void *) &S)->W[wid] : (hist_wave_own *) NULL;
+  smem_b        *const Sb = FAST && !OWNTOK ? (smem_b *) (void *) &S : (smem_b *) NULL;
+  uint32_t (*const ppw)[128][4] = !FAST ? (uint32_t (*)[128][4]) NULL : (OWNTOK ? Wo->pp : Sb->W[wid].pp);
+  uint16_t      *const wlist = !FAST ? Wl->list : (OWNTOK ? Wo->list : Sb->W[wid].list);
+  uint32_t *const words = (uint32_t *) (void *) &S;              // the whole of S as words (zeroed at the start)
+  const uint32_t  nwords = sizeof(S) / 4;
   const bool      toks  = FAST || ts.del != NULL;
-  // this lane's copy of the run-coded lines' fast bins
-  uint32_t *const hs0 = &H.rsym[0][0][(uint32_t) lane & (HC_RSYM - 1)], *const hs4 = &H.rsym[1][0][(uint32_t) lane & (HC_RSYM - 1)];
-  uint32_t *const hr0 = &H.run[0][0][(uint32_t) lane & (HC_RUN - 1)],   *const hr4 = &H.run[1][0][(uint32_t) lane & (HC_RUN - 1)];
+  // the run-coded lines' fast bins: this lane's copy of the workgroup's, or the wave's own
+  constexpr bool OT = FAST && OWNTOK;
+  uint32_t (*const rsymp)[HSYM_FAST][HC_RSYM] = FAST ? (OWNTOK ? (uint32_t (*)[HSYM_FAST][HC_RSYM]) NULL : Sb->rsym) : Hp->rsym;
+  uint32_t (*const runp)[HRUN_FAST][HC_RUN]   = FAST ? (OWNTOK ? (uint32_t (*)[HRUN_FAST][HC_RUN]) NULL : Sb->run) : Hp->run;
+  uint32_t *const hs0 = OT ? &Wo->ps[0][0][(uint32_t) lane & 1u] : &rsymp[0][0][(uint32_t) lane & (HC_RSYM - 1)];
+  uint32_t *const hs4 = OT ? &Wo->ps[1][0][(uint32_t) lane & 1u] : &rsymp[1][0][(uint32_t) lane & (HC_RSYM - 1)];
+  uint32_t *const hr0 = OT ? Wo->pr[0] : &runp[0][0][(uint32_t) lane & (HC_RUN - 1)];
+  uint32_t *const hr4 = OT ? Wo->pr[1] : &runp[1][0][(uint32_t) lane & (HC_RUN - 1)];
   const uint32_t  rc0 = (uint32_t) (a.delChar & 0xff) * 0x01010101u, rc4 = (uint32_t) (a.subChar & 0xff) * 0x01010101u;
 
   for (uint32_t k = tid; k < nwords; k += HIST_BLOCK) words[k] = 0;
@@ -624,32 +712,35 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
       const bool tags = FAST || tk0 != NULL;
 
       uint32_t pos = 16u * lane;
-      u32x4 c0 = fetch(p0, pos, L, over), c2 = fetch(p2, pos, L, over);
-      u32x4 c3 = fetch(p3, pos, L, over), c4 = fetch(p4, pos, L, over);
+      u32x4 c0 = fetch(p0, pos, L, over), c4 = fetch(p4, pos, L, over);
       u32x4 t1 = c0;
       if (tags) t1 = fetch(p1, pos, L, over);          // the deletion tags travel with the step's other chunks
       for (uint32_t base = 0; base < L; base += DX_STEP)
         { const uint32_t np = pos + DX_STEP;
-          // The last step's tokens leave first (tok_pend), then the next step's chunks are requested: the step ends with
-          // the wait for them -- the copies c = d below; with token stores in the loop every wait the compiler places
-          // is vmcnt(0) -- and by then both have had the whole step.  The explicit wait tells the compiler that nothing
-          // older is outstanding here (true but for an entry's first step, whose chunks were requested just before the
-          // loop): without it it waits for "everything" at the first use of a chunk in the step -- i.e. for the
+          // The last step's tokens leave first (tok_pend), then come the requests: the two plain lines' chunks of THIS step
+          // (they are looked at last, behind the run-coded lines: most of a step away; a register set of their own for the
+          // next step's would cost the kernel its fourth wave per SIMD) and the run-coded lines' chunks of the NEXT step.
+          // The step ends with the wait for those -- the copies c = d below; with token stores in the loop every wait the
+          // compiler places is vmcnt(0) -- and by then they have had the whole step.  The explicit wait tells the compiler
+          // that nothing older is outstanding here (true but for an entry's first step, whose chunks were requested just
+          // before the loop): without it it waits for "everything" at the first use of a chunk in the step -- i.e. for the
           // requests made a moment ago.
           __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
           if (toks)
             { tok_flush(pd0, tk0);
               tok_flush(pd4, tk4);
             }
-          u32x4 d0, d2, d3, d4, u1 = c0;               // (without tags u1 is never looked at; a copy of d0 would wait for d0's load)
-          if (HIST_BARE_FETCH && base + 2u * DX_STEP <= L)   // the whole next step is inside the lines: bare loads (see fetch_step)
-            { d0 = *(const u32x4_u *) (p0 + np); d2 = *(const u32x4_u *) (p2 + np);
-              d3 = *(const u32x4_u *) (p3 + np); d4 = *(const u32x4_u *) (p4 + np);
+          u32x4 c2, c3, d0, d4, u1 = c0;               // (without tags u1 is never looked at; a copy of d0 would wait for d0's load)
+          if (HIST_BARE_FETCH && base + DX_STEP <= L)  // this whole step is inside the lines: bare loads (see fetch_step)
+            { c2 = *(const u32x4_u *) (p2 + pos); c3 = *(const u32x4_u *) (p3 + pos); }
+          else
+            { c2 = fetch(p2, pos, L, over); c3 = fetch(p3, pos, L, over); }
+          if (HIST_BARE_FETCH && base + 2u * DX_STEP <= L)   // ... and so is the whole next step
+            { d0 = *(const u32x4_u *) (p0 + np); d4 = *(const u32x4_u *) (p4 + np);
               if (tags) u1 = *(const u32x4_u *) (p1 + np);
             }
           else
-            { d0 = fetch(p0, np, L, over); d2 = fetch(p2, np, L, over);
-              d3 = fetch(p3, np, L, over); d4 = fetch(p4, np, L, over);
+            { d0 = fetch(p0, np, L, over); d4 = fetch(p4, np, L, over);
               if (tags) u1 = fetch(p1, np, L, over);
             }
           const uint32_t sv    = L - base >= DX_STEP ? DX_STEP : L - base;
@@ -657,30 +748,76 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           const int      valid = valid_of(pos, L);
           const uint32_t vmask = (1u << valid) - 1u;
           if (HIST_SKIP & 16) { }
-          else if (drun) hist_runs_step<true>(W, c0, t1, vmask, sv, rc0, C0, n0, hs0, H.slow[DX_DEL], hr0, H.slow[DX_DRUN],
-                                              dinc, tk0, nt0, tk0 != NULL ? room : 0u, bad0, nx0, pd0);   // (no tags wanted: t1 = c0, never stored)
-          else      hist_plain_step<HC_RSYM>(c0, valid, full, H.rsym[0], H.slow[DX_DEL]);
+          else if (drun) hist_runs_step<true, OT, !FAST>(Wl, wlist, c0, t1, vmask, sv, rc0, C0, n0, hs0, slow[DX_DEL], hr0, slow[DX_DRUN],
+                                                    dinc, tk0, nt0, tk0 != NULL ? room : 0u, bad0, nx0, pd0);   // (no tags wanted: t1 = c0, never stored)
+          else      hist_plain_step<HC_RSYM>(c0, valid, full, Hp->rsym[0], slow[DX_DEL]);
           if (HIST_SKIP & 16) { }
-          else if (srun) hist_runs_step<false>(W, c4, c4, vmask, sv, rc4, C4, n4, hs4, H.slow[DX_SUB], hr4, H.slow[DX_SRUN],
-                                               sinc, tk4, nt4, tk4 != NULL ? room : 0u, bad4, nx4, pd4);
-          else      hist_plain_step<HC_RSYM>(c4, valid, full, H.rsym[1], H.slow[DX_SUB]);
-          if (!(HIST_SKIP & 2))
-            hist_plain_pair(c2, c3, valid, full, H);
-          c0 = d0; c2 = d2; c3 = d3; c4 = d4; t1 = u1;
+          else if (srun) hist_runs_step<false, OT, !FAST>(Wl, wlist, c4, c4, vmask, sv, rc4, C4, n4, hs4, slow[DX_SUB], hr4, slow[DX_SRUN],
+                                                     sinc, tk4, nt4, tk4 != NULL ? room : 0u, bad4, nx4, pd4);
+          else      hist_plain_step<HC_RSYM>(c4, valid, full, Hp->rsym[1], slow[DX_SUB]);
+          if (HIST_SKIP & 2) { }
+          else if (FAST) bad0 |= hist_plain_pair_own(c2, c3, valid, full, ppw, slow[DX_INS], slow[DX_MRG]);
+          else           hist_plain_pair(c2, c3, valid, full, *Hp);
+          c0 = d0; c4 = d4; t1 = u1;
           pos = np;
         }
       tok_flush(pd0, tk0);
       tok_flush(pd4, tk4);
+      if (FAST)
+        { // The entry's counters: to the workgroup's tables (the run counters only from del_first / sub_first on) and, 16 bits
+          // each, to memory.  Lane l holds the plain lines' symbols 2 l, 2 l + 1 (four copies each) and the same two bins of each of
+          // the four token tables.  (An entry of 2^16 symbols and more has no use for its 16-bit counters: it is on the list of the
+          // text-reading kernels; the workgroup's tables get the full counts.)
+          __builtin_amdgcn_wave_barrier();
+          uint32_t *e32 = eh + (uint64_t) r * EH_WORDS;
+          const u32x4 zero = { 0u, 0u, 0u, 0u };
+          #pragma unroll
+          for (int k = 0; k < 2; k++)
+            { u32x4 *w = (u32x4 *) &ppw[k][2 * lane][0];
+              const u32x4 v0 = w[0], v1 = w[1];
+              w[0] = zero; w[1] = zero;
+              const uint32_t ce = v0.x + v0.y + v0.z + v0.w, co = v1.x + v1.y + v1.z + v1.w;
+              e32[64 * k + lane] = (ce & 0xffffu) | (co << 16);
+              if (ce | co)
+                { atomicAdd(&slow[DX_INS + k][2 * lane], ce);
+                  atomicAdd(&slow[DX_INS + k][2 * lane + 1], co);
+                }
+            }
+          #pragma unroll
+          for (int k = 0; k < (OT ? 4 : 0); k++)
+            { uint32_t v0, v1;
+              if (k < 2)
+                { u32x4 *w = (u32x4 *) &Wo->ps[k][2 * lane][0];
+                  const u32x4 v = w[0];
+                  w[0] = zero;
+                  v0 = v.x + v.y; v1 = v.z + v.w;
+                }
+              else
+                { uint32_t *w = &Wo->pr[k - 2][2 * lane];
+                  v0 = w[0]; v1 = w[1];
+                  w[0] = 0; w[1] = 0;
+                }
+              e32[128 + 64 * k + lane] = (v0 & 0xffffu) | (v1 << 16);
+              const int      tab = k == 0 ? DX_DEL : (k == 1 ? DX_SUB : (k == 2 ? DX_DRUN : DX_SRUN));
+              const uint32_t on  = k == 2 ? dinc : (k == 3 ? sinc : 1u);
+              if (on && (v0 | v1))
+                { atomicAdd(&slow[tab][2 * lane], v0);
+                  atomicAdd(&slow[tab][2 * lane + 1], v1);
+                }
+            }
+          __builtin_amdgcn_wave_barrier();
+        }
       if (drun)                                        // trailing run + the run character's own count
-        { if (dinc && C0 > 0 && lane == 0) atomicAdd(&H.slow[DX_DRUN][C0 > 255u ? 255u : C0], 1u);
-          if (lane == 0 && n0) atomicAdd(&H.slow[DX_DEL][a.delChar], n0);
+        { if (dinc && C0 > 0 && lane == 0) atomicAdd(&slow[DX_DRUN][C0 > 255u ? 255u : C0], 1u);
+          if (lane == 0 && n0) atomicAdd(&slow[DX_DEL][a.delChar], n0);
         }
       if (srun)
-        { if (sinc && C4 > 0 && lane == 0) atomicAdd(&H.slow[DX_SRUN][C4 > 255u ? 255u : C4], 1u);
-          if (lane == 0 && n4) atomicAdd(&H.slow[DX_SUB][a.subChar], n4);
+        { if (sinc && C4 > 0 && lane == 0) atomicAdd(&slow[DX_SRUN][C4 > 255u ? 255u : C4], 1u);
+          if (lane == 0 && n4) atomicAdd(&slow[DX_SUB][a.subChar], n4);
         }
       if (toks)
-        { if (lane == 0)
+        { if (FAST && (bad0 || bad4)) { bad0 = 1; bad4 = 1; }      // (one line's counters not to be had: the whole entry by the text-reading kernels)
+          if (lane == 0)
             { uint32_t *w = ts.info + TOK_INFO * r;
               w[0] = nt0 | ((bad0 || !drun) ? TOK_BAD : 0u);
               w[1] = nt4 | ((bad4 || !srun) ? TOK_BAD : 0u);
@@ -688,6 +825,8 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
               w[3] = C4;
               w[4] = nx0;
               w[5] = nx4;
+              w[6] = (FAST && L > 65535u ? 1u : 0u) |  // the entry's 16-bit counters do not hold it: its sizes from its tokens and text
+                     (FAST && !OWNTOK ? 2u : 0u);      // no counters of the token lines: those lines' sizes from their tokens
             }
           if (((drun && bad0) || (srun && bad4)) && lane == 0)      // rare: the generic kernel works through this list
             ts.list[atomicAdd(ts.unusable, 1ull)] = (uint32_t) r;
@@ -695,10 +834,27 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
       tot   += L;
       since += L;
       if (since >= (1ull << 26))                       // keep the 32-bit LDS bins far from overflow
-        { for (uint32_t k = lane; k < nwords; k += 64)
-            { const uint32_t v = atomicExch(&words[k], 0u);
-              if (v) atomicAdd(&g_hist[hist_bin_of(k)], (unsigned long long) v);
+        { if (FAST)
+            { for (uint32_t k = lane; k < 6u * 256u; k += 64)
+                { const uint32_t v = atomicExch(&slow[0][k], 0u);
+                  if (v) atomicAdd(&g_hist[k], (unsigned long long) v);
+                }
+              if (!OWNTOK)
+                { for (uint32_t k = lane; k < 2u * HSYM_FAST * HC_RSYM; k += 64)
+                    { const uint32_t v = atomicExch(&(&Sb->rsym[0][0][0])[k], 0u);
+                      if (v) atomicAdd(&g_hist[(k / (HSYM_FAST * HC_RSYM) ? DX_SUB : DX_DEL) * 256u + (k / HC_RSYM) % HSYM_FAST], (unsigned long long) v);
+                    }
+                  for (uint32_t k = lane; k < 2u * HRUN_FAST * HC_RUN; k += 64)
+                    { const uint32_t v = atomicExch(&(&Sb->run[0][0][0])[k], 0u);
+                      if (v) atomicAdd(&g_hist[(4u + k / (HRUN_FAST * HC_RUN)) * 256u + (k / HC_RUN) % HRUN_FAST], (unsigned long long) v);
+                    }
+                }
             }
+          else
+            for (uint32_t k = lane; k < sizeof(hist_lds) / 4; k += 64)
+              { const uint32_t v = atomicExch(&words[k], 0u);
+                if (v) atomicAdd(&g_hist[hist_bin_of(k)], (unsigned long long) v);
+              }
           since = 0;
         }
     }
@@ -708,14 +864,27 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   __syncthreads();
   // fold the copies of every fast bin (rotated start: the lanes of a wave read distinct banks); one thread per 8 words
   // (8 divides every copy count), several threads per bin where it has more copies
-  for (uint32_t w8 = tid; w8 < HIST_FAST_WORDS / 8u; w8 += HIST_BLOCK)
-    { uint32_t v = 0;
-      for (uint32_t j = 0; j < 8u; j++)
-        v += words[w8 * 8u + ((j + (uint32_t) lane) & 7u)];
-      if (v) atomicAdd(&g_hist[hist_bin_of(w8 * 8u)], (unsigned long long) v);
+  if (FAST && !OWNTOK)                                   // the token lines' replicated bins of this instance
+    { for (uint32_t k = tid; k < 2u * HSYM_FAST; k += HIST_BLOCK)
+        { uint32_t v = 0;
+          for (uint32_t j = 0; j < HC_RSYM; j++) v += (&Sb->rsym[0][0][0])[k * HC_RSYM + j];
+          if (v) atomicAdd(&g_hist[(k / HSYM_FAST ? DX_SUB : DX_DEL) * 256u + k % HSYM_FAST], (unsigned long long) v);
+        }
+      for (uint32_t k = tid; k < 2u * HRUN_FAST; k += HIST_BLOCK)
+        { uint32_t v = 0;
+          for (uint32_t j = 0; j < HC_RUN; j++) v += (&Sb->run[0][0][0])[k * HC_RUN + j];
+          if (v) atomicAdd(&g_hist[(4u + k / HRUN_FAST) * 256u + k % HRUN_FAST], (unsigned long long) v);
+        }
     }
+  if (!FAST)
+    for (uint32_t w8 = tid; w8 < HIST_FAST_WORDS / 8u; w8 += HIST_BLOCK)
+      { uint32_t v = 0;
+        for (uint32_t j = 0; j < 8u; j++)
+          v += words[w8 * 8u + ((j + (uint32_t) lane) & 7u)];
+        if (v) atomicAdd(&g_hist[hist_bin_of(w8 * 8u)], (unsigned long long) v);
+      }
   for (uint32_t k = tid; k < 6 * 256; k += HIST_BLOCK)
-    { const uint32_t v = (&H.slow[0][0])[k];
+    { const uint32_t v = slow[0][k];
       if (v) atomicAdd(&g_hist[k], (unsigned long long) v);
     }
 }
@@ -913,7 +1082,7 @@ void k_qv_sizes(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint3
         if (pend == 0) break;
         const int l = __ffsll((unsigned long long) pend) - 1;
         pend &= pend - 1;
-        rlo = (uint64_t) __builtin_amdgcn_readlane(mine, l) - first_entry;
+        rlo = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) mine, l) - first_entry;
         rhi = rlo + 1;
         if (!tok_unusable(only_info, rlo, a.delChar, a.subChar))
           continue;
@@ -1577,7 +1746,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
           if (pend == 0) break;
           const int l = __ffsll((unsigned long long) pend) - 1;
           pend &= pend - 1;
-          r = (uint64_t) __builtin_amdgcn_readlane(mine, l) - first_entry;
+          r = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) mine, l) - first_entry;
           if (!tok_unusable(only_info, r, a.delChar, a.subChar))
             continue;                                    // (listed for a run character the coding dropped: the fast kernel has it)
         }
@@ -1904,10 +2073,12 @@ static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(DX_BLOCK), 0, ctx->stream, d_tile, ntiles, d_gran);
   hipLaunchKernelGGL(k_scan_apply, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, (const uint32_t *) d_room, n,
                      (const uint64_t *) d_tile, ctx->tk.off, (const uint64_t *) d_gran);
-  uint64_t total = 0;
-  if (hipMemcpyAsync(&total, d_gran, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+  uint64_t total = 0, share = 128;
+  if (hipMemcpyAsync(&share, (unsigned long long *) (ctx->d_u64 + 48) + 4, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(&total, d_gran, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess)
     { (void) hipGetLastError(); return false; }
+  ctx->tk.share8 = (uint32_t) share;
   if (ctx->tk.cap_tokens < total)
     { (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub);
       ctx->tk.del = NULL; ctx->tk.sub = NULL; ctx->tk.cap_tokens = 0;
@@ -1956,12 +2127,28 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE, hist_room = (uint64_t) ctx->num_cu * HIST_PER_CU;   // HIST_PER_CU workgroups per CU
-  if (ts.del != NULL && p->delChar >= 0 && p->subChar >= 0)
-    DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist<true>, (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
-              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts);
+  // the FAST instance also leaves every entry's own histograms (for k_qv_sizes_hist): 1.5 KB per entry
+  bool fast_hist = ts.del != NULL && p->delChar >= 0 && p->subChar >= 0;
+  ctx->tk.eh_valid = 0;
+  if (fast_hist && ctx->tk.cap_eh < n)
+    { (void) hipFree(ctx->tk.eh);
+      ctx->tk.eh = NULL; ctx->tk.cap_eh = 0;
+      if (hipMalloc((void **) &ctx->tk.eh, n * EH_WORDS * 4 + 64) != hipSuccess)
+        { (void) hipGetLastError();                        // (no memory for them: the instance without, and the slot encoder after it)
+          fast_hist = false;
+        }
+      else
+        ctx->tk.cap_eh = n;
+    }
+  if (fast_hist && ctx->tk.share8 <= 110 && getenv("DEXGPU_HIST_SHARED_TOKENS") == NULL)   // (tokens at most ~28 % of the denser line: run densities from ~0.72 up)
+    DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, true>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
+              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh);
+  else if (fast_hist)
+    DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, false>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
+              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh);
   else
-    DX_LAUNCH(ctx, DX_K_QV_HIST, k_qv_hist<false>, (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
-              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts);
+    DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<false, false>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
+              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, (uint32_t *) NULL);
   uint64_t host[6 * 256 + 2];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1977,6 +2164,7 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
       // the generic kernel reads the count on the device: kept in front of the list (the scratch it was counted in is reused)
       DX_HIP(ctx, hipMemcpyAsync(ctx->tk.count, d_hist + 6 * 256 + 1, 8, hipMemcpyDeviceToDevice, ctx->stream));
       ctx->tk.valid = 1;
+      ctx->tk.eh_valid = fast_hist ? 1 : 0;
     }
   return DX_OK;
 }
@@ -2285,7 +2473,7 @@ static bool onepass_tokens_ok(const dx_ctx *ctx, const dx_qv_batch *b)
 // as that group's offsets exist.  Only the first, small group's sizes are waited for with nothing to do.
 // Entries with unusable tokens take the generic kernels (sizes and encode from the text).
 static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
-                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total)
+                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total, bool by_hist)
 { const uint64_t n = b->n;
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const size_t   a4 = (n * 4 + 255) & ~(size_t) 255;
@@ -2306,7 +2494,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       for (uint64_t at = 0; at < n; at += gs)
         gb[++G] = at + gs < n ? at + gs : n;
     }
-  else if (n < 160000)
+  else if (n < 160000 || by_hist)                        // (sizes from the entries' own histograms take a moment: one group)
     gb[++G] = n;
   else                                                   // 1/16 of the batch, then 2.5 x the one before: a group's sizes
     { uint64_t size = n / 16, at = 0;                    // are ready before the encoder has finished the group before it
@@ -2341,8 +2529,13 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       rc = DX_E_HIP;
       if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
       dx_prof_begin_on(ctx, DX_K_QV_SIZES, B);
-      hipLaunchKernelGGL(k_qv_sizes_fast, dim3(fast_grid(ctx, (m + TICKET_BATCH - 1) / TICKET_BATCH)), dim3(FAST_BLOCK), 0, B,
-                         ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz, tg);
+      if (by_hist)
+        hipLaunchKernelGGL(k_qv_sizes_hist, dim3(dx_grid_waves(ctx, (m + 7) / 8, 32)), dim3(DX_BLOCK), 0, B,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, tg,
+                           (const uint32_t *) (ctx->tk.eh + g0 * EH_WORDS), ctx->tk.subChar);
+      else
+        hipLaunchKernelGGL(k_qv_sizes_fast, dim3(fast_grid(ctx, (m + TICKET_BATCH - 1) / TICKET_BATCH)), dim3(FAST_BLOCK), 0, B,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, d_seg + 5 * g0, d_size + g0, d_tick_sz, tg);
       dx_prof_end_on(ctx, B);
       if (odd)
         { if (hipMemsetAsync(d_tick_sz, 0, 4, B) != hipSuccess) break;
@@ -2401,7 +2594,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       hipStreamSynchronize(A) != hipSuccess)
     return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
   if (total) *total = tot;
-  ctx->route.groups = 0; ctx->route.direct = 1; ctx->route.tokens = 1; ctx->route.region_bytes = 0;
+  ctx->route.groups = 0; ctx->route.direct = by_hist ? 2 : 1; ctx->route.tokens = 1; ctx->route.region_bytes = 0;
   ctx->route.scratch_bytes = ctx->scratch_bytes; ctx->route.token_bytes = 4ull * ctx->tk.cap_tokens;
   ctx->route.text_entries = ctx->tk.unusable;
   if (tot > out_cap || (st & 8u))
@@ -2440,9 +2633,13 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // DEXGPU_DIRECT_ENCODE: sizes first, records written in place, no scratch slots (onepass_direct) -- what also runs
   // when the slots below cannot be allocated.  It is the slower of the two (34.5 ms against 31.0, 1 M x 10 kb): its
   // size kernel reads the 30 GB of plain lines once more, the compaction it saves moves 2 x 14 GB.
-  if (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_DIRECT_ENCODE") != NULL)
+  // The product route when the histogram pass has left every entry's own counters (k_qv_hist<true>): sizes by dot product
+  // (k_qv_sizes_hist), every record written where it belongs -- no scratch slots, no compaction.  DEXGPU_SLOTS=1: the
+  // slot route below all the same; DEXGPU_DIRECT_ENCODE: sizes by k_qv_sizes_fast (tokens and plain lines read again).
+  const bool by_hist = onepass_tokens_ok(ctx, b) && ctx->tk.eh_valid && getenv("DEXGPU_SLOTS") == NULL;
+  if (by_hist || (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_DIRECT_ENCODE") != NULL))
     { uint64_t t = 0;
-      const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
+      const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t, by_hist && getenv("DEXGPU_DIRECT_ENCODE") == NULL);
       if (total) *total = t;
       if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }   // (this route does not pipeline)
       return rc;
@@ -2532,7 +2729,7 @@ layout:
             }
           if (pass == 1 && onepass_tokens_ok(ctx, b))    // no room for any slots: the scheme that needs none
             { uint64_t t = 0;
-              const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
+              const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t, false);
               if (total) *total = t;
               if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }
               return rc;

@@ -246,6 +246,13 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
   return true;
 }
 
+// a 64-bit value of lane j (uniform j).  The builtin returns int: the low half must not be sign-extended into the high one.
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t j)
+{ const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, (int) j);
+  const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), (int) j);
+  return ((uint64_t) hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint32_t token_bits(const uint16_t *tok, uint32_t cnt, const uint8_t *slen, const uint8_t *rlen,
                                                const uint32_t *xend, uint32_t nx)
 { const uint32_t lane = (uint32_t) lane_id();
@@ -589,5 +596,161 @@ void k_qv_sizes_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, 
           rec_size[r] = hl + sz[0] + sz[1] + sz[2] + sz[3] + sz[4];
         }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  k_qv_sizes_hist: the five segment sizes of every entry from the entry's own histograms
+// ---------------------------------------------------------------------------------------------
+// k_qv_hist<true> leaves, per entry, how often every symbol occurs in its insertion and merge lines and every symbol and
+// run length among the tokens of its deletion and substitution lines (768 counters of 16 bits).  Once the tables exist a
+// line's bits are the dot product of its counters with the code lengths -- a wave per entry, two bins per lane, six sums --
+// plus what the counters do not hold: the runs of 127 and more (the line's exception list), the run open at a line's end,
+// and the pad rule (QV.c:436-442), which wants the last code's length.  1.5 KB read per entry where k_qv_sizes_fast read
+// the entry's tokens and plain lines again (28 GB for the 1 M x 10 kb batch: 7 ms) -- and with the sizes known up front the
+// encoder writes every record in place: no scratch slots, no compaction.
+__global__ __launch_bounds__(DX_BLOCK)
+void k_qv_sizes_hist(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *seg /* n x 5 */, uint32_t *rec_size,
+                     tok_src tk, const uint32_t *eh, int sub_made /* the substitution run character the counters were made under */)
+{ __shared__ uint32_t  s_tok[6][256];
+  __shared__ size_tabs s_t;
+  load_tables(s_tok, g_tok);
+  load_size_tables(s_t, g_tok, a.delChar, a.subChar);
+  const uint32_t lane = (uint32_t) lane_id();
+  const uint32_t im = !a.lossy ? 0xffu : 0xfeu, mm = !a.lossy ? 0xffu : 0xfcu;         // QV.c:1406-1415
+  const uint32_t s0 = 2u * lane, s1 = s0 + 1u;
+  // this lane's two bins of every table: their code lengths (constant over the entries)
+  const uint32_t l_ins0 = s_t.len[DX_INS][s0 & im], l_ins1 = s_t.len[DX_INS][s1 & im];
+  const uint32_t l_mrg0 = s_t.len[DX_MRG][s0 & mm], l_mrg1 = s_t.len[DX_MRG][s1 & mm];
+  const uint32_t l_del0 = s_t.len[DX_DEL][s0], l_del1 = s_t.len[DX_DEL][s1], l_sub0 = s_t.len[DX_SUB][s0], l_sub1 = s_t.len[DX_SUB][s1];
+  const uint32_t l_dr0 = s_t.len[DX_DRUN][s0], l_dr1 = s_t.len[DX_DRUN][s1], l_sr0 = s_t.len[DX_SRUN][s0], l_sr1 = s_t.len[DX_SRUN][s1];
+
+  // Create_QVcoding may drop the substitution run character the scan chose (QV.c:1044): the line is then coded plain, from the
+  // text, and its bits are its token symbols' plus its run characters' -- as many as the line has symbols that are no tokens.
+  const bool     sub_plain = a.subChar < 0 && sub_made >= 0;
+  const uint32_t l_subrc   = sub_plain ? (uint32_t) s_t.len[DX_SUB][sub_made & 0xff] : 0u;
+
+  // Eight entries a time, dealt to the waves in turn (every entry costs the same: no ticket counter, whose draws -- 11 ns
+  // each, chip-wide -- were nine tenths of this kernel's time).  What an entry's sizes need beside its counters -- length, token counts, open runs, the last
+  // token of either run-coded line, the last byte of either plain one -- lane j fetches for entry j: eight entries' worth
+  // in two dependent rounds of loads instead of sixteen; the dot products then go entry by entry over the whole wave, and
+  // lane j works its entry's five sizes out of the sums.
+  const uint64_t wave0 = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6), nwave = (uint64_t) gridDim.x * DX_WAVES_PER_BLK;
+  for (uint64_t r0 = 8u * wave0; r0 < a.n; r0 += 8u * nwave)
+  { const uint64_t r    = r0 + lane;
+    const bool     mine = lane < 8u && r < a.n;
+    uint32_t L = 0, i0 = TOK_BAD, i1 = TOK_BAD, C0 = 0, C4 = 0, nx0 = 0, nx4 = 0, hl = 0, nocnt = 0;
+    uint64_t toff = 0, tend = 0;
+    if (mine)
+      { const uint32_t *inf = tk.info + TOK_INFO * r;
+        L = a.len[r]; toff = tk.off[r]; tend = tk.off[r + 1];
+        i0 = inf[0]; i1 = inf[1]; C0 = inf[2]; C4 = inf[3]; nx0 = inf[4]; nx4 = inf[5]; nocnt = inf[6];
+        hl = hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u;
+      }
+    const bool     tokd = mine && !((a.delChar >= 0 && (i0 & TOK_BAD)) || (a.subChar >= 0 && (i1 & TOK_BAD)));   // (else: k_qv_sizes has this entry)
+    const bool     use  = tokd && !(nocnt & 1u);
+    const uint64_t longs = __ballot(tokd && (nocnt & 1u));   // entries of 2^16 symbols and more: from their tokens and text, below
+    const uint64_t bytok = __ballot(use && (nocnt & 2u));    // no counters of the token lines (k_qv_hist<true, false>): from the tokens
+    const uint32_t cnt0 = i0 & ~TOK_BAD, cnt4 = i1 & ~TOK_BAD;
+    uint32_t lt0 = 0, lt4 = 0, lb2 = 0, lb3 = 0, lb4 = 0;
+    if (use)
+      { if (cnt0) lt0 = tk.del[toff + cnt0 - 1];
+        if (cnt4) lt4 = tk.sub[toff + cnt4 - 1];
+        if (L)    { lb2 = line_ptr(a, r, L, 2)[L - 1]; lb3 = line_ptr(a, r, L, 3)[L - 1]; lb4 = line_ptr(a, r, L, 4)[L - 1]; }
+      }
+    const uint64_t usable = __ballot(use);
+    uint32_t T0 = 0, T2 = 0, T3 = 0, T4 = 0;             // this lane's entry: bits of del, ins, mrg, sub
+    for (uint32_t j = 0; j < 8u && r0 + j < a.n; j++)
+      { if (!((usable >> j) & 1ull)) continue;
+        const uint32_t *e32 = eh + (r0 + j) * EH_WORDS;
+        uint32_t v[6];
+        #pragma unroll
+        for (int k = 0; k < 6; k++) v[k] = e32[64 * k + lane];
+        uint32_t b_del = (v[2] & 0xffffu) * l_del0 + (v[2] >> 16) * l_del1 + (v[4] & 0xffffu) * l_dr0 + (v[4] >> 16) * l_dr1;
+        uint32_t b_sub = (v[3] & 0xffffu) * l_sub0 + (v[3] >> 16) * l_sub1;
+        if (!sub_plain) b_sub += (v[5] & 0xffffu) * l_sr0 + (v[5] >> 16) * l_sr1;
+        const uint32_t b_ins = (v[0] & 0xffffu) * l_ins0 + (v[0] >> 16) * l_ins1;
+        const uint32_t b_mrg = (v[1] & 0xffffu) * l_mrg0 + (v[1] >> 16) * l_mrg1;
+        const uint32_t xj0 = __builtin_amdgcn_readlane(nx0, (int) j), xj4 = __builtin_amdgcn_readlane(nx4, (int) j);
+        if ((bytok >> j) & 1ull)                         // the token lines from their tokens (lengths by table, exceptions included)
+          { const uint64_t to = readlane64(toff, j), te = readlane64(tend, j);
+            const uint32_t cj0 = __builtin_amdgcn_readlane(cnt0, (int) j), cj4 = __builtin_amdgcn_readlane(cnt4, (int) j);
+            b_del = token_bits(tk.del + to, cj0, s_t.len[DX_DEL], s_t.len[DX_DRUN], (const uint32_t *) (tk.del + te), xj0);
+            if (!sub_plain)
+              b_sub = token_bits(tk.sub + to, cj4, s_t.len[DX_SUB], s_t.len[DX_SRUN], (const uint32_t *) (tk.sub + te), xj4);
+            else                                         // (a dropped run character: the symbols of the tokens, plain)
+              { b_sub = 0;
+                for (uint32_t k = lane; k < cj4; k += 64u)
+                  b_sub += s_t.len[DX_SUB][((uint32_t) tk.sub[to + k] >> 2) & 0x7fu];
+              }
+          }
+        else if (xj0 | xj4)                              // runs of 127 and more: in no counter (hist_runs_step took them out again)
+          { const uint64_t te = readlane64(tend, j);
+            const uint32_t *xd = (const uint32_t *) (tk.del + te), *xs = (const uint32_t *) (tk.sub + te);
+            for (uint32_t k = lane; k < xj0; k += 64u)
+              { const uint32_t run = *(xd - 2 * (int) k - 1);
+                b_del += s_t.len[DX_DRUN][run > 255u ? 255u : run];
+              }
+            for (uint32_t k = lane; k < (sub_plain ? 0u : xj4); k += 64u)
+              { const uint32_t run = *(xs - 2 * (int) k - 1);
+                b_sub += s_t.len[DX_SRUN][run > 255u ? 255u : run];
+              }
+          }
+        const uint32_t t0 = wave_sum(b_del), t2 = wave_sum(b_ins), t3 = wave_sum(b_mrg), t4 = wave_sum(b_sub);
+        if (lane == j) { T0 = t0; T2 = t2; T3 = t3; T4 = t4; }
+      }
+    if (use)
+      { uint32_t sz[5];
+        uint64_t Td = T0, Ts = T4;
+        uint32_t lastd, lasts;
+        if (C0 > 0)                                      // run-only token at the line's end (QV.c:490-497)
+          { const uint32_t e = s_tok[DX_DRUN][C0 > 255u ? 255u : C0];
+            Td += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
+            lastd = TOK_ESC(e) ? 16u : TOK_LEN(e);
+          }
+        else if (cnt0 > 0)
+          { const uint32_t e = s_tok[DX_DEL][(lt0 >> 2) & 0x7fu];
+            lastd = TOK_ESC(e) ? 8u : TOK_LEN(e);
+          }
+        else
+          lastd = 0;
+        if (sub_plain)
+          { Ts   += (uint64_t) (L - cnt4) * l_subrc;
+            lasts = last_piece_byte(s_tok[DX_SUB], lb4, L, 0xffu);
+          }
+        else if (C4 > 0)
+          { const uint32_t e = s_tok[DX_SRUN][C4 > 255u ? 255u : C4];
+            Ts += TOK_LEN(e) + (TOK_ESC(e) ? 16u : 0u);
+            lasts = TOK_ESC(e) ? 16u : TOK_LEN(e);
+          }
+        else if (cnt4 > 0)
+          { const uint32_t e = s_tok[DX_SUB][(lt4 >> 2) & 0x7fu];
+            lasts = TOK_ESC(e) ? 8u : TOK_LEN(e);
+          }
+        else
+          lasts = 0;
+        sz[0] = seg_bytes(Td, lastd);
+        sz[1] = (cnt0 + 3u) >> 2;                        // Pack_Tag's count, QV.c:810-819
+        sz[2] = seg_bytes(T2, last_piece_byte(s_tok[DX_INS], lb2, L, im));
+        sz[3] = seg_bytes(T3, last_piece_byte(s_tok[DX_MRG], lb3, L, mm));
+        sz[4] = seg_bytes(Ts, lasts);
+        uint32_t *sg = seg + 5 * r;
+        sg[0] = sz[0]; sg[1] = sz[1]; sg[2] = sz[2]; sg[3] = sz[3]; sg[4] = sz[4];
+        rec_size[r] = hl + sz[0] + sz[1] + sz[2] + sz[3] + sz[4];
+      }
+    for (uint32_t j = 0; longs && j < 8u; j++)           // (rare: a .quiva entry seldom has 65536 symbols)
+      if ((longs >> j) & 1ull)
+        { const uint64_t rj = r0 + j;
+          const uint32_t Lj = a.len[rj];
+          uint32_t sz[5];
+          entry_sizes_fast(a, rj, Lj, tk.info + TOK_INFO * rj, tk.off[rj], tk.off[rj + 1], tk, s_tok, s_t.len,
+                           can_overread(a, line_ptr(a, rj, Lj, 4), Lj), sz);
+          if (lane == 0)
+            { const uint32_t hj = hdr_off ? (uint32_t) (hdr_off[rj + 1] - hdr_off[rj]) : 0u;
+              uint32_t *sg = seg + 5 * rj;
+              sg[0] = sz[0]; sg[1] = sz[1]; sg[2] = sz[2]; sg[3] = sz[3]; sg[4] = sz[4];
+              rec_size[rj] = hj + sz[0] + sz[1] + sz[2] + sz[3] + sz[4];
+            }
+        }
   }
 }

@@ -286,14 +286,15 @@ int dx_qv_encode_onepass_end(dx_ctx *ctx, uint64_t *total);
 
 /* Which way the last dx_qv_encode_onepass / _begin of this context took (it depends on the memory left on the
  * device), for logs and benchmarks: groups = scratch regions the batch was worked through in (0: none, see direct),
- * direct = 1 when no scratch slots could be had and the sizes-first route ran (k_qv_sizes_fast, records written in
- * place), tokens = 1 when the histogram pass's tokens fed the encoder; region_bytes = one scratch region,
+ * direct = 2 when the histogram pass left every entry's own counters and the sizes came from them (records written in place:
+ * the usual case), 1 when no scratch slots could be had and the sizes-first route with k_qv_sizes_fast ran, tokens = 1 when the histogram pass's tokens fed the encoder; region_bytes = one scratch region,
  * scratch_bytes = the context's scratch allocation after the call, avail_bytes = the memory the choice was made
  * against (free device memory + the scratch that exists, or the budget below), token_bytes = the token slots,
  * text_entries = entries the text-reading encoder took because their tokens could not be used (a byte >= 128 in a
  * run-coded line, more tokens than the slot holds).                                                              */
 typedef struct
-  { int32_t  groups, direct, tokens, reserved;        /* direct: 0 slots + compaction, 1 sizes first (own kernel) */
+  { int32_t  groups, direct, tokens, reserved;        /* direct: 0 slots + compaction, 1 sizes first by k_qv_sizes_fast (tokens and plain lines read
+                                                         again), 2 sizes from the entries' own histograms (k_qv_sizes_hist): the product route */
     uint64_t region_bytes, scratch_bytes, avail_bytes, token_bytes, text_entries;
     uint64_t chain_waits[3];                          /* always 0 (the routes that reported here are gone; kept for the layout) */
   } dx_onepass_info;

@@ -41,8 +41,9 @@ def test_bench_line_single_gpu():
     bases, out = 30000 * 10000, d["config"]["output_bytes"]
     assert abs(r["algo_bytes_per_step"] - (9 * bases + out)) < 1 and abs(r["achieved"] - (9 * bases + out) / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * r["achieved"]
     assert r["dominant_kernel"]["kernel"] in ("k_qv_hist", "k_qv_encode") and 0 < r["dominant_kernel"]["frac"] < 1
-    assert r["per_kernel"]["k_qv_compact"]["design_bytes_per_step"] == 0          # pure overhead, priced as such
-    assert d["encoder_route"]["groups"] >= 1 and d["encoder_route"]["direct"] == 0
+    assert "k_qv_compact" not in r["per_kernel"]                                    # no scratch slots, no compaction: the sizes come
+    assert d["encoder_route"]["direct"] == 2 and d["encoder_route"]["groups"] == 0  # from the entries' own histograms (k_qv_sizes_hist)
+    assert r["per_kernel"]["k_qv_sizes"]["algo_bytes_8d_per_step"] == 0
     assert abs(d["value"] - 5 * 30000 * 10000 / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]
 
 

@@ -57,11 +57,18 @@ class Corpus:
         return out, info, coding
 
 
-def test_onepass_routes_under_memory_pressure_write_the_same_stream():
+def test_onepass_routes_under_memory_pressure_write_the_same_stream(monkeypatch):
+    """The product route (sizes from the entries' own histograms, records in place: direct == 2, no scratch at all) and the
+    scratch-slot route behind it (DEXGPU_SLOTS=1: what runs when the histogram pass could not leave its counters) under
+    ever smaller scratch budgets, down to the sizes-first fallback: all the same stream."""
     with api.Context(0) as ctx:
         c = Corpus(ctx)
+        prod, info_p, _ = c.encode(ctx, 0)
+        assert info_p["direct"] == 2 and info_p["groups"] == 0 and info_p["tokens"] == 1 and info_p["text_entries"] == 0
+        monkeypatch.setenv("DEXGPU_SLOTS", "1")
         ref, info0, coding = c.encode(ctx, 0)                       # no budget: by free device memory
         assert info0["direct"] == 0 and info0["groups"] >= 1 and info0["tokens"] == 1
+        assert len(prod) == len(ref) and (prod == ref).all()
         # the first 300 records against the oracle (the same entries as a small file give the same tables only if the
         # whole corpus does: so compare record by record with the oracle's entry encoder under THESE tables)
         rec = c.d_rec.download(np.uint64, c.n + 1)
@@ -94,8 +101,12 @@ def test_budget_env_overrides_and_route_is_reported(monkeypatch):
         a, info_a, _ = c.encode(ctx, 0)
         monkeypatch.setenv("DEXGPU_SCRATCH_BUDGET", str(16 << 20))
         b, info_b, _ = c.encode(ctx, 0)
-        assert info_b["avail_bytes"] == 16 << 20
+        assert info_b["direct"] == 2 and (a == b).all()             # records in place: no regions for a budget to shape
+        monkeypatch.setenv("DEXGPU_SLOTS", "1")                     # the slot route, which has them
+        b, info_b, _ = c.encode(ctx, 0)
+        assert info_b["direct"] == 0 and info_b["avail_bytes"] == 16 << 20
         assert (a == b).all()
+        monkeypatch.delenv("DEXGPU_SLOTS")
         small = synth.make_quiva(40, seed=5, mean=3000)
         assert ctx.dexqv(small.text) == O.dexqv(small.text)         # the file driver under the same budget
 
