@@ -246,6 +246,52 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
   return true;
 }
 
+// ... and a line's last step, `valid` (0..16) bytes per lane: whole pairs through the pair table, an odd last byte through the
+// one-symbol table, a dummy of one zero bit for every pair behind the line's end (shifted out again at the string's end, as
+// in encode_plain_step).  The last step used to go to the one-symbol step altogether: 1.7 times a pair step's time -- per
+// line, which at 2 kb is every other step.
+__device__ __forceinline__ bool encode_plain_step_pair_last(wave_out &o, const u32x4 &c, int valid, const uint32_t *ptab, const uint32_t *stab,
+                                                            uint32_t lo4, uint32_t m4, sub_mark &sm)
+{ uint32_t tok[8];
+  uint32_t ssum = 0, zor = 0, bad = 0;
+  #pragma unroll
+  for (int w = 0; w < 4; w++)
+    { const int      n  = valid - 4 * w;                                  // this word's bytes inside the line
+      const uint32_t vm = n >= 4 ? ~0u : (n > 0 ? (1u << (8 * n)) - 1u : 0u);
+      const uint32_t cw = chunk_word(c, w) & m4;
+      const uint32_t x  = (cw - lo4) & vm;                                // (bytes behind the end: index 0)
+      const uint32_t m  = __umul24((x >> 8) & 0x003f003fu, PAIR_STRIDE) + (x & 0x003f003fu);
+      bad |= x;
+      const uint32_t t0 = ptab[m & 0xffffu], t1 = ptab[m >> 16];
+      const uint32_t s0 = stab[cw & 0xffu], s1 = stab[(cw >> 16) & 0xffu];    // the pair's first byte alone
+      tok[2 * w]     = n >= 2 ? t0 : (n == 1 ? s0 : STOK_DUMMY);
+      tok[2 * w + 1] = n >= 4 ? t1 : (n == 3 ? s1 : STOK_DUMMY);
+    }
+  #pragma unroll
+  for (int k = 0; k < 8; k++)
+    { ssum += 2 * k < valid ? tok[k] & 0xffu : 32u;                       // (a dummy: no bit of the line's)
+      zor  |= tok[k];                                                    // (bit 5: a pair or a lone byte without a code)
+    }
+  const uint32_t k  = 8u - (((uint32_t) valid + 1u) >> 1);                // dummies
+  const uint32_t nb = 256u - ssum;
+  if (__any((int) ((bad & 0xc0c0c0c0u) | (zor & 32u) | (nb + k > 128u))))
+    return false;
+  const uint32_t incl = wave_incl_scan(nb);
+  sub_step(sm, nb, (uint32_t) valid, false);
+  FOR_ONE_ROUND(o, incl, nb,
+    { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+      _Pragma("unroll")
+      for (int j = 0; j < 8; j++)
+        STOK_APPEND(tok[j])
+      w0 = __builtin_amdgcn_alignbit(w1, w0, k);
+      w1 = __builtin_amdgcn_alignbit(w2, w1, k);
+      w2 = __builtin_amdgcn_alignbit(w3, w2, k);
+      w3 >>= k;
+      place_bits128(o.win, bit_, nb, w0, w1, w2, w3);
+    })
+  return true;
+}
+
 // a 64-bit value of lane j (uniform j).  The builtin returns int: the low half must not be sign-extended into the high one.
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t j)
 { const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, (int) j);
@@ -513,7 +559,9 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
                   { const u32x4 d = fetch_step(p, base + DX_STEP, L, over);                      \
                     const bool full = L - base >= DX_STEP;                                       \
                     if (o.winbits >= QV_FLUSH_BITS) flush_quads(o, false);   /* behind the load */ \
-                    if (!full || !encode_plain_step_pair(o, c, PTAB, lo4, m4, sm))               \
+                    if ((FAST_SKIP & 32) && !full) { } else                                   \
+                    if (full ? !encode_plain_step_pair(o, c, PTAB, lo4, m4, sm)                  \
+                             : !encode_plain_step_pair_last(o, c, valid_of(pos, L), PTAB, STAB, lo4, m4, sm)) \
                       encode_plain_step<true>(o, c, valid_of(pos, L), full, tab, STAB, m4, sm);  \
                     c = d;                                                                       \
                     pos += DX_STEP;                                                              \
@@ -532,6 +580,8 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               else             { PLAIN_LOOP(s_stok[q]) }
 #undef PAIR_LOOP
 #undef PLAIN_LOOP
+              if (FAST_SKIP & 16) got = 4u * o.wordbase;
+              else
               got = finish_words(o, last_piece_byte(tab, lastb, L, mask));
               if (q == 0)                                // no delChar: the whole tag line is packed
                 { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
@@ -554,7 +604,7 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
           if (lane == 0)
             sc.rec_size[r] = rec;
         }
-      if (bad && lane == 0)
+      if (bad && lane == 0 && !FAST_SKIP)
         atomicOr(status, 2u);                            // slot overflow / a size differs from what k_qv_sizes_fast computed
     }
   }

@@ -13,7 +13,8 @@ reps = int(args[1]) if len(args) > 1 else 5
 with api.Context(0) as ctx:
     movie = "m000_000"
     hlen = 1 + len(movie) + 1 + 8 + 1 + 7 + 1 + 7 + 6 + 3 + 1
-    lens = synth.lengths(n, 4242, "fixed", 10000)
+    mean = int(args[2]) if len(args) > 2 else 10000
+    lens = synth.lengths(n, 4242, "fixed", mean)
     hdr4 = synth.headers(n, 4242, lens, 0)
     rec = hlen + 5 * (lens.astype(np.uint64) + 1)
     off = (np.concatenate([[0], np.cumsum(rec)[:-1]]) + hlen).astype(np.uint64)
