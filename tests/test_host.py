@@ -320,10 +320,10 @@ def test_out_bound_covers_the_encoded_size():
 
 
 def test_register_budgets_of_the_kernels_that_share_a_cu():
-    """The build leaves every kernel's register / scratch / LDS use in dextractor_amd/kernel_resources.txt.  The
-    compaction of a group runs beside the next group's encoder (dx_qv_encode_onepass): its waves (<= 56 VGPRs) only fit
-    a SIMD whose four encoder waves use <= 112 each -- at 116 the two kernels ran one after the other and a step took
-    5 % longer.  No kernel may spill to scratch."""
+    """The build leaves every kernel's register / scratch / LDS use in dextractor_amd/kernel_resources.txt.  Four waves per
+    SIMD (<= 128 VGPRs) for the kernels whose latency hiding was measured at four; no kernel may spill to scratch.  (Rounds 2
+    and 3 held the encoder to 112 so that the compaction's waves, <= 56 VGPRs, fit beside it: the product route has no
+    compaction any more -- records are written in place -- and the slot route behind DEXGPU_SLOTS=1 is a fallback.)"""
     path = os.path.join(os.path.dirname(L.LIB_PATH), "kernel_resources.txt")
     if not os.path.isfile(path):
         pytest.skip("no kernel_resources.txt (library built without the Makefile)")
@@ -336,7 +336,7 @@ def test_register_budgets_of_the_kernels_that_share_a_cu():
         assert hit, prefix
         return hit
     assert all(v["scratch"] == 0 for v in res.values()), {k: v for k, v in res.items() if v["scratch"]}
-    assert all(v["vgprs"] <= 112 for v in of("_Z16k_qv_encode_fastILb0EE"))    # the product encoder, no group index
+    assert all(v["vgprs"] <= 128 for v in of("_Z16k_qv_encode_fastILb0EE"))    # the product encoder, no group index
     assert len(of("_Z16k_qv_encode_fast")) == 2                                 # with and without the group index, nothing else
     assert all(v["vgprs"] <= 112 for v in of("_Z11k_qv_encode7qv_args"))         # the generic encoder
     assert all(v["vgprs"] <= 56 for v in of("_Z12k_qv_compact"))
