@@ -338,7 +338,7 @@ def test_register_budgets_of_the_kernels_that_share_a_cu():
     assert all(v["scratch"] == 0 for v in res.values()), {k: v for k, v in res.items() if v["scratch"]}
     assert all(v["vgprs"] <= 128 for v in of("_Z16k_qv_encode_fastILb0EE"))    # the product encoder, no group index
     assert len(of("_Z16k_qv_encode_fast")) == 2                                 # with and without the group index, nothing else
-    assert all(v["vgprs"] <= 112 for v in of("_Z11k_qv_encode7qv_args"))         # the generic encoder
+    assert all(v["vgprs"] <= 128 for v in of("_Z11k_qv_encode7qv_args"))         # the generic encoder
     assert all(v["vgprs"] <= 56 for v in of("_Z12k_qv_compact"))
     assert all(v["waves_per_simd"] >= 4 for v in of("_Z9k_qv_hist") + of("_Z16k_qv_encode_fast") + of("_Z17k_qv_decode_plain"))
     assert all(v["waves_per_simd"] >= 6 for v in of("_Z15k_qv_decode_subILi2EE"))
