@@ -12,7 +12,7 @@ EXTRA   ?=
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(EXTRA)
 CFLAGS   = -O2 -fPIC -Iinclude -Wall -Wextra
 
-HIP_SRC  = dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth dx_index
+HIP_SRC  = dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth dx_index dx_qv_walk
 HIP_OBJ  = $(HIP_SRC:%=$(BUILD)/%.o)
 C_OBJ    = $(BUILD)/dx_host.o $(BUILD)/dx_files.o $(BUILD)/dx_compat.o
 TOOLS    = dexta undexta dexar undexar dexqv undexqv
@@ -24,12 +24,12 @@ lib: $(LIB)
 # every device compile also leaves the kernels' register / LDS / scratch use in $(BUILD)/<file>.res (compiler remarks);
 # the library target condenses them into dextractor_amd/kernel_resources.txt, which tests/test_host.py checks:
 # some kernels must stay under a register count to share a CU with another kernel
-$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/dx_internal.hpp $(CSRC)/dx_device.hpp $(CSRC)/dx_layout.h $(CSRC)/dx_qv_fast.hpp include/dexgpu.h
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/dx_internal.hpp $(CSRC)/dx_device.hpp $(CSRC)/dx_layout.h $(CSRC)/dx_walk.h $(CSRC)/dx_qv_fast.hpp include/dexgpu.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/$*.res; rc=$$?; \
 	  grep -v "kernel-resource-usage\|^ *[0-9]* | \|^ *| *^" $(BUILD)/$*.res >&2; exit $$rc
 
-$(BUILD)/%.o: $(CSRC)/%.c $(CSRC)/dx_layout.h include/dexgpu.h include/dexcompat.h
+$(BUILD)/%.o: $(CSRC)/%.c $(CSRC)/dx_layout.h $(CSRC)/dx_walk.h include/dexgpu.h include/dexcompat.h
 	@mkdir -p $(BUILD)
 	$(CC) $(CFLAGS) -c $< -o $@
 

@@ -163,7 +163,7 @@ def main():
         # run density: the tokens of the run-coded lines hold runs up to 126 and longer ones by exception, so the
         # encoder's route must not depend on how long the runs are (share of entries on the text-reading encoder reported)
         sweep = {}
-        for pr in (0.95, 0.99):
+        for pr in (0.5, 0.95, 0.99):
             a3 = argparse.Namespace(**vars(args))
             a3.del_run_p, a3.sub_run_p, a3.steps, a3.warmup = pr, pr, 3, 1
             a3.no_walk_index = True
@@ -182,6 +182,21 @@ def main():
             except Exception as e:
                 sweep[str(pr)] = {"error": repr(e)}
         extra["dexqv_run_density"] = sweep
+        # entry length: a wave works an entry, a step is 1 KiB of each of its lines -- short entries fill neither
+        shapes = {}
+        for mean, entries in ((2000, 2_000_000), (300, 4_000_000)):
+            a5 = argparse.Namespace(**vars(args))
+            a5.mean, a5.entries, a5.steps, a5.warmup, a5.no_walk_index = mean, entries, 3, 1, True
+            trace(f"extra: dexqv, {entries} entries of {mean}")
+            try:
+                l5 = dexqv_bench(a5, 0, 1, local, cpu=False, front=False, index_decode=False)
+                shapes[f"{entries}x{mean}"] = {"value": l5["value"], "unit": "GB/s", "ms_per_step": l5["ms_per_step"],
+                                               "roundtrip_bit_exact": l5["roundtrip_bit_exact"],
+                                               "kernels": {k: round(v["ms_avg"], 3) for k, v in l5["kernels"].items()},
+                                               "decode_ms": (l5.get("decode") or {}).get("ms")}
+            except Exception as e:
+                shapes[f"{entries}x{mean}"] = {"error": repr(e)}
+        extra["dexqv_entry_length"] = shapes
         # BASELINE configs[4]: the slice ONE GPU of the 8-GPU job holds (2.5 M entries, 125 GB of QV bytes), under the scratch
         # budget every rank of that job runs with -- so that the per-GPU work of configs[4] is timed wherever this line is
         if args.entries == ENTRIES_1GPU and args.mean == 10_000:
@@ -436,6 +451,34 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                 ctx.profile(False)
                 torch.cuda.empty_cache()
                 state["decode_indexed"] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
+        if not args.twopass and world == 1:
+            # ... and as a bare file's record stream is indexed where it lies: dx_qv_walk_device, a lane per 128 KiB piece
+            # (no download, no host walk); its index against the encoder's own
+            try:
+                trace("verify: the record walk on the device")
+                ctx.profile(True)
+                t_w = time.perf_counter()
+                dix = ctx.qv_walk_device(p_out, int(state["total"]), 0, state["coding"], 1, 0)
+                torch.cuda.synchronize()
+                t_w1 = time.perf_counter()
+                kt = ctx.kernel_times().get("k_qv_walk")
+                ctx.profile(False)
+                same = dix.n == n
+                if same:
+                    for mine_, theirs_, nb_ in ((dix.seg, p_seg, 20 * n), (dix.rec_off, p_rec, 8 * (n + 1))):
+                        a_ = np.zeros(nb_, np.uint8); b_ = np.zeros(nb_, np.uint8)
+                        ctx._chk(ctx.lib.dx_d2h(ctx.h, a_.ctypes.data, mine_.ptr, nb_)); ctx._chk(ctx.lib.dx_d2h(ctx.h, b_.ctypes.data, theirs_.ptr, nb_))
+                        same = same and bool((a_ == b_).all())
+                state["device_walk"] = {"kernel": "k_walk_find + k_walk_pieces + k_walk_gather", "wall_ms": round((t_w1 - t_w) * 1e3, 2),
+                                        "kernel_ms": round(kt[0], 2) if kt else None, "launches": kt[1] if kt else None,
+                                        "pieces": dix.pieces, "piece_bytes": dix.piece_bytes, "records": dix.n,
+                                        "index_identical_to_the_encoders": bool(same),
+                                        "stream_GBps_wall": round(float(state["total"]) / (t_w1 - t_w) / 1e9, 1)}
+                roundtrip = roundtrip and same
+                dix.free()
+            except Exception as e:
+                ctx.profile(False)
+                state["device_walk"] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
         if not args.twopass and index_decode and not args.no_walk_index and world == 1:
             # ... and as a bare file gets it: the record stream goes to the host as a .dexqv image, dx_qv_walk_indexed finds the
             # segment boundaries AND leaves the group index (host threads; it passes every code anyway), dx_qv_use_index hands
@@ -611,6 +654,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
         "decode": state.get("decode"),
         "decode_indexed": state.get("decode_indexed"),
         "decode_walk_indexed": state.get("decode_walk_indexed"),
+        "device_walk": state.get("device_walk"),
         "text_front_end": fr,
         "pipeline": pipe,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}

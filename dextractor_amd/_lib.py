@@ -20,7 +20,7 @@ DX_LETTERS_LOWER, DX_LETTERS_UPPER, DX_LETTERS_ARROW = 0, 1, 2
 DX_DEL, DX_INS, DX_MRG, DX_SUB, DX_DRUN, DX_SRUN = range(6)
 KERNELS = ["k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
            "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact", "k_qv_encode_text",
-           "k_qv_decode_sub", "k_qv_decode_runs", "k_qv_decode_plain", "k_qv_decode_tags"]
+           "k_qv_decode_sub", "k_qv_decode_runs", "k_qv_decode_plain", "k_qv_decode_tags", "k_qv_walk"]
 DECODE_KERNELS = ["k_qv_decode", "k_qv_decode_sub", "k_qv_decode_runs", "k_qv_decode_plain", "k_qv_decode_tags"]
 
 
@@ -58,6 +58,10 @@ class QVIndex(C.Structure):
                 ("coding", QVCoding), ("prefix", C.c_char_p), ("newv", C.c_int), ("flip", C.c_int),
                 ("gidx", C.POINTER(C.c_uint32)), ("gidx_off", C.POINTER(C.c_uint64)), ("gidx_words", C.c_uint64),
                 ("gidx_none", C.c_uint64)]
+
+class QVDIndex(C.Structure):                     # dx_qv_dindex
+    _fields_ = [("n", C.c_uint64), ("d_rec_off", C.c_void_p), ("d_hdr_off", C.c_void_p), ("d_seg", C.c_void_p),
+                ("d_len", C.c_void_p), ("d_hdr4", C.c_void_p), ("pieces", C.c_uint64), ("piece_bytes", C.c_uint64)]
 
 # name -> (restype, argtypes); every symbol include/dexgpu.h declares
 _P = C.c_void_p
@@ -118,6 +122,9 @@ SIGNATURES = {
     "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
     "dx_qv_walk": (C.c_int, [_P, C.c_size_t, _P]),
     "dx_qv_walk_indexed": (C.c_int, [_P, C.c_size_t, _P, C.c_int]),
+    "dx_file_undexqv_plan_on": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "dx_qv_walk_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.c_int, C.c_int, _P]),
+    "dx_qv_dindex_free": (None, [_P, _P]),
     "dx_qv_use_index": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64]),
     "dx_qv_index_free": (None, [_P]),
     "dx_file_pack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),

@@ -57,6 +57,36 @@ class DevBuf:
         return self
 
 
+class DeviceIndex:
+    """The arrays dx_qv_walk_device left on the device (the library's memory: free())."""
+
+    class _View:
+        def __init__(self, ptr): self.ptr = ptr
+
+    def __init__(self, ctx, x):
+        self.ctx, self.x, self.n = ctx, x, int(x.n)
+        self.pieces, self.piece_bytes = int(x.pieces), int(x.piece_bytes)
+        self.rec_off, self.hdr_off = self._View(x.d_rec_off), self._View(x.d_hdr_off)
+        self.seg, self.len, self.hdr4 = self._View(x.d_seg), self._View(x.d_len), self._View(x.d_hdr4)
+
+    def download(self):
+        """-> dict of numpy arrays, as qv_walk returns them"""
+        n, out = self.n, {}
+        for name, v, dt, shape in (("rec_off", self.rec_off, np.uint64, (n + 1,)), ("hdr_off", self.hdr_off, np.uint64, (n + 1,)),
+                                   ("seg", self.seg, np.uint32, (n, 5)), ("len", self.len, np.uint32, (n,)), ("hdr4", self.hdr4, np.int32, (n, 4))):
+            a = np.zeros(shape, dt)
+            if a.nbytes:
+                self.ctx._chk(self.ctx.lib.dx_d2h(self.ctx.h, a.ctypes.data, v.ptr, a.nbytes))
+            out[name] = a
+        out["n"] = n
+        return out
+
+    def free(self):
+        if self.x is not None:
+            self.ctx.lib.dx_qv_dindex_free(self.ctx.h, C.byref(self.x))
+            self.x = None
+
+
 class Context:
     def __init__(self, device: int = 0):
         self.lib = L.load()
@@ -180,6 +210,14 @@ class Context:
         flags = (1 if upper else 0) | (2 if flip else 0)          # DX_DECODE_UPPER | DX_DECODE_FLIP
         self._chk(self.lib.dx_qv_decode(self.h, d_in.ptr, d_rec_off.ptr, d_hdr_off.ptr if d_hdr_off else None,
                                         d_seg.ptr, d_len.ptr, n, flags, d_out.ptr, d_out_off.ptr))
+
+    def qv_walk_device(self, d_img, nbytes, first, coding, newv=1, flip=0):
+        """dx_qv_walk_device: the record walk of the bare stream at d_img on the device -> DeviceIndex (device arrays
+        rec_off, hdr_off, seg, len, hdr4 as views that dx_qv_decode takes; .free() when done).  Raises DexGPUError
+        (DX_E_MISMATCH) when the stream has to be walked on the host."""
+        x = L.QVDIndex()
+        self._chk(self.lib.dx_qv_walk_device(self.h, d_img.ptr, nbytes, first, C.byref(coding), newv, flip, C.byref(x)))
+        return DeviceIndex(self, x)
 
     def index_quiva_device(self, d_text, nbytes):
         """GPU text front end -> (off uint64, len uint32, hdr4 int32 [n,4], prefix_len); raises

@@ -449,7 +449,16 @@ int dex_tool_main(int tool, int argc, char *argv[])
              its size comes from the host walk over the record stream, which runs while the GPU context is
              still being opened, and so does the allocation of the file's pages. */
           dx_undexqv_plan *plan = NULL;
-          int              rc = dx_file_undexqv_plan(in, n, &plan, &out_len), direct, fd = fileno(output);
+          int              rc, direct, fd = fileno(output);
+          if (n >= ((size_t) 256 << 20))                  /* a large file: its records are walked on the GPU (dx_file_undexqv_plan_on) */
+            { if (Opening)
+                { pthread_join(Opener, NULL);
+                  Opening = 0;
+                }
+              rc = dx_file_undexqv_plan_on(Ctx0, in, n, &plan, &out_len);
+            }
+          else
+            rc = dx_file_undexqv_plan(in, n, &plan, &out_len);
           tmark("records walked");
           if (rc == DX_OK)
             { direct = file_is_ours(output) &&

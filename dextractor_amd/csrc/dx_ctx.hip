@@ -407,7 +407,7 @@ int dx_grid_waves(dx_ctx *ctx, uint64_t n_units, int waves_per_cu)
 static const char *k_names[DX_K_COUNT] =
   { "k_pack2_encode", "k_pack2_decode", "k_qv_prescan", "k_qv_hist", "k_qv_sizes", "k_scan",
     "k_qv_encode", "k_qv_decode", "k_synth", "k_index", "k_qv_compact", "k_qv_encode_text",
-    "k_qv_decode_sub", "k_qv_decode_runs", "k_qv_decode_plain", "k_qv_decode_tags" };
+    "k_qv_decode_sub", "k_qv_decode_runs", "k_qv_decode_plain", "k_qv_decode_tags", "k_qv_walk" };
 
 extern "C" const char *dx_kernel_name(int kernel)
 { return (kernel >= 0 && kernel < DX_K_COUNT) ? k_names[kernel] : "?"; }

@@ -793,19 +793,108 @@ struct dx_undexqv_plan
     dx_qv_index    x;
     tbuf           hd;            /* the header lines, one after the other */
     uint64_t      *ooff, *hat;    /* per entry: where its five data lines start in the text; where its header line starts in hd */
+    /* a plan made on the device (dx_file_undexqv_plan_on): the image is there already, and so is the index */
+    dx_ctx        *ctx;
+    void          *d_in;
+    dx_qv_dindex   dix;
   };
 
 void dx_file_undexqv_plan_free(dx_undexqv_plan *p)
 { if (p == NULL) return;
   dx_qv_index_free(&p->x);
+  if (p->ctx != NULL)
+    { dx_qv_dindex_free(p->ctx, &p->dix);
+      if (p->d_in != NULL) (void) dx_free(p->ctx, p->d_in);
+    }
   free(p->ooff); free(p->hat); free(p->hd.p);
   free(p);
 }
 
+/* header lines (undexqv.c:182) and where every entry's lines go in the text, from p->x.n / len / hdr4 / prefix */
+static int plan_layout(dx_undexqv_plan *p)
+{ const size_t plen = strlen(p->x.prefix);
+  size_t   total = 0;
+  uint64_t i;
+  int      rc;
+  p->ooff = malloc((p->x.n + 1) * sizeof(*p->ooff));
+  p->hat  = malloc((p->x.n + 1) * sizeof(*p->hat));
+  if (!p->ooff || !p->hat) return DX_E_NOMEM;
+  for (i = 0; i < p->x.n; i++)
+    { const int32_t *h = p->x.hdr4 + 4*i;
+      if ((rc = tb_room(&p->hd, plen + 80)) != DX_OK) return rc;
+      p->hat[i]  = p->hd.len;
+      p->hd.len += (size_t) sprintf(p->hd.p + p->hd.len, "%s/%d/%d_%d RQ=0.%d\n", p->x.prefix, h[0], h[1], h[2], h[3]);
+      total     += p->hd.len - (size_t) p->hat[i];
+      p->ooff[i] = total;
+      total     += 5 * ((size_t) p->x.len[i] + 1);        /* undexqv.c:206-207 */
+    }
+  p->hat[p->x.n] = p->hd.len;
+  p->ooff[p->x.n] = total;
+  p->total = total;
+  return DX_OK;
+}
+
+/* The plan of a large 0x55aa-keyed image with the GPU at hand: the image goes to the device (where the run wants it anyway),
+   the records are walked THERE (dx_qv_walk_device: a lane per 32 KiB piece; 0.1 s for 14 GB of records where 32 host
+   threads take 7.5 s), and only the entries' lengths and header fields come back for the header lines.  Whatever the device
+   walk does not take -- small images (the host walk is over before the device's tables are up), 16-bit framing fields,
+   walks that do not chain up, a damaged stream -- is planned on the host as before (dx_file_undexqv_plan), which also
+   has the words for what is wrong with a file.  DEXGPU_HOST_WALK=1: always on the host.                             */
+#define DX_DEVICE_WALK_MIN ((size_t) 256 << 20)
+int dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len)
+{ dx_undexqv_plan *p;
+  uint16_t key;
+  size_t   at = 2, used = 0;
+  int      rc;
+  const char *e = getenv("DEXGPU_DEVICE_WALK_MIN");
+  const size_t least = e != NULL && *e ? (size_t) strtoull(e, NULL, 10) : DX_DEVICE_WALK_MIN;
+
+  if (img == NULL || plan == NULL || out_len == NULL) return DX_E_ARG;
+  if (ctx == NULL || n < least || n < 16 || getenv("DEXGPU_HOST_WALK") != NULL)
+    return dx_file_undexqv_plan(img, n, plan, out_len);
+  memcpy(&key, img, 2);
+  if (key != 0x55aa && key != 0xaa55)
+    return dx_file_undexqv_plan(img, n, plan, out_len);
+  *plan = NULL; *out_len = 0;
+  p = calloc(1, sizeof(*p));
+  if (p == NULL) return DX_E_NOMEM;
+  p->x.newv = 1;
+  { uint16_t k2 = 0;                                      /* the coding, as dx_qv_walk reads it (QV.c:1222-1256) */
+    uint32_t pl = 0;
+    memcpy(&k2, img + at, 2);
+    memcpy(&pl, img + at + 6, 4);
+    if (k2 != 0x33cc) pl = ((pl & 0xffu) << 24) | ((pl & 0xff00u) << 8) | ((pl >> 8) & 0xff00u) | (pl >> 24);
+    rc = (uint64_t) pl > (uint64_t) (n - at - 10) ? DX_E_FORMAT : DX_OK;
+    if (rc == DX_OK && (p->x.prefix = malloc((size_t) pl + 1)) == NULL) rc = DX_E_NOMEM;
+    if (rc == DX_OK) rc = dx_qv_read_coding(img + at, n - at, &p->x.coding, &p->x.flip, p->x.prefix, (size_t) pl + 1, &used);
+  }
+  if (rc != DX_OK) goto host;
+  at += used;
+  p->ctx = ctx;
+  if ((rc = dx_malloc(ctx, n + 64, &p->d_in)) != DX_OK || (rc = dx_h2d(ctx, p->d_in, img, n)) != DX_OK) goto host;
+  rc = dx_qv_walk_device(ctx, p->d_in, n, at, &p->x.coding, 1, p->x.flip, &p->dix);
+  if (rc != DX_OK) goto host;
+  p->x.n    = p->dix.n;
+  p->x.len  = malloc((p->x.n + 1) * sizeof(uint32_t));
+  p->x.hdr4 = malloc((p->x.n + 1) * 4 * sizeof(int32_t));
+  if (!p->x.len || !p->x.hdr4) { rc = DX_E_NOMEM; goto fail; }
+  if (p->x.n > 0 && ((rc = dx_d2h(ctx, p->x.len, p->dix.d_len, p->x.n * 4)) != DX_OK ||
+                     (rc = dx_d2h(ctx, p->x.hdr4, p->dix.d_hdr4, p->x.n * 16)) != DX_OK)) goto fail;
+  p->img = img; p->n = n;
+  if ((rc = plan_layout(p)) != DX_OK) goto fail;
+  *plan = p; *out_len = p->total;
+  return DX_OK;
+
+host:                                                     /* not the device's: the host walk (and its verdict) */
+  dx_file_undexqv_plan_free(p);
+  return dx_file_undexqv_plan(img, n, plan, out_len);
+fail:
+  dx_file_undexqv_plan_free(p);
+  return rc;
+}
+
 int dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len)
 { dx_undexqv_plan *p;
-  size_t   plen, total = 0;
-  uint64_t i;
   int      rc;
 
   if (img == NULL || plan == NULL || out_len == NULL) return DX_E_ARG;
@@ -821,23 +910,8 @@ int dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, s
   }
   if (rc != DX_OK) { free(p); return rc; }
   p->img = img; p->n = n;
-  plen = strlen(p->x.prefix);
-  p->ooff = malloc((p->x.n + 1) * sizeof(*p->ooff));
-  p->hat  = malloc((p->x.n + 1) * sizeof(*p->hat));
-  if (!p->ooff || !p->hat) { rc = DX_E_NOMEM; goto fail; }
-  for (i = 0; i < p->x.n; i++)                            /* header lines, undexqv.c:182 */
-    { const int32_t *h = p->x.hdr4 + 4*i;
-      if ((rc = tb_room(&p->hd, plen + 80)) != DX_OK) goto fail;
-      p->hat[i]  = p->hd.len;
-      p->hd.len += (size_t) sprintf(p->hd.p + p->hd.len, "%s/%d/%d_%d RQ=0.%d\n", p->x.prefix, h[0], h[1], h[2], h[3]);
-      total     += p->hd.len - (size_t) p->hat[i];
-      p->ooff[i] = total;
-      total     += 5 * ((size_t) p->x.len[i] + 1);        /* undexqv.c:206-207 */
-    }
-  p->hat[p->x.n] = p->hd.len;
-  p->ooff[p->x.n] = total;
-  p->total = total;
-  *plan = p; *out_len = total;
+  if ((rc = plan_layout(p)) != DX_OK) goto fail;
+  *plan = p; *out_len = p->total;
   return DX_OK;
 
 fail:
@@ -853,13 +927,18 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
 
   if (ctx == NULL || p == NULL || sink == NULL) return DX_E_ARG;
   h.n = p->x.n; h.ooff = p->ooff; h.hat = p->hat; h.hd = p->hd.p; h.sink = sink; h.user = user;
+  if (p->ctx != NULL && p->ctx != ctx) return DX_E_ARG;   /* (a plan made on a device runs there) */
   if (p->x.n > 0)
     { TRY(dx_qv_set_coding(ctx, &p->x.coding, 0));
-      TRY(dupload(&pool, p->img, p->n, &d_in));
-      TRY(dupload(&pool, p->x.rec_off, (p->x.n + 1) * 8, &d_rec));
-      TRY(dupload(&pool, p->x.hdr_off, (p->x.n + 1) * 8, &d_hoff));
-      TRY(dupload(&pool, p->x.seg, p->x.n * 5 * 4, &d_seg));
-      TRY(dupload(&pool, p->x.len, p->x.n * 4, &d_len));
+      if (p->ctx != NULL)                                 /* image and index are on the device already */
+        { d_in = p->d_in; d_rec = p->dix.d_rec_off; d_hoff = p->dix.d_hdr_off; d_seg = p->dix.d_seg; d_len = p->dix.d_len; }
+      else
+        { TRY(dupload(&pool, p->img, p->n, &d_in));
+          TRY(dupload(&pool, p->x.rec_off, (p->x.n + 1) * 8, &d_rec));
+          TRY(dupload(&pool, p->x.hdr_off, (p->x.n + 1) * 8, &d_hoff));
+          TRY(dupload(&pool, p->x.seg, p->x.n * 5 * 4, &d_seg));
+          TRY(dupload(&pool, p->x.len, p->x.n * 4, &d_len));
+        }
       TRY(dupload(&pool, p->ooff, p->x.n * 8, &d_ooff));
       TRY(dalloc(&pool, p->total, &d_out));
       if (p->x.gidx != NULL && !p->x.flip)               /* the walk's group index: a wavefront per line (dx_qv_use_index) */
@@ -893,7 +972,7 @@ int dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper, uint8_
 
   if (ctx == NULL || out == NULL || out_len == NULL || img == NULL) return DX_E_ARG;
   *out = NULL; *out_len = 0;
-  rc = dx_file_undexqv_plan(img, n, &p, &total);
+  rc = dx_file_undexqv_plan_on(ctx, img, n, &p, &total);
   if (rc != DX_OK) return rc;
   m.res = malloc(total + 16);
   if (m.res == NULL) rc = DX_E_NOMEM;

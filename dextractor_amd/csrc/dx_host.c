@@ -720,6 +720,52 @@ static void build_rwlut(const wlut *rt, const wlut *nt, int esc, rwlut *m)
     }
 }
 
+/* The same tables for the device walk (dx_qv_walk.hip), 16 bits an entry: layout in dx_walk.h. */
+#include "dx_walk.h"
+int dx_walk_luts_build(const dx_qv_coding *cd, uint8_t *blob, int esc[4])
+{ wlut  *lut[6] = { NULL, NULL, NULL, NULL, NULL, NULL };
+  mwlut *ml = malloc(sizeof(mwlut));
+  rwlut *rl = malloc(sizeof(rwlut));
+  int    s, rc = DX_OK;
+  uint32_t x;
+  if (cd == NULL || blob == NULL || esc == NULL || ml == NULL || rl == NULL) { free(ml); free(rl); return cd && blob && esc ? DX_E_NOMEM : DX_E_ARG; }
+  memset(blob, 0, WALK_BLOB_BYTES);
+  for (s = 0; s < 6; s++)
+    { if ((s == DX_DRUN && cd->delChar < 0) || (s == DX_SRUN && cd->subChar < 0)) continue;
+      lut[s] = malloc(sizeof(wlut));
+      if (lut[s] == NULL) { rc = DX_E_NOMEM; goto done; }
+      build_wlut(&cd->s[s], lut[s]);
+      memcpy(blob + WALK_W16_OFF + (size_t) s * 65536u * 2u, lut[s]->e, 65536u * 2u);
+    }
+  for (s = 0; s < 4; s++)
+    { uint16_t *m16 = (uint16_t *) (blob + WALK_MW_OFF) + (size_t) s * 4096u;
+      esc[s] = cd->s[s].type == 2;
+      build_mwlut(lut[s], esc[s], ml);
+      for (x = 0; x < 4096u; x++)
+        { const uint32_t e = lut[s]->e[x << 4], l = e >> 8;
+          const uint32_t first = (l > 0 && l <= WALK_WIN && !(esc[s] && (e & 0xff) == 255)) ? l : 0u;
+          m16[x] = ml->e[x].nsym ? (uint16_t) (ml->e[x].nbits | (ml->e[x].last << 4) | (ml->e[x].nsym << 8)) : 0;
+          ((uint16_t *) (blob + WALK_ONE_OFF))[(size_t) s * 4096u + x] = first ? (uint16_t) (first | (first << 4) | (1u << 8)) : 0;
+        }
+    }
+  for (s = 0; s < 2; s++)
+    { const int sym = s ? DX_SUB : DX_DEL, run = s ? DX_SRUN : DX_DRUN;
+      uint16_t *r16 = (uint16_t *) (blob + WALK_RW_OFF) + (size_t) s * 4096u;
+      uint16_t *o16 = (uint16_t *) (blob + WALK_R1_OFF) + (size_t) s * 4096u;
+      if (lut[run] == NULL) continue;
+      build_rwlut(lut[run], lut[sym], esc[sym], rl);
+      for (x = 0; x < 4096u; x++)
+        { const uint32_t e1 = lut[run]->e[x << 4], l1 = e1 >> 8;
+          r16[x] = rl->e[x].ok ? (uint16_t) (rl->e[x].nbits | (rl->e[x].last << 4) | (((uint32_t) rl->e[x].run + 1u) << 8)) : 0;
+          o16[x] = (l1 > 0 && l1 <= WALK_WIN && (e1 & 0xff) != 255) ? (uint16_t) (l1 | (l1 << 4) | ((e1 & 0xff) << 8)) : 0;
+        }
+    }
+done:
+  for (s = 0; s < 6; s++) free(lut[s]);
+  free(ml); free(rl);
+  return rc;
+}
+
 /* run-coded segment (QV.c:604-691); *nonrun receives the number of non-run symbols */
 static int64_t walk_runs(const uint8_t *p, const uint8_t *end, uint32_t rlen, const wlut *nt, int esc,
                          const wlut *rt, const rwlut *pair, uint32_t *nonrun, int flip)

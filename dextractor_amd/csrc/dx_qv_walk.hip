@@ -1,0 +1,587 @@
+// dx_qv_walk.hip -- the record walk of a bare .dexqv stream on the device.
+//
+// The format stores no record or segment lengths (QV.c:1428-1481, undexqv.c:119-208): where a segment ends is known only
+// after every code of it has been passed, so the index dx_qv_decode wants -- where every record starts, how long its five
+// segments are -- takes a walk over the whole stream, code by code, in the order of the file.  The host does that on up to
+// 32 threads (dx_host.c: walk_parallel; 7.5 s for the 14 GB of records of the 1 M x 10 kb batch); a GPU has no fast single
+// thread, but it has half a million slow ones, and the host walk's idea carries over lane for lane:
+//
+//   * the stream is cut into pieces of 32 KiB (more, beyond 16 GB: at most 512 K pieces); k_walk_find, a wave per piece, notes
+//     the first offsets in each piece at which a plausible record header stands (header_plausible, as on the host: 1.4e-8 of
+//     all offsets pass by chance -- and the byte or two in front of every true header, see there);
+//   * k_walk_pieces, ONE LANE per piece, tries those offsets in turn -- a start is taken when the record walks cleanly from
+//     it (within a budget of two pieces' bytes: garbage may claim any length) and another plausible header, or the stream's
+//     end, stands behind it -- and then walks record after record until it has left its piece, noting every record on the
+//     way.  The walk needs code LENGTHS only; the look-up tables are the host walk's, 16 bits an entry, in LDS (dx_walk.h);
+//   * the host looks at 48 bytes per piece: arriving exactly where the next piece's lane started proves both (a walk from a
+//     wrong offset does not fall back onto record boundaries: framing fields and pad words are not self-delimiting).  A
+//     piece the chain does not arrive at the start of is walked again from where the chain does arrive, a lane of its own,
+//     until the chain is whole; a record that does not walk, or a chain that will not close in a few dozen rounds, is
+//     DX_E_MISMATCH and the caller's business (the host walk, which also knows what to say about a damaged file);
+//   * k_walk_gather, a wave per piece, puts the records of the pieces on the chain side by side.
+//
+// Only offsets on an unbroken chain of walks from the first record are kept: the result is the host walk's by construction
+// (tests/test_gpu_walk.py: word for word, on pieces from 4 KiB up).
+// Roofline: none of the usual ones -- 64 independent chains of dependent look-ups per wave, a third of the instructions
+// scalar (divergent control flow), waves waiting two thirds of their time (SQ_WAIT_ANY) on LDS and load latency: 0.1 s for
+// those 14 GB (150 GB/s), 75 times the host's 32 threads.  profiles/r04_device_walk.txt.
+#include "dx_internal.hpp"
+#include "dx_device.hpp"
+#include "dx_walk.h"
+
+#include <stdlib.h>
+
+#ifndef WALK_BLOCK
+#define WALK_BLOCK     768              // two workgroups a CU (80 KB of LDS each): 24 waves, what the registers allow
+#endif
+#define WALK_CAND      4u
+#ifndef WALK_PIECE_KB
+#define WALK_PIECE_KB 32
+#endif
+#define WALK_PIECE_MIN ((uint64_t) WALK_PIECE_KB << 10)
+#define WALK_LANES_MAX ((uint64_t) 512 * 1024)
+#define WALK_ROUNDS    48
+
+#define WP_NONE     1u            // no start in this piece
+#define WP_BAD      2u            // a record on this lane's chain did not walk
+#define WP_OVERFLOW 4u            // more records than the lane's scratch holds
+
+struct walk_args
+{ const uint8_t  *img;
+  uint64_t        n, first, piece, pieces;
+  const uint16_t *w16, *mw, *rw, *r1;     // the blob's tables in device memory (dx_walk.h)
+  const uint16_t *one;
+  const uint8_t  *tail;                   // the image's last bytes from tail_at on, zeros behind them: 256 bytes
+  uint64_t        tail_at;
+  int             delChar, subChar, flip;
+  int             esc[4];
+};
+
+struct walk_rec_d   { uint64_t off; uint32_t hdr_bytes, len, seg[5]; int32_t dwell, beg, end, qv; uint32_t pad; };
+struct walk_piece_d { uint64_t start, end, dwell_sum; uint32_t count, flags, hdr_sum, first_hdr /* framing bytes of the first record */; uint32_t tried /* guesses that did not hold */, steps_k /* thousands of loop rounds (logs) */; };
+
+__device__ __forceinline__ uint32_t bswap_if(uint32_t v, int flip) { return flip ? __builtin_bswap32(v) : v; }
+
+__device__ __forceinline__ uint32_t load32_at(const uint8_t *p) { return *(const u32_u *) p; }
+
+// header_plausible of dx_host.c, word for word
+__device__ __forceinline__ bool header_plausible_d(const walk_args &a, uint64_t at)
+{ int k = 0;
+  while (at < a.n && a.img[at] == 255 && k < 16) { at += 1; k += 1; }
+  if (at + 13 > a.n) return false;
+  at += 1;
+  const int32_t beg = (int32_t) bswap_if(load32_at(a.img + at), a.flip), end_ = (int32_t) bswap_if(load32_at(a.img + at + 4), a.flip);
+  const int32_t qv  = (int32_t) bswap_if(load32_at(a.img + at + 8), a.flip);
+  return beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= (1 << 22) && qv >= 0 && qv < 1000000 &&
+         (uint64_t) (end_ - beg) <= 8u * (uint64_t) (a.n - at);
+}
+
+// ---------------------------------------------------------------------------------------------
+//  k_walk_find: the first WALK_CAND plausible offsets of every piece (a wave per piece, 64 offsets a time)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DX_BLOCK)
+void k_walk_find(walk_args a, uint64_t *cand, uint32_t *ncand)
+{ const uint32_t lane = (uint32_t) lane_id();
+  const uint64_t k = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
+  if (k >= a.pieces) return;
+  if (k == 0) { if (lane == 0) ncand[0] = 0; return; }            // (the first piece starts at the first record)
+  const uint64_t lo = a.first + k * a.piece, hi = k == a.pieces - 1 ? a.n : lo + a.piece;
+  uint32_t found = 0;
+  for (uint64_t base = lo; base < hi && found < WALK_CAND; base += 64u)
+    { const uint64_t p = base + lane;
+      bool ok = false;
+      if (p < hi && p + 16 <= a.n)
+        { // the thirteen bytes of a header without leading 255s out of one 16-byte load; 1 byte in 256 is a 255: those the long way
+          const u32x4 v = *(const u32x4_u *) (a.img + p);
+          if ((v.x & 0xffu) == 255u)
+            ok = header_plausible_d(a, p);
+          else
+            { const int32_t beg  = (int32_t) bswap_if((v.x >> 8) | (v.y << 24), a.flip);
+              const int32_t end_ = (int32_t) bswap_if((v.y >> 8) | (v.z << 24), a.flip);
+              const int32_t qv   = (int32_t) bswap_if((v.z >> 8) | (v.w << 24), a.flip);
+              ok = beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= (1 << 22) && qv >= 0 && qv < 1000000 &&
+                   (uint64_t) (end_ - beg) <= 8u * (uint64_t) (a.n - (p + 1));
+            }
+        }
+      else if (p < hi)
+        ok = header_plausible_d(a, p);
+      uint64_t m = __ballot(ok);
+      while (m && found < WALK_CAND)
+        { const uint32_t l = (uint32_t) __ffsll((unsigned long long) m) - 1u;
+          if (lane == l) cand[k * WALK_CAND + found] = p;
+          found += 1;
+          m &= m - 1;
+        }
+    }
+  // A true header at p makes p - 1 plausible too wherever the quality value is below 3906 and the entry short of 16 k
+  // symbols (its fields read one byte early: 256 times the length, 256 times the quality value) -- a guess that costs a
+  // walk of its garbage length, the whole budget.  Of two guesses next to each other the later one goes first: it claims
+  // the shorter record, and if it holds the earlier ones cannot (no record has fewer than 13 bytes).
+  if (lane == 0)
+    { uint64_t *c = cand + k * WALK_CAND;
+      for (uint32_t i = 0; i < found; )                      // (every run of neighbours back to front: two bytes early happens too)
+        { uint32_t e = i;
+          while (e + 1 < found && c[e + 1] == c[e] + 1) e++;
+          for (uint32_t x = i, y = e; x < y; x++, y--) { const uint64_t t = c[x]; c[x] = c[y]; c[y] = t; }
+          i = e + 1;
+        }
+      ncand[k] = found;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  the walk of one lane
+// ---------------------------------------------------------------------------------------------
+// The 64 lanes of a wave walk 64 different pieces, each somewhere else in its record: one in the insertion line, one in the
+// deletion line's runs, one reading a header.  Were every segment's walk a function of its own (as on the host), a wave
+// would run them one after the other for the lanes that happen to be in each -- so the whole walk of a piece is ONE loop
+// whose body is one look-up of whatever segment the lane is in, and the five segments, the header and the record's end are
+// states of the lane (ph).  The loop's common path: refill, a 16-bit look-up in LDS, a shift.
+//
+// MSB-first bit reader over 32-bit words (w_fill / w_peek / w_skip of dx_host.c) fed 16 bytes a time, the next 16 requested
+// when the current ones are taken up (a lane's loads are a dependent chain).  Bytes behind the image's end read as zero; a
+// segment's end compares the bytes used with what is there.
+struct wrd_d
+{ const uint8_t *q;             // the next 16 bytes to request
+  u32x4    cur, nxt;
+  uint32_t k;                   // words left in cur
+  uint64_t buf;
+  int      nb;
+  uint32_t nw;                  // words taken into buf since the segment's start: 32 nw - nb bits of it have been passed
+};
+
+// 16 bytes of the image at q, zeros behind its end: the image's last bytes come from a padded copy (walk_args.tail), by a select
+// of the address -- no branch, and nothing is done to the bytes here (a byte swap is the taker's business, w_fill_d): whatever
+// touches them waits for them, and they are requested four refills ahead of their use.
+__device__ __forceinline__ u32x4 load16_within(const walk_args &a, const uint8_t *q)
+{ const uint64_t off = (uint64_t) (q - a.img);
+  const uint64_t t   = off - a.tail_at;
+  const uint8_t *p   = off < a.tail_at ? q : a.tail + (t < 240u ? t : 240u);
+  return *(const u32x4_u *) p;
+}
+
+__device__ __forceinline__ void w_fill_d(wrd_d &r, const walk_args &a)
+{ if (r.nb <= 32)
+    { if (r.k == 0)                                      // (the 16 bytes asked for three words ago)
+        { r.cur = r.nxt;
+          r.k   = 4;
+        }
+      else if (r.k == 3)                                 // the next 16: asked for here, looked at when these are used up
+        { r.nxt = load16_within(a, r.q);
+          r.q  += 16;
+        }
+      const uint32_t w = bswap_if(r.cur.x, a.flip);
+      r.cur.x = r.cur.y; r.cur.y = r.cur.z; r.cur.z = r.cur.w;
+      r.k   -= 1;
+      r.buf |= (uint64_t) w << (32 - r.nb);
+      r.nb  += 32;
+      r.nw  += 1;
+    }
+}
+__device__ __forceinline__ void w_open_d(wrd_d &r, const walk_args &a, const uint8_t *p)
+{ r.cur = load16_within(a, p);
+  r.q = p + 16; r.k = 4; r.buf = 0; r.nb = 0; r.nw = 0;          // (nxt: requested when the first word of cur has been taken)
+  // waited for HERE, once a segment: left to the compiler, the wait for this request lands in the look-up loop, where it is a
+  // wait for everything outstanding at every refill -- the request for the next 16 bytes, made a moment ago, included
+  __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+}
+__device__ __forceinline__ uint32_t w_peek_d(wrd_d &r, const walk_args &a) { w_fill_d(r, a); return (uint32_t) (r.buf >> 48); }
+__device__ __forceinline__ void w_skip_d(wrd_d &r, uint32_t n) { r.buf <<= n; r.nb -= (int) n; }
+
+__device__ __forceinline__ uint32_t pad_words_d(uint64_t T, uint32_t last)      // QV.c:436-442
+{ const uint32_t olen = (uint32_t) T & 31u, llen = (uint32_t) (T - last) & 31u;
+  const uint32_t w = (uint32_t) (T >> 5) + (olen ? 1u : 0u);
+  if (olen > 0) return w + ((llen > 16u && olen > llen) ? 1u : 0u);
+  return w + ((T > 0 && llen > 16u) ? 1u : 0u);
+}
+
+// LDS: the tables of dx_walk.h a walk looks into -- t[0..3] the line's own (del, ins, mrg, sub: the pair table of a run-coded
+// line, else the several-codes table), r1 the run codes alone (del, sub), one the first code of a window alone (the four symbol
+// schemes); 80 KB.  All read alike: bits to skip | the last code's length << 4 | symbols covered << 8, 0: not this way.
+struct walk_lds { uint16_t t[4][4096]; uint16_t r1[2][4096]; uint16_t one[4][4096]; };
+
+#define PH_HEAD 0u              // at a record's first byte
+#define PH_DEL  1u
+#define PH_INS  2u
+#define PH_MRG  3u
+#define PH_SUB  4u
+#define PH_DONE 5u              // behind the record's last segment
+#ifndef WALK_BURST
+#define WALK_BURST 24           // look-ups in a row before the lanes that need something else are seen to
+#endif
+
+// One lane per piece (todo == NULL: piece = thread index; else the listed pieces, each from start[piece], which the chain has
+// arrived at): the piece's records into recs[piece * rcap ...], what became of it into pc[piece].
+//
+// The loop: a burst of up to WALK_BURST look-ups of the common kind -- the window holds whole codes (a whole run-and-symbol
+// pair) that stay inside the line: skip their bits, count their symbols; the same few instructions whichever line the lane
+// is in -- then, for the lanes the burst left waiting, one step of the other kinds: a single code (a line's last few, a pair
+// that does not fit the window), a code of more than 12 bits or an escape (from the 16-bit table in memory), a run's literal,
+// a segment's end, a record's header, a record's end.  (Measured: the single-code steps inside the burst as well, the lane's
+// mode choosing among three tables of one form, cost the burst more than the trips outside save: 119 against 106 ms.)
+__global__ __launch_bounds__(WALK_BLOCK)
+void k_walk_pieces(walk_args a, const uint64_t *cand, const uint32_t *ncand, const uint32_t *todo, uint32_t ntodo,
+                   const uint64_t *start, walk_piece_d *pc, walk_rec_d *recs, uint32_t rcap)
+{ __shared__ walk_lds S;
+#define WALK_STAGE(tab, from, words) { const uint32_t *s_ = (const uint32_t *) (const void *) (from); uint32_t *d_ = (uint32_t *) (void *) (tab); \
+                                       for (uint32_t i = threadIdx.x; i < (words); i += blockDim.x) d_[i] = s_[i]; }
+  WALK_STAGE(S.t[0], a.delChar < 0 ? a.mw + DX_DEL * 4096u : a.rw, 2048u)
+  WALK_STAGE(S.t[1], a.mw + DX_INS * 4096u, 2048u)
+  WALK_STAGE(S.t[2], a.mw + DX_MRG * 4096u, 2048u)
+  WALK_STAGE(S.t[3], a.subChar < 0 ? a.mw + DX_SUB * 4096u : a.rw + 4096u, 2048u)
+  WALK_STAGE(S.r1, a.r1, 4096u)
+  WALK_STAGE(S.one, a.one, 8192u)
+#undef WALK_STAGE
+  __syncthreads();
+  const uint64_t idx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t k;
+  if (todo) { if (idx >= ntodo) return; k = todo[idx]; }
+  else      { if (idx >= a.pieces) return; k = idx; }
+  const uint64_t hi = k == a.pieces - 1 ? a.n : a.first + (k + 1) * a.piece;
+  walk_rec_d *my = recs + k * (uint64_t) rcap;
+  walk_piece_d out = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  uint32_t rounds_ = 0;
+
+  // the lane's state
+  uint64_t at;                         // PH_HEAD: the record's first byte; in a segment: the segment's first byte
+  uint32_t ph = PH_HEAD, rlen = 0, j = 0, last = 0, nn = 0, clen = 0;
+  uint32_t trial = 0, ci = 0;          // trial: the record being walked is a guess (candidate ci of the piece)
+  uint64_t budget = ~0ull;
+  walk_rec_d r;
+  wrd_d rd;
+  bool live = true;
+  rd.nw = 0; rd.nb = 0; rd.k = 0; rd.buf = 0; rd.q = a.img;
+  rd.cur = u32x4{ 0u, 0u, 0u, 0u }; rd.nxt = rd.cur;
+  if (todo || k == 0)
+    { out.start = todo ? start[k] : a.first; at = out.start; }
+  else if (ncand[k] == 0)
+    { out.flags = WP_NONE; live = false; at = 0; }
+  else
+    { trial = 1; budget = 16u * a.piece; at = cand[k * WALK_CAND]; }          // (two pieces' bytes)
+  if (live && !trial && !(at < hi && at < a.n)) { live = false; out.end = at; }     // (nothing of this piece left to walk)
+
+  while (live)
+    { bool fail = false;
+      rounds_ += 1;
+      const uint32_t line = ph - PH_DEL;                        // 0 del, 1 ins, 2 mrg, 3 sub (in a segment)
+      if (ph >= PH_DEL && ph < PH_DONE)
+        { const uint16_t *tab = S.t[line];
+          bool more = true;
+          #pragma unroll 1
+          for (int it = 0; it < WALK_BURST && more; it++)
+            { w_fill_d(rd, a);
+              const uint32_t g = tab[(uint32_t) (rd.buf >> 52)], cnt = g >> 8;
+              more = g != 0u && j + cnt <= rlen;
+              if (more)
+                { const uint32_t nbits = g & 15u;
+                  rd.buf <<= nbits; rd.nb -= (int) nbits;
+                  j += cnt; nn += 1u; last = (g >> 4) & 15u;
+                }
+            }
+          if (!more)
+            { const bool runs = (line == 0 && a.delChar >= 0) || (line == 3 && a.subChar >= 0);
+              if (j < rlen)                                     // one step of another kind
+                { uint32_t w = w_peek_d(rd, a);
+                  bool sym = true;                              // a symbol's code is to be passed
+                  if (runs)                                     // walk_runs: the run code alone first
+                    { const uint32_t e1 = S.r1[line ? 1u : 0u][w >> (16 - WALK_WIN)];
+                      uint32_t c;
+                      if (e1) { last = e1 & 15u; c = e1 >> 8; w_skip_d(rd, last); }
+                      else                                      // more than 12 bits, the code of 255 (a 16-bit literal follows), none
+                        { const uint32_t e = a.w16[(DX_DRUN + (line ? 1u : 0u)) * 65536u + w];
+                          last = e >> 8; c = e & 0xffu;
+                          if (last == 0) fail = true;
+                          w_skip_d(rd, last);
+                          if (c == 255u)
+                            { c = w_peek_d(rd, a); w_skip_d(rd, 16u); last = 16; }
+                        }
+                      if (c > rlen - j) fail = true;
+                      j  += c;
+                      sym = !fail && j < rlen;
+                      if (sym) w = w_peek_d(rd, a);
+                    }
+                  if (sym)                                      // walk_plain's single code; walk_runs' symbol behind the run
+                    { const uint32_t f = S.one[line][w >> (16 - WALK_WIN)] & 15u;
+                      if (f) { last = f; w_skip_d(rd, f); }
+                      else                                      // more than 12 bits, an escape, no code at all
+                        { const uint32_t e = a.w16[line * 65536u + w];
+                          last = e >> 8;
+                          if (last == 0) fail = true;
+                          w_skip_d(rd, last);
+                          if (a.esc[line] && (e & 0xffu) == 255u)
+                            { w_fill_d(rd, a); w_skip_d(rd, 8u); last = 8; }
+                        }
+                      j  += 1;
+                      nn += 1;
+                    }
+                }
+              const uint64_t T = 32ull * rd.nw - (uint64_t) rd.nb;         // bits of the segment passed
+              if (T > budget) fail = true;
+              if (!fail && j >= rlen)                           // the segment's end: its bytes, and on to the next one
+                { const uint64_t bytes = 4ull * pad_words_d(T, last);
+                  if (at + bytes > a.n) fail = true;
+                  else
+                    { if (line == 0) r.seg[0] = (uint32_t) bytes; else if (line == 1) r.seg[2] = (uint32_t) bytes;
+                      else if (line == 2) r.seg[3] = (uint32_t) bytes; else r.seg[4] = (uint32_t) bytes;
+                      at += bytes;
+                      if (line == 0)                            // the tags (Pack_Tag's count, QV.c:810-819): no codes, just bytes
+                        { if (runs) clen = nn;
+                          r.seg[1] = (clen + 3u) >> 2;
+                          if (at + r.seg[1] > a.n) fail = true;
+                          at += r.seg[1];
+                        }
+                      ph += 1; j = 0; last = 0; nn = 0;
+                      if (ph < PH_DONE && !fail) w_open_d(rd, a, a.img + at);
+                    }
+                }
+            }
+        }
+      else if (ph == PH_HEAD)                                   // walk_framing of dx_host.c (0x55aa-keyed: 32-bit fields)
+        { const uint64_t h0 = at;
+          int32_t dw = 0;
+          while (at < a.n && a.img[at] == 255) { dw += 255; at += 1; }
+          if (at + 13 > a.n) fail = true;
+          else
+            { dw += a.img[at];
+              const int32_t beg = (int32_t) bswap_if(load32_at(a.img + at + 1), a.flip), end_ = (int32_t) bswap_if(load32_at(a.img + at + 5), a.flip);
+              const int32_t qv  = (int32_t) bswap_if(load32_at(a.img + at + 9), a.flip);
+              at += 13;
+              rlen = (uint32_t) ((int64_t) end_ - (int64_t) beg);
+              if (end_ < beg || (int64_t) end_ - (int64_t) beg > 0x7fffffff || (uint64_t) rlen > 65536u * 8u * (uint64_t) (a.n - at) + 64u)
+                fail = true;
+              r.off = h0; r.hdr_bytes = (uint32_t) (at - h0); r.len = rlen; r.dwell = dw; r.beg = beg; r.end = end_; r.qv = qv; r.pad = 0;
+              ph = PH_DEL; j = 0; last = 0; nn = 0; clen = rlen;
+              if (!fail) w_open_d(rd, a, a.img + at);
+            }
+        }
+      else                                                      // PH_DONE: `at` is behind the record
+        { if (trial)
+            { if (at == a.n || header_plausible_d(a, at))       // the guess holds: the lane's first record
+                { out.start = r.off; trial = 0; budget = ~0ull; }
+              else
+                fail = true;
+            }
+          if (!fail)
+            { if (out.count < rcap) my[out.count] = r; else out.flags |= WP_OVERFLOW;
+              if (out.count == 0) out.first_hdr = r.hdr_bytes;
+              out.count += 1; out.hdr_sum += r.hdr_bytes; out.dwell_sum += (uint64_t) (uint32_t) r.dwell;
+              ph = PH_HEAD;
+              if (!(at < hi && at < a.n)) { out.end = at; live = false; }
+            }
+        }
+      if (fail)
+        { if (trial)                                            // a wrong guess: the piece's next one
+            { ci += 1;
+              if (ci < ncand[k]) { at = cand[k * WALK_CAND + ci]; ph = PH_HEAD; }
+              else               { out.flags = WP_NONE; live = false; }
+            }
+          else                                                  // a record on the lane's chain does not walk
+            { out.flags |= WP_BAD; out.end = at; live = false; }
+        }
+    }
+  out.tried = ci; out.steps_k = rounds_ >> 10;
+  pc[k] = out;
+}
+
+// the records of the pieces on the chain, side by side: a wave per piece; dst[k] = its first record's index (~0: not on the
+// chain), hbase[k] / wbase[k] = the framing bytes / wells before it
+// (trim[k]: leading 255s of the piece's first record that belong to the record before it -- see the chain)
+__global__ __launch_bounds__(DX_BLOCK)
+void k_walk_gather(uint64_t pieces, const walk_piece_d *pc, const walk_rec_d *recs, uint32_t rcap, const uint64_t *dst,
+                   const uint64_t *hbase, const uint64_t *wbase, const uint64_t *trim,
+                   uint64_t *rec_off, uint64_t *hdr_off, uint32_t *seg, uint32_t *len, int32_t *hdr4)
+{ const uint32_t lane = (uint32_t) lane_id();
+  const uint64_t k = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
+  if (k >= pieces || dst[k] == ~0ull) return;
+  const walk_rec_d *my = recs + k * (uint64_t) rcap;
+  const uint32_t cnt = pc[k].count;
+  uint64_t hb = hbase[k], wb = wbase[k];
+  for (uint32_t i0 = 0; i0 < cnt; i0 += 64u)
+    { const uint32_t i = i0 + lane;
+      walk_rec_d r;
+      uint32_t h = 0, d = 0;
+      if (i < cnt)
+        { r = my[i];
+          if (i == 0) { const uint32_t t = (uint32_t) trim[k]; r.off += t; r.hdr_bytes -= t; r.dwell -= 255 * (int32_t) t; }
+          h = r.hdr_bytes; d = (uint32_t) r.dwell;
+        }
+      const uint32_t hi_ = wave_incl_scan(h), di_ = wave_incl_scan(d);
+      if (i < cnt)
+        { const uint64_t o = dst[k] + i;
+          rec_off[o] = r.off;
+          hdr_off[o] = hb + hi_ - h;
+          len[o]     = r.len;
+          seg[5 * o] = r.seg[0]; seg[5 * o + 1] = r.seg[1]; seg[5 * o + 2] = r.seg[2]; seg[5 * o + 3] = r.seg[3]; seg[5 * o + 4] = r.seg[4];
+          hdr4[4 * o] = (int32_t) (wb + di_); hdr4[4 * o + 1] = r.beg; hdr4[4 * o + 2] = r.end; hdr4[4 * o + 3] = r.qv;
+        }
+      hb += wave_total(hi_); wb += wave_total(di_);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  host
+// ---------------------------------------------------------------------------------------------
+void dx_qv_dindex_free(dx_ctx *ctx, dx_qv_dindex *x)
+{ if (x == NULL) return;
+  (void) ctx;
+  (void) hipFree(x->d_rec_off); (void) hipFree(x->d_hdr_off); (void) hipFree(x->d_seg); (void) hipFree(x->d_len); (void) hipFree(x->d_hdr4);
+  memset(x, 0, sizeof(*x));
+}
+
+int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t first, const dx_qv_coding *cd, int newv, int flip,
+                      dx_qv_dindex *out)
+{ if (ctx == NULL || d_img == NULL || cd == NULL || out == NULL || first > n) return DX_E_ARG;
+  memset(out, 0, sizeof(*out));
+  if (!newv)                       // 16-bit framing fields are too easily plausible (dx_host.c): the host walk's
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_walk_device: a stream with 16-bit framing fields is walked on the host");
+  int rc = dx_after_pending(ctx);
+  if (rc != DX_OK) return rc;
+
+  walk_args a;
+  memset(&a, 0, sizeof(a));
+  a.img = d_img; a.n = n; a.first = first; a.delChar = cd->delChar; a.subChar = cd->subChar; a.flip = flip;
+  { uint64_t piece = (n - first + WALK_LANES_MAX - 1) / WALK_LANES_MAX;
+    if (piece < WALK_PIECE_MIN) piece = WALK_PIECE_MIN;
+    if (const char *e = getenv("DEXGPU_WALK_PIECE")) { const uint64_t v = strtoull(e, NULL, 10); if (v >= 4096) piece = v; }   // (tests)
+    piece = (piece + 4095u) & ~(uint64_t) 4095u;
+    a.piece = piece;
+    a.pieces = n > first ? (n - first + piece - 1) / piece : 1;
+  }
+  const uint64_t P = a.pieces;
+  const uint32_t rcap = (uint32_t) (a.piece / 128u);
+
+  uint8_t  *blob = (uint8_t *) malloc(WALK_BLOB_BYTES);
+  uint8_t  *d_blob = NULL, *d_tail = NULL;
+  uint64_t *d_cand = NULL, *d_start = NULL, *d_dst = NULL;
+  uint32_t *d_ncand = NULL, *d_todo = NULL;
+  walk_piece_d *d_pc = NULL, *pc = (walk_piece_d *) malloc(P * sizeof(walk_piece_d));
+  walk_rec_d   *d_recs = NULL;
+  uint64_t *start = (uint64_t *) calloc(P, 8), *dst = (uint64_t *) malloc(4 * P * 8), *trim = dst ? dst + 3 * P : NULL;
+  uint32_t *todo = (uint32_t *) malloc(P * 4);
+  uint8_t  *onchain = (uint8_t *) calloc(P, 1);
+  uint64_t N = 0;
+#define WALK_FAIL(code, ...) do { rc = dx_fail(ctx, code, __VA_ARGS__); goto done; } while (0)
+#define WALK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) WALK_FAIL(DX_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+  if (!blob || !pc || !start || !dst || !todo || !onchain) WALK_FAIL(DX_E_NOMEM, "dx_qv_walk_device: out of host memory");
+  memset(dst, 0, 4 * P * 8);
+  rc = dx_walk_luts_build(cd, blob, a.esc);
+  if (rc != DX_OK) WALK_FAIL(rc, "dx_qv_walk_device: the look-up tables could not be built");
+  WALK_HIP(hipMalloc(&d_blob, WALK_BLOB_BYTES));
+  WALK_HIP(hipMalloc(&d_cand, P * WALK_CAND * 8));
+  WALK_HIP(hipMalloc(&d_ncand, P * 4));
+  WALK_HIP(hipMalloc(&d_pc, P * sizeof(walk_piece_d)));
+  WALK_HIP(hipMalloc(&d_recs, P * (uint64_t) rcap * sizeof(walk_rec_d)));
+  WALK_HIP(hipMemcpyAsync(d_blob, blob, WALK_BLOB_BYTES, hipMemcpyHostToDevice, ctx->stream));
+  a.w16 = (const uint16_t *) (d_blob + WALK_W16_OFF); a.mw = (const uint16_t *) (d_blob + WALK_MW_OFF);
+  a.rw  = (const uint16_t *) (d_blob + WALK_RW_OFF);  a.r1 = (const uint16_t *) (d_blob + WALK_R1_OFF);
+  a.one = (const uint16_t *) (d_blob + WALK_ONE_OFF);
+  a.tail_at = n >= 64 ? (n - 64) & ~(uint64_t) 15 : 0;
+  WALK_HIP(hipMalloc(&d_tail, 256));
+  WALK_HIP(hipMemsetAsync(d_tail, 0, 256, ctx->stream));
+  if (n > a.tail_at) WALK_HIP(hipMemcpyAsync(d_tail, d_img + a.tail_at, n - a.tail_at, hipMemcpyDeviceToDevice, ctx->stream));
+  a.tail = d_tail;
+
+  { // a workgroup per CU while the lanes allow (the tables fill 64 KB of LDS: two workgroups a CU at most), every CU busy
+    const uint64_t waves = (P + 63u) / 64u, per_cu = (waves + ctx->num_cu - 1) / ctx->num_cu;
+    const uint32_t bs = per_cu >= WALK_BLOCK / 64u ? WALK_BLOCK : (uint32_t) (per_cu ? per_cu * 64u : 64u);
+    dx_prof_begin(ctx, DX_K_QV_WALK);
+    hipLaunchKernelGGL(k_walk_find, dim3((unsigned) ((P + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream, a, d_cand, d_ncand);
+    hipLaunchKernelGGL(k_walk_pieces, dim3((unsigned) ((P + bs - 1) / bs)), dim3(bs), 0, ctx->stream, a, (const uint64_t *) d_cand,
+                       (const uint32_t *) d_ncand, (const uint32_t *) NULL, 0u, (const uint64_t *) NULL, d_pc, d_recs, rcap);
+    dx_prof_end(ctx);
+  }
+  WALK_HIP(hipGetLastError());
+  WALK_HIP(hipMemcpyAsync(pc, d_pc, P * sizeof(walk_piece_d), hipMemcpyDeviceToHost, ctx->stream));
+  WALK_HIP(hipStreamSynchronize(ctx->stream));
+
+  if (getenv("DEXGPU_WALK_DEBUG"))
+    { uint64_t tried = 0, rounds = 0, none = 0; uint32_t mx = 0;
+      for (uint64_t k = 0; k < P; k++) { tried += pc[k].tried; rounds += pc[k].steps_k; none += (pc[k].flags & WP_NONE) != 0; if (pc[k].steps_k > mx) mx = pc[k].steps_k; }
+      { uint64_t *hc = (uint64_t *) malloc(P * WALK_CAND * 8); int shown = 0;
+        if (hc && hipMemcpy(hc, d_cand, P * WALK_CAND * 8, hipMemcpyDeviceToHost) == hipSuccess)
+          for (uint64_t k = 0; k < P && shown < 12; k++)
+            if (pc[k].steps_k > 12) { fprintf(stderr, "[walk] piece %llu (from %llu): tried %u, guesses %llu %llu %llu %llu, took %llu, %u k rounds\n", (unsigned long long) k, (unsigned long long) (first + k * a.piece), pc[k].tried,
+                                       (unsigned long long) hc[4*k], (unsigned long long) hc[4*k+1], (unsigned long long) hc[4*k+2], (unsigned long long) hc[4*k+3], (unsigned long long) pc[k].start, pc[k].steps_k); shown++; }
+        free(hc);
+      }
+      fprintf(stderr, "[walk] %llu pieces: %llu guesses did not hold, %llu pieces without a start, %llu k loop rounds in all, %u k the most of a lane\n",
+              (unsigned long long) P, (unsigned long long) tried, (unsigned long long) none, (unsigned long long) rounds, mx);
+    }
+  // the chain, from the first record on
+  { uint64_t pos = first, k = 0;
+    int rounds = 0;
+    while (pos < n)
+      { // A header may begin with bytes of 255 (255 wells each) -- and so may the bytes in FRONT of a header end in some: the lane
+        // of a piece takes the first start that walks, which is then the true one less a few 255s.  Same records, but for the first
+        // one's first bytes: they are taken off again (trim), no second walk.
+        trim[k] = 0;
+        if (!(pc[k].flags & WP_NONE) && pc[k].start < pos && pc[k].count > 0 && pos - pc[k].start <= (uint64_t) pc[k].first_hdr - 13u)
+          { trim[k] = pos - pc[k].start;
+            pc[k].start = pos; pc[k].hdr_sum -= (uint32_t) trim[k]; pc[k].dwell_sum -= 255u * trim[k];
+          }
+        if (pc[k].flags & WP_NONE || pc[k].start != pos)      // the chain arrives elsewhere than this piece's lane started: once more, from here
+          { if (getenv("DEXGPU_WALK_DEBUG")) fprintf(stderr, "[walk] piece %llu: chain arrives at %llu, lane started at %llu (flags %u, %u records, end %llu)\n", (unsigned long long) k, (unsigned long long) pos, (unsigned long long) pc[k].start, pc[k].flags, pc[k].count, (unsigned long long) pc[k].end);
+            if (++rounds > WALK_ROUNDS) WALK_FAIL(DX_E_MISMATCH, "dx_qv_walk_device: the pieces' walks do not chain up");
+            if (d_start == NULL) { WALK_HIP(hipMalloc(&d_start, P * 8)); WALK_HIP(hipMalloc(&d_todo, 4)); }
+            const uint32_t kk = (uint32_t) k;
+            WALK_HIP(hipMemcpyAsync(d_start + k, &pos, 8, hipMemcpyHostToDevice, ctx->stream));
+            WALK_HIP(hipMemcpyAsync(d_todo, &kk, 4, hipMemcpyHostToDevice, ctx->stream));
+            dx_prof_begin(ctx, DX_K_QV_WALK);
+            hipLaunchKernelGGL(k_walk_pieces, dim3(1), dim3(64), 0, ctx->stream, a, (const uint64_t *) d_cand, (const uint32_t *) d_ncand,
+                               (const uint32_t *) d_todo, 1u, (const uint64_t *) d_start, d_pc, d_recs, rcap);
+            dx_prof_end(ctx);
+            WALK_HIP(hipGetLastError());
+            WALK_HIP(hipMemcpyAsync(pc + k, d_pc + k, sizeof(walk_piece_d), hipMemcpyDeviceToHost, ctx->stream));
+            WALK_HIP(hipStreamSynchronize(ctx->stream));
+          }
+        if (pc[k].flags & (WP_BAD | WP_OVERFLOW))
+          WALK_FAIL(DX_E_MISMATCH, (pc[k].flags & WP_BAD) ? "dx_qv_walk_device: a record does not walk (damaged stream?)"
+                                                          : "dx_qv_walk_device: more records in a piece than its scratch holds");
+        onchain[k] = 1;
+        N  += pc[k].count;
+        pos = pc[k].end;
+        if (pos >= n) break;
+        { const uint64_t k2 = (pos - first) / a.piece;
+          if (k2 <= k || k2 >= P) WALK_FAIL(DX_E_MISMATCH, "dx_qv_walk_device: a walk ended inside its own piece");
+          k = k2;
+        }
+      }
+    if (pos != n && n > first) WALK_FAIL(DX_E_MISMATCH, "dx_qv_walk_device: the last record ends behind the stream");
+  }
+
+  // side by side
+  { uint64_t at = 0, hb = 0, wb = 0;
+    for (uint64_t k = 0; k < P; k++)
+      { dst[k] = onchain[k] ? at : ~0ull; dst[P + k] = hb; dst[2 * P + k] = wb;
+        if (onchain[k]) { at += pc[k].count; hb += pc[k].hdr_sum; wb += pc[k].dwell_sum; }
+      }
+    WALK_HIP(hipMalloc(&d_dst, 4 * P * 8));
+    WALK_HIP(hipMemcpyAsync(d_dst, dst, 4 * P * 8, hipMemcpyHostToDevice, ctx->stream));
+    WALK_HIP(hipMalloc(&out->d_rec_off, (N + 1) * 8));
+    WALK_HIP(hipMalloc(&out->d_hdr_off, (N + 1) * 8));
+    WALK_HIP(hipMalloc(&out->d_seg, (N + 1) * 20));
+    WALK_HIP(hipMalloc(&out->d_len, (N + 1) * 4));
+    WALK_HIP(hipMalloc(&out->d_hdr4, (N + 1) * 16));
+    dx_prof_begin(ctx, DX_K_QV_WALK);
+    hipLaunchKernelGGL(k_walk_gather, dim3((unsigned) ((P + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream,
+                       P, (const walk_piece_d *) d_pc, (const walk_rec_d *) d_recs, rcap, (const uint64_t *) d_dst,
+                       (const uint64_t *) (d_dst + P), (const uint64_t *) (d_dst + 2 * P), (const uint64_t *) (d_dst + 3 * P),
+                       out->d_rec_off, out->d_hdr_off, out->d_seg, out->d_len, out->d_hdr4);
+    dx_prof_end(ctx);
+    WALK_HIP(hipGetLastError());
+    const uint64_t ends[2] = { n, hb };
+    WALK_HIP(hipMemcpyAsync(out->d_rec_off + N, &ends[0], 8, hipMemcpyHostToDevice, ctx->stream));
+    WALK_HIP(hipMemcpyAsync(out->d_hdr_off + N, &ends[1], 8, hipMemcpyHostToDevice, ctx->stream));
+    WALK_HIP(hipStreamSynchronize(ctx->stream));
+    out->n = N; out->pieces = P; out->piece_bytes = a.piece;
+  }
+  rc = DX_OK;
+done:
+  (void) hipFree(d_blob); (void) hipFree(d_tail); (void) hipFree(d_cand); (void) hipFree(d_ncand); (void) hipFree(d_pc); (void) hipFree(d_recs);
+  (void) hipFree(d_start); (void) hipFree(d_todo); (void) hipFree(d_dst);
+  free(blob); free(pc); free(start); free(dst); free(todo); free(onchain);
+  if (rc != DX_OK) dx_qv_dindex_free(ctx, out);
+  return rc;
+#undef WALK_HIP
+#undef WALK_FAIL
+}

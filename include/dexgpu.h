@@ -72,6 +72,7 @@ enum { DX_K_PACK2_ENC = 0, DX_K_PACK2_DEC, DX_K_QV_PRESCAN, DX_K_QV_HIST, DX_K_Q
        DX_K_QV_ENCODE, DX_K_QV_DECODE, DX_K_SYNTH, DX_K_INDEX, DX_K_QV_COMPACT,
        DX_K_QV_ENCODE_TEXT,                       /* the encoder that reads the text (two-pass path; entries without usable tokens) */
        DX_K_QV_DEC_SUB, DX_K_QV_DEC_RUNS, DX_K_QV_DEC_PLAIN, DX_K_QV_DEC_TAGS,   /* DX_K_QV_DECODE: the generic lane-per-line decoder */
+       DX_K_QV_WALK,                              /* the record walk of a bare stream (dx_qv_walk_device) */
        DX_K_COUNT };
 int         dx_profile(dx_ctx *ctx, int enable);                  /* enabling resets the counters */
 int         dx_profile_get(dx_ctx *ctx, int kernel, double *ms_total, uint64_t *launches);  /* syncs */
@@ -375,6 +376,28 @@ int  dx_qv_use_index(dx_ctx *ctx, const uint8_t *d_in, const uint32_t *d_seg, ui
                      const uint32_t *d_gidx, const uint64_t *d_gidx_off, uint64_t none);
 void dx_qv_index_free(dx_qv_index *idx);
 
+/* The same walk on the device, for a record stream already there (undexqv.c:119-208, QV.c:1428-1481): d_img[0, n) is the
+ * file image, `first` the offset of its first record (behind the 0x55aa key and the coding, which the caller has read on
+ * the host: dx_qv_read_coding), cd that coding, newv / flip as dx_qv_index has them.  The stream is cut into pieces of
+ * 32 KiB (more of a stream beyond 16 GB); a lane per piece finds a record start in its piece, checks it by walking, and walks on to the next piece's
+ * start; only offsets on an unbroken chain of such walks from the first record are kept, so the index is the host
+ * walk's (csrc/dx_qv_walk.hip).  The arrays are device memory of the library's (dx_qv_dindex_free): what dx_qv_decode
+ * takes, and d_hdr4 (n x 4: well, beg, end, qv) for the header lines.  DX_E_MISMATCH: the walks did not chain up, a record
+ * did not walk, 16-bit framing fields -- the caller then walks on the host (dx_qv_walk), which also names what is wrong
+ * with a damaged file.  No group index (dx_qv_walk_indexed has one).                                                  */
+typedef struct
+  { uint64_t  n;                /* records */
+    uint64_t *d_rec_off;        /* n + 1 */
+    uint64_t *d_hdr_off;        /* n + 1 */
+    uint32_t *d_seg;            /* n x 5 */
+    uint32_t *d_len;            /* n */
+    int32_t  *d_hdr4;           /* n x 4 */
+    uint64_t  pieces, piece_bytes;      /* how the stream was cut (for logs) */
+  } dx_qv_dindex;
+int  dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t first, const dx_qv_coding *cd, int newv, int flip,
+                       dx_qv_dindex *out);
+void dx_qv_dindex_free(dx_ctx *ctx, dx_qv_dindex *x);
+
 /* Group index (on = 1): dx_qv_encode_onepass also leaves, in the context, where the codes are: one byte per group of
  * 16 symbols of each plain line (the group's code bits), one word per group of <= 8 (run, symbol) tokens of each
  * run-coded line (bits and positions covered) -- about 4.5 KB per 10 kb entry.  A dx_qv_decode of that record stream
@@ -430,6 +453,10 @@ int  dx_file_undexqv(dx_ctx *ctx, const uint8_t *img, size_t n, int upper,
  * (dx_d2h_stream).  img must stay valid until the run is over.                                           */
 typedef struct dx_undexqv_plan dx_undexqv_plan;
 int  dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len);
+/* The plan with the GPU at hand: a large 0x55aa-keyed image is uploaded and its records are walked on the device
+ * (dx_qv_walk_device), anything else -- and anything the device walk turns down -- is planned on the host as above.  Such a
+ * plan holds device memory of ctx until it is freed, and runs on ctx only.  dx_file_undexqv plans this way.            */
+int  dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len);
 int  dx_file_undexqv_run (dx_ctx *ctx, const dx_undexqv_plan *plan, int upper, dx_sink_fn sink, void *user);
 void dx_file_undexqv_plan_free(dx_undexqv_plan *plan);
 void dx_file_free(void *p);

@@ -1,0 +1,152 @@
+"""The record walk of a bare .dexqv on the device (dx_qv_walk_device, csrc/dx_qv_walk.hip) against the host walk
+(dx_qv_walk, dx_host.c) and the oracle's undexqv: undexqv.c:119-208, QV.c:1428-1481.  The device walk keeps only offsets on an
+unbroken chain of lane walks from the first record, so its index must be the host's word for word -- on many pieces and few,
+records shorter and longer than a piece, headers with leading 255s, empty entries, every table kind."""
+import numpy as np
+import pytest
+
+import _oracle as O
+from dextractor_amd import _lib as L
+from dextractor_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    with api.Context(0) as c:
+        yield c
+
+
+def _walk_both(ctx, img):
+    """-> (host index, device index as numpy, DeviceIndex info)"""
+    h = api.qv_walk(img)
+    coding, flip, prefix, used = api.qv_read_coding(img[2:])
+    d = ctx.to_device(np.frombuffer(img, np.uint8))
+    x = ctx.qv_walk_device(d, len(img), 2 + used, coding, 1, flip)
+    try:
+        return h, x.download(), (x.pieces, x.piece_bytes)
+    finally:
+        x.free()
+        d.free()
+
+
+def _same(h, g):
+    assert g["n"] == h["n"]
+    for k in ("rec_off", "hdr_off", "seg", "len", "hdr4"):
+        assert g[k].shape == h[k].shape and (g[k] == h[k]).all(), k
+
+
+@pytest.mark.parametrize("n,mean,piece", [(1500, 4000, 16384), (400, 300, 4096), (3000, 300, 32768), (60, 9000, 8192), (2500, 2000, 0)])
+def test_device_walk_is_the_host_walk(ctx, monkeypatch, n, mean, piece):
+    """Many pieces per file (DEXGPU_WALK_PIECE: tests only; 0 = the product's 32 KiB), records shorter and longer than a piece."""
+    if piece:
+        monkeypatch.setenv("DEXGPU_WALK_PIECE", str(piece))
+    c = synth.make_quiva(n, seed=100 + n, mean=mean)
+    img = ctx.dexqv(c.text)
+    assert img == O.dexqv(c.text)
+    h, g, (pieces, pb) = _walk_both(ctx, img)
+    assert pieces >= 2 and pieces == (len(img) - int(h["rec_off"][0]) + pb - 1) // pb
+    _same(h, g)
+
+
+def test_device_walk_empty_entries_lossy_and_long_runs(ctx, monkeypatch):
+    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    lens = np.array([0, 1, 2, 15, 16, 17, 0, 0, 1023, 1024, 1025, 5000, 0, 3, 70000, 2, 0], np.uint32)
+    cases = [(synth.make_quiva(len(lens), seed=7, lens=lens).text, False),
+             (synth.make_quiva(200, seed=8, mean=3000).text, True),
+             (synth.make_quiva(30, seed=9, mean=9000, prof=synth.pacbio_profile(del_run_p=0.999, sub_run_p=0.97)).text, False),   # runs of 255 and more: literals
+             (synth.make_quiva(40, seed=10, mean=6000, prof=synth.pacbio_profile(del_run_p=0.3, sub_run_p=0.3)).text, False)]
+    for text, lossy in cases:
+        img = ctx.dexqv(text, lossy)
+        assert img == O.dexqv(text, lossy)
+        h, g, _ = _walk_both(ctx, img)
+        _same(h, g)
+
+
+def test_device_walk_wells_that_jump(ctx, monkeypatch):
+    """Framing bytes of 255 (255 wells each, undexqv.c:124-133) in front of a header -- and bytes of 255 at the end of the record
+    before it, which make a start one byte early walk just as well: the chain takes them off again (trim)."""
+    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    c = synth.make_quiva(600, seed=31, mean=1500)
+    hdr = c.hdr.copy()
+    hdr[:, 0] = np.cumsum(np.where(np.arange(len(hdr)) % 7 == 3, 700 + 255 * (np.arange(len(hdr)) % 5), 1))     # wells that jump by 255 k + j
+    text = b"".join(synth.header_text("quiva", "m000_000", hdr[i], False) + c.text[int(c.off[i]): int(c.off[i]) + 5 * (int(c.len[i]) + 1)]
+                    for i in range(len(hdr)))
+    img = ctx.dexqv(text)
+    assert img == O.dexqv(text)
+    h, g, _ = _walk_both(ctx, img)
+    _same(h, g)
+    assert (np.diff(h["hdr_off"]).astype(np.int64) > 13).sum() > 50        # (headers with leading 255s are in it)
+
+
+def test_undexqv_plans_on_the_device(ctx, monkeypatch):
+    """dx_file_undexqv with the device walk (DEXGPU_DEVICE_WALK_MIN=0: whatever the size; the product asks for 256 MB): the
+    oracle's text; the walk kernels ran; DEXGPU_HOST_WALK=1 takes it back to the host."""
+    monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")
+    monkeypatch.setenv("DEXGPU_WALK_PIECE", "8192")
+    for text, upper in ((synth.make_quiva(300, seed=41, mean=2500).text, True), (synth.make_quiva(50, seed=42, mean=12000).text, False)):
+        img = O.dexqv(text)
+        want = O.undexqv(img, upper=upper)
+        ctx.profile(True)
+        assert ctx.undexqv(img, upper=upper) == want
+        assert "k_qv_walk" in ctx.kernel_times()
+        ctx.profile(False)
+    monkeypatch.setenv("DEXGPU_HOST_WALK", "1")
+    ctx.profile(True)
+    assert ctx.undexqv(img, upper=False) == O.undexqv(img)
+    assert "k_qv_walk" not in ctx.kernel_times()
+    ctx.profile(False)
+
+
+def test_what_the_device_walk_turns_down_goes_to_the_host(ctx, monkeypatch):
+    """A stream cut short, or bytes damaged in the middle: DX_E_MISMATCH from the device walk; the file driver then walks on the
+    host and reports what the host walk reports.  Records much longer than the guesses' budget (two pieces): the chain is
+    walked piece by piece from where it arrives -- same index -- or given up after a few dozen rounds -- same text."""
+    monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")
+    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    c = synth.make_quiva(120, seed=51, mean=3000)
+    img = O.dexqv(c.text)
+    coding, flip, prefix, used = api.qv_read_coding(img[2:])
+    cut = img[: len(img) - 1000]
+    d = ctx.to_device(np.frombuffer(cut, np.uint8))
+    with pytest.raises(L.DexGPUError) as e:
+        ctx.qv_walk_device(d, len(cut), 2 + used, coding, 1, flip)
+    assert e.value.code == -7                                                # DX_E_MISMATCH
+    d.free()
+    with pytest.raises(L.DexGPUError) as e:
+        ctx.undexqv(cut)
+    assert e.value.code == -3                                                # DX_E_FORMAT, the host walk's
+    big = synth.make_quiva(6, seed=52, mean=40000)                           # records of ~55 KB, pieces of 4 KB
+    img = O.dexqv(big.text)
+    assert ctx.undexqv(img) == O.undexqv(img)
+
+
+def test_device_walk_of_a_byte_swapped_file(ctx, monkeypatch):
+    """A file written on a host of the other endianness (GETFLIP, QV.c:553-568): code words and framing fields byte-swapped."""
+    import struct
+    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    c = synth.make_quiva(150, seed=61, mean=2000)
+    img = O.dexqv(c.text)
+    h = api.qv_walk(img)
+    coding, flip, prefix, used = api.qv_read_coding(img[2:])
+    first = 2 + used
+    # swap the stream: every framing field and every code word; the tags are bytes.  (The coding in front stays as it is: the
+    # device walk is told `flip` by its caller, who has read the coding.)
+    out = bytearray(img[:first])
+    for i in range(int(h["n"])):
+        at = int(h["rec_off"][i]); hb = int(h["hdr_off"][i + 1] - h["hdr_off"][i]); seg = [int(x) for x in h["seg"][i]]
+        out += img[at: at + hb - 12]
+        out += b"".join(struct.pack(">i", v) for v in struct.unpack("<iii", img[at + hb - 12: at + hb]))
+        p = at + hb
+        for k, sb in enumerate(seg):
+            chunk = img[p: p + sb]
+            out += chunk if k == 1 else np.frombuffer(chunk, "<u4").astype(">u4").tobytes()
+            p += sb
+    sw = bytes(out)
+    assert len(sw) == len(img)
+    d = ctx.to_device(np.frombuffer(sw, np.uint8))
+    x = ctx.qv_walk_device(d, len(sw), first, coding, 1, 1)
+    g = x.download()
+    x.free(); d.free()
+    _same({k: h[k] for k in ("n", "rec_off", "hdr_off", "seg", "len", "hdr4")}, g)

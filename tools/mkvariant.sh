@@ -8,7 +8,7 @@ files=${@:-dx_qv}
 make lib > /dev/null
 mkdir -p build_var/$name tools/variants
 objs=""
-for o in dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth dx_index; do
+for o in dx_ctx dx_pack2 dx_qv dx_qv_decode dx_synth dx_index dx_qv_walk; do
   if [[ " $files " == *" $o "* ]]; then
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Idextractor_amd/csrc -Wall -Wno-unused-function $extra \
         -Rpass-analysis=kernel-resource-usage -c dextractor_amd/csrc/$o.hip -o build_var/$name/$o.o 2> build_var/$name/$o.res || { grep -v "remark" build_var/$name/$o.res | head -20; exit 1; }
