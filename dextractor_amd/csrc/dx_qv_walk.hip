@@ -6,7 +6,7 @@
 // 32 threads (dx_host.c: walk_parallel; 7.5 s for the 14 GB of records of the 1 M x 10 kb batch); a GPU has no fast single
 // thread, but it has half a million slow ones, and the host walk's idea carries over lane for lane:
 //
-//   * the stream is cut into pieces of 32 KiB (more, beyond 16 GB: at most 512 K pieces); k_walk_find, a wave per piece, notes
+//   * the stream is cut into pieces of 32 KiB or more (as many as the device holds lanes at once: 1536 a CU); k_walk_find, a wave per piece, notes
 //     the first offsets in each piece at which a plausible record header stands (header_plausible, as on the host: 1.4e-8 of
 //     all offsets pass by chance -- and the byte or two in front of every true header, see there);
 //   * k_walk_pieces, ONE LANE per piece, tries those offsets in turn -- a start is taken when the record walks cleanly from
@@ -23,8 +23,8 @@
 // Only offsets on an unbroken chain of walks from the first record are kept: the result is the host walk's by construction
 // (tests/test_gpu_walk.py: word for word, on pieces from 4 KiB up).
 // Roofline: none of the usual ones -- 64 independent chains of dependent look-ups per wave, a third of the instructions
-// scalar (divergent control flow), waves waiting two thirds of their time (SQ_WAIT_ANY) on LDS and load latency: 0.1 s for
-// those 14 GB (150 GB/s), 75 times the host's 32 threads.  profiles/r04_device_walk.txt.
+// scalar (divergent control flow), waves waiting two thirds of their time (SQ_WAIT_ANY) on LDS and load latency: 65 ms for
+// those 14 GB (220 GB/s), a hundred times the host's 32 threads.  profiles/r04_device_walk.txt.
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 #include "dx_walk.h"
@@ -34,6 +34,7 @@
 #ifndef WALK_BLOCK
 #define WALK_BLOCK     768              // two workgroups a CU (80 KB of LDS each): 24 waves, what the registers allow
 #endif
+#define WALK_WGS_PER_CU 2
 #define WALK_CAND      4u
 #ifndef WALK_PIECE_KB
 #define WALK_PIECE_KB 32
@@ -115,13 +116,14 @@ void k_walk_find(walk_args a, uint64_t *cand, uint32_t *ncand)
     }
   // A true header at p makes p - 1 plausible too wherever the quality value is below 3906 and the entry short of 16 k
   // symbols (its fields read one byte early: 256 times the length, 256 times the quality value) -- a guess that costs a
-  // walk of its garbage length, the whole budget.  Of two guesses next to each other the later one goes first: it claims
-  // the shorter record, and if it holds the earlier ones cannot (no record has fewer than 13 bytes).
+  // walk of its garbage length, the whole budget -- and a lane that walks garbage for the length of two pieces holds up the
+  // other 63 of its wave (one guess in eighty was such: half the waves had one).  Of guesses within 16 bytes of each other
+  // the last goes first: if it holds the earlier ones cannot (no record has fewer than 13 bytes).
   if (lane == 0)
     { uint64_t *c = cand + k * WALK_CAND;
-      for (uint32_t i = 0; i < found; )                      // (every run of neighbours back to front: two bytes early happens too)
-        { uint32_t e = i;
-          while (e + 1 < found && c[e + 1] == c[e] + 1) e++;
+      for (uint32_t i = 0; i < found; )                      // (every cluster back to front: two bytes early happens too, and nine --
+        { uint32_t e = i;                                      //  the quality value read from the well byte and a small `beg`)
+          while (e + 1 < found && c[e + 1] - c[e] <= 16u) e++;
           for (uint32_t x = i, y = e; x < y; x++, y--) { const uint64_t t = c[x]; c[x] = c[y]; c[y] = t; }
           i = e + 1;
         }
@@ -151,8 +153,7 @@ struct wrd_d
 };
 
 // 16 bytes of the image at q, zeros behind its end: the image's last bytes come from a padded copy (walk_args.tail), by a select
-// of the address -- no branch, and nothing is done to the bytes here (a byte swap is the taker's business, w_fill_d): whatever
-// touches them waits for them, and they are requested four refills ahead of their use.
+// of the address -- no branch, and nothing is done to the bytes here (a byte swap is the taker's business, w_fill_d).
 __device__ __forceinline__ u32x4 load16_within(const walk_args &a, const uint8_t *q)
 { const uint64_t off = (uint64_t) (q - a.img);
   const uint64_t t   = off - a.tail_at;
@@ -206,6 +207,9 @@ struct walk_lds { uint16_t t[4][4096]; uint16_t r1[2][4096]; uint16_t one[4][409
 #define PH_MRG  3u
 #define PH_SUB  4u
 #define PH_DONE 5u              // behind the record's last segment
+#ifndef WALK_BRANCHY
+#define WALK_BRANCHY 0
+#endif
 #ifndef WALK_BURST
 #define WALK_BURST 24           // look-ups in a row before the lanes that need something else are seen to
 #endif
@@ -268,6 +272,7 @@ void k_walk_pieces(walk_args a, const uint64_t *cand, const uint32_t *ncand, con
         { const uint16_t *tab = S.t[line];
           bool more = true;
           #pragma unroll 1
+#if WALK_BRANCHY
           for (int it = 0; it < WALK_BURST && more; it++)
             { w_fill_d(rd, a);
               const uint32_t g = tab[(uint32_t) (rd.buf >> 52)], cnt = g >> 8;
@@ -278,6 +283,34 @@ void k_walk_pieces(walk_args a, const uint64_t *cand, const uint32_t *ncand, con
                   j += cnt; nn += 1u; last = (g >> 4) & 15u;
                 }
             }
+#else
+          // Without branches but for the 16-byte refills (every sixth look-up or so): selects instead -- a lane the
+          // burst has left behind shifts by nothing and counts nothing.  With branches a look-up was 28 instructions of which ten
+          // scalar (execution masks) and five branches; the scalar unit is one to a CU.
+          for (int it = 0; it < WALK_BURST; it++)
+            { const bool need = rd.nb <= 32;
+              if (need && (rd.k == 3u || rd.k == 0u))          // (every sixth refill or so: these two stay branches -- a select
+                { if (rd.k == 0u)                              //  would look at nxt, i.e. wait for it, at every look-up)
+                    { rd.cur = rd.nxt; rd.k = 4; }             // the 16 bytes asked for three words ago
+                  else
+                    { rd.nxt = load16_within(a, rd.q);         // the next 16: asked for here, looked at when these are used up
+                      rd.q  += 16;
+                    }
+                }
+              const uint32_t w = bswap_if(rd.cur.x, a.flip);
+              rd.cur.x = need ? rd.cur.y : rd.cur.x; rd.cur.y = need ? rd.cur.z : rd.cur.y; rd.cur.z = need ? rd.cur.w : rd.cur.z;
+              rd.k   -= need ? 1u : 0u;
+              rd.buf |= need ? (uint64_t) w << ((32 - rd.nb) & 63) : 0ull;
+              rd.nb  += need ? 32 : 0;
+              rd.nw  += need ? 1u : 0u;
+              const uint32_t g = tab[(uint32_t) (rd.buf >> 52)], cnt = g >> 8;
+              more = more && g != 0u && j + cnt <= rlen;
+              const uint32_t nbits = more ? g & 15u : 0u;
+              rd.buf <<= nbits; rd.nb -= (int) nbits;
+              j += more ? cnt : 0u; nn += more ? 1u : 0u; last = more ? (g >> 4) & 15u : last;
+              if (!__any(more)) break;
+            }
+#endif
           if (!more)
             { const bool runs = (line == 0 && a.delChar >= 0) || (line == 3 && a.subChar >= 0);
               if (j < rlen)                                     // one step of another kind
@@ -440,7 +473,9 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   walk_args a;
   memset(&a, 0, sizeof(a));
   a.img = d_img; a.n = n; a.first = first; a.delChar = cd->delChar; a.subChar = cd->subChar; a.flip = flip;
-  { uint64_t piece = (n - first + WALK_LANES_MAX - 1) / WALK_LANES_MAX;
+  { // no more lanes than the device holds at once (two workgroups a CU): a second round of waves would run beside nothing
+    const uint64_t lanes = (uint64_t) ctx->num_cu * WALK_WGS_PER_CU * WALK_BLOCK < WALK_LANES_MAX ? (uint64_t) ctx->num_cu * WALK_WGS_PER_CU * WALK_BLOCK : WALK_LANES_MAX;
+    uint64_t piece = (n - first + lanes - 1) / lanes;
     if (piece < WALK_PIECE_MIN) piece = WALK_PIECE_MIN;
     if (const char *e = getenv("DEXGPU_WALK_PIECE")) { const uint64_t v = strtoull(e, NULL, 10); if (v >= 4096) piece = v; }   // (tests)
     piece = (piece + 4095u) & ~(uint64_t) 4095u;
