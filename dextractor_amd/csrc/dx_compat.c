@@ -355,3 +355,70 @@ void Free_QVcoding(QVcoding *coding)                /* QV.c:1324-1334: the auxil
   drop_results();
   free(Lens); Lens = NULL; free(Sums); Sums = NULL; LensCap = 0; Nent = 0;
 }
+
+/* ==========================================================================================
+ *  DB.h:257-267: the per-read helpers, one in-memory string at a time
+ * ==========================================================================================
+ * Compress_Read / Uncompress_Read / Lower_Read / Upper_Read / Number_Read / Letter_Arrow / Number_Arrow under their own
+ * names, over the 2-bit kernels (dx_pack2_encode / dx_pack2_decode with no framing; the alphabets DX_ALPHA_NUMBERS and
+ * DX_LETTERS_NUMBERS exist for these: a string that is already numbers, numbers wanted back).  Every call is a round trip to
+ * the GPU for ONE read -- a caller with many reads wants the batch calls --, but a program written against
+ * DB.h links and gets the reference's bytes.  A letters-to-letters call is two kernels (pack, unpack).  Not what the
+ * reference does: bytes of '\n' inside a string given to Number_Read / Number_Arrow (the packer drops line ends; the
+ * reference maps them to 0 / 3): such a call dies.  Print_Read and Change_Read are host formatting, not provided.       */
+static void  *RdDev[6];                   /* text, its three index words, packed, its offsets, letters out, their offsets */
+static size_t RdCap = 0;
+
+static void read_room(const char *who, size_t len)
+{ int k;
+  open_gpu(who);
+  if (len + 64 <= RdCap) return;
+  for (k = 0; k < 6; k++) if (RdDev[k]) { dx_free(Ctx, RdDev[k]); RdDev[k] = NULL; }
+  RdCap = 2 * len + 4096;
+  if (dx_malloc(Ctx, RdCap, &RdDev[0]) != DX_OK || dx_malloc(Ctx, 64, &RdDev[1]) != DX_OK ||
+      dx_malloc(Ctx, RdCap / 4 + 64, &RdDev[2]) != DX_OK || dx_malloc(Ctx, 64, &RdDev[3]) != DX_OK ||
+      dx_malloc(Ctx, RdCap + 64, &RdDev[4]) != DX_OK || dx_malloc(Ctx, 64, &RdDev[5]) != DX_OK)
+    die("out of device memory (a read)");
+}
+
+/* s[0, len) through the packer (alpha >= 0: s holds text / numbers; < 0: s holds the packed bytes already) and, letters >= 0,
+   back through the unpacker; the result into s (packed bytes when letters < 0)                                         */
+static void read_through(const char *who, char *s, size_t len, int alpha, int letters)
+{ const size_t clen = (len + 3) >> 2;
+  uint64_t off[2], coff[2], toff[2];
+  uint32_t idx[2];
+  if (len == 0) return;
+  if (len >= (1u << 31)) die("a read of 2^31 symbols and more");
+  read_room(who, len);
+  off[0] = 0; off[1] = len; coff[0] = 0; coff[1] = clen; toff[0] = 0; toff[1] = len + 1;
+  idx[0] = (uint32_t) len; idx[1] = (uint32_t) len;
+  if (dx_h2d(Ctx, RdDev[1], off, 16) != DX_OK || dx_h2d(Ctx, (char *) RdDev[1] + 16, idx, 8) != DX_OK ||
+      dx_h2d(Ctx, RdDev[3], coff, 16) != DX_OK || dx_h2d(Ctx, RdDev[5], toff, 16) != DX_OK)
+    die(dx_last_error(Ctx));
+  if (alpha >= 0)
+    { if (dx_h2d(Ctx, RdDev[0], s, len) != DX_OK ||
+          dx_pack2_encode(Ctx, alpha, RdDev[0], RdDev[1], (const uint32_t *) ((char *) RdDev[1] + 16), (const uint32_t *) ((char *) RdDev[1] + 20), 1,
+                          NULL, NULL, RdDev[2], RdDev[3]) != DX_OK)
+        die(dx_last_error(Ctx));
+    }
+  else if (dx_h2d(Ctx, RdDev[2], s, clen) != DX_OK)
+    die(dx_last_error(Ctx));
+  if (letters < 0)
+    { if (dx_d2h(Ctx, s, RdDev[2], clen) != DX_OK) die(dx_last_error(Ctx));
+      return;
+    }
+  if (dx_pack2_decode(Ctx, letters, RdDev[2], RdDev[3], (const uint32_t *) ((char *) RdDev[1] + 20), 1, (uint32_t) len, RdDev[4], RdDev[5]) != DX_OK ||
+      dx_d2h(Ctx, s, RdDev[4], len) != DX_OK)
+    die(dx_last_error(Ctx));
+}
+
+void Compress_Read(int len, char *s)   { if (len > 0) read_through("Compress_Read", s, (size_t) len, DX_ALPHA_NUMBERS, -1); }            /* DB.c:319-338 */
+void Uncompress_Read(int len, char *s) { if (len > 0) read_through("Uncompress_Read", s, (size_t) len, -1, DX_LETTERS_NUMBERS); s[len > 0 ? len : 0] = 4; }   /* DB.c:342-363 */
+
+static size_t numbers_len(const char *s) { size_t n = 0; while (s[n] != 4) n++; return n; }
+
+void Lower_Read(char *s)   { const size_t n = numbers_len(s); read_through("Lower_Read", s, n, DX_ALPHA_NUMBERS, DX_LETTERS_LOWER); s[n] = '\0'; }     /* DB.c:367 */
+void Upper_Read(char *s)   { const size_t n = numbers_len(s); read_through("Upper_Read", s, n, DX_ALPHA_NUMBERS, DX_LETTERS_UPPER); s[n] = '\0'; }     /* DB.c:375 */
+void Letter_Arrow(char *s) { const size_t n = numbers_len(s); read_through("Letter_Arrow", s, n, DX_ALPHA_NUMBERS, DX_LETTERS_ARROW); s[n] = '\0'; }   /* DB.c:383 */
+void Number_Read(char *s)  { const size_t n = strlen(s); read_through("Number_Read", s, n, DX_ALPHA_BASES, DX_LETTERS_NUMBERS); s[n] = 4; }             /* DB.c:393 */
+void Number_Arrow(char *s) { const size_t n = strlen(s); read_through("Number_Arrow", s, n, DX_ALPHA_ARROW, DX_LETTERS_NUMBERS); s[n] = 4; }            /* DB.c:418 */

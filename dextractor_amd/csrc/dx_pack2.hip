@@ -56,8 +56,10 @@ __device__ __forceinline__ uint32_t sym_code(uint32_t x)
     { uint32_t u = x & 0xdfu;                        // fold case; bytes >= 128 keep bit 7 and miss
       return (u == 'C') ? 1u : (u == 'G') ? 2u : (u == 'T') ? 3u : 0u;
     }
-  else
+  else if (ALPHA == DX_ALPHA_ARROW)
     return (x == '1') ? 0u : (x == '2') ? 1u : (x == '3' || x == 'G') ? 2u : 3u;
+  else
+    return x & 3u;                                   // DX_ALPHA_NUMBERS
 }
 
 #define BYTE_AT(c, b) ((chunk_word(c, (b) >> 2) >> (8 * ((b) & 3))) & 0xffu)
@@ -196,7 +198,8 @@ template <int LETTERS>
 __device__ __forceinline__ uint32_t sym_letter(uint32_t code)
 { if (LETTERS == DX_LETTERS_LOWER) return (0x74676361u >> (8 * code)) & 0xffu;       // "acgt"
   if (LETTERS == DX_LETTERS_UPPER) return (0x54474341u >> (8 * code)) & 0xffu;       // "ACGT"
-  return '1' + code;
+  if (LETTERS == DX_LETTERS_ARROW) return '1' + code;
+  return code;                                       // DX_LETTERS_NUMBERS
 }
 
 // 16 text bytes of the generic case: any width, chunks at the end of the text
@@ -434,7 +437,7 @@ extern "C" int dx_pack2_encode(dx_ctx *ctx, int alphabet,
                                const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                                uint8_t *d_out, const uint64_t *d_out_off)
 { if (ctx == NULL) return DX_E_ARG;
-  if (alphabet != DX_ALPHA_BASES && alphabet != DX_ALPHA_ARROW)
+  if (alphabet != DX_ALPHA_BASES && alphabet != DX_ALPHA_ARROW && alphabet != DX_ALPHA_NUMBERS)
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: unknown alphabet %d", alphabet);
   if ((d_hdr == NULL) != (d_hdr_off == NULL))
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_encode: d_hdr and d_hdr_off must be given together");
@@ -453,8 +456,11 @@ extern "C" int dx_pack2_encode(dx_ctx *ctx, int alphabet,
   if (alphabet == DX_ALPHA_BASES)
     DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_BASES>, grid, DX_BLOCK,
               d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status, d_ticket);
-  else
+  else if (alphabet == DX_ALPHA_ARROW)
     DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_ARROW>, grid, DX_BLOCK,
+              d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status, d_ticket);
+  else
+    DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_NUMBERS>, grid, DX_BLOCK,
               d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status, d_ticket);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -468,7 +474,7 @@ extern "C" int dx_pack2_decode(dx_ctx *ctx, int letters,
                                const uint8_t *d_in, const uint64_t *d_in_off, const uint32_t *d_nsym,
                                uint64_t n, uint32_t width, uint8_t *d_out, const uint64_t *d_out_off)
 { if (ctx == NULL) return DX_E_ARG;
-  if (letters < DX_LETTERS_LOWER || letters > DX_LETTERS_ARROW)
+  if (letters < DX_LETTERS_LOWER || letters > DX_LETTERS_NUMBERS)
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: unknown letter set %d", letters);
   if (width == 0)
     return dx_fail(ctx, DX_E_ARG, "dx_pack2_decode: line width must be >= 1 "
@@ -493,8 +499,12 @@ extern "C" int dx_pack2_decode(dx_ctx *ctx, int letters,
         DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_UPPER>, grid, DX_BLOCK,
                   d_in, d_in_off, d_nsym, n, width, d_out, d_out_off, d_ticket);
         break;
-      default:
+      case DX_LETTERS_ARROW:
         DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_ARROW>, grid, DX_BLOCK,
+                  d_in, d_in_off, d_nsym, n, width, d_out, d_out_off, d_ticket);
+        break;
+      default:
+        DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_NUMBERS>, grid, DX_BLOCK,
                   d_in, d_in_off, d_nsym, n, width, d_out, d_out_off, d_ticket);
         break;
     }

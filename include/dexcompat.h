@@ -67,6 +67,19 @@ void      Free_QVcoding(QVcoding *coding);                                      
 QVcoding *Read_QVcoding(FILE *input);                                                        /* QV.c:1214-1320 */
 int       Uncompress_Next_QVentry(FILE *input, char **entry, QVcoding *coding, int rlen);    /* QV.c:1428-1481 */
 
+/* DB.h:257-267, the per-read helpers: one in-memory string at a time through the 2-bit kernels (a GPU round trip per call: a
+ * caller with many reads wants dx_pack2_encode / dx_pack2_decode on a batch; these are for programs written against DB.h).
+ * Same results as the reference's for strings of its own alphabets; a '\n' inside a string given to Number_Read / Number_Arrow
+ * dies (the packer drops line ends).  Print_Read and Change_Read (formatting) are not provided.                        */
+#define COMPRESSED_LEN(len)  (((len)+3) >> 2)
+void   Compress_Read(int len, char *s);   /* DB.c:319-338: numbers 0..3 -> 2-bit form, in place */
+void Uncompress_Read(int len, char *s);   /* DB.c:342-363: 2-bit form -> numbers, s[len] = 4 */
+void Lower_Read(char *s);                 /* DB.c:367: numbers (terminated by 4) -> acgt */
+void Upper_Read(char *s);                 /* DB.c:375: -> ACGT */
+void Number_Read(char *s);                /* DB.c:393: letters -> numbers, terminated by 4 */
+void Letter_Arrow(char *s);               /* DB.c:383: numbers -> 1234 */
+void Number_Arrow(char *s);               /* DB.c:418: 1234 -> numbers */
+
 #ifdef __cplusplus
 }
 #endif

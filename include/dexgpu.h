@@ -82,10 +82,12 @@ const char *dx_kernel_name(int kernel);
  *  2-bit packers: dexta/undexta, dexar/undexar
  * ------------------------------------------------------------------------------------------ */
 enum { DX_ALPHA_BASES = 0,    /* Number_Read  DB.c:393: c/C->1 g/G->2 t/T->3, everything else 0   */
-       DX_ALPHA_ARROW = 1 };  /* Number_Arrow DB.c:418: '1'->0 '2'->1 '3','G'->2, everything else 3 */
+       DX_ALPHA_ARROW = 1,    /* Number_Arrow DB.c:418: '1'->0 '2'->1 '3','G'->2, everything else 3 */
+       DX_ALPHA_NUMBERS = 2 };/* already numbers 0..3 (what Compress_Read DB.c:319 takes): the low two bits */
 enum { DX_LETTERS_LOWER = 0,  /* Lower_Read  DB.c:367 acgt */
        DX_LETTERS_UPPER = 1,  /* Upper_Read  DB.c:375 ACGT */
-       DX_LETTERS_ARROW = 2 };/* Letter_Arrow DB.c:383 1234 */
+       DX_LETTERS_ARROW = 2,  /* Letter_Arrow DB.c:383 1234 */
+       DX_LETTERS_NUMBERS = 3 };/* the numbers 0..3 themselves (what Uncompress_Read DB.c:342 leaves) */
 
 /* Replaces, for n reads at once: the line-gathering loop dexta.c:161-183 (newlines are skipped on
  * the device), Number_Read/Number_Arrow (DB.c:393-441), Compress_Read (DB.c:319-338) and the

@@ -1622,3 +1622,48 @@ def test_old_name_decode_shims_like_undexqv(ctx, tmp_path):
         lib.Free_QVcoding(coding)
         libc.fclose(f)
         assert b"".join(out) == want
+
+
+def test_per_read_helpers_of_db_h(ctx):
+    """DB.h:257-267 under their own names (include/dexcompat.h), one in-memory string a call, over the 2-bit kernels with
+    the alphabets DX_ALPHA_NUMBERS / DX_LETTERS_NUMBERS: Number_Read / Compress_Read / Uncompress_Read / Lower_Read /
+    Upper_Read as DB.c:319-416 defines them (every byte value as a letter: the maps of Number_Read, bytes >= 128 -> 0 as in
+    test_pack2_arbitrary_bytes; line ends excepted: the packer drops them), Number_Arrow / Letter_Arrow :383, 418-441."""
+    lib = L.load()
+    rng = np.random.default_rng(77)
+    base = np.zeros(256, np.uint8)
+    for ch, v in ((b"cC", 1), (b"gG", 2), (b"tT", 3)):
+        for c in ch: base[c] = v
+    arrow = np.full(256, 3, np.uint8); arrow[ord("1")] = 0; arrow[ord("2")] = 1; arrow[ord("3")] = 2; arrow[ord("G")] = 2
+    for n in [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 63, 64, 65, 1000, 1023, 1024, 1025, 9999, 70001]:
+        letters = rng.integers(1, 256, n, dtype=np.uint8)
+        letters[letters == 10] = ord("a")                               # (no line ends inside a read's string)
+        want = base[letters]
+        buf = C.create_string_buffer(letters.tobytes() + b"\0", n + 8)
+        lib.Number_Read(buf)
+        got = np.frombuffer(buf.raw[: n + 1], np.uint8)
+        assert (got[:n] == want).all() and got[n] == 4
+        lib.Compress_Read(n, buf)
+        clen = (n + 3) >> 2
+        pad = np.concatenate([want, np.zeros(4 * clen - n, np.uint8)]).reshape(-1, 4)
+        packed = (pad[:, 0] << 6) | (pad[:, 1] << 4) | (pad[:, 2] << 2) | pad[:, 3]
+        assert (np.frombuffer(buf.raw[:clen], np.uint8) == packed).all()
+        lib.Uncompress_Read(n, buf)
+        got = np.frombuffer(buf.raw[: n + 1], np.uint8)
+        assert (got[:n] == want).all() and got[n] == 4
+        lib.Upper_Read(buf)
+        assert buf.raw[: n + 1] == bytes(b"ACGT"[v] for v in want) + b"\0"
+        lib.Number_Read(buf); lib.Lower_Read(buf)
+        assert buf.raw[: n + 1] == bytes(b"acgt"[v] for v in want) + b"\0"
+        al = letters.copy(); al[al == 0] = ord("4")
+        buf = C.create_string_buffer(al.tobytes() + b"\0", n + 8)
+        lib.Number_Arrow(buf)
+        got = np.frombuffer(buf.raw[: n + 1], np.uint8)
+        assert (got[:n] == arrow[al]).all() and got[n] == 4
+        lib.Letter_Arrow(buf)
+        assert buf.raw[: n + 1] == bytes(b"1234"[v] for v in arrow[al]) + b"\0"
+    empty = C.create_string_buffer(b"\0", 8)
+    lib.Number_Read(empty)
+    assert empty.raw[0] == 4
+    lib.Lower_Read(empty)
+    assert empty.raw[0] == 0

@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     old_names = set(re.findall(r"\b([A-Z][A-Za-z]*_[A-Za-z_]*[a-z]1?|QVentry)\s*\(", compat))
     assert old_names == {"QVcoding_Scan1", "Create_QVcoding", "Write_QVcoding", "Compress_Next_QVentry1", "Free_QVcoding",
                          "Read_QVcoding", "Uncompress_Next_QVentry",
-                         "QVcoding_Scan", "Compress_Next_QVentry", "Read_Lines", "QVentry", "Set_QV_Line", "Get_QV_Line"}, old_names
+                         "QVcoding_Scan", "Compress_Next_QVentry", "Read_Lines", "QVentry", "Set_QV_Line", "Get_QV_Line",
+                         "Compress_Read", "Uncompress_Read", "Lower_Read", "Upper_Read", "Number_Read", "Letter_Arrow", "Number_Arrow"}, old_names
     for name in old_names:
         assert hasattr(lib, name), f"{name} declared in dexcompat.h but not exported"
 
