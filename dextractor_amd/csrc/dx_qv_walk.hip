@@ -23,8 +23,8 @@
 // Only offsets on an unbroken chain of walks from the first record are kept: the result is the host walk's by construction
 // (tests/test_gpu_walk.py: word for word, on pieces from 4 KiB up).
 // Roofline: none of the usual ones -- 64 independent chains of dependent look-ups per wave, a third of the instructions
-// scalar (divergent control flow), waves waiting two thirds of their time (SQ_WAIT_ANY) on LDS and load latency: 65 ms for
-// those 14 GB (220 GB/s), a hundred times the host's 32 threads.  profiles/r04_device_walk.txt.
+// scalar (divergent control flow), waves waiting two thirds of their time (SQ_WAIT_ANY) on LDS and load latency: 53 ms for
+// those 14 GB (270 GB/s), a hundred times the host's 32 threads.  profiles/r04_device_walk.txt.
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 #include "dx_walk.h"
@@ -59,7 +59,7 @@ struct walk_args
 };
 
 struct walk_rec_d   { uint64_t off; uint32_t hdr_bytes, len, seg[5]; int32_t dwell, beg, end, qv; uint32_t pad; };
-struct walk_piece_d { uint64_t start, end, dwell_sum; uint32_t count, flags, hdr_sum, first_hdr /* framing bytes of the first record */; uint32_t tried /* guesses that did not hold */, steps_k /* thousands of loop rounds (logs) */; };
+struct walk_piece_d { uint64_t start, end, dwell_sum; uint32_t count, flags, hdr_sum, first_hdr /* framing bytes of the first record */; uint32_t tried /* guesses that did not hold */, lead255 /* bytes of 255 right in front of start (up to 4096) */; };
 
 __device__ __forceinline__ uint32_t bswap_if(uint32_t v, int flip) { return flip ? __builtin_bswap32(v) : v; }
 
@@ -78,8 +78,24 @@ __device__ __forceinline__ bool header_plausible_d(const walk_args &a, uint64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-//  k_walk_find: the first WALK_CAND plausible offsets of every piece (a wave per piece, 64 offsets a time)
+//  k_walk_find: the first plausible offsets of every piece (a wave per piece, 256 offsets a round)
 // ---------------------------------------------------------------------------------------------
+// An offset whose byte is 255 is never a guess: a header may begin with bytes of 255 (255 wells each, undexqv.c:124-133), but
+// then the offset behind them reads as a header too (fewer wells) and walks the same -- that one is the guess, k_walk_pieces
+// notes how many bytes of 255 stand in front of the start it took, and the chain, which knows where the record before ended,
+// gives them back to the header (a negative trim).  So every test is the thirteen bytes of one 16-byte load.
+// The scan stops behind the FIRST cluster of guesses (guesses within 16 bytes of each other: a true header and the offsets
+// one, two and nine bytes in front of it, whose fields read plausibly as well; WALK_CAND of them at most): half a record's
+// bytes on average.  Should none of them hold (one piece in ten thousand: a chance hit in front of the first header), the
+// piece's lane looks for the next cluster itself (k_walk_pieces).
+__device__ __forceinline__ bool header_fast_d(const walk_args &a, uint64_t p, const u32x4 &v)
+{ const int32_t beg  = (int32_t) bswap_if((v.x >> 8) | (v.y << 24), a.flip);
+  const int32_t end_ = (int32_t) bswap_if((v.y >> 8) | (v.z << 24), a.flip);
+  const int32_t qv   = (int32_t) bswap_if((v.z >> 8) | (v.w << 24), a.flip);
+  return (v.x & 0xffu) != 255u && beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= (1 << 22) && qv >= 0 && qv < 1000000 &&
+         (uint64_t) (end_ - beg) <= 8u * (uint64_t) (a.n - (p + 1));
+}
+
 __global__ __launch_bounds__(DX_BLOCK)
 void k_walk_find(walk_args a, uint64_t *cand, uint32_t *ncand)
 { const uint32_t lane = (uint32_t) lane_id();
@@ -87,32 +103,37 @@ void k_walk_find(walk_args a, uint64_t *cand, uint32_t *ncand)
   if (k >= a.pieces) return;
   if (k == 0) { if (lane == 0) ncand[0] = 0; return; }            // (the first piece starts at the first record)
   const uint64_t lo = a.first + k * a.piece, hi = k == a.pieces - 1 ? a.n : lo + a.piece;
-  uint32_t found = 0;
-  for (uint64_t base = lo; base < hi && found < WALK_CAND; base += 64u)
-    { const uint64_t p = base + lane;
-      bool ok = false;
-      if (p < hi && p + 16 <= a.n)
-        { // the thirteen bytes of a header without leading 255s out of one 16-byte load; 1 byte in 256 is a 255: those the long way
-          const u32x4 v = *(const u32x4_u *) (a.img + p);
-          if ((v.x & 0xffu) == 255u)
-            ok = header_plausible_d(a, p);
-          else
-            { const int32_t beg  = (int32_t) bswap_if((v.x >> 8) | (v.y << 24), a.flip);
-              const int32_t end_ = (int32_t) bswap_if((v.y >> 8) | (v.z << 24), a.flip);
-              const int32_t qv   = (int32_t) bswap_if((v.z >> 8) | (v.w << 24), a.flip);
-              ok = beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= (1 << 22) && qv >= 0 && qv < 1000000 &&
-                   (uint64_t) (end_ - beg) <= 8u * (uint64_t) (a.n - (p + 1));
-            }
+  uint32_t found = 0, clusters = 0;
+  uint64_t last = 0;
+  bool     stop = false;
+  for (uint64_t base = lo; base < hi && !stop; base += 256u)
+    { uint64_t m[4];
+      u32x4    v[4];
+      #pragma unroll
+      for (int u = 0; u < 4; u++)                               // four requests under way, then four tests
+        { const uint64_t p = base + 64u * u + lane;
+          v[u] = u32x4{ 255u, 0u, 0u, 0u };
+          if (p < hi && p + 16 <= a.n) v[u] = *(const u32x4_u *) (a.img + p);
         }
-      else if (p < hi)
-        ok = header_plausible_d(a, p);
-      uint64_t m = __ballot(ok);
-      while (m && found < WALK_CAND)
-        { const uint32_t l = (uint32_t) __ffsll((unsigned long long) m) - 1u;
-          if (lane == l) cand[k * WALK_CAND + found] = p;
-          found += 1;
-          m &= m - 1;
+      #pragma unroll
+      for (int u = 0; u < 4; u++)
+        { const uint64_t p = base + 64u * u + lane;
+          bool ok = header_fast_d(a, p, v[u]);
+          if (p < hi && p + 16 > a.n && a.img[p] != 255) ok = header_plausible_d(a, p);     // (the image's last bytes)
+          m[u] = __ballot(ok);
         }
+      #pragma unroll
+      for (int u = 0; u < 4; u++)
+        while (m[u] && !stop)
+          { const uint32_t l = (uint32_t) __ffsll((unsigned long long) m[u]) - 1u;
+            const uint64_t p = base + 64u * u + l;
+            m[u] &= m[u] - 1;
+            if (found == 0 || p - last > 16u) clusters += 1;
+            if (clusters > 1u || found == WALK_CAND) { stop = true; break; }
+            if (lane == 0) cand[k * WALK_CAND + found] = p;
+            found += 1; last = p;
+          }
+      if (found && base + 256u > last + 16u) stop = true;                                    // (the cluster is complete)
     }
   // A true header at p makes p - 1 plausible too wherever the quality value is below 3906 and the entry short of 16 k
   // symbols (its fields read one byte early: 256 times the length, 256 times the quality value) -- a guess that costs a
@@ -223,8 +244,8 @@ struct walk_lds { uint16_t t[4][4096]; uint16_t r1[2][4096]; uint16_t one[4][409
 // that does not fit the window), a code of more than 12 bits or an escape (from the 16-bit table in memory), a run's literal,
 // a segment's end, a record's header, a record's end.  (Measured: the single-code steps inside the burst as well, the lane's
 // mode choosing among three tables of one form, cost the burst more than the trips outside save: 119 against 106 ms.)
-__global__ __launch_bounds__(WALK_BLOCK)
-void k_walk_pieces(walk_args a, const uint64_t *cand, const uint32_t *ncand, const uint32_t *todo, uint32_t ntodo,
+__global__ __launch_bounds__(WALK_BLOCK, WALK_WGS_PER_CU * WALK_BLOCK / 256)     // (waves per SIMD: two workgroups a CU)
+void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uint32_t *todo, uint32_t ntodo,
                    const uint64_t *start, walk_piece_d *pc, walk_rec_d *recs, uint32_t rcap)
 { __shared__ walk_lds S;
 #define WALK_STAGE(tab, from, words) { const uint32_t *s_ = (const uint32_t *) (const void *) (from); uint32_t *d_ = (uint32_t *) (void *) (tab); \
@@ -249,7 +270,7 @@ void k_walk_pieces(walk_args a, const uint64_t *cand, const uint32_t *ncand, con
   // the lane's state
   uint64_t at;                         // PH_HEAD: the record's first byte; in a segment: the segment's first byte
   uint32_t ph = PH_HEAD, rlen = 0, j = 0, last = 0, nn = 0, clen = 0;
-  uint32_t trial = 0, ci = 0;          // trial: the record being walked is a guess (candidate ci of the piece)
+  uint32_t trial = 0, ci = 0, nc = 0;  // trial: the record being walked is a guess (candidate ci of the piece's nc)
   uint64_t budget = ~0ull;
   walk_rec_d r;
   wrd_d rd;
@@ -261,7 +282,7 @@ void k_walk_pieces(walk_args a, const uint64_t *cand, const uint32_t *ncand, con
   else if (ncand[k] == 0)
     { out.flags = WP_NONE; live = false; at = 0; }
   else
-    { trial = 1; budget = 16u * a.piece; at = cand[k * WALK_CAND]; }          // (two pieces' bytes)
+    { trial = 1; budget = 16u * a.piece; at = cand[k * WALK_CAND]; nc = ncand[k]; }          // (two pieces' bytes)
   if (live && !trial && !(at < hi && at < a.n)) { live = false; out.end = at; }     // (nothing of this piece left to walk)
 
   while (live)
@@ -405,20 +426,37 @@ void k_walk_pieces(walk_args a, const uint64_t *cand, const uint32_t *ncand, con
       if (fail)
         { if (trial)                                            // a wrong guess: the piece's next one
             { ci += 1;
-              if (ci < ncand[k]) { at = cand[k * WALK_CAND + ci]; ph = PH_HEAD; }
-              else               { out.flags = WP_NONE; live = false; }
+              if (ci < nc) { at = cand[k * WALK_CAND + ci]; ph = PH_HEAD; }
+              else                                              // none of the cluster held (rare): the next cluster, found by the lane itself
+                { uint64_t *c = cand + k * WALK_CAND, last = 0;   // (through memory: no registers for what happens once in ten thousand pieces)
+                  uint32_t m = 0;
+                  #pragma unroll 1
+                  for (uint64_t p = c[0] + 1; p < hi && (m == 0 || p <= last + 16u) && m < WALK_CAND; p++)
+                    if (a.img[p] != 255 && header_plausible_d(a, p)) { c[m++] = p; last = p; }
+                  if (m == 0) { out.flags = WP_NONE; live = false; }
+                  else
+                    { for (uint32_t x = 0, y = m - 1; x < y; x++, y--) { const uint64_t t = c[x]; c[x] = c[y]; c[y] = t; }   // (last first)
+                      nc = m; ci = 0; at = c[0]; ph = PH_HEAD;
+                    }
+                }
             }
           else                                                  // a record on the lane's chain does not walk
             { out.flags |= WP_BAD; out.end = at; live = false; }
         }
     }
-  out.tried = ci; out.steps_k = rounds_ >> 10;
+  out.tried = ci;
+  if (!(out.flags & WP_NONE) && out.count)                   // (see k_walk_find: bytes of 255 in front of the start may be the header's)
+    { uint32_t c = 0;
+      while (c < 4096u && out.start > a.first + c && a.img[out.start - 1 - c] == 255) c++;
+      out.lead255 = c;
+    }
+  (void) rounds_;
   pc[k] = out;
 }
 
 // the records of the pieces on the chain, side by side: a wave per piece; dst[k] = its first record's index (~0: not on the
 // chain), hbase[k] / wbase[k] = the framing bytes / wells before it
-// (trim[k]: leading 255s of the piece's first record that belong to the record before it -- see the chain)
+// (trim[k], signed: bytes of 255 in front of the piece's first record that are its header's (< 0) -- see the chain)
 __global__ __launch_bounds__(DX_BLOCK)
 void k_walk_gather(uint64_t pieces, const walk_piece_d *pc, const walk_rec_d *recs, uint32_t rcap, const uint64_t *dst,
                    const uint64_t *hbase, const uint64_t *wbase, const uint64_t *trim,
@@ -435,7 +473,7 @@ void k_walk_gather(uint64_t pieces, const walk_piece_d *pc, const walk_rec_d *re
       uint32_t h = 0, d = 0;
       if (i < cnt)
         { r = my[i];
-          if (i == 0) { const uint32_t t = (uint32_t) trim[k]; r.off += t; r.hdr_bytes -= t; r.dwell -= 255 * (int32_t) t; }
+          if (i == 0) { const int64_t t = (int64_t) trim[k]; r.off = (uint64_t) ((int64_t) r.off + t); r.hdr_bytes = (uint32_t) ((int64_t) r.hdr_bytes - t); r.dwell -= 255 * (int32_t) t; }
           h = r.hdr_bytes; d = (uint32_t) r.dwell;
         }
       const uint32_t hi_ = wave_incl_scan(h), di_ = wave_incl_scan(d);
@@ -519,50 +557,63 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   { // a workgroup per CU while the lanes allow (the tables fill 64 KB of LDS: two workgroups a CU at most), every CU busy
     const uint64_t waves = (P + 63u) / 64u, per_cu = (waves + ctx->num_cu - 1) / ctx->num_cu;
     const uint32_t bs = per_cu >= WALK_BLOCK / 64u ? WALK_BLOCK : (uint32_t) (per_cu ? per_cu * 64u : 64u);
+    hipEvent_t ev[3] = { NULL, NULL, NULL };                   // DEXGPU_WALK_DEBUG: the two kernels' times
+    const bool timed = getenv("DEXGPU_WALK_DEBUG") != NULL && hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess && hipEventCreate(&ev[2]) == hipSuccess;
     dx_prof_begin(ctx, DX_K_QV_WALK);
+    if (timed) (void) hipEventRecord(ev[0], ctx->stream);
     hipLaunchKernelGGL(k_walk_find, dim3((unsigned) ((P + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream, a, d_cand, d_ncand);
-    hipLaunchKernelGGL(k_walk_pieces, dim3((unsigned) ((P + bs - 1) / bs)), dim3(bs), 0, ctx->stream, a, (const uint64_t *) d_cand,
+    if (timed) (void) hipEventRecord(ev[1], ctx->stream);
+    hipLaunchKernelGGL(k_walk_pieces, dim3((unsigned) ((P + bs - 1) / bs)), dim3(bs), 0, ctx->stream, a, d_cand,
                        (const uint32_t *) d_ncand, (const uint32_t *) NULL, 0u, (const uint64_t *) NULL, d_pc, d_recs, rcap);
+    if (timed) (void) hipEventRecord(ev[2], ctx->stream);
     dx_prof_end(ctx);
+    if (timed)
+      { float t1 = 0, t2 = 0;
+        (void) hipEventSynchronize(ev[2]);
+        (void) hipEventElapsedTime(&t1, ev[0], ev[1]); (void) hipEventElapsedTime(&t2, ev[1], ev[2]);
+        fprintf(stderr, "[walk] k_walk_find %.2f ms, k_walk_pieces %.2f ms (%u threads a workgroup)\n", t1, t2, bs);
+      }
+    for (int i = 0; i < 3; i++) if (ev[i]) (void) hipEventDestroy(ev[i]);
   }
   WALK_HIP(hipGetLastError());
   WALK_HIP(hipMemcpyAsync(pc, d_pc, P * sizeof(walk_piece_d), hipMemcpyDeviceToHost, ctx->stream));
   WALK_HIP(hipStreamSynchronize(ctx->stream));
 
   if (getenv("DEXGPU_WALK_DEBUG"))
-    { uint64_t tried = 0, rounds = 0, none = 0; uint32_t mx = 0;
-      for (uint64_t k = 0; k < P; k++) { tried += pc[k].tried; rounds += pc[k].steps_k; none += (pc[k].flags & WP_NONE) != 0; if (pc[k].steps_k > mx) mx = pc[k].steps_k; }
-      { uint64_t *hc = (uint64_t *) malloc(P * WALK_CAND * 8); int shown = 0;
-        if (hc && hipMemcpy(hc, d_cand, P * WALK_CAND * 8, hipMemcpyDeviceToHost) == hipSuccess)
-          for (uint64_t k = 0; k < P && shown < 12; k++)
-            if (pc[k].steps_k > 12) { fprintf(stderr, "[walk] piece %llu (from %llu): tried %u, guesses %llu %llu %llu %llu, took %llu, %u k rounds\n", (unsigned long long) k, (unsigned long long) (first + k * a.piece), pc[k].tried,
-                                       (unsigned long long) hc[4*k], (unsigned long long) hc[4*k+1], (unsigned long long) hc[4*k+2], (unsigned long long) hc[4*k+3], (unsigned long long) pc[k].start, pc[k].steps_k); shown++; }
-        free(hc);
-      }
-      fprintf(stderr, "[walk] %llu pieces: %llu guesses did not hold, %llu pieces without a start, %llu k loop rounds in all, %u k the most of a lane\n",
-              (unsigned long long) P, (unsigned long long) tried, (unsigned long long) none, (unsigned long long) rounds, mx);
+    { uint64_t tried = 0, none = 0;
+      for (uint64_t k = 0; k < P; k++) { tried += pc[k].tried; none += (pc[k].flags & WP_NONE) != 0; }
+      fprintf(stderr, "[walk] %llu pieces of %llu bytes: %llu guesses did not hold, %llu pieces without a start\n",
+              (unsigned long long) P, (unsigned long long) a.piece, (unsigned long long) tried, (unsigned long long) none);
     }
   // the chain, from the first record on
   { uint64_t pos = first, k = 0;
     int rounds = 0;
     while (pos < n)
-      { // A header may begin with bytes of 255 (255 wells each) -- and so may the bytes in FRONT of a header end in some: the lane
-        // of a piece takes the first start that walks, which is then the true one less a few 255s.  Same records, but for the first
-        // one's first bytes: they are taken off again (trim), no second walk.
+      { // A header may begin with bytes of 255 (255 wells each).  The lane of a piece never starts on one (k_walk_find): it takes
+        // the offset behind them, where the same record reads with fewer wells, and says how many bytes of 255 stand in front
+        // of its start.  The chain knows where the record before ended: the bytes of 255 from there on are this header's --
+        // first record's offset, framing bytes and wells put right in the gather (trim < 0), no second walk.  (trim > 0, a start
+        // in front of where the chain arrives with only bytes of 255 between: cannot happen any more, handled all the same.)
         trim[k] = 0;
-        if (!(pc[k].flags & WP_NONE) && pc[k].start < pos && pc[k].count > 0 && pos - pc[k].start <= (uint64_t) pc[k].first_hdr - 13u)
-          { trim[k] = pos - pc[k].start;
-            pc[k].start = pos; pc[k].hdr_sum -= (uint32_t) trim[k]; pc[k].dwell_sum -= 255u * trim[k];
+        if (!(pc[k].flags & WP_NONE) && pc[k].count > 0)
+          { if (pc[k].start > pos && pc[k].start - pos <= (uint64_t) pc[k].lead255)
+              trim[k] = (uint64_t) 0 - (pc[k].start - pos);
+            else if (pc[k].start < pos && pos - pc[k].start <= (uint64_t) pc[k].first_hdr - 13u)
+              trim[k] = pos - pc[k].start;
+            if (trim[k])
+              { const int64_t t = (int64_t) trim[k];
+                pc[k].start = pos; pc[k].hdr_sum = (uint32_t) ((int64_t) pc[k].hdr_sum - t); pc[k].dwell_sum = (uint64_t) ((int64_t) pc[k].dwell_sum - 255 * t);
+              }
           }
         if (pc[k].flags & WP_NONE || pc[k].start != pos)      // the chain arrives elsewhere than this piece's lane started: once more, from here
-          { if (getenv("DEXGPU_WALK_DEBUG")) fprintf(stderr, "[walk] piece %llu: chain arrives at %llu, lane started at %llu (flags %u, %u records, end %llu)\n", (unsigned long long) k, (unsigned long long) pos, (unsigned long long) pc[k].start, pc[k].flags, pc[k].count, (unsigned long long) pc[k].end);
+          { if (getenv("DEXGPU_WALK_DEBUG")) fprintf(stderr, "[walk] piece %llu: chain arrives at %llu, lane started at %llu (flags %u, %u records, %u bytes of 255 in front): walked again\n", (unsigned long long) k, (unsigned long long) pos, (unsigned long long) pc[k].start, pc[k].flags, pc[k].count, pc[k].lead255);
             if (++rounds > WALK_ROUNDS) WALK_FAIL(DX_E_MISMATCH, "dx_qv_walk_device: the pieces' walks do not chain up");
             if (d_start == NULL) { WALK_HIP(hipMalloc(&d_start, P * 8)); WALK_HIP(hipMalloc(&d_todo, 4)); }
             const uint32_t kk = (uint32_t) k;
             WALK_HIP(hipMemcpyAsync(d_start + k, &pos, 8, hipMemcpyHostToDevice, ctx->stream));
             WALK_HIP(hipMemcpyAsync(d_todo, &kk, 4, hipMemcpyHostToDevice, ctx->stream));
             dx_prof_begin(ctx, DX_K_QV_WALK);
-            hipLaunchKernelGGL(k_walk_pieces, dim3(1), dim3(64), 0, ctx->stream, a, (const uint64_t *) d_cand, (const uint32_t *) d_ncand,
+            hipLaunchKernelGGL(k_walk_pieces, dim3(1), dim3(64), 0, ctx->stream, a, d_cand, (const uint32_t *) d_ncand,
                                (const uint32_t *) d_todo, 1u, (const uint64_t *) d_start, d_pc, d_recs, rcap);
             dx_prof_end(ctx);
             WALK_HIP(hipGetLastError());
