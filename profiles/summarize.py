@@ -19,10 +19,11 @@ import csv, glob, json, os, shutil, sys, collections
 BENCH_ID = {"k_qv_encode_fast": "k_qv_encode", "k_qv_encode": "k_qv_encode_text", "k_qv_hist": "k_qv_hist",
             "k_qv_compact": "k_qv_compact", "k_qv_decode": "k_qv_decode", "k_qv_decode_tags": "k_qv_decode_tags",
             "k_qv_decode_plain": "k_qv_decode_plain", "k_qv_decode_sub": "k_qv_decode_sub", "k_qv_decode_runs": "k_qv_decode_runs",
-            "k_qv_sizes_fast": "k_qv_sizes", "k_qv_sizes": "k_qv_sizes",
+            "k_qv_sizes_fast": "k_qv_sizes", "k_qv_sizes": "k_qv_sizes", "k_qv_sizes_hist": "k_qv_sizes",
+            "k_walk_find": "k_qv_walk", "k_walk_pieces": "k_qv_walk", "k_walk_gather": "k_qv_walk",
             "k_qv_prescan_del": "k_qv_prescan", "k_qv_prescan_sub": "k_qv_prescan",
             "k_scan_tiles": "k_scan", "k_scan_sums": "k_scan", "k_scan_apply": "k_scan", "k_scan_apply_base": "k_scan",
-            "k_qv_bounds": "k_scan", "k_tok_rooms": "k_scan", "k_sub_rooms": "k_scan",
+            "k_qv_bounds": "k_scan", "k_sub_rooms": "k_scan",
             "k_pack2_encode": "k_pack2_encode", "k_pack2_decode": "k_pack2_decode"}
 
 
