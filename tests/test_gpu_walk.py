@@ -120,6 +120,15 @@ def test_what_the_device_walk_turns_down_goes_to_the_host(ctx, monkeypatch):
     big = synth.make_quiva(6, seed=52, mean=40000)                           # records of ~55 KB, pieces of 4 KB
     img = O.dexqv(big.text)
     assert ctx.undexqv(img) == O.undexqv(img)
+    tiny = synth.make_quiva(4000, seed=53, lens=np.full(4000, 6, np.uint32))  # records of ~40 bytes: more of them in a piece than
+    img = O.dexqv(tiny.text)                                                 # a lane's scratch holds (a record per 128 bytes)
+    coding, flip, prefix, used = api.qv_read_coding(img[2:])
+    d = ctx.to_device(np.frombuffer(img, np.uint8))
+    with pytest.raises(L.DexGPUError) as e:
+        ctx.qv_walk_device(d, len(img), 2 + used, coding, 1, flip)
+    assert e.value.code == -7
+    d.free()
+    assert ctx.undexqv(img) == O.undexqv(img)                                # ... and the file driver walks it on the host
 
 
 def test_device_walk_of_a_byte_swapped_file(ctx, monkeypatch):
