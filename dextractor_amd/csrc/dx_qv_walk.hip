@@ -529,13 +529,12 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   uint32_t *d_ncand = NULL, *d_todo = NULL;
   walk_piece_d *d_pc = NULL, *pc = (walk_piece_d *) malloc(P * sizeof(walk_piece_d));
   walk_rec_d   *d_recs = NULL;
-  uint64_t *start = (uint64_t *) calloc(P, 8), *dst = (uint64_t *) malloc(4 * P * 8), *trim = dst ? dst + 3 * P : NULL;
-  uint32_t *todo = (uint32_t *) malloc(P * 4);
+  uint64_t *dst = (uint64_t *) malloc(4 * P * 8), *trim = dst ? dst + 3 * P : NULL;
   uint8_t  *onchain = (uint8_t *) calloc(P, 1);
   uint64_t N = 0;
 #define WALK_FAIL(code, ...) do { rc = dx_fail(ctx, code, __VA_ARGS__); goto done; } while (0)
 #define WALK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) WALK_FAIL(DX_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
-  if (!blob || !pc || !start || !dst || !todo || !onchain) WALK_FAIL(DX_E_NOMEM, "dx_qv_walk_device: out of host memory");
+  if (!blob || !pc || !dst || !onchain) WALK_FAIL(DX_E_NOMEM, "dx_qv_walk_device: out of host memory");
   memset(dst, 0, 4 * P * 8);
   rc = dx_walk_luts_build(cd, blob, a.esc);
   if (rc != DX_OK) WALK_FAIL(rc, "dx_qv_walk_device: the look-up tables could not be built");
@@ -665,7 +664,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
 done:
   (void) hipFree(d_blob); (void) hipFree(d_tail); (void) hipFree(d_cand); (void) hipFree(d_ncand); (void) hipFree(d_pc); (void) hipFree(d_recs);
   (void) hipFree(d_start); (void) hipFree(d_todo); (void) hipFree(d_dst);
-  free(blob); free(pc); free(start); free(dst); free(todo); free(onchain);
+  free(blob); free(pc); free(dst); free(onchain);
   if (rc != DX_OK) dx_qv_dindex_free(ctx, out);
   return rc;
 #undef WALK_HIP
