@@ -599,7 +599,11 @@ __device__ __forceinline__ uint32_t hist_plain_pair_own(const u32x4 &c2, const u
                                                         uint32_t *slow_ins, uint32_t *slow_mrg)
 { const uint32_t col = (uint32_t) lane_id() & 3u;
   uint32_t *const q0 = &pp[0][0][col], *const q1 = &pp[1][0][col];
+#if HIST_SKIP & 512             /* perturbation: every lane's symbols moved to bins of its own -- what the same-address adds cost */
+#define OWN_ADD(q, x) atomicAdd(&(q)[4u * (((x) + 2u * (uint32_t) lane_id()) & 127u)], 1u)
+#else
 #define OWN_ADD(q, x) atomicAdd(&(q)[4u * (x)], 1u)
+#endif
   if (!__any((int) ((c2.x | c2.y | c2.z | c2.w | c3.x | c3.y | c3.z | c3.w) & 0x80808080u)))
     { if (full || valid > 0)
         {
