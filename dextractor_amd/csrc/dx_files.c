@@ -324,10 +324,12 @@ static int tb_room(tbuf *b, size_t more)
 typedef struct
   { uint64_t n; const uint64_t *ooff, *hat; const char *hd;
     dx_sink_fn sink; void *user;
+    size_t base;                  /* where in the text the streamed buffer starts (a slice of the entries; else 0) */
   } hdr_patch;
 
-static int patch_and_pass(void *arg, uint8_t *data, size_t len, size_t at)
+static int patch_and_pass(void *arg, uint8_t *data, size_t len, size_t at0)
 { hdr_patch *h = arg;
+  const size_t at = at0 + h->base;
   uint64_t lo = 0, hi = h->n, i;
   while (lo < hi)                                         /* first entry whose text starts beyond `at` */
     { uint64_t mid = (lo + hi) / 2;
@@ -461,7 +463,7 @@ static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uin
             memcpy(res + ooff[i] - (hat[i+1] - hat[i]), hd.p + hat[i], (size_t) (hat[i+1] - hat[i]));
         }
       else
-        { hdr_patch h = { cnt, ooff, hat, hd.p, sink, user };
+        { hdr_patch h = { cnt, ooff, hat, hd.p, sink, user, 0 };
           TRY(dx_d2h_stream(ctx, d_out, total, patch_and_pass, &h));
         }
     }
@@ -919,6 +921,69 @@ fail:
   return rc;
 }
 
+/* ---- a text larger than the device (or than DEXGPU_TEXT_BUDGET): slices of whole entries ------------------------------
+ * The reference writes entry after entry (undexqv.c:182-207).  Here: per slice of at most `cap` bytes of text, the slice's
+ * records -- the whole image stays on the device when it is there already (a plan made there) or fits beside a slice's text,
+ * else the slice's bytes are uploaded -- are decoded into one buffer that goes out before the next slice comes in.
+ * Same text; such a file is bound by the host link.                                                               */
+static int undexqv_sliced(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sink_fn sink, void *user, size_t cap, int whole_in)
+{ dpool     pool = { {0}, 0, ctx };
+  const uint64_t n = p->x.n;
+  void     *d_in = NULL, *d_rec = NULL, *d_hoff = NULL, *d_seg = NULL, *d_len = NULL, *d_out = NULL, *d_ooff = NULL;
+  uint64_t *rel = NULL, i0, i1, i, most = 0;
+  size_t    tmax = 0, imax = 0;
+  hdr_patch h;
+  int       rc = DX_OK;
+#define TEXT_AT(i) ((i) < n ? (size_t) p->ooff[i] - (size_t) (p->hat[(i) + 1] - p->hat[i]) : p->total)      /* where entry i's header line starts */
+  h.n = n; h.ooff = p->ooff; h.hat = p->hat; h.hd = p->hd.p; h.sink = sink; h.user = user; h.base = 0;
+  for (i0 = 0; i0 < n; i0 = i1)                           /* the largest slice: one allocation serves them all */
+    { i1 = i0 + 1;
+      while (i1 < n && TEXT_AT(i1 + 1) - TEXT_AT(i0) <= cap) i1++;
+      if (TEXT_AT(i1) - TEXT_AT(i0) > tmax) tmax = TEXT_AT(i1) - TEXT_AT(i0);
+      if (i1 - i0 > most) most = i1 - i0;
+      if (!whole_in && p->x.rec_off[i1] - p->x.rec_off[i0] > imax) imax = (size_t) (p->x.rec_off[i1] - p->x.rec_off[i0]);
+    }
+  rel = malloc((most + 1) * 2 * sizeof(*rel));
+  if (rel == NULL) return DX_E_NOMEM;
+  TRY(dx_qv_set_coding(ctx, &p->x.coding, 0));
+  if (p->ctx != NULL)
+    { d_in = p->d_in; d_rec = p->dix.d_rec_off; d_hoff = p->dix.d_hdr_off; d_seg = p->dix.d_seg; d_len = p->dix.d_len; }
+  else
+    { if (whole_in) { TRY(dupload(&pool, p->img, p->n, &d_in)); TRY(dupload(&pool, p->x.rec_off, (n + 1) * 8, &d_rec)); }
+      else          { TRY(dalloc(&pool, imax, &d_in)); TRY(dalloc(&pool, (most + 1) * 8, &d_rec)); }
+      TRY(dupload(&pool, p->x.hdr_off, (n + 1) * 8, &d_hoff));
+      TRY(dupload(&pool, p->x.seg, n * 5 * 4, &d_seg));
+      TRY(dupload(&pool, p->x.len, n * 4, &d_len));
+    }
+  TRY(dalloc(&pool, (most + 1) * 8, &d_ooff));
+  TRY(dalloc(&pool, tmax, &d_out));
+  for (i0 = 0; i0 < n; i0 = i1)
+    { const size_t t0 = TEXT_AT(i0);
+      const uint64_t *rec = d_rec;
+      i1 = i0 + 1;
+      while (i1 < n && TEXT_AT(i1 + 1) - t0 <= cap) i1++;
+      for (i = i0; i < i1; i++) rel[i - i0] = p->ooff[i] - t0;
+      TRY(dx_h2d(ctx, d_ooff, rel, (i1 - i0) * 8));
+      if (p->ctx != NULL || whole_in)
+        rec = (const uint64_t *) d_rec + i0;
+      else                                                /* this slice's records, their offsets from the slice's first byte */
+        { const uint64_t b0 = p->x.rec_off[i0];
+          for (i = i0; i <= i1; i++) rel[most + 1 + (i - i0)] = p->x.rec_off[i] - b0;
+          TRY(dx_h2d(ctx, d_in, p->img + b0, (size_t) (p->x.rec_off[i1] - b0)));
+          TRY(dx_h2d(ctx, d_rec, rel + most + 1, (i1 - i0 + 1) * 8));
+        }
+      TRY(dx_qv_decode(ctx, d_in, rec, (const uint64_t *) d_hoff + i0, (const uint32_t *) d_seg + 5 * i0, (const uint32_t *) d_len + i0, i1 - i0,
+                       (upper ? DX_DECODE_UPPER : 0) | (p->x.flip ? DX_DECODE_FLIP : 0), d_out, d_ooff));
+      h.base = t0;
+      TRY(dx_d2h_stream(ctx, d_out, TEXT_AT(i1) - t0, patch_and_pass, &h));
+    }
+#undef TEXT_AT
+done:
+  dfree_all(&pool);
+  free(rel);
+  return rc;
+}
+
 int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sink_fn sink, void *user)
 { dpool     pool = { {0}, 0, ctx };
   void     *d_in, *d_rec, *d_hoff, *d_seg, *d_len, *d_out, *d_ooff;
@@ -926,8 +991,30 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
   int       rc = DX_OK, indexed = 0;
 
   if (ctx == NULL || p == NULL || sink == NULL) return DX_E_ARG;
-  h.n = p->x.n; h.ooff = p->ooff; h.hat = p->hat; h.hd = p->hd.p; h.sink = sink; h.user = user;
+  h.n = p->x.n; h.ooff = p->ooff; h.hat = p->hat; h.hd = p->hd.p; h.sink = sink; h.user = user; h.base = 0;
   if (p->ctx != NULL && p->ctx != ctx) return DX_E_ARG;   /* (a plan made on a device runs there) */
+  if (p->x.n > 0)
+    { /* does the text fit beside the image?  DEXGPU_TEXT_BUDGET (bytes) says how much text the device takes at once; else what
+         is free decides: the image (unless it is there already), the index and the text, and a tenth to spare */
+      const char *e = getenv("DEXGPU_TEXT_BUDGET");
+      uint64_t fr = 0, all = 0;
+      size_t   cap = 0;
+      int      whole_in = 1;
+      if (e != NULL && *e)
+        { const unsigned long long v = strtoull(e, NULL, 10);
+          if (v && v < p->total) cap = (size_t) (v < 65536u ? 65536u : v);
+        }
+      else if (dx_mem_info(ctx, &fr, &all) == DX_OK && fr > 0)
+        { const double in = p->ctx != NULL ? 0.0 : (double) p->n;
+          if (in + (double) p->total + 48.0 * (double) p->x.n > 0.9 * (double) fr)
+            { whole_in = in <= 0.4 * (double) fr;
+              cap = (size_t) ((0.9 * (double) fr - (whole_in ? in : 0.0) - 48.0 * (double) p->x.n) / (whole_in ? 1.0 : 1.4));
+              if (cap < ((size_t) 4 << 20)) cap = (size_t) 4 << 20;
+            }
+        }
+      if (cap)
+        return undexqv_sliced(ctx, p, upper, sink, user, cap, getenv("DEXGPU_SLICE_INPUT") != NULL && p->ctx == NULL ? 0 : whole_in);   /* (DEXGPU_SLICE_INPUT: tests) */
+    }
   if (p->x.n > 0)
     { TRY(dx_qv_set_coding(ctx, &p->x.coding, 0));
       if (p->ctx != NULL)                                 /* image and index are on the device already */

@@ -457,7 +457,8 @@ typedef struct dx_undexqv_plan dx_undexqv_plan;
 int  dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len);
 /* The plan with the GPU at hand: a large 0x55aa-keyed image is uploaded and its records are walked on the device
  * (dx_qv_walk_device), anything else -- and anything the device walk turns down -- is planned on the host as above.  Such a
- * plan holds device memory of ctx until it is freed, and runs on ctx only.  dx_file_undexqv plans this way.            */
+ * plan holds device memory of ctx until it is freed, and runs on ctx only.  dx_file_undexqv plans this way.
+ * A text that does not fit the device beside the image (or DEXGPU_TEXT_BUDGET bytes) comes out in slices of whole entries. */
 int  dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len);
 int  dx_file_undexqv_run (dx_ctx *ctx, const dx_undexqv_plan *plan, int upper, dx_sink_fn sink, void *user);
 void dx_file_undexqv_plan_free(dx_undexqv_plan *plan);

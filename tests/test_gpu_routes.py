@@ -179,3 +179,33 @@ def test_file_larger_than_the_text_budget_goes_in_slices(monkeypatch, tmp_path):
         r = subprocess.run([tool, "-k", str(src)], env=dict(os.environ, DEXGPU_TEXT_BUDGET=str(5 << 20)), capture_output=True, timeout=300)
         assert r.returncode == 0, r.stderr[-500:]
         assert (tmp_path / "big.dexqv").read_bytes() == whole
+
+
+def test_text_larger_than_the_budget_comes_out_in_slices(monkeypatch, tmp_path):
+    """dx_file_undexqv on a .dexqv whose text is 1.5 to 30 times what the device may hold at once (DEXGPU_TEXT_BUDGET): slices of
+    whole entries, decoded into one buffer that goes out before the next slice comes in -- with the image resident (uploaded
+    once, or there already after a plan made on the device) and with the slices' bytes uploaded one by one
+    (DEXGPU_SLICE_INPUT).  The oracle's text; through the CLI too."""
+    import os, subprocess
+    with api.Context(0) as ctx:
+        c = synth.make_quiva(500, seed=91, mean=7000, dist="lognormal")            # ~17 MB of text
+        img = O.dexqv(c.text)
+        want = O.undexqv(img)
+        for budget in (len(want) * 2 // 3, 1 << 20, 65536):
+            monkeypatch.setenv("DEXGPU_TEXT_BUDGET", str(budget))
+            assert ctx.undexqv(img) == want
+            assert ctx.undexqv(img, upper=True) == O.undexqv(img, upper=True)
+            monkeypatch.setenv("DEXGPU_SLICE_INPUT", "1")
+            assert ctx.undexqv(img) == want
+            monkeypatch.delenv("DEXGPU_SLICE_INPUT")
+            monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")                      # the plan on the device: image and index stay there
+            monkeypatch.setenv("DEXGPU_WALK_PIECE", "8192")
+            assert ctx.undexqv(img) == want
+            monkeypatch.delenv("DEXGPU_DEVICE_WALK_MIN"); monkeypatch.delenv("DEXGPU_WALK_PIECE")
+    src = tmp_path / "big.dexqv"
+    src.write_bytes(img)
+    tool = os.path.join(os.path.dirname(L.LIB_PATH), "bin", "undexqv")
+    if os.path.isfile(tool):
+        r = subprocess.run([tool, "-k", str(src)], env=dict(os.environ, DEXGPU_TEXT_BUDGET=str(1 << 20)), capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert (tmp_path / "big.quiva").read_bytes() == want
