@@ -70,6 +70,19 @@ static int ends_with_a_header(const uint8_t *text, size_t n)
   return at > 0 && text[at] == '>';
 }
 
+/* how much text the device packs at once: DEXGPU_TEXT_BUDGET (bytes) when set, else all of it (0) unless the text, its packed
+   image and the index do not fit what is free */
+static size_t pack2_cap(dx_ctx *ctx, size_t n)
+{ const char *e = getenv("DEXGPU_TEXT_BUDGET");
+  uint64_t fr = 0, all = 0;
+  if (e != NULL && *e)
+    { const unsigned long long v = strtoull(e, NULL, 10);
+      return v && v < n ? (size_t) (v < 65536u ? 65536u : v) : 0;
+    }
+  if (dx_mem_info(ctx, &fr, &all) != DX_OK || fr == 0) return 0;
+  return 1.35 * (double) n > 0.9 * (double) fr ? (size_t) (0.6 * (double) fr) : 0;
+}
+
 int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
                   uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
 { dpool     pool = { {0}, 0, ctx };
@@ -80,15 +93,20 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
   uint8_t  *blob = NULL, *img = NULL;
   size_t    plen = 0, at, total;
   void     *d_text = NULL, *d_off = NULL, *d_tlen = NULL, *d_nsym = NULL, *d_hdr, *d_hoff, *d_out, *d_ooff;
+  size_t    sliced;
   int       rc;
 
   if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
   *out = NULL; *out_len = 0;
 
+  /* A text that does not fit the device beside its packed image (or DEXGPU_TEXT_BUDGET): indexed on the host, then slices of
+     whole reads -- upload, pack, the slice's records into the image (the reference reads record after record,
+     dexta.c:104-205). */
+  sliced = pack2_cap(ctx, n);
   /* index: on the GPU for large images (newline scan, record extents there; only header lines come
      back), on the host for small ones and for anything the GPU front end rejects (exact message) */
-  if (n > 0) TRY(dupload(&pool, text, n, &d_text));
-  if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL && !ends_with_a_header(text, n))
+  if (n > 0 && !sliced) TRY(dupload(&pool, text, n, &d_text));
+  if (!sliced && n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL && !ends_with_a_header(text, n))
     { uint64_t *go = NULL; uint32_t *gt = NULL, *gs = NULL;
       rc = dx_index_seq_device(ctx, arrow, d_text, n, &go, &gt, &gs, &cnt, &hdr4, &cnr4, &plen, errline, errcode);
       if (rc == DX_OK)
@@ -111,9 +129,11 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
       cnr4 = malloc((cnt + 1) * 4 * sizeof(*cnr4));
       if (!off || !tlen || !nsym || !hdr4 || !cnr4) { rc = DX_E_NOMEM; goto done; }
       TRY(dx_index_seq(arrow, text, n, cnt, off, tlen, nsym, hdr4, cnr4, &cnt, &plen, errline, errcode));
-      TRY(dupload(&pool, off,  cnt * 8, &d_off));
-      TRY(dupload(&pool, tlen, cnt * 4, &d_tlen));
-      TRY(dupload(&pool, nsym, cnt * 4, &d_nsym));
+      if (!sliced)
+        { TRY(dupload(&pool, off,  cnt * 8, &d_off));
+          TRY(dupload(&pool, tlen, cnt * 4, &d_tlen));
+          TRY(dupload(&pool, nsym, cnt * 4, &d_nsym));
+        }
     }
   hoff = malloc((cnt + 1) * sizeof(*hoff));
   ooff = malloc((cnt + 1) * sizeof(*ooff));
@@ -139,7 +159,50 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
     memcpy(img + 6, text, plen);
   }
 
-  if (cnt > 0)
+  if (cnt > 0 && sliced)
+    { uint64_t *rel = NULL, i0, i1, most = 0;
+      size_t    tmax = 0, omax = 0;
+#define READ_END(i) ((size_t) off[i] + tlen[i])
+      for (i0 = 0; i0 < cnt; i0 = i1)
+        { i1 = i0 + 1;
+          while (i1 < cnt && READ_END(i1) - (size_t) off[i0] <= sliced) i1++;
+          if (READ_END(i1 - 1) - (size_t) off[i0] > tmax) tmax = READ_END(i1 - 1) - (size_t) off[i0];
+          if ((i1 < cnt ? ooff[i1] : total) - ooff[i0] > omax) omax = (size_t) ((i1 < cnt ? ooff[i1] : total) - ooff[i0]);
+          if (i1 - i0 > most) most = i1 - i0;
+        }
+      rel = malloc(3 * (most + 1) * sizeof(*rel));
+      if (rel == NULL) { rc = DX_E_NOMEM; goto done; }
+      rc = dalloc(&pool, tmax, &d_text);
+      if (rc == DX_OK) rc = dalloc(&pool, (most + 1) * 8, &d_off);
+      if (rc == DX_OK) rc = dupload(&pool, tlen, cnt * 4, &d_tlen);
+      if (rc == DX_OK) rc = dupload(&pool, nsym, cnt * 4, &d_nsym);
+      if (rc == DX_OK) rc = dupload(&pool, blob, (size_t) hoff[cnt], &d_hdr);
+      if (rc == DX_OK) rc = dalloc(&pool, (most + 1) * 8, &d_hoff);
+      if (rc == DX_OK) rc = dalloc(&pool, (most + 1) * 8, &d_ooff);
+      if (rc == DX_OK) rc = dalloc(&pool, omax, &d_out);
+      for (i0 = 0; i0 < cnt && rc == DX_OK; i0 = i1)
+        { const size_t b0 = (size_t) off[i0];
+          const uint64_t o0 = ooff[i0];
+          i1 = i0 + 1;
+          while (i1 < cnt && READ_END(i1) - b0 <= sliced) i1++;
+          for (i = i0; i <= i1; i++)
+            { if (i < i1) { rel[i - i0] = off[i] - b0; rel[2 * (most + 1) + (i - i0)] = ooff[i] - o0; }
+              rel[(most + 1) + (i - i0)] = hoff[i] - hoff[i0];
+            }
+          rc = dx_h2d(ctx, d_text, text + b0, READ_END(i1 - 1) - b0);
+          if (rc == DX_OK) rc = dx_h2d(ctx, d_off, rel, (i1 - i0) * 8);
+          if (rc == DX_OK) rc = dx_h2d(ctx, d_hoff, rel + (most + 1), (i1 - i0 + 1) * 8);
+          if (rc == DX_OK) rc = dx_h2d(ctx, d_ooff, rel + 2 * (most + 1), (i1 - i0) * 8);
+          if (rc == DX_OK)
+            rc = dx_pack2_encode(ctx, arrow ? DX_ALPHA_ARROW : DX_ALPHA_BASES, d_text, d_off, (const uint32_t *) d_tlen + i0, (const uint32_t *) d_nsym + i0,
+                                 i1 - i0, (const uint8_t *) d_hdr + hoff[i0], d_hoff, d_out, d_ooff);
+          if (rc == DX_OK) rc = dx_d2h(ctx, img + o0, d_out, (size_t) ((i1 < cnt ? ooff[i1] : total) - o0));
+        }
+#undef READ_END
+      free(rel);
+      if (rc != DX_OK) goto done;
+    }
+  else if (cnt > 0)
     { TRY(dupload(&pool, blob, (size_t) hoff[cnt], &d_hdr));
       TRY(dupload(&pool, hoff, (cnt + 1) * 8, &d_hoff));
       TRY(dupload(&pool, ooff, cnt * 8, &d_ooff));
@@ -345,6 +408,22 @@ static int patch_and_pass(void *arg, uint8_t *data, size_t len, size_t at0)
   return h->sink(h->user, data, len, at);
 }
 
+/* how much of an output of `total` bytes the device makes at once beside an input of n bytes (and 48 bytes of index a unit): 0 = all
+   of it; DEXGPU_TEXT_BUDGET (bytes) when set, else what is free decides */
+static size_t out_cap(dx_ctx *ctx, size_t n, size_t total, uint64_t units)
+{ const char *e = getenv("DEXGPU_TEXT_BUDGET");
+  uint64_t fr = 0, all = 0;
+  if (e != NULL && *e)
+    { const unsigned long long v = strtoull(e, NULL, 10);
+      return v && v < total ? (size_t) (v < 65536u ? 65536u : v) : 0;
+    }
+  if (dx_mem_info(ctx, &fr, &all) != DX_OK || fr == 0) return 0;
+  if ((double) n + (double) total + 48.0 * (double) units <= 0.9 * (double) fr) return 0;
+  { const double room = 0.9 * (double) fr - (double) n - 48.0 * (double) units;
+    return room > (double) ((size_t) 4 << 20) ? (size_t) room : (size_t) 4 << 20;
+  }
+}
+
 /* mode: DX_LETTERS_LOWER / _UPPER (dexta images) or _ARROW (dexar images); out != NULL: the text in memory,
    else through the sink */
 static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
@@ -450,6 +529,52 @@ static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uin
       if (!res) { rc = DX_E_NOMEM; goto done; }
     }
 
+  { /* A text that does not fit the device beside the image (or DEXGPU_TEXT_BUDGET): slices of whole reads, the image resident
+       (a quarter of the text), every slice's text out before the next one's is made (the reference writes read after read,
+       undexta.c:175-271). */
+    const size_t cap = out_cap(ctx, n, total, cnt);
+    if (cnt > 0 && cap)
+      { uint64_t *rel = NULL, i0, i1, most = 0;
+        size_t    tmax = 0;
+        hdr_patch h = { cnt, ooff, hat, hd.p, sink, user, 0 };
+#define TEXT_AT(i) ((i) < cnt ? (size_t) ooff[i] - (size_t) (hat[(i) + 1] - hat[i]) : total)
+        for (i0 = 0; i0 < cnt; i0 = i1)
+          { i1 = i0 + 1;
+            while (i1 < cnt && TEXT_AT(i1 + 1) - TEXT_AT(i0) <= cap) i1++;
+            if (TEXT_AT(i1) - TEXT_AT(i0) > tmax) tmax = TEXT_AT(i1) - TEXT_AT(i0);
+            if (i1 - i0 > most) most = i1 - i0;
+          }
+        rel = malloc((most + 1) * sizeof(*rel));
+        if (rel == NULL) { rc = DX_E_NOMEM; goto done; }
+        rc = dupload(&pool, img, n, &d_in);
+        if (rc == DX_OK) rc = dupload(&pool, ioff, cnt * 8, &d_ioff);
+        if (rc == DX_OK) rc = dupload(&pool, nsym, cnt * 4, &d_nsym);
+        if (rc == DX_OK) rc = dalloc(&pool, (most + 1) * 8, &d_ooff);
+        if (rc == DX_OK) rc = dalloc(&pool, tmax, &d_out);
+        for (i0 = 0; i0 < cnt && rc == DX_OK; i0 = i1)
+          { const size_t t0 = TEXT_AT(i0);
+            i1 = i0 + 1;
+            while (i1 < cnt && TEXT_AT(i1 + 1) - t0 <= cap) i1++;
+            for (i = i0; i < i1; i++) rel[i - i0] = ooff[i] - t0;
+            rc = dx_h2d(ctx, d_ooff, rel, (i1 - i0) * 8);
+            if (rc == DX_OK)
+              rc = dx_pack2_decode(ctx, mode, d_in, (const uint64_t *) d_ioff + i0, (const uint32_t *) d_nsym + i0, i1 - i0, width, d_out, d_ooff);
+            if (rc == DX_OK && out)
+              { rc = dx_d2h(ctx, res + t0, d_out, TEXT_AT(i1) - t0);
+                for (i = i0; i < i1 && rc == DX_OK; i++)
+                  memcpy(res + ooff[i] - (hat[i+1] - hat[i]), hd.p + hat[i], (size_t) (hat[i+1] - hat[i]));
+              }
+            else if (rc == DX_OK)
+              { h.base = t0;
+                rc = dx_d2h_stream(ctx, d_out, TEXT_AT(i1) - t0, patch_and_pass, &h);
+              }
+          }
+#undef TEXT_AT
+        free(rel);
+        if (rc != DX_OK) goto done;
+        cnt = 0;                                          /* (done: nothing left for the one-shot path below) */
+      }
+  }
   if (cnt > 0)
     { TRY(dupload(&pool, img, n, &d_in));
       TRY(dupload(&pool, ioff, cnt * 8, &d_ioff));

@@ -209,3 +209,39 @@ def test_text_larger_than_the_budget_comes_out_in_slices(monkeypatch, tmp_path):
         r = subprocess.run([tool, "-k", str(src)], env=dict(os.environ, DEXGPU_TEXT_BUDGET=str(1 << 20)), capture_output=True, timeout=300)
         assert r.returncode == 0, r.stderr[-500:]
         assert (tmp_path / "big.quiva").read_bytes() == want
+
+
+def test_two_bit_drivers_in_slices(monkeypatch, tmp_path):
+    """dx_file_pack2 / dx_file_unpack2[_to] on files 1.5 to 100 times what the device may hold at once (DEXGPU_TEXT_BUDGET): slices
+    of whole reads in both directions (dexta.c:104-205, undexta.c:175-271 go read by read).  The oracle's bytes; through the
+    CLI (the streaming sink) too."""
+    import os, subprocess
+    with api.Context(0) as ctx:
+        for kind in ("fasta", "arrow"):
+            c = synth.make_seqfile(kind, 900, seed=5, mean=6000, width=70)
+            want = O.dexta(c.text) if kind == "fasta" else O.dexar(c.text)
+            back = O.undexta(want) if kind == "fasta" else O.undexar(want)
+            for budget in (len(c.text) * 2 // 3, 1 << 20, 65536):
+                monkeypatch.setenv("DEXGPU_TEXT_BUDGET", str(budget))
+                assert (ctx.dexta(c.text) if kind == "fasta" else ctx.dexar(c.text)) == want
+                assert (ctx.undexta(want) if kind == "fasta" else ctx.undexar(want)) == back
+                if kind == "fasta":
+                    assert ctx.undexta(want, upper=True, width=33) == O.undexta(want, upper=True, width=33)
+                    got = bytearray(len(back))
+                    def sink(data, at):
+                        got[at: at + len(data)] = data
+                    assert ctx.unpack2_stream(want, sink) == len(back) and bytes(got) == back
+            monkeypatch.delenv("DEXGPU_TEXT_BUDGET")
+    src = tmp_path / "reads.fasta"
+    src.write_bytes(c.text if kind == "fasta" else synth.make_seqfile("fasta", 900, seed=5, mean=6000, width=70).text)
+    bindir = os.path.join(os.path.dirname(L.LIB_PATH), "bin")
+    if os.path.isfile(os.path.join(bindir, "dexta")):
+        env = dict(os.environ, DEXGPU_TEXT_BUDGET=str(1 << 20))
+        text = src.read_bytes()
+        r = subprocess.run([os.path.join(bindir, "dexta"), "-k", str(src)], env=env, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert (tmp_path / "reads.dexta").read_bytes() == O.dexta(text)
+        os.remove(src)
+        r = subprocess.run([os.path.join(bindir, "undexta"), "-k", str(tmp_path / "reads.dexta")], env=env, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert (tmp_path / "reads.fasta").read_bytes() == O.undexta(O.dexta(text))
