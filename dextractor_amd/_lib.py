@@ -122,6 +122,7 @@ SIGNATURES = {
     "dx_qv_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P]),
     "dx_qv_walk": (C.c_int, [_P, C.c_size_t, _P]),
     "dx_qv_walk_indexed": (C.c_int, [_P, C.c_size_t, _P, C.c_int]),
+    "dx_file_undexqv_plan_index": (C.c_int, [_P, _P]),
     "dx_file_undexqv_plan_on": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "dx_qv_walk_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "dx_qv_dindex_free": (None, [_P, _P]),

@@ -264,8 +264,10 @@ static void drop_decode(void)
 { free(DImg); DImg = NULL; DImgN = 0;
   if (DHave) dx_qv_index_free(&DWalk);
   DHave = 0;
-  dx_file_free(DText); DText = NULL; DTextN = 0; DAt = 0; DNext = 0;
+  free(DText); DText = NULL; DTextN = 0; DAt = 0; DNext = 0;
 }
+
+static int text_to_memory(void *user, uint8_t *data, size_t len, size_t at) { memcpy((uint8_t *) user + at, data, len); return 0; }
 
 static void open_gpu(const char *who)
 { if (Ctx == NULL)
@@ -297,13 +299,22 @@ QVcoding *Read_QVcoding(FILE *input)
   DImg  = malloc(DImgN ? DImgN : 1);
   if (DImg == NULL) die("Out of memory (Read_QVcoding)");
   if (DImgN && fread(DImg, 1, DImgN, input) != DImgN) die("Read_QVcoding: read failed");
-  if (dx_qv_walk(DImg, DImgN, &DWalk) != DX_OK) die("Read_QVcoding: not a .dexqv file, or a damaged one");
-  DHave = 1;
   open_gpu("Read_QVcoding");
-  if (dx_file_undexqv(Ctx, DImg, DImgN, /*upper*/ 0, &DText, &DTextN) != DX_OK)
-    { fprintf(stderr, "libdexgpu: Read_QVcoding: %s\n", dx_last_error(Ctx));
-      exit(1);
-    }
+  { /* the records walked where dx_file_undexqv walks them (on the device for a large file), once: the plan's index is the shim's */
+    dx_undexqv_plan *plan = NULL;
+    size_t total = 0;
+    if (dx_file_undexqv_plan_on(Ctx, DImg, DImgN, &plan, &total) != DX_OK) die("Read_QVcoding: not a .dexqv file, or a damaged one");
+    if (dx_file_undexqv_plan_index(plan, &DWalk) != DX_OK) die("Out of memory (Read_QVcoding)");
+    DHave = 1;
+    DText = malloc(total + 16);
+    DTextN = total;
+    if (DText == NULL) die("Out of memory (Read_QVcoding)");
+    if (dx_file_undexqv_run(Ctx, plan, /*upper*/ 0, text_to_memory, DText) != DX_OK)
+      { fprintf(stderr, "libdexgpu: Read_QVcoding: %s\n", dx_last_error(Ctx));
+        exit(1);
+      }
+    dx_file_undexqv_plan_free(plan);
+  }
   if (fseek(input, (long) DWalk.rec_off[0], SEEK_SET) != 0) die("Read_QVcoding: seek failed");   /* behind the coding, as QV.c:1214-1320 leaves it */
   memset(&DCoding, 0, sizeof(DCoding));
   DCoding.delScheme = &DWalk;                           /* opaque to the caller */

@@ -1046,6 +1046,38 @@ fail:
   return rc;
 }
 
+/* The record index a plan holds, as host arrays of the caller's (dx_qv_index_free): n, rec_off, hdr_off, seg, len, hdr4, the
+   coding, prefix, newv / flip -- copied from the host walk's, or downloaded when the plan was made on the device. */
+int dx_file_undexqv_plan_index(const dx_undexqv_plan *p, dx_qv_index *x)
+{ const uint64_t n = p ? p->x.n : 0;
+  int rc = DX_OK;
+  if (p == NULL || x == NULL) return DX_E_ARG;
+  memset(x, 0, sizeof(*x));
+  x->n = n; x->coding = p->x.coding; x->newv = p->x.newv; x->flip = p->x.flip;
+  x->rec_off = malloc((n + 1) * sizeof(uint64_t));
+  x->hdr_off = malloc((n + 1) * sizeof(uint64_t));
+  x->seg     = malloc((n + 1) * 5 * sizeof(uint32_t));
+  x->len     = malloc((n + 1) * sizeof(uint32_t));
+  x->hdr4    = malloc((n + 1) * 4 * sizeof(int32_t));
+  x->prefix  = malloc(strlen(p->x.prefix) + 1);
+  if (!x->rec_off || !x->hdr_off || !x->seg || !x->len || !x->hdr4 || !x->prefix) { dx_qv_index_free(x); return DX_E_NOMEM; }
+  strcpy(x->prefix, p->x.prefix);
+  memcpy(x->len, p->x.len, n * sizeof(uint32_t));
+  memcpy(x->hdr4, p->x.hdr4, n * 4 * sizeof(int32_t));
+  if (p->ctx != NULL)
+    { if ((rc = dx_d2h(p->ctx, x->rec_off, p->dix.d_rec_off, (n + 1) * 8)) == DX_OK &&
+          (rc = dx_d2h(p->ctx, x->hdr_off, p->dix.d_hdr_off, (n + 1) * 8)) == DX_OK && n > 0)
+        rc = dx_d2h(p->ctx, x->seg, p->dix.d_seg, n * 20);
+    }
+  else
+    { memcpy(x->rec_off, p->x.rec_off, (n + 1) * 8);
+      memcpy(x->hdr_off, p->x.hdr_off, (n + 1) * 8);
+      memcpy(x->seg, p->x.seg, n * 20);
+    }
+  if (rc != DX_OK) dx_qv_index_free(x);
+  return rc;
+}
+
 /* ---- a text larger than the device (or than DEXGPU_TEXT_BUDGET): slices of whole entries ------------------------------
  * The reference writes entry after entry (undexqv.c:182-207).  Here: per slice of at most `cap` bytes of text, the slice's
  * records -- the whole image stays on the device when it is there already (a plan made there) or fits beside a slice's text,

@@ -461,6 +461,9 @@ int  dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, 
  * A text that does not fit the device beside the image (or DEXGPU_TEXT_BUDGET bytes) comes out in slices of whole entries. */
 int  dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexqv_plan **plan, size_t *out_len);
 int  dx_file_undexqv_run (dx_ctx *ctx, const dx_undexqv_plan *plan, int upper, dx_sink_fn sink, void *user);
+/* The record index the plan holds, as host arrays of the caller's (release with dx_qv_index_free; no group index): where every
+ * record and segment of the image stands -- what the walk found, wherever it ran.                                       */
+int  dx_file_undexqv_plan_index(const dx_undexqv_plan *plan, dx_qv_index *idx);
 void dx_file_undexqv_plan_free(dx_undexqv_plan *plan);
 void dx_file_free(void *p);
 

@@ -1567,12 +1567,17 @@ print("NOT REACHED", flush=True)
     assert b"not the ones QVcoding_Scan1 was given" in r.stderr
 
 
-def test_old_name_decode_shims_like_undexqv(ctx, tmp_path):
+@pytest.mark.parametrize("walk", ["host", "device"])
+def test_old_name_decode_shims_like_undexqv(ctx, tmp_path, monkeypatch, walk):
     """include/dexcompat.h: Read_QVcoding / Uncompress_Next_QVentry driven the way undexqv.c:101-208 drives them -- the
     caller reads the 0x55aa key and, per entry, the framing bytes itself through the same FILE*, the shim hands out the
     five lines (lower-case tags) and leaves the stream at the next record.  The text put together that way is the
-    reference's `undexqv` output."""
+    reference's `undexqv` output.  (walk: where the shim's plan walks the records -- the host, or the device whatever the
+    file's size: its index then comes down from there, dx_file_undexqv_plan_index.)"""
     import struct
+    if walk == "device":
+        monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")
+        monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
     lib = L.load()
     libc = C.CDLL(None)
     libc.fopen.restype = C.c_void_p
