@@ -387,7 +387,10 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
         ends = np.concatenate([off[1:] - hlen, [text_bytes]]).astype(np.uint64)   # end of each entry's record
         dec_parts = {}
 
-        def decode_all():
+        class _At:                                                # a device address as qv_decode takes it
+            def __init__(self, ptr): self.ptr = ptr
+
+        def decode_all(idx=None):                                 # idx: the device walk's index instead of the encoder's own arrays
           roundtrip, dec_ms = True, 0.0
           dec_parts.clear()
           ctx.trim(1 | 2)                                         # the encoder's scratch and tokens go back to the device first
@@ -400,8 +403,12 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
               o_rel = Ptr(torch.from_numpy((off[a:b] - np.uint64(lo)).view(np.int64)).cuda())
               torch.cuda.synchronize()
               ctx.profile(True)
-              ctx.qv_decode(p_out, Ptr(p_rec.t[a:]), Ptr(p_hoff.t[a:]), Ptr(p_seg.t[5 * a:]), Ptr(t_len[a:]), b - a, True,
-                            Ptr(d_back), o_rel)
+              if idx is None:
+                  ctx.qv_decode(p_out, Ptr(p_rec.t[a:]), Ptr(p_hoff.t[a:]), Ptr(p_seg.t[5 * a:]), Ptr(t_len[a:]), b - a, True,
+                                Ptr(d_back), o_rel)
+              else:
+                  ctx.qv_decode(p_out, _At(idx.rec_off.ptr + 8 * a), _At(idx.hdr_off.ptr + 8 * a), _At(idx.seg.ptr + 20 * a), _At(idx.len.ptr + 4 * a),
+                                b - a, True, Ptr(d_back), o_rel)
               ctx.sync(); torch.cuda.synchronize()
               kt = ctx.kernel_times()
               dec_ms += sum(kt.get(k, (0.0, 0))[0] for k in L.DECODE_KERNELS)
@@ -475,6 +482,11 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                                         "index_identical_to_the_encoders": bool(same),
                                         "stream_GBps_wall": round(float(state["total"]) / (t_w1 - t_w) / 1e9, 1)}
                 roundtrip = roundtrip and same
+                if same:                                          # ... and the stream decoded from THAT index: a bare stream, device only
+                    okw, decw_ms = decode_all(dix)
+                    state["device_walk"].update({"decode_ms_from_this_index": round(decw_ms, 2), "decode_bit_exact": bool(okw),
+                                                 "walk_and_decode_ms": round((kt[0] if kt else 0.0) + decw_ms, 2)})
+                    roundtrip = roundtrip and okw
                 dix.free()
             except Exception as e:
                 ctx.profile(False)
