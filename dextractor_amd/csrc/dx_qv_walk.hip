@@ -42,6 +42,11 @@
 #define WALK_PIECE_MIN ((uint64_t) WALK_PIECE_KB << 10)
 #define WALK_LANES_MAX ((uint64_t) 512 * 1024)
 #define WALK_ROUNDS    48
+// What one lane will walk of its own accord: a damaged stream can claim an entry of 2^31 symbols or a gigabyte of 255s, and a lane
+// is a slow walker (minutes for that; every other lane of the kernel long done).  Entries beyond 4 M symbols (the bound of the
+// guesses too) and headers with more than 64 K leading 255s (16 M wells) are left to the host walk: DX_E_MISMATCH.
+#define WALK_RLEN_MAX  (1 << 22)
+#define WALK_LEAD_MAX  65536u
 
 #define WP_NONE     1u            // no start in this piece
 #define WP_BAD      2u            // a record on this lane's chain did not walk
@@ -393,15 +398,15 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
       else if (ph == PH_HEAD)                                   // walk_framing of dx_host.c (0x55aa-keyed: 32-bit fields)
         { const uint64_t h0 = at;
           int32_t dw = 0;
-          while (at < a.n && a.img[at] == 255) { dw += 255; at += 1; }
-          if (at + 13 > a.n) fail = true;
+          while (at < a.n && a.img[at] == 255 && at - h0 < WALK_LEAD_MAX) { dw += 255; at += 1; }
+          if (at + 13 > a.n || at - h0 >= WALK_LEAD_MAX) fail = true;
           else
             { dw += a.img[at];
               const int32_t beg = (int32_t) bswap_if(load32_at(a.img + at + 1), a.flip), end_ = (int32_t) bswap_if(load32_at(a.img + at + 5), a.flip);
               const int32_t qv  = (int32_t) bswap_if(load32_at(a.img + at + 9), a.flip);
               at += 13;
               rlen = (uint32_t) ((int64_t) end_ - (int64_t) beg);
-              if (end_ < beg || (int64_t) end_ - (int64_t) beg > 0x7fffffff || (uint64_t) rlen > 65536u * 8u * (uint64_t) (a.n - at) + 64u)
+              if (end_ < beg || (int64_t) end_ - (int64_t) beg > WALK_RLEN_MAX || (uint64_t) rlen > 65536u * 8u * (uint64_t) (a.n - at) + 64u)
                 fail = true;
               r.off = h0; r.hdr_bytes = (uint32_t) (at - h0); r.len = rlen; r.dwell = dw; r.beg = beg; r.end = end_; r.qv = qv; r.pad = 0;
               ph = PH_DEL; j = 0; last = 0; nn = 0; clen = rlen;

@@ -159,3 +159,47 @@ def test_device_walk_of_a_byte_swapped_file(ctx, monkeypatch):
     g = x.download()
     x.free(); d.free()
     _same({k: h[k] for k in ("n", "rec_off", "hdr_off", "seg", "len", "hdr4")}, g)
+
+
+def test_device_walk_of_damaged_streams(ctx, monkeypatch):
+    """One byte of a sound image changed, or the image cut: the device walk gives the host walk's index or turns the stream down
+    (DX_E_MISMATCH) -- never another index, never a fault --, and the file driver with the device walk forced on returns what it
+    returns with the walk on the host: the same text, or the same refusal."""
+    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    c = synth.make_quiva(150, seed=71, mean=2500)
+    img = O.dexqv(c.text)
+    coding, flip, prefix, used = api.qv_read_coding(img[2:])
+    first = 2 + used
+    rng = np.random.default_rng(5)
+    outcomes = {"same": 0, "turned down": 0}
+    for k in range(60):
+        bad = bytearray(img)
+        if k % 6 == 5:
+            bad = bad[: int(rng.integers(first + 50, len(img)))]
+        else:
+            at = int(rng.integers(first, len(img)))
+            bad[at] = (bad[at] + int(rng.integers(1, 256))) & 0xff if k % 2 else (255 if bad[at] != 255 else 0)
+        bad = bytes(bad)
+        d = ctx.to_device(np.frombuffer(bad, np.uint8))
+        try:
+            x = ctx.qv_walk_device(d, len(bad), first, coding, 1, flip)
+        except L.DexGPUError as e:
+            assert e.code == -7, e
+            outcomes["turned down"] += 1
+        else:
+            g = x.download()
+            x.free()
+            h = api.qv_walk(bad)                                            # what the device accepts the host accepts, and finds the same
+            _same(h, g)
+            outcomes["same"] += 1
+        d.free()
+        res = []
+        for env in ({"DEXGPU_DEVICE_WALK_MIN": "0"}, {"DEXGPU_HOST_WALK": "1"}):
+            for kk, vv in env.items(): monkeypatch.setenv(kk, vv)
+            try:
+                res.append(ctx.undexqv(bad))
+            except L.DexGPUError as e:
+                res.append(e.code)
+            for kk in env: monkeypatch.delenv(kk)
+        assert res[0] == res[1], (k, type(res[0]), type(res[1]))
+    assert outcomes["same"] > 5 and outcomes["turned down"] > 5, outcomes
