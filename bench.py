@@ -484,7 +484,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                 roundtrip = roundtrip and same
                 if same:                                          # ... and the stream decoded from THAT index: a bare stream, device only
                     okw, decw_ms = decode_all(dix)
-                    state["device_walk"].update({"decode_ms_from_this_index": round(decw_ms, 2), "decode_bit_exact": bool(okw),
+                    state["device_walk"].update({"decode_ms_from_this_index": round(decw_ms, 2), "decode_bit_exact": bool(okw), "ms_by_kernel": dict(dec_parts),
                                                  "walk_and_decode_ms": round((kt[0] if kt else 0.0) + decw_ms, 2)})
                     roundtrip = roundtrip and okw
                 dix.free()

@@ -76,7 +76,7 @@ def check(root):
             # the decoders: totals over the passes of the verification (launch counts differ from pass to pass)
             if which == "profiled_bench.json":
                 tot = {}
-                for key in ("decode", "decode_indexed", "decode_walk_indexed"):
+                for key in ("decode", "decode_indexed", "decode_walk_indexed", "device_walk"):
                     for k, v in ((d.get(key) or {}).get("ms_by_kernel") or {}).items():
                         tot[k] = tot.get(k, 0.0) + v
                 for k, v in tot.items():
