@@ -15,7 +15,16 @@ hipError_t dx_hip_malloc(void **p, size_t bytes)
     { const char *e = getenv("DEXGPU_POISON");
       poison = (e != NULL && e[0] != '\0') ? (int) (strtol(e, NULL, 0) & 0xff) : -1;
     }
-  const hipError_t rc = hipMalloc(p, bytes);
+  // DEXGPU_FAIL_MALLOC_OVER=<bytes> [DEXGPU_FAIL_MALLOC_UNDER=<bytes>] (tests): allocations beyond that size (and below the other) fail as if the device were full
+  const char *fo = getenv("DEXGPU_FAIL_MALLOC_OVER");       // (looked up every time: a test sets it around one call;
+  const char *fu = getenv("DEXGPU_FAIL_MALLOC_UNDER");      //  with _UNDER: only allocations below that size)
+  long long fail_over = (fo != NULL && fo[0] != '\0') ? strtoll(fo, NULL, 0) : -1;
+  if (fail_over >= 0 && fu != NULL && fu[0] != '\0' && (long long) bytes >= strtoll(fu, NULL, 0)) fail_over = -1;
+  const hipError_t rc = (fail_over >= 0 && bytes > (size_t) fail_over) ? hipErrorOutOfMemory : hipMalloc(p, bytes);
+  if (rc != hipSuccess)                                    // the runtime keeps a failed call's error until it is read: the next
+    { (void) hipGetLastError();                            // launch's hipGetLastError() would report THIS one (a caller that
+      *p = NULL;                                           // goes on another way after a failed allocation must find none)
+    }
   if (rc == hipSuccess && poison >= 0 && bytes)
     { (void) hipMemset(*p, poison, bytes);
       (void) hipDeviceSynchronize();

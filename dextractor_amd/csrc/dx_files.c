@@ -922,9 +922,11 @@ struct dx_undexqv_plan
     uint64_t      *ooff, *hat;    /* per entry: where its five data lines start in the text; where its header line starts in hd */
     /* a plan made on the device (dx_file_undexqv_plan_on): the image is there already, and so is the index */
     dx_ctx        *ctx;
-    void          *d_in;
-    dx_qv_dindex   dix;
+    void          *d_in;          /* the image, when it is on ctx's device already */
+    dx_qv_dindex   dix;           /* the index, when it was made there (d_rec_off != NULL) */
   };
+#define PLAN_HAS_IMAGE(p) ((p)->ctx != NULL && (p)->d_in != NULL)
+#define PLAN_HAS_INDEX(p) ((p)->ctx != NULL && (p)->dix.d_rec_off != NULL)
 
 void dx_file_undexqv_plan_free(dx_undexqv_plan *p)
 { if (p == NULL) return;
@@ -972,7 +974,7 @@ int dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexq
 { dx_undexqv_plan *p;
   uint16_t key;
   size_t   at = 2, used = 0;
-  int      rc;
+  int      rc, keep = 0;
   const char *e = getenv("DEXGPU_DEVICE_WALK_MIN");
   const size_t least = e != NULL && *e ? (size_t) strtoull(e, NULL, 10) : DX_DEVICE_WALK_MIN;
 
@@ -997,10 +999,16 @@ int dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexq
   }
   if (rc != DX_OK) goto host;
   at += used;
+  { /* image, walk scratch (0.44 of the image) and index must fit together; asked before anything goes up */
+    uint64_t fr = 0, all = 0;
+    if (dx_mem_info(ctx, &fr, &all) == DX_OK && fr > 0 && 1.55 * (double) n + (double) (128 << 20) > 0.95 * (double) fr)
+      goto host;
+  }
   p->ctx = ctx;
-  if ((rc = dx_malloc(ctx, n + 64, &p->d_in)) != DX_OK || (rc = dx_h2d(ctx, p->d_in, img, n)) != DX_OK) goto host;
+  if ((rc = dx_malloc(ctx, n + 64, &p->d_in)) != DX_OK) { p->d_in = NULL; goto host; }
+  if ((rc = dx_h2d(ctx, p->d_in, img, n)) != DX_OK) goto host;
   rc = dx_qv_walk_device(ctx, p->d_in, n, at, &p->x.coding, 1, p->x.flip, &p->dix);
-  if (rc != DX_OK) goto host;
+  if (rc != DX_OK) { keep = rc != DX_E_NOMEM && rc != DX_E_HIP; goto host; }
   p->x.n    = p->dix.n;
   p->x.len  = malloc((p->x.n + 1) * sizeof(uint32_t));
   p->x.hdr4 = malloc((p->x.n + 1) * 4 * sizeof(int32_t));
@@ -1013,8 +1021,16 @@ int dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexq
   return DX_OK;
 
 host:                                                     /* not the device's: the host walk (and its verdict) */
-  dx_file_undexqv_plan_free(p);
-  return dx_file_undexqv_plan(img, n, plan, out_len);
+  { void *d_in = keep ? p->d_in : NULL;                   /* an image that is up stays up: the run wants it there */
+    if (d_in != NULL) p->d_in = NULL;
+    dx_file_undexqv_plan_free(p);
+    rc = dx_file_undexqv_plan(img, n, plan, out_len);
+    if (d_in != NULL)
+      { if (rc == DX_OK) { (*plan)->ctx = ctx; (*plan)->d_in = d_in; }
+        else             (void) dx_free(ctx, d_in);
+      }
+    return rc;
+  }
 fail:
   dx_file_undexqv_plan_free(p);
   return rc;
@@ -1064,7 +1080,7 @@ int dx_file_undexqv_plan_index(const dx_undexqv_plan *p, dx_qv_index *x)
   strcpy(x->prefix, p->x.prefix);
   memcpy(x->len, p->x.len, n * sizeof(uint32_t));
   memcpy(x->hdr4, p->x.hdr4, n * 4 * sizeof(int32_t));
-  if (p->ctx != NULL)
+  if (PLAN_HAS_INDEX(p))
     { if ((rc = dx_d2h(p->ctx, x->rec_off, p->dix.d_rec_off, (n + 1) * 8)) == DX_OK &&
           (rc = dx_d2h(p->ctx, x->hdr_off, p->dix.d_hdr_off, (n + 1) * 8)) == DX_OK && n > 0)
         rc = dx_d2h(p->ctx, x->seg, p->dix.d_seg, n * 20);
@@ -1083,8 +1099,9 @@ int dx_file_undexqv_plan_index(const dx_undexqv_plan *p, dx_qv_index *x)
  * records -- the whole image stays on the device when it is there already (a plan made there) or fits beside a slice's text,
  * else the slice's bytes are uploaded -- are decoded into one buffer that goes out before the next slice comes in.
  * Same text; such a file is bound by the host link.                                                               */
-static int undexqv_sliced(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sink_fn sink, void *user, size_t cap, int whole_in)
-{ dpool     pool = { {0}, 0, ctx };
+static int undexqv_sliced(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sink_fn sink, void *user, size_t cap, int whole_in_)
+{ const int whole_in = whole_in_ || PLAN_HAS_IMAGE(p);    /* (an image that is there is there whole) */
+  dpool     pool = { {0}, 0, ctx };
   const uint64_t n = p->x.n;
   void     *d_in = NULL, *d_rec = NULL, *d_hoff = NULL, *d_seg = NULL, *d_len = NULL, *d_out = NULL, *d_ooff = NULL;
   uint64_t *rel = NULL, i0, i1, i, most = 0;
@@ -1103,11 +1120,14 @@ static int undexqv_sliced(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_s
   rel = malloc((most + 1) * 2 * sizeof(*rel));
   if (rel == NULL) return DX_E_NOMEM;
   TRY(dx_qv_set_coding(ctx, &p->x.coding, 0));
-  if (p->ctx != NULL)
-    { d_in = p->d_in; d_rec = p->dix.d_rec_off; d_hoff = p->dix.d_hdr_off; d_seg = p->dix.d_seg; d_len = p->dix.d_len; }
+  if (PLAN_HAS_IMAGE(p))  d_in = p->d_in;
+  else if (whole_in)      TRY(dupload(&pool, p->img, p->n, &d_in));
+  else                    TRY(dalloc(&pool, imax, &d_in));
+  if (PLAN_HAS_INDEX(p))
+    { d_rec = p->dix.d_rec_off; d_hoff = p->dix.d_hdr_off; d_seg = p->dix.d_seg; d_len = p->dix.d_len; }
   else
-    { if (whole_in) { TRY(dupload(&pool, p->img, p->n, &d_in)); TRY(dupload(&pool, p->x.rec_off, (n + 1) * 8, &d_rec)); }
-      else          { TRY(dalloc(&pool, imax, &d_in)); TRY(dalloc(&pool, (most + 1) * 8, &d_rec)); }
+    { if (whole_in) TRY(dupload(&pool, p->x.rec_off, (n + 1) * 8, &d_rec));
+      else          TRY(dalloc(&pool, (most + 1) * 8, &d_rec));
       TRY(dupload(&pool, p->x.hdr_off, (n + 1) * 8, &d_hoff));
       TRY(dupload(&pool, p->x.seg, n * 5 * 4, &d_seg));
       TRY(dupload(&pool, p->x.len, n * 4, &d_len));
@@ -1121,7 +1141,7 @@ static int undexqv_sliced(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_s
       while (i1 < n && TEXT_AT(i1 + 1) - t0 <= cap) i1++;
       for (i = i0; i < i1; i++) rel[i - i0] = p->ooff[i] - t0;
       TRY(dx_h2d(ctx, d_ooff, rel, (i1 - i0) * 8));
-      if (p->ctx != NULL || whole_in)
+      if (whole_in)
         rec = (const uint64_t *) d_rec + i0;
       else                                                /* this slice's records, their offsets from the slice's first byte */
         { const uint64_t b0 = p->x.rec_off[i0];
@@ -1162,7 +1182,7 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
           if (v && v < p->total) cap = (size_t) (v < 65536u ? 65536u : v);
         }
       else if (dx_mem_info(ctx, &fr, &all) == DX_OK && fr > 0)
-        { const double in = p->ctx != NULL ? 0.0 : (double) p->n;
+        { const double in = PLAN_HAS_IMAGE(p) ? 0.0 : (double) p->n;
           if (in + (double) p->total + 48.0 * (double) p->x.n > 0.9 * (double) fr)
             { whole_in = in <= 0.4 * (double) fr;
               cap = (size_t) ((0.9 * (double) fr - (whole_in ? in : 0.0) - 48.0 * (double) p->x.n) / (whole_in ? 1.0 : 1.4));
@@ -1170,15 +1190,16 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
             }
         }
       if (cap)
-        return undexqv_sliced(ctx, p, upper, sink, user, cap, getenv("DEXGPU_SLICE_INPUT") != NULL && p->ctx == NULL ? 0 : whole_in);   /* (DEXGPU_SLICE_INPUT: tests) */
+        return undexqv_sliced(ctx, p, upper, sink, user, cap, getenv("DEXGPU_SLICE_INPUT") != NULL && !PLAN_HAS_IMAGE(p) ? 0 : whole_in);   /* (DEXGPU_SLICE_INPUT: tests) */
     }
   if (p->x.n > 0)
     { TRY(dx_qv_set_coding(ctx, &p->x.coding, 0));
-      if (p->ctx != NULL)                                 /* image and index are on the device already */
-        { d_in = p->d_in; d_rec = p->dix.d_rec_off; d_hoff = p->dix.d_hdr_off; d_seg = p->dix.d_seg; d_len = p->dix.d_len; }
+      if (PLAN_HAS_IMAGE(p)) d_in = p->d_in;              /* (the image is on the device already) */
+      else                   TRY(dupload(&pool, p->img, p->n, &d_in));
+      if (PLAN_HAS_INDEX(p))                              /* (and so is the index) */
+        { d_rec = p->dix.d_rec_off; d_hoff = p->dix.d_hdr_off; d_seg = p->dix.d_seg; d_len = p->dix.d_len; }
       else
-        { TRY(dupload(&pool, p->img, p->n, &d_in));
-          TRY(dupload(&pool, p->x.rec_off, (p->x.n + 1) * 8, &d_rec));
+        { TRY(dupload(&pool, p->x.rec_off, (p->x.n + 1) * 8, &d_rec));
           TRY(dupload(&pool, p->x.hdr_off, (p->x.n + 1) * 8, &d_hoff));
           TRY(dupload(&pool, p->x.seg, p->x.n * 5 * 4, &d_seg));
           TRY(dupload(&pool, p->x.len, p->x.n * 4, &d_len));

@@ -47,6 +47,7 @@
 // guesses too) and headers with more than 64 K leading 255s (16 M wells) are left to the host walk: DX_E_MISMATCH.
 #define WALK_RLEN_MAX  (1 << 22)
 #define WALK_LEAD_MAX  65536u
+#define WALK_RECLUSTER 8u               // clusters of guesses a lane looks for by itself before it leaves its piece to the chain
 
 #define WP_NONE     1u            // no start in this piece
 #define WP_BAD      2u            // a record on this lane's chain did not walk
@@ -187,16 +188,38 @@ __device__ __forceinline__ u32x4 load16_within(const walk_args &a, const uint8_t
   return *(const u32x4_u *) p;
 }
 
-__device__ __forceinline__ void w_fill_d(wrd_d &r, const walk_args &a)
-{ if (r.nb <= 32)
+// The request for a lane's next 16 bytes and the wait for it are the wave's, not the lane's: one counter (vmcnt) a wave, loads
+// retiring in the order they were issued -- and in every look-up of a wave SOME lane is taking up its next 16 bytes while some
+// other lane asked for its own a moment ago.  Left to the compiler every such step is `s_waitcnt vmcnt(0)`: a full memory round
+// trip per look-up (what round 4's 45 ms were: 63 k steps a wave of ~0.7 us).  So the request is made behind the compiler's
+// back (inline assembly: no wait is inserted for it) and every step of a reader -- w_tick_d, once in front of every refill --
+// issues ONE one-word load of its own (a.tail: the same address for every lane, a cache hit) and then waits until at most
+// WALK_INFLIGHT loads are under way.  A lane takes up its 16 bytes three words after it asked for them: >= 81 bits of codes
+// (17 <= bits in the buffer in front of a refill <= 32), at <= 16 bits a step that is >= 6 steps, i.e. >= 6 loads issued behind
+// the request: with at most 5 under way the request has retired.  (The one-word load is what makes the count hold whatever the
+// other lanes do; loads the compiler knows of only make either side's waits more conservative: in-order retirement.)
+#define WALK_INFLIGHT 5
+__device__ __forceinline__ void w_request_d(wrd_d &r, const walk_args &a)
+{ const uint64_t off = (uint64_t) (r.q - a.img);
+  const uint64_t t   = off - a.tail_at;
+  const uint8_t *p   = off < a.tail_at ? r.q : a.tail + (t < 240u ? t : 240u);
+  asm volatile("global_load_dwordx4 %[d], %[p], off" : [d] "+v"(r.nxt) : [p] "v"(p) : "memory");
+  r.q += 16;
+}
+__device__ __forceinline__ void w_tick_d(wrd_d &r, const walk_args &a, uint32_t &beat)
+{ asm volatile("global_load_dword %[b], %[z], %[t]\n\ts_waitcnt vmcnt(%[n])"
+               : [b] "+v"(beat), "+v"(r.nxt) : [z] "v"(0u), [t] "s"(a.tail), [n] "n"(WALK_INFLIGHT) : "memory");
+}
+
+__device__ __forceinline__ void w_fill_d(wrd_d &r, const walk_args &a, uint32_t &beat)
+{ w_tick_d(r, a, beat);
+  if (r.nb <= 32)
     { if (r.k == 0)                                      // (the 16 bytes asked for three words ago)
         { r.cur = r.nxt;
           r.k   = 4;
         }
       else if (r.k == 3)                                 // the next 16: asked for here, looked at when these are used up
-        { r.nxt = load16_within(a, r.q);
-          r.q  += 16;
-        }
+        w_request_d(r, a);
       const uint32_t w = bswap_if(r.cur.x, a.flip);
       r.cur.x = r.cur.y; r.cur.y = r.cur.z; r.cur.z = r.cur.w;
       r.k   -= 1;
@@ -212,7 +235,7 @@ __device__ __forceinline__ void w_open_d(wrd_d &r, const walk_args &a, const uin
   // wait for everything outstanding at every refill -- the request for the next 16 bytes, made a moment ago, included
   __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
 }
-__device__ __forceinline__ uint32_t w_peek_d(wrd_d &r, const walk_args &a) { w_fill_d(r, a); return (uint32_t) (r.buf >> 48); }
+__device__ __forceinline__ uint32_t w_peek_d(wrd_d &r, const walk_args &a, uint32_t &beat) { w_fill_d(r, a, beat); return (uint32_t) (r.buf >> 48); }
 __device__ __forceinline__ void w_skip_d(wrd_d &r, uint32_t n) { r.buf <<= n; r.nb -= (int) n; }
 
 __device__ __forceinline__ uint32_t pad_words_d(uint64_t T, uint32_t last)      // QV.c:436-442
@@ -275,11 +298,13 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
   // the lane's state
   uint64_t at;                         // PH_HEAD: the record's first byte; in a segment: the segment's first byte
   uint32_t ph = PH_HEAD, rlen = 0, j = 0, last = 0, nn = 0, clen = 0;
+  uint32_t reclusters = 0;
   uint32_t trial = 0, ci = 0, nc = 0;  // trial: the record being walked is a guess (candidate ci of the piece's nc)
   uint64_t budget = ~0ull;
   walk_rec_d r;
   wrd_d rd;
   bool live = true;
+  uint32_t beat = 0;                   // (w_tick_d's one-word load lands here)
   rd.nw = 0; rd.nb = 0; rd.k = 0; rd.buf = 0; rd.q = a.img;
   rd.cur = u32x4{ 0u, 0u, 0u, 0u }; rd.nxt = rd.cur;
   if (todo || k == 0)
@@ -300,7 +325,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
           #pragma unroll 1
 #if WALK_BRANCHY
           for (int it = 0; it < WALK_BURST && more; it++)
-            { w_fill_d(rd, a);
+            { w_fill_d(rd, a, beat);
               const uint32_t g = tab[(uint32_t) (rd.buf >> 52)], cnt = g >> 8;
               more = g != 0u && j + cnt <= rlen;
               if (more)
@@ -314,14 +339,13 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
           // burst has left behind shifts by nothing and counts nothing.  With branches a look-up was 28 instructions of which ten
           // scalar (execution masks) and five branches; the scalar unit is one to a CU.
           for (int it = 0; it < WALK_BURST; it++)
-            { const bool need = rd.nb <= 32;
+            { w_tick_d(rd, a, beat);
+              const bool need = rd.nb <= 32;
               if (need && (rd.k == 3u || rd.k == 0u))          // (every sixth refill or so: these two stay branches -- a select
                 { if (rd.k == 0u)                              //  would look at nxt, i.e. wait for it, at every look-up)
                     { rd.cur = rd.nxt; rd.k = 4; }             // the 16 bytes asked for three words ago
                   else
-                    { rd.nxt = load16_within(a, rd.q);         // the next 16: asked for here, looked at when these are used up
-                      rd.q  += 16;
-                    }
+                    w_request_d(rd, a);                        // the next 16: asked for here, looked at when these are used up
                 }
               const uint32_t w = bswap_if(rd.cur.x, a.flip);
               rd.cur.x = need ? rd.cur.y : rd.cur.x; rd.cur.y = need ? rd.cur.z : rd.cur.y; rd.cur.z = need ? rd.cur.w : rd.cur.z;
@@ -337,10 +361,12 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
               if (!__any(more)) break;
             }
 #endif
+          if (32ull * rd.nw - (uint64_t) rd.nb > budget)        // a guess that walks on and on (garbage may claim any length, and zeros
+            { fail = true; more = true; }                       // behind the image read as codes): every burst, whatever became of it
           if (!more)
             { const bool runs = (line == 0 && a.delChar >= 0) || (line == 3 && a.subChar >= 0);
               if (j < rlen)                                     // one step of another kind
-                { uint32_t w = w_peek_d(rd, a);
+                { uint32_t w = w_peek_d(rd, a, beat);
                   bool sym = true;                              // a symbol's code is to be passed
                   if (runs)                                     // walk_runs: the run code alone first
                     { const uint32_t e1 = S.r1[line ? 1u : 0u][w >> (16 - WALK_WIN)];
@@ -352,12 +378,12 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                           if (last == 0) fail = true;
                           w_skip_d(rd, last);
                           if (c == 255u)
-                            { c = w_peek_d(rd, a); w_skip_d(rd, 16u); last = 16; }
+                            { c = w_peek_d(rd, a, beat); w_skip_d(rd, 16u); last = 16; }
                         }
                       if (c > rlen - j) fail = true;
                       j  += c;
                       sym = !fail && j < rlen;
-                      if (sym) w = w_peek_d(rd, a);
+                      if (sym) w = w_peek_d(rd, a, beat);
                     }
                   if (sym)                                      // walk_plain's single code; walk_runs' symbol behind the run
                     { const uint32_t f = S.one[line][w >> (16 - WALK_WIN)] & 15u;
@@ -368,7 +394,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                           if (last == 0) fail = true;
                           w_skip_d(rd, last);
                           if (a.esc[line] && (e & 0xffu) == 255u)
-                            { w_fill_d(rd, a); w_skip_d(rd, 8u); last = 8; }
+                            { w_fill_d(rd, a, beat); w_skip_d(rd, 8u); last = 8; }
                         }
                       j  += 1;
                       nn += 1;
@@ -435,8 +461,9 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
               else                                              // none of the cluster held (rare): the next cluster, found by the lane itself
                 { uint64_t *c = cand + k * WALK_CAND, last = 0;   // (through memory: no registers for what happens once in ten thousand pieces)
                   uint32_t m = 0;
+                  reclusters += 1;                              // (WALK_RECLUSTER of them at most: a crafted piece may hold thousands)
                   #pragma unroll 1
-                  for (uint64_t p = c[0] + 1; p < hi && (m == 0 || p <= last + 16u) && m < WALK_CAND; p++)
+                  for (uint64_t p = c[0] + 1; reclusters <= WALK_RECLUSTER && p < hi && (m == 0 || p <= last + 16u) && m < WALK_CAND; p++)
                     if (a.img[p] != 255 && header_plausible_d(a, p)) { c[m++] = p; last = p; }
                   if (m == 0) { out.flags = WP_NONE; live = false; }
                   else
@@ -456,6 +483,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
       out.lead255 = c;
     }
   (void) rounds_;
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(beat), "+v"(rd.nxt) :: "memory");       // (nothing of w_tick_d's / w_request_d's under way behind the loop)
   pc[k] = out;
 }
 
@@ -510,6 +538,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   memset(out, 0, sizeof(*out));
   if (!newv)                       // 16-bit framing fields are too easily plausible (dx_host.c): the host walk's
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_walk_device: a stream with 16-bit framing fields is walked on the host");
+  DX_HIP(ctx, hipSetDevice(ctx->device));         // (the scratch and the index go where the context's stream runs)
   int rc = dx_after_pending(ctx);
   if (rc != DX_OK) return rc;
 
@@ -527,6 +556,13 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   }
   const uint64_t P = a.pieces;
   const uint32_t rcap = (uint32_t) (a.piece / 128u);
+  { // does the scratch fit (56 bytes a possible record, 0.44 of the stream) with room for the index behind it?  Asked first: a
+    // failed allocation half way costs the allocations before it, and the caller has another way (the host walk).
+    uint64_t fr = 0, all = 0;
+    const double need = (double) P * ((double) rcap * sizeof(walk_rec_d) + sizeof(walk_piece_d) + WALK_CAND * 8 + 48) + 0.06 * (double) (n - first) + (64 << 20);
+    if (dx_mem_info(ctx, &fr, &all) == DX_OK && fr > 0 && need > (double) fr)
+      return dx_fail(ctx, DX_E_NOMEM, "dx_qv_walk_device: %.1f GB of scratch do not fit the device's free %.1f GB", need / 1e9, (double) fr / 1e9);
+  }
 
   uint8_t  *blob = (uint8_t *) malloc(WALK_BLOB_BYTES);
   uint8_t  *d_blob = NULL, *d_tail = NULL;
@@ -538,7 +574,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   uint8_t  *onchain = (uint8_t *) calloc(P, 1);
   uint64_t N = 0;
 #define WALK_FAIL(code, ...) do { rc = dx_fail(ctx, code, __VA_ARGS__); goto done; } while (0)
-#define WALK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) WALK_FAIL(DX_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+#define WALK_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (void) hipGetLastError(); WALK_FAIL(DX_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } } while (0)
   if (!blob || !pc || !dst || !onchain) WALK_FAIL(DX_E_NOMEM, "dx_qv_walk_device: out of host memory");
   memset(dst, 0, 4 * P * 8);
   rc = dx_walk_luts_build(cd, blob, a.esc);

@@ -1374,6 +1374,38 @@ def test_file_pointer_shims_in_the_order_of_dexqv(tmp_path):
     assert ran >= 5
 
 
+def test_the_references_own_mains_over_the_shims(tmp_path):
+    """oracle/_ref_compat/{dexqv,undexqv}: the reference's OWN dexqv.c / undexqv.c (main() and all, with its DB.c), compiled
+    unchanged against include/dexcompat.h in place of QV.h and linked with libdexgpu.so in place of QV.c (oracle/Makefile:
+    compat).  Its main() drives QVcoding_Scan / Create_QVcoding / Write_QVcoding / Compress_Next_QVentry (dexqv.c:81-141) and
+    Read_QVcoding / Uncompress_Next_QVentry (undexqv.c:112-208) -- the shims, the GPU behind them -- and must leave the golden
+    bytes: every .quiva golden -> its .dexqv, and back (-U) -> the reference's own round trip."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = {t: os.path.join(root, "oracle", "_ref_compat", t) for t in ("dexqv", "undexqv")}
+    if not all(os.path.isfile(e) for e in exe.values()):
+        pytest.skip("oracle/_ref_compat not built (make -C oracle compat needs /root/reference)")
+    ran = 0
+    for case in O.cases("quiva"):
+        if case.get("expect_error"):
+            continue
+        d = tmp_path / case["name"]
+        d.mkdir()
+        src = d / "x.quiva"
+        src.write_bytes(O.golden(case["input"] + ".quiva"))
+        r = subprocess.run([exe["dexqv"], "-k"] + case["flags"] + [str(src)], capture_output=True, timeout=180, cwd=str(d))
+        assert r.returncode == 0, (case["name"], r.stderr[-500:])
+        got = (d / "x.dexqv").read_bytes()
+        assert got == O.golden(case["name"] + ".dexqv"), case["name"]
+        src.unlink()
+        r = subprocess.run([exe["undexqv"], "-k", "-U", str(d / "x.dexqv")], capture_output=True, timeout=180, cwd=str(d))
+        assert r.returncode == 0, (case["name"], r.stderr[-500:])
+        rt = O.golden(case["input"] + ".quiva") if case["rt_is_input"] else O.golden(case["name"] + ".rt.quiva")
+        assert src.read_bytes() == rt, case["name"]
+        ran += 1
+    assert ran >= 5
+
+
 @pytest.mark.parametrize("name,kind", [("ta_small.legacy", "dexta"), ("ta_small.swapped", "dexta"),
                                        ("ta_small.legacy_swapped", "dexta"), ("ar_small.swapped", "dexar")])
 def test_unpack2_older_and_other_endian_layouts_golden(ctx, name, kind):

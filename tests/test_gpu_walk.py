@@ -203,3 +203,37 @@ def test_device_walk_of_damaged_streams(ctx, monkeypatch):
             for kk in env: monkeypatch.delenv(kk)
         assert res[0] == res[1], (k, type(res[0]), type(res[1]))
     assert outcomes["same"] > 5 and outcomes["turned down"] > 5, outcomes
+
+
+def test_a_walk_that_cannot_allocate_leaves_the_host_walk_a_clean_slate(ctx, monkeypatch):
+    """The device walk's scratch does not fit (DEXGPU_FAIL_MALLOC_OVER: allocations beyond that size fail like a full device):
+    dx_qv_walk_device reports it, and the file driver goes on with the host walk -- whose launches must not trip over the failed
+    allocation's error (the runtime keeps it until it is read)."""
+    monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")
+    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    c = synth.make_quiva(400, seed=81, mean=3000)
+    img = O.dexqv(c.text)
+    want = O.undexqv(img)
+    coding, flip, prefix, used = api.qv_read_coding(img[2:])
+    d = ctx.to_device(np.frombuffer(img, np.uint8))
+    monkeypatch.setenv("DEXGPU_FAIL_MALLOC_OVER", str(len(img) // 8))       # the records' scratch (0.44 of the image) fails, the tables do not
+    with pytest.raises(L.DexGPUError) as e:
+        ctx.qv_walk_device(d, len(img), 2 + used, coding, 1, flip)
+    assert e.value.code in (-2, -6), e.value                                 # DX_E_NOMEM / DX_E_HIP
+    monkeypatch.delenv("DEXGPU_FAIL_MALLOC_OVER")
+    d.free()
+    # through the file driver: the image goes up (it fits), the walk's scratch does not, the host plan takes over
+    monkeypatch.setenv("DEXGPU_FAIL_MALLOC_OVER", str(len(img) // 8))
+    monkeypatch.setenv("DEXGPU_FAIL_MALLOC_UNDER", str(len(img) // 2 + len(img) // 4))
+    ctx.profile(True)
+    got = ctx.undexqv(img)
+    assert "k_qv_walk" not in ctx.kernel_times()                             # (the device walk did not get as far as a kernel)
+    ctx.profile(False)
+    monkeypatch.delenv("DEXGPU_FAIL_MALLOC_OVER")
+    monkeypatch.delenv("DEXGPU_FAIL_MALLOC_UNDER")
+    assert got == want
+    monkeypatch.setenv("DEXGPU_FAIL_MALLOC_OVER", str(len(img) // 8))       # ... and when not even the image goes up
+    with pytest.raises(L.DexGPUError):
+        ctx.undexqv(img)
+    monkeypatch.delenv("DEXGPU_FAIL_MALLOC_OVER")
+    assert ctx.undexqv(img) == want                                          # nothing of it is left behind
