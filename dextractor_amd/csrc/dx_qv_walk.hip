@@ -32,9 +32,9 @@
 #include <stdlib.h>
 
 #ifndef WALK_BLOCK
-#define WALK_BLOCK     768              // two workgroups a CU (80 KB of LDS each): 24 waves, what the registers allow
+#define WALK_BLOCK     1024             // one workgroup a CU: 80 KB of tables and 72 KB of rings (a lane's next 16 words) in LDS
 #endif
-#define WALK_WGS_PER_CU 2
+#define WALK_WGS_PER_CU 1
 #define WALK_CAND      4u
 #ifndef WALK_PIECE_KB
 #define WALK_PIECE_KB 32
@@ -47,6 +47,13 @@
 // guesses too) and headers with more than 64 K leading 255s (16 M wells) are left to the host walk: DX_E_MISMATCH.
 #define WALK_RLEN_MAX  (1 << 22)
 #define WALK_LEAD_MAX  65536u
+// A header that is no header (1.4e-8 of all offsets read plausibly) claims whatever its bytes say -- two million symbols on average --
+// and any bits walk as codes (a Huffman code is complete): the lane that tries it walks garbage until its budget is spent, alone,
+// long after every other wave has left (one such guess in 250 000 pieces made a 30 ms kernel a 52 ms one).  So a GUESS is taken
+// only when it claims at most WALK_TRIAL_RLEN symbols, and is given 32 bits a claimed symbol (no stream of a true record
+// averages 8 bits a code), two pieces' bytes at most; a piece whose first record is longer is left to the chain, which walks from
+// where it arrives without guessing.
+#define WALK_TRIAL_RLEN 65536
 #define WALK_RECLUSTER 8u               // clusters of guesses a lane looks for by itself before it leaves its piece to the chain
 
 #define WP_NONE     1u            // no start in this piece
@@ -72,14 +79,14 @@ __device__ __forceinline__ uint32_t bswap_if(uint32_t v, int flip) { return flip
 __device__ __forceinline__ uint32_t load32_at(const uint8_t *p) { return *(const u32_u *) p; }
 
 // header_plausible of dx_host.c, word for word
-__device__ __forceinline__ bool header_plausible_d(const walk_args &a, uint64_t at)
+__device__ __forceinline__ bool header_plausible_d(const walk_args &a, uint64_t at, int32_t maxlen = (1 << 22))
 { int k = 0;
   while (at < a.n && a.img[at] == 255 && k < 16) { at += 1; k += 1; }
   if (at + 13 > a.n) return false;
   at += 1;
   const int32_t beg = (int32_t) bswap_if(load32_at(a.img + at), a.flip), end_ = (int32_t) bswap_if(load32_at(a.img + at + 4), a.flip);
   const int32_t qv  = (int32_t) bswap_if(load32_at(a.img + at + 8), a.flip);
-  return beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= (1 << 22) && qv >= 0 && qv < 1000000 &&
+  return beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= maxlen && qv >= 0 && qv < 1000000 &&
          (uint64_t) (end_ - beg) <= 8u * (uint64_t) (a.n - at);
 }
 
@@ -98,7 +105,7 @@ __device__ __forceinline__ bool header_fast_d(const walk_args &a, uint64_t p, co
 { const int32_t beg  = (int32_t) bswap_if((v.x >> 8) | (v.y << 24), a.flip);
   const int32_t end_ = (int32_t) bswap_if((v.y >> 8) | (v.z << 24), a.flip);
   const int32_t qv   = (int32_t) bswap_if((v.z >> 8) | (v.w << 24), a.flip);
-  return (v.x & 0xffu) != 255u && beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= (1 << 22) && qv >= 0 && qv < 1000000 &&
+  return (v.x & 0xffu) != 255u && beg >= 0 && beg < (1 << 28) && end_ >= beg && end_ - beg <= WALK_TRIAL_RLEN && qv >= 0 && qv < 1000000 &&
          (uint64_t) (end_ - beg) <= 8u * (uint64_t) (a.n - (p + 1));
 }
 
@@ -125,7 +132,7 @@ void k_walk_find(walk_args a, uint64_t *cand, uint32_t *ncand)
       for (int u = 0; u < 4; u++)
         { const uint64_t p = base + 64u * u + lane;
           bool ok = header_fast_d(a, p, v[u]);
-          if (p < hi && p + 16 > a.n && a.img[p] != 255) ok = header_plausible_d(a, p);     // (the image's last bytes)
+          if (p < hi && p + 16 > a.n && a.img[p] != 255) ok = header_plausible_d(a, p, WALK_TRIAL_RLEN);     // (the image's last bytes)
           m[u] = __ballot(ok);
         }
       #pragma unroll
@@ -167,76 +174,86 @@ void k_walk_find(walk_args a, uint64_t *cand, uint32_t *ncand)
 // whose body is one look-up of whatever segment the lane is in, and the five segments, the header and the record's end are
 // states of the lane (ph).  The loop's common path: refill, a 16-bit look-up in LDS, a shift.
 //
-// MSB-first bit reader over 32-bit words (w_fill / w_peek / w_skip of dx_host.c) fed 16 bytes a time, the next 16 requested
-// when the current ones are taken up (a lane's loads are a dependent chain).  Bytes behind the image's end read as zero; a
-// segment's end compares the bytes used with what is there.
+// MSB-first bit reader over the segment's 32-bit words (w_peek / w_skip of dx_host.c), by POSITION: the lane keeps the number
+// of bits it has passed (T) and a ring of the segment's next 16 words in LDS; a look-up reads the two words its position falls in
+// and shifts -- no bit buffer, no refill inside the look-up loop.  The ring is filled by the wave as a whole, once per turn of the
+// lane loop (w_pump_d): what was asked for a turn ago goes into the ring, and up to two 16-byte requests go out for the room that
+// is free -- so the one wait for memory of a turn is for requests a whole burst old, and no look-up ever waits on a load (round
+// 4's reader asked and waited lane by lane: with 64 lanes in 64 phases that was a `s_waitcnt vmcnt(0)` in nearly every look-up,
+// and 57 instructions a look-up of refill and select logic; the kernel was bound by instruction issue, profiles/r05_device_walk.txt).
+// A turn passes at most WALK_BURST codes of <= 12 bits and one step of another kind (<= 16 + 16 + 16 + 8 bits): <= 152 bits, i.e.
+// at most 5 words further on, and a look-up reads the word after its own: a turn that starts with >= 7 words in the ring never
+// reads past them.  w_pump_d keeps >= 8: with <= 8 in the ring it asks for 8 more, with <= 12 for 4.
+// Bytes behind the image's end read as zero; a segment's end compares the bytes used with what is there.
+#define WRING_WORDS  16u
+#define WRING_STRIDE 17u        // words a lane: the ring and its first word once more behind it (a look-up's two words never wrap); odd: the
+                                // 64 rows of a wave start in 32 different banks
 struct wrd_d
-{ const uint8_t *q;             // the next 16 bytes to request
-  u32x4    cur, nxt;
-  uint32_t k;                   // words left in cur
-  uint64_t buf;
-  int      nb;
-  uint32_t nw;                  // words taken into buf since the segment's start: 32 nw - nb bits of it have been passed
+{ const uint8_t *seg;           // the segment's first byte
+  uint32_t *ring;               // the lane's ring
+  uint32_t T;                   // bits of the segment passed
+  uint32_t have;                // words of the segment that have reached the ring (a multiple of 4)
+  uint32_t ua, ub;              // 16-byte requests under way in either set: 0, 1, 2
+  u32x4    a0, a1, b0, b1;      // what they bring: set a asked for by the even pumps, set b by the odd ones
 };
+// words in the ring from the one the lane stands in: a burst of WALK_BURST look-ups wants WRING_BURST of them (<= 12 bits a
+// look-up: 3 words further on at most, and a look-up reads the word after its own), a step of another kind WRING_STEP (<= 56 bits)
+#define WRING_BURST 5u
+#define WRING_STEP  4u
+__device__ __forceinline__ uint32_t w_words_d(const wrd_d &r) { return r.have - (r.T >> 5); }
 
 // 16 bytes of the image at q, zeros behind its end: the image's last bytes come from a padded copy (walk_args.tail), by a select
-// of the address -- no branch, and nothing is done to the bytes here (a byte swap is the taker's business, w_fill_d).
-__device__ __forceinline__ u32x4 load16_within(const walk_args &a, const uint8_t *q)
+// of the address -- no branch, and nothing is done to the bytes here (a byte swap is the taker's business, w_commit_d).
+__device__ __forceinline__ const uint8_t *within(const walk_args &a, const uint8_t *q)
 { const uint64_t off = (uint64_t) (q - a.img);
   const uint64_t t   = off - a.tail_at;
-  const uint8_t *p   = off < a.tail_at ? q : a.tail + (t < 240u ? t : 240u);
-  return *(const u32x4_u *) p;
+  return off < a.tail_at ? q : a.tail + (t < 240u ? t : 240u);
 }
+__device__ __forceinline__ u32x4 load16_within(const walk_args &a, const uint8_t *q) { return *(const u32x4_u *) within(a, q); }
 
-// The request for a lane's next 16 bytes and the wait for it are the wave's, not the lane's: one counter (vmcnt) a wave, loads
-// retiring in the order they were issued -- and in every look-up of a wave SOME lane is taking up its next 16 bytes while some
-// other lane asked for its own a moment ago.  Left to the compiler every such step is `s_waitcnt vmcnt(0)`: a full memory round
-// trip per look-up (what round 4's 45 ms were: 63 k steps a wave of ~0.7 us).  So the request is made behind the compiler's
-// back (inline assembly: no wait is inserted for it) and every step of a reader -- w_tick_d, once in front of every refill --
-// issues ONE one-word load of its own (a.tail: the same address for every lane, a cache hit) and then waits until at most
-// WALK_INFLIGHT loads are under way.  A lane takes up its 16 bytes three words after it asked for them: >= 81 bits of codes
-// (17 <= bits in the buffer in front of a refill <= 32), at <= 16 bits a step that is >= 6 steps, i.e. >= 6 loads issued behind
-// the request: with at most 5 under way the request has retired.  (The one-word load is what makes the count hold whatever the
-// other lanes do; loads the compiler knows of only make either side's waits more conservative: in-order retirement.)
-#define WALK_INFLIGHT 5
-__device__ __forceinline__ void w_request_d(wrd_d &r, const walk_args &a)
-{ const uint64_t off = (uint64_t) (r.q - a.img);
-  const uint64_t t   = off - a.tail_at;
-  const uint8_t *p   = off < a.tail_at ? r.q : a.tail + (t < 240u ? t : 240u);
-  asm volatile("global_load_dwordx4 %[d], %[p], off" : [d] "+v"(r.nxt) : [p] "v"(p) : "memory");
-  r.q += 16;
+__device__ __forceinline__ void w_commit_d(wrd_d &r, const u32x4 &v, int flip)
+{ const uint32_t s = r.have & (WRING_WORDS - 1u);
+  const uint32_t x = bswap_if(v.x, flip), y = bswap_if(v.y, flip), z = bswap_if(v.z, flip), w = bswap_if(v.w, flip);
+  uint32_t *d = r.ring + s;
+  d[0] = x; d[1] = y; d[2] = z; d[3] = w;
+  if (s == 0u) r.ring[WRING_WORDS] = x;
+  r.have += 4u;
 }
-__device__ __forceinline__ void w_tick_d(wrd_d &r, const walk_args &a, uint32_t &beat)
-{ asm volatile("global_load_dword %[b], %[z], %[t]\n\ts_waitcnt vmcnt(%[n])"
-               : [b] "+v"(beat), "+v"(r.nxt) : [z] "v"(0u), [t] "s"(a.tail), [n] "n"(WALK_INFLIGHT) : "memory");
-}
-
-__device__ __forceinline__ void w_fill_d(wrd_d &r, const walk_args &a, uint32_t &beat)
-{ w_tick_d(r, a, beat);
-  if (r.nb <= 32)
-    { if (r.k == 0)                                      // (the 16 bytes asked for three words ago)
-        { r.cur = r.nxt;
-          r.k   = 4;
-        }
-      else if (r.k == 3)                                 // the next 16: asked for here, looked at when these are used up
-        w_request_d(r, a);
-      const uint32_t w = bswap_if(r.cur.x, a.flip);
-      r.cur.x = r.cur.y; r.cur.y = r.cur.z; r.cur.z = r.cur.w;
-      r.k   -= 1;
-      r.buf |= (uint64_t) w << (32 - r.nb);
-      r.nb  += 32;
-      r.nw  += 1;
-    }
+// The rings are filled by the wave as a whole, in front of every burst: what was asked for TWO pumps ago goes into the ring, and up
+// to two 16-byte requests go out for the room that will be free.  Every pump issues exactly TWO loads, whatever its lanes want (a
+// lane with nothing to ask for reads a.tail, a cache hit for the whole wave): a wave has one counter for its loads and they retire
+// in order, so the compiler, which counts instructions, can wait in front of the commit for all but the last pump's two -- were
+// the requests conditional it would have to wait for everything outstanding, a full memory round trip per burst.  How much a lane
+// may pass before its ring runs dry is not left to arithmetic over what the pumps keep in stock: a lane whose ring holds fewer
+// words than a burst (a step) can use sits the burst (the step) out, w_words_d.
+template <int SET>
+__device__ __forceinline__ void w_pump_d(wrd_d &r, const walk_args &a, bool want)
+{ u32x4 &c0 = SET ? r.b0 : r.a0, &c1 = SET ? r.b1 : r.a1;
+  uint32_t &u = SET ? r.ub : r.ua;
+  const uint32_t other = SET ? r.ua : r.ub;
+  if (u >= 1u) w_commit_d(r, c0, a.flip);
+  if (u == 2u) w_commit_d(r, c1, a.flip);
+  const uint32_t ahead = r.have + 4u * other, occ = ahead - (r.T >> 5);
+  u = want && occ <= 12u ? (occ <= 8u ? 2u : 1u) : 0u;
+  const uint8_t *q  = r.seg + 4ull * ahead;
+  const uint8_t *p0 = u >= 1u ? within(a, q) : a.tail, *p1 = u == 2u ? within(a, q + 16) : a.tail;
+  c0 = *(const u32x4_u *) p0;
+  c1 = *(const u32x4_u *) p1;
 }
 __device__ __forceinline__ void w_open_d(wrd_d &r, const walk_args &a, const uint8_t *p)
-{ r.cur = load16_within(a, p);
-  r.q = p + 16; r.k = 4; r.buf = 0; r.nb = 0; r.nw = 0;          // (nxt: requested when the first word of cur has been taken)
-  // waited for HERE, once a segment: left to the compiler, the wait for this request lands in the look-up loop, where it is a
-  // wait for everything outstanding at every refill -- the request for the next 16 bytes, made a moment ago, included
-  __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+{ r.seg = p; r.T = 0u; r.have = 0u; r.ua = 0u; r.ub = 0u;       // (what is under way for the segment before is dropped)
+  const u32x4 c0 = load16_within(a, p), c1 = load16_within(a, p + 16);
+  w_commit_d(r, c0, a.flip);
+  w_commit_d(r, c1, a.flip);                                    // 8 words: a burst's worth and a step's
 }
-__device__ __forceinline__ uint32_t w_peek_d(wrd_d &r, const walk_args &a, uint32_t &beat) { w_fill_d(r, a, beat); return (uint32_t) (r.buf >> 48); }
-__device__ __forceinline__ void w_skip_d(wrd_d &r, uint32_t n) { r.buf <<= n; r.nb -= (int) n; }
+// the next 32 bits
+__device__ __forceinline__ uint32_t w_win_d(const wrd_d &r)
+{ const uint32_t *p = r.ring + ((r.T >> 5) & (WRING_WORDS - 1u));
+  const uint64_t two = ((uint64_t) p[0] << 32) | p[1];
+  return (uint32_t) ((two << (r.T & 31u)) >> 32);
+}
+__device__ __forceinline__ uint32_t w_peek_d(const wrd_d &r) { return w_win_d(r) >> 16; }
+__device__ __forceinline__ void w_skip_d(wrd_d &r, uint32_t n) { r.T += n; }
 
 __device__ __forceinline__ uint32_t pad_words_d(uint64_t T, uint32_t last)      // QV.c:436-442
 { const uint32_t olen = (uint32_t) T & 31u, llen = (uint32_t) (T - last) & 31u;
@@ -248,7 +265,7 @@ __device__ __forceinline__ uint32_t pad_words_d(uint64_t T, uint32_t last)      
 // LDS: the tables of dx_walk.h a walk looks into -- t[0..3] the line's own (del, ins, mrg, sub: the pair table of a run-coded
 // line, else the several-codes table), r1 the run codes alone (del, sub), one the first code of a window alone (the four symbol
 // schemes); 80 KB.  All read alike: bits to skip | the last code's length << 4 | symbols covered << 8, 0: not this way.
-struct walk_lds { uint16_t t[4][4096]; uint16_t r1[2][4096]; uint16_t one[4][4096]; };
+struct walk_lds { uint16_t t[4][4096]; uint16_t r1[2][4096]; uint16_t one[4][4096]; uint32_t ring[WALK_BLOCK][WRING_STRIDE]; };
 
 #define PH_HEAD 0u              // at a record's first byte
 #define PH_DEL  1u
@@ -260,8 +277,11 @@ struct walk_lds { uint16_t t[4][4096]; uint16_t r1[2][4096]; uint16_t one[4][409
 #define WALK_BRANCHY 0
 #endif
 #ifndef WALK_BURST
-#define WALK_BURST 24           // look-ups in a row before the lanes that need something else are seen to
+#ifndef WALK_SUB
+#define WALK_SUB 4              // bursts between two looks at the lanes that need something else (an even number: the pumps' two sets)
 #endif
+#define WALK_BURST 8            // look-ups in a row before the lanes that need something else are seen to (and the rings: w_pump_d's
+#endif                          // arithmetic is for at most 8)
 
 // One lane per piece (todo == NULL: piece = thread index; else the listed pieces, each from start[piece], which the chain has
 // arrived at): the piece's records into recs[piece * rcap ...], what became of it into pc[piece].
@@ -304,9 +324,8 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
   walk_rec_d r;
   wrd_d rd;
   bool live = true;
-  uint32_t beat = 0;                   // (w_tick_d's one-word load lands here)
-  rd.nw = 0; rd.nb = 0; rd.k = 0; rd.buf = 0; rd.q = a.img;
-  rd.cur = u32x4{ 0u, 0u, 0u, 0u }; rd.nxt = rd.cur;
+  rd.seg = a.img; rd.ring = S.ring[threadIdx.x]; rd.T = 0; rd.have = 0; rd.ua = 0; rd.ub = 0;
+  rd.a0 = u32x4{ 0u, 0u, 0u, 0u }; rd.a1 = rd.a0; rd.b0 = rd.a0; rd.b1 = rd.a0;
   if (todo || k == 0)
     { out.start = todo ? start[k] : a.first; at = out.start; }
   else if (ncand[k] == 0)
@@ -315,58 +334,46 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
     { trial = 1; budget = 16u * a.piece; at = cand[k * WALK_CAND]; nc = ncand[k]; }          // (two pieces' bytes)
   if (live && !trial && !(at < hi && at < a.n)) { live = false; out.end = at; }     // (nothing of this piece left to walk)
 
-  while (live)
+  // (a lane that is done stays in the loop, doing nothing, until its wave is: w_pump_d and the burst are the wave's)
+  while (__any(live))
     { bool fail = false;
       rounds_ += 1;
+      const bool inseg = live && ph >= PH_DEL && ph < PH_DONE;
       const uint32_t line = ph - PH_DEL;                        // 0 del, 1 ins, 2 mrg, 3 sub (in a segment)
-      if (ph >= PH_DEL && ph < PH_DONE)
-        { const uint16_t *tab = S.t[line];
-          bool more = true;
-          #pragma unroll 1
-#if WALK_BRANCHY
-          for (int it = 0; it < WALK_BURST && more; it++)
-            { w_fill_d(rd, a, beat);
-              const uint32_t g = tab[(uint32_t) (rd.buf >> 52)], cnt = g >> 8;
-              more = g != 0u && j + cnt <= rlen;
-              if (more)
-                { const uint32_t nbits = g & 15u;
-                  rd.buf <<= nbits; rd.nb -= (int) nbits;
-                  j += cnt; nn += 1u; last = (g >> 4) & 15u;
-                }
-            }
-#else
-          // Without branches but for the 16-byte refills (every sixth look-up or so): selects instead -- a lane the
-          // burst has left behind shifts by nothing and counts nothing.  With branches a look-up was 28 instructions of which ten
-          // scalar (execution masks) and five branches; the scalar unit is one to a CU.
-          for (int it = 0; it < WALK_BURST; it++)
-            { w_tick_d(rd, a, beat);
-              const bool need = rd.nb <= 32;
-              if (need && (rd.k == 3u || rd.k == 0u))          // (every sixth refill or so: these two stay branches -- a select
-                { if (rd.k == 0u)                              //  would look at nxt, i.e. wait for it, at every look-up)
-                    { rd.cur = rd.nxt; rd.k = 4; }             // the 16 bytes asked for three words ago
-                  else
-                    w_request_d(rd, a);                        // the next 16: asked for here, looked at when these are used up
-                }
-              const uint32_t w = bswap_if(rd.cur.x, a.flip);
-              rd.cur.x = need ? rd.cur.y : rd.cur.x; rd.cur.y = need ? rd.cur.z : rd.cur.y; rd.cur.z = need ? rd.cur.w : rd.cur.z;
-              rd.k   -= need ? 1u : 0u;
-              rd.buf |= need ? (uint64_t) w << ((32 - rd.nb) & 63) : 0ull;
-              rd.nb  += need ? 32 : 0;
-              rd.nw  += need ? 1u : 0u;
-              const uint32_t g = tab[(uint32_t) (rd.buf >> 52)], cnt = g >> 8;
-              more = more && g != 0u && j + cnt <= rlen;
-              const uint32_t nbits = more ? g & 15u : 0u;
-              rd.buf <<= nbits; rd.nb -= (int) nbits;
-              j += more ? cnt : 0u; nn += more ? 1u : 0u; last = more ? (g >> 4) & 15u : last;
-              if (!__any(more)) break;
-            }
-#endif
-          if (32ull * rd.nw - (uint64_t) rd.nb > budget)        // a guess that walks on and on (garbage may claim any length, and zeros
+      bool more = inseg;
+      // WALK_SUB bursts, the rings seen to in front of each (the wave together: lanes outside a segment, or left behind by a
+      // burst, ask for nothing and pass nothing).  Without branches: a lane left behind shifts by nothing and counts nothing.
+      const uint16_t *tab = S.t[inseg ? line : 0u];
+#define WALK_BURST_ONCE(SET) \
+        { w_pump_d<SET>(rd, a, more); \
+          const bool ready = w_words_d(rd) >= WRING_BURST;      /* (a ring that is short: this burst without the lane) */ \
+          bool go = more && ready; \
+          _Pragma("unroll 1") \
+          for (int it = 0; it < WALK_BURST; it++) \
+            { const uint32_t g = tab[w_win_d(rd) >> (32 - WALK_WIN)], cnt = g >> 8; \
+              go = go && g != 0u && j + cnt <= rlen; \
+              rd.T += go ? g & 15u : 0u; \
+              j += go ? cnt : 0u; nn += go ? 1u : 0u; last = go ? (g >> 4) & 15u : last; \
+              if (!__any(go)) break; \
+            } \
+          more = more && (go || !ready); \
+        }
+      #pragma unroll 1
+      for (int sub = 0; sub < WALK_SUB; sub += 2)
+        { WALK_BURST_ONCE(0)
+          WALK_BURST_ONCE(1)
+          if (!__any(more)) break;
+        }
+#undef WALK_BURST_ONCE
+      if (inseg && !more && j < rlen && w_words_d(rd) < WRING_STEP) more = true;     // (the step waits for the ring too)
+      if (inseg)
+        {
+          if ((uint64_t) rd.T > budget)        // a guess that walks on and on (garbage may claim any length, and zeros
             { fail = true; more = true; }                       // behind the image read as codes): every burst, whatever became of it
           if (!more)
             { const bool runs = (line == 0 && a.delChar >= 0) || (line == 3 && a.subChar >= 0);
               if (j < rlen)                                     // one step of another kind
-                { uint32_t w = w_peek_d(rd, a, beat);
+                { uint32_t w = w_peek_d(rd);
                   bool sym = true;                              // a symbol's code is to be passed
                   if (runs)                                     // walk_runs: the run code alone first
                     { const uint32_t e1 = S.r1[line ? 1u : 0u][w >> (16 - WALK_WIN)];
@@ -378,12 +385,12 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                           if (last == 0) fail = true;
                           w_skip_d(rd, last);
                           if (c == 255u)
-                            { c = w_peek_d(rd, a, beat); w_skip_d(rd, 16u); last = 16; }
+                            { c = w_peek_d(rd); w_skip_d(rd, 16u); last = 16; }
                         }
                       if (c > rlen - j) fail = true;
                       j  += c;
                       sym = !fail && j < rlen;
-                      if (sym) w = w_peek_d(rd, a, beat);
+                      if (sym) w = w_peek_d(rd);
                     }
                   if (sym)                                      // walk_plain's single code; walk_runs' symbol behind the run
                     { const uint32_t f = S.one[line][w >> (16 - WALK_WIN)] & 15u;
@@ -394,13 +401,13 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                           if (last == 0) fail = true;
                           w_skip_d(rd, last);
                           if (a.esc[line] && (e & 0xffu) == 255u)
-                            { w_fill_d(rd, a, beat); w_skip_d(rd, 8u); last = 8; }
+                            { w_skip_d(rd, 8u); last = 8; }
                         }
                       j  += 1;
                       nn += 1;
                     }
                 }
-              const uint64_t T = 32ull * rd.nw - (uint64_t) rd.nb;         // bits of the segment passed
+              const uint64_t T = rd.T;                                     // bits of the segment passed
               if (T > budget) fail = true;
               if (!fail && j >= rlen)                           // the segment's end: its bytes, and on to the next one
                 { const uint64_t bytes = 4ull * pad_words_d(T, last);
@@ -421,6 +428,8 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                 }
             }
         }
+      else if (!live)
+        { }
       else if (ph == PH_HEAD)                                   // walk_framing of dx_host.c (0x55aa-keyed: 32-bit fields)
         { const uint64_t h0 = at;
           int32_t dw = 0;
@@ -435,6 +444,10 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
               if (end_ < beg || (int64_t) end_ - (int64_t) beg > WALK_RLEN_MAX || (uint64_t) rlen > 65536u * 8u * (uint64_t) (a.n - at) + 64u)
                 fail = true;
               r.off = h0; r.hdr_bytes = (uint32_t) (at - h0); r.len = rlen; r.dwell = dw; r.beg = beg; r.end = end_; r.qv = qv; r.pad = 0;
+              if (trial)                                        // (see WALK_TRIAL_RLEN)
+                { if (rlen > (uint32_t) WALK_TRIAL_RLEN) fail = true;
+                  budget = 32ull * rlen + 8192u < 16u * a.piece ? 32ull * rlen + 8192u : 16u * a.piece;
+                }
               ph = PH_DEL; j = 0; last = 0; nn = 0; clen = rlen;
               if (!fail) w_open_d(rd, a, a.img + at);
             }
@@ -464,7 +477,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                   reclusters += 1;                              // (WALK_RECLUSTER of them at most: a crafted piece may hold thousands)
                   #pragma unroll 1
                   for (uint64_t p = c[0] + 1; reclusters <= WALK_RECLUSTER && p < hi && (m == 0 || p <= last + 16u) && m < WALK_CAND; p++)
-                    if (a.img[p] != 255 && header_plausible_d(a, p)) { c[m++] = p; last = p; }
+                    if (a.img[p] != 255 && header_plausible_d(a, p, WALK_TRIAL_RLEN)) { c[m++] = p; last = p; }
                   if (m == 0) { out.flags = WP_NONE; live = false; }
                   else
                     { for (uint32_t x = 0, y = m - 1; x < y; x++, y--) { const uint64_t t = c[x]; c[x] = c[y]; c[y] = t; }   // (last first)
@@ -483,7 +496,6 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
       out.lead255 = c;
     }
   (void) rounds_;
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(beat), "+v"(rd.nxt) :: "memory");       // (nothing of w_tick_d's / w_request_d's under way behind the loop)
   pc[k] = out;
 }
 
