@@ -483,10 +483,16 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                                         "stream_GBps_wall": round(float(state["total"]) / (t_w1 - t_w) / 1e9, 1)}
                 roundtrip = roundtrip and same
                 if same:                                          # ... and the stream decoded from THAT index: a bare stream, device only
+                    okw0, decw0_ms = decode_all(dix)              # (record and segment starts alone: the lane-per-line kernels)
+                    parts0 = dict(dec_parts)
+                    dix.use(p_out)                                # ... and with the run-coded lines' groups the walk has noted on its way
                     okw, decw_ms = decode_all(dix)
-                    state["device_walk"].update({"decode_ms_from_this_index": round(decw_ms, 2), "decode_bit_exact": bool(okw), "ms_by_kernel": dict(dec_parts),
-                                                 "walk_and_decode_ms": round((kt[0] if kt else 0.0) + decw_ms, 2)})
-                    roundtrip = roundtrip and okw
+                    dix.use(None)
+                    state["device_walk"].update({"decode_ms_from_this_index": round(decw_ms, 2), "decode_bit_exact": bool(okw and okw0), "ms_by_kernel": dict(dec_parts),
+                                                 "walk_and_decode_ms": round((kt[0] if kt else 0.0) + decw_ms, 2),
+                                                 "run_lines_without_groups": dix.gidx_none, "group_index_bytes": 4 * dix.gidx_words,
+                                                 "decode_ms_without_the_groups": round(decw0_ms, 2), "ms_by_kernel_without_the_groups": parts0})
+                    roundtrip = roundtrip and okw and okw0
                 dix.free()
             except Exception as e:
                 ctx.profile(False)

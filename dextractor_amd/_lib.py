@@ -61,7 +61,9 @@ class QVIndex(C.Structure):
 
 class QVDIndex(C.Structure):                     # dx_qv_dindex
     _fields_ = [("n", C.c_uint64), ("d_rec_off", C.c_void_p), ("d_hdr_off", C.c_void_p), ("d_seg", C.c_void_p),
-                ("d_len", C.c_void_p), ("d_hdr4", C.c_void_p), ("pieces", C.c_uint64), ("piece_bytes", C.c_uint64)]
+                ("d_len", C.c_void_p), ("d_hdr4", C.c_void_p), ("pieces", C.c_uint64), ("piece_bytes", C.c_uint64),
+                ("d_gidx", C.c_void_p), ("d_gidx_off", C.c_void_p), ("gidx_words", C.c_uint64), ("gidx_none", C.c_uint64),
+                ("gidx_nosync", C.c_uint64), ("sync_kinds", C.c_uint32)]
 
 # name -> (restype, argtypes); every symbol include/dexgpu.h declares
 _P = C.c_void_p
@@ -126,6 +128,7 @@ SIGNATURES = {
     "dx_file_undexqv_plan_on": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "dx_qv_walk_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "dx_qv_dindex_free": (None, [_P, _P]),
+    "dx_qv_use_dindex": (C.c_int, [_P, _P, _P]),
     "dx_qv_use_index": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64]),
     "dx_qv_index_free": (None, [_P]),
     "dx_file_pack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),

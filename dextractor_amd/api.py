@@ -68,6 +68,15 @@ class DeviceIndex:
         self.pieces, self.piece_bytes = int(x.pieces), int(x.piece_bytes)
         self.rec_off, self.hdr_off = self._View(x.d_rec_off), self._View(x.d_hdr_off)
         self.seg, self.len, self.hdr4 = self._View(x.d_seg), self._View(x.d_len), self._View(x.d_hdr4)
+        self.gidx_words, self.gidx_none = int(x.gidx_words), int(x.gidx_none)
+        self.gidx = self._View(x.d_gidx) if x.d_gidx else None
+        self.gidx_off = self._View(x.d_gidx_off) if x.d_gidx_off else None
+
+    def use(self, d_in):
+        """dx_qv_use_dindex: the run-coded lines' groups this walk has noted go to the decoder (d_in: the stream's device
+        address, as dx_qv_decode will get it); use(None) takes them back."""
+        self.ctx._chk(self.ctx.lib.dx_qv_use_dindex(self.ctx.h, d_in.ptr if d_in is not None else None,
+                                                    C.byref(self.x) if d_in is not None else None))
 
     def download(self):
         """-> dict of numpy arrays, as qv_walk returns them"""

@@ -37,7 +37,7 @@ void dx_sx_drop_external(dx_ctx *ctx)
 { if (!ctx->sx.external) return;
   ctx->sx.idx = NULL; ctx->sx.off = NULL; ctx->sx.cap_idx = 0;
   (void) hipFree(ctx->sx.room); ctx->sx.room = NULL; ctx->sx.cap_entries = 0;
-  ctx->sx.external = 0; ctx->sx.valid = 0;
+  ctx->sx.external = 0; ctx->sx.valid = 0; ctx->sx.walk = 0;
 }
 
 int dx_fail(dx_ctx *ctx, int code, const char *fmt, ...)

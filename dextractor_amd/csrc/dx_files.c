@@ -1107,7 +1107,7 @@ static int undexqv_sliced(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_s
   uint64_t *rel = NULL, i0, i1, i, most = 0;
   size_t    tmax = 0, imax = 0;
   hdr_patch h;
-  int       rc = DX_OK;
+  int       rc = DX_OK, indexed = 0;
 #define TEXT_AT(i) ((i) < n ? (size_t) p->ooff[i] - (size_t) (p->hat[(i) + 1] - p->hat[i]) : p->total)      /* where entry i's header line starts */
   h.n = n; h.ooff = p->ooff; h.hat = p->hat; h.hd = p->hd.p; h.sink = sink; h.user = user; h.base = 0;
   for (i0 = 0; i0 < n; i0 = i1)                           /* the largest slice: one allocation serves them all */
@@ -1134,6 +1134,10 @@ static int undexqv_sliced(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_s
     }
   TRY(dalloc(&pool, (most + 1) * 8, &d_ooff));
   TRY(dalloc(&pool, tmax, &d_out));
+  if (PLAN_HAS_IMAGE(p) && PLAN_HAS_INDEX(p) && p->dix.d_gidx != NULL && !p->x.flip)     /* (a slice is a contiguous part of the walk's index) */
+    { TRY(dx_qv_use_dindex(ctx, d_in, &p->dix));
+      indexed = 1;
+    }
   for (i0 = 0; i0 < n; i0 = i1)
     { const size_t t0 = TEXT_AT(i0);
       const uint64_t *rec = d_rec;
@@ -1156,6 +1160,7 @@ static int undexqv_sliced(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_s
     }
 #undef TEXT_AT
 done:
+  if (indexed) (void) dx_qv_use_index(ctx, NULL, NULL, 0, NULL, NULL, 0);
   dfree_all(&pool);
   free(rel);
   return rc;
@@ -1211,6 +1216,10 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
           TRY(dupload(&pool, p->x.gidx, (size_t) p->x.gidx_words * 4, &d_gidx));
           TRY(dupload(&pool, p->x.gidx_off, (p->x.n + 1) * 8, &d_goff));
           TRY(dx_qv_use_index(ctx, d_in, d_seg, p->x.n, d_gidx, d_goff, p->x.gidx_none));
+          indexed = 1;
+        }
+      else if (PLAN_HAS_INDEX(p) && p->dix.d_gidx != NULL && !p->x.flip)      /* the device walk's: the run-coded lines' groups */
+        { TRY(dx_qv_use_dindex(ctx, d_in, &p->dix));
           indexed = 1;
         }
       TRY(dx_qv_decode(ctx, d_in, d_rec, d_hoff, d_seg, d_len, p->x.n,

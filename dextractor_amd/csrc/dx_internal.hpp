@@ -74,6 +74,9 @@ struct dx_ctx
   struct
   { int       want, valid;
     int       external;          // idx / off are the caller's (dx_qv_use_index): never freed here, dropped before the context makes its own
+    int       walk;              // ... and are the device walk's (dx_qv_use_dindex): a plain line's share holds a word per 64 symbols
+    uint32_t  sync_kinds;        //     (k_qv_decode_sync) of the kinds in sync_kinds, `nosync` lines without
+    uint64_t  nosync;
     uint32_t *idx;               // one byte per group of 16 symbols, 4 * sub_words(len) words per entry
     uint64_t *off;               // n + 1: where each entry's words start
     uint32_t *room;              // n: scratch of the offsets' scan

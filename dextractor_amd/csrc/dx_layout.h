@@ -12,6 +12,10 @@
 
 #define DXL_SUB_NONE     255u                 /* first byte of a plain line's share: no index for it */
 #define DXL_RUN_NONE     0xffffffffu          /* header word of a run-coded line: no index for it */
+#define DXL_RUN_EIGHTS   0x80000000u          /* in the third header word (the deletion line's passes): the LAST pass's tokens are dealt 8 a
+                                                 lane like every other pass's (the device walk's index), not (m + 63) / 64 a lane (the encoder's) */
+#define DXL_SYNC_NONE    0xffffffffu          /* first word of a plain line's share in the device walk's index (its other words: where symbol 64 g
+                                                 is, k_qv_decode_sync): no words for this line */
 #define DXL_RUN_PASSBITS 13312u               /* bits the 64 groups of a pass may take together */
 #define DXL_RUN_PASS     512u                 /* tokens of a pass: 64 groups of up to 8 */
 #define DXL_RUN_STRETCH  5120u                /* positions of a pass the decoder stages in LDS at a time */

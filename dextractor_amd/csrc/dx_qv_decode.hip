@@ -601,7 +601,9 @@ __device__ __forceinline__ void dp_build_tables(uint16_t (*s_tab)[DP_SIZE], uint
 
 __global__ __launch_bounds__(DP_BLOCK)
 void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds,
-                       uint32_t *status)
+                       uint32_t *status, const uint32_t *sync_idx /* the device walk's index, or NULL: of the kinds in sync_kinds only the
+                       lines without their words are this kernel's (k_qv_decode_sync has decoded the others) */,
+                       const uint64_t *sync_off, uint32_t sync_kinds)
 { __shared__ uint16_t s_tab[4][DP_SIZE];                   // 32 KB: 32 - len | symbol << 8 (low bits 0: longer than DP_BITS)
   __shared__ uint32_t s_long[4][1 + DX_LONG_MAX];          //  4 KB
   __shared__ uint32_t s_ring[DP_BLOCK][DP_STRIDE];         // 100 KB
@@ -621,11 +623,15 @@ void k_qv_decode_plain(dec_args a, const uint16_t *g_dec, const uint32_t *g_long
       if (!((kinds >> q) & 1u))
         continue;
       const uint64_t r    = g * 64 + (uint64_t) lane_id();
-      const bool     live = r < a.n;
+      bool           live = r < a.n;
       const int      line = q == 0 ? 0 : q + 1;            // output line / segment index
       uint32_t L = 0, sbytes = 0;
       const uint8_t *seg = a.in;
       uint8_t *out = a.out;
+      if (live && sync_idx != NULL && ((sync_kinds >> q) & 1u))
+        { const uint32_t Lr = a.len[r];
+          live = Lr != 0u && sync_idx[sync_off[r] + (uint64_t) q * sub_words(Lr)] == DXL_SYNC_NONE;
+        }
       if (live)
         { const uint32_t *sg = a.seg + 5 * r;
           uint64_t at = a.rec_off[r] + (a.hdr_off ? a.hdr_off[r + 1] - a.hdr_off[r] : 0);
@@ -1141,6 +1147,156 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 #undef DS_ASK
 
 // ---------------------------------------------------------------------------------------------
+//  plain lines of a bare stream, with what the device walk noted on its way: k_qv_decode_sync
+// ---------------------------------------------------------------------------------------------
+// The walk of a bare stream (dx_qv_walk.hip) passes a plain line several codes a look-up and cannot say where every 16th symbol
+// is (k_qv_decode_sub's index) without walking it code by code; what it can note for nothing is where the look-up BEGAN that
+// reached every 64th symbol: a word per 64 symbols, the bits passed | the symbols from there to the 64th << 28 (at most 12: a
+// look-up's codes), word g of the line's share of the index (word 0: 0, or DXL_SYNC_NONE: a line without -- k_qv_decode_plain
+// takes it).  Here a wavefront per (entry, plain line), a LANE per 64 symbols: the words the round's lanes span go into the wave's
+// LDS window (coalesced), a lane passes the few codes in front of its 64 symbols one by one and then decodes the 64 by positioned
+// reads (ds_block8_pos: two codes a read, no bit buffer) into 16 registers = four 16-byte stores, 64 consecutive bytes a lane, 4 KiB
+// a wave.  A round takes as many lanes as its window holds (a lane's codes take 28 bytes at the bench's 3.5 bits a code; the
+// window holds 5 KB).  Decode QV.c:510-599.
+#define DY_BLOCK 768
+#define DY_NWAVE (DY_BLOCK / 64)
+#define DY_WIN   1280                                       // words per wave: 5 KB
+#define DY_SLACK 288u                                       // bits a lane may look at behind the next lane's start: <= 12 codes of 16 bits in front
+                                                            // of ITS 64 symbols, the positioned reads' 32 bits, and the last pair's second look
+template <int NK>
+__global__ __launch_bounds__(DY_BLOCK, NK <= 2 ? 6 : 3)
+void k_qv_decode_sync(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, uint32_t *next_task, uint32_t kinds,
+                      const uint32_t *sub_idx, const uint64_t *sub_off, uint32_t *status)
+{ __shared__ uint16_t s_tab[NK][DP_SIZE];                  // 8 KB each
+  __shared__ uint32_t s_long[NK][1 + DX_LONG_MAX];         // 1 KB each
+  __shared__ uint32_t s_win[DY_NWAVE][DY_WIN];             // 60 KB
+  nocode_begin();
+  { int slot_of[4], nk = 0;                                // tables of the kinds present, in the order of their bits (as k_qv_decode_sub)
+    for (int q = 0; q < 4; q++) slot_of[q] = ((kinds >> q) & 1u) ? nk++ : -1;
+    for (int q = 0; q < 4; q++)
+      if (slot_of[q] >= 0)
+        for (int k = threadIdx.x; k < 1 + DX_LONG_MAX; k += DY_BLOCK) s_long[slot_of[q]][k] = g_long[q * (1 + DX_LONG_MAX) + k];
+    __syncthreads();
+    for (int q = 0; q < 4; q++)
+      if (slot_of[q] >= 0)
+        for (int i_ = threadIdx.x; i_ < DP_SIZE; i_ += DY_BLOCK)
+          { const uint32_t i = (uint32_t) i_, e = g_dec[q * DX_DEC_SIZE + (i >> (DP_BITS - DX_DEC_BITS))];
+            uint32_t len = e >> 8, sym = e & 0xffu;
+            if (len == 0)
+              { const uint32_t *lg = s_long[slot_of[q]], cnt = lg[0], pre = i << (16 - DP_BITS);
+                for (uint32_t j = 1; j <= cnt; j++)
+                  { const uint32_t t = lg[j], l = (t >> 8) & 0xffu;
+                    if (l <= DP_BITS && (pre >> (16u - l)) == ((t >> 16) >> (16u - l)))
+                      { len = l; sym = t & 0xffu; }
+                  }
+              }
+            s_tab[slot_of[q]][i] = (uint16_t) ((len ? 32u - len : 0u) | (sym << 8));
+          }
+    __syncthreads();
+  }
+  uint32_t *const win  = s_win[threadIdx.x >> 6] + 1;      // ([-1]: the positioned reads look one word back)
+  const int       lane = lane_id();
+  if (lane == 0) win[-1] = 0u;
+
+  uint64_t r, r_end, r1;
+  uint32_t tkv = 0, dv = 0, dv_nx = 0;
+  bool     fresh;
+  DT_FIRST(r, r_end, tkv)
+  if (r < a.n) DR_DESC(dv, r)
+  for (; r < a.n; r = r1, r_end = fresh ? r1 + dec_ticket : r_end, dv = dv_nx)       // (every wave gets past the end: the counter only grows)
+    { dr_entry cur;
+      DR_TAKE(cur, dv)
+      DT_NEXT(r1, fresh, r, r_end, tkv)
+      if (r1 < a.n) DR_DESC(dv_nx, r1)
+      int slot = -1;
+      #pragma unroll 1
+      for (uint32_t q = 0; q < 4; q++)
+      { if (!((kinds >> q) & 1u)) continue;
+        slot += 1;
+        const ds_line   ln     = ds_line_of(a, cur, q, sub_idx);
+        const uint32_t  L      = ln.L, SG = (L + 63u) >> 6, sbytes = ln.sbytes;
+        const uint8_t  *seg    = ln.seg;
+        uint8_t        *out    = ln.out;
+        const uint16_t *tab    = s_tab[slot];
+        const uint32_t *lng    = s_long[slot];
+        const uint32_t *sy     = (const uint32_t *) (const void *) ln.at8;         // the line's share: a word per 64 symbols
+        if (SG && uniform(sy[0]) == DXL_SYNC_NONE) continue;                       // a line without: k_qv_decode_plain's
+
+        for (uint32_t g0 = 0; g0 < SG; )
+          { const uint32_t g  = g0 + (uint32_t) lane;
+            const uint32_t w  = g < SG && g ? sy[g] : 0u;
+            const uint32_t wn = g + 1u < SG ? sy[g + 1u] : 0u;
+            const uint32_t T  = w & 0x0fffffffu, dl = w >> 28;
+            const uint32_t w0 = uniform(T) >> 5;                                   // the window's first word: lane 0's
+            // the bits a lane may look at end DY_SLACK behind the next lane's start (the line's last lane: behind the segment)
+            const uint32_t need = g + 1u < SG ? (wn & 0x0fffffffu) + DY_SLACK : 8u * sbytes + 64u;
+            const bool     fits = g < SG && ((need + 31u) >> 5) + 1u - w0 <= DY_WIN - 2u;
+            const uint64_t miss = __ballot(!fits);
+            const uint32_t cntl = miss ? (uint32_t) __ffsll((unsigned long long) miss) - 1u : 64u;      // (>= 1: one lane's bits are < 50 words)
+            const bool     mine = (uint32_t) lane < cntl;
+            uint32_t nw = mine ? ((need + 31u) >> 5) + 1u - w0 : 0u;
+            nw = wave_total(wave_incl_max(nw));
+            for (uint32_t i = (uint32_t) lane; i < nw; i += 64u)
+              { const uint64_t byte = 4ull * (w0 + i);
+                win[i] = byte + 4u <= sbytes ? *(const u32_u *) (seg + byte) : 0u;   // (segments are whole words, QV.c:436-442)
+              }
+            wave_sync();
+            if (mine)
+              { const uint32_t p0 = T - 32u * w0;
+                uint32_t p = p0, x[16], z = 31u;
+                // the codes in front of the lane's 64 symbols (the look-up that reached them began here)
+                for (uint32_t k = 0; k < dl; k++)
+                  { const uint32_t  e  = p + 31u;
+                    const uint32_t *wp = win + (e >> 5);
+                    const uint32_t  ea = tab[__builtin_amdgcn_alignbit(wp[-1], wp[0], ~e) >> (32 - DP_BITS)];
+                    z &= ea;
+                    p += 32u - (ea & 31u);
+                  }
+                #pragma unroll
+                for (int b = 0; b < 8; b++)
+                  z &= ds_block8_pos(win, p, tab, x[2 * b], x[2 * b + 1]);
+                if (!(z & 16u))                            // a code beyond the tables' index somewhere: the lane's symbols again, code by code
+                  { winrd rd;
+                    rd.win = win; rd.wi = (p0 >> 5) + 1u;
+                    rd.hi = win[p0 >> 5] << (p0 & 31u); rd.lo = 0u; rd.nb = 32 - (int) (p0 & 31u);
+                    for (uint32_t k = 0; k < dl; k++) (void) wr_symbol(rd, tab, lng);
+                    #pragma unroll 1
+                    for (int k = 0; k < 64; k++)
+                      { const uint32_t c = wr_symbol(rd, tab, lng);
+                        #pragma unroll
+                        for (int i = 0; i < 16; i++)
+                          if (i == (k >> 2)) x[i] = (k & 3) ? (x[i] | (c << (8 * (k & 3)))) : c;
+                      }
+                  }
+                uint8_t *o = out + 64ull * g;
+                const uint32_t valid = L - 64u * g < 64u ? L - 64u * g : 64u;
+                if (valid == 64u)
+                  { const u32x4 v0 = { x[0], x[1], x[2], x[3] },   v1 = { x[4], x[5], x[6], x[7] };
+                    const u32x4 v2 = { x[8], x[9], x[10], x[11] }, v3 = { x[12], x[13], x[14], x[15] };
+                    u32x4_u *gp = (u32x4_u *) o;
+                    gp[0] = v0; gp[1] = v1; gp[2] = v2; gp[3] = v3;
+                  }
+                else                                       // the ragged end of the line (its codes past the end were zeros or the next segment's: thrown away)
+                  {
+                    #pragma unroll
+                    for (int i = 0; i < 16; i++)
+                      { if (4u * (uint32_t) i + 4u <= valid) *(u32_u *) (o + 4 * i) = x[i];
+                        else
+                          for (uint32_t j = 4u * (uint32_t) i; j < valid; j++) o[j] = (uint8_t) (x[i] >> (8u * (j & 3u)));
+                      }
+                  }
+              }
+            wave_sync();
+            g0 += cntl;
+          }
+        if (lane == 0)
+          out[L] = '\n';
+      }
+    }
+  nocode_end(status);
+}
+
+// ---------------------------------------------------------------------------------------------
 //  run-coded lines with the encoder's group index: k_qv_decode_runs
 // ---------------------------------------------------------------------------------------------
 // A wavefront per (entry, run-coded line).  The index holds, for every group of <= 8 consecutive (run, symbol)
@@ -1185,11 +1341,12 @@ __device__ __forceinline__ dr_line dr_line_of(const dec_args &a, const dr_entry 
   const uint32_t L = e.L;
   ln.cnt = head[q == 0 ? 0 : 1];                           // tokens (RUN_NONE: not indexed)
   const uint64_t share = e.so1 - e.so;                     // words of this entry in the index
-  const uint64_t need  = (uint64_t) run_base(L) + 3u + 64ull * ((q == 0 ? 0u : head[2]) + run_passes(ln.cnt));
+  const uint32_t dpass = head[2] & ~DXL_RUN_EIGHTS;          // (the flag: how the last pass's tokens are dealt, k_qv_decode_runs)
+  const uint64_t need  = (uint64_t) run_base(L) + 3u + 64ull * ((q == 0 ? 0u : dpass) + run_passes(ln.cnt));
   ln.ok     = ln.cnt != RUN_NONE && ln.cnt <= dxl_tok_limit(L) && need <= share;
   ln.seg    = a.in + e.rec + e.hl + (q == 0 ? 0ull : (uint64_t) e.sg[0] + e.sg[1] + e.sg[2] + e.sg[3]);
   ln.sbytes = q == 0 ? e.sg[0] : e.sg[4];
-  ln.g16    = sub_idx + e.so + run_base(L) + 3u + (q == 0 ? 0u : 64u * head[2]);      // three header words, then the groups
+  ln.g16    = sub_idx + e.so + run_base(L) + 3u + (q == 0 ? 0u : 64u * dpass);        // three header words, then the groups
   return ln;
 }
 
@@ -1306,7 +1463,8 @@ void k_qv_decode_runs(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
         if (cnt) ready = false;                            // (this line's first pass takes them)
         for (uint32_t k0 = 0; k0 < ((DR_SKIP & 32) ? 0u : cnt); k0 += 512u)
           { const uint32_t m     = cnt - k0 < 512u ? cnt - k0 : 512u;
-            const uint32_t T     = (m + 63u) >> 6;         // tokens per lane in this pass (as the encoder cut them)
+            const uint32_t T     = (head[2] & DXL_RUN_EIGHTS) ? 8u : (m + 63u) >> 6;   // tokens per lane in this pass (as the encoder cut
+                                                           // them; the device walk's index: 8 in the last pass as in every other)
             const uint32_t first = (uint32_t) lane * T;
             const uint32_t c     = first < m ? (m - first < T ? m - first : T) : 0u;
             const uint32_t gw    = gw_nx;
@@ -1643,8 +1801,18 @@ extern "C" int dx_qv_use_index(dx_ctx *ctx, const uint8_t *d_in, const uint32_t 
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->sx.idx = (uint32_t *) d_gidx; ctx->sx.off = (uint64_t *) d_gidx_off;
   ctx->sx.out = d_in; ctx->sx.seg = d_seg; ctx->sx.n = n;
-  ctx->sx.external = 1; ctx->sx.valid = 1;
+  ctx->sx.external = 1; ctx->sx.valid = 1; ctx->sx.walk = 0;
   return DX_OK;
+}
+
+// ... and the one a device walk has left (dx_qv_walk_device): the run-coded lines' groups only
+extern "C" int dx_qv_use_dindex(dx_ctx *ctx, const uint8_t *d_in, const dx_qv_dindex *x)
+{ if (ctx == NULL) return DX_E_ARG;
+  if (x == NULL || x->d_gidx == NULL || x->n == 0)
+    return dx_qv_use_index(ctx, NULL, NULL, 0, NULL, NULL, 0);
+  const int rc = dx_qv_use_index(ctx, d_in, x->d_seg, x->n, x->d_gidx, x->d_gidx_off, x->gidx_none);
+  if (rc == DX_OK) { ctx->sx.walk = 1; ctx->sx.sync_kinds = x->sync_kinds; ctx->sx.nosync = x->gidx_nosync; }
+  return rc;
 }
 
 extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_rec_off, const uint64_t *d_hdr_off,
@@ -1684,7 +1852,10 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   const uint64_t *skip_off = NULL;
   uint32_t        skip_kinds = 0;
   // the encoder's group index for this very stream (dx_qv_subindex): a wavefront per line instead of a lane
-  if (plain && ctx->sx.valid && d_in == ctx->sx.out && !(flags & DX_DECODE_FLIP) && getenv("DEXGPU_NO_SUBINDEX") == NULL &&
+  const uint32_t *sync_idx = NULL;                       // (the device walk's index: what is left for k_qv_decode_plain)
+  const uint64_t *sync_off = NULL;
+  uint32_t        sync_kinds = 0;
+  if ((plain || ctx->sx.walk) && ctx->sx.valid && d_in == ctx->sx.out && !(flags & DX_DECODE_FLIP) && getenv("DEXGPU_NO_SUBINDEX") == NULL &&
       (const uint32_t *) d_seg >= (const uint32_t *) ctx->sx.seg &&
       ((const uint32_t *) d_seg - (const uint32_t *) ctx->sx.seg) % 5 == 0)
     { const uint64_t first = (uint64_t) ((const uint32_t *) d_seg - (const uint32_t *) ctx->sx.seg) / 5;
@@ -1693,6 +1864,27 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
           DX_HIP(ctx, hipMemsetAsync(d_next3, 0, 4, ctx->stream));
           hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, a.rec_off, a.rec_off + n, (const uint32_t *) NULL, n,
                              DEC_TICKET * 14000u, DEC_TICKET, d_next3);         // (4 entries of 10 kb per ticket; more of shorter ones)
+          if (ctx->sx.walk)                                 // the device walk's index (dx_qv_use_dindex): a word per 64 symbols of a plain line
+            { const uint32_t sy = plain & ctx->sx.sync_kinds & (getenv("DEXGPU_NO_SYNCINDEX") == NULL ? 15u : 0u);
+              const int nk = __builtin_popcount(sy);
+              uint64_t sb = (n + DY_NWAVE - 1) / DY_NWAVE;
+              if (sb > cap * (nk <= 2 ? 2 : 1)) sb = cap * (nk <= 2 ? 2 : 1);
+#define SYNC_LAUNCH(NK)                                                                                       \
+              DX_LAUNCH(ctx, DX_K_QV_DEC_SUB, k_qv_decode_sync<NK>, (int) sb, DY_BLOCK, a, (const uint16_t *) ctx->d_dec,  \
+                        (const uint32_t *) ctx->d_long, d_next3, sy, (const uint32_t *) ctx->sx.idx,           \
+                        (const uint64_t *) (ctx->sx.off + first), ctx->d_status)
+              if (nk == 1)      SYNC_LAUNCH(1);
+              else if (nk == 2) SYNC_LAUNCH(2);
+              else if (nk == 3) SYNC_LAUNCH(3);
+              else if (nk == 4) SYNC_LAUNCH(4);
+#undef SYNC_LAUNCH
+              if (sy)
+                { if (ctx->sx.nosync == 0) plain &= ~sy;   // every such line had its words
+                  else { sync_idx = ctx->sx.idx; sync_off = ctx->sx.off + first; sync_kinds = sy; }
+                }
+            }
+          else
+          {
           const int nk = __builtin_popcount(plain);
           uint64_t sb = (n + DS_NWAVE - 1) / DS_NWAVE;
           if (sb > cap * (nk <= 2 ? 2 : 1)) sb = cap * (nk <= 2 ? 2 : 1);       // two workgroups per CU fit with <= 2 tables
@@ -1706,6 +1898,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
           else              SUB_LAUNCH(4);
 #undef SUB_LAUNCH
           plain = 0;                                       // done
+          }
           // the run-coded lines whose symbols have no escape code, by their token groups; what has no index
           // (entries the generic encoder took) is left to k_qv_decode below
           uint32_t runs = 0;
@@ -1734,7 +1927,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
     { uint64_t pb = (4 * ((n + 63) / 64) + DP_NWAVE - 1) / DP_NWAVE;
       if (pb > cap * DP_WG_PER_CU) pb = cap * DP_WG_PER_CU;
       DX_LAUNCH(ctx, DX_K_QV_DEC_PLAIN, k_qv_decode_plain, (int) pb, DP_BLOCK, a, (const uint16_t *) ctx->d_dec,
-                (const uint32_t *) ctx->d_long, d_next2, plain, ctx->d_status);
+                (const uint32_t *) ctx->d_long, d_next2, plain, ctx->d_status, sync_idx, sync_off, sync_kinds);
     }
   if (plain_kinds != 15u)
     DX_LAUNCH(ctx, DX_K_QV_DECODE, k_qv_decode, (int) blocks, DEC_BLOCK, a, (const uint16_t *) ctx->d_dec,

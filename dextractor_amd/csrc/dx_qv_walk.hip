@@ -28,8 +28,11 @@
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 #include "dx_walk.h"
+#include "dx_layout.h"
 
 #include <stdlib.h>
+
+int dx_scan_u32(dx_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out /* n+1 */, uint64_t *total);     // dx_qv.hip
 
 #ifndef WALK_BLOCK
 #define WALK_BLOCK     1024             // one workgroup a CU: 80 KB of tables and 72 KB of rings (a lane's next 16 words) in LDS
@@ -71,7 +74,12 @@ struct walk_args
   int             esc[4];
 };
 
-struct walk_rec_d   { uint64_t off; uint32_t hdr_bytes, len, seg[5]; int32_t dwell, beg, end, qv; uint32_t pad; };
+struct walk_rec_d   { uint64_t off; uint32_t hdr_bytes, len, seg[5]; int32_t dwell, beg, end, qv; uint32_t pad;
+                      uint32_t gat[4], gtok[4];   /* what the lane noted for the group index, line by line (del, ins, mrg, sub): where it
+                                                     starts in the lane's share of the group words, and -- a run-coded line -- the line's
+                                                     tokens (a word per 8 of them), -- a plain line -- the words noted (one per 64 symbols
+                                                     but the first); WG_NONE: nothing usable */ };
+#define WG_NONE 0xffffffffu
 struct walk_piece_d { uint64_t start, end, dwell_sum; uint32_t count, flags, hdr_sum, first_hdr /* framing bytes of the first record */; uint32_t tried /* guesses that did not hold */, lead255 /* bytes of 255 right in front of start (up to 4096) */; };
 
 __device__ __forceinline__ uint32_t bswap_if(uint32_t v, int flip) { return flip ? __builtin_bswap32(v) : v; }
@@ -294,7 +302,7 @@ struct walk_lds { uint16_t t[4][4096]; uint16_t r1[2][4096]; uint16_t one[4][409
 // mode choosing among three tables of one form, cost the burst more than the trips outside save: 119 against 106 ms.)
 __global__ __launch_bounds__(WALK_BLOCK, WALK_WGS_PER_CU * WALK_BLOCK / 256)     // (waves per SIMD: two workgroups a CU)
 void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uint32_t *todo, uint32_t ntodo,
-                   const uint64_t *start, walk_piece_d *pc, walk_rec_d *recs, uint32_t rcap)
+                   const uint64_t *start, walk_piece_d *pc, walk_rec_d *recs, uint32_t rcap, uint32_t *gwords, uint32_t gcap)
 { __shared__ walk_lds S;
 #define WALK_STAGE(tab, from, words) { const uint32_t *s_ = (const uint32_t *) (const void *) (from); uint32_t *d_ = (uint32_t *) (void *) (tab); \
                                        for (uint32_t i = threadIdx.x; i < (words); i += blockDim.x) d_[i] = s_[i]; }
@@ -319,9 +327,53 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
   uint64_t at;                         // PH_HEAD: the record's first byte; in a segment: the segment's first byte
   uint32_t ph = PH_HEAD, rlen = 0, j = 0, last = 0, nn = 0, clen = 0;
   uint32_t reclusters = 0;
+  // What the lane notes for the group index on its way (dx_layout.h), into its share of gwords (gcap words; a line the lane has no
+  // room for, or that does not fit the format, is left without: WG_NONE, a lane-per-line decoder takes it):
+  //  * a run-coded line (what k_qv_decode_runs wants to decode it a wavefront at a time): a word per 8 tokens, the bits they take |
+  //    the positions they cover << 16.  gT / gj: where the open group began; gP: where the open pass of 64 groups began;
+  //  * a plain line without escape codes (k_qv_decode_sync): a word per 64 symbols but the first 64 -- the bits passed where the
+  //    look-up began that reached symbol 64 g | the symbols from there to 64 g << 28 (<= 12: a look-up's codes).
+  // gi: the next word; gline: where the line's words began.  A burst holds at most one of either (8 look-ups: 8 tokens; <= 96
+  // symbols, and a line whose burst does pass two marks -- codes of a bit -- is left without).
+  uint32_t *myg = gwords ? gwords + k * (uint64_t) gcap : (uint32_t *) NULL;
+  uint32_t gi = 0, gT = 0, gj = 0, gP = 0, gline = 0, ghead = 0;
+  bool gbad = false, trailing = false;
+#define WALK_GROUP_OUT(Tx, jx) \
+  { const uint32_t b_ = (Tx) - gT, s_ = (jx) - gj; \
+    if (b_ > 0xffffu || s_ > 0xffffu || (gi | 3u) >= gcap) gbad = true; \
+    if ((gi | 3u) < gcap) WALK_STORE(b_ | (s_ << 16))       /* (a word of a line that is left without is stored all the same: the four go together) */ \
+    gi += 1u; gT = (Tx); gj = (jx); \
+    if (((gi - gline) & 63u) == 0u) { if ((Tx) - gP > DXL_RUN_PASSBITS) gbad = true; gP = (Tx); } \
+  }
+  /* Bx: the multiple of 64 reached; Tx: the bits passed dx symbols in front of it */ \
+#define WALK_SYNC_AT(Tx, dx, Bx) \
+  { if ((Bx) < rlen) \
+      { if ((Tx) >= (1u << 28) || (dx) > 15u || (gi | 3u) >= gcap || (Bx) != 64u * (gi - gline + 1u)) gbad = true; \
+        if ((gi | 3u) < gcap) WALK_STORE((Tx) | ((dx) << 28)) \
+        gi += 1u; \
+      } \
+  }
+  /* (Tx, jx): where the look-up began that passed a multiple of 64 */ \
+#define WALK_SYNC_OUT(Tx, jx) { const uint32_t B_ = ((jx) | 63u) + 1u; WALK_SYNC_AT(Tx, B_ - (jx), B_) }
   uint32_t trial = 0, ci = 0, nc = 0;  // trial: the record being walked is a guess (candidate ci of the piece's nc)
   uint64_t budget = ~0ull;
-  walk_rec_d r;
+  // the record being walked goes to its place in the lane's records field by field as it becomes known (a record that does not
+  // hold -- a guess -- is written over by the next; only what the lane adds up over its records stays in registers)
+  uint64_t r_off = 0;
+  uint32_t r_hdr = 0;
+  int32_t  r_dwell = 0;
+#define R_SLOT (my + (out.count < rcap ? out.count : rcap - 1u))      /* (more records than rcap: WP_OVERFLOW, the walk is the host's) */
+  // the words for the group index: four at a time to the lane's share (a lane's words one by one are 700 M four-byte writes to
+  // 250 000 different lines: 10 ms of a 32 ms kernel)
+  u32x4 gbuf = { 0u, 0u, 0u, 0u };
+#define WALK_STORE(word) \
+  { const uint32_t q_ = gi & 3u; \
+    gbuf.x = q_ == 0u ? (word) : gbuf.x; gbuf.y = q_ == 1u ? (word) : gbuf.y; gbuf.z = q_ == 2u ? (word) : gbuf.z; gbuf.w = q_ == 3u ? (word) : gbuf.w; \
+    if (q_ == 3u) *(u32x4 *) (myg + (gi - 3u)) = gbuf; \
+  }
+  /* what is left in the buffer, behind the lane's last record */ \
+#define WALK_STORE_FLUSH() \
+  { if (myg != NULL && (gi & 3u) && (gi | 3u) < gcap) *(u32x4 *) (myg + (gi & ~3u)) = gbuf; }
   wrd_d rd;
   bool live = true;
   rd.seg = a.img; rd.ring = S.ring[threadIdx.x]; rd.T = 0; rd.have = 0; rd.ua = 0; rd.ub = 0;
@@ -344,19 +396,38 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
       // WALK_SUB bursts, the rings seen to in front of each (the wave together: lanes outside a segment, or left behind by a
       // burst, ask for nothing and pass nothing).  Without branches: a lane left behind shifts by nothing and counts nothing.
       const uint16_t *tab = S.t[inseg ? line : 0u];
+      const bool runs_ = inseg && myg != NULL && ((line == 0 && a.delChar >= 0) || (line == 3 && a.subChar >= 0));
+      const bool sync_ = inseg && myg != NULL && !runs_ && !a.esc[inseg ? line : 0u];
+      // The burst, written so that nothing of it is decided by the scalar unit (one to a CU: a look-up whose conditions are
+      // and-ed and or-ed as lane masks spends more scalar than vector instructions): a lane may pass `room` more symbols (none:
+      // the burst without it); a look-up that is none (cnt = 0) or would pass more changes nothing, and neither does any after
+      // it in the burst -- the lane stands where it stood --, so no lane needs to be told that it has stopped.  A mark of the
+      // group index (the 8th token of a group, x = the tokens; a multiple of 64 symbols, x = the symbols) is passed when x
+      // changes above bit gsh; where, is kept: behind the look-up (a group's end), in front of it (gpm: the plain lines' words).
+      const uint32_t gsh = runs_ ? 3u : sync_ ? 6u : 31u, gpm = runs_ ? 0u : ~0u;
 #define WALK_BURST_ONCE(SET) \
         { w_pump_d<SET>(rd, a, more); \
           const bool ready = w_words_d(rd) >= WRING_BURST;      /* (a ring that is short: this burst without the lane) */ \
-          bool go = more && ready; \
+          uint32_t room = more && ready ? rlen - j : 0u, fT = 0u, fj = 0u, marks = 0u, x0 = runs_ ? nn : j; \
+          bool took = false; \
           _Pragma("unroll 1") \
           for (int it = 0; it < WALK_BURST; it++) \
             { const uint32_t g = tab[w_win_d(rd) >> (32 - WALK_WIN)], cnt = g >> 8; \
-              go = go && g != 0u && j + cnt <= rlen; \
-              rd.T += go ? g & 15u : 0u; \
-              j += go ? cnt : 0u; nn += go ? 1u : 0u; last = go ? (g >> 4) & 15u : last; \
-              if (!__any(go)) break; \
+              took = cnt - 1u < room; \
+              const uint32_t nb = took ? g & 15u : 0u, c = took ? cnt : 0u; \
+              rd.T += nb; j += c; room -= c; nn += took ? 1u : 0u; last = took ? (g >> 4) & 15u : last; \
+              const uint32_t x1 = runs_ ? nn : j; \
+              const bool mark = ((x0 ^ x1) >> gsh) != 0u; \
+              marks += mark ? 1u : 0u; \
+              fT = mark ? rd.T - (nb & gpm) : fT; fj = mark ? j - (c & gpm) : fj; \
+              x0 = x1; \
+              if (!__any(took)) break; \
             } \
-          more = more && (go || !ready); \
+          if (marks) \
+            { if (marks > 1u) gbad = true; \
+              if (runs_) WALK_GROUP_OUT(fT, fj) else WALK_SYNC_OUT(fT, fj) \
+            } \
+          more = more && (took || !ready); \
         }
       #pragma unroll 1
       for (int sub = 0; sub < WALK_SUB; sub += 2)
@@ -375,6 +446,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
               if (j < rlen)                                     // one step of another kind
                 { uint32_t w = w_peek_d(rd);
                   bool sym = true;                              // a symbol's code is to be passed
+                  const uint32_t T0 = rd.T, j0 = j;
                   if (runs)                                     // walk_runs: the run code alone first
                     { const uint32_t e1 = S.r1[line ? 1u : 0u][w >> (16 - WALK_WIN)];
                       uint32_t c;
@@ -391,6 +463,8 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                       j  += c;
                       sym = !fail && j < rlen;
                       if (sym) w = w_peek_d(rd);
+                      else if (runs_ && (nn & 7u))              // the line ends in a run: no token, and none of the open group's bits
+                        { WALK_GROUP_OUT(T0, j0) trailing = true; }
                     }
                   if (sym)                                      // walk_plain's single code; walk_runs' symbol behind the run
                     { const uint32_t f = S.one[line][w >> (16 - WALK_WIN)] & 15u;
@@ -405,6 +479,8 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                         }
                       j  += 1;
                       nn += 1;
+                      if (runs_ && (nn & 7u) == 0u) WALK_GROUP_OUT(rd.T, j)
+                      if (sync_ && (j & 63u) == 0u) WALK_SYNC_AT(rd.T, 0u, j)
                     }
                 }
               const uint64_t T = rd.T;                                     // bits of the segment passed
@@ -413,16 +489,23 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
                 { const uint64_t bytes = 4ull * pad_words_d(T, last);
                   if (at + bytes > a.n) fail = true;
                   else
-                    { if (line == 0) r.seg[0] = (uint32_t) bytes; else if (line == 1) r.seg[2] = (uint32_t) bytes;
-                      else if (line == 2) r.seg[3] = (uint32_t) bytes; else r.seg[4] = (uint32_t) bytes;
+                    { walk_rec_d *rs = R_SLOT;
+                      rs->seg[line ? line + 1u : 0u] = (uint32_t) bytes;
                       at += bytes;
+                      // what the lane has noted of the line for the group index: where it is, how much of it
+                      if (runs_ && (nn & 7u) && !trailing) WALK_GROUP_OUT(rd.T, j)
+                      { const uint32_t gt = gbad ? WG_NONE : runs_ ? nn : sync_ && gi - gline + 1u == ((rlen + 63u) >> 6) ? gi - gline : WG_NONE;
+                        rs->gat[line] = gline; rs->gtok[line] = gt;
+                      }
                       if (line == 0)                            // the tags (Pack_Tag's count, QV.c:810-819): no codes, just bytes
                         { if (runs) clen = nn;
-                          r.seg[1] = (clen + 3u) >> 2;
-                          if (at + r.seg[1] > a.n) fail = true;
-                          at += r.seg[1];
+                          const uint32_t tb = (clen + 3u) >> 2;
+                          rs->seg[1] = tb;
+                          if (at + tb > a.n) fail = true;
+                          at += tb;
                         }
                       ph += 1; j = 0; last = 0; nn = 0;
+                      gT = 0; gj = 0; gP = 0; gline = gi; gbad = false; trailing = false;
                       if (ph < PH_DONE && !fail) w_open_d(rd, a, a.img + at);
                     }
                 }
@@ -443,26 +526,30 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
               rlen = (uint32_t) ((int64_t) end_ - (int64_t) beg);
               if (end_ < beg || (int64_t) end_ - (int64_t) beg > WALK_RLEN_MAX || (uint64_t) rlen > 65536u * 8u * (uint64_t) (a.n - at) + 64u)
                 fail = true;
-              r.off = h0; r.hdr_bytes = (uint32_t) (at - h0); r.len = rlen; r.dwell = dw; r.beg = beg; r.end = end_; r.qv = qv; r.pad = 0;
+              r_off = h0; r_hdr = (uint32_t) (at - h0); r_dwell = dw;
+              { walk_rec_d *rs = R_SLOT;
+                rs->off = h0; rs->hdr_bytes = r_hdr; rs->len = rlen; rs->dwell = dw; rs->beg = beg; rs->end = end_; rs->qv = qv; rs->pad = 0;
+              }
               if (trial)                                        // (see WALK_TRIAL_RLEN)
                 { if (rlen > (uint32_t) WALK_TRIAL_RLEN) fail = true;
                   budget = 32ull * rlen + 8192u < 16u * a.piece ? 32ull * rlen + 8192u : 16u * a.piece;
                 }
               ph = PH_DEL; j = 0; last = 0; nn = 0; clen = rlen;
+              ghead = gi; gT = 0; gj = 0; gP = 0; gline = gi; gbad = false; trailing = false;
               if (!fail) w_open_d(rd, a, a.img + at);
             }
         }
       else                                                      // PH_DONE: `at` is behind the record
         { if (trial)
             { if (at == a.n || header_plausible_d(a, at))       // the guess holds: the lane's first record
-                { out.start = r.off; trial = 0; budget = ~0ull; }
+                { out.start = r_off; trial = 0; budget = ~0ull; }
               else
                 fail = true;
             }
           if (!fail)
-            { if (out.count < rcap) my[out.count] = r; else out.flags |= WP_OVERFLOW;
-              if (out.count == 0) out.first_hdr = r.hdr_bytes;
-              out.count += 1; out.hdr_sum += r.hdr_bytes; out.dwell_sum += (uint64_t) (uint32_t) r.dwell;
+            { if (out.count >= rcap) out.flags |= WP_OVERFLOW;
+              if (out.count == 0) out.first_hdr = r_hdr;
+              out.count += 1; out.hdr_sum += r_hdr; out.dwell_sum += (uint64_t) (uint32_t) r_dwell;
               ph = PH_HEAD;
               if (!(at < hi && at < a.n)) { out.end = at; live = false; }
             }
@@ -470,6 +557,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
       if (fail)
         { if (trial)                                            // a wrong guess: the piece's next one
             { ci += 1;
+              gi = ghead;                                       // (its groups are nobody's)
               if (ci < nc) { at = cand[k * WALK_CAND + ci]; ph = PH_HEAD; }
               else                                              // none of the cluster held (rare): the next cluster, found by the lane itself
                 { uint64_t *c = cand + k * WALK_CAND, last = 0;   // (through memory: no registers for what happens once in ten thousand pieces)
@@ -496,6 +584,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
       out.lead255 = c;
     }
   (void) rounds_;
+  WALK_STORE_FLUSH()
   pc[k] = out;
 }
 
@@ -505,7 +594,8 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
 __global__ __launch_bounds__(DX_BLOCK)
 void k_walk_gather(uint64_t pieces, const walk_piece_d *pc, const walk_rec_d *recs, uint32_t rcap, const uint64_t *dst,
                    const uint64_t *hbase, const uint64_t *wbase, const uint64_t *trim,
-                   uint64_t *rec_off, uint64_t *hdr_off, uint32_t *seg, uint32_t *len, int32_t *hdr4)
+                   uint64_t *rec_off, uint64_t *hdr_off, uint32_t *seg, uint32_t *len, int32_t *hdr4,
+                   uint32_t gcap, uint64_t *gsrc /* 4 a record: where its lines' words lie in the lanes' group words */, uint32_t *gtok)
 { const uint32_t lane = (uint32_t) lane_id();
   const uint64_t k = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
   if (k >= pieces || dst[k] == ~0ull) return;
@@ -529,9 +619,69 @@ void k_walk_gather(uint64_t pieces, const walk_piece_d *pc, const walk_rec_d *re
           len[o]     = r.len;
           seg[5 * o] = r.seg[0]; seg[5 * o + 1] = r.seg[1]; seg[5 * o + 2] = r.seg[2]; seg[5 * o + 3] = r.seg[3]; seg[5 * o + 4] = r.seg[4];
           hdr4[4 * o] = (int32_t) (wb + di_); hdr4[4 * o + 1] = r.beg; hdr4[4 * o + 2] = r.end; hdr4[4 * o + 3] = r.qv;
+          if (gsrc)
+            for (int x = 0; x < 4; x++)
+              { gsrc[4 * o + x] = k * (uint64_t) gcap + r.gat[x];
+                gtok[4 * o + x] = r.gtok[x];
+              }
         }
       hb += wave_total(hi_); wb += wave_total(di_);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  the run-coded lines' share of the group index (dx_layout.h), from the lanes' group words
+// ---------------------------------------------------------------------------------------------
+// An entry's share: room for the four plain lines' bytes (left as they are: nobody reads them, DXL_RUNS_ONLY), three header words
+// -- the deletion line's tokens or DXL_RUN_NONE, the substitution line's, the deletion line's passes | DXL_RUN_EIGHTS --, then 64
+// words per pass of 512 tokens of either line.  The lanes noted a word per 8 tokens, the last group of a line whatever was
+// left: pass p's lane l decodes tokens 512 p + 8 l ... (k_qv_encode_fast deals the last pass's m tokens (m + 63) / 64 a lane:
+// DXL_RUN_EIGHTS says which).
+__global__ __launch_bounds__(DX_BLOCK)
+void k_walk_rooms(const uint32_t *len, const uint32_t *gtok, uint64_t n, int del_runs, int sub_runs, uint32_t *room)
+{ const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t d = del_runs ? gtok[4 * i] : WG_NONE, s_ = sub_runs ? gtok[4 * i + 3] : WG_NONE;
+  room[i] = dxl_run_base(len[i]) + 3u + 64u * ((d == WG_NONE ? 0u : dxl_run_passes(d)) + (s_ == WG_NONE ? 0u : dxl_run_passes(s_)));
+}
+
+// a wave per entry: the header words, the run-coded lines' groups (zeros behind a line's last, to the pass's end), and the plain
+// lines' words: word g of a line's share = what the lane noted for symbol 64 g (word 0: 0, or DXL_SYNC_NONE: no words for this line)
+__global__ __launch_bounds__(DX_BLOCK)
+void k_walk_index(const uint32_t *len, const uint32_t *gtok, const uint64_t *gsrc, const uint32_t *gwords, uint64_t n,
+                  const uint64_t *goff, uint32_t *gidx, int del_runs, int sub_runs, uint32_t sync_kinds, uint32_t *none /* [0] run-coded, [1] plain lines without */)
+{ const uint32_t lane = (uint32_t) lane_id();
+  const uint64_t i = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const uint32_t L = len[i];
+  const uint32_t d = del_runs ? gtok[4 * i] : WG_NONE, s_ = sub_runs ? gtok[4 * i + 3] : WG_NONE;
+  const uint32_t pd = d == WG_NONE ? 0u : dxl_run_passes(d), ps = s_ == WG_NONE ? 0u : dxl_run_passes(s_);
+  uint32_t *share = gidx + goff[i], *base = share + dxl_run_base(L);
+  if (lane == 0)
+    { base[0] = d == WG_NONE ? DXL_RUN_NONE : d;
+      base[1] = s_ == WG_NONE ? DXL_RUN_NONE : s_;
+      base[2] = pd | DXL_RUN_EIGHTS;
+      const uint32_t lost = (del_runs && d == WG_NONE ? 1u : 0u) + (sub_runs && s_ == WG_NONE ? 1u : 0u);
+      if (lost) atomicAdd(none, lost);
+    }
+  for (int x = 0; x < 4; x += 3)
+    { const uint32_t tokens = x ? s_ : d, passes = x ? ps : pd;
+      if (tokens == WG_NONE) continue;
+      const uint32_t groups = (tokens + 7u) >> 3;
+      const uint32_t *from = gwords + gsrc[4 * i + x];
+      uint32_t *to = base + 3u + (x ? 64u * pd : 0u);
+      for (uint32_t g = lane; g < 64u * passes; g += 64u) to[g] = g < groups ? from[g] : 0u;
+    }
+  const uint32_t sw = dxl_sub_words(L);
+  for (uint32_t q = 0; q < 4; q++)
+    if (((sync_kinds >> q) & 1u) && sw)
+      { const uint32_t cnt = gtok[4 * i + q];
+        const bool ok = cnt != WG_NONE && cnt + 1u == sw;
+        const uint32_t *from = gwords + gsrc[4 * i + q];
+        uint32_t *to = share + (uint64_t) q * sw;
+        if (lane == 0) { to[0] = ok ? 0u : DXL_SYNC_NONE; if (!ok) atomicAdd(none + 1, 1u); }
+        if (ok) for (uint32_t g = 1u + lane; g < sw; g += 64u) to[g] = from[g - 1u];
+      }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -541,6 +691,7 @@ void dx_qv_dindex_free(dx_ctx *ctx, dx_qv_dindex *x)
 { if (x == NULL) return;
   (void) ctx;
   (void) hipFree(x->d_rec_off); (void) hipFree(x->d_hdr_off); (void) hipFree(x->d_seg); (void) hipFree(x->d_len); (void) hipFree(x->d_hdr4);
+  (void) hipFree(x->d_gidx); (void) hipFree(x->d_gidx_off);
   memset(x, 0, sizeof(*x));
 }
 
@@ -568,10 +719,14 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   }
   const uint64_t P = a.pieces;
   const uint32_t rcap = (uint32_t) (a.piece / 128u);
+  // the run-coded lines' group words: a word per 8 tokens.  A share of piece / 8 words holds a token per 4 bytes of the piece; lines
+  // of a lane that runs out are left without (DEXGPU_WALK_NOGROUPS: none at all -- the index is then the round-4 one)
+  const bool     groups = !flip && getenv("DEXGPU_WALK_NOGROUPS") == NULL;
+  const uint32_t gcap = groups ? (uint32_t) (a.piece / 8u) : 0u;
   { // does the scratch fit (56 bytes a possible record, 0.44 of the stream) with room for the index behind it?  Asked first: a
     // failed allocation half way costs the allocations before it, and the caller has another way (the host walk).
     uint64_t fr = 0, all = 0;
-    const double need = (double) P * ((double) rcap * sizeof(walk_rec_d) + sizeof(walk_piece_d) + WALK_CAND * 8 + 48) + 0.06 * (double) (n - first) + (64 << 20);
+    const double need = (double) P * ((double) rcap * sizeof(walk_rec_d) + 4.0 * gcap + sizeof(walk_piece_d) + WALK_CAND * 8 + 48) + 0.2 * (double) (n - first) + (64 << 20);
     if (dx_mem_info(ctx, &fr, &all) == DX_OK && fr > 0 && need > (double) fr)
       return dx_fail(ctx, DX_E_NOMEM, "dx_qv_walk_device: %.1f GB of scratch do not fit the device's free %.1f GB", need / 1e9, (double) fr / 1e9);
   }
@@ -582,6 +737,8 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   uint32_t *d_ncand = NULL, *d_todo = NULL;
   walk_piece_d *d_pc = NULL, *pc = (walk_piece_d *) malloc(P * sizeof(walk_piece_d));
   walk_rec_d   *d_recs = NULL;
+  uint32_t *d_gwords = NULL, *d_gtok = NULL, *d_room = NULL, *d_none = NULL;
+  uint64_t *d_gsrc = NULL;
   uint64_t *dst = (uint64_t *) malloc(4 * P * 8), *trim = dst ? dst + 3 * P : NULL;
   uint8_t  *onchain = (uint8_t *) calloc(P, 1);
   uint64_t N = 0;
@@ -596,6 +753,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   WALK_HIP(hipMalloc(&d_ncand, P * 4));
   WALK_HIP(hipMalloc(&d_pc, P * sizeof(walk_piece_d)));
   WALK_HIP(hipMalloc(&d_recs, P * (uint64_t) rcap * sizeof(walk_rec_d)));
+  if (groups) WALK_HIP(hipMalloc(&d_gwords, P * (uint64_t) gcap * 4u));
   WALK_HIP(hipMemcpyAsync(d_blob, blob, WALK_BLOB_BYTES, hipMemcpyHostToDevice, ctx->stream));
   a.w16 = (const uint16_t *) (d_blob + WALK_W16_OFF); a.mw = (const uint16_t *) (d_blob + WALK_MW_OFF);
   a.rw  = (const uint16_t *) (d_blob + WALK_RW_OFF);  a.r1 = (const uint16_t *) (d_blob + WALK_R1_OFF);
@@ -616,7 +774,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
     hipLaunchKernelGGL(k_walk_find, dim3((unsigned) ((P + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream, a, d_cand, d_ncand);
     if (timed) (void) hipEventRecord(ev[1], ctx->stream);
     hipLaunchKernelGGL(k_walk_pieces, dim3((unsigned) ((P + bs - 1) / bs)), dim3(bs), 0, ctx->stream, a, d_cand,
-                       (const uint32_t *) d_ncand, (const uint32_t *) NULL, 0u, (const uint64_t *) NULL, d_pc, d_recs, rcap);
+                       (const uint32_t *) d_ncand, (const uint32_t *) NULL, 0u, (const uint64_t *) NULL, d_pc, d_recs, rcap, d_gwords, gcap);
     if (timed) (void) hipEventRecord(ev[2], ctx->stream);
     dx_prof_end(ctx);
     if (timed)
@@ -666,7 +824,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
             WALK_HIP(hipMemcpyAsync(d_todo, &kk, 4, hipMemcpyHostToDevice, ctx->stream));
             dx_prof_begin(ctx, DX_K_QV_WALK);
             hipLaunchKernelGGL(k_walk_pieces, dim3(1), dim3(64), 0, ctx->stream, a, d_cand, (const uint32_t *) d_ncand,
-                               (const uint32_t *) d_todo, 1u, (const uint64_t *) d_start, d_pc, d_recs, rcap);
+                               (const uint32_t *) d_todo, 1u, (const uint64_t *) d_start, d_pc, d_recs, rcap, d_gwords, gcap);
             dx_prof_end(ctx);
             WALK_HIP(hipGetLastError());
             WALK_HIP(hipMemcpyAsync(pc + k, d_pc + k, sizeof(walk_piece_d), hipMemcpyDeviceToHost, ctx->stream));
@@ -700,11 +858,13 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
     WALK_HIP(hipMalloc(&out->d_seg, (N + 1) * 20));
     WALK_HIP(hipMalloc(&out->d_len, (N + 1) * 4));
     WALK_HIP(hipMalloc(&out->d_hdr4, (N + 1) * 16));
+    if (groups && N > 0)
+      { WALK_HIP(hipMalloc(&d_gsrc, N * 32)); WALK_HIP(hipMalloc(&d_gtok, N * 16)); }
     dx_prof_begin(ctx, DX_K_QV_WALK);
     hipLaunchKernelGGL(k_walk_gather, dim3((unsigned) ((P + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream,
                        P, (const walk_piece_d *) d_pc, (const walk_rec_d *) d_recs, rcap, (const uint64_t *) d_dst,
                        (const uint64_t *) (d_dst + P), (const uint64_t *) (d_dst + 2 * P), (const uint64_t *) (d_dst + 3 * P),
-                       out->d_rec_off, out->d_hdr_off, out->d_seg, out->d_len, out->d_hdr4);
+                       out->d_rec_off, out->d_hdr_off, out->d_seg, out->d_len, out->d_hdr4, gcap, d_gsrc, d_gtok);
     dx_prof_end(ctx);
     WALK_HIP(hipGetLastError());
     const uint64_t ends[2] = { n, hb };
@@ -713,10 +873,39 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
     WALK_HIP(hipStreamSynchronize(ctx->stream));
     out->n = N; out->pieces = P; out->piece_bytes = a.piece;
   }
+  // the run-coded lines' share of the group index, laid out as the decoders take it (an entry's room, a scan, the words)
+  if (groups && N > 0)
+    { uint64_t words = 0;
+      uint32_t lost[2] = { 0, 0 }, sync_kinds = 0;
+      for (int q = 0; q < 4; q++)                          // the plain lines without escape codes (dx_qv_decode's `plain`)
+        if ((q == 0 ? cd->delChar : q == 3 ? cd->subChar : -1) < 0 && !a.esc[q]) sync_kinds |= 1u << q;
+      WALK_HIP(hipMalloc(&d_room, N * 4));
+      WALK_HIP(hipMalloc(&d_none, 64));
+      WALK_HIP(hipMalloc(&out->d_gidx_off, (N + 1) * 8));
+      WALK_HIP(hipMemsetAsync(d_none, 0, 8, ctx->stream));
+      dx_prof_begin(ctx, DX_K_QV_WALK);
+      hipLaunchKernelGGL(k_walk_rooms, dim3((unsigned) ((N + DX_BLOCK - 1) / DX_BLOCK)), dim3(DX_BLOCK), 0, ctx->stream,
+                         (const uint32_t *) out->d_len, (const uint32_t *) d_gtok, N, cd->delChar >= 0 ? 1 : 0, cd->subChar >= 0 ? 1 : 0, d_room);
+      dx_prof_end(ctx);
+      WALK_HIP(hipGetLastError());
+      rc = dx_scan_u32(ctx, d_room, N, out->d_gidx_off, &words);
+      if (rc != DX_OK) goto done;
+      WALK_HIP(hipMalloc(&out->d_gidx, (words + 4) * 4));
+      dx_prof_begin(ctx, DX_K_QV_WALK);
+      hipLaunchKernelGGL(k_walk_index, dim3((unsigned) ((N + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream,
+                         (const uint32_t *) out->d_len, (const uint32_t *) d_gtok, (const uint64_t *) d_gsrc, (const uint32_t *) d_gwords, N,
+                         (const uint64_t *) out->d_gidx_off, out->d_gidx, cd->delChar >= 0 ? 1 : 0, cd->subChar >= 0 ? 1 : 0, sync_kinds, d_none);
+      dx_prof_end(ctx);
+      WALK_HIP(hipGetLastError());
+      WALK_HIP(hipMemcpyAsync(lost, d_none, 8, hipMemcpyDeviceToHost, ctx->stream));
+      WALK_HIP(hipStreamSynchronize(ctx->stream));
+      out->gidx_words = words; out->gidx_none = lost[0]; out->gidx_nosync = lost[1]; out->sync_kinds = sync_kinds;
+    }
   rc = DX_OK;
 done:
   (void) hipFree(d_blob); (void) hipFree(d_tail); (void) hipFree(d_cand); (void) hipFree(d_ncand); (void) hipFree(d_pc); (void) hipFree(d_recs);
   (void) hipFree(d_start); (void) hipFree(d_todo); (void) hipFree(d_dst);
+  (void) hipFree(d_gwords); (void) hipFree(d_gtok); (void) hipFree(d_room); (void) hipFree(d_none); (void) hipFree(d_gsrc);
   free(blob); free(pc); free(dst); free(onchain);
   if (rc != DX_OK) dx_qv_dindex_free(ctx, out);
   return rc;

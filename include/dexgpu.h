@@ -386,7 +386,7 @@ void dx_qv_index_free(dx_qv_index *idx);
  * walk's (csrc/dx_qv_walk.hip).  The arrays are device memory of the library's (dx_qv_dindex_free): what dx_qv_decode
  * takes, and d_hdr4 (n x 4: well, beg, end, qv) for the header lines.  DX_E_MISMATCH: the walks did not chain up, a record
  * did not walk, 16-bit framing fields -- the caller then walks on the host (dx_qv_walk), which also names what is wrong
- * with a damaged file.  No group index (dx_qv_walk_indexed has one).                                                  */
+ * with a damaged file.  The run-coded lines' groups of the group index are noted on the way (dx_qv_use_dindex).               */
 typedef struct
   { uint64_t  n;                /* records */
     uint64_t *d_rec_off;        /* n + 1 */
@@ -395,10 +395,22 @@ typedef struct
     uint32_t *d_len;            /* n */
     int32_t  *d_hdr4;           /* n x 4 */
     uint64_t  pieces, piece_bytes;      /* how the stream was cut (for logs) */
+    /* the run-coded lines' share of the group index (NULL: none made -- neither line run-coded, a byte-swapped stream):
+       gidx_words words, gidx_off[n + 1] where each entry's begin, gidx_none run-coded lines without (dx_qv_use_dindex) */
+    uint32_t *d_gidx;
+    uint64_t *d_gidx_off;
+    uint64_t  gidx_words, gidx_none;
+    uint64_t  gidx_nosync;      /* plain lines without their words (where every 64th symbol is) */
+    uint32_t  sync_kinds;       /* bit q: the plain lines of kind q (0 del, 1 ins, 2 mrg, 3 sub) have such words */
   } dx_qv_dindex;
 int  dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t first, const dx_qv_coding *cd, int newv, int flip,
                        dx_qv_dindex *out);
 void dx_qv_dindex_free(dx_ctx *ctx, dx_qv_dindex *x);
+/* Hands the index a device walk has left to the decoder: a dx_qv_decode of the stream at d_in with x's arrays (the whole of
+ * it or a contiguous part) then decodes every run-coded line -- and the tag line with the deletion line -- a wavefront at a
+ * time (k_qv_decode_runs; QV.c:604-691, 823-847) instead of a lane; the plain lines have no groups in this index and stay with
+ * the lane-per-line kernel.  x == NULL or x->d_gidx == NULL: takes it back.  x must outlive the decodes.                  */
+int  dx_qv_use_dindex(dx_ctx *ctx, const uint8_t *d_in, const dx_qv_dindex *x);
 
 /* Group index (on = 1): dx_qv_encode_onepass also leaves, in the context, where the codes are: one byte per group of
  * 16 symbols of each plain line (the group's code bits), one word per group of <= 8 (run, symbol) tokens of each

@@ -237,3 +237,47 @@ def test_a_walk_that_cannot_allocate_leaves_the_host_walk_a_clean_slate(ctx, mon
         ctx.undexqv(img)
     monkeypatch.delenv("DEXGPU_FAIL_MALLOC_OVER")
     assert ctx.undexqv(img) == want                                          # nothing of it is left behind
+
+
+@pytest.mark.parametrize("n,mean,piece,prof", [(1500, 4000, 16384, None), (60, 9000, 8192, None), (300, 3000, 4096, (0.3, 0.3)),
+                                               (40, 9000, 4096, (0.999, 0.97)), (2500, 2000, 0, None), (3000, 40, 4096, None)])
+def test_decode_with_the_groups_the_walk_notes(ctx, monkeypatch, n, mean, piece, prof):
+    """dx_qv_walk_device notes a word per 8 tokens of every run-coded line (dx_layout.h, DXL_RUN_EIGHTS) and lays them out as
+    k_qv_decode_runs takes them (dx_qv_use_dindex): the decode with them is the oracle's text (QV.c:604-691, 823-847), the wave-per-line
+    kernel ran, and the lines that got no groups (runs with literals: a group's positions beyond 16 bits) still come out right."""
+    if piece:
+        monkeypatch.setenv("DEXGPU_WALK_PIECE", str(piece))
+    kw = {"prof": synth.pacbio_profile(del_run_p=prof[0], sub_run_p=prof[1])} if prof else {}
+    c = synth.make_quiva(n, seed=300 + n, mean=mean, **kw)
+    img = O.dexqv(c.text)
+    want = O.undexqv(img)
+    coding, flip, prefix, used = api.qv_read_coding(img[2:])
+    h = api.qv_walk(img)
+    d = ctx.to_device(np.frombuffer(img + b"\0" * 64, np.uint8))
+    x = ctx.qv_walk_device(d, len(img), 2 + used, coding, 1, flip)
+    try:
+        assert x.n == h["n"] and x.gidx is not None
+        L_ = h["len"].astype(np.uint64)
+        hl = np.array([len(b"%s/%d/%d_%d RQ=0.%d\n" % (prefix, *h["hdr4"][i])) for i in range(x.n)], np.uint64)
+        ooff = (np.cumsum(hl + 5 * (L_ + 1)) - 5 * (L_ + 1)).astype(np.uint64)
+        total = int(ooff[-1] + 5 * (L_[-1] + 1)) if x.n else 0
+        d_out = ctx.to_device(np.zeros(total + 64, np.uint8))
+        d_oo = ctx.to_device(ooff)
+        ctx.qv_set_coding(coding)
+        x.use(d)
+        ctx.profile(True)
+        ctx.qv_decode(d, x.rec_off, x.hdr_off, x.seg, x.len, x.n, False, d_out, d_oo)
+        kt = ctx.kernel_times()
+        ctx.profile(False)
+        x.use(None)
+        got = d_out.download(np.uint8, total)
+        wantb = np.frombuffer(want, np.uint8)
+        assert len(wantb) == total
+        for i in range(x.n):                                     # (the decoder writes the five data lines; the header lines are the caller's)
+            a, b = int(ooff[i]), int(ooff[i] + 5 * (L_[i] + 1))
+            assert (got[a:b] == wantb[a:b]).all(), i
+        assert "k_qv_decode_runs" in kt
+        d_out.free(); d_oo.free()
+    finally:
+        x.free()
+        d.free()
