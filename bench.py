@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--scratch-budget-gb", type=float, default=None,
                     help="dexqv: memory the one-pass encoder may take for its scratch regions (dx_set_scratch_budget); default: "
                          "none at N=1 (by free device memory), 64 at N>1 so that every rank of a sharded job takes the same route")
+    ap.add_argument("--cli-large-gb", type=float, default=20.0,
+                    help="size of the .quiva the tools are timed on end to end in the cpu_baseline leg (tools/cli_scale.py); 0: not at all")
     ap.add_argument("--no-walk-index", action="store_true",
                     help="dexqv: skip the decode of the batch with the HOST walk's group index (brings the 14 GB stream to the host and walks it)")
     ap.add_argument("--only-main", action="store_true",
@@ -490,13 +492,18 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                     dix.use(None)
                     state["device_walk"].update({"decode_ms_from_this_index": round(decw_ms, 2), "decode_bit_exact": bool(okw and okw0), "ms_by_kernel": dict(dec_parts),
                                                  "walk_and_decode_ms": round((kt[0] if kt else 0.0) + decw_ms, 2),
-                                                 "run_lines_without_groups": dix.gidx_none, "group_index_bytes": 4 * dix.gidx_words,
+                                                 "run_lines_without_groups": dix.gidx_none, "plain_lines_without_words": dix.gidx_nosync, "group_index_bytes": 4 * dix.gidx_words,
                                                  "decode_ms_without_the_groups": round(decw0_ms, 2), "ms_by_kernel_without_the_groups": parts0})
                     roundtrip = roundtrip and okw and okw0
                 dix.free()
-            except Exception as e:
-                ctx.profile(False)
-                state["device_walk"] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
+            except Exception as e:                                # (the bench's own, undamaged stream: a walk that turns it down, or a
+                ctx.profile(False)                                # decode that fails, is a defect -- never "skipped"; no room for the
+                if getattr(e, "code", None) == -6 or isinstance(e, torch.OutOfMemoryError):      # walk's scratch beside a 125 GB slice is not)
+                    torch.cuda.empty_cache()
+                    state["device_walk"] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
+                else:
+                    state["device_walk"] = {"failed": f"{type(e).__name__}: {e}"[:200], "index_identical_to_the_encoders": False, "decode_bit_exact": False}
+                    roundtrip = False
         if not args.twopass and index_decode and not args.no_walk_index and world == 1:
             # ... and as a bare file gets it: the record stream goes to the host as a .dexqv image, dx_qv_walk_indexed finds the
             # segment boundaries AND leaves the group index (host threads; it passes every code anyway), dx_qv_use_index hands
@@ -627,6 +634,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                           "whole step (k_qv_prescan, k_qv_hist, host tables, k_qv_encode_fast + k_qv_compact per group)",
                 "bound": "hbm", "achieved": round(step_algo / step_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(step_algo / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": step_traffic,
+                "traffic_source": "PMC passes of the committed evidence set (" + os.path.relpath(args.traffic_file, ROOT) + "): a constant of the tree, not a measurement of this run" if step_traffic is not None else None,
                 "algo_bytes_per_step": step_algo,
                 "formula": "SURVEY 8(d): (4 B/base histogram pass + 5 B/base encode pass + output bytes) / step wall time / 8 TB/s",
                 "dominant_kernel": {"kernel": dom, "ms_avg_launch": round(dom_ms_launch, 4),
@@ -679,6 +687,15 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                     for k, v in kern.items()},
     }
     if world > 1:
+        # what ONE GPU does with the same slice (2.5 M entries) when it runs alone: the figure a scaling efficiency is to be read
+        # against -- the N = 1 line of this bench is BASELINE configs[3], 1 M entries, a different per-GPU workload (measured by
+        # tools/evidence.sh under WORLD_SIZE=1 --entries 2500000, kept in profiles/per_gpu_reference.json)
+        try:
+            ref = json.load(open(os.path.join(ROOT, "profiles", "per_gpu_reference.json")))
+            if ref.get("entries_per_gpu") == n and ref.get("mean_len") == args.mean:
+                line["per_gpu_reference"] = ref
+        except Exception:
+            line["per_gpu_reference"] = None
         dist.destroy_process_group()
     del d_text, p_out, state["p_out"], p_text
     ctx.close()
@@ -770,6 +787,25 @@ def cpu_baseline(ctx, api, d_text, off, lens, hlen, args, state, big):
         res["cli_end_to_end" if tool == "dexqv" else "cli_undexqv_end_to_end"] = {
             "seconds": round(dtc, 3), "GBps": round(5 * sbases / dtc / 1e9, 3), "output_identical": bool(same),
             "runs_s": runs, "note": "process start to exit, tmpfs to tmpfs, best of the runs; this process holds the GPU meanwhile"}
+
+    # ... and on a LARGE file (tools/cli_scale.py: a 20 GB .quiva and its 4 GB .fasta, made, packed, unpacked and compared in a
+    # process of its own; per-stage marks of the tools in "marks_ms")
+    if args.cli_large_gb > 0:
+        trace("cpu_baseline: the tools on a large file")
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_scale.py"), str(args.cli_large_gb)], capture_output=True, timeout=900)
+            big_cli = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            brief = {"file": big_cli["file"]}
+            for tool_, runs_ in big_cli["runs"].items():
+                best = min(runs_, key=lambda x: x["s"])
+                brief[tool_] = {k_: v_ for k_, v_ in best.items() if k_ != "marks_ms"}
+                brief[tool_]["stages_ms"] = [m_ for m_ in best["marks_ms"] if m_[1] not in ("start", "set device", "device properties", "events")]
+                brief[tool_]["all_runs_s"] = [x["s"] for x in runs_]
+                ok_ = [x.get("round_trip_identical") for x in runs_ if x.get("round_trip_identical") is not None]
+                brief[tool_]["round_trip_identical"] = bool(ok_) and all(ok_) if tool_.startswith("un") else None
+            res["cli_end_to_end_large"] = brief
+        except Exception as e:
+            res["cli_end_to_end_large"] = {"skipped": f"{type(e).__name__}: {e}"[:300]}
 
     # how the single-threaded reference would be deployed: one independent copy per host core
     trace("cpu_baseline: all cores")
@@ -938,7 +974,8 @@ def pack2_bench(args, arrow):
                        "text_bytes": text_in, "packed_bytes": out_bytes},
             "roofline": {"kernel": "k_pack2_encode", "bound": "hbm", "achieved": round(algo_enc / (enc_ms * 1e-3) / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_enc / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "traffic": tr, "algo_bytes_per_launch": algo_enc},
+                         "traffic": tr, "traffic_source": "PMC passes of the committed evidence set (" + os.path.relpath(args.traffic_file, ROOT) + "): a constant of the tree, not a measurement of this run" if tr is not None else None,
+                         "algo_bytes_per_launch": algo_enc},
             "decode": {"kernel": "k_pack2_decode", "ms": round(dec_ms, 3), "GBps": round(algo_dec / (dec_ms * 1e-3) / 1e9, 1),
                        "frac": round(algo_dec / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                        "traffic": read_traffic(args.traffic_file, name, "k_pack2_decode", dict(reads=n, mean=args.mean))},

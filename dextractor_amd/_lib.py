@@ -129,6 +129,9 @@ SIGNATURES = {
     "dx_qv_walk_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "dx_qv_dindex_free": (None, [_P, _P]),
     "dx_qv_use_dindex": (C.c_int, [_P, _P, _P]),
+    "dx_set_sink_threads": (C.c_int, [_P, C.c_int]),
+    "dx_h2d_fd": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_size_t]),
+    "dx_file_dexqv_fd_to": (C.c_int, [_P, C.c_int, C.c_size_t, C.c_int, SINK_FN, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dx_qv_use_index": (C.c_int, [_P, _P, _P, C.c_uint64, _P, _P, C.c_uint64]),
     "dx_qv_index_free": (None, [_P]),
     "dx_file_pack2": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.POINTER(_P), C.POINTER(C.c_size_t),

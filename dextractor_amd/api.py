@@ -68,7 +68,7 @@ class DeviceIndex:
         self.pieces, self.piece_bytes = int(x.pieces), int(x.piece_bytes)
         self.rec_off, self.hdr_off = self._View(x.d_rec_off), self._View(x.d_hdr_off)
         self.seg, self.len, self.hdr4 = self._View(x.d_seg), self._View(x.d_len), self._View(x.d_hdr4)
-        self.gidx_words, self.gidx_none = int(x.gidx_words), int(x.gidx_none)
+        self.gidx_words, self.gidx_none, self.gidx_nosync = int(x.gidx_words), int(x.gidx_none), int(x.gidx_nosync)
         self.gidx = self._View(x.d_gidx) if x.d_gidx else None
         self.gidx_off = self._View(x.d_gidx_off) if x.d_gidx_off else None
 

@@ -23,6 +23,20 @@
 
 void dx_file_free(void *p) { free(p); }
 
+/* DEXGPU_TIMING=1: where a file driver spends its time (stderr; the tools print their own marks beside these) */
+#include <time.h>
+#include <unistd.h>
+static void fmark(const char *what)
+{ static double t0 = -1.0;
+  struct timespec ts;
+  double now;
+  if (getenv("DEXGPU_TIMING") == NULL) return;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  now = ts.tv_sec + 1e-9 * ts.tv_nsec;
+  if (t0 < 0) t0 = now;
+  fprintf(stderr, "[dx_file %8.1f ms] %s\n", (now - t0) * 1e3, what);
+}
+
 #define TRY(x) do { rc = (x); if (rc != DX_OK) goto done; } while (0)
 
 #define DX_GPU_INDEX_MIN (1u << 20)      /* .quiva images from 1 MiB on are indexed on the GPU */
@@ -662,9 +676,9 @@ static int dexqv_sliced(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, s
   void        *d_text = NULL, *d_off = NULL, *d_len = NULL, *d_hdr = NULL, *d_hoff = NULL, *d_rec = NULL, *d_seg = NULL, *d_out = NULL;
   size_t       out_cap = 0;
   grow_sink    grow = { NULL, 0, 0 };
-  int          rc, pass;
+  int          rc, pass, was_threads = 0;
 
-  if (out) { sink = grow_take; user = &grow; }
+  if (out) { sink = grow_take; user = &grow; was_threads = dx_set_sink_threads(ctx, 1); }     /* (grow_take wants its chunks in order) */
   cd = malloc(sizeof(*cd)); hist = calloc(6, sizeof(*hist)); junk = calloc(6, sizeof(*junk));
   if (!cd || !hist || !junk) { rc = DX_E_NOMEM; goto done; }
   TRY(dx_index_quiva(text, n, 0, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
@@ -758,6 +772,7 @@ static int dexqv_sliced(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, s
   rc = DX_OK;
 
 done:
+  if (was_threads) (void) dx_set_sink_threads(ctx, was_threads);
   if (d_hdr) dx_free(ctx, d_hdr);
   if (d_out) dx_free(ctx, d_out);
   dfree_all(&pool);
@@ -780,9 +795,12 @@ static size_t text_cap(dx_ctx *ctx, size_t n)
 }
 
 /* out != NULL: the image in memory; else through the sink, in order, nothing before all of it is known to exist */
-static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uint8_t **out, dx_sink_fn sink, void *user,
+/* text == NULL: the image is the first n bytes of the file behind fd (dx_file_dexqv_fd_to): uploaded by dx_h2d_fd, and whatever
+   wants it in memory -- a small file, slices, the host indexer's words for a malformed one -- is DX_E_AGAIN */
+static int dexqv_core(dx_ctx *ctx, const uint8_t *text, int fd, size_t n, int lossy, uint8_t **out, dx_sink_fn sink, void *user,
                       size_t *out_len, uint64_t *errline, int *errcode)
 { dpool        pool = { {0}, 0, ctx };
+  uint8_t      headbuf[4096];
   uint64_t     cnt = 0, *off = NULL, *hoff = NULL, total = 0, tot = 0;
   uint32_t    *len = NULL;
   int32_t     *hdr4 = NULL, lwell = 0;
@@ -800,8 +818,9 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uin
   *out_len = 0;
   { const size_t cap = text_cap(ctx, n);
     if (cap)
-      return dexqv_sliced(ctx, text, n, lossy, cap, out, sink, user, out_len, errline, errcode);
+      return text == NULL ? DX_E_AGAIN : dexqv_sliced(ctx, text, n, lossy, cap, out, sink, user, out_len, errline, errcode);
   }
+  if (text == NULL && (n < DX_GPU_INDEX_MIN || getenv("DEXGPU_HOST_INDEX") != NULL)) return DX_E_AGAIN;
 
   /* pass 1 of the reference (QVcoding_Scan, dexqv.c:81-82): validate + index.  Large images are
    * indexed on the GPU (newline scan + structure checks there, only the header lines come back);
@@ -810,7 +829,19 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uin
   cd   = malloc(sizeof(*cd));
   hist = calloc(6, sizeof(*hist));
   if (!cd || !hist) { rc = DX_E_NOMEM; goto done; }
-  TRY(dupload(&pool, text, n, &d_text));
+  fmark("dexqv: begin");
+  if (text != NULL) TRY(dupload(&pool, text, n, &d_text));
+  else
+    { size_t got = 0, want = n < sizeof(headbuf) ? n : sizeof(headbuf);
+      TRY(dalloc(&pool, n, &d_text));
+      TRY(dx_h2d_fd(ctx, d_text, fd, 0, n));
+      while (got < want)                                  /* (the first header line, for the coding's prefix) */
+        { const ssize_t k = pread(fd, headbuf + got, want - got, (off_t) got);
+          if (k <= 0) { rc = DX_E_IO; goto done; }
+          got += (size_t) k;
+        }
+    }
+  fmark("dexqv: text on the device");
   if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL)
     { uint64_t *go = NULL; uint32_t *gl = NULL;
       rc = dx_index_quiva_device(ctx, d_text, n, &go, &gl, &cnt, &hdr4, &plen, errline, errcode);
@@ -820,7 +851,13 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uin
         }
       else if (rc != DX_OK && rc != DX_E_FORMAT)
         goto done;
+      else if (text == NULL)                              /* (malformed, or empty: the in-memory driver says what is wrong) */
+        { rc = DX_E_AGAIN; goto done; }
       rc = DX_OK;
+    }
+  if (text == NULL)
+    { if (plen >= sizeof(headbuf)) { rc = DX_E_AGAIN; goto done; }
+      text = headbuf;                                     /* (from here on only the prefix is looked at) */
     }
   if (d_off == NULL)
     { TRY(dx_index_quiva(text, n, 0, NULL, NULL, NULL, &cnt, &plen, errline, errcode));
@@ -839,6 +876,7 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uin
     { rc = DX_E_DEGENERATE;     /* empty file: the reference dereferences a NULL header (dexqv.c:94) */
       goto done;
     }
+  fmark("dexqv: indexed");
   hoff = malloc((cnt + 1) * sizeof(*hoff));
   if (!hoff) { rc = DX_E_NOMEM; goto done; }
 
@@ -858,6 +896,7 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uin
   TRY(dx_qv_hist(ctx, &b, 0, &p, hist, &tot));
   TRY(dx_qv_build((const uint64_t (*)[256]) hist, tot, &p, lossy, cd));   /* Create_QVcoding, dexqv.c:86 */
   TRY(dx_qv_set_coding(ctx, cd, lossy));
+  fmark("dexqv: scanned, tables built");
 
   rc = dx_qv_write_coding(cd, (const char *) text, plen, NULL, 0, &clen);  /* size of Write_QVcoding */
   if (rc != DX_OK && rc != DX_E_SPACE) goto done;
@@ -874,6 +913,7 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uin
       TRY(dalloc(&pool, total, &d_out));
       TRY(dx_qv_encode(ctx, &b, d_hdr, d_hoff, d_rec, d_seg, d_out));
     }
+  fmark("dexqv: encoded");
   img = malloc(head + (out ? total : 0) + 16);
   if (!img) { rc = DX_E_NOMEM; goto done; }
   { uint16_t key = 0x55aa;                                                 /* dexqv.c:105-108 */
@@ -891,23 +931,31 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, uin
     }
   *out_len = head + total;
   rc = DX_OK;
+  fmark("dexqv: output passed on");
 
 done:
   dfree_all(&pool);
   free(off); free(hoff); free(len); free(hdr4); free(blob); free(cd); free(hist); free(img);
+  fmark("dexqv: device memory released");
   return rc;
 }
 
 int dx_file_dexqv(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,
                   uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
-{ if (out == NULL) return DX_E_ARG;
-  return dexqv_core(ctx, text, n, lossy, out, NULL, NULL, out_len, errline, errcode);
+{ if (out == NULL || text == NULL) return DX_E_ARG;
+  return dexqv_core(ctx, text, -1, n, lossy, out, NULL, NULL, out_len, errline, errcode);
+}
+
+int dx_file_dexqv_fd_to(dx_ctx *ctx, int fd, size_t n, int lossy, dx_sink_fn sink, void *user,
+                        size_t *out_len, uint64_t *errline, int *errcode)
+{ if (sink == NULL || fd < 0) return DX_E_ARG;
+  return dexqv_core(ctx, NULL, fd, n, lossy, NULL, sink, user, out_len, errline, errcode);
 }
 
 int dx_file_dexqv_to(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, dx_sink_fn sink, void *user,
                      size_t *out_len, uint64_t *errline, int *errcode)
-{ if (sink == NULL) return DX_E_ARG;
-  return dexqv_core(ctx, text, n, lossy, NULL, sink, user, out_len, errline, errcode);
+{ if (sink == NULL || text == NULL) return DX_E_ARG;
+  return dexqv_core(ctx, text, -1, n, lossy, NULL, sink, user, out_len, errline, errcode);
 }
 
 /* ==========================================================================================
@@ -1222,9 +1270,12 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
         { TRY(dx_qv_use_dindex(ctx, d_in, &p->dix));
           indexed = 1;
         }
+      fmark("undexqv: buffers ready");
       TRY(dx_qv_decode(ctx, d_in, d_rec, d_hoff, d_seg, d_len, p->x.n,
                        (upper ? DX_DECODE_UPPER : 0) | (p->x.flip ? DX_DECODE_FLIP : 0), d_out, d_ooff));
+      fmark("undexqv: decoded");
       TRY(dx_d2h_stream(ctx, d_out, p->total, patch_and_pass, &h));
+      fmark("undexqv: text passed on");
     }
 done:
   if (indexed) (void) dx_qv_use_index(ctx, NULL, NULL, 0, NULL, NULL, 0);     /* (the index lives in the pool freed below) */
@@ -1284,6 +1335,9 @@ typedef struct
     uint8_t          *img;
     size_t            head, total;
     shard_job        *jobs;
+    /* by bytes (large files): no index of the whole file exists; every shard finds and indexes its own records (shard_slice) */
+    int               by_bytes, again;       /* again: something is not as it should be -- the whole file once more, the serial way */
+    size_t            n, plen;
   } shard_all;
 
 struct shard_job
@@ -1293,6 +1347,12 @@ struct shard_job
     uint64_t     lo, hi;                      /* entries [lo, hi) */
     dx_qv_params p;
     uint64_t     hist[6][256], tot, bytes, at;
+    /* by bytes: the shard's byte range as dealt, the newlines in it, where its first record begins and the line that is, its own
+       index (hdr4 / len: host, the shard's entries; the offsets stay on the device) */
+    size_t       p0, p1, start;
+    uint64_t     nl, line0;
+    int32_t     *hdr4;
+    uint32_t    *len;
   };
 
 /* Steps alternate between "every shard works and sets its own rc" and "shard 0 folds the results",
@@ -1304,6 +1364,8 @@ static int all_ok(shard_all *a)
     if (a->jobs[k].rc != DX_OK) return 0;
   return a->rc == DX_OK;
 }
+
+static int shard_slice(shard_job *j, dpool *pool, void **d_text, void **d_off, void **d_len, uint64_t *span);
 
 static void *shard_main(void *arg)
 { shard_job  *j = arg;
@@ -1325,7 +1387,24 @@ static void *shard_main(void *arg)
   j->p.delChar = j->p.subChar = -1; j->p.del_first = j->p.sub_first = -1;
   memset(j->hist, 0, sizeof(j->hist)); j->tot = 0; j->bytes = 0;
 
-  if (m > 0)                                             /* this shard's slice of the text image */
+  if (a->by_bytes)
+    { rc = shard_slice(j, &pool, &d_text, &d_off, &d_len, &span);        /* (five barriers inside, whatever becomes of it) */
+      m = j->hi - j->lo;
+      if (rc == DX_OK && m > 0)
+        { int32_t lwell = j->id ? a->jobs[j->id - 1].hdr4[4 * (a->jobs[j->id - 1].hi - a->jobs[j->id - 1].lo - 1)] : 0;
+          hoff = malloc((m + 1) * sizeof(*hoff));
+          blob = malloc(dx_frame_bound(j->hdr4, m, lwell, 0) + 16);
+          if (!hoff || !blob) rc = DX_E_NOMEM;
+          if (rc == DX_OK) rc = dx_frame_headers(j->hdr4, NULL, m, 0, &lwell, blob, hoff);
+          if (rc == DX_OK) rc = dupload(&pool, blob, (size_t) hoff[m], &d_hdr);
+          if (rc == DX_OK) rc = dupload(&pool, hoff, (m + 1) * 8, &d_hoff);
+          if (rc == DX_OK) rc = dalloc(&pool, (m + 1) * 8, &d_rec);
+          if (rc == DX_OK) rc = dalloc(&pool, m * 20, &d_seg);
+          b.d_text = d_text; b.d_off = d_off; b.d_len = d_len; b.n = m; b.line_pad = 1; b.text_bytes = span;
+          if (rc == DX_OK) rc = dx_qv_prescan(j->ctx, &b, j->lo, &j->p);
+        }
+    }
+  else if (m > 0)                                        /* this shard's slice of the text image */
     { int32_t lwell = j->lo ? a->hdr4[4*(j->lo-1)] : 0;
       base = a->off[j->lo];
       span = a->off[j->hi-1] + 5 * ((uint64_t) a->len[j->hi-1] + 1) - base;
@@ -1345,7 +1424,7 @@ static void *shard_main(void *arg)
       b.d_text = d_text; b.d_off = d_off; b.d_len = d_len; b.n = m; b.line_pad = 1; b.text_bytes = span;
       if (rc == DX_OK) rc = dx_qv_prescan(j->ctx, &b, j->lo, &j->p);       /* QV.c:993-1015, per shard */
     }
-  if (rc == DX_OK && j->id == 0 && a->cut >= j->hi)
+  if (rc == DX_OK && j->id == 0 && a->cut >= j->hi && !a->by_bytes)      /* (by bytes: shard_slice has seen to it that this is not so) */
     { /* the file's first 100000 symbols (QV.c:1006-1015) reach beyond shard 0: find the provisional
          subChar on a prefix batch of entries [0, cut] instead */
       uint64_t     mp = a->cut + 1, sp = a->off[a->cut] + 5 * ((uint64_t) a->len[a->cut] + 1) - a->off[0];
@@ -1414,8 +1493,11 @@ static void *shard_main(void *arg)
 
   if (j->id == 0 && (a->ok = all_ok(a)))                 /* layout of the final image */
     { size_t clen = 0, plen = 0;
-      const uint8_t *h = a->text, *slash = memchr(h + 1, '/', (size_t) (a->off[0] - 1));
-      plen = slash ? (size_t) (slash - h) : 0;
+      if (a->by_bytes) plen = a->plen;
+      else
+        { const uint8_t *h = a->text, *slash = memchr(h + 1, '/', (size_t) (a->off[0] - 1));
+          plen = slash ? (size_t) (slash - h) : 0;
+        }
       dx_qv_write_coding(&a->cd, (const char *) a->text, plen, NULL, 0, &clen);
       a->head = 2 + clen;
       a->total = a->head;
@@ -1441,6 +1523,76 @@ static void *shard_main(void *arg)
   return NULL;
 }
 
+/* A file too large to be indexed by one thread first (a terabyte over eight GPUs): the bytes are dealt evenly, and
+ * every shard finds the records that BEGIN in its range -- a record is six lines (QV.c:948-978), so all it needs of the others is
+ * how many newlines stand in front of its range --, uploads exactly those and has its own device index them (dx_index_quiva_device:
+ * structure checks and all).  Anything out of the ordinary (a line count that is no multiple of six, an indexer that says no, the
+ * first 100000 symbols reaching beyond shard 0) sets a->again: dx_file_dexqv_sharded then does the file the serial way, which also has
+ * the reference's words for a malformed file.  Every thread passes the same five barriers.                                     */
+static int shard_slice(shard_job *j, dpool *pool, void **d_text, void **d_off, void **d_len, uint64_t *span)
+{ shard_all *a = j->all;
+  int rc = DX_OK, k;
+  { const uint8_t *q = a->text + j->p0, *e = a->text + j->p1;            /* 1: the newlines of the range as dealt */
+    uint64_t c = 0;
+    while (q < e && (q = memchr(q, '\n', (size_t) (e - q))) != NULL) { c += 1; q += 1; }
+    j->nl = c;
+  }
+  pthread_barrier_wait(&a->bar);
+  if (j->id == 0)                                        /* 2: the lines in front of every range; six lines a record, the last one whole */
+    { uint64_t before = 0;
+      for (k = 0; k < a->nsh; k++) { a->jobs[k].line0 = before; before += a->jobs[k].nl; }
+      if (before % 6 != 0 || before == 0 || a->text[a->n - 1] != '\n') a->again = 1;
+      a->cnt = before / 6;
+    }
+  pthread_barrier_wait(&a->bar);
+  if (!a->again)                                         /* 3: the first record that begins in the range */
+    { const uint8_t *q = a->text + j->p0, *e = a->text + a->n;
+      uint64_t line = j->line0;                            /* (the line p0 stands in) */
+      if (j->p0 > 0 && q[-1] != '\n')                       /* ... which began in front of the range: the next one */
+        { q = memchr(q, '\n', (size_t) (e - q)); q = q ? q + 1 : e; line += 1; }
+      while (line % 6 != 0 && q < e)
+        { q = memchr(q, '\n', (size_t) (e - q)); q = q ? q + 1 : e; line += 1; }
+      j->start = (size_t) (q - a->text);
+      j->lo = line / 6;
+    }
+  pthread_barrier_wait(&a->bar);
+  if (!a->again)                                         /* 4: the shard's records, to its device, indexed there */
+    { const size_t end = j->id + 1 < a->nsh ? a->jobs[j->id + 1].start : a->n;
+      uint64_t cnt = 0, el = 0;
+      int      ec = 0;
+      j->hi = j->id + 1 < a->nsh ? a->jobs[j->id + 1].lo : a->cnt;
+      *span = end - j->start;
+      if (j->hi > j->lo)
+        { uint64_t *go = NULL; uint32_t *gl = NULL;
+          size_t plen = 0;
+          rc = dupload(pool, a->text + j->start, (size_t) *span, d_text);
+          if (rc == DX_OK) rc = dx_index_quiva_device(j->ctx, *d_text, *span, &go, &gl, &cnt, &j->hdr4, &plen, &el, &ec);
+          if (rc == DX_OK && cnt > 0) { pool->p[pool->n++] = go; pool->p[pool->n++] = gl; *d_off = go; *d_len = gl; }
+          if (rc == DX_OK && cnt != j->hi - j->lo) rc = DX_E_FORMAT;
+          if (rc == DX_OK && (j->len = malloc((size_t) cnt * 4)) == NULL) rc = DX_E_NOMEM;
+          if (rc == DX_OK) rc = dx_d2h(j->ctx, j->len, gl, (size_t) cnt * 4);
+          if (j->id == 0) a->plen = plen;
+        }
+      else if (j->hi < j->lo) rc = DX_E_FORMAT;
+      if (rc != DX_OK) { j->rc = rc; }
+    }
+  pthread_barrier_wait(&a->bar);
+  if (j->id == 0 && !a->again)                           /* the entry at which the running symbol count reaches 100000 (QV.c:1006-1015) */
+    { uint64_t run = 0, e2 = 0, m0 = a->jobs[0].hi - a->jobs[0].lo;
+      for (k = 0; k < a->nsh; k++) if (a->jobs[k].rc != DX_OK || a->jobs[k].hi <= a->jobs[k].lo) a->again = 1;
+      for (e2 = 0; !a->again && e2 < m0; e2++)
+        { run += a->jobs[0].len[e2];
+          if (run >= 100000) break;
+        }
+      if (!a->again && e2 >= m0) a->again = 1;             /* (not within shard 0: a small file, the serial way knows what to do) */
+      a->cut = e2;
+    }
+  pthread_barrier_wait(&a->bar);
+  if (a->again) { j->hi = j->lo; return DX_E_FORMAT; }
+  return rc;
+}
+
+#define DX_SHARD_BYTES_MIN ((size_t) 64 << 20)           /* per shard: from here on the shards index their own byte ranges */
 int dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n, int lossy,
                           uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
 { shard_all  a;
@@ -1449,34 +1601,42 @@ int dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n
   uint32_t  *len = NULL;
   int32_t   *hdr4 = NULL;
   size_t     plen = 0;
-  int        rc, k, started = 0;
+  int        rc, k, started = 0, by_bytes;
 
   if (ctxs == NULL || nctx < 1 || out == NULL || out_len == NULL) return DX_E_ARG;
   if (nctx == 1) return dx_file_dexqv(ctxs[0], text, n, lossy, out, out_len, errline, errcode);
   *out = NULL; *out_len = 0;
+  { const char *e = getenv("DEXGPU_SHARD_BYTES_MIN");     /* (tests: the by-bytes way on small files) */
+    const size_t least = e != NULL && *e ? (size_t) strtoull(e, NULL, 10) : DX_SHARD_BYTES_MIN;
+    by_bytes = n / (size_t) nctx >= least && n / (size_t) nctx >= 4096 && getenv("DEXGPU_HOST_INDEX") == NULL;
+  }
+again:
   memset(&a, 0, sizeof(a));
-
-  rc = dx_index_quiva(text, n, 0, NULL, NULL, NULL, &cnt, &plen, errline, errcode);
-  if (rc != DX_OK) return rc;
-  if (cnt == 0) return DX_E_DEGENERATE;
-  off  = malloc((cnt + 1) * sizeof(*off));
-  len  = malloc((cnt + 1) * sizeof(*len));
-  hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+  started = 0;
   a.jobs = calloc((size_t) nctx, sizeof(*a.jobs));
   th = calloc((size_t) nctx, sizeof(*th));
-  if (!off || !len || !hdr4 || !a.jobs || !th) { rc = DX_E_NOMEM; goto done; }
-  TRY(dx_index_quiva(text, n, cnt, off, len, hdr4, &cnt, &plen, errline, errcode));
+  if (!a.jobs || !th) { rc = DX_E_NOMEM; goto done; }
+  a.nsh = nctx; a.lossy = lossy; a.text = text; a.n = n; a.rc = DX_OK; a.by_bytes = by_bytes;
 
-  a.nsh = nctx; a.lossy = lossy; a.text = text; a.off = off; a.len = len; a.hdr4 = hdr4; a.cnt = cnt;
-  a.rc = DX_OK;
-  { uint64_t run = 0, e;
-    a.cut = 0;
-    for (e = 0; e < cnt; e++)
-      { run += len[e];
-        if (run >= 100000) break;
+  if (!by_bytes)                                          /* the whole file indexed here first (small files; what the shards turn down) */
+    { rc = dx_index_quiva(text, n, 0, NULL, NULL, NULL, &cnt, &plen, errline, errcode);
+      if (rc != DX_OK) goto done;
+      if (cnt == 0) { rc = DX_E_DEGENERATE; goto done; }
+      off  = malloc((cnt + 1) * sizeof(*off));
+      len  = malloc((cnt + 1) * sizeof(*len));
+      hdr4 = malloc((cnt + 1) * 4 * sizeof(*hdr4));
+      if (!off || !len || !hdr4) { rc = DX_E_NOMEM; goto done; }
+      TRY(dx_index_quiva(text, n, cnt, off, len, hdr4, &cnt, &plen, errline, errcode));
+      a.off = off; a.len = len; a.hdr4 = hdr4; a.cnt = cnt;
+      { uint64_t run = 0, e;
+        a.cut = 0;
+        for (e = 0; e < cnt; e++)
+          { run += len[e];
+            if (run >= 100000) break;
+          }
+        a.cut = e < cnt ? e : 0;             /* never reached: no subChar at all, shard 0 finds that too */
       }
-    a.cut = e < cnt ? e : 0;                 /* never reached: no subChar at all, shard 0 finds that too */
-  }
+    }
   pthread_barrier_init(&a.bar, NULL, (unsigned) nctx);
   pthread_mutex_init(&a.gate_mx, NULL);
   pthread_cond_init(&a.gate_cv, NULL);
@@ -1487,6 +1647,8 @@ int dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n
         a.jobs[k].all = &a; a.jobs[k].ctx = ctxs[k]; a.jobs[k].id = k;
         a.jobs[k].lo = lo; a.jobs[k].hi = lo + m; a.jobs[k].rc = DX_OK;
         lo += m;
+        a.jobs[k].p0 = (size_t) ((unsigned __int128) n * (unsigned) k / (unsigned) nctx);        /* (by bytes: the range as dealt) */
+        a.jobs[k].p1 = (size_t) ((unsigned __int128) n * (unsigned) (k + 1) / (unsigned) nctx);
       }
   }
   for (k = 0; k < nctx; k++)                              /* the barriers count nctx threads: all of them or none */
@@ -1506,14 +1668,20 @@ int dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n
       for (k = 0; k < nctx && rc == DX_OK; k++)
         rc = a.jobs[k].rc;
     }
-  if (rc == DX_OK)
+  if (rc == DX_OK && !a.again)
     { *out = a.img; *out_len = a.total; a.img = NULL; }
 
   pthread_barrier_destroy(&a.bar);
   pthread_mutex_destroy(&a.gate_mx);
   pthread_cond_destroy(&a.gate_cv);
 done:
+  for (k = 0; a.jobs != NULL && k < nctx; k++) { free(a.jobs[k].hdr4); free(a.jobs[k].len); }
   free(off); free(len); free(hdr4); free(a.jobs); free(th); free(a.img);
+  off = NULL; len = NULL; hdr4 = NULL; th = NULL;
+  if (by_bytes && a.again && started == nctx)            /* the shards turned the file down: the serial way (and its words for what is wrong) */
+    { by_bytes = 0;
+      goto again;
+    }
   return rc;
 }
 

@@ -97,6 +97,9 @@ struct dx_ctx
   uint64_t *d_scan;            // grow-only tile sums of dx_scan_u32 (its callers hold d_scratch)
   size_t    scan_words;
   uint8_t  *h_stage[2];        // pinned staging of dx_d2h_stream (made at its first call)
+  uint8_t  *h_up;              // pinned staging of a large dx_h2d (made at its first such call)
+  uint8_t  *h_down;            // pinned staging of dx_d2h_stream with several sink threads (dx_set_sink_threads)
+  int       sink_threads;
   void     *d_hscr;            // grow-only scratch of dx_qv_hist (its own: d_scratch may still be read by the compaction
   size_t    hscr_bytes;        //   of an encode that has begun, dx_qv_encode_onepass_begin)
   // an encode that has begun and not ended (dx_qv_encode_onepass_begin / _end)

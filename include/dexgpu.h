@@ -37,7 +37,9 @@ extern "C" {
 #define DX_E_NOMEM       (-6)
 #define DX_E_MISMATCH    (-7)   /* device-side consistency check failed (e.g. symbol count != expected) */
 #define DX_E_SPACE       (-8)   /* output buffer too small */
-#define DX_E_IO          (-9)   /* a caller's sink refused data (dx_d2h_stream) */
+#define DX_E_IO          (-9)   /* a caller's sink refused data (dx_d2h_stream); a file could not be read (dx_h2d_fd) */
+#define DX_E_AGAIN       (-10)  /* not this way: an entry point that takes a file descriptor wants the image in memory after all
+                                   (a small or malformed file, one that does not fit the device): call its in-memory twin */
 
 typedef struct dx_ctx dx_ctx;
 
@@ -57,6 +59,10 @@ int dx_malloc(dx_ctx *ctx, size_t bytes, void **d_ptr);
 int dx_free  (dx_ctx *ctx, void *d_ptr);
 int dx_h2d   (dx_ctx *ctx, void *d_dst, const void *src, size_t bytes);   /* synchronous */
 int dx_d2h   (dx_ctx *ctx, void *dst, const void *d_src, size_t bytes);   /* synchronous */
+/* bytes [foff, foff + bytes) of the file behind fd to device memory, read (pread) by several threads straight into pinned buffers
+ * that leave as they fill: no mapping of the file in the caller's address space (a large dx_h2d from memory goes through the same
+ * threads).  DX_E_IO: the file could not be read.                                                                       */
+int dx_h2d_fd(dx_ctx *ctx, void *d_dst, int fd, uint64_t foff, size_t bytes);
 /* Device memory to a consumer on the host, in order, in chunks (32 MiB) through two pinned staging buffers the
  * context owns: sink(user, data, len, at) is called on a helper thread for the bytes [at, at + len) while the
  * next chunk is in flight; it may modify data[0 .. len) and returns 0, or nonzero to stop (DX_E_IO comes back).
@@ -64,6 +70,11 @@ int dx_d2h   (dx_ctx *ctx, void *dst, const void *d_src, size_t bytes);   /* syn
  * dx_d2h into fresh memory pays one per 4 KiB (0.25 s per GiB, single-threaded).                             */
 typedef int (*dx_sink_fn)(void *user, uint8_t *data, size_t len, size_t at);
 int dx_d2h_stream(dx_ctx *ctx, const void *d_src, size_t bytes, dx_sink_fn sink, void *user);
+/* A sink that is positional -- it takes chunk [at, at + len) whatever came before, from whichever thread (a pwrite per chunk) --
+ * may be fed by several threads: from 128 MiB on dx_d2h_stream (and every file driver that delivers through a sink) then keeps up
+ * to eight 16 MiB copies in flight and calls the sink from `threads` helper threads, chunks in any order (one thread writing into
+ * a file's pages is slower than the link brings them).  Default 1: in order, one thread.  Returns the value in force before.     */
+int dx_set_sink_threads(dx_ctx *ctx, int threads);
 int dx_memset(dx_ctx *ctx, void *d_dst, int value, size_t bytes);
 
 /* Per-kernel device time, measured with HIP events on the context's stream around every launch
@@ -447,6 +458,11 @@ int  dx_file_unpack2_to(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uin
  *  DEXGPU_TEXT_BUDGET bytes when that is set -- is worked through in SLICES of whole entries, like the reference streams a
  *  file of any size (dexqv.c:112-143): the scan pass over every slice (histograms added up on the host, the scan state
  *  carried along), the tables, then slice by slice again -- upload, tokens, encode, records out.  Same bytes.)          */
+/* ... and with the .quiva read from a file descriptor (dx_h2d_fd: no image of it in the caller's memory at all): n bytes from
+ * offset 0.  DX_E_AGAIN -- nothing has been passed to the sink -- when the file has to be handed over in memory after all (below
+ * 1 MiB, larger than the device takes at once, or malformed: the in-memory driver has the reference's words for that).   */
+int  dx_file_dexqv_fd_to(dx_ctx *ctx, int fd, size_t n, int lossy, dx_sink_fn sink, void *user,
+                         size_t *out_len, uint64_t *errline, int *errcode);
 int  dx_file_dexqv_to(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, dx_sink_fn sink, void *user,
                       size_t *out_len, uint64_t *errline, int *errcode);
 /* dexqv of ONE file on several GPUs (one context each; contiguous entry ranges, one host thread per

@@ -11,7 +11,8 @@
        - within 7 % with the un-profiled bench line of the set (<tag>_bench*.json; profiled runs clock a little lower;
          15 % for k_qv_decode_plain, a lane-per-line kernel whose time moves that much from run to run with where the
          chunks of the verification land in memory),
-     kernel by kernel: the `frac` figures of DESIGN.md section 5 are (bytes in the bench line) / (these times)."""
+     kernel by kernel: the `frac` figures of DESIGN.md section 5 are (bytes in the bench line) / (these times).
+  3. The HBM traffic DESIGN.md quotes per kernel stands in one table tied to the set's traffic file (design_traffic)."""
 import csv, glob, hashlib, json, os, sys
 
 BENCH_ID = {"k_qv_encode_fast": "k_qv_encode", "k_qv_encode": "k_qv_encode_text", "k_qv_hist": "k_qv_hist", "k_qv_compact": "k_qv_compact"}
@@ -97,7 +98,54 @@ def check(root):
                     problems.append(f"{which} of the set is missing"); continue
                 compare(f"k_pack2_encode [{which}]", st.get("k_pack2_encode", (None,))[0], d.get("encode_ms"), tol)
                 compare(f"k_pack2_decode [{which}]", st.get("k_pack2_decode", (None,))[0], (d.get("decode") or {}).get("ms"), tol)
+    problems += design_traffic(root, m)
     return problems
+
+
+def design_traffic(root, m):
+    """3. DESIGN.md quotes HBM traffic per kernel in ONE table, headed by a line `<!-- traffic-table: profiles/<file> -->`; every row
+    `| kernel | GB per launch |` must be within 5 % of that file's figure (workloads.dexqv.kernels.<kernel>.hbm_bytes_per_launch),
+    and the file must be the set's own: a traffic figure in the text with no file behind it, or an old file's, fails here."""
+    import re
+    out = []
+    try:
+        text = open(os.path.join(root, "DESIGN.md")).read()
+    except OSError:
+        return ["DESIGN.md is missing"]
+    mk = re.search(r"<!-- traffic-table: (profiles/\S+) -->", text)
+    if mk is None:
+        return ["DESIGN.md has no traffic table (a line `<!-- traffic-table: profiles/<tag>_traffic.json -->` followed by `| kernel | GB |` rows)"]
+    path = os.path.join(root, mk.group(1))
+    if os.path.basename(path) != m["files"].get("traffic.json"):
+        out.append(f"DESIGN.md's traffic table quotes {mk.group(1)}, the evidence set's traffic file is profiles/{m['files'].get('traffic.json')}")
+    if not os.path.isfile(path):
+        return out + [f"DESIGN.md's traffic table quotes {mk.group(1)}, which does not exist"]
+    doc = json.load(open(path))
+    kernels = {}
+    for w in doc["workloads"].values():
+        for k, v in w["kernels"].items():
+            kernels.setdefault(k, v["hbm_bytes_per_launch"])
+    rows = 0
+    for ln in text[mk.end():].splitlines()[1:]:
+        if not ln.startswith("|"):
+            if rows: break
+            continue
+        cells = [c.strip().strip("`") for c in ln.strip("|").split("|")]
+        if len(cells) < 2 or not cells[0].startswith("k_"):
+            continue
+        rows += 1
+        try:
+            gb = float(cells[1])
+        except ValueError:
+            out.append(f"DESIGN.md traffic table: `{ln.strip()}` has no number in its second column"); continue
+        if cells[0] not in kernels:
+            out.append(f"DESIGN.md traffic table: {cells[0]} is not in {mk.group(1)}"); continue
+        have = kernels[cells[0]] / 1e9
+        if rel(gb, have) > 0.05:
+            out.append(f"DESIGN.md traffic table: {cells[0]} {gb} GB, {mk.group(1)} has {have:.2f} GB")
+    if rows == 0:
+        out.append("DESIGN.md's traffic table has no rows")
+    return out
 
 
 if __name__ == "__main__":

@@ -20,11 +20,25 @@ BENCH_ID = {"k_qv_encode_fast": "k_qv_encode", "k_qv_encode": "k_qv_encode_text"
             "k_qv_compact": "k_qv_compact", "k_qv_decode": "k_qv_decode", "k_qv_decode_tags": "k_qv_decode_tags",
             "k_qv_decode_plain": "k_qv_decode_plain", "k_qv_decode_sub": "k_qv_decode_sub", "k_qv_decode_runs": "k_qv_decode_runs",
             "k_qv_sizes_fast": "k_qv_sizes", "k_qv_sizes": "k_qv_sizes", "k_qv_sizes_hist": "k_qv_sizes",
-            "k_walk_find": "k_qv_walk", "k_walk_pieces": "k_qv_walk", "k_walk_gather": "k_qv_walk",
+            "k_walk_find": "k_qv_walk", "k_walk_pieces": "k_qv_walk", "k_walk_gather": "k_qv_walk", "k_walk_rooms": "k_qv_walk", "k_walk_index": "k_qv_walk",
+            "k_qv_decode_sync": "k_qv_decode_sub",
             "k_qv_prescan_del": "k_qv_prescan", "k_qv_prescan_sub": "k_qv_prescan",
             "k_scan_tiles": "k_scan", "k_scan_sums": "k_scan", "k_scan_apply": "k_scan", "k_scan_apply_base": "k_scan",
             "k_qv_bounds": "k_scan", "k_sub_rooms": "k_scan",
             "k_pack2_encode": "k_pack2_encode", "k_pack2_decode": "k_pack2_decode"}
+
+
+# how a kernel's lanes read (see traffic()): "stream" = 16 B a lane, consecutive lanes consecutive bytes; "lanes" = every lane its own
+ACCESS = {"k_qv_hist": "stream", "k_qv_encode_fast": "stream", "k_qv_encode": "stream", "k_qv_compact": "stream", "k_qv_sizes_hist": "stream",
+          "k_qv_sizes_fast": "stream", "k_qv_sizes": "stream", "k_qv_prescan_del": "stream", "k_qv_prescan_sub": "stream", "k_qv_density": "stream",
+          "k_qv_bounds": "stream", "k_sub_rooms": "stream", "k_scan_tiles": "stream", "k_scan_sums": "stream", "k_scan_apply": "stream",
+          "k_scan_apply_base": "stream", "k_ticket_units": "lanes", "k_qv_lossy_text": "stream",
+          "k_pack2_encode": "stream", "k_pack2_decode": "stream", "k_synth_quiva": "stream", "k_synth_seq": "stream",
+          "k_nl_count": "stream", "k_nl_fill": "stream", "k_qv_entries": "lanes", "k_seq_lines": "lanes", "k_seq_records": "lanes", "k_seq_extent": "lanes",
+          "k_qv_decode": "lanes", "k_qv_decode_plain": "lanes", "k_qv_decode_sub": "lanes", "k_qv_decode_runs": "lanes", "k_qv_decode_sync": "lanes",
+          "k_qv_decode_tags": "stream",
+          "k_add_one": "lanes", "k_gather_headers": "lanes", "k_gather_lines": "lanes", "k_tok_rooms": "stream",
+          "k_walk_find": "stream", "k_walk_pieces": "lanes", "k_walk_gather": "lanes", "k_walk_rooms": "lanes", "k_walk_index": "lanes"}
 
 
 def kname(full):
@@ -66,11 +80,16 @@ def traffic(src, suffix):
             continue
         f = fe.get(name, {}).get("FETCH_SIZE", [])
         w = wr.get(name, {}).get("WRITE_SIZE", [])
-        # the x2 is for wide coalesced streams (16 B per lane, consecutive lanes consecutive bytes): every kernel here
-        # but the lane-per-stream decoders, whose lanes each read their own line (raw request bytes kept for them)
-        scattered = name in ("k_qv_decode", "k_qv_decode_plain", "k_qv_decode_sub", "k_qv_decode_runs")
+        # The guide's x2 is for wide coalesced streams (16 B per lane, consecutive lanes consecutive bytes).  Every kernel is
+        # classified by how its lanes read, in ACCESS below; a kernel that is not listed fails the summary (a new kernel must be
+        # looked at, not inherit a correction): "stream" x2; "lanes" (every lane its own line or piece: the lane-per-line decoders,
+        # the walk's lanes, the window loads of the wave-per-line decoders, which are 4 B a lane) raw request bytes.
+        if name not in ACCESS:
+            raise SystemExit(f"profiles/summarize.py: kernel {name} has no entry in ACCESS (how do its lanes read?)")
+        scattered = ACCESS[name] == "lanes"
         out[name] = {"fetch_bytes": sum(f) / len(f) * 1024 * (1 if scattered else 2) if f else None,
                      "fetch_bytes_raw_counter": sum(f) / len(f) * 1024 if f else None,
+                     "fetch_correction": 1 if scattered else 2, "access": ACCESS[name],
                      "write_bytes": sum(w) / len(w) * 1024 if w else None,
                      "rows_sampled": len(f) or len(w)}
         out[name]["hbm_bytes_per_launch"] = (out[name]["fetch_bytes"] or 0) + (out[name]["write_bytes"] or 0)

@@ -194,3 +194,35 @@ def test_cli_degenerate_file_is_refused_loudly_where_the_reference_reads_out_of_
         _write(ref / "d.quiva", text)
         q = run("dexqv", ["-k", "d.quiva"], ref, ref=True)
         print("reference on the degenerate file: exit code", q.returncode, "stderr", q.stderr[:200], "wrote a file:", (ref / "d.dexqv").exists())
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_cli_large_file_paths_on_small_files(tmp_path):
+    """What the tools do with LARGE files, brought down to test size by their thresholds: dexqv reads its input from the file
+    descriptor into the upload's pinned buffers (dx_file_dexqv_fd_to, DEXGPU_FD_MIN) and writes into an output file whose pages an
+    allocator thread lays out meanwhile (DEXGPU_OUTFILE_MIN: three tenths of the input, the rest given back) -- and hands a file
+    that way refuses (a malformed one, one below 1 MiB) to the in-memory driver, which has the reference's words --; undexqv walks
+    the records on the device (DEXGPU_DEVICE_WALK_MIN) and decodes with what the walk noted.  Same files as the reference's."""
+    qv = synth.make_quiva(60, seed=9, mean=8000).text                 # ~2.4 MB
+    env = dict(os.environ, DEXGPU_FD_MIN="1", DEXGPU_OUTFILE_MIN="1", DEXGPU_DEVICE_WALK_MIN="0", DEXGPU_WALK_PIECE="8192")
+    mine, ref = tmp_path / "mine", tmp_path / "ref"
+    for d, isref in ((mine, False), (ref, True)):
+        d.mkdir()
+        _write(d / "c.quiva", qv)
+        exe = lambda t: os.path.join(O.REF_BIN if isref else BIN, t)
+        assert subprocess.run([exe("dexqv"), "-k", "c"], cwd=str(d), env=env, capture_output=True).returncode == 0
+        os.remove(d / "c.quiva")
+        assert subprocess.run([exe("undexqv"), "-k", "-U", "c"], cwd=str(d), env=env, capture_output=True).returncode == 0
+    for nme in ("c.dexqv", "c.quiva"):
+        assert _read(mine / nme) == _read(ref / nme), nme
+    assert _read(mine / "c.quiva") == qv
+    small = synth.make_quiva(3, seed=10, mean=500).text               # below 1 MiB: DX_E_AGAIN, then through memory
+    bad = qv[: len(qv) // 2 - 7] + qv[len(qv) // 2:]                  # a line seven symbols short
+    for name, data in (("s", small), ("b", bad)):
+        outs = []
+        for d, isref in ((mine, False), (ref, True)):
+            _write(d / (name + ".quiva"), data)
+            r = subprocess.run([os.path.join(O.REF_BIN if isref else BIN, "dexqv"), "-k", name], cwd=str(d), env=env, capture_output=True)
+            outs.append((r.returncode, r.stderr, _read(d / (name + ".dexqv")) if (d / (name + ".dexqv")).exists() and r.returncode == 0 else None))
+        assert outs[0] == outs[1], name

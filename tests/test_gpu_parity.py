@@ -891,6 +891,42 @@ def test_file_dexqv_sharded_over_contexts(ctx, nctx, lossy):
             x.close()
 
 
+@pytest.mark.parametrize("nctx", [2, 5])
+def test_file_dexqv_sharded_by_byte_ranges(ctx, monkeypatch, nctx):
+    """A file too large to index on one thread first (BASELINE configs[4]): dx_file_dexqv_sharded deals BYTES, every shard counts the
+    newlines of its range, finds the records that begin in it (six lines a record, data lines may begin with '@' too), uploads and
+    indexes them on its own device (dx_index_quiva_device) -- no pass over the whole file anywhere.  DEXGPU_SHARD_BYTES_MIN brings a
+    small file that way: the reference's bytes; a malformed file comes back with what the one-context driver says about it; a file
+    whose first 100000 symbols reach beyond shard 0 goes the serial way and comes out right."""
+    monkeypatch.setenv("DEXGPU_SHARD_BYTES_MIN", "4096")
+    c = synth.make_quiva(320, seed=73, mean=5000)
+    cs = [api.Context(_dev(k)) for k in range(nctx)]
+    try:
+        for lossy in (0, 1):
+            assert api.dexqv_sharded(cs, c.text, lossy) == O.dexqv(c.text, lossy)
+        short = synth.make_quiva(9000, seed=74, lens=np.full(9000, 37, np.uint32))        # many entries in every range
+        assert api.dexqv_sharded(cs, short.text, 0) == O.dexqv(short.text, 0)
+        small = synth.make_quiva(24, seed=75, mean=9000)                                  # (100000 symbols reach beyond shard 0 of 5)
+        assert api.dexqv_sharded(cs, small.text, 0) == O.dexqv(small.text, 0)
+        bad = bytearray(c.text)
+        at = c.text.index(b"\n", len(c.text) // 2)
+        del bad[at - 3: at]                                                               # a data line three symbols short
+        with pytest.raises(L.DexGPUError) as e1:
+            ctx.dexqv(bytes(bad))
+        with pytest.raises(L.DexGPUError) as e2:
+            api.dexqv_sharded(cs, bytes(bad), 0)
+        import re
+        where = lambda e: (e.value.code, re.search(r"line (\d+)", str(e.value)).group(1), re.search(r"code (\d+)", str(e.value)).group(1))
+        assert where(e1) == where(e2), (str(e1.value), str(e2.value))
+        cut = c.text[: c.text.rindex(b"\n", 0, len(c.text) - 1) + 1]                      # the last entry a line short
+        with pytest.raises(L.DexGPUError) as e3:
+            api.dexqv_sharded(cs, cut, 0)
+        assert e3.value.code == -3
+    finally:
+        for x in cs:
+            x.close()
+
+
 def test_sharded_file_drivers_over_every_physical_device():
     """dx_file_dexqv_sharded / dx_file_pack2_sharded with ONE context on EVERY device hipGetDeviceCount reports: the
     hipSetDevice-per-thread path of csrc/dx_files.c on real multi-GPU hardware (BASELINE configs[4]'s layout: contiguous

@@ -281,3 +281,51 @@ def test_decode_with_the_groups_the_walk_notes(ctx, monkeypatch, n, mean, piece,
     finally:
         x.free()
         d.free()
+
+
+def test_plain_lines_the_walk_leaves_without_words(ctx, monkeypatch):
+    """An insertion line of one value nearly throughout codes to a bit a symbol: a burst of the walk's look-ups passes more than
+    64 symbols, two marks of the index at once, and the line is left without its words (DXL_SYNC_NONE) -- k_qv_decode_plain takes
+    exactly those lines, k_qv_decode_sync the others; same text.  With DEXGPU_NO_SYNCINDEX / DEXGPU_NO_RUNINDEX the lane-per-line
+    kernels take everything: same text again."""
+    import dataclasses
+    monkeypatch.setenv("DEXGPU_WALK_PIECE", "8192")
+    base = synth.pacbio_profile()
+    flat = dataclasses.replace(base, ins_lut=synth.make_lut([ord("5"), ord("6"), ord("7")], [0.97, 0.02, 0.01]))
+    c = synth.make_quiva(300, seed=91, mean=5000, prof=flat)
+    img = O.dexqv(c.text)
+    want = O.undexqv(img)
+    coding, flip, prefix, used = api.qv_read_coding(img[2:])
+    h = api.qv_walk(img)
+    d = ctx.to_device(np.frombuffer(img + b"\0" * 64, np.uint8))
+    x = ctx.qv_walk_device(d, len(img), 2 + used, coding, 1, flip)
+    try:
+        assert x.n == h["n"] and x.gidx_nosync > 0                          # (lines without their words are in it)
+        L_ = h["len"].astype(np.uint64)
+        hl = np.array([len(b"%s/%d/%d_%d RQ=0.%d\n" % (prefix, *h["hdr4"][i])) for i in range(x.n)], np.uint64)
+        ooff = (np.cumsum(hl + 5 * (L_ + 1)) - 5 * (L_ + 1)).astype(np.uint64)
+        total = int(ooff[-1] + 5 * (L_[-1] + 1))
+        d_oo = ctx.to_device(ooff)
+        ctx.qv_set_coding(coding)
+        wantb = np.frombuffer(want, np.uint8)
+        for env in ({}, {"DEXGPU_NO_SYNCINDEX": "1"}, {"DEXGPU_NO_RUNINDEX": "1"}):
+            for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+            d_out = ctx.to_device(np.zeros(total + 64, np.uint8))
+            x.use(d)
+            ctx.profile(True)
+            ctx.qv_decode(d, x.rec_off, x.hdr_off, x.seg, x.len, x.n, False, d_out, d_oo)
+            kt = ctx.kernel_times()
+            ctx.profile(False)
+            x.use(None)
+            got = d_out.download(np.uint8, total)
+            for i in range(x.n):
+                a_, b_ = int(ooff[i]), int(ooff[i] + 5 * (L_[i] + 1))
+                assert (got[a_:b_] == wantb[a_:b_]).all(), (env, i)
+            if not env:
+                assert "k_qv_decode_sub" in kt and "k_qv_decode_plain" in kt and "k_qv_decode_runs" in kt, kt
+            d_out.free()
+            for k_ in env: monkeypatch.delenv(k_)
+        d_oo.free()
+    finally:
+        x.free()
+        d.free()
