@@ -23,6 +23,18 @@
 #define P2_WIN_WORDS  448                // per-wave LDS window: flush threshold + one step (128 words) + slack
 #define P2_FLUSH_BITS 8192u
 #define P2_BATCH      16u                // reads a wave draws at a time (one same-address atomic costs ~11 ns chip-wide)
+#ifndef P2_FLAT
+#define P2_FLAT       0                  // > 0: no ticket counter -- as many waves as there are P2_FLAT reads, each takes its own and leaves
+#endif                                   //      (the hardware's dispatcher deals the workgroups as the CUs fall free)
+#if P2_FLAT
+#define P2_FIRST(TICKET, TB) (((uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6)) * (TB))
+#define P2_NEXT(TICKET, TB)  (~0ull)
+#define P2_TB(TICKET)        ((uint32_t) P2_FLAT)
+#else
+#define P2_FIRST(TICKET, TB) next_unit(TICKET, TB)
+#define P2_NEXT(TICKET, TB)  next_unit(TICKET, TB)
+#define P2_TB(TICKET)        ticket_units_of(TICKET, P2_BATCH)
+#endif
 #ifndef P2D_UNROLL
 #define P2D_UNROLL    1u                 // k_pack2_decode: 1 KiB steps whose loads go out together (measured, 10 M x 10 kb, ms per launch:
                                          // 1: 32.8-35.5, 2: 33.8-35.9, 4: 39.0-39.3, 8: 41-42, 4 + non-temporal stores: 37.7-39.1 --
@@ -102,9 +114,9 @@ void k_pack2_encode(const uint8_t *__restrict__ text, const uint64_t *__restrict
   __syncthreads();
 
   const uint64_t text_end = off[n - 1] + tlen[n - 1];    // (the reads lie one behind the other: the last one's end is the buffer's)
-  const uint32_t TB = ticket_units_of(ticket, P2_BATCH);  // (k_ticket_units in front of the launch: 16 reads of 10 kb, more of shorter ones)
-  for (uint64_t r0 = next_unit(ticket, TB), nxt; r0 < n; r0 = nxt)
-  { nxt = next_unit(ticket, TB);                         // drawn early: hidden behind these reads
+  const uint32_t TB = P2_TB(ticket);                     // (k_ticket_units in front of the launch: 16 reads of 10 kb, more of shorter ones)
+  for (uint64_t r0 = P2_FIRST(ticket, TB), nxt; r0 < n; r0 = nxt)
+  { nxt = P2_NEXT(ticket, TB);                           // drawn early: hidden behind these reads
     for (uint64_t r = r0; r < r0 + TB && r < n; r++)
     { const uint8_t *src = text + off[r];
       const uint32_t T   = tlen[r];
@@ -261,9 +273,9 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
   const uint32_t dline  = DX_STEP / W1, dcol = DX_STEP - dline * W1;
   const bool     narrow = width < 16u;   // several line ends may fall into 16 bytes: generic path only
 
-  const uint32_t TB = ticket_units_of(ticket, P2_BATCH);
-  for (uint64_t r0 = next_unit(ticket, TB), nxt; r0 < n; r0 = nxt)
-  { nxt = next_unit(ticket, TB);
+  const uint32_t TB = P2_TB(ticket);
+  for (uint64_t r0 = P2_FIRST(ticket, TB), nxt; r0 < n; r0 = nxt)
+  { nxt = P2_NEXT(ticket, TB);
     for (uint64_t r = r0; r < r0 + TB && r < n; r++)
     { const uint8_t *src  = in + in_off[r];
       uint8_t       *dst  = out + out_off[r];
@@ -452,7 +464,7 @@ extern "C" int dx_pack2_encode(dx_ctx *ctx, int alphabet,
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, d_off, d_off + (n - 1), d_tlen + (n - 1), n,
                      P2_BATCH * 10000u, P2_BATCH, d_ticket);
-  const int grid = dx_grid_waves(ctx, n, 32);
+  const int grid = P2_FLAT ? (int) ((n + (uint64_t) P2_FLAT * DX_WAVES_PER_BLK - 1) / ((uint64_t) P2_FLAT * DX_WAVES_PER_BLK)) : dx_grid_waves(ctx, n, 32);
   if (alphabet == DX_ALPHA_BASES)
     DX_LAUNCH(ctx, DX_K_PACK2_ENC, k_pack2_encode<DX_ALPHA_BASES>, grid, DX_BLOCK,
               d_text, d_off, d_tlen, d_nsym, n, d_hdr, d_hdr_off, d_out, d_out_off, ctx->d_status, d_ticket);
@@ -489,7 +501,7 @@ extern "C" int dx_pack2_decode(dx_ctx *ctx, int letters,
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, d_out_off, d_out_off + (n - 1), d_nsym + (n - 1), n,
                      P2_BATCH * 10000u, P2_BATCH, d_ticket);
-  const int grid = dx_grid_waves(ctx, n, 32);
+  const int grid = P2_FLAT ? (int) ((n + (uint64_t) P2_FLAT * DX_WAVES_PER_BLK - 1) / ((uint64_t) P2_FLAT * DX_WAVES_PER_BLK)) : dx_grid_waves(ctx, n, 32);
   switch (letters)
     { case DX_LETTERS_LOWER:
         DX_LAUNCH(ctx, DX_K_PACK2_DEC, k_pack2_decode<DX_LETTERS_LOWER>, grid, DX_BLOCK,

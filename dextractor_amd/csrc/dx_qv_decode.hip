@@ -1161,6 +1161,9 @@ void k_qv_decode_sub(dec_args a, const uint16_t *g_dec, const uint32_t *g_long, 
 #define DY_BLOCK 768
 #define DY_NWAVE (DY_BLOCK / 64)
 #define DY_WIN   1280                                       // words per wave: 5 KB
+#ifndef DY_PER
+#define DY_PER   3u                                         // stretches of 64 symbols a lane takes in a round
+#endif
 #define DY_SLACK 288u                                       // bits a lane may look at behind the next lane's start: <= 12 codes of 16 bits in front
                                                             // of ITS 64 symbols, the positioned reads' 32 bits, and the last pair's second look
 template <int NK>
@@ -1169,7 +1172,7 @@ void k_qv_decode_sync(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                       const uint32_t *sub_idx, const uint64_t *sub_off, uint32_t *status)
 { __shared__ uint16_t s_tab[NK][DP_SIZE];                  // 8 KB each
   __shared__ uint32_t s_long[NK][1 + DX_LONG_MAX];         // 1 KB each
-  __shared__ uint32_t s_win[DY_NWAVE][DY_WIN];             // 60 KB
+  __shared__ __attribute__((aligned(16))) uint32_t s_win[DY_NWAVE][DY_WIN];   // 60 KB
   nocode_begin();
   { int slot_of[4], nk = 0;                                // tables of the kinds present, in the order of their bits (as k_qv_decode_sub)
     for (int q = 0; q < 4; q++) slot_of[q] = ((kinds >> q) & 1u) ? nk++ : -1;
@@ -1241,6 +1244,8 @@ void k_qv_decode_sync(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 win[i] = byte + 4u <= sbytes ? *(const u32_u *) (seg + byte) : 0u;   // (segments are whole words, QV.c:436-442)
               }
             wave_sync();
+            u32x4 v0 = { 0u, 0u, 0u, 0u }, v1 = v0, v2 = v0, v3 = v0;
+            bool  whole = false;                           // the lane holds a whole stretch's 64 letters in v0 .. v3
             if (mine)
               { const uint32_t p0 = T - 32u * w0;
                 uint32_t p = p0, x[16], z = 31u;
@@ -1271,10 +1276,9 @@ void k_qv_decode_sync(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                 uint8_t *o = out + 64ull * g;
                 const uint32_t valid = L - 64u * g < 64u ? L - 64u * g : 64u;
                 if (valid == 64u)
-                  { const u32x4 v0 = { x[0], x[1], x[2], x[3] },   v1 = { x[4], x[5], x[6], x[7] };
-                    const u32x4 v2 = { x[8], x[9], x[10], x[11] }, v3 = { x[12], x[13], x[14], x[15] };
-                    u32x4_u *gp = (u32x4_u *) o;
-                    gp[0] = v0; gp[1] = v1; gp[2] = v2; gp[3] = v3;
+                  { v0 = u32x4{ x[0], x[1], x[2], x[3] };   v1 = u32x4{ x[4], x[5], x[6], x[7] };
+                    v2 = u32x4{ x[8], x[9], x[10], x[11] }; v3 = u32x4{ x[12], x[13], x[14], x[15] };
+                    whole = true;
                   }
                 else                                       // the ragged end of the line (its codes past the end were zeros or the next segment's: thrown away)
                   {
@@ -1286,7 +1290,32 @@ void k_qv_decode_sync(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
                       }
                   }
               }
+            // A lane's 64 letters are 64 consecutive bytes of the text: stored as they are, a wave's store instruction is 64 requests of
+            // 16 bytes 64 bytes apart, four times the requests of a store whose lanes write side by side -- the kernel then waits
+            // on its stores (13.2 ms; k_qv_decode_sub, whose lanes interleave 16 letters each, 9).  So the round's 4 KiB change
+            // hands in the window, which the round no longer needs: lane l leaves its 16-byte piece c at row l, place c ^ (l / 2 & 3)
+            // (eight lanes in a row fill the LDS's eight 16-byte bank groups: no conflict, writing or reading), and takes piece
+            // l & 3 of row 16 k + l / 4 for the k-th KiB of the round.
             wave_sync();
+            const uint64_t wholes = __ballot(whole);
+            if (wholes)
+              { u32x4 *stage = (u32x4 *) (void *) (win + 3);                     // (16-byte aligned: win is s_win + 1)
+                const uint32_t sw = ((uint32_t) lane >> 1) & 3u;
+                if (whole)
+                  { stage[4u * (uint32_t) lane + (0u ^ sw)] = v0; stage[4u * (uint32_t) lane + (1u ^ sw)] = v1;
+                    stage[4u * (uint32_t) lane + (2u ^ sw)] = v2; stage[4u * (uint32_t) lane + (3u ^ sw)] = v3;
+                  }
+                wave_sync();
+                #pragma unroll
+                for (int k = 0; k < 4; k++)
+                  { const uint32_t row = 16u * (uint32_t) k + ((uint32_t) lane >> 2), c = (uint32_t) lane & 3u;
+                    if ((wholes >> row) & 1ull)
+                      { const u32x4 v = stage[4u * row + (c ^ ((row >> 1) & 3u))];
+                        *(u32x4_u *) (out + 64ull * (g0 + row) + 16u * c) = v;
+                      }
+                  }
+                wave_sync();
+              }
             g0 += cntl;
           }
         if (lane == 0)
