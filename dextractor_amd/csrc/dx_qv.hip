@@ -22,6 +22,17 @@
 #include "dx_internal.hpp"
 #include "dx_device.hpp"
 
+// the text's chunks as k_qv_hist asks for them: read once, never again by this kernel -- HIST_NT: marked so (the lines they would
+// push out of the L2 include the token lines under way: a step's tokens end in the middle of a cache line the next step fills up)
+#ifndef HIST_NT
+#define HIST_NT 0
+#endif
+#if HIST_NT
+#define HIST_LOAD(p) __builtin_nontemporal_load((const u32x4_u *) (p))
+#else
+#define HIST_LOAD(p) (*(const u32x4_u *) (p))
+#endif
+
 // Packed token: bits [0,24) code bits (for an escaped symbol: code<<8 | literal), bit 25 = escape
 // flag, [26,32) length in bits (a single shift extracts it; a symbol without a code is entry 0).
 // For run schemes the entry holds the bare run code; the 16-bit literal of an escaped run is
@@ -745,12 +756,12 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
             }
           u32x4 c2, c3, d0, d4, u1 = c0;               // (without tags u1 is never looked at; a copy of d0 would wait for d0's load)
           if (HIST_BARE_FETCH && base + DX_STEP <= L)  // this whole step is inside the lines: bare loads (see fetch_step)
-            { c2 = *(const u32x4_u *) (p2 + pos); c3 = *(const u32x4_u *) (p3 + pos); }
+            { c2 = HIST_LOAD(p2 + pos); c3 = HIST_LOAD(p3 + pos); }
           else
             { c2 = fetch(p2, pos, L, over); c3 = fetch(p3, pos, L, over); }
           if (HIST_BARE_FETCH && base + 2u * DX_STEP <= L)   // ... and so is the whole next step
-            { d0 = *(const u32x4_u *) (p0 + np); d4 = *(const u32x4_u *) (p4 + np);
-              if (tags) u1 = *(const u32x4_u *) (p1 + np);
+            { d0 = HIST_LOAD(p0 + np); d4 = HIST_LOAD(p4 + np);
+              if (tags) u1 = HIST_LOAD(p1 + np);
             }
           else
             { d0 = fetch(p0, np, L, over); d4 = fetch(p4, np, L, over);

@@ -40,9 +40,15 @@ int dx_scan_u32(dx_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out /
 #define WALK_WGS_PER_CU 1
 #define WALK_CAND      4u
 #ifndef WALK_PIECE_KB
-#define WALK_PIECE_KB 32
+#define WALK_PIECE_KB 16
 #endif
 #define WALK_PIECE_MIN ((uint64_t) WALK_PIECE_KB << 10)
+#ifndef WALK_SERVE
+#define WALK_SERVE 4u                    // a power of two: every how many turns lanes end and begin pieces
+#endif
+#ifndef WALK_PER_LANE
+#define WALK_PER_LANE 2u                 // pieces a lane, on average (a lane takes the next piece nobody has taken)
+#endif
 #define WALK_LANES_MAX ((uint64_t) 512 * 1024)
 #define WALK_ROUNDS    48
 // What one lane will walk of its own accord: a damaged stream can claim an entry of 2^31 symbols or a gigabyte of 255s, and a lane
@@ -338,7 +344,8 @@ struct walk_lds { uint16_t t[4][4096]; uint16_t r1[2][4096]; uint16_t one[4][409
 // mode choosing among three tables of one form, cost the burst more than the trips outside save: 119 against 106 ms.)
 __global__ __launch_bounds__(WALK_BLOCK, WALK_WGS_PER_CU * WALK_BLOCK / 256)     // (waves per SIMD: two workgroups a CU)
 void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uint32_t *todo, uint32_t ntodo,
-                   const uint64_t *start, walk_piece_d *pc, walk_rec_d *recs, uint32_t rcap, uint32_t *gwords, uint32_t gcap)
+                   const uint64_t *start, walk_piece_d *pc, walk_rec_d *recs, uint32_t rcap, uint32_t *gwords, uint32_t gcap,
+                   uint32_t *queue /* the next piece nobody has taken (starts at the number of lanes launched); NULL: a lane, a piece */)
 { __shared__ walk_lds S;
 #define WALK_STAGE(tab, from, words) { const uint32_t *s_ = (const uint32_t *) (const void *) (from); uint32_t *d_ = (uint32_t *) (void *) (tab); \
                                        for (uint32_t i = threadIdx.x; i < (words); i += blockDim.x) d_[i] = s_[i]; }
@@ -350,12 +357,15 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
   WALK_STAGE(S.one, a.one, 8192u)
 #undef WALK_STAGE
   __syncthreads();
+  // A lane takes a piece, walks it, and takes the next one nobody has taken (queue): pieces are smaller than a lane's share of the
+  // stream, so that a lane with a long record in its piece -- it walks the record to its end, wherever that is -- does not leave
+  // the others waiting: with a piece a lane the kernel took as long as its longest lane (lognormal lengths: 45 ms for work of 24).
   const uint64_t idx = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t k;
-  if (todo) { if (idx >= ntodo) return; k = todo[idx]; }
-  else      { if (idx >= a.pieces) return; k = idx; }
-  const uint64_t hi = k == a.pieces - 1 ? a.n : a.first + (k + 1) * a.piece;
-  walk_rec_d *my = recs + k * (uint64_t) rcap;
+  uint64_t k, hi = 0;
+  bool have_piece;
+  if (todo) { have_piece = idx < ntodo; k = have_piece ? todo[idx] : 0; }
+  else      { have_piece = idx < a.pieces; k = have_piece ? idx : 0; }
+  walk_rec_d *my = recs;
   walk_piece_d out = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   uint32_t rounds_ = 0;
 
@@ -371,7 +381,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
   //    look-up began that reached symbol 64 g | the symbols from there to 64 g << 28 (<= 12: a look-up's codes).
   // gi: the next word; gline: where the line's words began.  A burst holds at most one of either (8 look-ups: 8 tokens; <= 96
   // symbols, and a line whose burst does pass two marks -- codes of a bit -- is left without).
-  uint32_t *myg = gwords ? gwords + k * (uint64_t) gcap : (uint32_t *) NULL;
+  uint32_t *myg = NULL;
   uint32_t gi = 0, gT = 0, gj = 0, gP = 0, gline = 0, ghead = 0;
   bool gbad = false, trailing = false;
 #define WALK_GROUP_OUT(Tx, jx) \
@@ -411,20 +421,51 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
 #define WALK_STORE_FLUSH() \
   { if (myg != NULL && (gi & 3u) && (gi | 3u) < gcap) *(u32x4 *) (myg + (gi & ~3u)) = gbuf; }
   wrd_d rd;
-  bool live = true;
+  bool live = false, fresh = have_piece;                      // fresh: a piece has been taken and not begun
   rd.seg = a.img; rd.ring = S.ring[threadIdx.x]; rd.T = 0; rd.have = 0; rd.ua = 0; rd.ub = 0;
   rd.a0 = u32x4{ 0u, 0u, 0u, 0u }; rd.a1 = rd.a0; rd.b0 = rd.a0; rd.b1 = rd.a0;
-  if (todo || k == 0)
-    { out.start = todo ? start[k] : a.first; at = out.start; }
-  else if (ncand[k] == 0)
-    { out.flags = WP_NONE; live = false; at = 0; }
-  else
-    { trial = 1; budget = 16u * a.piece; at = cand[k * WALK_CAND]; nc = ncand[k]; }          // (two pieces' bytes)
-  if (live && !trial && !(at < hi && at < a.n)) { live = false; out.end = at; }     // (nothing of this piece left to walk)
+  at = 0;
 
   // (a lane that is done stays in the loop, doing nothing, until its wave is: w_pump_d and the burst are the wave's)
-  while (__any(live))
-    { bool fail = false;
+  for (uint32_t turn = 0; ; turn++)
+    { // (pieces end and begin every WALK_SERVE-th turn only: what that takes -- the piece's verdict stored, the queue, the next
+      //  piece's guesses fetched -- is memory round trips for the whole wave, and with 64 lanes some lane is between pieces in
+      //  nearly every turn; a lane waits two turns on average, of the 150 a piece takes)
+      const bool serve = (turn & (WALK_SERVE - 1u)) == 0u;
+      if (serve && !live && !fresh && have_piece)               // the lane's piece is walked: what became of it, and the next piece
+        { out.tried = ci;
+          if (!(out.flags & WP_NONE) && out.count)               // (see k_walk_find: bytes of 255 in front of the start may be the header's)
+            { uint32_t c = 0;
+              while (c < 4096u && out.start > a.first + c && a.img[out.start - 1 - c] == 255) c++;
+              out.lead255 = c;
+            }
+          WALK_STORE_FLUSH()
+          pc[k] = out;
+          have_piece = false;
+          if (queue != NULL)
+            { const uint64_t nk = atomicAdd(queue, 1u);
+              if (nk < a.pieces) { k = nk; have_piece = true; fresh = true; }
+            }
+        }
+      if (serve && fresh)                                       // begin the piece
+        { fresh = false; live = true;
+          hi  = k == a.pieces - 1 ? a.n : a.first + (k + 1) * a.piece;
+          my  = recs + k * (uint64_t) rcap;
+          myg = gwords ? gwords + k * (uint64_t) gcap : (uint32_t *) NULL;
+          out = walk_piece_d{ 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+          ph = PH_HEAD; rlen = 0; j = 0; last = 0; nn = 0; clen = 0; reclusters = 0;
+          gi = 0; gT = 0; gj = 0; gP = 0; gline = 0; ghead = 0; gbad = false; trailing = false;
+          trial = 0; ci = 0; nc = 0; budget = ~0ull;
+          if (todo || k == 0)
+            { out.start = todo ? start[k] : a.first; at = out.start; }
+          else if (ncand[k] == 0)
+            { out.flags = WP_NONE; live = false; at = 0; }
+          else
+            { trial = 1; budget = 16u * a.piece; at = cand[k * WALK_CAND]; nc = ncand[k]; }          // (two pieces' bytes)
+          if (live && !trial && !(at < hi && at < a.n)) { live = false; out.end = at; }     // (nothing of this piece left to walk)
+        }
+      if (!__any(live || have_piece)) break;
+      bool fail = false;
       rounds_ += 1;
       const bool inseg = live && ph >= PH_DEL && ph < PH_DONE;
       const uint32_t line = ph - PH_DEL;                        // 0 del, 1 ins, 2 mrg, 3 sub (in a segment)
@@ -613,15 +654,7 @@ void k_walk_pieces(walk_args a, uint64_t *cand, const uint32_t *ncand, const uin
             { out.flags |= WP_BAD; out.end = at; live = false; }
         }
     }
-  out.tried = ci;
-  if (!(out.flags & WP_NONE) && out.count)                   // (see k_walk_find: bytes of 255 in front of the start may be the header's)
-    { uint32_t c = 0;
-      while (c < 4096u && out.start > a.first + c && a.img[out.start - 1 - c] == 255) c++;
-      out.lead255 = c;
-    }
   (void) rounds_;
-  WALK_STORE_FLUSH()
-  pc[k] = out;
 }
 
 // the records of the pieces on the chain, side by side: a wave per piece; dst[k] = its first record's index (~0: not on the
@@ -744,9 +777,14 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   walk_args a;
   memset(&a, 0, sizeof(a));
   a.img = d_img; a.n = n; a.first = first; a.delChar = cd->delChar; a.subChar = cd->subChar; a.flip = flip;
-  { // no more lanes than the device holds at once (two workgroups a CU): a second round of waves would run beside nothing
-    const uint64_t lanes = (uint64_t) ctx->num_cu * WALK_WGS_PER_CU * WALK_BLOCK < WALK_LANES_MAX ? (uint64_t) ctx->num_cu * WALK_WGS_PER_CU * WALK_BLOCK : WALK_LANES_MAX;
-    uint64_t piece = (n - first + lanes - 1) / lanes;
+  uint64_t lanes;
+  { // As many lanes as the device holds at once (a workgroup a CU), WALK_PER_LANE pieces a lane on average: a lane takes the next piece
+    // nobody has taken when it is done with its own (k_walk_pieces), so what a long record costs its lane the others make up for.
+    // (Smaller pieces cost k_walk_find: every piece is scanned to its first header, half a record.)
+    uint64_t per_lane = WALK_PER_LANE;
+    if (const char *e = getenv("DEXGPU_WALK_PER_LANE")) { const uint64_t v = strtoull(e, NULL, 10); if (v >= 1 && v <= 64) per_lane = v; }
+    lanes = (uint64_t) ctx->num_cu * WALK_WGS_PER_CU * WALK_BLOCK < WALK_LANES_MAX ? (uint64_t) ctx->num_cu * WALK_WGS_PER_CU * WALK_BLOCK : WALK_LANES_MAX;
+    uint64_t piece = (n - first + lanes * per_lane - 1) / (lanes * per_lane);
     if (piece < WALK_PIECE_MIN) piece = WALK_PIECE_MIN;
     if (const char *e = getenv("DEXGPU_WALK_PIECE")) { const uint64_t v = strtoull(e, NULL, 10); if (v >= 4096) piece = v; }   // (tests)
     piece = (piece + 4095u) & ~(uint64_t) 4095u;
@@ -755,10 +793,10 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   }
   const uint64_t P = a.pieces;
   const uint32_t rcap = (uint32_t) (a.piece / 128u);
-  // the run-coded lines' group words: a word per 8 tokens.  A share of piece / 8 words holds a token per 4 bytes of the piece; lines
+  // the lanes' words for the group index: 0.05 words a byte at the bench's 690 words a 14.4 KB record; a share of piece / 8 + 4096 words; lines
   // of a lane that runs out are left without (DEXGPU_WALK_NOGROUPS: none at all -- the index is then the round-4 one)
   const bool     groups = !flip && getenv("DEXGPU_WALK_NOGROUPS") == NULL;
-  const uint32_t gcap = groups ? (uint32_t) (a.piece / 8u) : 0u;
+  const uint32_t gcap = groups ? (uint32_t) (a.piece / 8u) + 4096u : 0u;     // (+ what the record takes that the lane walks beyond its piece: 80 KB's worth)
   { // does the scratch fit (56 bytes a possible record, 0.44 of the stream) with room for the index behind it?  Asked first: a
     // failed allocation half way costs the allocations before it, and the caller has another way (the host walk).
     uint64_t fr = 0, all = 0;
@@ -773,7 +811,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   uint32_t *d_ncand = NULL, *d_todo = NULL;
   walk_piece_d *d_pc = NULL, *pc = (walk_piece_d *) malloc(P * sizeof(walk_piece_d));
   walk_rec_d   *d_recs = NULL;
-  uint32_t *d_gwords = NULL, *d_gtok = NULL, *d_room = NULL, *d_none = NULL;
+  uint32_t *d_gwords = NULL, *d_gtok = NULL, *d_room = NULL, *d_none = NULL, *d_queue = NULL;
   uint64_t *d_gsrc = NULL;
   uint64_t *dst = (uint64_t *) malloc(4 * P * 8), *trim = dst ? dst + 3 * P : NULL;
   uint8_t  *onchain = (uint8_t *) calloc(P, 1);
@@ -800,17 +838,21 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   if (n > a.tail_at) WALK_HIP(hipMemcpyAsync(d_tail, d_img + a.tail_at, n - a.tail_at, hipMemcpyDeviceToDevice, ctx->stream));
   a.tail = d_tail;
 
-  { // a workgroup per CU while the lanes allow (the tables fill 64 KB of LDS: two workgroups a CU at most), every CU busy
-    const uint64_t waves = (P + 63u) / 64u, per_cu = (waves + ctx->num_cu - 1) / ctx->num_cu;
+  WALK_HIP(hipMalloc(&d_queue, 64));
+  { // a workgroup per CU while the lanes allow, every CU busy; the pieces beyond the lanes launched wait in the queue
+    const uint64_t L0 = P < lanes ? P : lanes;
+    const uint64_t waves = (L0 + 63u) / 64u, per_cu = (waves + ctx->num_cu - 1) / ctx->num_cu;
     const uint32_t bs = per_cu >= WALK_BLOCK / 64u ? WALK_BLOCK : (uint32_t) (per_cu ? per_cu * 64u : 64u);
+    const uint32_t q0 = (uint32_t) (((L0 + bs - 1) / bs) * bs);             // (the lanes launched take pieces 0 .. q0 - 1 themselves)
+    WALK_HIP(hipMemcpyAsync(d_queue, &q0, 4, hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t ev[3] = { NULL, NULL, NULL };                   // DEXGPU_WALK_DEBUG: the two kernels' times
     const bool timed = getenv("DEXGPU_WALK_DEBUG") != NULL && hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess && hipEventCreate(&ev[2]) == hipSuccess;
     dx_prof_begin(ctx, DX_K_QV_WALK);
     if (timed) (void) hipEventRecord(ev[0], ctx->stream);
     hipLaunchKernelGGL(k_walk_find, dim3((unsigned) ((P + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream, a, d_cand, d_ncand);
     if (timed) (void) hipEventRecord(ev[1], ctx->stream);
-    hipLaunchKernelGGL(k_walk_pieces, dim3((unsigned) ((P + bs - 1) / bs)), dim3(bs), 0, ctx->stream, a, d_cand,
-                       (const uint32_t *) d_ncand, (const uint32_t *) NULL, 0u, (const uint64_t *) NULL, d_pc, d_recs, rcap, d_gwords, gcap);
+    hipLaunchKernelGGL(k_walk_pieces, dim3((unsigned) ((L0 + bs - 1) / bs)), dim3(bs), 0, ctx->stream, a, d_cand,
+                       (const uint32_t *) d_ncand, (const uint32_t *) NULL, 0u, (const uint64_t *) NULL, d_pc, d_recs, rcap, d_gwords, gcap, d_queue);
     if (timed) (void) hipEventRecord(ev[2], ctx->stream);
     dx_prof_end(ctx);
     if (timed)
@@ -860,7 +902,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
             WALK_HIP(hipMemcpyAsync(d_todo, &kk, 4, hipMemcpyHostToDevice, ctx->stream));
             dx_prof_begin(ctx, DX_K_QV_WALK);
             hipLaunchKernelGGL(k_walk_pieces, dim3(1), dim3(64), 0, ctx->stream, a, d_cand, (const uint32_t *) d_ncand,
-                               (const uint32_t *) d_todo, 1u, (const uint64_t *) d_start, d_pc, d_recs, rcap, d_gwords, gcap);
+                               (const uint32_t *) d_todo, 1u, (const uint64_t *) d_start, d_pc, d_recs, rcap, d_gwords, gcap, (uint32_t *) NULL);
             dx_prof_end(ctx);
             WALK_HIP(hipGetLastError());
             WALK_HIP(hipMemcpyAsync(pc + k, d_pc + k, sizeof(walk_piece_d), hipMemcpyDeviceToHost, ctx->stream));
@@ -941,7 +983,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
 done:
   (void) hipFree(d_blob); (void) hipFree(d_tail); (void) hipFree(d_cand); (void) hipFree(d_ncand); (void) hipFree(d_pc); (void) hipFree(d_recs);
   (void) hipFree(d_start); (void) hipFree(d_todo); (void) hipFree(d_dst);
-  (void) hipFree(d_gwords); (void) hipFree(d_gtok); (void) hipFree(d_room); (void) hipFree(d_none); (void) hipFree(d_gsrc);
+  (void) hipFree(d_queue); (void) hipFree(d_gwords); (void) hipFree(d_gtok); (void) hipFree(d_room); (void) hipFree(d_none); (void) hipFree(d_gsrc);
   free(blob); free(pc); free(dst); free(onchain);
   if (rc != DX_OK) dx_qv_dindex_free(ctx, out);
   return rc;
