@@ -461,7 +461,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                 torch.cuda.empty_cache()
                 state["decode_indexed"] = {"skipped": f"{type(e).__name__}: {e}"[:200]}
         if not args.twopass and world == 1:
-            # ... and as a bare file's record stream is indexed where it lies: dx_qv_walk_device, a lane per 128 KiB piece
+            # ... and as a bare file's record stream is indexed where it lies: dx_qv_walk_device, lanes taking pieces of 28 KiB
             # (no download, no host walk); its index against the encoder's own
             try:
                 trace("verify: the record walk on the device")
@@ -478,7 +478,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                         a_ = np.zeros(nb_, np.uint8); b_ = np.zeros(nb_, np.uint8)
                         ctx._chk(ctx.lib.dx_d2h(ctx.h, a_.ctypes.data, mine_.ptr, nb_)); ctx._chk(ctx.lib.dx_d2h(ctx.h, b_.ctypes.data, theirs_.ptr, nb_))
                         same = same and bool((a_ == b_).all())
-                state["device_walk"] = {"kernel": "k_walk_find + k_walk_pieces + k_walk_gather", "wall_ms": round((t_w1 - t_w) * 1e3, 2),
+                state["device_walk"] = {"kernel": "k_walk_find + k_walk_pieces + k_walk_gather + k_walk_rooms + k_walk_index; decode: k_qv_decode_sync (timed as k_qv_decode_sub) + k_qv_decode_runs", "wall_ms": round((t_w1 - t_w) * 1e3, 2),
                                         "kernel_ms": round(kt[0], 2) if kt else None, "launches": kt[1] if kt else None,
                                         "pieces": dix.pieces, "piece_bytes": dix.piece_bytes, "records": dix.n,
                                         "index_identical_to_the_encoders": bool(same),

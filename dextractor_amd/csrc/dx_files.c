@@ -1047,9 +1047,10 @@ int dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexq
   }
   if (rc != DX_OK) goto host;
   at += used;
-  { /* image, walk scratch (0.44 of the image) and index must fit together; asked before anything goes up */
+  { /* image, walk scratch (records 0.7, the lanes' words for the group index 1.1 of the image) and index (0.3) must fit together;
+       asked before anything goes up (dx_qv_walk_device asks again, to the byte) */
     uint64_t fr = 0, all = 0;
-    if (dx_mem_info(ctx, &fr, &all) == DX_OK && fr > 0 && 1.55 * (double) n + (double) (128 << 20) > 0.95 * (double) fr)
+    if (dx_mem_info(ctx, &fr, &all) == DX_OK && fr > 0 && 3.2 * (double) n + (double) (128 << 20) > 0.95 * (double) fr)
       goto host;
   }
   p->ctx = ctx;
