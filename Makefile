@@ -24,7 +24,7 @@ lib: $(LIB)
 # every device compile also leaves the kernels' register / LDS / scratch use in $(BUILD)/<file>.res (compiler remarks);
 # the library target condenses them into dextractor_amd/kernel_resources.txt, which tests/test_host.py checks:
 # some kernels must stay under a register count to share a CU with another kernel
-$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/dx_internal.hpp $(CSRC)/dx_device.hpp $(CSRC)/dx_layout.h $(CSRC)/dx_walk.h $(CSRC)/dx_qv_fast.hpp include/dexgpu.h
+$(BUILD)/%.o: $(CSRC)/%.hip $(CSRC)/dx_internal.hpp $(CSRC)/dx_device.hpp $(CSRC)/dx_layout.h $(CSRC)/dx_walk.h $(CSRC)/dx_qv_fast.hpp $(CSRC)/dx_qv_short.hpp include/dexgpu.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c $< -o $@ 2> $(BUILD)/$*.res; rc=$$?; \
 	  grep -v "kernel-resource-usage\|^ *[0-9]* | \|^ *| *^" $(BUILD)/$*.res >&2; exit $$rc

@@ -2013,6 +2013,9 @@ static qv_args make_args(const dx_qv_batch *b, int delChar, int subChar, int los
   return a;
 }
 
+int dx_scan_u32(dx_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *total);
+#include "dx_qv_short.hpp"
+
 extern "C" int dx_qv_prescan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx_qv_params *p)
 { int e = check_batch(ctx, b, "dx_qv_prescan");
   if (e) return e;
@@ -2160,6 +2163,21 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   unsigned long long *d_hist = (unsigned long long *) scr;
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 2) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
+  bool brief = false;
+  if ((e = qs_short(ctx, b, &brief))) return e;
+  if (brief)                                             // short entries: a lane each (dx_qv_short.hpp); no tokens, no counters per entry
+    { ctx->tk.valid = 0; ctx->tk.eh_valid = 0;
+      DX_LAUNCH(ctx, DX_K_QV_HIST, k_qs_hist, qs_grid(ctx, n), QS_BLOCK, a, entry0, (long long) p->del_first, (long long) p->sub_first,
+                d_hist, d_hist + 6 * 256);
+      uint64_t host[6 * 256 + 1];
+      DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+      DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (int s = 0; s < 6; s++)
+        for (int k = 0; k < 256; k++)
+          hist[s][k] += host[s * 256 + k];
+      *totChar += host[6 * 256];
+      return DX_OK;
+    }
   tok_sink ts = { NULL, NULL, NULL, NULL, d_hist + 6 * 256 + 1, NULL };
   if (tokens_prepare(ctx, b, p, scr, hbytes))
     { ts.del = ctx->tk.del; ts.sub = ctx->tk.sub; ts.off = ctx->tk.off; ts.info = ctx->tk.info; ts.list = ctx->tk.list; }
@@ -2363,7 +2381,13 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
     }
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 18);
+  bool brief = false;
+  if ((e = qs_short(ctx, b, &brief))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
+  if (brief)
+    DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qs_entries<false>, qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
+              (const uint64_t *) NULL, d_seg, d_size, (uint8_t *) NULL, ctx->d_status);
+  else
   DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, n, 4 * SIZES_WAVES), DX_BLOCK,
             a, (const uint32_t *) ctx->d_tok, d_hdr_off, d_seg, d_size, d_ticket,
             (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL);
@@ -2394,7 +2418,13 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
+  bool brief = false;
+  if ((e = qs_short(ctx, b, &brief))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
+  if (brief)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qs_entries<true>, qs_grid(ctx, b->n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+              d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
+  else
   DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
             a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 },
             (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0,
@@ -2675,6 +2705,16 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // The product route when the histogram pass has left every entry's own counters (k_qv_hist<true>): sizes by dot product
   // (k_qv_sizes_hist), every record written where it belongs -- no scratch slots, no compaction.  DEXGPU_SLOTS=1: the
   // slot route below all the same; DEXGPU_DIRECT_ENCODE: sizes by k_qv_sizes_fast (tokens and plain lines read again).
+  { bool brief = false;
+    if ((e = qs_short(ctx, b, &brief))) return e;
+    if (brief)
+      { uint64_t t = 0;
+        const int rc = onepass_short(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
+        if (total) *total = t;
+        if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }   // (this route does not pipeline)
+        return rc;
+      }
+  }
   const bool by_hist = onepass_tokens_ok(ctx, b) && ctx->tk.eh_valid && getenv("DEXGPU_SLOTS") == NULL;
   if (by_hist || (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_DIRECT_ENCODE") != NULL))
     { uint64_t t = 0;
