@@ -2309,6 +2309,9 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
         }
       ctx->bps[s] = bound;
     }
+  ctx->tok_wide = 0;                                     // a symbol token of more than 16 bits (an escape and its literal)?
+  for (int i = 0; i < 4 * 256; i++)
+    if (TOK_LEN(tok[i]) > 16u) ctx->tok_wide = 1;
   for (int s = 0; s < 2; s++)                            // ins, mrg: band of coded byte values for the pair tables
     { int lo = -1, hi = -1;                                // (k_qv_encode_fast: two symbols per look-up)
       for (int x = 0; x < 256; x++)
@@ -2385,7 +2388,7 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
   if ((e = qs_short(ctx, b, &brief))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   if (brief)
-    DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qs_entries<false>, qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
+    DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
               (const uint64_t *) NULL, d_seg, d_size, (uint8_t *) NULL, ctx->d_status);
   else
   DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, n, 4 * SIZES_WAVES), DX_BLOCK,
@@ -2421,8 +2424,11 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   bool brief = false;
   if ((e = qs_short(ctx, b, &brief))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
-  if (brief)
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qs_entries<true>, qs_grid(ctx, b->n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+  if (brief && ctx->tok_wide)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, b->n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+              d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
+  else if (brief)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, b->n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
               d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
   else
   DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,

@@ -15,7 +15,9 @@
 #ifndef QS_MEAN
 #define QS_MEAN   1200u
 #endif
+#ifndef QS_BLOCK
 #define QS_BLOCK  256
+#endif
 #define QS_COPIES 4u                    // copies of every histogram bin in a workgroup's LDS (copy = lane & 3)
 
 #define QS_W      8                     // 16-byte chunks a lane asks for at a time: one cache line of its line, whole and aligned (its neighbours'
@@ -23,7 +25,6 @@
                                         // is fetched twice -- 28 waves x 64 lanes x 128 bytes a CU outlive neither the 32 KB L1 nor a share of the L2)
 #define QS_MAXLEN 4096u                 // ... and no entry longer than this (a lane is alone with its entry)
 
-#define QS_BYTE(v, b) ((((b) < 4 ? (v).x : (b) < 8 ? (v).y : (b) < 12 ? (v).z : (v).w) >> (8 * ((b) & 3))) & 0xffu)
 
 typedef __attribute__((address_space(3))) uint32_t qs_lds;        // (the tables and counters of a workgroup)
 #define QS_LDS(p) ((qs_lds *) (p))
@@ -33,6 +34,8 @@ typedef __attribute__((address_space(1))) const u32x4_u qs_g128;  // (global_loa
 typedef __attribute__((address_space(1))) u32_u qs_g32;
 typedef __attribute__((address_space(1))) uint8_t qs_g8;
 typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_u __attribute__((aligned(1)));
 
 // The cache line around p + pos: its 32 words (one vector: the chunk a uniform loop counter names is read out of it through the
 // register index, not by selects), and which of its bytes are the line's from pos on: [skip, skip + len).
@@ -67,6 +70,12 @@ __device__ __forceinline__ u32x32 qs_fetch_raw(const uint8_t *q0, const uint8_t 
     { v[4 * k] = c[k].x; v[4 * k + 1] = c[k].y; v[4 * k + 2] = c[k].z; v[4 * k + 3] = c[k].w; }
   return v;
 }
+__device__ __forceinline__ u32x2 qs_fetch8(const uint8_t *q, const uint8_t *lo, const uint8_t *end16)
+{ const uint8_t *qc = q < lo ? lo : q;
+  u32x2 c = *(__attribute__((address_space(1))) const u32x2_u *) (qc < end16 ? qc : end16);
+  if (q < lo || q > end16) { const u32x4 e = qs_edge(q, lo, end16 + 16); c = u32x2{ e.x, e.y }; }
+  return c;
+}
 // the cache line around p + pos
 __device__ __forceinline__ qs_span qs_fetch(const uint8_t *p, uint32_t pos, uint32_t L, const uint8_t *lo, const uint8_t *end16)
 { qs_span s;
@@ -76,13 +85,17 @@ __device__ __forceinline__ qs_span qs_fetch(const uint8_t *p, uint32_t pos, uint
   s.v    = qs_fetch_raw(q - s.skip, lo, end16);
   return s;
 }
-// a line's spans, a span's chunks (k uniform), a chunk's bytes
+// a line's spans; a span's sixteen pieces of 8 bytes (k uniform: the piece is read out of the vector through the register index);
+// a piece's bytes
+#define QS_PIECES 16
 #define QS_SPANS(s, p, L, lo, end16) for (uint32_t pos = 0, step_ = 0; pos < (L); pos += step_) { qs_span s = qs_fetch(p, pos, L, lo, end16); step_ = (s).len;
-#define QS_CHUNKS(s, k, c) _Pragma("nounroll") for (int k = 0; k < QS_W; k++) \
-                             { if (16u * k + 16u <= (s).skip || 16u * k >= (s).skip + (s).len) continue; \
-                               const u32x4 c = { (s).v[4 * k], (s).v[4 * k + 1], (s).v[4 * k + 2], (s).v[4 * k + 3] };
-#define QS_BYTES(b)        _Pragma("unroll") for (int b = 0; b < 16; b++)
-#define QS_LIVE(s, k, b)   ((uint32_t) (16 * (k) + (b)) - (s).skip < (s).len)
+#define QS_DEAD(s, k)      (8u * (k) + 8u <= (s).skip || 8u * (k) >= (s).skip + (s).len)
+#define QS_CHUNKS(s, k, c) _Pragma("nounroll") for (int k = 0; k < QS_PIECES; k++) \
+                             { if (QS_DEAD(s, k)) continue; \
+                               const u32x2 c = { (s).v[2 * k], (s).v[2 * k + 1] };
+#define QS_BYTES(b)        _Pragma("unroll") for (int b = 0; b < 8; b++)
+#define QS_BYTE(v, b)      ((((b) < 4 ? (v).x : (v).y) >> (8 * ((b) & 3))) & 0xffu)
+#define QS_LIVE(s, k, b)   ((uint32_t) (8 * (k) + (b)) - (s).skip < (s).len)
 
 __global__ __launch_bounds__(256)
 void k_qs_maxlen(const uint32_t *len, uint64_t n, uint32_t *out)
@@ -170,45 +183,36 @@ void k_qs_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
 // ---------------------------------------------------------------------------------------------
 //  a lane's walk over one entry: sizes only (EMIT = false) or the record written (EMIT = true)
 // ---------------------------------------------------------------------------------------------
-// MSB-first into 32-bit words as OCODE does (QV.c:404-422); T: bits so far, last: the length of the last code appended (an
-// escape's literal counts as a code of its own: the pad rule QV.c:436-442 looks at where the last OCODE began).  Finished words
-// wait in q0..q2 for a fourth: a lane's stores are 16 bytes (its neighbours' records are elsewhere: nothing coalesces).
-#ifndef QS_QUAD
-#define QS_QUAD 0
-#endif
-struct qs_bits { uint8_t *p; uint64_t acc; uint32_t fill, T, last, q0, q1, q2, nq; };
+// MSB-first into 32-bit words as OCODE does (QV.c:404-422).  Sizes: T counts the bits.  Records: finished words go to the lane's
+// column of a ring in LDS (QS_RING words; word j at ring[(j % QS_RING) * QS_BLOCK]: the lanes of a wave write side by side), and
+// leave it sixteen bytes at a time at the end of every chunk -- a lane's records are its own (its neighbours' are elsewhere,
+// nothing coalesces), and 4-byte stores cost the encoder 2.8 of its 7.4 ms.  A piece adds at most 14 words (eight symbols
+// of 16 + 16 + 24 bits) to the at most 3 that stayed.
+#define QS_RING 32u
+struct qs_bits { uint8_t *p; qs_lds *ring; uint64_t acc; uint32_t fill, T, wr, rd; };
 
+__device__ __forceinline__ qs_bits qs_begin(uint8_t *dst, qs_lds *ring)
+{ return qs_bits{ dst, ring, 0ull, 0u, 0u, 0u, 0u }; }
 __device__ __forceinline__ void qs_word(qs_bits &w, uint32_t word)
-{
-#if QS_QUAD
-  if (w.nq == 3u)
-    { *(__attribute__((address_space(1))) u32x4_u *) w.p = u32x4{ w.q0, w.q1, w.q2, word };
-      w.p += 16; w.nq = 0u;
-    }
-  else
-    { w.q0 = w.nq == 0u ? word : w.q0; w.q1 = w.nq == 1u ? word : w.q1; w.q2 = w.nq == 2u ? word : w.q2;
-      w.nq += 1u;
-    }
-#else
-  *(qs_g32 *) w.p = word; w.p += 4;
-#endif
+{ w.ring[(w.wr & (QS_RING - 1u)) * QS_BLOCK] = word;
+  w.wr += 1u;
 }
-__device__ __forceinline__ void qs_drain(qs_bits &w)
-{
-#if QS_QUAD
-  if (w.nq > 0u) { *(qs_g32 *) w.p = w.q0; w.p += 4; }
-  if (w.nq > 1u) { *(qs_g32 *) w.p = w.q1; w.p += 4; }
-  if (w.nq > 2u) { *(qs_g32 *) w.p = w.q2; w.p += 4; }
-  w.nq = 0u;
+__device__ __forceinline__ void qs_quads(qs_bits &w)
+{ while (w.wr - w.rd >= 4u)
+    { const uint32_t j = w.rd & (QS_RING - 1u);            // (a multiple of 4: the ring is read in fours only, until the line's end)
+      const u32x4 v = { w.ring[j * QS_BLOCK], w.ring[(j + 1u) * QS_BLOCK], w.ring[(j + 2u) * QS_BLOCK], w.ring[(j + 3u) * QS_BLOCK] };
+#ifndef QS_NOSTORE
+      *(__attribute__((address_space(1))) u32x4_u *) w.p = v;
 #endif
+      w.p += 16; w.rd += 4u;
+    }
 }
-
 // len bits (<= 32; 0: nothing), right-aligned in bits
 template <bool EMIT>
 __device__ __forceinline__ void qs_put(qs_bits &w, uint32_t len, uint32_t bits)
 { if (!EMIT) w.T += len;
   if (EMIT)
-    { w.acc |= ((uint64_t) bits << (32u - len)) << (32u - w.fill);      // (fill < 32)
+    { w.acc |= (uint64_t) bits << ((64u - len - w.fill) & 63u);         // (fill < 32: a shift of 1..63, or bits of no length)
       w.fill += len;
       if (w.fill >= 32u)
         { qs_word(w, (uint32_t) (w.acc >> 32));
@@ -216,24 +220,23 @@ __device__ __forceinline__ void qs_put(qs_bits &w, uint32_t len, uint32_t bits)
         }
     }
 }
-// a run's code and, behind the longest code, its 16-bit literal (QV.c:478-488)
+// the segment's end (QV.c:436-442): its bytes.  last: the length of the last code appended (a literal counts as a code of its
+// own: the pad rule looks at where the last OCODE began)
 template <bool EMIT>
-__device__ __forceinline__ void qs_run(qs_bits &w, const qs_lds *rtab, uint32_t run)
-{ const uint32_t t = rtab[run > 255u ? 255u : run];
-  qs_put<EMIT>(w, TOK_LEN(t), TOK_BITS(t));
-  w.last = TOK_LEN(t);
-  if (TOK_ESC(t)) { qs_put<EMIT>(w, 16u, run & 0xffffu); w.last = 16u; }
-}
-// the segment's end (QV.c:436-442): its bytes
-template <bool EMIT>
-__device__ __forceinline__ uint32_t qs_finish(qs_bits &w, const uint8_t *dst)
-{ if (EMIT) w.T = (uint32_t) (w.p - dst) * 8u + 32u * w.nq + w.fill;      // (the sizes count their bits, the records their words)
-  const uint32_t olen = w.T & 31u, llen = (w.T - w.last) & 31u;
+__device__ __forceinline__ uint32_t qs_finish(qs_bits &w, const uint8_t *dst, uint32_t last)
+{ if (EMIT)
+    { qs_quads(w);
+      while (w.wr != w.rd)
+        { *(qs_g32 *) w.p = w.ring[(w.rd & (QS_RING - 1u)) * QS_BLOCK];
+          w.p += 4; w.rd += 1u;
+        }
+      w.T = (uint32_t) (w.p - dst) * 8u + w.fill;          // (the sizes count their bits, the records their words)
+    }
+  const uint32_t olen = w.T & 31u, llen = (w.T - last) & 31u;
   const uint32_t words = (w.T >> 5) + (olen ? 1u : 0u);
   const bool again = olen ? (llen > 16u && olen > llen) : (w.T > 0u && llen > 16u);
   if (EMIT)
     { const uint32_t part = (uint32_t) (w.acc >> 32);       // (0 when the last word was whole)
-      qs_drain(w);
       if (olen) { *(qs_g32 *) w.p = part; w.p += 4; }
       if (again) { *(qs_g32 *) w.p = part; w.p += 4; }
     }
@@ -242,37 +245,51 @@ __device__ __forceinline__ uint32_t qs_finish(qs_bits &w, const uint8_t *dst)
 
 struct qs_ret { uint32_t bytes, n; };                   // the segment's bytes; the symbols under which a tag stands
 
-// one plain line (Encode, QV.c:386-443); mask: the lossy rounding of the insertion / merge QVs (QV.c:1406-1415), in all four bytes
-// of a word.  A token holds a symbol's code and, for an escape, its 8-bit literal behind it (one OCODE each, QV.c:430-433: the
-// last code is then the literal); a byte beyond the line is a token of no bits.
-template <bool EMIT>
-__device__ __forceinline__ qs_ret qs_plain(const uint8_t *p, uint32_t L, const uint8_t *lo, const uint8_t *end16, const qs_lds *tab, uint32_t mask4, uint8_t *dst)
-{ qs_bits w = { dst, 0ull, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+// one plain line (Encode, QV.c:386-443); mask4: the lossy rounding of the insertion / merge QVs (QV.c:1406-1415), in all four
+// bytes of a word.  A token holds a symbol's code and, for an escape, its 8-bit literal behind it (one OCODE each, QV.c:430-433:
+// the last code is then the literal); a byte beyond the line is a token of no bits.
+template <bool EMIT, bool WIDE>
+__device__ __forceinline__ qs_ret qs_plain(const uint8_t *p, uint32_t L, const uint8_t *lo, const uint8_t *end16, const qs_lds *tab, uint32_t mask4,
+                                           uint8_t *dst, qs_lds *ring)
+{ qs_bits w = qs_begin(dst, ring);
   uint32_t tl = 0;                                        // the line's last token
   QS_SPANS(s, p, L, lo, end16)
       s.v &= mask4;
       QS_CHUNKS(s, k, c)
-        uint32_t t[16];
-        QS_BYTES(b) t[b] = tab[QS_BYTE(c, b)];            // (whatever byte: an address in the table; the sixteen look-ups go out together)
+        uint32_t t[8];
+        QS_BYTES(b) t[b] = tab[QS_BYTE(c, b)];            // (whatever byte: an address in the table; the eight look-ups go out together)
         QS_BYTES(b)
           { const bool live = QS_LIVE(s, k, b);
             t[b] = live ? t[b] : 0u;
             tl   = live ? t[b] : tl;
-            qs_put<EMIT>(w, TOK_LEN(t[b]), TOK_BITS(t[b]));
           }
+        if (!EMIT)
+          { QS_BYTES(b) w.T += TOK_LEN(t[b]); }
+        else if (WIDE)                                    // (a table with escapes: a token of up to 24 bits at a time)
+          { QS_BYTES(b) qs_put<EMIT>(w, TOK_LEN(t[b]), TOK_BITS(t[b])); }
+        else                                              // codes of at most 16 bits: two symbols at a time
+          { _Pragma("unroll")
+            for (int b = 0; b < 8; b += 2)
+              qs_put<EMIT>(w, TOK_LEN(t[b]) + TOK_LEN(t[b + 1]), (TOK_BITS(t[b]) << TOK_LEN(t[b + 1])) | TOK_BITS(t[b + 1]));
+          }
+        if (EMIT) qs_quads(w);
       }
     }
-  w.last = TOK_ESC(tl) ? 8u : TOK_LEN(tl);
-  return qs_ret{ qs_finish<EMIT>(w, dst), L };
+  return qs_ret{ qs_finish<EMIT>(w, dst, TOK_ESC(tl) ? 8u : TOK_LEN(tl)), L };
 }
 
 // 2-bit codes, four to a byte, the first in the top bits (Compress_Read DB.c:319-338): sixteen to a stored word
 struct qs_tags { uint8_t *p; uint32_t acc, n; };
-__device__ __forceinline__ void qs_tag(qs_tags &g, uint32_t letter)
-{ g.acc = (g.acc << 2) | tag_code(letter);
-  g.n += 1u;
-  if ((g.n & 15u) == 0u)
-    { *(qs_g32 *) g.p = __builtin_bswap32(g.acc); g.p += 4; }
+__device__ __forceinline__ void qs_tag(qs_tags &g, uint32_t letter, bool on)
+{ g.acc = on ? (g.acc << 2) | tag_code(letter) : g.acc;
+  g.n  += on;
+  if (on && (g.n & 15u) == 0u)
+    {
+#ifndef QS_NOSTORE
+      *(qs_g32 *) g.p = __builtin_bswap32(g.acc);
+#endif
+      g.p += 4;
+    }
 }
 __device__ __forceinline__ void qs_tag_end(qs_tags &g)
 { const uint32_t left = g.n & 15u;
@@ -282,46 +299,77 @@ __device__ __forceinline__ void qs_tag_end(qs_tags &g)
     }
 }
 
-// one run-coded line (Encode_Run, QV.c:448-506); TAGS: the deletion line -- the tags under its non-run symbols are packed on the
-// way (Pack_Tag QV.c:810-819, Number_Read DB.c:393-416), .n = how many
+// one run-coded line (Encode_Run, QV.c:448-506): before every symbol that is not the run character the code of the run that ended
+// there (of 0 too), the longest code with a 16-bit literal behind it (QV.c:478-488), then the symbol's; a run at the line's end:
+// its code alone.  TAGS: the deletion line -- the tags under its symbols are packed on the way (Pack_Tag QV.c:810-819,
+// Number_Read DB.c:393-416), .n = how many.  A chunk's 32 look-ups go out together (the run's code for every byte, whatever it
+// is); the run's code and the symbol's are one piece of at most 32 bits, a run character's or a dead byte's a piece of none --
+// unless a literal stands behind one of them in the chunk (any lane's): that chunk is walked code by code.
 template <bool EMIT, bool TAGS>
 __device__ __forceinline__ qs_ret qs_runs(const uint8_t *p, const uint8_t *ptag, uint32_t L, const uint8_t *lo, const uint8_t *end16, const qs_lds *tab,
-                                       const qs_lds *rtab, uint32_t rc, uint8_t *dst, uint8_t *tdst)
-{ qs_bits w = { dst, 0ull, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+                                          const qs_lds *rtab, uint32_t rc, uint8_t *dst, uint8_t *tdst, qs_lds *ring)
+{ qs_bits w = qs_begin(dst, ring);
   qs_tags g = { tdst, 0u, 0u };
-  uint32_t run = 0;
+  const u32x2 c_zero = { 0u, 0u };
+  uint32_t run = 0, nsym = 0, tl = 0;                      // the open run; symbols so far; the last symbol's token
   QS_SPANS(s, p, L, lo, end16)
-      u32x32 gv = s.v;                                     // the tags under the span's bytes: the same 128 positions of the tag line
-      if (TAGS && EMIT) gv = qs_fetch_raw(ptag + pos - s.skip, lo, end16);
-      QS_CHUNKS(s, k, c)
-        const u32x4 gc = { gv[4 * k], gv[4 * k + 1], gv[4 * k + 2], gv[4 * k + 3] };
-        uint32_t ts[16];
-        QS_BYTES(b) ts[b] = tab[QS_BYTE(c, b)];
-        QS_BYTES(b)
-          { const uint32_t x = QS_BYTE(c, b);
-            const bool live = QS_LIVE(s, k, b);
-            if (x == rc) run += live;
-            else if (live)
-              { const uint32_t tr = rtab[run > 255u ? 255u : run], t = ts[b];
-                if (!TOK_ESC(tr | t))                        // the run's code and the symbol's in one piece of <= 32 bits
-                  { qs_put<EMIT>(w, TOK_LEN(tr) + TOK_LEN(t), (TOK_BITS(tr) << TOK_LEN(t)) | TOK_BITS(t));
-                    w.last = TOK_LEN(t);
-                  }
-                else                                         // (a literal behind one of them)
-                  { qs_run<EMIT>(w, rtab, run);
-                    qs_put<EMIT>(w, TOK_LEN(t), TOK_BITS(t));
-                    w.last = TOK_ESC(t) ? 8u : TOK_LEN(t);
-                  }
-                run = 0;
-                if (TAGS && EMIT) qs_tag(g, QS_BYTE(gc, b));
-                else g.n += 1u;
-              }
-          }
-      }
+      // the tags under the span's bytes: the same positions of the tag line, a piece ahead of the piece at work
+      const uint8_t *tq = ptag + pos - s.skip;
+      u32x2 gnext = c_zero;
+      if (TAGS && EMIT) gnext = qs_fetch8(tq, lo, end16);
+      _Pragma("nounroll")
+      for (int k = 0; k < QS_PIECES; k++)
+        { const u32x2 gc = gnext;
+          if (TAGS && EMIT && k + 1 < QS_PIECES) gnext = qs_fetch8(tq + 8 * (k + 1), lo, end16);
+          if (QS_DEAD(s, k)) continue;
+          const u32x2 c = { s.v[2 * k], s.v[2 * k + 1] };
+          uint32_t ts[8], tr[8], syms = 0, esc = 0;
+          const uint32_t run0 = run;
+          QS_BYTES(b) ts[b] = tab[QS_BYTE(c, b)];
+          QS_BYTES(b)
+            { const bool live = QS_LIVE(s, k, b), isrc = QS_BYTE(c, b) == rc, sym = live && !isrc;
+              tr[b] = rtab[run > 255u ? 255u : run];
+              run   = sym ? 0u : run + (live ? 1u : 0u);
+              syms |= sym ? 1u << b : 0u;
+            }
+          QS_BYTES(b)
+            { const bool sym = (syms >> b) & 1u;
+              ts[b] = sym ? ts[b] : 0u; tr[b] = sym ? tr[b] : 0u;
+              tl    = sym ? ts[b] : tl;
+              esc  |= ts[b] | tr[b];
+            }
+          nsym += __builtin_popcount(syms);
+          if (!__any(TOK_ESC(esc)))
+            { QS_BYTES(b)
+                qs_put<EMIT>(w, TOK_LEN(tr[b]) + TOK_LEN(ts[b]), (TOK_BITS(tr[b]) << TOK_LEN(ts[b])) | TOK_BITS(ts[b]));
+            }
+          else                                               // (rare: long runs, or tables with escapes)
+            { uint32_t rn = run0;
+              QS_BYTES(b)
+                { if ((syms >> b) & 1u)
+                    { qs_put<EMIT>(w, TOK_LEN(tr[b]), TOK_BITS(tr[b]));
+                      if (TOK_ESC(tr[b])) qs_put<EMIT>(w, 16u, rn & 0xffffu);
+                      qs_put<EMIT>(w, TOK_LEN(ts[b]), TOK_BITS(ts[b]));
+                      rn = 0;
+                    }
+                  else
+                    rn += QS_LIVE(s, k, b) ? 1u : 0u;
+                }
+            }
+          if (TAGS && EMIT)
+            { QS_BYTES(b) qs_tag(g, QS_BYTE(gc, b), (syms >> b) & 1u); }
+          if (EMIT) qs_quads(w);
+        }
     }
-  if (run) qs_run<EMIT>(w, rtab, run);                      // (a line that ends in a run: its code, no symbol behind it)
+  uint32_t last = TOK_ESC(tl) ? 8u : TOK_LEN(tl);
+  if (run)                                                  // (a line that ends in a run: its code, no symbol behind it)
+    { const uint32_t t = rtab[run > 255u ? 255u : run];
+      qs_put<EMIT>(w, TOK_LEN(t), TOK_BITS(t));
+      last = TOK_LEN(t);
+      if (TOK_ESC(t)) { qs_put<EMIT>(w, 16u, run & 0xffffu); last = 16u; }
+    }
   if (TAGS && EMIT) qs_tag_end(g);
-  return qs_ret{ qs_finish<EMIT>(w, dst), g.n };
+  return qs_ret{ qs_finish<EMIT>(w, dst, last), nsym };
 }
 
 // the whole tag line packed (no deletion run character: QV.c:1393-1396)
@@ -329,7 +377,7 @@ __device__ __forceinline__ void qs_tags_all(const uint8_t *ptag, uint32_t L, con
 { qs_tags g = { tdst, 0u, 0u };
   QS_SPANS(s, ptag, L, lo, end16)
       QS_CHUNKS(s, k, c)
-        QS_BYTES(b) if (QS_LIVE(s, k, b)) qs_tag(g, QS_BYTE(c, b));
+        QS_BYTES(b) qs_tag(g, QS_BYTE(c, b), QS_LIVE(s, k, b));
       }
     }
   qs_tag_end(g);
@@ -338,12 +386,14 @@ __device__ __forceinline__ void qs_tags_all(const uint8_t *ptag, uint32_t L, con
 // EMIT = false: seg[5 r ..] and rec_size[r] (dx_qv_sizes' contract); EMIT = true: the record at rec_off[r], its segment sizes
 // compared with seg (status bit 1: they differ).  A symbol the tables have
 // no code for costs no bits, as in the reference (Encode's OCODE of length 0) and in k_qv_encode
-template <bool EMIT>
+template <bool EMIT, bool WIDE>
 __global__ __launch_bounds__(QS_BLOCK)
 void k_qs_entries(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off, const uint64_t *rec_off,
                   uint32_t *seg, uint32_t *rec_size, uint8_t *out, uint32_t *status)
 { __shared__ uint32_t s_tok[6][256];
+  __shared__ uint32_t s_ring[EMIT ? QS_RING : 1u][QS_BLOCK];
   load_tables(s_tok, g_tok);
+  qs_lds *ring = QS_LDS(&s_ring[0][threadIdx.x]);
   const uint32_t imask = a.lossy ? 0xfefefefeu : ~0u, mmask = a.lossy ? 0xfcfcfcfcu : ~0u;
   uint32_t differ = 0;
   for (uint64_t r = (uint64_t) blockIdx.x * QS_BLOCK + threadIdx.x; r < a.n; r += (uint64_t) gridDim.x * QS_BLOCK)
@@ -363,23 +413,23 @@ void k_qs_entries(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const ui
       uint8_t *d0 = dst, *d1 = d0 + want[0], *d2 = d1 + want[1], *d3 = d2 + want[2], *d4 = d3 + want[3];
       qs_ret q;
       if (a.delChar >= 0)
-        { q = qs_runs<EMIT, true>(p0, p1, L, a.text, end16, QS_LDS(s_tok[DX_DEL]), QS_LDS(s_tok[DX_DRUN]), (uint32_t) a.delChar & 0xffu, d0, d1);
+        { q = qs_runs<EMIT, true>(p0, p1, L, a.text, end16, QS_LDS(s_tok[DX_DEL]), QS_LDS(s_tok[DX_DRUN]), (uint32_t) a.delChar & 0xffu, d0, d1, ring);
           clen = q.n;
         }
       else
-        { q = qs_plain<EMIT>(p0, L, a.text, end16, QS_LDS(s_tok[DX_DEL]), ~0u, d0);
+        { q = qs_plain<EMIT, WIDE>(p0, L, a.text, end16, QS_LDS(s_tok[DX_DEL]), ~0u, d0, ring);
           if (EMIT) qs_tags_all(p1, L, a.text, end16, d1);
         }
       sg[0] = q.bytes;
       sg[1] = (clen + 3u) >> 2;
-      q = qs_plain<EMIT>(p2, L, a.text, end16, QS_LDS(s_tok[DX_INS]), imask, d2);
+      q = qs_plain<EMIT, WIDE>(p2, L, a.text, end16, QS_LDS(s_tok[DX_INS]), imask, d2, ring);
       sg[2] = q.bytes;
-      q = qs_plain<EMIT>(p3, L, a.text, end16, QS_LDS(s_tok[DX_MRG]), mmask, d3);
+      q = qs_plain<EMIT, WIDE>(p3, L, a.text, end16, QS_LDS(s_tok[DX_MRG]), mmask, d3, ring);
       sg[3] = q.bytes;
       if (a.subChar >= 0)
-        q = qs_runs<EMIT, false>(p4, p4, L, a.text, end16, QS_LDS(s_tok[DX_SUB]), QS_LDS(s_tok[DX_SRUN]), (uint32_t) a.subChar & 0xffu, d4, d4);
+        q = qs_runs<EMIT, false>(p4, p4, L, a.text, end16, QS_LDS(s_tok[DX_SUB]), QS_LDS(s_tok[DX_SRUN]), (uint32_t) a.subChar & 0xffu, d4, d4, ring);
       else
-        q = qs_plain<EMIT>(p4, L, a.text, end16, QS_LDS(s_tok[DX_SUB]), ~0u, d4);
+        q = qs_plain<EMIT, WIDE>(p4, L, a.text, end16, QS_LDS(s_tok[DX_SUB]), ~0u, d4, ring);
       sg[4] = q.bytes;
       if (EMIT)
         { if (sg[0] != want[0] || sg[1] != want[1] || sg[2] != want[2] || sg[3] != want[3] || sg[4] != want[4]) differ = 1u; }
@@ -427,7 +477,7 @@ static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr
   ctx->sx.valid = 0;                                     // (these kernels leave no group index)
   const qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
-  DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qs_entries<false>, qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
+  DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
             (const uint64_t *) NULL, d_seg, d_size, (uint8_t *) NULL, ctx->d_status);
   uint64_t tot = 0;
   if ((e = dx_scan_u32(ctx, d_size, n, d_rec_off, &tot))) return e;
@@ -437,8 +487,12 @@ static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr
   if (tot > out_cap)
     return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
                    (unsigned long long) tot, (unsigned long long) out_cap);
-  DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qs_entries<true>, qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
-            (const uint64_t *) d_rec_off, d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
+  if (ctx->tok_wide)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+              (const uint64_t *) d_rec_off, d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
+  else
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+              (const uint64_t *) d_rec_off, d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
