@@ -2,25 +2,43 @@
 //
 // The wave-per-entry kernels give an entry a whole wavefront: a step is 1 KiB of each of its lines, and an entry pays its fixed
 // costs -- a ticket, its whereabouts, five first requests, 1.5 KB of counters out, five segment ends -- whatever its length.  At
-// 300 symbols an entry fills a third of a step and the batch runs at 0.06 of the HBM peak (4 M x 300: 27 ms for 6 GB); the
-// round-4 verdict asked for several entries per wave.  Here: 64 entries per wave, a lane each, through the reference's own loops
-// (QVcoding_Scan QV.c:922-1023 with Histogram_Seqs / Histogram_Runs :702-724; Compress_Next_QVentry QV.c:1381-1426 with
-// Encode :386-443, Encode_Run :448-506, Pack_Tag :810-819 + Number_Read + Compress_Read) -- a lane reads its lines 16 bytes at
-// a time and goes through them byte by byte: ~20 instructions a symbol where the wave-per-entry kernels spend 2, but no step is
-// ever a third full and nothing is per entry but the entry.  Three passes over the text (histograms; sizes; records written where
-// the sizes' prefix sums put them), as dx_qv_sizes / dx_qv_encode have it.  Taken for batches whose entries average at most
-// QS_MEAN symbols (dx_qv_hist, dx_qv_encode_onepass, dx_qv_sizes, dx_qv_encode); DEXGPU_NO_SHORT: never.
+// 300 symbols an entry fills a third of a step and the batch ran at 216 GB/s (4 M x 300: 27.8 ms for 6 GB); the round-4 verdict
+// asked for several entries per wave.  Here: 64 entries per wave, a lane each, through the reference's own loops (QVcoding_Scan
+// QV.c:922-1023 with Histogram_Seqs / Histogram_Runs :702-724; Compress_Next_QVentry QV.c:1381-1426 with Encode :386-443,
+// Encode_Run :448-506, Pack_Tag :810-819 + Number_Read + Compress_Read).  Three passes over the text (histograms; sizes;
+// records written where the sizes' prefix sums put them), as dx_qv_sizes / dx_qv_encode have it.
 //
-// Roofline: HBM in name only -- a lane's 16-byte loads are a request each; the kernels are bound by their instructions.
+// What shapes the kernels (profiles/r05_short_entries.txt has the measurements, 4 M x 300, ms per step):
+//   * a lane's line is 1.5 KB from its neighbour's: nothing coalesces, and a cache line asked for in two goes is fetched twice
+//     (a CU's lanes hold 16 waves x 64 x 128 bytes: more than its L1, and with the other CUs' more than the L2).  A lane asks for the
+//     whole aligned 128-byte line around its position in eight requests that go out together (15.8 -> 12.8);
+//   * they are bound by their vector instructions -- a wave64 instruction takes a SIMD four cycles, 6.1e11 a second on the chip,
+//     and the three kernels issue 4.6e9 -- so: the span is one 32-word vector and the piece at work is read out of it through
+//     the register index (a loop counter, uniform), not unrolled sixteen times or chosen by selects; the look-ups of a piece go
+//     out together; two symbols of a plain line are one piece of <= 32 bits for the bit buffer, a run's code and its symbol's
+//     too; in a run-coded line only the symbols are walked (qs_others finds them eight bytes at a time);
+//   * finished words leave through a ring in LDS sixteen bytes at a time (4-byte stores: 2.8 of the encoder's 7.4 ms);
+//   * the lanes of a wave are at different places in their cache lines: of the byte steps a wave takes 69 % are some lane's
+//     (300-symbol lines; 88 % at 1000).
+// 4 M x 300: 10.8 ms, 555 GB/s (k_qs_hist 1.9, k_qs_entries<sizes> 2.0, <records> 6.1).  Against the wave-per-entry kernels by
+// mean length (2 M entries, GB/s): 600: 632 / 407, 1000: 689 / 647, 1200: 699 / 735 -- taken for batches of >= 4096 entries whose
+// entries average at most QS_MEAN symbols and are none longer than QS_MAXLEN (a lane is alone with its entry); DEXGPU_NO_SHORT:
+// never.  No tokens, no group index: the decoder reads such a stream with its generic kernel.
+//
+// Roofline: the vector ALUs, not the HBM: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs accounts for 1.5 of k_qs_hist's 1.9 ms, 2.1 of the
+// sizes' 2.1 and 3.8 of the records' 6.1 (the rest of those: waits for the look-ups and for the next cache line, 4 waves a SIMD).
 #ifndef QS_MEAN
-#define QS_MEAN   1200u
+#define QS_MEAN   1000u
 #endif
 #ifndef QS_BLOCK
 #define QS_BLOCK  256
 #endif
 #define QS_COPIES 4u                    // copies of every histogram bin in a workgroup's LDS (copy = lane & 3)
 
-#define QS_W      8                     // 16-byte chunks a lane asks for at a time: one cache line of its line, whole and aligned (its neighbours'
+#ifndef QS_W
+#define QS_W      8
+#endif
+//                ^                    // 16-byte chunks a lane asks for at a time: one cache line of its line, whole and aligned (its neighbours'
                                         // lines are 1.5 KB away: a lane's requests share nothing with theirs, and a cache line asked for in two goes
                                         // is fetched twice -- 28 waves x 64 lanes x 128 bytes a CU outlive neither the 32 KB L1 nor a share of the L2)
 #define QS_MAXLEN 4096u                 // ... and no entry longer than this (a lane is alone with its entry)
@@ -33,7 +51,7 @@ typedef __attribute__((address_space(3))) uint32_t qs_lds;        // (the tables
 typedef __attribute__((address_space(1))) const u32x4_u qs_g128;  // (global_load / global_store, not flat)
 typedef __attribute__((address_space(1))) u32_u qs_g32;
 typedef __attribute__((address_space(1))) uint8_t qs_g8;
-typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
+typedef uint32_t u32x32 __attribute__((ext_vector_type(4 * QS_W)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 u32x2_u __attribute__((aligned(1)));
 
@@ -80,14 +98,14 @@ __device__ __forceinline__ u32x2 qs_fetch8(const uint8_t *q, const uint8_t *lo, 
 __device__ __forceinline__ qs_span qs_fetch(const uint8_t *p, uint32_t pos, uint32_t L, const uint8_t *lo, const uint8_t *end16)
 { qs_span s;
   const uint8_t *q = p + pos;
-  s.skip = (uint32_t) ((uintptr_t) q & 127u);
-  s.len  = L - pos < 128u - s.skip ? L - pos : 128u - s.skip;
+  s.skip = (uint32_t) ((uintptr_t) q & (16u * QS_W - 1u));
+  s.len  = L - pos < 16u * QS_W - s.skip ? L - pos : 16u * QS_W - s.skip;
   s.v    = qs_fetch_raw(q - s.skip, lo, end16);
   return s;
 }
 // a line's spans; a span's sixteen pieces of 8 bytes (k uniform: the piece is read out of the vector through the register index);
 // a piece's bytes
-#define QS_PIECES 16
+#define QS_PIECES (2 * QS_W)
 #define QS_SPANS(s, p, L, lo, end16) for (uint32_t pos = 0, step_ = 0; pos < (L); pos += step_) { qs_span s = qs_fetch(p, pos, L, lo, end16); step_ = (s).len;
 #define QS_DEAD(s, k)      (8u * (k) + 8u <= (s).skip || 8u * (k) >= (s).skip + (s).len)
 #define QS_CHUNKS(s, k, c) _Pragma("nounroll") for (int k = 0; k < QS_PIECES; k++) \
@@ -186,9 +204,12 @@ void k_qs_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
 // MSB-first into 32-bit words as OCODE does (QV.c:404-422).  Sizes: T counts the bits.  Records: finished words go to the lane's
 // column of a ring in LDS (QS_RING words; word j at ring[(j % QS_RING) * QS_BLOCK]: the lanes of a wave write side by side), and
 // leave it sixteen bytes at a time at the end of every chunk -- a lane's records are its own (its neighbours' are elsewhere,
-// nothing coalesces), and 4-byte stores cost the encoder 2.8 of its 7.4 ms.  A piece adds at most 14 words (eight symbols
-// of 16 + 16 + 24 bits) to the at most 3 that stayed.
-#define QS_RING 32u
+// nothing coalesces), and 4-byte stores cost the encoder 2.8 of its 7.4 ms.  A piece of 8 bytes adds at most 11 words to the at most 3
+// that stayed: a run of 255 and more, which has a literal, can only end at a piece's first symbol (32 bits), the other runs in
+// it are of 6 at most (7 codes of 16 bits), and eight symbols have 24 bits at most.
+#ifndef QS_RING
+#define QS_RING 16u
+#endif
 struct qs_bits { uint8_t *p; qs_lds *ring; uint64_t acc; uint32_t fill, T, wr, rd; };
 
 __device__ __forceinline__ qs_bits qs_begin(uint8_t *dst, qs_lds *ring)
@@ -299,18 +320,30 @@ __device__ __forceinline__ void qs_tag_end(qs_tags &g)
     }
 }
 
+// bit b: byte b of the piece is not the byte rc4 holds four times
+__device__ __forceinline__ uint32_t qs_others(u32x2 c, uint32_t rc4)
+{ const uint32_t t0 = c.x ^ rc4, t1 = c.y ^ rc4;
+  const uint32_t n0 = ((((t0 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t0) & 0x80808080u) >> 7;     // bits 0, 8, 16, 24: the byte is not zero
+  const uint32_t n1 = ((((t1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t1) & 0x80808080u) >> 7;
+  return (((n0 * 0x00204081u) >> 21) & 0xfu) | (((n1 * 0x00204081u) >> 17) & 0xf0u);
+}
+__device__ __forceinline__ uint32_t qs_byte_at(u32x2 c, uint32_t b)      // (b a lane's own: 0..7)
+{ return ((b < 4u ? c.x : c.y) >> (8u * (b & 3u))) & 0xffu; }
+
 // one run-coded line (Encode_Run, QV.c:448-506): before every symbol that is not the run character the code of the run that ended
 // there (of 0 too), the longest code with a 16-bit literal behind it (QV.c:478-488), then the symbol's; a run at the line's end:
 // its code alone.  TAGS: the deletion line -- the tags under its symbols are packed on the way (Pack_Tag QV.c:810-819,
-// Number_Read DB.c:393-416), .n = how many.  A chunk's 32 look-ups go out together (the run's code for every byte, whatever it
-// is); the run's code and the symbol's are one piece of at most 32 bits, a run character's or a dead byte's a piece of none --
-// unless a literal stands behind one of them in the chunk (any lane's): that chunk is walked code by code.
+// Number_Read DB.c:393-416), .n = how many.  Most bytes are the run character: a piece's symbols are found eight bytes at a time
+// and only they are walked (the wave goes round as often as its lane with the most has symbols: 4 to 5 times in 8 bytes at the
+// reference's run densities, not 8); the run's code and the symbol's are one piece of at most 32 bits unless a literal stands
+// behind one of them.
 template <bool EMIT, bool TAGS>
 __device__ __forceinline__ qs_ret qs_runs(const uint8_t *p, const uint8_t *ptag, uint32_t L, const uint8_t *lo, const uint8_t *end16, const qs_lds *tab,
                                           const qs_lds *rtab, uint32_t rc, uint8_t *dst, uint8_t *tdst, qs_lds *ring)
 { qs_bits w = qs_begin(dst, ring);
   qs_tags g = { tdst, 0u, 0u };
   const u32x2 c_zero = { 0u, 0u };
+  const uint32_t rc4 = rc * 0x01010101u;
   uint32_t run = 0, nsym = 0, tl = 0;                      // the open run; symbols so far; the last symbol's token
   QS_SPANS(s, p, L, lo, end16)
       // the tags under the span's bytes: the same positions of the tag line, a piece ahead of the piece at work
@@ -323,41 +356,26 @@ __device__ __forceinline__ qs_ret qs_runs(const uint8_t *p, const uint8_t *ptag,
           if (TAGS && EMIT && k + 1 < QS_PIECES) gnext = qs_fetch8(tq + 8 * (k + 1), lo, end16);
           if (QS_DEAD(s, k)) continue;
           const u32x2 c = { s.v[2 * k], s.v[2 * k + 1] };
-          uint32_t ts[8], tr[8], syms = 0, esc = 0;
-          const uint32_t run0 = run;
-          QS_BYTES(b) ts[b] = tab[QS_BYTE(c, b)];
-          QS_BYTES(b)
-            { const bool live = QS_LIVE(s, k, b), isrc = QS_BYTE(c, b) == rc, sym = live && !isrc;
-              tr[b] = rtab[run > 255u ? 255u : run];
-              run   = sym ? 0u : run + (live ? 1u : 0u);
-              syms |= sym ? 1u << b : 0u;
-            }
-          QS_BYTES(b)
-            { const bool sym = (syms >> b) & 1u;
-              ts[b] = sym ? ts[b] : 0u; tr[b] = sym ? tr[b] : 0u;
-              tl    = sym ? ts[b] : tl;
-              esc  |= ts[b] | tr[b];
-            }
+          const uint32_t b0 = s.skip > 8u * k ? s.skip - 8u * k : 0u;                          // the line's bytes of the piece: [b0, b1)
+          const uint32_t b1 = s.skip + s.len - 8u * k < 8u ? s.skip + s.len - 8u * k : 8u;
+          uint32_t syms = qs_others(c, rc4) & ((1u << b1) - (1u << b0)), cur = b0;
           nsym += __builtin_popcount(syms);
-          if (!__any(TOK_ESC(esc)))
-            { QS_BYTES(b)
-                qs_put<EMIT>(w, TOK_LEN(tr[b]) + TOK_LEN(ts[b]), (TOK_BITS(tr[b]) << TOK_LEN(ts[b])) | TOK_BITS(ts[b]));
-            }
-          else                                               // (rare: long runs, or tables with escapes)
-            { uint32_t rn = run0;
-              QS_BYTES(b)
-                { if ((syms >> b) & 1u)
-                    { qs_put<EMIT>(w, TOK_LEN(tr[b]), TOK_BITS(tr[b]));
-                      if (TOK_ESC(tr[b])) qs_put<EMIT>(w, 16u, rn & 0xffffu);
-                      qs_put<EMIT>(w, TOK_LEN(ts[b]), TOK_BITS(ts[b]));
-                      rn = 0;
-                    }
-                  else
-                    rn += QS_LIVE(s, k, b) ? 1u : 0u;
+          while (syms)
+            { const uint32_t b = __builtin_ctz(syms);
+              syms &= syms - 1u;
+              run += b - cur; cur = b + 1u;
+              const uint32_t tr = rtab[run > 255u ? 255u : run], t = tab[qs_byte_at(c, b)];
+              if (!TOK_ESC(tr | t))
+                qs_put<EMIT>(w, TOK_LEN(tr) + TOK_LEN(t), (TOK_BITS(tr) << TOK_LEN(t)) | TOK_BITS(t));
+              else                                           // (rare: a run of 255 and more, or tables with escapes)
+                { qs_put<EMIT>(w, TOK_LEN(tr), TOK_BITS(tr));
+                  if (TOK_ESC(tr)) qs_put<EMIT>(w, 16u, run & 0xffffu);
+                  qs_put<EMIT>(w, TOK_LEN(t), TOK_BITS(t));
                 }
+              tl = t; run = 0u;
+              if (TAGS && EMIT) qs_tag(g, qs_byte_at(gc, b), true);
             }
-          if (TAGS && EMIT)
-            { QS_BYTES(b) qs_tag(g, QS_BYTE(gc, b), (syms >> b) & 1u); }
+          run += b1 - cur;
           if (EMIT) qs_quads(w);
         }
     }
@@ -386,8 +404,13 @@ __device__ __forceinline__ void qs_tags_all(const uint8_t *ptag, uint32_t L, con
 // EMIT = false: seg[5 r ..] and rec_size[r] (dx_qv_sizes' contract); EMIT = true: the record at rec_off[r], its segment sizes
 // compared with seg (status bit 1: they differ).  A symbol the tables have
 // no code for costs no bits, as in the reference (Encode's OCODE of length 0) and in k_qv_encode
+#ifdef QS_OCC
+#define QS_WAVES __attribute__((amdgpu_waves_per_eu(QS_OCC)))
+#else
+#define QS_WAVES
+#endif
 template <bool EMIT, bool WIDE>
-__global__ __launch_bounds__(QS_BLOCK)
+__global__ __launch_bounds__(QS_BLOCK) QS_WAVES
 void k_qs_entries(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off, const uint64_t *rec_off,
                   uint32_t *seg, uint32_t *rec_size, uint8_t *out, uint32_t *status)
 { __shared__ uint32_t s_tok[6][256];

@@ -1,6 +1,6 @@
 """Batches of SHORT entries: the lane-per-entry kernels of dx_qv_short.hpp (k_qs_hist, k_qs_entries) against the oracle.
 
-They are taken for batches of >= 4096 entries that average at most 1200 symbols with none longer than 4096; every case here checks
+They are taken for batches of >= 4096 entries that average at most 1000 symbols with none longer than 4096; every case here checks
 that it took them (dx_qv_onepass_info: direct == 3) -- or, where the case is about NOT taking them, that it did not.  Bar: bit-exact."""
 import numpy as np
 import pytest
