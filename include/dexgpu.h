@@ -308,7 +308,8 @@ int dx_qv_encode_onepass_end(dx_ctx *ctx, uint64_t *total);
  * run-coded line, more tokens than the slot holds).                                                              */
 typedef struct
   { int32_t  groups, direct, tokens, reserved;        /* direct: 0 slots + compaction, 1 sizes first by k_qv_sizes_fast (tokens and plain lines read
-                                                         again), 2 sizes from the entries' own histograms (k_qv_sizes_hist): the product route */
+                                                         again), 2 sizes from the entries' own histograms (k_qv_sizes_hist): the product route,
+                                                         3 a batch of short entries: a lane per entry (k_qs_entries: sizes, then records) */
     uint64_t region_bytes, scratch_bytes, avail_bytes, token_bytes, text_entries;
     uint64_t chain_waits[3];                          /* always 0 (the routes that reported here are gone; kept for the layout) */
   } dx_onepass_info;
