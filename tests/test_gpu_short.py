@@ -165,3 +165,18 @@ def test_long_entry_or_few_entries_keep_the_wave_per_entry_kernels(ctx, monkeypa
     assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
     c = synth.make_quiva(300, seed=4, dist="fixed", mean=150)
     assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
+
+
+def test_mixed_lengths_1_to_20000(ctx):
+    """a batch of entries of 1 ... 20 000 symbols, most of them short (the wave-per-entry kernels: an entry is longer than a lane
+    takes), and the same batch with the long ones cut down to 4096 (the lane-per-entry kernels): both against the oracle"""
+    rng = np.random.Generator(np.random.PCG64(20))
+    lens = np.concatenate([rng.integers(1, 400, 4000), rng.integers(400, 3000, 700), rng.integers(3000, 20001, 60),
+                           [1, 2, 3, 15, 16, 17, 20000]]).astype(np.uint32)
+    rng.shuffle(lens)
+    c = synth.make_quiva(len(lens), seed=21, lens=lens)
+    assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
+    c = synth.make_quiva(len(lens), seed=21, lens=np.minimum(lens, 4096).astype(np.uint32))
+    want = O.dexqv(c.text)
+    assert ctx.dexqv(c.text) == want and _took_short(ctx)
+    assert ctx.undexqv(want, upper=True) == O.undexqv(want, upper=True)
