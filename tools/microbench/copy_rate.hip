@@ -38,6 +38,18 @@ __global__ __launch_bounds__(256) void k_fill(u32x4 *__restrict__ dst, size_t n1
       for (int k = 0; k < U; k++) if (i + k * stride < n16) dst[i + k * stride] = v;
     }
 }
+// ... through 16-byte stores that begin `off` bytes past a 16-byte boundary (what k_pack2_decode's lanes do: a read's text begins anywhere)
+typedef u32x4 u32x4_un __attribute__((aligned(1)));
+template <int U>
+__global__ __launch_bounds__(256) void k_fill_off(uint8_t *__restrict__ dst, size_t n16, unsigned off)
+{ const size_t stride = (size_t) gridDim.x * blockDim.x;
+  const u32x4 v = { 1, 2, 3, 4 };
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n16; i += stride * U)
+    {
+      #pragma unroll
+      for (int k = 0; k < U; k++) if (i + k * stride + 1 < n16) *(u32x4_un *) (dst + 16 * (i + k * stride) + off) = v;
+    }
+}
 // the plainest float4 copy there is: one element a thread, as many workgroups as there are elements (what a guide's "float4 copy"
 // usually is); BS threads a workgroup
 template <int BS>
@@ -123,6 +135,8 @@ int main()
       printf("%-28s %2d workgroups of 256 per CU: %7.3f ms  %6.2f TB/s\n", NAME, per, best, (GB) / best / 1e9); fflush(stdout); }
   RUN("read 16 GiB (x4)", (double) bytes, k_read<4>, dim3(cus * per), dim3(256), 0, 0, a, o, n16)
   RUN("fill 16 GiB (x4)", (double) bytes, k_fill<4>, dim3(cus * per), dim3(256), 0, 0, b, n16)
+  RUN("fill 16 GiB (x4), stores 4 bytes off", (double) bytes, k_fill_off<4>, dim3(cus * per), dim3(256), 0, 0, (uint8_t *) b, n16, 4u)
+  RUN("fill 16 GiB (x4), stores 5 bytes off", (double) bytes, k_fill_off<4>, dim3(cus * per), dim3(256), 0, 0, (uint8_t *) b, n16, 5u)
   RUN("copy 16 GiB (x1), r + w", 2.0 * bytes, (k_copy<1, false>), dim3(cus * per), dim3(256), 0, 0, a, b, n16)
   RUN("copy 16 GiB (x4), r + w", 2.0 * bytes, (k_copy<4, false>), dim3(cus * per), dim3(256), 0, 0, a, b, n16)
   RUN("copy 16 GiB (x4, nt), r + w", 2.0 * bytes, (k_copy<4, true>), dim3(cus * per), dim3(256), 0, 0, a, b, n16)
