@@ -48,6 +48,15 @@ __global__ void NAME(uint32_t *out, uint64_t *clk, uint32_t seed)               
 #define A_BCNT(n)   "v_bcnt_u32_b32 %" #n ", %" #n ", %8\n"
 #define A_FFBH(n)   "v_ffbh_u32 %" #n ", %" #n "\n"
 #define A_CNDM(n)   "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define A_AND(n)    "v_and_b32 %" #n ", %" #n ", %8\n"
+#define A_OR(n)     "v_or_b32 %" #n ", %" #n ", %8\n"
+#define A_SHL(n)    "v_lshlrev_b32 %" #n ", 3, %" #n "\n"
+#define A_SHR(n)    "v_lshrrev_b32 %" #n ", 3, %" #n "\n"
+#define A_MIN(n)    "v_min_u32 %" #n ", %" #n ", %8\n"
+#define A_SUB(n)    "v_sub_u32 %" #n ", %" #n ", %8\n"
+#define A_CMP(n)    "v_cmp_lt_u32 vcc, %" #n ", %8\n"
+#define A_CNDS(n)   "v_cndmask_b32_e64 %" #n ", %" #n ", %8, s[20:21]\n"
+#define A_CMPCND(n) "v_cmp_lt_u32 vcc, %" #n ", %8\nv_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
 #define A_ADDLSH(n) "v_add_lshl_u32 %" #n ", %" #n ", %8, 2\n"
 #define A_LSHLADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 2, %8\n"
 
@@ -68,6 +77,15 @@ DEF_KERNEL(k_bcnt, A_BCNT)
 DEF_KERNEL(k_ffbh, A_FFBH)
 DEF_KERNEL(k_cndmask, A_CNDM)
 DEF_KERNEL(k_add_lshl, A_ADDLSH)
+DEF_KERNEL(k_and, A_AND)
+DEF_KERNEL(k_or, A_OR)
+DEF_KERNEL(k_shl, A_SHL)
+DEF_KERNEL(k_shr, A_SHR)
+DEF_KERNEL(k_min, A_MIN)
+DEF_KERNEL(k_sub, A_SUB)
+DEF_KERNEL(k_cmp, A_CMP)
+DEF_KERNEL(k_cnds, A_CNDS)
+DEF_KERNEL(k_cmpcnd, A_CMPCND)
 DEF_KERNEL(k_lshl_add, A_LSHLADD)
 
 // 64-bit shift: 4 register pairs
@@ -141,7 +159,8 @@ int main()
     { "v_bfe_u32", k_bfe }, { "v_perm_b32", k_perm }, { "v_mul_u32_u24", k_mul24 }, { "v_mul_lo_u32", k_mullo },
     { "v_add_u32_dpp row_shr:1", k_dpp_add }, { "v_lshlrev_b32_sdwa", k_sdwa_shl }, { "v_add3_u32", k_add3 },
     { "v_bfi_b32", k_bfi }, { "v_bcnt_u32_b32", k_bcnt }, { "v_ffbh_u32", k_ffbh }, { "v_cndmask_b32", k_cndmask },
-    { "v_add_lshl_u32", k_add_lshl }, { "v_lshl_add_u32", k_lshl_add }, { "v_lshrrev_b64", k_lshr64 } };
+    { "v_add_lshl_u32", k_add_lshl }, { "v_and_b32", k_and }, { "v_or_b32", k_or }, { "v_lshlrev_b32", k_shl }, { "v_lshrrev_b32", k_shr },
+    { "v_min_u32", k_min }, { "v_sub_u32", k_sub }, { "v_cmp_lt_u32 (vcc)", k_cmp }, { "v_cndmask_b32_e64 (sgpr pair)", k_cnds }, { "v_cmp + v_cndmask (pair = 2)", k_cmpcnd }, { "v_lshl_add_u32", k_lshl_add }, { "v_lshrrev_b64", k_lshr64 } };
   const int wps[] = { 1, 2, 4, 8 };
   for (auto &kk : ks)
     for (int w : wps)
