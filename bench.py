@@ -643,6 +643,8 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
                                     "frac": round(dk["algo_bytes_8d_per_step"] / (dk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                     "traffic": (dk["traffic_bytes_per_step"] / dk["launches_per_step"]) if dk["traffic_bytes_per_step"] else None},
                 "per_kernel": per_kernel}
+    if by_hist and args.dist == "fixed" and not args.lossy:
+        roofline["valu_issue"] = read_valu_issue(bases, times, args.steps)
     pipe = {"algo_bytes": step_algo, "step_ms": round(step_s * 1e3, 3),
             "kernel_ms_sum": round(sum(kern[k]["ms_avg"] * kern[k]["launches"] / args.steps for k in kern if k != "k_synth"), 3),
             "GBps": round(step_algo / step_s / 1e9, 1),
@@ -715,6 +717,34 @@ def read_traffic(path, workload, kernel, want, launches_per_step=1, per_step=Fal
         if e is None or e["launches_per_step"] != launches_per_step:
             return None                                   # not profiled, or profiled with another grouping
         return e["hbm_bytes_per_step"] if per_step else e["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+VALU_CYCLES = 4.15        # cycles a SIMD spends on a wave64 instruction of the kinds the kernels are made of (profiles/r05_valu_issue.txt)
+
+
+def read_valu_issue(bases, times_ms, steps):
+    """What the step's main kernels cost in vector instruction issue: SQ_INSTS_VALU of the committed evidence set's counter pass
+    (profiles/<tag>_sq_counters.json: a batch of 200 k x 10 kb; the counts go with the symbols) x 4.15 cycles / (1024 SIMDs x 2.4 GHz),
+    beside the kernels' measured times.  A constant of the tree, like roofline.traffic -- None when the set has no counters."""
+    try:
+        man = json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))
+        sq = json.load(open(os.path.join(ROOT, "profiles", man["files"]["sq_counters.json"])))
+        n0, m0 = (int(x) for x in sq["batch"].split(" x "))
+        scale = bases / float(n0 * m0)
+        out, tot_issue, tot_ms = {}, 0.0, 0.0
+        for dev, bid in (("k_qv_hist", "k_qv_hist"), ("k_qv_sizes_hist", "k_qv_sizes"), ("k_qv_encode_fast", "k_qv_encode")):
+            insts = sq["per_launch"][dev]["SQ_INSTS_VALU"] * scale
+            ms_issue = insts * VALU_CYCLES / (1024 * 2.4e9) * 1e3
+            ms = times_ms.get(bid, (0.0, 0))[0] / steps
+            out[dev] = {"valu_insts_per_step": round(insts), "ms_of_issue": round(ms_issue, 2), "ms_measured": round(ms, 2),
+                        "frac_of_kernel_time": round(ms_issue / ms, 3) if ms else None}
+            tot_issue += ms_issue; tot_ms += ms
+        return {"cycles_per_instruction_and_simd": VALU_CYCLES, "peak_wave64_insts_per_s": round(1024 * 2.4e9 / VALU_CYCLES),
+                "per_kernel": out, "ms_of_issue_per_step": round(tot_issue, 2), "frac_of_the_kernels_time": round(tot_issue / tot_ms, 3) if tot_ms else None,
+                "source": "profiles/" + man["files"]["sq_counters.json"] + " scaled by symbols; issue cost: profiles/r05_valu_issue.txt (tools/microbench/valu_issue.hip)",
+                "note": "the step's kernels are held by vector instruction issue more than by the HBM: the roofline above stays SURVEY 8(d)'s"}
     except Exception:
         return None
 
