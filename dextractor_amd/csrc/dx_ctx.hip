@@ -200,6 +200,7 @@ extern "C" int dx_trim(dx_ctx *ctx, int what)
     { (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info);
       (void) hipFree(ctx->tk.count); (void) hipFree(ctx->tk.eh);
       memset(&ctx->tk, 0, sizeof(ctx->tk));
+          memset(&ctx->qs, 0, sizeof(ctx->qs));
     }
   if (what & DX_TRIM_INDEX)
     { const int want = ctx->sx.want;

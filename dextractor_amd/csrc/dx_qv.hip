@@ -2164,7 +2164,7 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 2) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
   bool brief = false;
-  if ((e = qs_short(ctx, b, &brief))) return e;
+  if ((e = qs_short(ctx, b, true, &brief))) return e;
   if (brief)                                             // short entries: a lane each (dx_qv_short.hpp); no tokens, no counters per entry
     { ctx->tk.valid = 0; ctx->tk.eh_valid = 0;
       DX_LAUNCH(ctx, DX_K_QV_HIST, k_qs_hist, qs_grid(ctx, n), QS_BLOCK, a, entry0, (long long) p->del_first, (long long) p->sub_first,
@@ -2385,7 +2385,7 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 18);
   bool brief = false;
-  if ((e = qs_short(ctx, b, &brief))) return e;
+  if ((e = qs_short(ctx, b, false, &brief))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   if (brief)
     DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
@@ -2422,7 +2422,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   bool brief = false;
-  if ((e = qs_short(ctx, b, &brief))) return e;
+  if ((e = qs_short(ctx, b, false, &brief))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   if (brief && ctx->tok_wide)
     DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, b->n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
@@ -2712,7 +2712,7 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // (k_qv_sizes_hist), every record written where it belongs -- no scratch slots, no compaction.  DEXGPU_SLOTS=1: the
   // slot route below all the same; DEXGPU_DIRECT_ENCODE: sizes by k_qv_sizes_fast (tokens and plain lines read again).
   { bool brief = false;
-    if ((e = qs_short(ctx, b, &brief))) return e;
+    if ((e = qs_short(ctx, b, false, &brief))) return e;
     if (brief)
       { uint64_t t = 0;
         const int rc = onepass_short(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);

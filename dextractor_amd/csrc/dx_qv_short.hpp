@@ -20,10 +20,14 @@
 //   * finished words leave through a ring in LDS sixteen bytes at a time (4-byte stores: 2.8 of the encoder's 7.4 ms);
 //   * the lanes of a wave are at different places in their cache lines: of the byte steps a wave takes 69 % are some lane's
 //     (300-symbol lines; 88 % at 1000).
+//   * a wave takes as long as its longest entry: a workgroup deals the 256 consecutive entries of a round to its lanes in the order of
+//     their lengths (qs_order), and what decides whether a batch is these kernels' is what an entry COSTS them -- the longest entry of
+//     its wave, averaged over the batch (k_qs_survey) -- not the mean length.
 // 4 M x 300: 10.8 ms, 555 GB/s (k_qs_hist 1.9, k_qs_entries<sizes> 2.0, <records> 6.1).  Against the wave-per-entry kernels by
-// mean length (2 M entries, GB/s): 600: 632 / 407, 1000: 689 / 647, 1200: 699 / 735 -- taken for batches of >= 4096 entries whose
-// entries average at most QS_MEAN symbols and are none longer than QS_MAXLEN (a lane is alone with its entry); DEXGPU_NO_SHORT:
-// never.  No tokens, no group index: the decoder reads such a stream with its generic kernel.
+// mean length (2 M entries, GB/s): fixed lengths 600: 632 / 407, 1000: 689 / 647, 1200: 699 / 735; lognormal (sigma 0.35, a wave's
+// longest 1.45 x the mean) 600: 494 / 431, 800: 497 / 533 -- taken for batches of >= 4096 entries that cost at most QS_MEAN symbols
+// an entry and have none longer than QS_MAXLEN (a lane is alone with its entry); DEXGPU_NO_SHORT: never.  No tokens, no group
+// index: the decoder reads such a stream with its generic kernel.
 //
 // Roofline: the vector ALUs, not the HBM: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs accounts for 1.5 of k_qs_hist's 1.9 ms, 2.1 of the
 // sizes' 2.1 and 3.8 of the records' 6.1 (the rest of those: waits for the look-ups and for the next cache line, 4 waves a SIMD).
@@ -41,7 +45,10 @@
 //                ^                    // 16-byte chunks a lane asks for at a time: one cache line of its line, whole and aligned (its neighbours'
                                         // lines are 1.5 KB away: a lane's requests share nothing with theirs, and a cache line asked for in two goes
                                         // is fetched twice -- 28 waves x 64 lanes x 128 bytes a CU outlive neither the 32 KB L1 nor a share of the L2)
-#define QS_MAXLEN 4096u                 // ... and no entry longer than this (a lane is alone with its entry)
+#ifndef QS_MAXLEN
+#define QS_MAXLEN 4096u
+#endif
+//                    ^                // ... and no entry longer than this (a lane is alone with its entry)
 
 
 typedef __attribute__((address_space(3))) uint32_t qs_lds;        // (the tables and counters of a workgroup)
@@ -115,16 +122,57 @@ __device__ __forceinline__ qs_span qs_fetch(const uint8_t *p, uint32_t pos, uint
 #define QS_BYTE(v, b)      ((((b) < 4 ? (v).x : (v).y) >> (8 * ((b) & 3))) & 0xffu)
 #define QS_LIVE(s, k, b)   ((uint32_t) (8 * (k) + (b)) - (s).skip < (s).len)
 
-__global__ __launch_bounds__(256)
-void k_qs_maxlen(const uint32_t *len, uint64_t n, uint32_t *out)
-{ uint32_t m = 0;
-  for (uint64_t i = (uint64_t) blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t) gridDim.x * 256u)
-    m = len[i] > m ? len[i] : m;
-  for (int d = 32; d >= 1; d >>= 1)
-    { const uint32_t o = (uint32_t) __shfl_xor((int) m, d);
-      m = o > m ? o : m;
+// The 64 lanes of a wave go through their entries in step: a wave takes as long as its longest entry.  A workgroup therefore deals the
+// QS_BLOCK consecutive entries of a round to its lanes in the order of their lengths (a bitonic sort of length << 8 | place in LDS:
+// 36 exchanges a round, against ~1e5 instructions an entry): a wave's 64 entries are then of a length (lognormal lengths: of the byte
+// steps a wave took half were some lane's), and they are still neighbours in the file -- dealing the whole batch's entries by length
+// and alignment costs the cache lines two entries share and the DRAM rows more than it gains (profiles/r05_short_entries.txt).
+// Returns the entry's place in the round (0xffffffff: the round has fewer entries).  Entries of one length keep the file's order.
+__device__ __forceinline__ uint32_t qs_order(qs_lds *s_key /* [QS_BLOCK] */, const uint32_t *len, uint64_t base, uint64_t n)
+{ static_assert(QS_BLOCK <= 256, "qs_order: the place in the round has 8 bits");
+  const uint32_t t = threadIdx.x;
+  const uint32_t mine = base + t < n ? len[base + t] : 0xffffffffu;
+  if (!__syncthreads_or((int) (mine != 0xffffffffu && mine != len[base])))     // (a round of one length: as it comes)
+    return mine == 0xffffffffu ? mine : t;
+  s_key[t] = mine == 0xffffffffu ? mine : (mine << 8) | t;
+  __syncthreads();
+  for (uint32_t k = 2; k <= QS_BLOCK; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1)
+      { const uint32_t p = t ^ j;
+        if (p > t)
+          { const uint32_t x = s_key[t], y = s_key[p];
+            if ((x > y) == ((t & k) == 0u)) { s_key[t] = y; s_key[p] = x; }
+          }
+        __syncthreads();
+      }
+  const uint32_t key = s_key[t];
+  __syncthreads();                                         // (the next round writes the keys again)
+  return key == 0xffffffffu ? key : key & 0xffu;
+}
+
+// what the batch would cost these kernels: work[0] = its longest entry, work[2..3] = the sum over the waves of the wave's longest
+// entry (a wave's 64 lanes go through their entries in step; qs_order has dealt them): x 64 / n it is the length an entry costs.
+// every: the rounds that are sorted for it (one in `every`, their sums counted `every` times: an estimate, 0.5 ms less for 4 M entries)
+__global__ __launch_bounds__(QS_BLOCK)
+void k_qs_survey(const uint32_t *len, uint64_t n, uint32_t every, uint32_t *work)
+{ __shared__ uint32_t s_key[QS_BLOCK];
+  const uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK;
+  if (blockIdx.x % every != 0u)                            // (uniform) the longest entry only
+    { uint32_t m = base + threadIdx.x < n ? len[base + threadIdx.x] : 0u;
+      for (int d = 32; d >= 1; d >>= 1)
+        { const uint32_t o = (uint32_t) __shfl_xor((int) m, d);
+          m = o > m ? o : m;
+        }
+      if (lane_id() == 0 && m > __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))   // (62 500 atomics on one word are 0.6 ms)
+        atomicMax(work, m);
+      return;
     }
-  if (lane_id() == 0 && m) atomicMax(out, m);
+  const uint32_t place = qs_order(QS_LDS(s_key), len, base, n);
+  const uint32_t L = place == 0xffffffffu ? 0u : len[base + place];
+  if ((threadIdx.x & 63u) == 63u || base + threadIdx.x + 1 == n)     // the last lane of a wave that has entries holds its longest
+    atomicAdd((unsigned long long *) (work + 2), (unsigned long long) L * every);
+  if ((threadIdx.x == QS_BLOCK - 1u || base + threadIdx.x + 1 == n) && L > __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(work, L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -161,15 +209,20 @@ __device__ __forceinline__ void qs_count_runs(const uint8_t *p, uint32_t L, cons
 }
 
 __global__ __launch_bounds__(QS_BLOCK)
-void k_qs_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first, unsigned long long *hist, unsigned long long *tot)
+void k_qs_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first, unsigned long long *hist,
+               unsigned long long *tot)
 { __shared__ uint32_t s_h[6][256][QS_COPIES];             // 24 KB
+  __shared__ uint32_t s_key[QS_BLOCK];
   for (uint32_t i = threadIdx.x; i < 6u * 256u * QS_COPIES; i += QS_BLOCK) (&s_h[0][0][0])[i] = 0u;
   __syncthreads();
   const uint32_t cp = threadIdx.x & (QS_COPIES - 1u);
   #define H(s) (QS_LDS(&s_h[s][0][0]) + cp)
   uint64_t chars = 0;
-  for (uint64_t r = (uint64_t) blockIdx.x * QS_BLOCK + threadIdx.x; r < a.n; r += (uint64_t) gridDim.x * QS_BLOCK)
-    { const uint32_t L = a.len[r];
+  for (uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK; base < a.n; base += (uint64_t) gridDim.x * QS_BLOCK)
+    { const uint32_t place = qs_order(QS_LDS(s_key), a.len, base, a.n);
+      if (place == 0xffffffffu) continue;
+      const uint64_t r = base + place;
+      const uint32_t L = a.len[r];
       const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2), *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
       const uint8_t *end16 = a.text + a.text_bytes - 16u;    // (text_bytes known and large: qs_short)
       chars += L;
@@ -407,7 +460,7 @@ __device__ __forceinline__ void qs_tags_all(const uint8_t *ptag, uint32_t L, con
 #ifdef QS_OCC
 #define QS_WAVES __attribute__((amdgpu_waves_per_eu(QS_OCC)))
 #else
-#define QS_WAVES
+#define QS_WAVES __attribute__((amdgpu_waves_per_eu(EMIT ? 4 : 5)))     // (the sizes at 99 registers would lose their fifth wave a SIMD)
 #endif
 template <bool EMIT, bool WIDE>
 __global__ __launch_bounds__(QS_BLOCK) QS_WAVES
@@ -415,12 +468,16 @@ void k_qs_entries(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const ui
                   uint32_t *seg, uint32_t *rec_size, uint8_t *out, uint32_t *status)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_ring[EMIT ? QS_RING : 1u][QS_BLOCK];
+  __shared__ uint32_t s_key[QS_BLOCK];
   load_tables(s_tok, g_tok);
   qs_lds *ring = QS_LDS(&s_ring[0][threadIdx.x]);
   const uint32_t imask = a.lossy ? 0xfefefefeu : ~0u, mmask = a.lossy ? 0xfcfcfcfcu : ~0u;
   uint32_t differ = 0;
-  for (uint64_t r = (uint64_t) blockIdx.x * QS_BLOCK + threadIdx.x; r < a.n; r += (uint64_t) gridDim.x * QS_BLOCK)
-    { const uint32_t L = a.len[r];
+  for (uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK; base < a.n; base += (uint64_t) gridDim.x * QS_BLOCK)
+    { const uint32_t place = qs_order(QS_LDS(s_key), a.len, base, a.n);
+      if (place == 0xffffffffu) continue;
+      const uint64_t r = base + place;
+      const uint32_t L = a.len[r];
       const uint8_t *p0 = line_ptr(a, r, L, 0), *p1 = line_ptr(a, r, L, 1), *p2 = line_ptr(a, r, L, 2);
       const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
       const uint8_t *end16 = a.text + a.text_bytes - 16u;    // (text_bytes known and large: qs_short)
@@ -472,19 +529,35 @@ static int qs_grid(const dx_ctx *ctx, uint64_t n)
   return (int) (need < room ? need : room);
 }
 
-// is this a batch for the lane-per-entry kernels?  Mean length from the image's size, the longest entry from the device.
-// (decided anew by every call from the same inputs: dx_qv_hist, dx_qv_sizes, dx_qv_encode and the one-pass encoder agree)
-static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool *yes)
+// Is this a batch for the lane-per-entry kernels?  What an entry costs them is the length of the longest entry of its wave
+// (k_qs_survey): a batch is theirs when that, averaged over the entries, is at most QS_MEAN -- fixed lengths: the mean itself,
+// 1100 symbols being where the wave-per-entry kernels take over; lognormal lengths (sigma 0.35): 1.45 x the mean, and measured
+// (2 M entries, GB/s with / without): mean 600: 493 / 431, mean 800: 497 / 533 -- and no entry is longer than QS_MAXLEN (a lane
+// takes ~2.4 us a symbol through the three kernels: one entry of 4096 is 10 ms of one lane).
+// fresh (dx_qv_hist, the first to see a batch): looked at anew; the others take what the context remembers of a batch of these
+// arrays and sizes -- were the arrays' contents changed in between, the verdict is the old contents': slow at worst, not wrong.
+static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, bool *yes)
 { *yes = false;
   const char *off = getenv("DEXGPU_NO_SHORT");
   if ((off != NULL && off[0] != '\0' && off[0] != '0') || b->n < 4096 || b->text_bytes == 0) return DX_OK;
   if (b->text_bytes / b->n > 5ull * (QS_MEAN + 1u) + 64u) return DX_OK;
-  uint32_t *d_max = (uint32_t *) (ctx->d_u64 + 40), longest = 0;
-  DX_HIP(ctx, hipMemsetAsync(d_max, 0, 4, ctx->stream));
-  hipLaunchKernelGGL(k_qs_maxlen, dim3((unsigned) ctx->num_cu * 4u), dim3(256), 0, ctx->stream, (const uint32_t *) b->d_len, b->n, d_max);
-  DX_HIP(ctx, hipMemcpyAsync(&longest, d_max, 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (!fresh && ctx->qs.valid && ctx->qs.off == (const void *) b->d_off && ctx->qs.len == (const void *) b->d_len && ctx->qs.n == b->n &&
+      ctx->qs.text_bytes == b->text_bytes)
+    { *yes = ctx->qs.brief != 0;
+      return DX_OK;
+    }
+  uint32_t *d_work = (uint32_t *) (ctx->d_u64 + 40);
+  uint32_t  work[4] = { 0u, 0u, 0u, 0u };
+  DX_HIP(ctx, hipMemsetAsync(d_work, 0, 16, ctx->stream));
+  const uint64_t nblk = (b->n + QS_BLOCK - 1) / QS_BLOCK;
+  hipLaunchKernelGGL(k_qs_survey, dim3((unsigned) nblk), dim3(QS_BLOCK), 0, ctx->stream, (const uint32_t *) b->d_len, b->n, nblk >= 1024 ? 16u : 1u, d_work);
+  DX_HIP(ctx, hipMemcpyAsync(work, d_work, 16, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  *yes = longest <= QS_MAXLEN;
+  const uint64_t cost = ((uint64_t) work[3] << 32) | work[2];
+  *yes = work[0] <= QS_MAXLEN && 64u * cost <= (uint64_t) QS_MEAN * b->n;
+  ctx->qs.off = b->d_off; ctx->qs.len = b->d_len; ctx->qs.n = b->n; ctx->qs.text_bytes = b->text_bytes;
+  ctx->qs.brief = *yes ? 1 : 0;
+  ctx->qs.valid = 1;
   return DX_OK;
 }
 

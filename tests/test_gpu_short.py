@@ -1,6 +1,7 @@
 """Batches of SHORT entries: the lane-per-entry kernels of dx_qv_short.hpp (k_qs_hist, k_qs_entries) against the oracle.
 
-They are taken for batches of >= 4096 entries that average at most 1000 symbols with none longer than 4096; every case here checks
+They are taken for batches of >= 4096 entries none of which is longer than 4096 symbols when the length of the longest entry of a wave,
+averaged over the entries, is at most 1000 (fixed lengths: the mean; lognormal lengths: about 1.45 x the mean); every case here checks
 that it took them (dx_qv_onepass_info: direct == 3) -- or, where the case is about NOT taking them, that it did not.  Bar: bit-exact."""
 import numpy as np
 import pytest
@@ -33,7 +34,7 @@ def _quiva(lines_of, n, movie=b"m7"):
 
 
 @pytest.mark.parametrize("lossy", [0, 1])
-@pytest.mark.parametrize("seed,n,mean", [(1, 5000, 120), (2, 4500, 900), (3, 20000, 300)])
+@pytest.mark.parametrize("seed,n,mean", [(1, 5000, 120), (2, 4500, 500), (3, 20000, 300)])
 def test_short_dexqv_vs_oracle(ctx, seed, n, mean, lossy):
     c = synth.make_quiva(n, seed=seed, mean=mean)
     if int(c.len.max()) > 4096:                       # (the lognormal tail: clipped so that the batch qualifies)
@@ -165,11 +166,15 @@ def test_long_entry_or_few_entries_keep_the_wave_per_entry_kernels(ctx, monkeypa
     assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
     c = synth.make_quiva(300, seed=4, dist="fixed", mean=150)
     assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
+    c = synth.make_quiva(4500, seed=2, mean=900)           # lognormal: a wave's longest entry is 1.45 x the mean -- more than 1000
+    c = synth.make_quiva(4500, seed=2, lens=np.minimum(c.len, 4096).astype(np.uint32))
+    assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
 
 
 def test_mixed_lengths_1_to_20000(ctx):
     """a batch of entries of 1 ... 20 000 symbols, most of them short (the wave-per-entry kernels: an entry is longer than a lane
-    takes), and the same batch with the long ones cut down to 4096 (the lane-per-entry kernels): both against the oracle"""
+    takes), the same batch with the long ones cut down to 4096 (still theirs: a wave's longest entry sets what its 64 cost) and to 1500
+    (the lane-per-entry kernels): all against the oracle"""
     rng = np.random.Generator(np.random.PCG64(20))
     lens = np.concatenate([rng.integers(1, 400, 4000), rng.integers(400, 3000, 700), rng.integers(3000, 20001, 60),
                            [1, 2, 3, 15, 16, 17, 20000]]).astype(np.uint32)
@@ -177,6 +182,8 @@ def test_mixed_lengths_1_to_20000(ctx):
     c = synth.make_quiva(len(lens), seed=21, lens=lens)
     assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
     c = synth.make_quiva(len(lens), seed=21, lens=np.minimum(lens, 4096).astype(np.uint32))
+    assert ctx.dexqv(c.text) == O.dexqv(c.text)
+    c = synth.make_quiva(len(lens), seed=21, lens=np.minimum(lens, 1500).astype(np.uint32))
     want = O.dexqv(c.text)
     assert ctx.dexqv(c.text) == want and _took_short(ctx)
     assert ctx.undexqv(want, upper=True) == O.undexqv(want, upper=True)
