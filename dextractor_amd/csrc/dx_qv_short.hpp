@@ -460,7 +460,7 @@ __device__ __forceinline__ void qs_tags_all(const uint8_t *ptag, uint32_t L, con
 #ifdef QS_OCC
 #define QS_WAVES __attribute__((amdgpu_waves_per_eu(QS_OCC)))
 #else
-#define QS_WAVES __attribute__((amdgpu_waves_per_eu(EMIT ? 4 : 5)))     // (the sizes at 99 registers would lose their fifth wave a SIMD)
+#define QS_WAVES
 #endif
 template <bool EMIT, bool WIDE>
 __global__ __launch_bounds__(QS_BLOCK) QS_WAVES
@@ -478,11 +478,14 @@ void k_qs_entries(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const ui
       if (place == 0xffffffffu) continue;
       const uint64_t r = base + place;
       const uint32_t L = a.len[r];
-      const uint8_t *p0 = line_ptr(a, r, L, 0), *p1 = line_ptr(a, r, L, 1), *p2 = line_ptr(a, r, L, 2);
-      const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
+      const uint8_t *p0 = line_ptr(a, r, L, 0);              // (the other lines' addresses where they are wanted: five pointers held are ten registers)
+#define p1 (p0 + ((uint64_t) L + a.pad))
+#define p2 (p0 + 2u * ((uint64_t) L + a.pad))
+#define p3 (p0 + 3u * ((uint64_t) L + a.pad))
+#define p4 (p0 + 4u * ((uint64_t) L + a.pad))
       const uint8_t *end16 = a.text + a.text_bytes - 16u;    // (text_bytes known and large: qs_short)
       const uint32_t hl = hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u;
-      uint32_t sg[5] = { 0u, 0u, 0u, 0u, 0u }, want[5] = { 0u, 0u, 0u, 0u, 0u }, clen = L;
+      uint32_t want[5] = { 0u, 0u, 0u, 0u, 0u }, clen = L;
       uint8_t *dst = out;
       if (EMIT)
         { dst = out + rec_off[r];
@@ -500,24 +503,27 @@ void k_qs_entries(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const ui
         { q = qs_plain<EMIT, WIDE>(p0, L, a.text, end16, QS_LDS(s_tok[DX_DEL]), ~0u, d0, ring);
           if (EMIT) qs_tags_all(p1, L, a.text, end16, d1);
         }
-      sg[0] = q.bytes;
-      sg[1] = (clen + 3u) >> 2;
+      // a size is noted (sizes) or compared (records) as soon as it is known: five of them held to the entry's end are five registers
+      uint32_t sum = hl;
+#define QS_SEG(k, v) { const uint32_t v_ = (v); if (EMIT) differ |= v_ ^ want[k]; else { seg[5 * r + (k)] = v_; sum += v_; } }
+      QS_SEG(0, q.bytes)
+      QS_SEG(1, (clen + 3u) >> 2)
       q = qs_plain<EMIT, WIDE>(p2, L, a.text, end16, QS_LDS(s_tok[DX_INS]), imask, d2, ring);
-      sg[2] = q.bytes;
+      QS_SEG(2, q.bytes)
       q = qs_plain<EMIT, WIDE>(p3, L, a.text, end16, QS_LDS(s_tok[DX_MRG]), mmask, d3, ring);
-      sg[3] = q.bytes;
+      QS_SEG(3, q.bytes)
       if (a.subChar >= 0)
         q = qs_runs<EMIT, false>(p4, p4, L, a.text, end16, QS_LDS(s_tok[DX_SUB]), QS_LDS(s_tok[DX_SRUN]), (uint32_t) a.subChar & 0xffu, d4, d4, ring);
       else
         q = qs_plain<EMIT, WIDE>(p4, L, a.text, end16, QS_LDS(s_tok[DX_SUB]), ~0u, d4, ring);
-      sg[4] = q.bytes;
-      if (EMIT)
-        { if (sg[0] != want[0] || sg[1] != want[1] || sg[2] != want[2] || sg[3] != want[3] || sg[4] != want[4]) differ = 1u; }
-      else
-        { seg[5 * r] = sg[0]; seg[5 * r + 1] = sg[1]; seg[5 * r + 2] = sg[2]; seg[5 * r + 3] = sg[3]; seg[5 * r + 4] = sg[4];
-          rec_size[r] = hl + sg[0] + sg[1] + sg[2] + sg[3] + sg[4];
-        }
+      QS_SEG(4, q.bytes)
+#undef QS_SEG
+      if (!EMIT) rec_size[r] = sum;
     }
+#undef p1
+#undef p2
+#undef p3
+#undef p4
   if (differ) atomicOr(status, 2u);
 }
 
