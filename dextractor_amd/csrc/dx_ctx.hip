@@ -166,6 +166,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   if (ctx->h_down) (void) hipHostFree(ctx->h_down);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipFree(ctx->tk.eh);
+  (void) hipFree(ctx->qs.perm);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
   for (int k = 0; k < 19; k++) (void) hipEventDestroy(ctx->ev[k]);

@@ -45,10 +45,11 @@ struct dx_ctx
   int       delChar, subChar;
   uint32_t  bps[4];            // upper bound of encoded bits per symbol of del/ins/mrg/sub (dx_qv_encode_onepass)
   int       tok_wide;          // a symbol token of more than 16 bits in the tables (k_qs_entries: one code at a time then)
-  struct                       // batches of short entries (dx_qv_short.hpp): the verdict on the last batch looked at
-    { uint64_t  n, text_bytes;
+  struct                       // batches of short entries (dx_qv_short.hpp): the verdict on the last batch looked at, and every entry's place
+    { uint8_t  *perm;          // among the 256 of its round when they are taken by length (k_qs_survey; NULL while none was wanted)
+      uint64_t  cap, n, text_bytes;
       const void *off, *len;
-      int       valid, brief;
+      int       valid, brief, ordered;
     } qs;
   uint32_t  pair_lo[2];        // ins, mrg: lowest coded byte value when the coded values span <= 64 (pair tables), else ~0
   int       onepass_min_groups;// dx_qv_encode_onepass: fewest groups whose scratch regions have fitted the device so far

@@ -2164,10 +2164,11 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 2) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
   bool brief = false;
-  if ((e = qs_short(ctx, b, true, &brief))) return e;
+  const uint8_t *perm = NULL;
+  if ((e = qs_short(ctx, b, true, &brief, &perm))) return e;
   if (brief)                                             // short entries: a lane each (dx_qv_short.hpp); no tokens, no counters per entry
     { ctx->tk.valid = 0; ctx->tk.eh_valid = 0;
-      DX_LAUNCH(ctx, DX_K_QV_HIST, k_qs_hist, qs_grid(ctx, n), QS_BLOCK, a, entry0, (long long) p->del_first, (long long) p->sub_first,
+      DX_LAUNCH(ctx, DX_K_QV_HIST, k_qs_hist, qs_grid(ctx, n), QS_BLOCK, a, perm, entry0, (long long) p->del_first, (long long) p->sub_first,
                 d_hist, d_hist + 6 * 256);
       uint64_t host[6 * 256 + 1];
       DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
@@ -2385,10 +2386,11 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 18);
   bool brief = false;
-  if ((e = qs_short(ctx, b, false, &brief))) return e;
+  const uint8_t *perm = NULL;
+  if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   if (brief)
-    DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
+    DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
               (const uint64_t *) NULL, d_seg, d_size, (uint8_t *) NULL, ctx->d_status);
   else
   DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, n, 4 * SIZES_WAVES), DX_BLOCK,
@@ -2422,13 +2424,14 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
   bool brief = false;
-  if ((e = qs_short(ctx, b, false, &brief))) return e;
+  const uint8_t *perm = NULL;
+  if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   if (brief && ctx->tok_wide)
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, b->n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, b->n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
               d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
   else if (brief)
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, b->n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, b->n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
               d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
   else
   DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
@@ -2712,10 +2715,11 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // (k_qv_sizes_hist), every record written where it belongs -- no scratch slots, no compaction.  DEXGPU_SLOTS=1: the
   // slot route below all the same; DEXGPU_DIRECT_ENCODE: sizes by k_qv_sizes_fast (tokens and plain lines read again).
   { bool brief = false;
-    if ((e = qs_short(ctx, b, false, &brief))) return e;
+    const uint8_t *perm = NULL;
+  if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
     if (brief)
       { uint64_t t = 0;
-        const int rc = onepass_short(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
+        const int rc = onepass_short(ctx, b, perm, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
         if (total) *total = t;
         if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }   // (this route does not pipeline)
         return rc;

@@ -20,9 +20,9 @@
 //   * finished words leave through a ring in LDS sixteen bytes at a time (4-byte stores: 2.8 of the encoder's 7.4 ms);
 //   * the lanes of a wave are at different places in their cache lines: of the byte steps a wave takes 69 % are some lane's
 //     (300-symbol lines; 88 % at 1000).
-//   * a wave takes as long as its longest entry: a workgroup deals the 256 consecutive entries of a round to its lanes in the order of
-//     their lengths (qs_order), and what decides whether a batch is these kernels' is what an entry COSTS them -- the longest entry of
-//     its wave, averaged over the batch (k_qs_survey) -- not the mean length.
+//   * a wave takes as long as its longest entry: the 256 consecutive entries of a round are dealt to a workgroup's lanes in the order
+//     of their lengths (k_qs_survey sorts once a batch and leaves a byte an entry), and what decides whether a batch is these kernels'
+//     is what an entry COSTS them -- the longest entry of its wave, averaged over the batch -- not the mean length.
 // 4 M x 300: 10.8 ms, 555 GB/s (k_qs_hist 1.9, k_qs_entries<sizes> 2.0, <records> 6.1).  Against the wave-per-entry kernels by
 // mean length (2 M entries, GB/s): fixed lengths 600: 632 / 407, 1000: 689 / 647, 1200: 699 / 735; lognormal (sigma 0.35, a wave's
 // longest 1.45 x the mean) 600: 494 / 431, 800: 497 / 533 -- taken for batches of >= 4096 entries that cost at most QS_MEAN symbols
@@ -122,12 +122,12 @@ __device__ __forceinline__ qs_span qs_fetch(const uint8_t *p, uint32_t pos, uint
 #define QS_BYTE(v, b)      ((((b) < 4 ? (v).x : (v).y) >> (8 * ((b) & 3))) & 0xffu)
 #define QS_LIVE(s, k, b)   ((uint32_t) (8 * (k) + (b)) - (s).skip < (s).len)
 
-// The 64 lanes of a wave go through their entries in step: a wave takes as long as its longest entry.  A workgroup therefore deals the
-// QS_BLOCK consecutive entries of a round to its lanes in the order of their lengths (a bitonic sort of length << 8 | place in LDS:
-// 36 exchanges a round, against ~1e5 instructions an entry): a wave's 64 entries are then of a length (lognormal lengths: of the byte
-// steps a wave took half were some lane's), and they are still neighbours in the file -- dealing the whole batch's entries by length
-// and alignment costs the cache lines two entries share and the DRAM rows more than it gains (profiles/r05_short_entries.txt).
-// Returns the entry's place in the round (0xffffffff: the round has fewer entries).  Entries of one length keep the file's order.
+// The 64 lanes of a wave go through their entries in step: a wave takes as long as its longest entry.  The QS_BLOCK consecutive entries
+// of a round are therefore dealt to a workgroup's lanes in the order of their lengths (a bitonic sort of length << 8 | place in LDS, once
+// a batch: k_qs_survey leaves every entry's place, a byte, for the three kernels): a wave's 64 entries are then of a length (lognormal
+// lengths, 2 M x 800: 450 -> 497 GB/s), and they are still neighbours in the file -- dealing the whole batch's entries by length and
+// alignment costs the cache lines two entries share and the DRAM rows more than it gains (profiles/r05_short_entries.txt).
+// Returns this thread's entry's place in the round (0xffffffff: the round has fewer entries); a round of one length: as it comes.
 __device__ __forceinline__ uint32_t qs_order(qs_lds *s_key /* [QS_BLOCK] */, const uint32_t *len, uint64_t base, uint64_t n)
 { static_assert(QS_BLOCK <= 256, "qs_order: the place in the round has 8 bits");
   const uint32_t t = threadIdx.x;
@@ -150,29 +150,24 @@ __device__ __forceinline__ uint32_t qs_order(qs_lds *s_key /* [QS_BLOCK] */, con
   return key == 0xffffffffu ? key : key & 0xffu;
 }
 
-// what the batch would cost these kernels: work[0] = its longest entry, work[2..3] = the sum over the waves of the wave's longest
-// entry (a wave's 64 lanes go through their entries in step; qs_order has dealt them): x 64 / n it is the length an entry costs.
-// every: the rounds that are sorted for it (one in `every`, their sums counted `every` times: an estimate, 0.5 ms less for 4 M entries)
+// Every entry's place among the QS_BLOCK of its round when they are taken by length (perm, a byte an entry: the three kernels read it
+// instead of sorting again -- and without the sort's code they keep the registers of their fifth wave a SIMD), and what the batch
+// would cost these kernels: work[0] = its longest entry, work[1] = its shortest, work[2..3] = the sum over the waves of the wave's
+// longest entry (a wave's 64 lanes go through their entries in step): x 64 / n it is the length an entry costs.
 __global__ __launch_bounds__(QS_BLOCK)
-void k_qs_survey(const uint32_t *len, uint64_t n, uint32_t every, uint32_t *work)
+void k_qs_survey(const uint32_t *len, uint64_t n, uint8_t *perm, uint32_t every /* one round in `every` counts for the sum, `every` times */, uint32_t *work)
 { __shared__ uint32_t s_key[QS_BLOCK];
   const uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK;
-  if (blockIdx.x % every != 0u)                            // (uniform) the longest entry only
-    { uint32_t m = base + threadIdx.x < n ? len[base + threadIdx.x] : 0u;
-      for (int d = 32; d >= 1; d >>= 1)
-        { const uint32_t o = (uint32_t) __shfl_xor((int) m, d);
-          m = o > m ? o : m;
-        }
-      if (lane_id() == 0 && m > __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))   // (62 500 atomics on one word are 0.6 ms)
-        atomicMax(work, m);
-      return;
-    }
-  const uint32_t place = qs_order(QS_LDS(s_key), len, base, n);
-  const uint32_t L = place == 0xffffffffu ? 0u : len[base + place];
-  if ((threadIdx.x & 63u) == 63u || base + threadIdx.x + 1 == n)     // the last lane of a wave that has entries holds its longest
-    atomicAdd((unsigned long long *) (work + 2), (unsigned long long) L * every);
+  const uint32_t place = qs_order(QS_LDS(s_key), len, base, n);      // (the t-th shortest of the round is this thread's)
+  const bool     have  = place != 0xffffffffu;
+  const uint32_t L = have ? len[base + place] : 0u;
+  if (have) perm[base + threadIdx.x] = (uint8_t) place;
+  if (blockIdx.x % every == 0u && ((threadIdx.x & 63u) == 63u || base + threadIdx.x + 1 == n))     // the last lane of a wave that has entries holds its longest
+    atomicAdd((unsigned long long *) (work + 2), (unsigned long long) L * every);      // (62 500 atomics on one word are 0.6 ms: an estimate from a sixteenth)
   if ((threadIdx.x == QS_BLOCK - 1u || base + threadIdx.x + 1 == n) && L > __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    atomicMax(work, L);
+    atomicMax(work, L);                                    // (checked first: 15 625 atomics on one word are 0.15 ms)
+  if (threadIdx.x == 0u && L < __hip_atomic_load(work + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMin(work + 1, L);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -209,7 +204,7 @@ __device__ __forceinline__ void qs_count_runs(const uint8_t *p, uint32_t L, cons
 }
 
 __global__ __launch_bounds__(QS_BLOCK)
-void k_qs_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first, unsigned long long *hist,
+void k_qs_hist(qv_args a, const uint8_t *perm, uint64_t entry0, long long del_first, long long sub_first, unsigned long long *hist,
                unsigned long long *tot)
 { __shared__ uint32_t s_h[6][256][QS_COPIES];             // 24 KB
   __shared__ uint32_t s_key[QS_BLOCK];
@@ -219,9 +214,8 @@ void k_qs_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   #define H(s) (QS_LDS(&s_h[s][0][0]) + cp)
   uint64_t chars = 0;
   for (uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK; base < a.n; base += (uint64_t) gridDim.x * QS_BLOCK)
-    { const uint32_t place = qs_order(QS_LDS(s_key), a.len, base, a.n);
-      if (place == 0xffffffffu) continue;
-      const uint64_t r = base + place;
+    { if (base + threadIdx.x >= a.n) continue;
+      const uint64_t r = base + (perm ? (uint32_t) perm[base + threadIdx.x] : threadIdx.x);   // (by length within the round: k_qs_survey)
       const uint32_t L = a.len[r];
       const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2), *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
       const uint8_t *end16 = a.text + a.text_bytes - 16u;    // (text_bytes known and large: qs_short)
@@ -464,19 +458,17 @@ __device__ __forceinline__ void qs_tags_all(const uint8_t *ptag, uint32_t L, con
 #endif
 template <bool EMIT, bool WIDE>
 __global__ __launch_bounds__(QS_BLOCK) QS_WAVES
-void k_qs_entries(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off, const uint64_t *rec_off,
+void k_qs_entries(qv_args a, const uint8_t *perm, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off, const uint64_t *rec_off,
                   uint32_t *seg, uint32_t *rec_size, uint8_t *out, uint32_t *status)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_ring[EMIT ? QS_RING : 1u][QS_BLOCK];
-  __shared__ uint32_t s_key[QS_BLOCK];
   load_tables(s_tok, g_tok);
   qs_lds *ring = QS_LDS(&s_ring[0][threadIdx.x]);
   const uint32_t imask = a.lossy ? 0xfefefefeu : ~0u, mmask = a.lossy ? 0xfcfcfcfcu : ~0u;
   uint32_t differ = 0;
   for (uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK; base < a.n; base += (uint64_t) gridDim.x * QS_BLOCK)
-    { const uint32_t place = qs_order(QS_LDS(s_key), a.len, base, a.n);
-      if (place == 0xffffffffu) continue;
-      const uint64_t r = base + place;
+    { if (base + threadIdx.x >= a.n) continue;
+      const uint64_t r = base + (perm ? (uint32_t) perm[base + threadIdx.x] : threadIdx.x);   // (by length within the round: k_qs_survey)
       const uint32_t L = a.len[r];
       const uint8_t *p0 = line_ptr(a, r, L, 0);              // (the other lines' addresses where they are wanted: five pointers held are ten registers)
 #define p1 (p0 + ((uint64_t) L + a.pad))
@@ -542,25 +534,38 @@ static int qs_grid(const dx_ctx *ctx, uint64_t n)
 // takes ~2.4 us a symbol through the three kernels: one entry of 4096 is 10 ms of one lane).
 // fresh (dx_qv_hist, the first to see a batch): looked at anew; the others take what the context remembers of a batch of these
 // arrays and sizes -- were the arrays' contents changed in between, the verdict is the old contents': slow at worst, not wrong.
-static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, bool *yes)
-{ *yes = false;
+static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, bool *yes, const uint8_t **perm)
+{ *yes = false; *perm = NULL;
   const char *off = getenv("DEXGPU_NO_SHORT");
   if ((off != NULL && off[0] != '\0' && off[0] != '0') || b->n < 4096 || b->text_bytes == 0) return DX_OK;
   if (b->text_bytes / b->n > 5ull * (QS_MEAN + 1u) + 64u) return DX_OK;
   if (!fresh && ctx->qs.valid && ctx->qs.off == (const void *) b->d_off && ctx->qs.len == (const void *) b->d_len && ctx->qs.n == b->n &&
       ctx->qs.text_bytes == b->text_bytes)
-    { *yes = ctx->qs.brief != 0;
+    { *yes = ctx->qs.brief != 0; *perm = *yes && ctx->qs.ordered ? ctx->qs.perm : NULL;
       return DX_OK;
     }
+  ctx->qs.valid = 0;
+  if (ctx->qs.cap < b->n)
+    { (void) hipFree(ctx->qs.perm);
+      ctx->qs.perm = NULL; ctx->qs.cap = 0;
+      if (hipMalloc((void **) &ctx->qs.perm, b->n + 256) != hipSuccess)
+        { (void) hipGetLastError();
+          return DX_OK;                                    // (no memory for a byte an entry: the wave-per-entry kernels)
+        }
+      ctx->qs.cap = b->n;
+    }
   uint32_t *d_work = (uint32_t *) (ctx->d_u64 + 40);
-  uint32_t  work[4] = { 0u, 0u, 0u, 0u };
-  DX_HIP(ctx, hipMemsetAsync(d_work, 0, 16, ctx->stream));
+  uint32_t  work[4] = { 0u, 0xffffffffu, 0u, 0u };
+  DX_HIP(ctx, hipMemcpyAsync(d_work, work, 16, hipMemcpyHostToDevice, ctx->stream));
   const uint64_t nblk = (b->n + QS_BLOCK - 1) / QS_BLOCK;
-  hipLaunchKernelGGL(k_qs_survey, dim3((unsigned) nblk), dim3(QS_BLOCK), 0, ctx->stream, (const uint32_t *) b->d_len, b->n, nblk >= 1024 ? 16u : 1u, d_work);
+  hipLaunchKernelGGL(k_qs_survey, dim3((unsigned) nblk), dim3(QS_BLOCK), 0, ctx->stream, (const uint32_t *) b->d_len, b->n,
+                     ctx->qs.perm, nblk >= 1024 ? 16u : 1u, d_work);
   DX_HIP(ctx, hipMemcpyAsync(work, d_work, 16, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint64_t cost = ((uint64_t) work[3] << 32) | work[2];
   *yes = work[0] <= QS_MAXLEN && 64u * cost <= (uint64_t) QS_MEAN * b->n;
+  ctx->qs.ordered = work[0] != work[1] && getenv("DEXGPU_SHORT_FILE_ORDER") == NULL;      // (entries of one length: as they come)
+  *perm = *yes && ctx->qs.ordered ? ctx->qs.perm : NULL;
   ctx->qs.off = b->d_off; ctx->qs.len = b->d_len; ctx->qs.n = b->n; ctx->qs.text_bytes = b->text_bytes;
   ctx->qs.brief = *yes ? 1 : 0;
   ctx->qs.valid = 1;
@@ -568,7 +573,7 @@ static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, bool *yes)
 }
 
 // sizes, offsets, records: dx_qv_encode_onepass's contract
-static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *perm, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total)
 { const uint64_t n = b->n;
   int e;
@@ -579,7 +584,7 @@ static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr
   ctx->sx.valid = 0;                                     // (these kernels leave no group index)
   const qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
-  DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
+  DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
             (const uint64_t *) NULL, d_seg, d_size, (uint8_t *) NULL, ctx->d_status);
   uint64_t tot = 0;
   if ((e = dx_scan_u32(ctx, d_size, n, d_rec_off, &tot))) return e;
@@ -590,10 +595,10 @@ static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr
     return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
                    (unsigned long long) tot, (unsigned long long) out_cap);
   if (ctx->tok_wide)
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
               (const uint64_t *) d_rec_off, d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
   else
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, n), QS_BLOCK, a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
               (const uint64_t *) d_rec_off, d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
   uint32_t st = 0;
   DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
