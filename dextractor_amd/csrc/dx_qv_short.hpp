@@ -563,7 +563,12 @@ static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, bool *yes, co
   DX_HIP(ctx, hipMemcpyAsync(work, d_work, 16, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint64_t cost = ((uint64_t) work[3] << 32) | work[2];
-  *yes = work[0] <= QS_MAXLEN && 64u * cost <= (uint64_t) QS_MEAN * b->n;
+  // ... and the longest entry's lane (1.35 us a symbol through the three kernels when it is the last one running) is done when the batch is:
+  // no longer than the batch takes (0.6 TB/s), a millisecond at least -- one entry of 4096 symbols in a batch of 16 k x 300 would be
+  // 5.5 ms of a 0.9 ms step
+  const double room_s = (double) b->text_bytes / 6e11 > 1e-3 ? (double) b->text_bytes / 6e11 : 1e-3;
+  *yes = work[0] <= QS_MAXLEN && (double) work[0] * 1.35e-6 <= room_s && 64u * cost <= (uint64_t) QS_MEAN * b->n;
+  if (getenv("DEXGPU_SHORT_FORCE") != NULL) *yes = work[0] <= QS_MAXLEN;       // (tests: whatever the lengths cost)
   ctx->qs.ordered = work[0] != work[1] && getenv("DEXGPU_SHORT_FILE_ORDER") == NULL;      // (entries of one length: as they come)
   *perm = *yes && ctx->qs.ordered ? ctx->qs.perm : NULL;
   ctx->qs.off = b->d_off; ctx->qs.len = b->d_len; ctx->qs.n = b->n; ctx->qs.text_bytes = b->text_bytes;

@@ -19,6 +19,13 @@ def ctx():
     c.close()
 
 
+@pytest.fixture
+def force(monkeypatch):
+    """the lane-per-entry kernels whatever the batch's lengths would cost them (they are for batches whose longest entry's lane is done when
+    the batch is: a small batch with a long entry is not theirs) -- the kernels' code for long lines is what these cases are about"""
+    monkeypatch.setenv("DEXGPU_SHORT_FORCE", "1")
+
+
 def _took_short(ctx):
     return ctx.qv_onepass_info()["direct"] == 3
 
@@ -35,7 +42,7 @@ def _quiva(lines_of, n, movie=b"m7"):
 
 @pytest.mark.parametrize("lossy", [0, 1])
 @pytest.mark.parametrize("seed,n,mean", [(1, 5000, 120), (2, 4500, 500), (3, 20000, 300)])
-def test_short_dexqv_vs_oracle(ctx, seed, n, mean, lossy):
+def test_short_dexqv_vs_oracle(ctx, force, seed, n, mean, lossy):
     c = synth.make_quiva(n, seed=seed, mean=mean)
     if int(c.len.max()) > 4096:                       # (the lognormal tail: clipped so that the batch qualifies)
         c = synth.make_quiva(n, seed=seed, lens=np.minimum(c.len, 4096).astype(np.uint32))
@@ -60,7 +67,7 @@ def test_short_scan_vs_oracle(ctx):
         assert (hist[s] == want[s]).all(), f"histogram {s}"
 
 
-def test_short_every_small_length(ctx):
+def test_short_every_small_length(ctx, force):
     """every length 0..600 and the chunk / request boundaries, several times over"""
     lens = np.array((list(range(0, 601)) + [1007, 1008, 1009, 1023, 1024, 1025, 1040, 2048, 2049, 3000, 4095, 4096]) * 8, dtype=np.uint32)
     c = synth.make_quiva(len(lens), seed=31, lens=lens)
@@ -70,14 +77,14 @@ def test_short_every_small_length(ctx):
 
 
 @pytest.mark.parametrize("run_p", [0.02, 0.6, 0.97, 0.999])
-def test_short_run_densities(ctx, run_p):
+def test_short_run_densities(ctx, force, run_p):
     prof = synth.pacbio_profile(del_run_p=run_p, sub_run_p=run_p)
     c = synth.make_quiva(4200, seed=77, dist="fixed", mean=700, prof=prof)
     assert ctx.dexqv(c.text) == O.dexqv(c.text)
     assert _took_short(ctx)
 
 
-def test_short_type2_escapes_and_pad_rule(ctx):
+def test_short_type2_escapes_and_pad_rule(ctx, force):
     """Fibonacci-weighted symbols (8-bit escapes behind the longest code) in the plain lines, runs beyond 255 (16-bit literals)
     in the run-coded ones: every branch of the pad rule (QV.c:436-442) sees both kinds of last code"""
     rng = np.random.Generator(np.random.PCG64(3))
@@ -104,7 +111,7 @@ def test_short_type2_escapes_and_pad_rule(ctx):
     assert ctx.undexqv(want, upper=True) == O.undexqv(want, upper=True)
 
 
-def test_short_without_run_characters(ctx):
+def test_short_without_run_characters(ctx, force):
     """no N under any deletion QV: no deletion run character (all tags packed, the deletion line coded plain)"""
     rng = np.random.Generator(np.random.PCG64(5))
     prof = synth.pacbio_profile()
@@ -121,7 +128,7 @@ def test_short_without_run_characters(ctx):
     assert _took_short(ctx)
 
 
-def test_short_two_pass_api_gives_the_same_records(ctx):
+def test_short_two_pass_api_gives_the_same_records(ctx, force):
     """dx_qv_sizes + dx_qv_encode (k_qs_entries<false> / <true> on their own) against per-entry oracle calls"""
     c = synth.make_quiva(4100, seed=8, dist="fixed", mean=200)
     st = O.qv_scan(c.text)
@@ -173,8 +180,8 @@ def test_long_entry_or_few_entries_keep_the_wave_per_entry_kernels(ctx, monkeypa
 
 def test_mixed_lengths_1_to_20000(ctx):
     """a batch of entries of 1 ... 20 000 symbols, most of them short (the wave-per-entry kernels: an entry is longer than a lane
-    takes), the same batch with the long ones cut down to 4096 (still theirs: a wave's longest entry sets what its 64 cost) and to 1500
-    (the lane-per-entry kernels): all against the oracle"""
+    takes), the same batch with the long ones cut down to 4096 (still theirs: a wave's longest entry sets what its 64 cost, and the longest
+    entry's lane would still be running when the rest of so small a batch is done) and to 700 (the lane-per-entry kernels): all against the oracle"""
     rng = np.random.Generator(np.random.PCG64(20))
     lens = np.concatenate([rng.integers(1, 400, 4000), rng.integers(400, 3000, 700), rng.integers(3000, 20001, 60),
                            [1, 2, 3, 15, 16, 17, 20000]]).astype(np.uint32)
@@ -183,7 +190,7 @@ def test_mixed_lengths_1_to_20000(ctx):
     assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
     c = synth.make_quiva(len(lens), seed=21, lens=np.minimum(lens, 4096).astype(np.uint32))
     assert ctx.dexqv(c.text) == O.dexqv(c.text)
-    c = synth.make_quiva(len(lens), seed=21, lens=np.minimum(lens, 1500).astype(np.uint32))
+    c = synth.make_quiva(len(lens), seed=21, lens=np.minimum(lens, 700).astype(np.uint32))
     want = O.dexqv(c.text)
     assert ctx.dexqv(c.text) == want and _took_short(ctx)
     assert ctx.undexqv(want, upper=True) == O.undexqv(want, upper=True)
