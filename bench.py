@@ -21,6 +21,7 @@ line also carries, under "other_workloads", the lognormal-length dexqv run and t
 import argparse
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
@@ -302,11 +303,13 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
         return h
 
     def step():
-        p = ctx.qv_prescan(batch, entry0)
         if world > 1:                        # one file sharded over the ranks: agree on the scan state (host, gloo)
+            p = ctx.qv_prescan(batch, entry0)
             dC, dF, sC, sF = shard.agree_params(dist, (p.delChar, p.del_first), lens, entry0, sub_hist)
             p = L.QVParams(dC, sC, dF, sF)
-        mine, tot = ctx.qv_hist(batch, p, entry0)
+            mine, tot = ctx.qv_hist(batch, p, entry0)
+        else:                                # QVcoding_Scan in one call: the scan state stays on the device (dx_qv_scan)
+            p, mine, tot = ctx.qv_scan(batch, entry0)
         state["hist_mine"] = mine
         hist = mine
         if world > 1:                        # host-side sum of the 12 KB histograms (no RCCL)
@@ -347,7 +350,8 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
         state.update(total=total, coding=coding, params=p)
         if not args.twopass:
             state["route"] = ctx.qv_onepass_info()
-            state["mem_used_peak"] = max(state.get("mem_used_peak", 0), (lambda f, t: t - f)(*torch.cuda.mem_get_info()))
+            if not state.get("timing"):          # (a query of the driver: the warm-up steps', never the timed ones' -- 0.1 ms of a step's host time)
+                state["mem_used_peak"] = max(state.get("mem_used_peak", 0), (lambda f, t: t - f)(*torch.cuda.mem_get_info()))
 
     def fence():
         if state.get("begun"):                # the job's last encode: its compaction belongs inside the timed region
@@ -366,11 +370,13 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
         step()
     fence()
     ctx.profile(True)
+    state["timing"] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    state["timing"] = False
     times = ctx.kernel_times()
     ctx.profile(False)
     ctx.qv_subindex(False)
@@ -822,9 +828,13 @@ def cpu_baseline(ctx, api, d_text, off, lens, hlen, args, state, big):
     # process of its own; per-stage marks of the tools in "marks_ms")
     if args.cli_large_gb > 0:
         trace("cpu_baseline: the tools on a large file")
+        big_dir = tempfile.mkdtemp(prefix="cliscale.", dir=shm)      # ours to remove: a timeout's SIGKILL skips the script's own cleanup
         try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_scale.py"), str(args.cli_large_gb)], capture_output=True, timeout=900)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_scale.py"), str(args.cli_large_gb), "--dir", big_dir],
+                               capture_output=True, timeout=900)
             big_cli = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            if "skipped" in big_cli:
+                raise RuntimeError(big_cli["skipped"])
             brief = {"file": big_cli["file"]}
             for tool_, runs_ in big_cli["runs"].items():
                 best = min(runs_, key=lambda x: x["s"])
@@ -836,6 +846,8 @@ def cpu_baseline(ctx, api, d_text, off, lens, hlen, args, state, big):
             res["cli_end_to_end_large"] = brief
         except Exception as e:
             res["cli_end_to_end_large"] = {"skipped": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            shutil.rmtree(big_dir, ignore_errors=True)
 
     # how the single-threaded reference would be deployed: one independent copy per host core
     trace("cpu_baseline: all cores")

@@ -106,6 +106,8 @@ SIGNATURES = {
     "dx_mem_info": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "dx_qv_hist": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams), C.POINTER(HIST),
                              C.POINTER(C.c_uint64)]),
+    "dx_qv_scan": (C.c_int, [_P, C.POINTER(QVBatch), C.c_uint64, C.POINTER(QVParams), C.POINTER(HIST),
+                             C.POINTER(C.c_uint64)]),
     "dx_qv_build": (C.c_int, [C.POINTER(HIST), C.c_uint64, C.POINTER(QVParams), C.c_int, C.POINTER(QVCoding)]),
     "dx_qv_write_coding": (C.c_int, [C.POINTER(QVCoding), C.c_char_p, C.c_size_t, _P, C.c_size_t,
                                      C.POINTER(C.c_size_t)]),

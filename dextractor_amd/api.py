@@ -181,6 +181,16 @@ class Context:
         self._chk(self.lib.dx_qv_hist(self.h, C.byref(batch), entry0, C.byref(params), C.byref(h), C.byref(t)))
         return np.ctypeslib.as_array(h).reshape(6, 256).copy(), t.value
 
+    def qv_scan(self, batch, entry0=0, params=None, hist=None, tot=0):
+        """dx_qv_scan: qv_prescan + qv_hist with one wait on the device.  Returns (params, hist uint64 [6,256], totChar)."""
+        p = params or L.QVParams(-1, -1, -1, -1)
+        h = L.HIST()
+        if hist is not None:
+            np.ctypeslib.as_array(h)[:] = hist
+        t = C.c_uint64(tot)
+        self._chk(self.lib.dx_qv_scan(self.h, C.byref(batch), entry0, C.byref(p), C.byref(h), C.byref(t)))
+        return p, np.ctypeslib.as_array(h).reshape(6, 256).copy(), t.value
+
     def qv_set_coding(self, coding, lossy=False):
         self._chk(self.lib.dx_qv_set_coding(self.h, C.byref(coding), int(lossy)))
 

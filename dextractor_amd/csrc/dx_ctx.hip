@@ -164,6 +164,7 @@ extern "C" void dx_close(dx_ctx *ctx)
   if (ctx->h_stage[0]) (void) hipHostFree(ctx->h_stage[0]);
   if (ctx->h_up) (void) hipHostFree(ctx->h_up);
   if (ctx->h_down) (void) hipHostFree(ctx->h_down);
+  if (ctx->h_pin) (void) hipHostFree(ctx->h_pin);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipFree(ctx->tk.eh);
   (void) hipFree(ctx->qs.perm);
@@ -201,7 +202,8 @@ extern "C" int dx_trim(dx_ctx *ctx, int what)
     { (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info);
       (void) hipFree(ctx->tk.count); (void) hipFree(ctx->tk.eh);
       memset(&ctx->tk, 0, sizeof(ctx->tk));
-          memset(&ctx->qs, 0, sizeof(ctx->qs));
+      (void) hipFree(ctx->qs.perm);                      /* the short-entry survey's dealing of the batch (k_qs_survey) */
+      memset(&ctx->qs, 0, sizeof(ctx->qs));
     }
   if (what & DX_TRIM_INDEX)
     { const int want = ctx->sx.want;

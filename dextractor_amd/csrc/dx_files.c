@@ -734,9 +734,7 @@ static int dexqv_sliced(dx_ctx *ctx, const uint8_t *text, size_t n, int lossy, s
           TRY(dx_h2d(ctx, d_len, len + e0, (size_t) m * 4));
           b.d_text = d_text; b.d_off = d_off; b.d_len = d_len; b.n = m; b.line_pad = 1; b.text_bytes = s1 - s0;
           if (pass == 1)
-            { TRY(dx_qv_prescan(ctx, &b, e0, &p));                                       /* QV.c:993-1015, state carried along */
-              TRY(dx_qv_hist(ctx, &b, e0, &p, hist, &tot));
-            }
+            TRY(dx_qv_scan(ctx, &b, e0, &p, hist, &tot));                               /* QV.c:993-1017, state carried along */
           else
             { uint64_t t2 = 0, bound;
               size_t   bb;
@@ -892,8 +890,7 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, int fd, size_t n, int lo
   b.text_bytes = n;
 
   /* ... and histogram on the device (QV.c:988-1017) */
-  TRY(dx_qv_prescan(ctx, &b, 0, &p));
-  TRY(dx_qv_hist(ctx, &b, 0, &p, hist, &tot));
+  TRY(dx_qv_scan(ctx, &b, 0, &p, hist, &tot));
   TRY(dx_qv_build((const uint64_t (*)[256]) hist, tot, &p, lossy, cd));   /* Create_QVcoding, dexqv.c:86 */
   TRY(dx_qv_set_coding(ctx, cd, lossy));
   fmark("dexqv: scanned, tables built");
@@ -1761,8 +1758,7 @@ int dx_entries_compress(dx_ctx *ctx, const dx_entries *e, int lossy, dx_qv_codin
   TRY(dalloc(&pool, (e->n + 1) * 8, &d_rec));
   TRY(dalloc(&pool, e->n * 20, &d_seg));
   b.d_text = d_text; b.d_off = d_off; b.d_len = d_len; b.n = e->n; b.line_pad = 0; b.text_bytes = e->tlen;
-  TRY(dx_qv_prescan(ctx, &b, 0, &p));                      /* QVcoding_Scan1 over all entries */
-  TRY(dx_qv_hist(ctx, &b, 0, &p, hist, &tot));
+  TRY(dx_qv_scan(ctx, &b, 0, &p, hist, &tot));             /* QVcoding_Scan1 over all entries */
   TRY(dx_qv_build((const uint64_t (*)[256]) hist, tot, &p, lossy, coding));   /* Create_QVcoding */
   TRY(dx_qv_set_coding(ctx, coding, lossy));
   if (!two_pass())                                              /* Compress_Next_QVentry1 x n */

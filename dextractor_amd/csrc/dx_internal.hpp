@@ -107,6 +107,13 @@ struct dx_ctx
   uint8_t  *h_up;              // pinned staging of a large dx_h2d (made at its first such call)
   uint8_t  *h_down;            // pinned staging of dx_d2h_stream with several sink threads (dx_set_sink_threads)
   int       sink_threads;
+  // dx_qv_scan: what the last scan of this context launched (a guess for the next, checked on the device) and pinned host words --
+  // [0, 2048): what a scan brings back (histograms, totals, the device's scan state), [2048, 2048 + 768): the code tables on their way up
+  struct { int valid; uint32_t inst; } scan;
+  uint64_t *h_pin;
+  std::vector<uint16_t> h_dec; // the decode tables dx_qv_set_coding built (Read_Scheme's look-up, two levels), uploaded by the first
+  std::vector<uint32_t> h_lng; //   dx_qv_decode that wants them (dec_stale): an encode step never reads them
+  int       dec_stale;
   void     *d_hscr;            // grow-only scratch of dx_qv_hist (its own: d_scratch may still be read by the compaction
   size_t    hscr_bytes;        //   of an encode that has begun, dx_qv_encode_onepass_begin)
   // an encode that has begun and not ended (dx_qv_encode_onepass_begin / _end)
@@ -120,6 +127,7 @@ int  dx_fail(dx_ctx *ctx, int code, const char *fmt, ...);
 hipError_t dx_hip_malloc(void **p, size_t bytes);
 #define hipMalloc(p, n) dx_hip_malloc((void **) (p), (n))
 int  dx_scratch(dx_ctx *ctx, size_t bytes, void **p);
+int  dx_dec_tables(dx_ctx *ctx);             // the decode tables on the device (uploads them when dx_qv_set_coding has left them stale)
 void dx_sx_drop_external(dx_ctx *ctx);      // forget a caller's group index (dx_qv_use_index) before the context's own buffers are touched
 uint64_t dx_budget(const dx_ctx *ctx);
 int  dx_after_pending(dx_ctx *ctx);

@@ -64,6 +64,9 @@
 #ifndef HIST_SKIP
 #define HIST_SKIP 0
 #endif
+#ifndef HIST_TRIM
+#define HIST_TRIM 0
+#endif
 
 struct qv_args
 { const uint8_t  *text;
@@ -459,11 +462,32 @@ struct hist_wave_lds
 { uint8_t  chunk[DX_STEP], tags[DX_STEP];
   uint16_t list[DX_STEP];
 };
+// copies of every counter of the two plain lines (copy = lane & (copies - 1); 4 or 8): lanes of a 32-lane group that hold the same
+// symbol add to the same address, one LDS cycle each -- SQ_LDS_BANK_CONFLICT is 64 % of the kernel's LDS cycles, the waves stand
+// a fifth of their time at the LDS's door (SQ_WAIT_INST_LDS; profiles/r06_hist_lds.txt)
+#ifndef PPC_INS
+#define PPC_INS 8
+#endif
+#ifndef PPC_MRG
+#define PPC_MRG 4
+#endif
+// tokens a wave's list holds: a step's (1024 symbols) all, or half that -- a step with more (a run density below a half; the
+// instance with the wave's own token counters is launched for sampled densities from ~0.72 up) then leaves no tokens, and its
+// entry goes to the text-reading kernels like every other entry whose tokens cannot be used
+#ifndef HIST_LIST
+#define HIST_LIST 512
+#endif
 struct hist_wave_own
-{ uint32_t pp[2][128][4];                               // (16 bits packed two to a word, eight copies: the same time, 3 instructions more per byte)
-  uint32_t ps[2][128][2];                               // token symbols of del, of sub: two copies (copy = lane & 1)
-  uint32_t pr[2][128];                                  // runs of del, of sub
-  uint16_t list[DX_STEP];
+{ uint32_t pi[128][PPC_INS], pm[128][PPC_MRG];          // (16 bits packed two to a word, eight copies: the same time, 3 instructions more per byte)
+#ifndef PSC
+#define PSC 1
+#endif
+  uint32_t ps[2][128][PSC];                             // token symbols of del, of sub: PSC copies (copy = lane & (PSC - 1))
+#ifndef PRC
+#define PRC 1
+#endif
+  uint32_t pr[2][128][PRC];                             // runs of del, of sub (PRC copies, copy = lane & (PRC - 1))
+  uint16_t list[HIST_LIST];
 };
 #define EH_WORDS 384u                                   // an entry's counters in memory: 768 x 16 bits: ins, mrg, del, sub, del runs, sub runs
 
@@ -476,7 +500,7 @@ __device__ __forceinline__ void hist_runs_step(hist_wave_lds *W, uint16_t *wlist
                                                uint32_t *hr, uint32_t *slow_r, uint32_t inc,
                                                uint16_t *tok, uint32_t &ntok, uint32_t room, uint32_t &bad, uint32_t &nexc,
                                                tok_pend &pend_out)
-{ constexpr uint32_t HCS = OWN ? 2u : HC_RSYM, HCR = OWN ? 1u : HC_RUN;
+{ constexpr uint32_t HCS = OWN ? (uint32_t) PSC : HC_RSYM, HCR = OWN ? (uint32_t) PRC : HC_RUN;
   const uint32_t lane  = (uint32_t) lane_id();
   const uint32_t nr0   = chunk_ne_mask(c, rc4) & vmask;
   const uint32_t cnt   = __popc(nr0);
@@ -488,8 +512,9 @@ __device__ __forceinline__ void hist_runs_step(hist_wave_lds *W, uint16_t *wlist
       if (TAGS) *(u32x4 *) (W->tags + 16u * lane) = t;
     }
   // room: what the slot holds less TOK_XMARGIN (0: no tokens wanted)
-  const bool emit = !(HIST_SKIP & 8) && !bad && ntok + total + 4u * nexc <= room;
-  if (!emit) bad = 1;                                            // more tokens (and exceptions) than the slot holds
+  const bool fits = OWN ? total <= (uint32_t) HIST_LIST : true;  // (the list of the instances with the wave's own counters may be the shorter one)
+  const bool emit = !(HIST_SKIP & 8) && !bad && fits && ntok + total + 4u * nexc <= room;
+  if (!emit) bad = 1;                                            // more tokens (and exceptions) than the slot holds, or than the list
   // where the last token of this lane ends (position + 1), the run open at the step's start added; 0: the lane has none
   const uint32_t tend  = cnt ? 16u * lane + 32u - (uint32_t) __clz(nr0) + C : 0u;
   const uint32_t imax  = wave_incl_max(tend);
@@ -497,7 +522,7 @@ __device__ __forceinline__ void hist_runs_step(hist_wave_lds *W, uint16_t *wlist
   const uint32_t s0    = wave_shr1(imax) - (16u * lane + C);     // the run in front of the lane's token at byte b: b - s
   const uint32_t li0   = incl - cnt;                             // the lane's first token in the step's list
   uint32_t nr = (HIST_SKIP & 1) ? 0u : nr0, s = s0, acc = 0;
-  uint16_t      *lp = wlist + li0;
+  uint16_t      *lp = wlist + (fits ? li0 : 0u);                 // (a step that does not fit: every lane's tokens over the list's first sixteen)
   const uint8_t *cp = LDSX ? W->chunk + 16u * lane : (const uint8_t *) NULL;
   const uint32_t pinc = OWN ? 1u : inc;                          // what the fast run bins count
   while (nr)
@@ -517,11 +542,20 @@ __device__ __forceinline__ void hist_runs_step(hist_wave_lds *W, uint16_t *wlist
       const uint32_t r7  = run < TOK_RUN_MAX ? run : TOK_RUN_MAX;
       s   = b + 1u;
       acc = max(acc, max(run, x));
+#if HIST_TRIM
+      // the symbol shifted once, for the token and for its counter's address (a counter is HCS words: (x & 127) * 4 HCS bytes)
+      const uint32_t x4 = x << 2;
+      atomicAdd((uint32_t *) ((uint8_t *) hs + (x4 & (4u * (HSYM_FAST - 1))) * HCS), 1u);
+      atomicAdd(&hr[r7 * HCR], pinc);
+      uint32_t tk = (r7 << 9) | x4;
+      if (TAGS) tk |= tag_code(tg);
+#else
       atomicAdd(&hs[(x & (HSYM_FAST - 1)) * HCS], 1u);
       atomicAdd(&hr[r7 * HCR], pinc);
       uint32_t tk = x | (r7 << 7);
       if (TAGS) tk = (tk << 2) | tag_code(tg);
       else      tk <<= 2;
+#endif
       *lp++ = (uint16_t) tk;
     }
   uint32_t odd = 0;
@@ -606,15 +640,10 @@ __device__ __forceinline__ void hist_plain_pair(const u32x4 &c2, const u32x4 &c3
 // byte-by-byte loop that used to do the last step (a variable byte index, four branches a byte) cost more than a whole
 // step's unrolled adds: an entry's last step took 2.2 times a full one, a 2 kb entry's two steps the time of three
 // (k_qv_hist 13.0 -> 12.6 ms at 10 kb, 7.6 -> 6.5 at 2 kb, 10.8 -> 9.3 at 300 symbols; same box).
-__device__ __forceinline__ uint32_t hist_plain_pair_own(const u32x4 &c2, const u32x4 &c3, int valid, bool full, uint32_t (*pp)[128][4],
+__device__ __forceinline__ uint32_t hist_plain_pair_own(const u32x4 &c2, const u32x4 &c3, int valid, bool full, uint32_t *pi, uint32_t *pm,
                                                         uint32_t *slow_ins, uint32_t *slow_mrg)
-{ const uint32_t col = (uint32_t) lane_id() & 3u;
-  uint32_t *const q0 = &pp[0][0][col], *const q1 = &pp[1][0][col];
-#if HIST_SKIP & 512             /* perturbation: every lane's symbols moved to bins of its own -- what the same-address adds cost */
-#define OWN_ADD(q, x) atomicAdd(&(q)[4u * (((x) + 2u * (uint32_t) lane_id()) & 127u)], 1u)
-#else
-#define OWN_ADD(q, x) atomicAdd(&(q)[4u * (x)], 1u)
-#endif
+{ uint32_t *const q0 = pi + ((uint32_t) lane_id() & (PPC_INS - 1u)), *const q1 = pm + ((uint32_t) lane_id() & (PPC_MRG - 1u));
+#define OWN_ADD(q, x) atomicAdd(&(q)[((q) == q0 ? (uint32_t) PPC_INS : (uint32_t) PPC_MRG) * (x)], 1u)
   if (!__any((int) ((c2.x | c2.y | c2.z | c2.w | c3.x | c3.y | c3.z | c3.w) & 0x80808080u)))
     { if (full || valid > 0)
         {
@@ -659,6 +688,29 @@ __device__ __forceinline__ uint32_t hist_bin_of(uint32_t k)
 __device__ __forceinline__ uint32_t hist_copies_of(uint32_t k)
 { return k < HIST_W_PLAIN ? HC_PLAIN : (k < HIST_W_PLAIN + HIST_W_RSYM ? HC_RSYM : HC_RUN); }
 
+// ---------------------------------------------------------------------------------------------
+//  the scan state on the device (dx_qv_scan)
+// ---------------------------------------------------------------------------------------------
+// dx_qv_prescan hands delChar / subChar to the host, which hands them to dx_qv_hist's kernels as arguments: a round trip,
+// and a second one for the token total (what the slots need) and the slot share (which instance of k_qv_hist) -- 0.25 ms of
+// a 25 ms step with nothing on the device.  dx_qv_scan leaves the state where it is made: k_scan_state folds what the two
+// prescan kernels found into this record, k_qv_density / k_tok_rooms / k_qv_hist read it there, and the host sees it with the
+// histograms, in the one copy it waits for.  What the host has to decide before it knows -- which instance of k_qv_hist to
+// launch, whether the token buffers it has are large enough -- it GUESSES from the context's last scan, and the device
+// checks: a wrong guess leaves SCAN_MISS here, k_qv_hist returns at once, and the host goes the old way (dx_qv_hist) with
+// the state it now knows.  No result is carried over from one batch to the next, only the guess.
+struct scan_dev
+{ int32_t   delChar, subChar;
+  long long del_first, sub_first;
+  uint32_t  inst;                                        // the instance of k_qv_hist this batch wants (SCAN_*), | SCAN_MISS
+  uint32_t  share8;                                      // k_tok_rooms' slot share
+};
+#define SCAN_G     0u                                    // k_qv_hist<false, false> with tokens
+#define SCAN_A     1u                                    // <true, true>
+#define SCAN_B     2u                                    // <true, false>
+#define SCAN_NOTOK 3u                                    // no run character at all: no tokens (never guessed)
+#define SCAN_MISS  0x100u
+
 // FAST: tokens wanted and both run characters known -- the usual launch: both lines are run-coded in every entry, the tag
 // line travels with them, none of that is asked per entry and step, and the histograms are first the wave's own, per
 // entry (hist_wave_own); !FAST: everything decided at run time, the workgroup's replicated bins.
@@ -669,7 +721,7 @@ __device__ __forceinline__ uint32_t hist_copies_of(uint32_t k)
 template <bool FAST, bool OWNTOK> struct hist_smem;
 template <> struct hist_smem<false, false> { hist_lds H; hist_wave_lds W[HIST_NWAVE]; };
 template <> struct hist_smem<true, true>   { uint32_t slow[6][256]; hist_wave_own W[HIST_NWAVE]; };
-struct hist_wave_plain { uint32_t pp[2][128][4]; uint16_t list[DX_STEP]; };
+struct hist_wave_plain { uint32_t pi[128][PPC_INS], pm[128][PPC_MRG]; uint16_t list[DX_STEP]; };     // (the instance of the dense batches: a whole step's room)
 template <> struct hist_smem<true, false>
 { uint32_t slow[6][256];
   uint32_t rsym[2][HSYM_FAST][HC_RSYM], run[2][HRUN_FAST][HC_RUN];
@@ -679,8 +731,15 @@ template <> struct hist_smem<true, false>
 template <bool FAST, bool OWNTOK>
 __global__ __launch_bounds__(HIST_BLOCK, (HIST_NWAVE * HIST_PER_CU + 3) / 4)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
-               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts, uint32_t *eh /* n x EH_WORDS (FAST) */)
+               unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts, uint32_t *eh /* n x EH_WORDS (FAST) */,
+               const scan_dev *sd /* dx_qv_scan: the scan state, and the verdict on the host's guesses */, uint64_t tok_cap /* tokens the buffers hold */)
 { __shared__ __attribute__((aligned(16))) hist_smem<FAST, OWNTOK> S;
+  if (sd != NULL)
+    { if (sd->inst != (FAST ? (OWNTOK ? SCAN_A : SCAN_B) : SCAN_G) || ts.off[a.n] > tok_cap)
+        return;                                          // not the instance the batch wants, or slots beyond the buffers: the host sees it (dx_qv_scan)
+      a.delChar = sd->delChar; a.subChar = sd->subChar;
+      del_first = sd->del_first; sub_first = sd->sub_first;
+    }
   typedef hist_smem<false, false> smem_g;
   typedef hist_smem<true, true>   smem_a;
   typedef hist_smem<true, false>  smem_b;
@@ -692,7 +751,8 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   hist_wave_lds *const Wl = FAST ? (hist_wave_lds *) NULL : &((smem_g *) (void *) &S)->W[wid];
   hist_wave_own *const Wo = FAST && OWNTOK ? &((smem_a *) (void *) &S)->W[wid] : (hist_wave_own *) NULL;
   smem_b        *const Sb = FAST && !OWNTOK ? (smem_b *) (void *) &S : (smem_b *) NULL;
-  uint32_t (*const ppw)[128][4] = !FAST ? (uint32_t (*)[128][4]) NULL : (OWNTOK ? Wo->pp : Sb->W[wid].pp);
+  uint32_t *const piw = !FAST ? (uint32_t *) NULL : (OWNTOK ? &Wo->pi[0][0] : &Sb->W[wid].pi[0][0]);
+  uint32_t *const pmw = !FAST ? (uint32_t *) NULL : (OWNTOK ? &Wo->pm[0][0] : &Sb->W[wid].pm[0][0]);
   uint16_t      *const wlist = !FAST ? Wl->list : (OWNTOK ? Wo->list : Sb->W[wid].list);
   uint32_t *const words = (uint32_t *) (void *) &S;              // the whole of S as words (zeroed at the start)
   const uint32_t  nwords = sizeof(S) / 4;
@@ -701,10 +761,10 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   constexpr bool OT = FAST && OWNTOK;
   uint32_t (*const rsymp)[HSYM_FAST][HC_RSYM] = FAST ? (OWNTOK ? (uint32_t (*)[HSYM_FAST][HC_RSYM]) NULL : Sb->rsym) : Hp->rsym;
   uint32_t (*const runp)[HRUN_FAST][HC_RUN]   = FAST ? (OWNTOK ? (uint32_t (*)[HRUN_FAST][HC_RUN]) NULL : Sb->run) : Hp->run;
-  uint32_t *const hs0 = OT ? &Wo->ps[0][0][(uint32_t) lane & 1u] : &rsymp[0][0][(uint32_t) lane & (HC_RSYM - 1)];
-  uint32_t *const hs4 = OT ? &Wo->ps[1][0][(uint32_t) lane & 1u] : &rsymp[1][0][(uint32_t) lane & (HC_RSYM - 1)];
-  uint32_t *const hr0 = OT ? Wo->pr[0] : &runp[0][0][(uint32_t) lane & (HC_RUN - 1)];
-  uint32_t *const hr4 = OT ? Wo->pr[1] : &runp[1][0][(uint32_t) lane & (HC_RUN - 1)];
+  uint32_t *const hs0 = OT ? &Wo->ps[0][0][(uint32_t) lane & (PSC - 1)] : &rsymp[0][0][(uint32_t) lane & (HC_RSYM - 1)];
+  uint32_t *const hs4 = OT ? &Wo->ps[1][0][(uint32_t) lane & (PSC - 1)] : &rsymp[1][0][(uint32_t) lane & (HC_RSYM - 1)];
+  uint32_t *const hr0 = OT ? &Wo->pr[0][0][(uint32_t) lane & (PRC - 1)] : &runp[0][0][(uint32_t) lane & (HC_RUN - 1)];
+  uint32_t *const hr4 = OT ? &Wo->pr[1][0][(uint32_t) lane & (PRC - 1)] : &runp[1][0][(uint32_t) lane & (HC_RUN - 1)];
   const uint32_t  rc0 = (uint32_t) (a.delChar & 0xff) * 0x01010101u, rc4 = (uint32_t) (a.subChar & 0xff) * 0x01010101u;
 
   for (uint32_t k = tid; k < nwords; k += HIST_BLOCK) words[k] = 0;
@@ -780,7 +840,7 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
                                                      sinc, tk4, nt4, tk4 != NULL ? room : 0u, bad4, nx4, pd4);
           else      hist_plain_step<HC_RSYM>(c4, valid, full, Hp->rsym[1], slow[DX_SUB]);
           if (HIST_SKIP & 2) { }
-          else if (FAST) bad0 |= hist_plain_pair_own(c2, c3, valid, full, ppw, slow[DX_INS], slow[DX_MRG]);
+          else if (FAST) bad0 |= hist_plain_pair_own(c2, c3, valid, full, piw, pmw, slow[DX_INS], slow[DX_MRG]);
           else           hist_plain_pair(c2, c3, valid, full, *Hp);
           c0 = d0; c4 = d4; t1 = u1;
           pos = np;
@@ -797,10 +857,23 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           const u32x4 zero = { 0u, 0u, 0u, 0u };
           #pragma unroll
           for (int k = 0; k < 2; k++)
-            { u32x4 *w = (u32x4 *) &ppw[k][2 * lane][0];
-              const u32x4 v0 = w[0], v1 = w[1];
-              w[0] = zero; w[1] = zero;
-              const uint32_t ce = v0.x + v0.y + v0.z + v0.w, co = v1.x + v1.y + v1.z + v1.w;
+            { const int cp = k == 0 ? PPC_INS : PPC_MRG;                              // copies a counter has (2, 4 or 8)
+              u32x4 *w = (u32x4 *) ((k == 0 ? piw : pmw) + 2 * lane * cp);            // this lane's two counters: 2 cp words side by side
+              uint32_t ce = 0, co = 0;
+              if (cp == 2)
+                { const u32x4 v = w[0];
+                  w[0] = zero;
+                  ce = v.x + v.y; co = v.z + v.w;
+                }
+              else
+                {
+                  #pragma unroll
+                  for (int j = 0; j < cp / 4; j++)
+                    { const u32x4 v0 = w[j], v1 = w[cp / 4 + j];
+                      w[j] = zero; w[cp / 4 + j] = zero;
+                      ce += v0.x + v0.y + v0.z + v0.w; co += v1.x + v1.y + v1.z + v1.w;
+                    }
+                }
               e32[64 * k + lane] = (ce & 0xffffu) | (co << 16);
               if (ce | co)
                 { atomicAdd(&slow[DX_INS + k][2 * lane], ce);
@@ -811,15 +884,22 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
           for (int k = 0; k < (OT ? 4 : 0); k++)
             { uint32_t v0, v1;
               if (k < 2)
-                { u32x4 *w = (u32x4 *) &Wo->ps[k][2 * lane][0];
-                  const u32x4 v = w[0];
-                  w[0] = zero;
-                  v0 = v.x + v.y; v1 = v.z + v.w;
+                { uint32_t *w = &Wo->ps[k][2 * lane][0];
+                  v0 = 0; v1 = 0;
+                  #pragma unroll
+                  for (int j = 0; j < PSC; j++)
+                    { v0 += w[j]; v1 += w[PSC + j];
+                      w[j] = 0; w[PSC + j] = 0;
+                    }
                 }
               else
-                { uint32_t *w = &Wo->pr[k - 2][2 * lane];
-                  v0 = w[0]; v1 = w[1];
-                  w[0] = 0; w[1] = 0;
+                { uint32_t *w = &Wo->pr[k - 2][2 * lane][0];
+                  v0 = 0; v1 = 0;
+                  #pragma unroll
+                  for (int j = 0; j < PRC; j++)
+                    { v0 += w[j]; v1 += w[PRC + j];
+                      w[j] = 0; w[PRC + j] = 0;
+                    }
                 }
               e32[128 + 64 * k + lane] = (v0 & 0xffffu) | (v1 << 16);
               const int      tab = k == 0 ? DX_DEL : (k == 1 ? DX_SUB : (k == 2 ? DX_DRUN : DX_SRUN));
@@ -913,13 +993,30 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
     }
 }
 
+__global__ void k_scan_state(const unsigned long long *key, const long long *sub, dx_qv_params in, int want_del, int want_sub, scan_dev *sd)
+{ if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  scan_dev d;
+  d.delChar = in.delChar; d.subChar = in.subChar; d.del_first = in.del_first; d.sub_first = in.sub_first;
+  if (want_del && *key != ~0ull)
+    { d.delChar   = (int32_t) (*key & 0xff);
+      d.del_first = (long long) (*key >> 8);
+    }
+  if (want_sub && sub[0] >= 0)
+    { d.subChar   = (int32_t) sub[1];
+      d.sub_first = sub[0];
+    }
+  d.inst = 0; d.share8 = 0;
+  *sd = d;
+}
+
 // How many of a run-coded line's symbols are tokens (not the run character)?  Counted on a sample -- up to 1024 entries spread
 // evenly over the batch, the first 4 KiB of their deletion and substitution lines -- so that the token slots can be sized for
 // the batch at hand: half a slot per symbol (rounds 2 and 3) sends every entry of a batch with run density 0.3 to the
 // text-reading encoder and wastes two thirds of the slots at 0.85.  cnt[0..3]: symbols seen / tokens among them, del then sub.
 __global__ __launch_bounds__(DX_BLOCK)
-void k_qv_density(qv_args a, uint64_t stride, unsigned long long *cnt)
-{ const int      lane = lane_id();
+void k_qv_density(qv_args a, uint64_t stride, unsigned long long *cnt, const scan_dev *sd /* NULL: the run characters are a's */)
+{ if (sd != NULL) { a.delChar = sd->delChar; a.subChar = sd->subChar; }
+  const int      lane = lane_id();
   const uint64_t w    = (uint64_t) blockIdx.x * DX_WAVES_PER_BLK + (threadIdx.x >> 6);
   const uint64_t r    = w * stride;
   if (r >= a.n) return;
@@ -950,11 +1047,22 @@ __device__ __forceinline__ uint32_t tok_share_of(const unsigned long long *cnt)
 }
 
 // slot sizes of the token hand-over (tokens per entry); the share it used goes to cnt[4] for the host's records
+// sd (dx_qv_scan): the share and the instance of k_qv_hist the batch wants go to the record too -- SCAN_MISS with them when the
+// instance is not the one the host has launched (guess)
+#define HIST_SHARE_A 110u                                // tokens at most ~28 % of the denser line (run densities from ~0.72 up): instance A
 __global__ __launch_bounds__(DX_BLOCK)
-void k_tok_rooms(const uint32_t *len, uint64_t n, unsigned long long *cnt, uint32_t *room)
+void k_tok_rooms(const uint32_t *len, uint64_t n, unsigned long long *cnt, uint32_t *room, scan_dev *sd, uint32_t guess, int shared_tokens)
 { const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
   const uint32_t fr8 = tok_share_of(cnt);
-  if (i == 0) cnt[4] = fr8;
+  if (i == 0)
+    { cnt[4] = fr8;
+      if (sd != NULL)
+        { const uint32_t inst = sd->delChar < 0 && sd->subChar < 0 ? SCAN_NOTOK
+                              : (sd->delChar >= 0 && sd->subChar >= 0 ? (fr8 <= HIST_SHARE_A && !shared_tokens ? SCAN_A : SCAN_B) : SCAN_G);
+          sd->share8 = fr8;
+          sd->inst   = inst | (inst != guess ? SCAN_MISS : 0u);
+        }
+    }
   if (i < n) room[i] = tok_room(len[i], fr8);
 }
 
@@ -2082,10 +2190,18 @@ extern "C" int dx_qv_lossy_text(dx_ctx *ctx, const dx_qv_batch *b)
 
 // Token slots for the batch: offsets by a scan of the per-entry rooms, buffers grown as needed.  Returns
 // false (and leaves the hand-over off) when tokens are not wanted or the memory is not to be had.
-static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params *p, uint8_t *scr, size_t scr_at)
+// sd (dx_qv_scan): the run characters are the device's (p is not looked at), the share and the wanted instance of k_qv_hist go
+// to *sd, `guess` is the instance the host is about to launch, and nothing comes back to the host here: the buffers are
+// taken as they are (dx_qv_scan has seen to the entries' arrays; whether the tokens fit is k_qv_hist's to say).
+static bool tokens_off()
+{ const char *off = getenv("DEXGPU_NO_TOKENS");
+  return off != NULL && off[0] != '\0' && off[0] != '0';
+}
+
+static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params *p, uint8_t *scr, size_t scr_at,
+                           scan_dev *sd = NULL, uint32_t guess = 0)
 { ctx->tk.valid = 0;
-  const char *off = getenv("DEXGPU_NO_TOKENS");
-  if ((off != NULL && off[0] != '\0' && off[0] != '0') || (p->delChar < 0 && p->subChar < 0))
+  if (sd == NULL && (tokens_off() || (p->delChar < 0 && p->subChar < 0)))
     return false;
   const uint64_t n      = b->n;
   const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -2093,7 +2209,8 @@ static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params
   uint64_t *d_tile = (uint64_t *) (scr + scr_at + ((n * 4 + 63) & ~(size_t) 63));
   uint64_t *d_gran = d_tile + ntiles;
   if (ctx->tk.cap_entries < n)
-    { (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
+    { if (sd != NULL) return false;
+      (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
       ctx->tk.off = NULL; ctx->tk.info = NULL; ctx->tk.count = NULL; ctx->tk.list = NULL; ctx->tk.cap_entries = 0;
       if (hipMalloc((void **) &ctx->tk.off, (n + 1) * 8) != hipSuccess ||
           hipMalloc((void **) &ctx->tk.info, n * 4 * TOK_INFO) != hipSuccess ||
@@ -2105,16 +2222,18 @@ static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params
   { unsigned long long *d_cnt = (unsigned long long *) (ctx->d_u64 + 48);          // (5 words: k_qv_density's four, the share chosen)
     const uint64_t sample = n < 1024 ? n : 1024, stride = n / sample;
     if (hipMemsetAsync(d_cnt, 0, 40, ctx->stream) != hipSuccess) { (void) hipGetLastError(); return false; }
-    qv_args a = make_args(b, p->delChar, p->subChar, 0);
+    qv_args a = make_args(b, sd ? -1 : p->delChar, sd ? -1 : p->subChar, 0);
     hipLaunchKernelGGL(k_qv_density, dim3((unsigned) ((sample + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream,
-                       a, stride, d_cnt);
+                       a, stride, d_cnt, (const scan_dev *) sd);
     hipLaunchKernelGGL(k_tok_rooms, dim3((unsigned) ((n + DX_BLOCK - 1) / DX_BLOCK)), dim3(DX_BLOCK), 0, ctx->stream,
-                       (const uint32_t *) b->d_len, n, d_cnt, d_room);
+                       (const uint32_t *) b->d_len, n, d_cnt, d_room, sd, guess, getenv("DEXGPU_HIST_SHARED_TOKENS") != NULL ? 1 : 0);
   }
   hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, (const uint32_t *) d_room, n, d_tile);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(DX_BLOCK), 0, ctx->stream, d_tile, ntiles, d_gran);
   hipLaunchKernelGGL(k_scan_apply, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, (const uint32_t *) d_room, n,
                      (const uint64_t *) d_tile, ctx->tk.off, (const uint64_t *) d_gran);
+  if (sd != NULL)                                        // (share and total: with the histograms)
+    return hipGetLastError() == hipSuccess;
   uint64_t total = 0, share = 128;
   if (hipMemcpyAsync(&share, (unsigned long long *) (ctx->d_u64 + 48) + 4, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(&total, d_gran, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -2198,15 +2317,26 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
       else
         ctx->tk.cap_eh = n;
     }
-  if (fast_hist && ctx->tk.share8 <= 110 && getenv("DEXGPU_HIST_SHARED_TOKENS") == NULL)   // (tokens at most ~28 % of the denser line: run densities from ~0.72 up)
-    DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, true>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
-              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh);
+  uint32_t inst = SCAN_G;
+  if (fast_hist && ctx->tk.share8 <= HIST_SHARE_A && getenv("DEXGPU_HIST_SHARED_TOKENS") == NULL)   // (tokens at most ~28 % of the denser line: run densities from ~0.72 up)
+    { inst = SCAN_A;
+      DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, true>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
+                a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh,
+                (const scan_dev *) NULL, (uint64_t) 0);
+    }
   else if (fast_hist)
-    DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, false>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
-              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh);
+    { inst = SCAN_B;
+      DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, false>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
+                a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh,
+                (const scan_dev *) NULL, (uint64_t) 0);
+    }
   else
     DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<false, false>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
-              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, (uint32_t *) NULL);
+              a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, (uint32_t *) NULL,
+              (const scan_dev *) NULL, (uint64_t) 0);
+  // what dx_qv_scan may guess for this context's next batch (only instances that leave tokens are guessed)
+  ctx->scan.valid = ts.del != NULL && (inst != SCAN_G || (p->delChar >= 0) != (p->subChar >= 0));
+  ctx->scan.inst  = inst;
   uint64_t host[6 * 256 + 2];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2224,6 +2354,99 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
       ctx->tk.valid = 1;
       ctx->tk.eh_valid = fast_hist ? 1 : 0;
     }
+  return DX_OK;
+}
+
+// the context's pinned host words (dx_internal.hpp: h_pin)
+static uint64_t *scan_pin(dx_ctx *ctx)
+{ if (ctx->h_pin == NULL && hipHostMalloc((void **) &ctx->h_pin, (2048 + 768) * 8, hipHostMallocDefault) != hipSuccess)
+    { (void) hipGetLastError();
+      ctx->h_pin = NULL;
+    }
+  return ctx->h_pin;
+}
+
+// dx_qv_prescan + dx_qv_hist with ONE wait: the scan state stays on the device (scan_dev), the host's two decisions are
+// guesses the device checks.  Same results as the two calls, to which it falls back whenever there is nothing to guess from
+// (a context's first batch), a guess fails, or the batch may be one for the lane-per-entry kernels.
+extern "C" int dx_qv_scan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx_qv_params *p, uint64_t hist[6][256], uint64_t *totChar)
+{ int e = check_batch(ctx, b, "dx_qv_scan");
+  if (e) return e;
+  if (p == NULL || hist == NULL || totChar == NULL)
+    return dx_fail(ctx, DX_E_ARG, "dx_qv_scan: NULL argument");
+  const uint64_t n      = b->n;
+  const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  const size_t   hbytes = ((6 * 256 + 2) * 8 + 255) & ~(size_t) 255;
+  const size_t   want   = hbytes + ((n * 4 + 63) & ~(size_t) 63) + (ntiles + 2) * 8 + 64;
+  const uint32_t guess  = ctx->scan.inst;
+  bool spec = n > 0 && ctx->scan.valid && !tokens_off() && getenv("DEXGPU_NO_SCAN_GUESS") == NULL &&
+              ctx->tk.cap_entries >= n && ctx->tk.cap_tokens > 0 && ctx->tk.del != NULL && ctx->tk.sub != NULL &&
+              (guess == SCAN_G || ctx->tk.cap_eh >= n) && want <= ctx->hscr_bytes && scan_pin(ctx) != NULL;
+  if (spec && n >= 4096 && b->text_bytes && b->text_bytes / n <= 5ull * (QS_MEAN + 1u) + 64u && getenv("DEXGPU_NO_SHORT") == NULL)
+    spec = false;                                        // (qs_short's to look at)
+  if (!spec)
+    { if ((e = dx_qv_prescan(ctx, b, entry0, p))) return e;
+      return dx_qv_hist(ctx, b, entry0, p, hist, totChar);
+    }
+  DX_HIP(ctx, hipSetDevice(ctx->device));
+  uint8_t *scr = (uint8_t *) ctx->d_hscr;
+  unsigned long long *d_hist = (unsigned long long *) scr;
+  unsigned long long *d_key  = (unsigned long long *) ctx->d_u64;
+  long long          *d_sub  = (long long *) (ctx->d_u64 + 2);
+  scan_dev           *sd     = (scan_dev *) (ctx->d_u64 + 56);
+  uint64_t           *d_gran = (uint64_t *) (scr + hbytes + ((n * 4 + 63) & ~(size_t) 63)) + ntiles;
+  const bool want_del = p->delChar < 0, want_sub = p->subChar < 0 && entry0 == 0;
+  qv_args a = make_args(b, -1, -1, 0);
+  if (want_del)
+    { DX_HIP(ctx, hipMemsetAsync(d_key, 0xff, 8, ctx->stream));
+      DX_LAUNCH(ctx, DX_K_QV_PRESCAN, k_qv_prescan_del, dx_grid_waves(ctx, n, 8), DX_BLOCK, a, entry0, d_key);
+    }
+  if (want_sub)
+    DX_LAUNCH(ctx, DX_K_QV_PRESCAN, k_qv_prescan_sub, 1, DX_BLOCK, a, d_sub);
+  hipLaunchKernelGGL(k_scan_state, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *) d_key, (const long long *) d_sub, *p,
+                     want_del ? 1 : 0, want_sub ? 1 : 0, sd);
+  DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 2) * 8, ctx->stream));
+  ctx->tk.eh_valid = 0;
+  if (!tokens_prepare(ctx, b, p, scr, hbytes, sd, guess))
+    { (void) hipStreamSynchronize(ctx->stream);
+      return dx_fail(ctx, DX_E_HIP, "dx_qv_scan: a launch failed (%s)", hipGetErrorString(hipGetLastError()));
+    }
+  tok_sink ts = { ctx->tk.del, ctx->tk.sub, ctx->tk.off, ctx->tk.info, d_hist + 6 * 256 + 1, ctx->tk.list };
+  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
+  DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
+  const uint64_t hist_blocks = (n + HIST_NWAVE - 1) / HIST_NWAVE, hist_room = (uint64_t) ctx->num_cu * HIST_PER_CU;
+  const int      grid = (int) (hist_blocks < hist_room ? hist_blocks : hist_room);
+  if (guess == SCAN_A)
+    DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, true>), grid, HIST_BLOCK, a, entry0, 0ll, 0ll, d_hist, d_hist + 6 * 256, d_ticket, ts,
+              ctx->tk.eh, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens);
+  else if (guess == SCAN_B)
+    DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, false>), grid, HIST_BLOCK, a, entry0, 0ll, 0ll, d_hist, d_hist + 6 * 256, d_ticket, ts,
+              ctx->tk.eh, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens);
+  else
+    DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<false, false>), grid, HIST_BLOCK, a, entry0, 0ll, 0ll, d_hist, d_hist + 6 * 256, d_ticket, ts,
+              (uint32_t *) NULL, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens);
+  uint64_t *host = ctx->h_pin;                           // [0, 1538): histograms, total, unusable; [1600): scan_dev; [1610): tokens the slots want
+  DX_HIP(ctx, hipMemcpyAsync(host, d_hist, (6 * 256 + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipMemcpyAsync(host + 1600, sd, sizeof(scan_dev), hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipMemcpyAsync(host + 1610, d_gran, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  scan_dev got;
+  memcpy(&got, host + 1600, sizeof(got));
+  p->delChar = got.delChar; p->subChar = got.subChar; p->del_first = got.del_first; p->sub_first = got.sub_first;
+  if ((got.inst & SCAN_MISS) || host[1610] > ctx->tk.cap_tokens)
+    return dx_qv_hist(ctx, b, entry0, p, hist, totChar);  // a guess failed (k_qv_hist has counted nothing): the plain way, the state now known
+  for (int s = 0; s < 6; s++)
+    for (int k = 0; k < 256; k++)
+      hist[s][k] += host[s * 256 + k];
+  *totChar += host[6 * 256];
+  ctx->tk.share8 = got.share8;
+  ctx->tk.text = b->d_text; ctx->tk.boff = b->d_off; ctx->tk.blen = b->d_len;
+  ctx->tk.n = b->n; ctx->tk.text_bytes = b->text_bytes; ctx->tk.pad = b->line_pad;
+  ctx->tk.delChar = p->delChar; ctx->tk.subChar = p->subChar;
+  ctx->tk.unusable = host[6 * 256 + 1];
+  DX_HIP(ctx, hipMemcpyAsync(ctx->tk.count, d_hist + 6 * 256 + 1, 8, hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->tk.valid = 1;
+  ctx->tk.eh_valid = guess != SCAN_G ? 1 : 0;
   return DX_OK;
 }
 
@@ -2258,10 +2481,10 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
     }
   // decode side (Read_Scheme's look-up table, QV.c:365-372, in two levels): ascending symbol order
   // so that for codes shared through the escape the last writer, 255, wins
-  std::vector<uint16_t> dec_v(6 * DX_DEC_SIZE, 0);                // per call: contexts run on their own threads
-  std::vector<uint32_t> lng_v(6 * (1 + DX_LONG_MAX), 0);
-  uint16_t *dec = dec_v.data();
-  uint32_t *lng = lng_v.data();
+  ctx->h_dec.assign(6 * DX_DEC_SIZE, 0);                          // the context's own: contexts run on their own threads
+  ctx->h_lng.assign(6 * (1 + DX_LONG_MAX), 0);
+  uint16_t *dec = ctx->h_dec.data();
+  uint32_t *lng = ctx->h_lng.data();
   for (int s = 0; s < 6; s++)
     { if ((s == DX_DRUN && c->delChar < 0) || (s == DX_SRUN && c->subChar < 0))
         continue;
@@ -2286,11 +2509,22 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
             }
         }
     }
+  // The encoders read d_tok only: it goes up now, through pinned words and without a wait (the stream orders it in front of
+  // whatever uses it; ev[17] says when the words may be written again).  The decode tables go up when a decode wants them
+  // (dx_dec_tables): 30 KB and a wait that an encode step -- scan, tables, encode, scan, ... -- never needed.
   DX_HIP(ctx, hipSetDevice(ctx->device));
-  DX_HIP(ctx, hipMemcpyAsync(ctx->d_tok, tok, sizeof(tok), hipMemcpyHostToDevice, ctx->stream));
-  DX_HIP(ctx, hipMemcpyAsync(ctx->d_dec, dec, dec_v.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
-  DX_HIP(ctx, hipMemcpyAsync(ctx->d_long, lng, lng_v.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (scan_pin(ctx) != NULL)
+    { uint32_t *up = (uint32_t *) (ctx->h_pin + 2048);
+      DX_HIP(ctx, hipEventSynchronize(ctx->ev[17]));
+      memcpy(up, tok, sizeof(tok));
+      DX_HIP(ctx, hipMemcpyAsync(ctx->d_tok, up, sizeof(tok), hipMemcpyHostToDevice, ctx->stream));
+      DX_HIP(ctx, hipEventRecord(ctx->ev[17], ctx->stream));
+    }
+  else
+    { DX_HIP(ctx, hipMemcpyAsync(ctx->d_tok, tok, sizeof(tok), hipMemcpyHostToDevice, ctx->stream));
+      DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  ctx->dec_stale = 1;
   for (int s = 0; s < 4; s++)
     { ctx->sym_type[s] = c->s[s].type;
       // most bits one symbol position can cost: its own code (with the 8-bit literal of an escape), and
@@ -2328,6 +2562,15 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
   ctx->subChar = c->subChar;
   ctx->sx.valid = 0;                                     // (a group index belongs to a stream of the tables before)
   if (ctx->op.pending) ctx->op.sx_idx = NULL;            // ... also the one an encode that has begun would arm at its end
+  return DX_OK;
+}
+
+int dx_dec_tables(dx_ctx *ctx)
+{ if (!ctx->dec_stale) return DX_OK;
+  DX_HIP(ctx, hipMemcpyAsync(ctx->d_dec, ctx->h_dec.data(), ctx->h_dec.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+  DX_HIP(ctx, hipMemcpyAsync(ctx->d_long, ctx->h_lng.data(), ctx->h_lng.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));        // (pageable sources: the context may rebuild them at once)
+  ctx->dec_stale = 0;
   return DX_OK;
 }
 
@@ -2572,8 +2815,8 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       for (uint64_t at = 0; at < n; at += gs)
         gb[++G] = at + gs < n ? at + gs : n;
     }
-  else if (n < 160000 || by_hist)                        // (sizes from the entries' own histograms take a moment: one group)
-    gb[++G] = n;
+  else if (n < 160000 || by_hist)                        // (sizes from the entries' own histograms take a moment: one group -- measured in
+    gb[++G] = n;                                         //  round 6: a sixteenth first and the rest's sizes beside its encoder, 12.3 against 12.2 ms)
   else                                                   // 1/16 of the batch, then 2.5 x the one before: a group's sizes
     { uint64_t size = n / 16, at = 0;                    // are ready before the encoder has finished the group before it
       if (size < 40000) size = 40000;

@@ -1236,6 +1236,10 @@ void k_qv_decode_sync(dec_args a, const uint16_t *g_dec, const uint32_t *g_long,
             const bool     fits = g < SG && ((need + 31u) >> 5) + 1u - w0 <= DY_WIN - 2u;
             const uint64_t miss = __ballot(!fits);
             const uint32_t cntl = miss ? (uint32_t) __ffsll((unsigned long long) miss) - 1u : 64u;      // (>= 1: one lane's bits are < 50 words)
+            if (cntl == 0u)                                // words that are no index of this stream (dx_qv_use_dindex takes the caller's arrays):
+              { if (lane == 0) atomicOr(status, 4u);       //   a corrupt stream, and never a round that advances by nothing
+                break;
+              }
             const bool     mine = (uint32_t) lane < cntl;
             uint32_t nw = mine ? ((need + 31u) >> 5) + 1u - w0 : 0u;
             nw = wave_total(wave_incl_max(nw));
@@ -1857,6 +1861,9 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   if (!d_in || !d_rec_off || !d_seg || !d_len || !d_out || !d_out_off)
     return dx_fail(ctx, DX_E_ARG, "dx_qv_decode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
+  { const int e = dx_dec_tables(ctx);                    // (dx_qv_set_coding leaves them on the host until a decode asks)
+    if (e) return e;
+  }
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   dec_args a;
   a.in = d_in; a.rec_off = d_rec_off; a.hdr_off = d_hdr_off; a.seg = d_seg; a.len = d_len; a.n = n;

@@ -688,6 +688,8 @@ void k_qv_sizes_hist(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, 
   // text, and its bits are its token symbols' plus its run characters' -- as many as the line has symbols that are no tokens.
   const bool     sub_plain = a.subChar < 0 && sub_made >= 0;
   const uint32_t l_subrc   = sub_plain ? (uint32_t) s_t.len[DX_SUB][sub_made & 0xff] : 0u;
+  const uint32_t need = ((l_ins0 | l_ins1) ? 1u : 0u) | ((l_mrg0 | l_mrg1) ? 2u : 0u) | ((l_del0 | l_del1) ? 4u : 0u) | ((l_sub0 | l_sub1) ? 8u : 0u) |
+                        ((l_dr0 | l_dr1) ? 16u : 0u) | ((!sub_plain && (l_sr0 | l_sr1)) ? 32u : 0u);      // the tables of which this lane's counters count
 
   // Eight entries a time, dealt to the waves in turn (every entry costs the same: no ticket counter, whose draws -- 11 ns
   // each, chip-wide -- were nine tenths of this kernel's time).  What an entry's sizes need beside its counters -- length, token counts, open runs, the last
@@ -722,9 +724,11 @@ void k_qv_sizes_hist(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, 
     for (uint32_t j = 0; j < 8u && r0 + j < a.n; j++)
       { if (!((usable >> j) & 1ull)) continue;
         const uint32_t *e32 = eh + (r0 + j) * EH_WORDS;
+        // (a lane whose two symbols have no code -- they occur nowhere in the file -- asks for nothing: of the twelve cache lines of
+        //  an entry's counters the symbols of a .quiva file touch six or seven)
         uint32_t v[6];
         #pragma unroll
-        for (int k = 0; k < 6; k++) v[k] = e32[64 * k + lane];
+        for (int k = 0; k < 6; k++) v[k] = (need >> k) & 1u ? e32[64 * k + lane] : 0u;
         uint32_t b_del = (v[2] & 0xffffu) * l_del0 + (v[2] >> 16) * l_del1 + (v[4] & 0xffffu) * l_dr0 + (v[4] >> 16) * l_dr1;
         uint32_t b_sub = (v[3] & 0xffffu) * l_sub0 + (v[3] >> 16) * l_sub1;
         if (!sub_plain) b_sub += (v[5] & 0xffffu) * l_sr0 + (v[5] >> 16) * l_sr1;

@@ -232,6 +232,15 @@ int dx_qv_prescan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx_qv_para
 int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, const dx_qv_params *p,
                uint64_t hist[6][256], uint64_t *totChar);
 
+/* QVcoding_Scan (QV.c:922-1023) over one batch in one call: dx_qv_prescan followed by dx_qv_hist -- the same *p, hist and
+ * *totChar as the two calls leave -- with ONE wait on the device instead of three.  The scan state stays on the device
+ * between the kernels; the two things the host has to decide before it knows that state (which of its histogram kernels
+ * fits the batch's run density, whether the token buffers it holds are large enough) it takes from the context's last
+ * scan, and the device checks them: a context's first batch, or a batch unlike the last one, simply goes through the
+ * two calls.  Nothing of one batch's RESULTS is carried to the next.  DEXGPU_NO_SCAN_GUESS=1: always the two calls.      */
+int dx_qv_scan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx_qv_params *p,
+               uint64_t hist[6][256], uint64_t *totChar);
+
 typedef struct
   { int32_t  type;              /* 0 normal, 2 truncated with escape code (QV.c:76-81) */
     uint32_t bits[256];

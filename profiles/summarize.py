@@ -38,7 +38,8 @@ ACCESS = {"k_qv_hist": "stream", "k_qv_encode_fast": "stream", "k_qv_encode": "s
           "k_qv_decode": "lanes", "k_qv_decode_plain": "lanes", "k_qv_decode_sub": "lanes", "k_qv_decode_runs": "lanes", "k_qv_decode_sync": "lanes",
           "k_qv_decode_tags": "stream",
           "k_add_one": "lanes", "k_gather_headers": "lanes", "k_gather_lines": "lanes", "k_tok_rooms": "stream",
-          "k_walk_find": "stream", "k_walk_pieces": "lanes", "k_walk_gather": "lanes", "k_walk_rooms": "lanes", "k_walk_index": "lanes"}
+          "k_walk_find": "stream", "k_walk_pieces": "lanes", "k_walk_gather": "lanes", "k_walk_rooms": "lanes", "k_walk_index": "lanes",
+          "k_qs_survey": "lanes", "k_qs_hist": "lanes", "k_qs_entries": "lanes"}
 
 
 def kname(full):

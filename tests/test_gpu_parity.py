@@ -160,6 +160,82 @@ def test_qv_scan_vs_oracle(ctx, seed, n, mean):
         assert (hist[s] == want[s]).all(), f"histogram {s}"
 
 
+def test_qv_scan_in_one_call_like_the_two(monkeypatch):
+    """dx_qv_scan == dx_qv_prescan + dx_qv_hist whatever the context guessed from its last batch: the guess holding (the same
+    kind of batch again), missing (another run density: the other instance of k_qv_hist), the token buffers too small (a
+    larger batch), no run character at all, a start state handed in -- and the encode that follows gives the oracle's bytes."""
+    cases = [("first", synth.make_quiva(150, seed=31, mean=3000)),
+             ("again", synth.make_quiva(150, seed=32, mean=3000)),
+             ("dense tokens", synth.make_quiva(150, seed=33, mean=3000, prof=synth.pacbio_profile(0.4, 0.35))),
+             ("sparse again", synth.make_quiva(140, seed=34, mean=3000)),
+             ("larger", synth.make_quiva(420, seed=35, mean=4000)),
+             ("smaller", synth.make_quiva(30, seed=36, mean=800))]
+    nodel = synth.make_quiva(60, seed=37, mean=2000)
+    t = bytearray(nodel.text)                                  # no 'N' tag anywhere: no delChar (QV.c:993-1002)
+    for i in range(60):
+        L_, o = int(nodel.len[i]), int(nodel.off[i])
+        t[o + L_ + 1: o + 2 * L_ + 1] = bytes(t[o + L_ + 1: o + 2 * L_ + 1]).replace(b"N", b"A").replace(b"n", b"a")
+    nodel.text = bytes(t)
+    cases.insert(4, ("no deletion run character", nodel))
+    with api.Context(0) as ctx:
+        for what, c in cases:
+            st = O.qv_scan(c.text)
+            b, keep = _upload_quiva(ctx, c)
+            p, hist, tot = ctx.qv_scan(b)
+            want = O.hist_array(st)
+            want[4:6] -= 1
+            assert (p.delChar, p.subChar, p.del_first, p.sub_first) == (st.delChar, st.subChar, st.del_first, st.sub_first), what
+            assert tot == st.totChar and (hist == want).all(), what
+            p2 = ctx.qv_prescan(b)                             # ... and the two calls, in the same context
+            h2, t2 = ctx.qv_hist(b, p2)
+            assert (p2.delChar, p2.subChar, p2.del_first, p2.sub_first) == (p.delChar, p.subChar, p.del_first, p.sub_first), what
+            assert t2 == tot and (h2 == hist).all(), what
+            assert ctx.dexqv(c.text) == O.dexqv(c.text), what
+        # a start state handed in (a later slice of a file): kept, as dx_qv_prescan keeps it
+        c = cases[1][1]
+        b, keep = _upload_quiva(ctx, c)
+        ctx.qv_scan(b)                                         # (something to guess from)
+        given = L.QVParams(ord("3"), ord("@"), 5, 7)
+        p, hist, tot = ctx.qv_scan(b, entry0=100, params=L.QVParams(ord("3"), ord("@"), 5, 7))
+        h2, t2 = ctx.qv_hist(b, given, entry0=100)
+        assert (p.delChar, p.subChar, p.del_first, p.sub_first) == (ord("3"), ord("@"), 5, 7)
+        assert t2 == tot and (h2 == hist).all()
+        monkeypatch.setenv("DEXGPU_NO_SCAN_GUESS", "1")        # the switch: the two calls
+        p, hist, tot = ctx.qv_scan(b)
+        st = O.qv_scan(c.text)
+        assert (p.delChar, p.subChar) == (st.delChar, st.subChar) and tot == st.totChar
+
+
+def test_dense_stretches_in_a_sparse_batch(ctx):
+    """A batch whose sampled run density picks the histogram kernel with the short token list (512 tokens a step), with
+    stretches in which nearly every symbol is a token: those entries' tokens are given up, their bytes are the oracle's."""
+    rng = np.random.Generator(np.random.PCG64(23))
+    c = synth.make_quiva(90, seed=41, mean=6000)
+    st0 = O.qv_scan(c.text)
+    txt = bytearray(c.text)
+    for i in range(90):
+        L_, o = int(c.len[i]), int(c.off[i])
+        if i % 9 != 2 or L_ < 4000:
+            continue
+        a0 = int(rng.integers(0, L_ - 3000))
+        n_ = int(rng.integers(700, 2900))                          # one to three steps' worth
+        for line, rc in ((0, st0.delChar), (4, st0.subChar)):
+            vals = rng.integers(40, 60, n_).astype(np.uint8)
+            vals[vals == rc] = 61
+            txt[o + line * (L_ + 1) + a0: o + line * (L_ + 1) + a0 + n_] = vals.tobytes()
+        txt[o + (L_ + 1) + a0: o + (L_ + 1) + a0 + n_] = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n_))
+    c.text = bytes(txt)
+    st = O.qv_scan(c.text)
+    b, keep = _upload_quiva(ctx, c)
+    p = ctx.qv_prescan(b)
+    hist, tot = ctx.qv_hist(b, p)
+    want = O.hist_array(st)
+    want[4:6] -= 1
+    assert (p.delChar, p.subChar) == (st.delChar, st.subChar) and tot == st.totChar and (hist == want).all()
+    assert ctx.dexqv(c.text) == O.dexqv(c.text)
+    assert ctx.undexqv(ctx.dexqv(c.text), upper=True).split(b"\n")[1::6] == c.text.split(b"\n")[1::6]
+
+
 def test_qv_scan_wide_bytes_and_long_runs(ctx):
     """Bytes >= 128 and runs >= 64 leave the conflict-free 32-copy bins of k_qv_hist for its plain
     tables; the file still encodes byte-identically."""

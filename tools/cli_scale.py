@@ -3,7 +3,7 @@
   reads; per run the wall time, the tool's own DEXGPU_TIMING marks (stages), and the effective rate; every round trip compared with
   its input (cmp); --ref: the reference's undexqv / undexta (oracle/_ref, one core) read the GPU tools' files back too.
 One JSON object on stdout (bench.py picks it up as cpu_baseline.cli_end_to_end_large when it is in profiles/)."""
-import json, os, re, subprocess, sys, time
+import atexit, json, os, re, shutil, signal, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -12,10 +12,22 @@ from dextractor_amd import api, synth
 
 GB = float(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 20.0
 REF = "--ref" in sys.argv
-D = "/dev/shm/cliscale"
+# a directory of this run's own (two runs on one box must not share files), removed however the run ends: the files are tens
+# of GB of RAM-backed tmpfs.  --dir D: the caller made D and removes it itself as well (bench.py does, after a timeout's kill)
+D = sys.argv[sys.argv.index("--dir") + 1] if "--dir" in sys.argv else tempfile.mkdtemp(prefix="cliscale.", dir="/dev/shm")
 BIN = os.path.join(ROOT, "dextractor_amd", "bin")
 REFBIN = os.path.join(ROOT, "oracle", "_ref")
 os.makedirs(D, exist_ok=True)
+atexit.register(shutil.rmtree, D, True)
+for _sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+    signal.signal(_sig, lambda *_: sys.exit(1))          # (sys.exit runs the atexit handler; SIGKILL cannot be caught: see --dir)
+
+
+def free_shm():
+    st = os.statvfs("/dev/shm")
+    return st.f_bavail * st.f_frsize
+
+
 mean, movie, seed = 10000, "m000_000", 20261003
 hlen = 1 + len(movie) + 1 + 8 + 1 + 7 + 1 + 7 + 6 + 3 + 1
 n = max(1, int(GB * 1e9 / (hlen + 5 * (mean + 1))))
@@ -77,6 +89,10 @@ def same(a, b):
 
 
 res = {"file": {}, "runs": {}}
+need = int(2.4 * GB * 1e9)                               # .quiva + its link's copy-free twin, the packed file, the unpacked text, the .fasta set
+if free_shm() < need:
+    print(json.dumps({"skipped": f"/dev/shm has {free_shm() >> 30} GiB free, the run wants {need >> 30}"}))
+    sys.exit(0)
 t0 = time.perf_counter()
 qbytes = make_files()
 fbytes = os.path.getsize(os.path.join(D, "s.fasta"))
@@ -119,5 +135,5 @@ for kind, pack, unpack, ext, px, uflags in (("quiva", "dexqv", "undexqv", ".quiv
         os.unlink(os.path.join(D, "s" + ext))
     res["file"][px[1:] + "_bytes"] = psize
     os.unlink(os.path.join(D, "s" + px)); os.unlink(os.path.join(D, "s0" + ext))
-subprocess.run(["rm", "-rf", D])
+shutil.rmtree(D, True)
 print(json.dumps(res))
