@@ -600,7 +600,7 @@ def dexqv_bench(args, rank, world, local, cpu=True, front=True, index_decode=Tru
     cd, prm = state["coding"], state["params"]
     hist_mine = state.get("hist_mine")
     tok = 0.0                                              # tokens of the run-coded lines (2 bytes each, written and read once)
-    if hist_mine is not None and not args.twopass and os.environ.get("DEXGPU_NO_TOKENS") is None:
+    if hist_mine is not None and not args.twopass and "no_tokens" not in (os.environ.get("DEXGPU_TEST") or ""):
         if prm.delChar >= 0:
             tok += float(hist_mine[0].sum() - hist_mine[0][prm.delChar])
         if prm.subChar >= 0:

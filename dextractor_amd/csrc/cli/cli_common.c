@@ -19,6 +19,7 @@
 
 #include "cli_common.h"
 #include "dexgpu.h"
+#include "../dx_env.h"
 
 typedef struct
   { const char *name, *flags, *src_ext, *dst_ext, *what, *usage;
@@ -291,8 +292,7 @@ static void *outfile_alloc(void *arg)
 static int outfile_begin(outfile *o, FILE *f, size_t expect)
 { memset(o, 0, sizeof(*o));
   o->fd = fileno(f); o->n = expect;
-  { const char *e = getenv("DEXGPU_OUTFILE_MIN");          /* (tests: that way from this size on) */
-    const size_t least = e != NULL && *e ? (size_t) strtoull(e, NULL, 10) : (size_t) 1 << 30;
+  { const size_t least = (size_t) dx_test_num("outfile_min", (long long) 1 << 30);          /* (tests: that way from this size on) */
     if (expect < least || expect == 0 || !file_is_ours(f)) return 0;
   }
   pthread_mutex_init(&o->mx, NULL);
@@ -514,8 +514,7 @@ int dex_tool_main(int tool, int argc, char *argv[])
              of it in this process, whose pages a mapping brings in one by one and gives back one by one (a second and a half
              of the two and a half a 20 GB file took) */
           struct stat st;
-          const char *fm = getenv("DEXGPU_FD_MIN");         /* (tests: that way from this size on) */
-          const off_t least = fm != NULL && *fm ? (off_t) strtoll(fm, NULL, 10) : ((off_t) 256 << 20);
+          const off_t least = (off_t) dx_test_num("fd_min", (long long) 256 << 20);         /* (tests: that way from this size on) */
           if (fstat(fileno(input), &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= least && st.st_size > 0 && file_is_ours(output))
             { uint64_t line = 0;
               int      code = 0, rc, fd = fileno(output);

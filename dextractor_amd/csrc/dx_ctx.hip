@@ -13,14 +13,15 @@ static char g_open_err[512] = "";
 hipError_t dx_hip_malloc(void **p, size_t bytes)
 { static int poison = -2;                                   // -2: not looked up yet, -1: off
   if (poison == -2)
-    { const char *e = getenv("DEXGPU_POISON");
-      poison = (e != NULL && e[0] != '\0') ? (int) (strtol(e, NULL, 0) & 0xff) : -1;
+    { const long long v = dx_test_num("poison", -1);
+      poison = v >= 0 ? (int) (v & 0xff) : -1;
     }
-  // DEXGPU_FAIL_MALLOC_OVER=<bytes> [DEXGPU_FAIL_MALLOC_UNDER=<bytes>] (tests): allocations beyond that size (and below the other) fail as if the device were full
-  const char *fo = getenv("DEXGPU_FAIL_MALLOC_OVER");       // (looked up every time: a test sets it around one call;
-  const char *fu = getenv("DEXGPU_FAIL_MALLOC_UNDER");      //  with _UNDER: only allocations below that size)
-  long long fail_over = (fo != NULL && fo[0] != '\0') ? strtoll(fo, NULL, 0) : -1;
-  if (fail_over >= 0 && fu != NULL && fu[0] != '\0' && (long long) bytes >= strtoll(fu, NULL, 0)) fail_over = -1;
+  // DEXGPU_TEST=fail_malloc_over=<bytes>[,fail_malloc_under=<bytes>] (tests): allocations beyond that size (and below the other) fail as
+  // if the device were full (looked up every time: a test sets it around one call)
+  long long fail_over = dx_test_num("fail_malloc_over", -1);
+  { const long long under = dx_test_num("fail_malloc_under", -1);
+    if (fail_over >= 0 && under >= 0 && (long long) bytes >= under) fail_over = -1;
+  }
   const hipError_t rc = (fail_over >= 0 && bytes > (size_t) fail_over) ? hipErrorOutOfMemory : hipMalloc(p, bytes);
   if (rc != hipSuccess)                                    // the runtime keeps a failed call's error until it is read: the next
     { (void) hipGetLastError();                            // launch's hipGetLastError() would report THIS one (a caller that
@@ -321,7 +322,7 @@ extern "C" int dx_h2d_fd(dx_ctx *ctx, void *d_dst, int fd, uint64_t foff, size_t
 }
 
 static int h2d_from(dx_ctx *ctx, void *d_dst, const void *src, int fd, uint64_t foff, size_t bytes)
-{ if ((fd >= 0 || bytes >= DX_UP_MIN) && (fd >= 0 || getenv("DEXGPU_PLAIN_H2D") == NULL))
+{ if ((fd >= 0 || bytes >= DX_UP_MIN) && (fd >= 0 || !dx_test_on("plain_h2d")))
     { DX_HIP(ctx, hipSetDevice(ctx->device));
       if (ctx->h_up == NULL && hipHostMalloc((void **) &ctx->h_up, 2 * DX_UP_THREADS * DX_UP_CHUNK, hipHostMallocDefault) != hipSuccess)
         { (void) hipGetLastError(); ctx->h_up = NULL; }
@@ -509,7 +510,7 @@ extern "C" int dx_d2h_stream(dx_ctx *ctx, const void *d_src, size_t bytes, dx_si
   { int e = dx_after_pending(ctx);
     if (e) return e;
   }
-  if (ctx->sink_threads > 1 && bytes >= DX_MT_MIN && getenv("DEXGPU_PLAIN_D2H") == NULL)
+  if (ctx->sink_threads > 1 && bytes >= DX_MT_MIN && !dx_test_on("plain_d2h"))
     { const int rc = d2h_stream_mt(ctx, d_src, bytes, sink, user, ctx->sink_threads);
       if (rc <= 0) return rc;                              // (1: no pinned memory or no thread -- nothing has been passed on: the one-thread way)
     }

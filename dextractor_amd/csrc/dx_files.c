@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include "dexgpu.h"
+#include "dx_env.h"
 
 void dx_file_free(void *p) { free(p); }
 
@@ -57,12 +58,10 @@ static int dupload(dpool *pool, const void *src, size_t bytes, void **out)
   return rc;
 }
 
-/* The encoder of the file drivers is dx_qv_encode_onepass (no size pass; the same bytes).  DEXGPU_TWOPASS
- * in the environment selects dx_qv_sizes + dx_qv_encode instead (kept for comparison and as a cross-check). */
+/* The encoder of the file drivers is dx_qv_encode_onepass (no size pass; the same bytes).  DEXGPU_TEST=twopass
+ * selects dx_qv_sizes + dx_qv_encode instead (the two-pass API, kept as a cross-check). */
 static int two_pass(void)
-{ const char *e = getenv("DEXGPU_TWOPASS");
-  return e != NULL && e[0] != '\0' && e[0] != '0';
-}
+{ return dx_test_on("twopass"); }
 
 static void dfree_all(dpool *pool)
 { int i;
@@ -120,7 +119,7 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
   /* index: on the GPU for large images (newline scan, record extents there; only header lines come
      back), on the host for small ones and for anything the GPU front end rejects (exact message) */
   if (n > 0 && !sliced) TRY(dupload(&pool, text, n, &d_text));
-  if (!sliced && n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL && !ends_with_a_header(text, n))
+  if (!sliced && n >= DX_GPU_INDEX_MIN && !dx_test_on("host_index") && !ends_with_a_header(text, n))
     { uint64_t *go = NULL; uint32_t *gt = NULL, *gs = NULL;
       rc = dx_index_seq_device(ctx, arrow, d_text, n, &go, &gt, &gs, &cnt, &hdr4, &cnr4, &plen, errline, errcode);
       if (rc == DX_OK)
@@ -818,7 +817,7 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, int fd, size_t n, int lo
     if (cap)
       return text == NULL ? DX_E_AGAIN : dexqv_sliced(ctx, text, n, lossy, cap, out, sink, user, out_len, errline, errcode);
   }
-  if (text == NULL && (n < DX_GPU_INDEX_MIN || getenv("DEXGPU_HOST_INDEX") != NULL)) return DX_E_AGAIN;
+  if (text == NULL && (n < DX_GPU_INDEX_MIN || dx_test_on("host_index"))) return DX_E_AGAIN;
 
   /* pass 1 of the reference (QVcoding_Scan, dexqv.c:81-82): validate + index.  Large images are
    * indexed on the GPU (newline scan + structure checks there, only the header lines come back);
@@ -840,7 +839,7 @@ static int dexqv_core(dx_ctx *ctx, const uint8_t *text, int fd, size_t n, int lo
         }
     }
   fmark("dexqv: text on the device");
-  if (n >= DX_GPU_INDEX_MIN && getenv("DEXGPU_HOST_INDEX") == NULL)
+  if (n >= DX_GPU_INDEX_MIN && !dx_test_on("host_index"))
     { uint64_t *go = NULL; uint32_t *gl = NULL;
       rc = dx_index_quiva_device(ctx, d_text, n, &go, &gl, &cnt, &hdr4, &plen, errline, errcode);
       if (rc == DX_OK && cnt > 0)
@@ -1020,11 +1019,10 @@ int dx_file_undexqv_plan_on(dx_ctx *ctx, const uint8_t *img, size_t n, dx_undexq
   uint16_t key;
   size_t   at = 2, used = 0;
   int      rc, keep = 0;
-  const char *e = getenv("DEXGPU_DEVICE_WALK_MIN");
-  const size_t least = e != NULL && *e ? (size_t) strtoull(e, NULL, 10) : DX_DEVICE_WALK_MIN;
+  const size_t least = (size_t) dx_test_num("device_walk_min", (long long) DX_DEVICE_WALK_MIN);
 
   if (img == NULL || plan == NULL || out_len == NULL) return DX_E_ARG;
-  if (ctx == NULL || n < least || n < 16 || getenv("DEXGPU_HOST_WALK") != NULL)
+  if (ctx == NULL || n < least || n < 16 || dx_test_on("host_walk"))
     return dx_file_undexqv_plan(img, n, plan, out_len);
   memcpy(&key, img, 2);
   if (key != 0x55aa && key != 0xaa55)
@@ -1094,9 +1092,7 @@ int dx_file_undexqv_plan(const uint8_t *img, size_t n, dx_undexqv_plan **plan, s
      (dx_qv_use_index below): 31 instead of 50 ms of kernels per 14 GB of records -- but the walk is 45 % longer with it
      and the index is another 30 % to upload, and from file to file that costs more than it saves (undexqv of a 1 GB
      .quiva: 0.54-0.59 s with, 0.44-0.48 s without; profiles/r03c_cli_timing.txt), so it is off unless asked for */
-  { const char *e = getenv("DEXGPU_WALK_INDEX");
-    rc = dx_qv_walk_indexed(img, n, &p->x, e != NULL && e[0] != '\0' && e[0] != '0');
-  }
+  rc = dx_qv_walk_indexed(img, n, &p->x, dx_test_on("walk_index"));
   if (rc != DX_OK) { free(p); return rc; }
   p->img = img; p->n = n;
   if ((rc = plan_layout(p)) != DX_OK) goto fail;
@@ -1241,7 +1237,7 @@ int dx_file_undexqv_run(dx_ctx *ctx, const dx_undexqv_plan *p, int upper, dx_sin
             }
         }
       if (cap)
-        return undexqv_sliced(ctx, p, upper, sink, user, cap, getenv("DEXGPU_SLICE_INPUT") != NULL && !PLAN_HAS_IMAGE(p) ? 0 : whole_in);   /* (DEXGPU_SLICE_INPUT: tests) */
+        return undexqv_sliced(ctx, p, upper, sink, user, cap, dx_test_on("slice_input") && !PLAN_HAS_IMAGE(p) ? 0 : whole_in);   /* (DEXGPU_TEST=slice_input) */
     }
   if (p->x.n > 0)
     { TRY(dx_qv_set_coding(ctx, &p->x.coding, 0));
@@ -1604,9 +1600,8 @@ int dx_file_dexqv_sharded(dx_ctx **ctxs, int nctx, const uint8_t *text, size_t n
   if (ctxs == NULL || nctx < 1 || out == NULL || out_len == NULL) return DX_E_ARG;
   if (nctx == 1) return dx_file_dexqv(ctxs[0], text, n, lossy, out, out_len, errline, errcode);
   *out = NULL; *out_len = 0;
-  { const char *e = getenv("DEXGPU_SHARD_BYTES_MIN");     /* (tests: the by-bytes way on small files) */
-    const size_t least = e != NULL && *e ? (size_t) strtoull(e, NULL, 10) : DX_SHARD_BYTES_MIN;
-    by_bytes = n / (size_t) nctx >= least && n / (size_t) nctx >= 4096 && getenv("DEXGPU_HOST_INDEX") == NULL;
+  { const size_t least = (size_t) dx_test_num("shard_bytes_min", (long long) DX_SHARD_BYTES_MIN);     /* (tests: the by-bytes way on small files) */
+    by_bytes = n / (size_t) nctx >= least && n / (size_t) nctx >= 4096 && !dx_test_on("host_index");
   }
 again:
   memset(&a, 0, sizeof(a));

@@ -7,6 +7,40 @@
 #include <string.h>
 
 #include "dexgpu.h"
+#include "dx_env.h"
+
+/* ---- DEXGPU_TEST (dx_env.h) ------------------------------------------------------------------------------------------- */
+const char *dx_test_str(const char *key)
+{ static __thread char val[160];
+  const char *e = getenv("DEXGPU_TEST");
+  const size_t kl = strlen(key);
+  if (e == NULL) return NULL;
+  while (*e)
+    { const char *t = e;
+      size_t n;
+      while (*e && *e != ',' && *e != ' ') e++;
+      n = (size_t) (e - t);
+      if (n >= kl && memcmp(t, key, kl) == 0 && (n == kl || t[kl] == '='))
+        { size_t vl = n == kl ? 0 : n - kl - 1;
+          if (vl >= sizeof(val)) vl = sizeof(val) - 1;
+          memcpy(val, t + kl + (n == kl ? 0 : 1), vl);
+          val[vl] = '\0';
+          return val;
+        }
+      while (*e == ',' || *e == ' ') e++;
+    }
+  return NULL;
+}
+
+int dx_test_on(const char *key)
+{ const char *v = dx_test_str(key);
+  return v != NULL && v[0] != '0';
+}
+
+long long dx_test_num(const char *key, long long dflt)
+{ const char *v = dx_test_str(key);
+  return v != NULL && v[0] != '\0' ? strtoll(v, NULL, 0) : dflt;
+}
 
 /* ==========================================================================================
  *  record framing (dexta.c:187-198, dexar.c:159-163 + 193-204, dexqv.c:128-139)
@@ -1336,7 +1370,7 @@ int dx_qv_walk_indexed(const uint8_t *img, size_t n, dx_qv_index *x, int want_in
   rc = DX_E_MISMATCH;
   if (threads > 1 && x->newv && n - at >= 4 * WALK_PIECE_MIN)
     rc = walk_parallel(&t, img, n, at, threads, &L);
-  if (rc == DX_E_MISMATCH && getenv("DEXGPU_WALK_REQUIRE_PARALLEL") != NULL)
+  if (rc == DX_E_MISMATCH && dx_test_on("walk_require_parallel"))
     goto fail;                                            /* (tests: no silent front-to-back walk) */
   if (rc == DX_E_MISMATCH)
     { free(L.r); free(L.gx.w); free(L.gx.tb); free(L.gx.ts);

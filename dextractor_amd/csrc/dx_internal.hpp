@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "dexgpu.h"
+#include "dx_env.h"
 
 #define DX_WAVE          64
 #define DX_BLOCK         256                 // 4 waves per workgroup

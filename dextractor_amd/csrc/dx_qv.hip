@@ -1812,19 +1812,6 @@ __device__ __forceinline__ uint32_t encode_all_tags(wave_out &ot, const uint8_t 
   return finish_tags(ot);
 }
 
-// Scratch mode of k_qv_encode (dx_qv_encode_onepass): the entry is written compactly (del, ins,
-// mrg, sub; the tags at the slot's end) into a slot of a size bounded from the tables, and the
-// sizes it turns out to have are recorded, instead of being taken from a size pass.
-struct enc_scratch
-{ uint8_t        *base;        // NULL: direct mode (offsets and sizes from k_qv_sizes)
-  const uint64_t *slot_off;    // n + 1
-  uint32_t       *seg_out;     // n x 5
-  uint32_t       *rec_size;    // n
-  uint64_t        lo, hi;      // the slot offsets this launch may use: [lo, hi) is its scratch region (see slot_sane)
-};
-
-__host__ __device__ __forceinline__ uint32_t tag_room(uint32_t L) { return (((L + 3u) >> 2) + 7u) & ~3u; }
-
 // The encoders form addresses from index arrays (entry offsets and lengths, slot offsets, token slots).  An index that
 // does not hold together is reported (status bit 6) and its entry skipped -- never followed into memory: a kernel that
 // faults takes the process, and possibly the node's GPUs, with it.  Wave-uniform tests on values the wave holds anyway.
@@ -1834,15 +1821,11 @@ __device__ __forceinline__ bool entry_sane(const qv_args &a, uint64_t r, uint32_
   const uint64_t o = a.off[r], span = 4ull * ((uint64_t) L + a.pad) + L;
   return o <= a.text_bytes && span <= a.text_bytes - o;
 }
-__device__ __forceinline__ bool slot_sane(const enc_scratch &sc, uint64_t r, uint32_t L)
-{ const uint64_t s0 = sc.slot_off[r], s1 = sc.slot_off[r + 1];
-  return s0 >= sc.lo && s1 <= sc.hi && s1 >= s0 && s1 - s0 >= tag_room(L);
-}
 
 __global__ __launch_bounds__(DX_BLOCK, ENC_WAVES)
 void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off,
                  const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint32_t *status, uint32_t *ticket,
-                 enc_scratch sc, const uint32_t *only_list, const unsigned long long *only_count, uint64_t first_entry,
+                 const uint32_t *only_list, const unsigned long long *only_count, uint64_t first_entry,
                  const uint32_t *only_info, uint64_t out_cap, sub_sink sx)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_stok[6][256];
@@ -1898,36 +1881,23 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
             continue;                                    // (listed for a run character the coding dropped: the fast kernel has it)
         }
       const uint32_t  L   = a.len[r];
-      const bool      S   = sc.base != NULL;             // scratch mode
       const uint32_t *sg  = seg + 5 * r;
-      uint32_t       *sgw = sc.seg_out + 5 * r;
-      uint8_t        *dst, *tag_at = NULL;
-      uint32_t        sum = 0;
-      if (!entry_sane(a, r, L))                          // (two tests, not one: the joint condition costs four registers,
-        { if (lane == 0) atomicOr(status, DX_ST_INDEX);  //  and 112 is this kernel's budget beside the compaction)
-          continue;
-        }
-      if (S && !slot_sane(sc, r, L))
+      uint8_t        *dst;
+      if (!entry_sane(a, r, L))
         { if (lane == 0) atomicOr(status, DX_ST_INDEX);
           continue;
         }
-      if (S)
-        { dst    = sc.base + sc.slot_off[r];
-          tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
+      if (rec_off[r + 1] > out_cap)                      // (dx_qv_encode_onepass: d_out too small) report, never overrun
+        { if (lane == 0) atomicOr(status, 8u);
+          continue;
         }
-      else
-        { if (rec_off[r + 1] > out_cap)                  // (dx_qv_encode_onepass: d_out too small) report, never overrun
-            { if (lane == 0) atomicOr(status, 8u);
-              continue;
-            }
-          dst = out + rec_off[r];
-          if (hdr != NULL)                               // record framing (dexqv.c:128-139)
-            { const uint64_t h0 = hdr_off[r];
-              const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
-              for (uint32_t k = lane; k < hl; k += 64)
-                dst[k] = hdr[h0 + k];
-              dst += hl;
-            }
+      dst = out + rec_off[r];
+      if (hdr != NULL)                                   // record framing (dexqv.c:128-139)
+        { const uint64_t h0 = hdr_off[r];
+          const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
+          for (uint32_t k = lane; k < hl; k += 64)
+            dst[k] = hdr[h0 + k];
+          dst += hl;
         }
       const uint8_t *p1   = line_ptr(a, r, L, 1);
       const bool     over = can_overread(a, line_ptr(a, r, L, 4), L);
@@ -1942,7 +1912,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
           const uint8_t  *p    = line_ptr(a, r, L, line);
           const int       rci  = q == 0 ? a.delChar : (q == 3 ? a.subChar : -1);
           const uint32_t *tab  = s_tok[q];
-          const uint32_t  want = S ? 0u : sg[line];
+          const uint32_t  want = sg[line];
           const uint32_t  mask = !a.lossy ? 0xffu : (q == 1 ? 0xfeu : (q == 2 ? 0xfcu : 0xffu));   // QV.c:1406-1415
           o.seg = dst; o.wordbase = 0; o.winbits = 0;
           uint32_t got, pos = 16u * lane;
@@ -1955,7 +1925,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
                 { sx.idx[sx.off[r] + run_base(L) + (q == 0 ? 0u : 1u)] = RUN_NONE;
                   atomicAdd(sx.none, 1u);
                 }
-              ot.seg = S ? tag_at : dst + want; ot.wordbase = 0; ot.winbits = 0;
+              ot.seg = dst + want; ot.wordbase = 0; ot.winbits = 0;
               u32x4 c = fetch(p, pos, L, over), t = c;
               if (tags) t = fetch(p1, pos, L, over);
               for (uint32_t base = 0; base < L; base += DX_STEP)
@@ -1972,8 +1942,7 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
               got = finish_words(o, last);
               if (tags)
                 { const uint32_t tb = finish_tags(ot);
-                  if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
-                  else   { bad |= tb ^ sg[1]; dst += sg[1]; }
+                  bad |= tb ^ sg[1]; dst += sg[1];
                 }
             }
           else                                           // Encode
@@ -1996,103 +1965,17 @@ void k_qv_encode(qv_args a, const uint32_t *g_tok, const uint8_t *hdr, const uin
 #undef PLAIN_LOOP
               got = finish_words(o, last_piece_plain(tab, p, L, mask));
               if (q == 0)                                // no delChar: the whole tag line is packed
-                { ot.seg = S ? tag_at : dst + want; ot.wordbase = 0; ot.winbits = 0;
+                { ot.seg = dst + want; ot.wordbase = 0; ot.winbits = 0;
                   const uint32_t tb = encode_all_tags(ot, p1, L, over);
-                  if (S) { if (lane == 0) sgw[1] = tb; sum += tb; }
-                  else   { bad |= tb ^ sg[1]; dst += sg[1]; }
+                  bad |= tb ^ sg[1]; dst += sg[1];
                 }
             }
-          if (S)
-            { if (lane == 0) sgw[line] = got;
-              sum += got;
-              dst += got;
-            }
-          else
-            { bad |= got ^ want;
-              dst += want;
-            }
-        }
-      if (S)
-        { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
-          if (lane == 0)
-            sc.rec_size[r] = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
+          bad |= got ^ want;
+          dst += want;
         }
       if (bad && lane == 0)
-        atomicOr(status, 2u);                            // sizes disagree with k_qv_sizes / slot overflow
+        atomicOr(status, 2u);                            // sizes disagree with the size kernel's
     }
-}
-
-// per-entry slot size for the scratch mode: sum over the streams of the table-derived bound
-__global__ __launch_bounds__(DX_BLOCK)
-void k_qv_bounds(const uint32_t *len, uint64_t n, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t *bound,
-                 unsigned long long *too_long)
-{ const uint64_t i = (uint64_t) blockIdx.x * DX_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t L = len[i];
-  const uint64_t bits = L * b0 + L * b1 + L * b2 + L * b3;
-  uint64_t bytes = ((bits + 7) >> 3) + 4 * 20 + tag_room((uint32_t) L);           // + partial and pad words, trailing run tokens
-  bytes = (bytes + 127) & ~(uint64_t) 127;                                       // (whole 128-byte lines: no cache line holds two entries' slots,
-                                                                                 //  and the compaction's 16-byte loads of a slot start on a line)
-  if (bytes >= (1ull << 32))                                                     // a slot is addressed in 32 bits: such an entry (some
-    { atomicMax(too_long, (unsigned long long) L);                               // 3.5e8 symbols at 96 bits per position) is refused, never
-      bytes = 16;                                                                // given a wrapped bound
-    }
-  bound[i] = (uint32_t) bytes;
-}
-
-// bytes [0, nbytes) from src to dst, both arbitrarily aligned, by one wave: a byte-wise head up to
-// dst's 16-byte boundary, then aligned 16-byte stores fed by unaligned loads, four in flight per lane
-__device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint32_t nbytes)
-{ const uint32_t lane = (uint32_t) lane_id();
-  uint32_t head = (uint32_t) ((16u - ((uintptr_t) dst & 15u)) & 15u);
-  if (head > nbytes) head = nbytes;
-  if (lane < head) dst[lane] = src[lane];
-  dst += head; src += head; nbytes -= head;
-  const uint32_t n16 = nbytes >> 4;
-  uint32_t k = lane;
-  for (; k + 192u < n16; k += 256u)
-    { const u32x4 v0 = *(const u32x4_u *) (src + 16ull * k),          v1 = *(const u32x4_u *) (src + 16ull * (k + 64u));
-      const u32x4 v2 = *(const u32x4_u *) (src + 16ull * (k + 128u)), v3 = *(const u32x4_u *) (src + 16ull * (k + 192u));
-      *(u32x4 *) (dst + 16ull * k)          = v0; *(u32x4 *) (dst + 16ull * (k + 64u))  = v1;
-      *(u32x4 *) (dst + 16ull * (k + 128u)) = v2; *(u32x4 *) (dst + 16ull * (k + 192u)) = v3;
-    }
-  for (; k < n16; k += 64u)
-    *(u32x4 *) (dst + 16ull * k) = *(const u32x4_u *) (src + 16ull * k);
-  for (uint32_t t = 16u * n16 + lane; t < nbytes; t += 64u)
-    dst[t] = src[t];
-}
-
-#define COMPACT_BATCH 8u
-#ifndef COMPACT_WAVES_PER_CU
-#define COMPACT_WAVES_PER_CU 16                         // (a copy kernel: few registers, no LDS)
-#endif
-// scratch slots -> the record stream: header, del, tags, ins + mrg + sub (QV.c:1393-1423 order)
-__global__ __launch_bounds__(DX_BLOCK)
-void k_qv_compact(uint64_t n, const uint32_t *len, const uint8_t *scratch, const uint64_t *slot_off, const uint32_t *seg,
-                  const uint64_t *rec_off, const uint8_t *hdr, const uint64_t *hdr_off, uint8_t *out, uint64_t out_cap,
-                  uint32_t *status, uint32_t *ticket, uint32_t units)
-{ for (uint64_t r0 = next_unit(ticket, units), nxt; r0 < n; r0 = nxt)
-  { nxt = next_unit(ticket, units);                      // (one same-address atomic costs ~11 ns chip-wide; units: 8 of 10 kb)
-    for (uint64_t r = r0; r < r0 + units && r < n; r++)
-    { const uint32_t *sg  = seg + 5 * r;
-      const uint8_t  *src = scratch + slot_off[r];
-      uint8_t        *dst = out + rec_off[r];
-      if (rec_off[r + 1] > out_cap)                      // d_out is too small: report, never overrun
-        { if (lane_id() == 0) atomicOr(status, 8u);
-          continue;
-        }
-      if (hdr != NULL)
-        { const uint64_t h0 = hdr_off[r];
-          const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
-          for (uint32_t k = (uint32_t) lane_id(); k < hl; k += 64)
-            dst[k] = hdr[h0 + k];
-          dst += hl;
-        }
-      wave_copy(dst, src, sg[0]);
-      wave_copy(dst + sg[0], scratch + slot_off[r + 1] - tag_room(len[r]), sg[1]);
-      wave_copy(dst + sg[0] + sg[1], src + sg[0], sg[2] + sg[3] + sg[4]);
-    }
-  }
 }
 
 #include "dx_qv_fast.hpp"
@@ -2194,9 +2077,7 @@ extern "C" int dx_qv_lossy_text(dx_ctx *ctx, const dx_qv_batch *b)
 // to *sd, `guess` is the instance the host is about to launch, and nothing comes back to the host here: the buffers are
 // taken as they are (dx_qv_scan has seen to the entries' arrays; whether the tokens fit is k_qv_hist's to say).
 static bool tokens_off()
-{ const char *off = getenv("DEXGPU_NO_TOKENS");
-  return off != NULL && off[0] != '\0' && off[0] != '0';
-}
+{ return dx_test_on("no_tokens") != 0; }
 
 static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params *p, uint8_t *scr, size_t scr_at,
                            scan_dev *sd = NULL, uint32_t guess = 0)
@@ -2226,7 +2107,7 @@ static bool tokens_prepare(dx_ctx *ctx, const dx_qv_batch *b, const dx_qv_params
     hipLaunchKernelGGL(k_qv_density, dim3((unsigned) ((sample + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream,
                        a, stride, d_cnt, (const scan_dev *) sd);
     hipLaunchKernelGGL(k_tok_rooms, dim3((unsigned) ((n + DX_BLOCK - 1) / DX_BLOCK)), dim3(DX_BLOCK), 0, ctx->stream,
-                       (const uint32_t *) b->d_len, n, d_cnt, d_room, sd, guess, getenv("DEXGPU_HIST_SHARED_TOKENS") != NULL ? 1 : 0);
+                       (const uint32_t *) b->d_len, n, d_cnt, d_room, sd, guess, dx_test_on("hist_shared_tokens"));
   }
   hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned) ntiles), dim3(DX_BLOCK), 0, ctx->stream, (const uint32_t *) d_room, n, d_tile);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(DX_BLOCK), 0, ctx->stream, d_tile, ntiles, d_gran);
@@ -2318,7 +2199,7 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
         ctx->tk.cap_eh = n;
     }
   uint32_t inst = SCAN_G;
-  if (fast_hist && ctx->tk.share8 <= HIST_SHARE_A && getenv("DEXGPU_HIST_SHARED_TOKENS") == NULL)   // (tokens at most ~28 % of the denser line: run densities from ~0.72 up)
+  if (fast_hist && ctx->tk.share8 <= HIST_SHARE_A && !dx_test_on("hist_shared_tokens"))   // (tokens at most ~28 % of the denser line: run densities from ~0.72 up)
     { inst = SCAN_A;
       DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, true>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
                 a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh,
@@ -2379,10 +2260,10 @@ extern "C" int dx_qv_scan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx
   const size_t   hbytes = ((6 * 256 + 2) * 8 + 255) & ~(size_t) 255;
   const size_t   want   = hbytes + ((n * 4 + 63) & ~(size_t) 63) + (ntiles + 2) * 8 + 64;
   const uint32_t guess  = ctx->scan.inst;
-  bool spec = n > 0 && ctx->scan.valid && !tokens_off() && getenv("DEXGPU_NO_SCAN_GUESS") == NULL &&
+  bool spec = n > 0 && ctx->scan.valid && !tokens_off() && !dx_test_on("no_scan_guess") &&
               ctx->tk.cap_entries >= n && ctx->tk.cap_tokens > 0 && ctx->tk.del != NULL && ctx->tk.sub != NULL &&
               (guess == SCAN_G || ctx->tk.cap_eh >= n) && want <= ctx->hscr_bytes && scan_pin(ctx) != NULL;
-  if (spec && n >= 4096 && b->text_bytes && b->text_bytes / n <= 5ull * (QS_MEAN + 1u) + 64u && getenv("DEXGPU_NO_SHORT") == NULL)
+  if (spec && n >= 4096 && b->text_bytes && b->text_bytes / n <= 5ull * (QS_MEAN + 1u) + 64u && !dx_test_on("no_short"))
     spec = false;                                        // (qs_short's to look at)
   if (!spec)
     { if ((e = dx_qv_prescan(ctx, b, entry0, p))) return e;
@@ -2554,7 +2435,7 @@ extern "C" int dx_qv_set_coding(dx_ctx *ctx, const dx_qv_coding *c, int lossy)
           { if (lo < 0) lo = x;
             hi = x;
           }
-      ctx->pair_lo[s] = (lo >= 0 && lo <= 192 && hi - lo < 64 && getenv("DEXGPU_NO_PAIRS") == NULL) ? (uint32_t) lo : 0xffffffffu;
+      ctx->pair_lo[s] = (lo >= 0 && lo <= 192 && hi - lo < 64 && !dx_test_on("no_pairs")) ? (uint32_t) lo : 0xffffffffu;
     }
   ctx->coding_set = 1;
   ctx->lossy   = lossy != 0;
@@ -2650,6 +2531,43 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
   return DX_OK;
 }
 
+// every record of the batch from the text, in place (sizes and offsets given): the lane-per-entry kernels for a batch of short
+// entries, else k_qv_encode -- with the plain lines' group index when sx_idx is given (the wave-per-entry kernel only)
+static int encode_text(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                       const uint64_t *d_rec_off, const uint32_t *d_seg, uint8_t *d_out, uint64_t out_cap, uint32_t *sx_idx)
+{ int e;
+  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+  qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
+  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
+  bool brief = false;
+  const uint8_t *perm = NULL;
+  if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
+  if (sx_idx != NULL) brief = false;                     // (the lane-per-entry kernels leave no index)
+  DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
+  if (brief && ctx->tok_wide)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, b->n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+              d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
+  else if (brief)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, b->n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+              d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
+  else
+  DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
+            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket,
+            (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, out_cap,
+            sub_sink{ sx_idx, sx_idx ? (const uint64_t *) ctx->sx.off : (const uint64_t *) NULL, ctx->sx.none });
+  uint32_t st = 0;
+  DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (st & DX_ST_INDEX)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode: an entry's offset and length reach beyond text_bytes");
+  if (st & 8u)
+    return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode: the record stream does not fit d_out (%llu bytes)", (unsigned long long) out_cap);
+  if (st & 2u)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode: a segment's size differs from what dx_qv_sizes "
+                                       "computed (d_seg / coding do not belong to this batch?)");
+  return DX_OK;
+}
+
 extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                             const uint64_t *d_rec_off, const uint32_t *d_seg, uint8_t *d_out)
 { int e = check_batch(ctx, b, "dx_qv_encode");
@@ -2663,31 +2581,7 @@ extern "C" int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_
   if (!d_rec_off || !d_seg || !d_out) return dx_fail(ctx, DX_E_ARG, "dx_qv_encode: NULL device pointer");
   DX_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->sx.out == (const void *) d_out) ctx->sx.valid = 0;            // (the two-pass encoder leaves no group index)
-  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
-  qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
-  uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
-  bool brief = false;
-  const uint8_t *perm = NULL;
-  if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
-  DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
-  if (brief && ctx->tok_wide)
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, b->n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
-              d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
-  else if (brief)
-    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, b->n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
-              d_rec_off, (uint32_t *) d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
-  else
-  DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, b->n, 4 * ENC_WAVES), DX_BLOCK,
-            a, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ctx->d_status, d_ticket, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 },
-            (const uint32_t *) NULL, (const unsigned long long *) NULL, (uint64_t) 0, (const uint32_t *) NULL, ~(uint64_t) 0,
-            sub_sink{ NULL, NULL, NULL });
-  uint32_t st = 0;
-  DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
-  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (st & 2u)
-    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode: a segment's size differs from what dx_qv_sizes "
-                                       "computed (d_seg / coding do not belong to this batch?)");
-  return DX_OK;
+  return encode_text(ctx, b, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, ~(uint64_t) 0, (uint32_t *) NULL);
 }
 
 // grid of k_qv_encode_fast: FAST_BLOCK-thread workgroups, 4 * FAST_WAVES waves per CU, no more waves than entries
@@ -2700,24 +2594,6 @@ static int fast_grid(dx_ctx *ctx, uint64_t entries)
 }
 
 #define ONEPASS_MAX_GROUPS 64
-#define ONEPASS_REGION_CAP ((uint64_t) 32 << 30)          // bytes of one of the two scratch regions of dx_qv_encode_onepass
-
-// side-stream stage of one group: its record offsets (continuing at *base_in), then its compaction
-static int onepass_side(dx_ctx *ctx, hipStream_t B, int waves_per_cu, const uint32_t *d_size, uint64_t m, uint64_t mt, uint64_t *d_tile, uint64_t *d_gran,
-                        uint64_t *d_rec_off, const uint64_t *base_in, uint64_t *base_out, const uint32_t *d_len,
-                        const uint8_t *d_slots, const uint64_t *d_slot, const uint32_t *d_seg, const uint8_t *d_hdr,
-                        const uint64_t *d_hdr_off, uint8_t *d_out, uint64_t out_cap, uint32_t *d_tick)
-{ DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, B));
-  DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_tiles, (int) mt, DX_BLOCK, d_size, m, d_tile);
-  DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, mt, d_gran);
-  DX_LAUNCH_ON(ctx, B, DX_K_SCAN, k_scan_apply_base, (int) mt, DX_BLOCK, d_size, m, (const uint64_t *) d_tile, d_rec_off,
-               (const uint64_t *) d_gran, base_in, base_out);
-  DX_LAUNCH_ON(ctx, B, DX_K_QV_COMPACT, k_qv_compact, dx_grid_waves(ctx, m, waves_per_cu), DX_BLOCK,
-            m, d_len, d_slots, d_slot, d_seg, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, out_cap,
-            ctx->d_status, d_tick, ctx->compact_units ? ctx->compact_units : COMPACT_BATCH);
-  return DX_OK;
-}
-
 // ---- group index: room for it -----------------------------------------------------------------------------
 __global__ __launch_bounds__(DX_BLOCK)
 void k_sub_rooms(const uint32_t *len, uint64_t n, const uint32_t *info /* token counts (k_qv_hist), or NULL */, uint32_t *room)
@@ -2785,7 +2661,7 @@ static bool onepass_tokens_ok(const dx_ctx *ctx, const dx_qv_batch *b)
 { return ctx->tk.valid && ctx->tk.text == (const void *) b->d_text && ctx->tk.boff == (const void *) b->d_off &&
          ctx->tk.blen == (const void *) b->d_len && ctx->tk.n == b->n && ctx->tk.text_bytes == b->text_bytes &&
          ctx->tk.pad == b->line_pad && ctx->tk.delChar == ctx->delChar &&
-         (ctx->subChar < 0 || ctx->subChar == ctx->tk.subChar) && getenv("DEXGPU_NO_TOKENS") == NULL;
+         (ctx->subChar < 0 || ctx->subChar == ctx->tk.subChar) && !tokens_off();
 }
 
 // dx_qv_encode_onepass with the token hand-over and no scratch slots (DEXGPU_DIRECT_ENCODE, or no memory for the
@@ -2807,8 +2683,8 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
   uint64_t gb[ONEPASS_MAX_GROUPS + 1];
   int      G = 0;
   gb[0] = 0;
-  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests: that many equal groups)
-    { int k = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
+  if (dx_test_str("onepass_groups") != NULL)             // (experiments and tests: that many equal groups)
+    { int k = (int) dx_test_num("onepass_groups", 1);
       if (k < 1) k = 1;
       if (k > ONEPASS_MAX_GROUPS) k = ONEPASS_MAX_GROUPS;
       const uint64_t gs = (n + (uint64_t) k - 1) / (uint64_t) k;
@@ -2880,12 +2756,12 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
       dx_prof_begin_on(ctx, DX_K_QV_ENCODE, A);
       if (sx_idx)
         hipLaunchKernelGGL(FAST_K_IX, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
                            (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
       else
         hipLaunchKernelGGL(FAST_K, dim3(fast_grid(ctx, m)), dim3(FAST_BLOCK), 0, A,
-                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, tg,
+                           ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, tg,
                            ctx->pair_lo[0], ctx->pair_lo[1], d_hdr, (const uint64_t *) (d_rec_off + g0),
                            (const uint32_t *) (d_seg + 5 * g0), d_out, out_cap, sx_g);
       dx_prof_end_on(ctx, A);
@@ -2895,7 +2771,7 @@ static int onepass_direct(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hd
           hipLaunchKernelGGL(k_qv_encode, dim3(dx_grid_waves(ctx, ctx->tk.unusable < m ? ctx->tk.unusable : m, 4 * ENC_WAVES)),
                              dim3(DX_BLOCK), 0, A, ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g,
                              (const uint64_t *) (d_rec_off + g0), (const uint32_t *) (d_seg + 5 * g0), d_out, ctx->d_status,
-                             d_tick_enc, enc_scratch{ NULL, NULL, NULL, NULL, 0, 0 }, (const uint32_t *) ctx->tk.list,
+                             d_tick_enc, (const uint32_t *) ctx->tk.list,
                              (const unsigned long long *) ctx->tk.count, g0, (const uint32_t *) (ctx->tk.info + TOK_INFO * g0), out_cap, sx_g);
           dx_prof_end_on(ctx, A);
         }
@@ -2951,12 +2827,10 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
       if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = DX_OK; ctx->op.total = 0; }
       return DX_OK;
     }
-  // DEXGPU_DIRECT_ENCODE: sizes first, records written in place, no scratch slots (onepass_direct) -- what also runs
-  // when the slots below cannot be allocated.  It is the slower of the two (34.5 ms against 31.0, 1 M x 10 kb): its
-  // size kernel reads the 30 GB of plain lines once more, the compaction it saves moves 2 x 14 GB.
-  // The product route when the histogram pass has left every entry's own counters (k_qv_hist<true>): sizes by dot product
-  // (k_qv_sizes_hist), every record written where it belongs -- no scratch slots, no compaction.  DEXGPU_SLOTS=1: the
-  // slot route below all the same; DEXGPU_DIRECT_ENCODE: sizes by k_qv_sizes_fast (tokens and plain lines read again).
+  // Three routes, all of which write every record where it belongs.  A batch of short entries: the lane-per-entry kernels
+  // (dx_qv_short.hpp).  A batch whose tokens this context's histogram pass has left: k_qv_encode_fast, its sizes from the
+  // entries' own histograms (k_qv_sizes_hist: a dot product) or, where there are none (DEXGPU_TEST=sizes_from_tokens; one
+  // run character only), from tokens and plain lines (k_qv_sizes_fast).  Anything else: sizes and records from the text.
   { bool brief = false;
     const uint8_t *perm = NULL;
   if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
@@ -2968,241 +2842,43 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
         return rc;
       }
   }
-  const bool by_hist = onepass_tokens_ok(ctx, b) && ctx->tk.eh_valid && getenv("DEXGPU_SLOTS") == NULL;
-  if (by_hist || (onepass_tokens_ok(ctx, b) && getenv("DEXGPU_DIRECT_ENCODE") != NULL))
+  if (onepass_tokens_ok(ctx, b))
     { uint64_t t = 0;
-      const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t, by_hist && getenv("DEXGPU_DIRECT_ENCODE") == NULL);
+      const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t, ctx->tk.eh_valid && !dx_test_on("sizes_from_tokens"));
       if (total) *total = t;
       if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }   // (this route does not pipeline)
       return rc;
     }
 
-  // Groups of entries: the encoder works through them on the context's stream while the compaction of the
-  // group before runs beside it on the side stream.  Both stages move memory at close to the rate the
-  // two can share (each slows the other down by about what the overlap gains), so what counts is the
-  // number of group boundaries -- kernel tails, launch gaps, waits for a scratch region to be free: as few
-  // groups as the scratch budget allows (regions of at most ONEPASS_REGION_CAP bytes, sized from the
-  // table-derived slot bounds), two from 240 k entries on so that half of the compaction is hidden.
-  // Measured, 1 M x 10 kb, ms per step: 2 equal groups 31.0, 4: 31.3, 8: 32.9, 16: 35.0, 64: 46.7;
-  // 40 % / 30 % / 30 % in three regions: 31.4; 7 groups with a halving tail: 32.7.
-  const int regions_max = 3;
-  uint64_t gb[ONEPASS_MAX_GROUPS + 1];
-  int      G = 1;
-  { const uint64_t bits = (uint64_t) ctx->bps[0] + ctx->bps[1] + ctx->bps[2] + ctx->bps[3];
-    const uint64_t syms = b->text_bytes ? b->text_bytes / 5 / n : 0;   // per entry (a file image: five lines each)
-    const uint64_t per_entry = syms ? syms * bits / 8 + syms / 4 + 128 : 0;       // mean slot bound
-    if (n >= 240000) G = 2;
-    if (per_entry)
-      { while (G < ONEPASS_MAX_GROUPS && (n + G - 1) / G * per_entry > ONEPASS_REGION_CAP) G++;
-        // ... and as the free device memory allows (the scratch that exists counts as free: it is replaced): more,
-        // smaller groups when two big regions do not fit (a 125 GB shard leaves ~40 GB beside its tokens and output)
-        // (or the budget the caller set, dx_set_scratch_budget: the route is then a function of the batch and the budget)
-        size_t free_b = 0, all_b = 0;
-        const uint64_t budget = dx_budget(ctx);
-        uint64_t avail = budget;
-        if (!budget && hipMemGetInfo(&free_b, &all_b) == hipSuccess)
-          avail = (uint64_t) free_b + ctx->scratch_bytes;
-        if (avail)
-          while (G < ONEPASS_MAX_GROUPS &&
-                 (uint64_t) (G > regions_max ? regions_max : G) * ((n + G - 1) / G * per_entry) + 28 * n + (budget ? 0 : 1ull << 30) > avail)
-            G++;
-        ctx->route.avail_bytes = avail;
-      }
-    else if (n >= 240000)
-      G = (int) (n / 250000) > 2 ? (int) (n / 250000) : 2;
-    if (G < ctx->onepass_min_groups) G = ctx->onepass_min_groups;      // (what an earlier call had to fall back to)
-    if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
+  // No tokens of this batch (its histogram pass was another context's, or its scan state has changed since): sizes and
+  // records from the text, in place, by the generic kernels -- dx_qv_sizes + dx_qv_encode.  (Rounds 2-4 had scratch slots
+  // and a compaction kernel here, and for every batch before the entries' own histograms made the sizes a dot product:
+  // taken out in round 6.)
+  { uint64_t t = 0;
+    uint32_t *sx_idx = NULL;
+    int rc = dx_qv_sizes(ctx, b, d_hdr_off, d_seg, d_rec_off, &t);
+    if (rc == DX_OK && t > out_cap)
+      rc = dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
+                   (unsigned long long) t, (unsigned long long) out_cap);
+    if (rc == DX_OK) rc = subindex_prepare(ctx, b, d_out, d_seg, &sx_idx);
+    if (rc == DX_OK) rc = encode_text(ctx, b, d_hdr, d_hdr_off, d_rec_off, d_seg, d_out, out_cap, sx_idx);
+    if (total) *total = t;
+    ctx->route.groups = 0; ctx->route.direct = 4; ctx->route.tokens = 0; ctx->route.region_bytes = 0;
+    ctx->route.scratch_bytes = ctx->scratch_bytes; ctx->route.token_bytes = 0; ctx->route.text_entries = n;
+    if (rc == DX_OK) ctx->sx.valid = sx_idx != NULL;
+    if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }
+    return rc;
   }
-  if (getenv("DEXGPU_ONEPASS_GROUPS"))                   // (experiments and tests)
-    { G = atoi(getenv("DEXGPU_ONEPASS_GROUPS"));
-      if (G < 1) G = 1;
-      if (G > ONEPASS_MAX_GROUPS) G = ONEPASS_MAX_GROUPS;
-    }
-layout:
-  { const uint64_t gs = (n + (uint64_t) G - 1) / (uint64_t) G;
-    const char *split = getenv("DEXGPU_ONEPASS_SPLIT");  // (experiments: group sizes in percent, e.g. 20,40,40)
-    G = 0;
-    gb[0] = 0;
-    if (split != NULL && *split && n >= 1000)
-      { uint64_t at = 0;
-        while (*split && G < ONEPASS_MAX_GROUPS - 1)
-          { char *e2;
-            const long pc = strtol(split, &e2, 10);
-            if (e2 == split || pc <= 0) break;
-            at += n * (uint64_t) pc / 100;
-            if (at >= n) break;
-            gb[++G] = at;
-            split = *e2 == ',' ? e2 + 1 : e2;
-          }
-        gb[++G] = n;
-      }
-    else
-      for (uint64_t at = 0; at < n; at += gs)
-        gb[++G] = at + gs < n ? at + gs : n;
-  }
-  const uint64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  const size_t   a4     = (n * 4 + 255) & ~(size_t) 255, a8 = ((n + 1) * 8 + 255) & ~(size_t) 255;
-  const size_t   small  = 2 * a4 + a8 + (((ntiles + 2) * 8 + 255) & ~(size_t) 255);
-  uint64_t       region = 0, gstart[ONEPASS_MAX_GROUPS + 1] = { 0 };   // slot offset at which each group starts; largest group's extent
-  uint8_t       *scr    = NULL;
-  uint32_t      *d_bound = NULL, *d_size = NULL;
-  uint64_t      *d_slot = NULL, *d_tile = NULL, *d_gran = NULL;
-  // the slot layout needs the scratch to exist and the scratch's size needs the layout: lay out, size,
-  // and lay out again if the buffer had to move.  Three rotating regions hold the groups' slots.
-  uint64_t laid_gen = 0;                                 // the scratch generation the layout below was computed in
-  for (int pass = 0; pass < 2; pass++)
-    { void *base;
-      if ((e = dx_scratch(ctx, small + (uint64_t) (G > regions_max ? regions_max : G) * region + 512, &base)))
-        { (void) hipGetLastError();                      // (the failed allocation's error is dealt with here)
-          if (pass == 1 && G >= 2 && 2 * G <= ONEPASS_MAX_GROUPS && getenv("DEXGPU_ONEPASS_GROUPS") == NULL)
-            { G = G < 3 ? 4 : 2 * G;                     // no room for regions this big: more, smaller groups
-              ctx->onepass_min_groups = G;
-              goto layout;
-            }
-          if (pass == 1 && onepass_tokens_ok(ctx, b))    // no room for any slots: the scheme that needs none
-            { uint64_t t = 0;
-              const int rc = onepass_direct(ctx, b, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t, false);
-              if (total) *total = t;
-              if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }
-              return rc;
-            }
-          return e;
-        }
-      // (not "base == scr": a re-allocated block can come back at the old address, with whatever its pages held before --
-      // the layout of pass 0 gone, and the encoder sent after junk offsets)
-      if (pass == 1 && ctx->scratch_gen == laid_gen) break;
-      laid_gen = ctx->scratch_gen;
-      scr     = (uint8_t *) base;
-      d_bound = (uint32_t *) scr;
-      d_size  = (uint32_t *) (scr + a4);
-      d_slot  = (uint64_t *) (scr + 2 * a4);
-      d_tile  = (uint64_t *) (scr + 2 * a4 + a8);
-      d_gran  = d_tile + ntiles;
-      unsigned long long *d_long = (unsigned long long *) (ctx->d_u64 + 32), too_long = 0;
-      DX_HIP(ctx, hipMemsetAsync(d_long, 0, 8, ctx->stream));
-      DX_LAUNCH(ctx, DX_K_SCAN, k_qv_bounds, (int) ((n + DX_BLOCK - 1) / DX_BLOCK), DX_BLOCK,
-                (const uint32_t *) b->d_len, n, ctx->bps[0], ctx->bps[1], ctx->bps[2], ctx->bps[3], d_bound, d_long);
-      DX_LAUNCH(ctx, DX_K_SCAN, k_scan_tiles, (int) ntiles, DX_BLOCK, (const uint32_t *) d_bound, n, d_tile);
-      DX_LAUNCH(ctx, DX_K_SCAN, k_scan_sums, 1, DX_BLOCK, d_tile, ntiles, d_gran);
-      DX_LAUNCH(ctx, DX_K_SCAN, k_scan_apply, (int) ntiles, DX_BLOCK, (const uint32_t *) d_bound, n,
-                (const uint64_t *) d_tile, d_slot, (const uint64_t *) d_gran);
-      for (int g = 0; g <= G; g++)
-        DX_HIP(ctx, hipMemcpyAsync(&gstart[g], d_slot + gb[g], 8, hipMemcpyDeviceToHost, ctx->stream));
-      DX_HIP(ctx, hipMemcpyAsync(&too_long, d_long, 8, hipMemcpyDeviceToHost, ctx->stream));
-      DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (too_long)
-        return dx_fail(ctx, DX_E_UNSUPPORTED, "dx_qv_encode_onepass: an entry of %llu symbols needs a scratch slot of 4 GiB or more "
-                       "under these tables (use dx_qv_sizes + dx_qv_encode)", too_long);
-      region = 0;
-      for (int g = 0; g < G; g++)
-        if (gstart[g + 1] - gstart[g] > region) region = gstart[g + 1] - gstart[g];
-      region = (region + 255) & ~(uint64_t) 255;
-    }
-  uint8_t *d_slots = scr + ((small + 255) & ~(size_t) 255);
-
-  uint32_t *sx_idx = NULL;
-  if ((e = subindex_prepare(ctx, b, d_out, d_seg, &sx_idx))) return e;
-  hipStream_t    A = ctx->stream, B = ctx->side;
-  hipEvent_t    *enc_done = ctx->ev, *cmp_done = ctx->ev + 8, done = ctx->ev[16];
-  uint64_t      *d_base = ctx->d_u64 + 24;               // [0], [1]: running record offset, ping-pong
-  uint32_t      *d_tick_enc = (uint32_t *) (ctx->d_u64 + 19), *d_tick_cmp = (uint32_t *) (ctx->d_u64 + 22);
-  qv_args        a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
-  ctx->compact_units = COMPACT_BATCH / TICKET_BATCH * a.units;      // (8 records of a 10 kb entry; more of shorter ones)
-  // the token hand-over applies when k_qv_hist made its tokens for exactly this batch under the run characters now in force
-  // (a substitution run character dropped by Create_QVcoding, QV.c:1044, just leaves its tokens unused)
-  const bool fast = onepass_tokens_ok(ctx, b);
-  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, A));
-  DX_HIP(ctx, hipMemsetAsync(d_base, 0, 16, A));
-  int rc = DX_OK, ng = 0;                                // ng: groups run so far (selects the ping-pong base)
-  for (int g = 0; g < G && rc == DX_OK; g++)
-    { const uint64_t g0 = gb[g], g1 = gb[g + 1];
-      if (g0 >= g1) continue;
-      const uint64_t m = g1 - g0, mt = (m + SCAN_TILE - 1) / SCAN_TILE;
-      // this group's slots live in region g % 3: slot_off[r] is file-wide, so shift the base
-      uint8_t *slots_g = d_slots + (uint64_t) (g % 3) * region - gstart[g];
-      qv_args ag = a;
-      ag.off = a.off + g0; ag.len = a.len + g0; ag.n = m;
-      const uint64_t *hoff_g = d_hdr_off ? d_hdr_off + g0 : NULL;
-      const sub_sink  sx_g   = { sx_idx, sx_idx ? (const uint64_t *) (ctx->sx.off + g0) : (const uint64_t *) NULL, ctx->sx.none };
-      if (g >= 3)
-        DX_HIP(ctx, hipStreamWaitEvent(A, cmp_done[(g - 3) & 7], 0));    // the region is free once its last tenant has been copied out
-      const enc_scratch sc_g = { slots_g, d_slot + g0, d_seg + 5 * g0, d_size + g0, gstart[g], gstart[g] + region };
-      if (fast)                                          // entries with usable tokens: walked from the tokens
-        { const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off + g0, ctx->tk.info + TOK_INFO * g0 };
-          DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          if (sx_idx)
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K_IX, fast_grid(ctx, m), FAST_BLOCK,
-                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
-                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g);
-          else
-            DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K, fast_grid(ctx, m), FAST_BLOCK,
-                      ag, (const uint32_t *) ctx->d_tok, hoff_g, ctx->d_status, d_tick_enc, sc_g, tg,
-                      ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                      (uint8_t *) NULL, (uint64_t) 0, sx_g);
-        }
-      if (!fast || ctx->tk.unusable > 0)                 // everything, or the entries the fast kernel leaves out: from the text
-        { const uint64_t work = fast ? (ctx->tk.unusable < m ? ctx->tk.unusable : m) : m;
-          DX_HIP(ctx, hipMemsetAsync(d_tick_enc, 0, 4, A));
-          DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, work, 4 * ENC_WAVES), DX_BLOCK,
-                    ag, (const uint32_t *) ctx->d_tok, d_hdr, hoff_g, (const uint64_t *) NULL, (const uint32_t *) NULL,
-                    (uint8_t *) NULL, ctx->d_status, d_tick_enc, sc_g,
-                    fast ? (const uint32_t *) ctx->tk.list : (const uint32_t *) NULL,
-                    fast ? (const unsigned long long *) ctx->tk.count : (const unsigned long long *) NULL, g0,
-                    fast ? (const uint32_t *) (ctx->tk.info + TOK_INFO * g0) : (const uint32_t *) NULL, ~(uint64_t) 0, sx_g);
-        }
-      DX_HIP(ctx, hipEventRecord(enc_done[g & 7], A));
-      // side stream: offsets of this group (continuing where the last one ended), then its compaction
-      DX_HIP(ctx, hipStreamWaitEvent(B, enc_done[g & 7], 0));
-      rc = onepass_side(ctx, B, COMPACT_WAVES_PER_CU, d_size + g0, m, mt, d_tile, d_gran, d_rec_off + g0, d_base + (ng & 1), d_base + ((ng + 1) & 1),
-                        b->d_len + g0, slots_g, d_slot + g0, d_seg + 5 * g0, d_hdr, hoff_g, d_out, out_cap, d_tick_cmp);
-      (void) hipEventRecord(cmp_done[g & 7], B);
-      ng += 1;
-    }
-  if (rc != DX_OK)
-    { (void) hipStreamSynchronize(B);
-      return rc;
-    }
-  (void) hipEventRecord(done, B);
-  ctx->route.groups = ng; ctx->route.direct = 0; ctx->route.tokens = fast ? 1 : 0;
-  ctx->route.region_bytes = region; ctx->route.scratch_bytes = ctx->scratch_bytes;
-  ctx->route.token_bytes = fast ? 4ull * ctx->tk.cap_tokens : 0;
-  ctx->route.text_entries = fast ? ctx->tk.unusable : n;
-  ctx->op.pending = 1; ctx->op.direct = 0; ctx->op.d_total = d_base + (ng & 1); ctx->op.out_cap = out_cap; ctx->op.sx_idx = sx_idx;
-  if (!wait) return DX_OK;                               // (the last compaction is still running on the side stream)
-  return onepass_end(ctx, total);
 }
 
-// the other half: the caller's stream waits for the last compaction, total and status come back
+// the other half of dx_qv_encode_onepass_begin: the total and the verdict (every route has waited for its records: what
+// "begin" leaves for "end" is the answer)
 static int onepass_end(dx_ctx *ctx, uint64_t *total)
 { if (!ctx->op.pending)
     return dx_fail(ctx, DX_E_ARG, "dx_qv_encode_onepass_end: no encode has begun in this context");
   ctx->op.pending = 0;
-  if (ctx->op.direct)
-    { if (total) *total = ctx->op.total;
-      return ctx->op.rc;
-    }
-  hipStream_t A = ctx->stream;
-  uint64_t tot = 0;
-  uint32_t st  = 0;
-  DX_HIP(ctx, hipSetDevice(ctx->device));
-  (void) hipStreamWaitEvent(A, ctx->ev[16], 0);          // the caller's stream sees the finished output
-  if (hipMemcpyAsync(&tot, ctx->op.d_total, 8, hipMemcpyDeviceToHost, A) != hipSuccess ||
-      hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, A) != hipSuccess ||
-      hipStreamSynchronize(A) != hipSuccess)
-    return dx_fail(ctx, DX_E_HIP, "dx_qv_encode_onepass: reading back the totals failed");
-  if (total) *total = tot;
-  ctx->route.chain_waits[0] = ctx->route.chain_waits[1] = ctx->route.chain_waits[2] = 0;
-  if (st & DX_ST_INDEX)
-    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry's offsets, length or scratch / token slot do not hold together "
-                   "(d_off / d_len beyond text_bytes, or an internal index is corrupt)");
-  if (st & 2u)
-    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry outgrew its scratch slot");
-  if (tot > ctx->op.out_cap || (st & 8u))
-    return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
-                   (unsigned long long) tot, (unsigned long long) ctx->op.out_cap);
-  ctx->sx.valid = ctx->op.sx_idx != NULL;
-  return DX_OK;
+  if (total) *total = ctx->op.total;
+  return ctx->op.rc;
 }
 
 extern "C" int dx_qv_onepass_info(const dx_ctx *ctx, dx_onepass_info *out)

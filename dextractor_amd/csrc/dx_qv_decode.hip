@@ -1879,7 +1879,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
     { const int rc = q == 0 ? ctx->delChar : (q == 3 ? ctx->subChar : -1);
       if (rc < 0 && ctx->sym_type[q] != 2) plain |= 1u << q;
     }
-  if (getenv("DEXGPU_GENERIC_DECODE") != NULL) plain = 0;
+  if (dx_test_on("generic_decode")) plain = 0;
   uint32_t *d_next = (uint32_t *) (ctx->d_u64 + 16), *d_next2 = (uint32_t *) (ctx->d_u64 + 31);   // task counters
   DX_HIP(ctx, hipMemsetAsync(d_next, 0, 4, ctx->stream));
   DX_HIP(ctx, hipMemsetAsync(d_next2, 0, 4, ctx->stream));
@@ -1891,7 +1891,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
   const uint32_t *sync_idx = NULL;                       // (the device walk's index: what is left for k_qv_decode_plain)
   const uint64_t *sync_off = NULL;
   uint32_t        sync_kinds = 0;
-  if ((plain || ctx->sx.walk) && ctx->sx.valid && d_in == ctx->sx.out && !(flags & DX_DECODE_FLIP) && getenv("DEXGPU_NO_SUBINDEX") == NULL &&
+  if ((plain || ctx->sx.walk) && ctx->sx.valid && d_in == ctx->sx.out && !(flags & DX_DECODE_FLIP) && !dx_test_on("no_subindex") &&
       (const uint32_t *) d_seg >= (const uint32_t *) ctx->sx.seg &&
       ((const uint32_t *) d_seg - (const uint32_t *) ctx->sx.seg) % 5 == 0)
     { const uint64_t first = (uint64_t) ((const uint32_t *) d_seg - (const uint32_t *) ctx->sx.seg) / 5;
@@ -1901,7 +1901,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
           hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, a.rec_off, a.rec_off + n, (const uint32_t *) NULL, n,
                              DEC_TICKET * 14000u, DEC_TICKET, d_next3);         // (4 entries of 10 kb per ticket; more of shorter ones)
           if (ctx->sx.walk)                                 // the device walk's index (dx_qv_use_dindex): a word per 64 symbols of a plain line
-            { const uint32_t sy = plain & ctx->sx.sync_kinds & (getenv("DEXGPU_NO_SYNCINDEX") == NULL ? 15u : 0u);
+            { const uint32_t sy = plain & ctx->sx.sync_kinds & (!dx_test_on("no_syncindex") ? 15u : 0u);
               const int nk = __builtin_popcount(sy);
               uint64_t sb = (n + DY_NWAVE - 1) / DY_NWAVE;
               if (sb > cap * (nk <= 2 ? 2 : 1)) sb = cap * (nk <= 2 ? 2 : 1);
@@ -1940,7 +1940,7 @@ extern "C" int dx_qv_decode(dx_ctx *ctx, const uint8_t *d_in, const uint64_t *d_
           uint32_t runs = 0;
           if (ctx->delChar >= 0 && ctx->sym_type[0] != 2) runs |= 1u;
           if (ctx->subChar >= 0 && ctx->sym_type[3] != 2) runs |= 8u;
-          if (runs && getenv("DEXGPU_NO_RUNINDEX") == NULL)
+          if (runs && !dx_test_on("no_runindex"))
             { uint32_t *d_next4 = (uint32_t *) (ctx->d_u64 + 29);
               DX_HIP(ctx, hipMemsetAsync(d_next4, 0, 4, ctx->stream));
               hipLaunchKernelGGL(k_ticket_units, dim3(1), dim3(1), 0, ctx->stream, a.rec_off, a.rec_off + n, (const uint32_t *) NULL, n,

@@ -6,9 +6,9 @@
 // position lists, no second read of the deletion, tag and substitution lines -- and Pack_Tag +
 // Number_Read + Compress_Read (QV.c:810-819, 1402-1404) is the 2-bit field already sitting in each
 // deletion token.  The insertion and merge lines (always plain, QV.c:1417-1418) are read from the text.
-// Entries are written into scratch slots exactly as the generic kernel's scratch mode does (del, ins,
-// mrg, sub compactly; tags at the slot's end) and their five sizes recorded; entries whose tokens are
-// marked unusable are left to the generic kernel.
+// Every record is written where it belongs (sizes and offsets are known: k_qv_sizes_hist / k_qv_sizes_fast + the scan), and
+// the sizes its segments turn out to have are compared with the given ones; entries whose tokens are marked unusable are
+// left to the generic kernel.
 // perturbation experiments (tools/microbench/hist_time.py --encode): parts of k_qv_encode_fast compiled out -- wrong
 // output, a kernel time that says what the part costs.  1: no run-coded lines, 2: no plain lines, 4: bits are not placed
 // in the window (plain lines), 8: one-symbol steps instead of pair tables
@@ -408,10 +408,13 @@ __device__ __forceinline__ void entry_sizes_fast(const qv_args &a, uint64_t r, u
 // whose four encoder waves leave 64 of the 512 registers, i.e. at <= 112 each.  The plain instance has 110; with the
 // index code compiled in it had 116 (-> 120 allocated) even when no index was asked for, the two kernels ran one
 // after the other, and a step took 32.7 ms instead of 31.0.
+#ifndef FAST_VGPR_CAP
+#define FAST_VGPR_CAP __attribute__((amdgpu_num_vgpr(112)))
+#endif
 template <bool SUB>
-__global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES) __attribute__((amdgpu_num_vgpr(112)))
+__global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES) FAST_VGPR_CAP
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
-                      enc_scratch sc, tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
+                      tok_src tk, uint32_t pair_lo_ins, uint32_t pair_lo_mrg,
                       const uint8_t *hdr, const uint64_t *rec_off, const uint32_t *seg, uint8_t *out, uint64_t out_cap,
                       sub_sink sx)
 { __shared__ uint32_t s_tok[6][256];
@@ -443,54 +446,43 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
     {
       if (tok_unusable(tk.info, r, a.delChar, a.subChar))
         continue;                                        // the generic kernel encodes this entry from the text
-      // Two modes.  Scratch (sc.base != NULL): the entry goes into its slot, the sizes it turns out to have are
-      // recorded.  Direct: the sizes are known (k_qv_sizes_fast), the record is written where it belongs --
-      // framing bytes, del words, tag bytes, ins, mrg, sub words (QV.c:1393-1423) -- and every size is checked.
-#define SEG_OUT(k, v) { sgw[k] = (v); }
-      const bool      S      = sc.base != NULL;
+      // The sizes are known (k_qv_sizes_hist, k_qv_sizes_fast): the record is written where it belongs -- framing bytes, del
+      // words, tag bytes, ins, mrg, sub words (QV.c:1393-1423) -- and every size is checked.
       const uint32_t  L      = a.len[r];
       const uint32_t *inf    = tk.info + TOK_INFO * r;
       const uint64_t  toff   = tk.off[r];
 #if FAST_GUARDS
-      { // the entry inside the text, its token slot as k_tok_rooms laid it out, the counts inside the slot, its scratch
-        // slot inside this launch's region: else report and skip (see entry_sane).  Off by default: the branch makes the
-        // wave wait for ALL of an entry's index words before its first data load goes out -- one more memory round trip
-        // per entry, 0.6 ms of the 13.7 a 1 M-entry batch takes (measured); the generic kernel (the odd entries) has them
+      { // the entry inside the text, its token slot as k_tok_rooms laid it out, the counts inside the slot: else report and
+        // skip (see entry_sane).  Off by default: the branch makes the wave wait for ALL of an entry's index words before its
+        // first data load goes out -- one more memory round trip per entry, 0.6 ms of the 13.7 a 1 M-entry batch takes
+        // (measured); the generic kernel (the odd entries) has them
         const uint64_t room = tk.off[r + 1] - toff;
         const bool ok = entry_sane(a, r, L) && room >= 64u + TOK_XMARGIN &&
-                        (inf[0] & ~TOK_BAD) <= room && (inf[1] & ~TOK_BAD) <= room && inf[4] <= room / 4u && inf[5] <= room / 4u &&
-                        (!S || slot_sane(sc, r, L));
+                        (inf[0] & ~TOK_BAD) <= room && (inf[1] & ~TOK_BAD) <= room && inf[4] <= room / 4u && inf[5] <= room / 4u;
         if (!ok)
           { if (lane == 0) atomicOr(status, DX_ST_INDEX);
             continue;
           }
       }
 #endif
-      const uint32_t *sg     = seg + 5 * r;              // (direct mode)
-      uint32_t       *sgw    = sc.seg_out + 5 * r;       // (scratch mode)
+      const uint32_t *sg     = seg + 5 * r;
       uint8_t        *dst, *tag_at;
-      if (S)
-        { dst    = sc.base + sc.slot_off[r];
-          tag_at = sc.base + sc.slot_off[r + 1] - tag_room(L);
+      if (rec_off[r + 1] > out_cap)                      // d_out is too small: report, never overrun
+        { if (lane == 0) atomicOr(status, 8u);
+          continue;
         }
-      else
-        { if (rec_off[r + 1] > out_cap)                  // d_out is too small: report, never overrun
-            { if (lane == 0) atomicOr(status, 8u);
-              continue;
-            }
-          dst = out + rec_off[r];
-          if (hdr != NULL)                               // record framing (dexqv.c:128-139)
-            { const uint64_t h0 = hdr_off[r];
-              const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
-              for (uint32_t k = (uint32_t) lane; k < hl; k += 64)
-                dst[k] = hdr[h0 + k];
-              dst += hl;
-            }
-          tag_at = dst + sg[0];
+      dst = out + rec_off[r];
+      if (hdr != NULL)                                   // record framing (dexqv.c:128-139)
+        { const uint64_t h0 = hdr_off[r];
+          const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
+          for (uint32_t k = (uint32_t) lane; k < hl; k += 64)
+            dst[k] = hdr[h0 + k];
+          dst += hl;
         }
+      tag_at = dst + sg[0];
       const uint8_t  *p1     = line_ptr(a, r, L, 1);
       const bool      over   = can_overread(a, line_ptr(a, r, L, 4), L);
-      uint32_t        sum    = 0, bad = 0;
+      uint32_t        bad    = 0;
 
       // The four QV streams in file order: del (its tag segment goes to the slot's end), ins, mrg, sub
       // (QV.c:1393-1423).
@@ -542,8 +534,8 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               got = finish_words(o, last);
               if (q == 0)
                 { const uint32_t tb = finish_tags(ot);
-                  if (S) { if (lane == 0) SEG_OUT(1, tb) sum += tb; }
-                  else   { const uint32_t w1 = sg[1]; bad |= tb ^ w1; dst += w1; }
+                  const uint32_t w1 = sg[1];
+                  bad |= tb ^ w1; dst += w1;
                 }
             }
           else                                           // Encode
@@ -595,29 +587,17 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               if (q == 0)                                // no delChar: the whole tag line is packed
                 { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
                   const uint32_t tb = encode_all_tags(ot, p1, L, over);
-                  if (S) { if (lane == 0) SEG_OUT(1, tb) sum += tb; }
-                  else   { const uint32_t w1 = sg[1]; bad |= tb ^ w1; dst += w1; }
+                  const uint32_t w1 = sg[1];
+                  bad |= tb ^ w1; dst += w1;
                 }
             }
-          if (S)
-            { if (lane == 0) SEG_OUT(line, got)
-              sum += got;
-            }
-          else
-            bad |= got ^ sg[line];
+          bad |= got ^ sg[line];
           dst += got;
         }
-      if (S)
-        { if (dst > tag_at) bad = 1;                     // the slot bound was too small: never expected
-          const uint32_t rec = sum + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
-          if (lane == 0)
-            sc.rec_size[r] = rec;
-        }
       if (bad && lane == 0 && !FAST_SKIP)
-        atomicOr(status, 2u);                            // slot overflow / a size differs from what k_qv_sizes_fast computed
+        atomicOr(status, 2u);                            // a size differs from what the size kernel computed
     }
   }
-#undef SEG_OUT
 }
 
 

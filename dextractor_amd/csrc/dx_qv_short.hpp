@@ -536,8 +536,7 @@ static int qs_grid(const dx_ctx *ctx, uint64_t n)
 // arrays and sizes -- were the arrays' contents changed in between, the verdict is the old contents': slow at worst, not wrong.
 static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, bool *yes, const uint8_t **perm)
 { *yes = false; *perm = NULL;
-  const char *off = getenv("DEXGPU_NO_SHORT");
-  if ((off != NULL && off[0] != '\0' && off[0] != '0') || b->n < 4096 || b->text_bytes == 0) return DX_OK;
+  if (dx_test_on("no_short") || b->n < 4096 || b->text_bytes == 0) return DX_OK;
   if (b->text_bytes / b->n > 5ull * (QS_MEAN + 1u) + 64u) return DX_OK;
   if (!fresh && ctx->qs.valid && ctx->qs.off == (const void *) b->d_off && ctx->qs.len == (const void *) b->d_len && ctx->qs.n == b->n &&
       ctx->qs.text_bytes == b->text_bytes)
@@ -568,8 +567,8 @@ static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, bool *yes, co
   // 5.5 ms of a 0.9 ms step
   const double room_s = (double) b->text_bytes / 6e11 > 1e-3 ? (double) b->text_bytes / 6e11 : 1e-3;
   *yes = work[0] <= QS_MAXLEN && (double) work[0] * 1.35e-6 <= room_s && 64u * cost <= (uint64_t) QS_MEAN * b->n;
-  if (getenv("DEXGPU_SHORT_FORCE") != NULL) *yes = work[0] <= QS_MAXLEN;       // (tests: whatever the lengths cost)
-  ctx->qs.ordered = work[0] != work[1] && getenv("DEXGPU_SHORT_FILE_ORDER") == NULL;      // (entries of one length: as they come)
+  if (dx_test_on("short_force")) *yes = work[0] <= QS_MAXLEN;       // (tests: whatever the lengths cost)
+  ctx->qs.ordered = work[0] != work[1] && !dx_test_on("short_file_order");      // (entries of one length: as they come)
   *perm = *yes && ctx->qs.ordered ? ctx->qs.perm : NULL;
   ctx->qs.off = b->d_off; ctx->qs.len = b->d_len; ctx->qs.n = b->n; ctx->qs.text_bytes = b->text_bytes;
   ctx->qs.brief = *yes ? 1 : 0;

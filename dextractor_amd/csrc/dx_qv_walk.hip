@@ -782,11 +782,11 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
     // nobody has taken when it is done with its own (k_walk_pieces), so what a long record costs its lane the others make up for.
     // (Smaller pieces cost k_walk_find: every piece is scanned to its first header, half a record.)
     uint64_t per_lane = WALK_PER_LANE;
-    if (const char *e = getenv("DEXGPU_WALK_PER_LANE")) { const uint64_t v = strtoull(e, NULL, 10); if (v >= 1 && v <= 64) per_lane = v; }
+    { const uint64_t v = (uint64_t) dx_test_num("walk_per_lane", 0); if (v >= 1 && v <= 64) per_lane = v; }
     lanes = (uint64_t) ctx->num_cu * WALK_WGS_PER_CU * WALK_BLOCK < WALK_LANES_MAX ? (uint64_t) ctx->num_cu * WALK_WGS_PER_CU * WALK_BLOCK : WALK_LANES_MAX;
     uint64_t piece = (n - first + lanes * per_lane - 1) / (lanes * per_lane);
     if (piece < WALK_PIECE_MIN) piece = WALK_PIECE_MIN;
-    if (const char *e = getenv("DEXGPU_WALK_PIECE")) { const uint64_t v = strtoull(e, NULL, 10); if (v >= 4096) piece = v; }   // (tests)
+    { const uint64_t v = (uint64_t) dx_test_num("walk_piece", 0); if (v >= 4096) piece = v; }   // (tests)
     piece = (piece + 4095u) & ~(uint64_t) 4095u;
     a.piece = piece;
     a.pieces = n > first ? (n - first + piece - 1) / piece : 1;
@@ -795,7 +795,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   const uint32_t rcap = (uint32_t) (a.piece / 128u);
   // the lanes' words for the group index: 0.05 words a byte at the bench's 690 words a 14.4 KB record; a share of piece / 8 + 4096 words; lines
   // of a lane that runs out are left without (DEXGPU_WALK_NOGROUPS: none at all -- the index is then the round-4 one)
-  const bool     groups = !flip && getenv("DEXGPU_WALK_NOGROUPS") == NULL;
+  const bool     groups = !flip && !dx_test_on("walk_nogroups");
   const uint32_t gcap = groups ? (uint32_t) (a.piece / 8u) + 4096u : 0u;     // (+ what the record takes that the lane walks beyond its piece: 80 KB's worth)
   { // does the scratch fit (56 bytes a possible record, 0.44 of the stream) with room for the index behind it?  Asked first: a
     // failed allocation half way costs the allocations before it, and the caller has another way (the host walk).
@@ -846,7 +846,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
     const uint32_t q0 = (uint32_t) (((L0 + bs - 1) / bs) * bs);             // (the lanes launched take pieces 0 .. q0 - 1 themselves)
     WALK_HIP(hipMemcpyAsync(d_queue, &q0, 4, hipMemcpyHostToDevice, ctx->stream));
     hipEvent_t ev[3] = { NULL, NULL, NULL };                   // DEXGPU_WALK_DEBUG: the two kernels' times
-    const bool timed = getenv("DEXGPU_WALK_DEBUG") != NULL && hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess && hipEventCreate(&ev[2]) == hipSuccess;
+    const bool timed = dx_test_on("walk_debug") && hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess && hipEventCreate(&ev[2]) == hipSuccess;
     dx_prof_begin(ctx, DX_K_QV_WALK);
     if (timed) (void) hipEventRecord(ev[0], ctx->stream);
     hipLaunchKernelGGL(k_walk_find, dim3((unsigned) ((P + DX_WAVES_PER_BLK - 1) / DX_WAVES_PER_BLK)), dim3(DX_BLOCK), 0, ctx->stream, a, d_cand, d_ncand);
@@ -867,7 +867,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
   WALK_HIP(hipMemcpyAsync(pc, d_pc, P * sizeof(walk_piece_d), hipMemcpyDeviceToHost, ctx->stream));
   WALK_HIP(hipStreamSynchronize(ctx->stream));
 
-  if (getenv("DEXGPU_WALK_DEBUG"))
+  if (dx_test_on("walk_debug"))
     { uint64_t tried = 0, none = 0;
       for (uint64_t k = 0; k < P; k++) { tried += pc[k].tried; none += (pc[k].flags & WP_NONE) != 0; }
       fprintf(stderr, "[walk] %llu pieces of %llu bytes: %llu guesses did not hold, %llu pieces without a start\n",
@@ -894,7 +894,7 @@ int dx_qv_walk_device(dx_ctx *ctx, const uint8_t *d_img, uint64_t n, uint64_t fi
               }
           }
         if (pc[k].flags & WP_NONE || pc[k].start != pos)      // the chain arrives elsewhere than this piece's lane started: once more, from here
-          { if (getenv("DEXGPU_WALK_DEBUG")) fprintf(stderr, "[walk] piece %llu: chain arrives at %llu, lane started at %llu (flags %u, %u records, %u bytes of 255 in front): walked again\n", (unsigned long long) k, (unsigned long long) pos, (unsigned long long) pc[k].start, pc[k].flags, pc[k].count, pc[k].lead255);
+          { if (dx_test_on("walk_debug")) fprintf(stderr, "[walk] piece %llu: chain arrives at %llu, lane started at %llu (flags %u, %u records, %u bytes of 255 in front): walked again\n", (unsigned long long) k, (unsigned long long) pos, (unsigned long long) pc[k].start, pc[k].flags, pc[k].count, pc[k].lead255);
             if (++rounds > WALK_ROUNDS) WALK_FAIL(DX_E_MISMATCH, "dx_qv_walk_device: the pieces' walks do not chain up");
             if (d_start == NULL) { WALK_HIP(hipMalloc(&d_start, P * 8)); WALK_HIP(hipMalloc(&d_todo, 4)); }
             const uint32_t kk = (uint32_t) k;

@@ -13,8 +13,8 @@ cd $D
 T() { local a=$(date +%s%N); "$@"; local b=$(date +%s%N); echo "   wall $(( (b - a) / 1000000 )) ms: $*"; }
 for i in 1 2 3; do DEXGPU_TIMING=1 T $R/dextractor_amd/bin/dexqv -k s; done
 cp s.quiva s0.quiva
-echo "== undexqv -U with the walk's group index (DEXGPU_WALK_INDEX=1)"
-for i in 1 2 3; do DEXGPU_WALK_INDEX=1 DEXGPU_TIMING=1 T $R/dextractor_amd/bin/undexqv -k -U s; cmp s.quiva s0.quiva && echo "   identical to the input"; done
+echo "== undexqv -U with the walk's group index (DEXGPU_TEST=walk_index)"
+for i in 1 2 3; do DEXGPU_TEST=walk_index DEXGPU_TIMING=1 T $R/dextractor_amd/bin/undexqv -k -U s; cmp s.quiva s0.quiva && echo "   identical to the input"; done
 echo "== undexqv -U without (the default)"
 for i in 1 2 3; do DEXGPU_TIMING=1 T $R/dextractor_amd/bin/undexqv -k -U s; cmp s.quiva s0.quiva && echo "   identical to the input"; done
 rm -rf $D

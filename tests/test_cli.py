@@ -6,6 +6,8 @@ import subprocess
 
 import pytest
 
+from _flags import set_flag, test_env
+
 import _oracle as O
 from dextractor_amd import synth
 
@@ -200,12 +202,12 @@ def test_cli_degenerate_file_is_refused_loudly_where_the_reference_reads_out_of_
 @needs_ref
 def test_cli_large_file_paths_on_small_files(tmp_path):
     """What the tools do with LARGE files, brought down to test size by their thresholds: dexqv reads its input from the file
-    descriptor into the upload's pinned buffers (dx_file_dexqv_fd_to, DEXGPU_FD_MIN) and writes into an output file whose pages an
-    allocator thread lays out meanwhile (DEXGPU_OUTFILE_MIN: three tenths of the input, the rest given back) -- and hands a file
+    descriptor into the upload's pinned buffers (dx_file_dexqv_fd_to, DEXGPU_TEST=fd_min) and writes into an output file whose pages an
+    allocator thread lays out meanwhile (outfile_min: three tenths of the input, the rest given back) -- and hands a file
     that way refuses (a malformed one, one below 1 MiB) to the in-memory driver, which has the reference's words --; undexqv walks
-    the records on the device (DEXGPU_DEVICE_WALK_MIN) and decodes with what the walk noted.  Same files as the reference's."""
+    the records on the device (device_walk_min) and decodes with what the walk noted.  Same files as the reference's."""
     qv = synth.make_quiva(60, seed=9, mean=8000).text                 # ~2.4 MB
-    env = dict(os.environ, DEXGPU_FD_MIN="1", DEXGPU_OUTFILE_MIN="1", DEXGPU_DEVICE_WALK_MIN="0", DEXGPU_WALK_PIECE="8192")
+    env = dict(os.environ, DEXGPU_TEST=test_env(fd_min=1, outfile_min=1, device_walk_min=0, walk_piece=8192))
     mine, ref = tmp_path / "mine", tmp_path / "ref"
     for d, isref in ((mine, False), (ref, True)):
         d.mkdir()

@@ -7,6 +7,8 @@ import hashlib
 import numpy as np
 import pytest
 
+from _flags import set_flag, test_env
+
 import _oracle as O
 from dextractor_amd import _lib as L
 from dextractor_amd import api, synth
@@ -54,9 +56,9 @@ def test_dexar_golden(ctx, case):
 @pytest.mark.parametrize("case", O.cases("quiva"), ids=lambda c: c["name"])
 def test_dexqv_golden(ctx, case, tokens, monkeypatch):
     """The reference's own .dexqv bytes through the file driver: with the token hand-over between the scan and
-    the encoder (k_qv_encode_fast) and, DEXGPU_NO_TOKENS set, with the generic kernel reading the text."""
+    the encoder (k_qv_encode_fast) and, DEXGPU_TEST=no_tokens set, with the generic kernel reading the text."""
     if not tokens:
-        monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
+        set_flag(monkeypatch, "no_tokens", "1")
     txt, dx = O.golden(case["input"] + ".quiva"), O.golden(case["name"] + ".dexqv")
     got = ctx.dexqv(txt, "-l" in case["flags"])
     assert len(got) == len(dx)
@@ -200,7 +202,7 @@ def test_qv_scan_in_one_call_like_the_two(monkeypatch):
         h2, t2 = ctx.qv_hist(b, given, entry0=100)
         assert (p.delChar, p.subChar, p.del_first, p.sub_first) == (ord("3"), ord("@"), 5, 7)
         assert t2 == tot and (h2 == hist).all()
-        monkeypatch.setenv("DEXGPU_NO_SCAN_GUESS", "1")        # the switch: the two calls
+        set_flag(monkeypatch, "no_scan_guess", "1")        # the switch: the two calls
         p, hist, tot = ctx.qv_scan(b)
         st = O.qv_scan(c.text)
         assert (p.delChar, p.subChar) == (st.delChar, st.subChar) and tot == st.totChar
@@ -405,9 +407,9 @@ def test_errors_are_loud(ctx):
 @pytest.fixture(params=["plain kernel", "generic kernel"])
 def decoder(request, monkeypatch):
     """The plain lines are decoded by k_qv_decode_plain (aligned-line input rings, 16 symbols per store); with
-    DEXGPU_GENERIC_DECODE set everything goes through the generic lane-per-stream kernel: both must agree."""
+    DEXGPU_TEST=generic_decode set everything goes through the generic lane-per-stream kernel: both must agree."""
     if request.param == "generic kernel":
-        monkeypatch.setenv("DEXGPU_GENERIC_DECODE", "1")
+        set_flag(monkeypatch, "generic_decode", "1")
     return request.param
 
 
@@ -521,9 +523,9 @@ def test_decode_with_the_encoders_group_index(ctx, case, route, monkeypatch):
     plain lines; dx_qv_decode of that stream in the same context then runs k_qv_decode_sub, a wavefront per line.  Same text
     as without the index, byte for byte -- whole batch, a contiguous part of it, and after the index has gone stale."""
     if route == "direct":
-        monkeypatch.setenv("DEXGPU_DIRECT_ENCODE", "1")
+        set_flag(monkeypatch, "sizes_from_tokens", "1")
     if route == "text":
-        monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
+        set_flag(monkeypatch, "no_tokens", "1")
     lossy = case == "lossy"
     if case == "long_runs":                                       # runs of hundreds and thousands: passes that cover more of the line
         c = synth.make_quiva(30, seed=34, mean=20000)             # than the decoder stages (RUN_STRETCH), 16-bit run literals
@@ -706,7 +708,7 @@ def test_a_line_of_one_symbol_is_written_like_the_reference_and_refused_like_it(
     undexqv then stops with "Could not read more bits (Decode)", exit 1.  Same bytes here, and a loud refusal instead of
     a text of zeros (found by tools/stress_decode.py)."""
     if index:
-        monkeypatch.setenv("DEXGPU_WALK_INDEX", "1")
+        set_flag(monkeypatch, "walk_index", "1")
     dx = ctx.dexqv(SINGLE_SYMBOL_QUIVA)
     assert dx == O.dexqv(SINGLE_SYMBOL_QUIVA)
     if O.have_ref():
@@ -794,22 +796,22 @@ def test_undexqv_older_layout(ctx):
 @pytest.mark.parametrize("name", ["qv_full", "qv_lossy", "qv_type2", "qv_mid"])
 def test_dexqv_golden_without_pair_tables(ctx, name, monkeypatch):
     """k_qv_encode_fast codes the insertion and merge lines two symbols per look-up when their coded byte
-    values span at most 64 (the usual case, all goldens); DEXGPU_NO_PAIRS keeps the one-symbol step: same bytes.
+    values span at most 64 (the usual case, all goldens); DEXGPU_TEST=no_pairs keeps the one-symbol step: same bytes.
     qv_type2's insertion scheme has 8-bit escapes: pairs beyond 24 bits fall back step by step."""
     case = [c for c in O.cases("quiva") if c["name"] == name][0]
     txt, dx = O.golden(case["input"] + ".quiva"), O.golden(name + ".dexqv")
     assert ctx.dexqv(txt, "-l" in case["flags"]) == dx
-    monkeypatch.setenv("DEXGPU_NO_PAIRS", "1")
+    set_flag(monkeypatch, "no_pairs", "1")
     assert ctx.dexqv(txt, "-l" in case["flags"]) == dx
 
 
 def test_file_drivers_two_pass_switch_gives_the_same_bytes(ctx, monkeypatch):
-    """DEXGPU_TWOPASS selects dx_qv_sizes + dx_qv_encode in the file drivers instead of the one-pass
+    """DEXGPU_TEST=twopass selects dx_qv_sizes + dx_qv_encode in the file drivers instead of the one-pass
     encoder: same file."""
     c = synth.make_quiva(50, seed=23, mean=5000)
     want = O.dexqv(c.text)
     assert ctx.dexqv(c.text) == want
-    monkeypatch.setenv("DEXGPU_TWOPASS", "1")
+    set_flag(monkeypatch, "twopass", "1")
     assert ctx.dexqv(c.text) == want
 
 
@@ -916,13 +918,13 @@ def test_dexqv_large_file_uses_gpu_index_and_still_matches(ctx, monkeypatch):
     c = synth.make_quiva(120, seed=17, mean=9000)                  # > 1 MiB: GPU-indexed in dx_file_dexqv
     assert len(c.text) > (1 << 20)
     a = ctx.dexqv(c.text)
-    monkeypatch.setenv("DEXGPU_HOST_INDEX", "1")
+    set_flag(monkeypatch, "host_index", "1")
     b = ctx.dexqv(c.text)
     assert a == b == O.dexqv(c.text)
     bad = c.text[:-5]                                              # truncated last line: same error either way
     with pytest.raises(L.DexGPUError) as e1:
         ctx.dexqv(bad)
-    monkeypatch.delenv("DEXGPU_HOST_INDEX")
+    set_flag(monkeypatch, "host_index", None)
     with pytest.raises(L.DexGPUError) as e2:
         ctx.dexqv(bad)
     assert str(e1.value) == str(e2.value)
@@ -971,10 +973,10 @@ def test_file_dexqv_sharded_over_contexts(ctx, nctx, lossy):
 def test_file_dexqv_sharded_by_byte_ranges(ctx, monkeypatch, nctx):
     """A file too large to index on one thread first (BASELINE configs[4]): dx_file_dexqv_sharded deals BYTES, every shard counts the
     newlines of its range, finds the records that begin in it (six lines a record, data lines may begin with '@' too), uploads and
-    indexes them on its own device (dx_index_quiva_device) -- no pass over the whole file anywhere.  DEXGPU_SHARD_BYTES_MIN brings a
+    indexes them on its own device (dx_index_quiva_device) -- no pass over the whole file anywhere.  DEXGPU_TEST=shard_bytes_min brings a
     small file that way: the reference's bytes; a malformed file comes back with what the one-context driver says about it; a file
     whose first 100000 symbols reach beyond shard 0 goes the serial way and comes out right."""
-    monkeypatch.setenv("DEXGPU_SHARD_BYTES_MIN", "4096")
+    set_flag(monkeypatch, "shard_bytes_min", "4096")
     c = synth.make_quiva(320, seed=73, mean=5000)
     cs = [api.Context(_dev(k)) for k in range(nctx)]
     try:
@@ -1107,7 +1109,7 @@ def test_pack2_large_file_uses_gpu_index(ctx, kind, monkeypatch):
     assert len(c.text) > (1 << 20)
     f = ctx.dexta if kind == "fasta" else ctx.dexar
     a = f(c.text)
-    monkeypatch.setenv("DEXGPU_HOST_INDEX", "1")
+    set_flag(monkeypatch, "host_index", "1")
     assert a == f(c.text) == (O.dexta(c.text) if kind == "fasta" else O.dexar(c.text))
 
 
@@ -1220,17 +1222,16 @@ def _two_pass(ctx, c, coding, lossy=False, given=None):
                                   "odd_entries"])
 def test_encode_onepass_equals_two_pass(ctx, case, groups, tokens, monkeypatch):
     """dx_qv_encode_onepass gives the bytes of the oracle, entry by entry, and the bytes, record offsets and
-    segment index of dx_qv_sizes + dx_qv_encode.  Three routes: from the tokens k_qv_hist left for the batch
-    into scratch slots + compaction (k_qv_encode_fast; the generic kernel for the entries whose tokens are
-    unusable) -- the product path; from the tokens, sizes first (k_qv_sizes_fast) and the records written in
-    place (DEXGPU_DIRECT_ENCODE, the route taken when the slots cannot be allocated); and without tokens, from
-    the text alone (scratch slots bounded from the tables)."""
+    segment index of dx_qv_sizes + dx_qv_encode.  Three routes, all writing the records in place: from the tokens
+    k_qv_hist left for the batch, the sizes from the entries' own histograms (k_qv_encode_fast; the generic kernel
+    for the entries whose tokens are unusable) -- the product path; from the tokens, the sizes from tokens and plain
+    lines (k_qv_sizes_fast: DEXGPU_TEST=sizes_from_tokens); and without tokens, from the text alone."""
     if groups:                                                    # several groups: two streams
-        monkeypatch.setenv("DEXGPU_ONEPASS_GROUPS", groups)
+        set_flag(monkeypatch, "onepass_groups", groups)
     if tokens == "text":
-        monkeypatch.setenv("DEXGPU_NO_TOKENS", "1")
+        set_flag(monkeypatch, "no_tokens", "1")
     if tokens == "tokens_direct":
-        monkeypatch.setenv("DEXGPU_DIRECT_ENCODE", "1")
+        set_flag(monkeypatch, "sizes_from_tokens", "1")
     lossy = case == "lossy"
     if case == "small_lengths":
         lens = np.array(list(range(0, 70)) + [1023, 1024, 1025, 2047, 4097, 0, 1, 9000], np.uint32)
@@ -1628,7 +1629,7 @@ def test_undexqv_of_a_bare_file_decodes_with_the_walks_group_index(ctx, monkeypa
     for text in cases:
         dx = O.dexqv(text)
         want = O.undexqv(dx, upper=True)
-        monkeypatch.setenv("DEXGPU_WALK_INDEX", "1")          # (off by default in the file drivers: it costs the CLI more than it saves)
+        set_flag(monkeypatch, "walk_index", "1")          # (off by default in the file drivers: it costs the CLI more than it saves)
         ctx.profile(True)
         got = ctx.undexqv(dx, upper=True)
         used = ctx.kernel_times()
@@ -1638,7 +1639,7 @@ def test_undexqv_of_a_bare_file_decodes_with_the_walks_group_index(ctx, monkeypa
         if w["delChar"] >= 0 or w["subChar"] >= 0:
             assert "k_qv_decode_runs" in used, used.keys()
         assert "k_qv_decode_sub" in used or "k_qv_decode" in used
-        monkeypatch.delenv("DEXGPU_WALK_INDEX")
+        set_flag(monkeypatch, "walk_index", None)
         ctx.profile(True)
         assert ctx.undexqv(dx, upper=True) == want
         assert "k_qv_decode_sub" not in ctx.kernel_times() and "k_qv_decode_runs" not in ctx.kernel_times()
@@ -1720,8 +1721,8 @@ def test_old_name_decode_shims_like_undexqv(ctx, tmp_path, monkeypatch, walk):
     file's size: its index then comes down from there, dx_file_undexqv_plan_index.)"""
     import struct
     if walk == "device":
-        monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")
-        monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+        set_flag(monkeypatch, "device_walk_min", "0")
+        set_flag(monkeypatch, "walk_piece", "4096")
     lib = L.load()
     libc = C.CDLL(None)
     libc.fopen.restype = C.c_void_p

@@ -10,6 +10,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from _flags import set_flag, test_env
+
 import _oracle as O
 from dextractor_amd import _lib as L
 from dextractor_amd import api, synth
@@ -57,18 +59,14 @@ class Corpus:
         return out, info, coding
 
 
-def test_onepass_routes_under_memory_pressure_write_the_same_stream(monkeypatch):
-    """The product route (sizes from the entries' own histograms, records in place: direct == 2, no scratch at all) and the
-    scratch-slot route behind it (DEXGPU_SLOTS=1: what runs when the histogram pass could not leave its counters) under
-    ever smaller scratch budgets, down to the sizes-first fallback: all the same stream."""
+def test_onepass_routes_write_the_same_stream(monkeypatch):
+    """The product route (sizes from the entries' own histograms, records in place: direct == 2), the one whose sizes come from
+    tokens and plain lines (DEXGPU_TEST=sizes_from_tokens: direct == 1; what runs when a batch has one run character only) and
+    the one without tokens (no_tokens: sizes and records from the text, direct == 4): all the same stream, and the oracle's."""
     with api.Context(0) as ctx:
         c = Corpus(ctx)
-        prod, info_p, _ = c.encode(ctx, 0)
+        prod, info_p, coding = c.encode(ctx, 0)
         assert info_p["direct"] == 2 and info_p["groups"] == 0 and info_p["tokens"] == 1 and info_p["text_entries"] == 0
-        monkeypatch.setenv("DEXGPU_SLOTS", "1")
-        ref, info0, coding = c.encode(ctx, 0)                       # no budget: by free device memory
-        assert info0["direct"] == 0 and info0["groups"] >= 1 and info0["tokens"] == 1
-        assert len(prod) == len(ref) and (prod == ref).all()
         # the first 300 records against the oracle (the same entries as a small file give the same tables only if the
         # whole corpus does: so compare record by record with the oracle's entry encoder under THESE tables)
         rec = c.d_rec.download(np.uint64, c.n + 1)
@@ -80,35 +78,31 @@ def test_onepass_routes_under_memory_pressure_write_the_same_stream(monkeypatch)
             lines = np.stack([text[o + k * (ln + 1): o + k * (ln + 1) + ln] for k in range(5)])
             want, _ = O.qv_encode_entry(oc, False, lines)
             hl = int(c.hoff[i + 1] - c.hoff[i])
-            assert ref[int(rec[i]) + hl: int(rec[i + 1])].tobytes() == want, i
-        seen = {(info0["groups"], info0["direct"])}
-        # a half, an eighth, an eighteenth of what the slots of the whole batch take (three regions of a group's slots
-        # must fit: 6, 24, 54 groups), then nothing to speak of (no slots at all: sizes first, records in place)
-        whole = info0["groups"] * info0["region_bytes"]
-        for budget in (whole // 2 + 28 * c.n, whole // 8 + 28 * c.n, whole // 18 + 28 * c.n, 80 << 20):
-            got, info, _ = c.encode(ctx, budget)
-            assert info["avail_bytes"] == budget
-            assert len(got) == len(ref) and (got == ref).all(), info
-            seen.add((info["groups"], info["direct"]))
-        assert any(d == 1 for _, d in seen), seen                   # the sizes-first route ran ...
-        assert len({g for g, d in seen if d == 0}) >= 3, seen       # ... and three different groupings of the slot route
-        ctx.set_scratch_budget(0)
+            assert prod[int(rec[i]) + hl: int(rec[i + 1])].tobytes() == want, i
+        set_flag(monkeypatch, "sizes_from_tokens", "1")
+        got, info, _ = c.encode(ctx, 0)
+        assert info["direct"] == 1 and info["tokens"] == 1 and len(got) == len(prod) and (got == prod).all()
+        set_flag(monkeypatch, "sizes_from_tokens", None)
+        set_flag(monkeypatch, "no_tokens", "1")
+        got, info, _ = c.encode(ctx, 0)
+        assert info["direct"] == 4 and info["tokens"] == 0 and info["text_entries"] == c.n
+        assert len(got) == len(prod) and (got == prod).all()
 
 
-def test_budget_env_overrides_and_route_is_reported(monkeypatch):
+def test_a_scratch_budget_shapes_nothing_any_more(monkeypatch):
+    """Records are written in place: there are no scratch regions for a budget (dx_set_scratch_budget, DEXGPU_SCRATCH_BUDGET) to
+    shape -- the same route, the same bytes; the file driver under the same budget."""
     with api.Context(0) as ctx:
         c = Corpus(ctx, n=3000, mean=4000)
         a, info_a, _ = c.encode(ctx, 0)
         monkeypatch.setenv("DEXGPU_SCRATCH_BUDGET", str(16 << 20))
         b, info_b, _ = c.encode(ctx, 0)
-        assert info_b["direct"] == 2 and (a == b).all()             # records in place: no regions for a budget to shape
-        monkeypatch.setenv("DEXGPU_SLOTS", "1")                     # the slot route, which has them
-        b, info_b, _ = c.encode(ctx, 0)
-        assert info_b["direct"] == 0 and info_b["avail_bytes"] == 16 << 20
-        assert (a == b).all()
-        monkeypatch.delenv("DEXGPU_SLOTS")
+        assert info_b["direct"] == 2 and (a == b).all()
+        b, info_b, _ = c.encode(ctx, 64 << 20)
+        assert info_b["direct"] == 2 and (a == b).all()
+        ctx.set_scratch_budget(0)
         small = synth.make_quiva(40, seed=5, mean=3000)
-        assert ctx.dexqv(small.text) == O.dexqv(small.text)         # the file driver under the same budget
+        assert ctx.dexqv(small.text) == O.dexqv(small.text)
 
 
 _POISON_SCRIPT = r"""
@@ -137,14 +131,14 @@ print("POISON_OK")
 
 @pytest.mark.parametrize("poison", ["0xa5", "0xff"])
 def test_poisoned_allocations_change_nothing(poison):
-    """DEXGPU_POISON fills every device allocation of the library with a byte: a kernel that reads memory nothing has
+    """DEXGPU_TEST=poison=<byte> fills every device allocation of the library with a byte: a kernel that reads memory nothing has
     written (fresh device memory usually reads as zeros and hides it) then fails here instead of in the field.  Found
     this way: dx_qv_encode_onepass took a re-allocated scratch buffer that came back at its old address for the old
     buffer and kept a slot layout that was gone (a GPU memory fault when the pages held another process's leftovers)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = _POISON_SCRIPT.format(root=root, tests=os.path.join(root, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DEXGPU_POISON=poison), capture_output=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DEXGPU_TEST=test_env(poison=poison)), capture_output=True, timeout=600)
     assert r.returncode == 0 and b"POISON_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
@@ -185,7 +179,7 @@ def test_text_larger_than_the_budget_comes_out_in_slices(monkeypatch, tmp_path):
     """dx_file_undexqv on a .dexqv whose text is 1.5 to 30 times what the device may hold at once (DEXGPU_TEXT_BUDGET): slices of
     whole entries, decoded into one buffer that goes out before the next slice comes in -- with the image resident (uploaded
     once, or there already after a plan made on the device) and with the slices' bytes uploaded one by one
-    (DEXGPU_SLICE_INPUT).  The oracle's text; through the CLI too."""
+    (DEXGPU_TEST=slice_input).  The oracle's text; through the CLI too."""
     import os, subprocess
     with api.Context(0) as ctx:
         c = synth.make_quiva(500, seed=91, mean=7000, dist="lognormal")            # ~17 MB of text
@@ -195,13 +189,13 @@ def test_text_larger_than_the_budget_comes_out_in_slices(monkeypatch, tmp_path):
             monkeypatch.setenv("DEXGPU_TEXT_BUDGET", str(budget))
             assert ctx.undexqv(img) == want
             assert ctx.undexqv(img, upper=True) == O.undexqv(img, upper=True)
-            monkeypatch.setenv("DEXGPU_SLICE_INPUT", "1")
+            set_flag(monkeypatch, "slice_input", "1")
             assert ctx.undexqv(img) == want
-            monkeypatch.delenv("DEXGPU_SLICE_INPUT")
-            monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")                      # the plan on the device: image and index stay there
-            monkeypatch.setenv("DEXGPU_WALK_PIECE", "8192")
+            set_flag(monkeypatch, "slice_input", None)
+            set_flag(monkeypatch, "device_walk_min", "0")                      # the plan on the device: image and index stay there
+            set_flag(monkeypatch, "walk_piece", "8192")
             assert ctx.undexqv(img) == want
-            monkeypatch.delenv("DEXGPU_DEVICE_WALK_MIN"); monkeypatch.delenv("DEXGPU_WALK_PIECE")
+            set_flag(monkeypatch, "device_walk_min", None); set_flag(monkeypatch, "walk_piece", None)
     src = tmp_path / "big.dexqv"
     src.write_bytes(img)
     tool = os.path.join(os.path.dirname(L.LIB_PATH), "bin", "undexqv")

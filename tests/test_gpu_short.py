@@ -6,6 +6,8 @@ that it took them (dx_qv_onepass_info: direct == 3) -- or, where the case is abo
 import numpy as np
 import pytest
 
+from _flags import set_flag, test_env
+
 import _oracle as O
 from dextractor_amd import api, synth
 
@@ -23,7 +25,7 @@ def ctx():
 def force(monkeypatch):
     """the lane-per-entry kernels whatever the batch's lengths would cost them (they are for batches whose longest entry's lane is done when
     the batch is: a small batch with a long entry is not theirs) -- the kernels' code for long lines is what these cases are about"""
-    monkeypatch.setenv("DEXGPU_SHORT_FORCE", "1")
+    set_flag(monkeypatch, "short_force", "1")
 
 
 def _took_short(ctx):
@@ -165,9 +167,9 @@ def test_short_two_pass_api_gives_the_same_records(ctx, force):
 def test_long_entry_or_few_entries_keep_the_wave_per_entry_kernels(ctx, monkeypatch):
     c = synth.make_quiva(5000, seed=4, dist="fixed", mean=150)
     want = O.dexqv(c.text)
-    monkeypatch.setenv("DEXGPU_NO_SHORT", "1")
+    set_flag(monkeypatch, "no_short", "1")
     assert ctx.dexqv(c.text) == want and not _took_short(ctx)
-    monkeypatch.delenv("DEXGPU_NO_SHORT")
+    set_flag(monkeypatch, "no_short", None)
     lens = np.full(5000, 150, np.uint32); lens[4321] = 9000
     c = synth.make_quiva(5000, seed=4, lens=lens)
     assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)

@@ -14,6 +14,8 @@ import sys
 
 import pytest
 
+from _flags import set_flag, test_env
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -28,7 +30,7 @@ def test_random_shapes(tool, rounds, seed):
 def test_random_shapes_with_the_records_walked_on_the_device():
     """The same file-driver rounds with undexqv's record walk on the device whatever the file's size (the product asks for
     256 MB), in pieces of 4 KiB: escape schemes, files without a run character, records longer than a piece, ..."""
-    env = dict(os.environ, DEXGPU_DEVICE_WALK_MIN="0", DEXGPU_WALK_PIECE="4096")
+    env = dict(os.environ, DEXGPU_TEST=test_env(device_walk_min=0, walk_piece=4096))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_files.py"), "60", "23"], capture_output=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout.decode()[-2000:], r.stderr.decode()[-2000:])
     assert b"OK" in r.stdout.splitlines()[-1]

@@ -5,6 +5,8 @@ records shorter and longer than a piece, headers with leading 255s, empty entrie
 import numpy as np
 import pytest
 
+from _flags import set_flag, test_env
+
 import _oracle as O
 from dextractor_amd import _lib as L
 from dextractor_amd import api, synth
@@ -39,9 +41,9 @@ def _same(h, g):
 
 @pytest.mark.parametrize("n,mean,piece", [(1500, 4000, 16384), (400, 300, 4096), (3000, 300, 32768), (60, 9000, 8192), (2500, 2000, 0)])
 def test_device_walk_is_the_host_walk(ctx, monkeypatch, n, mean, piece):
-    """Many pieces per file (DEXGPU_WALK_PIECE: tests only; 0 = the product's 32 KiB), records shorter and longer than a piece."""
+    """Many pieces per file (DEXGPU_TEST=walk_piece=<bytes>: tests only; 0 = the product's 32 KiB), records shorter and longer than a piece."""
     if piece:
-        monkeypatch.setenv("DEXGPU_WALK_PIECE", str(piece))
+        set_flag(monkeypatch, "walk_piece", str(piece))
     c = synth.make_quiva(n, seed=100 + n, mean=mean)
     img = ctx.dexqv(c.text)
     assert img == O.dexqv(c.text)
@@ -51,7 +53,7 @@ def test_device_walk_is_the_host_walk(ctx, monkeypatch, n, mean, piece):
 
 
 def test_device_walk_empty_entries_lossy_and_long_runs(ctx, monkeypatch):
-    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    set_flag(monkeypatch, "walk_piece", "4096")
     lens = np.array([0, 1, 2, 15, 16, 17, 0, 0, 1023, 1024, 1025, 5000, 0, 3, 70000, 2, 0], np.uint32)
     cases = [(synth.make_quiva(len(lens), seed=7, lens=lens).text, False),
              (synth.make_quiva(200, seed=8, mean=3000).text, True),
@@ -67,7 +69,7 @@ def test_device_walk_empty_entries_lossy_and_long_runs(ctx, monkeypatch):
 def test_device_walk_wells_that_jump(ctx, monkeypatch):
     """Framing bytes of 255 (255 wells each, undexqv.c:124-133) in front of a header -- and bytes of 255 at the end of the record
     before it, which make a start one byte early walk just as well: the chain takes them off again (trim)."""
-    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    set_flag(monkeypatch, "walk_piece", "4096")
     c = synth.make_quiva(600, seed=31, mean=1500)
     hdr = c.hdr.copy()
     hdr[:, 0] = np.cumsum(np.where(np.arange(len(hdr)) % 7 == 3, 700 + 255 * (np.arange(len(hdr)) % 5), 1))     # wells that jump by 255 k + j
@@ -81,10 +83,10 @@ def test_device_walk_wells_that_jump(ctx, monkeypatch):
 
 
 def test_undexqv_plans_on_the_device(ctx, monkeypatch):
-    """dx_file_undexqv with the device walk (DEXGPU_DEVICE_WALK_MIN=0: whatever the size; the product asks for 256 MB): the
-    oracle's text; the walk kernels ran; DEXGPU_HOST_WALK=1 takes it back to the host."""
-    monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")
-    monkeypatch.setenv("DEXGPU_WALK_PIECE", "8192")
+    """dx_file_undexqv with the device walk (DEXGPU_TEST=device_walk_min=0: whatever the size; the product asks for 256 MB): the
+    oracle's text; the walk kernels ran; DEXGPU_TEST=host_walk takes it back to the host."""
+    set_flag(monkeypatch, "device_walk_min", "0")
+    set_flag(monkeypatch, "walk_piece", "8192")
     for text, upper in ((synth.make_quiva(300, seed=41, mean=2500).text, True), (synth.make_quiva(50, seed=42, mean=12000).text, False)):
         img = O.dexqv(text)
         want = O.undexqv(img, upper=upper)
@@ -92,7 +94,7 @@ def test_undexqv_plans_on_the_device(ctx, monkeypatch):
         assert ctx.undexqv(img, upper=upper) == want
         assert "k_qv_walk" in ctx.kernel_times()
         ctx.profile(False)
-    monkeypatch.setenv("DEXGPU_HOST_WALK", "1")
+    set_flag(monkeypatch, "host_walk", "1")
     ctx.profile(True)
     assert ctx.undexqv(img, upper=False) == O.undexqv(img)
     assert "k_qv_walk" not in ctx.kernel_times()
@@ -103,8 +105,8 @@ def test_what_the_device_walk_turns_down_goes_to_the_host(ctx, monkeypatch):
     """A stream cut short, or bytes damaged in the middle: DX_E_MISMATCH from the device walk; the file driver then walks on the
     host and reports what the host walk reports.  Records much longer than the guesses' budget (two pieces): the chain is
     walked piece by piece from where it arrives -- same index -- or given up after a few dozen rounds -- same text."""
-    monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")
-    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    set_flag(monkeypatch, "device_walk_min", "0")
+    set_flag(monkeypatch, "walk_piece", "4096")
     c = synth.make_quiva(120, seed=51, mean=3000)
     img = O.dexqv(c.text)
     coding, flip, prefix, used = api.qv_read_coding(img[2:])
@@ -134,7 +136,7 @@ def test_what_the_device_walk_turns_down_goes_to_the_host(ctx, monkeypatch):
 def test_device_walk_of_a_byte_swapped_file(ctx, monkeypatch):
     """A file written on a host of the other endianness (GETFLIP, QV.c:553-568): code words and framing fields byte-swapped."""
     import struct
-    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    set_flag(monkeypatch, "walk_piece", "4096")
     c = synth.make_quiva(150, seed=61, mean=2000)
     img = O.dexqv(c.text)
     h = api.qv_walk(img)
@@ -165,7 +167,7 @@ def test_device_walk_of_damaged_streams(ctx, monkeypatch):
     """One byte of a sound image changed, or the image cut: the device walk gives the host walk's index or turns the stream down
     (DX_E_MISMATCH) -- never another index, never a fault --, and the file driver with the device walk forced on returns what it
     returns with the walk on the host: the same text, or the same refusal."""
-    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    set_flag(monkeypatch, "walk_piece", "4096")
     c = synth.make_quiva(150, seed=71, mean=2500)
     img = O.dexqv(c.text)
     coding, flip, prefix, used = api.qv_read_coding(img[2:])
@@ -194,48 +196,48 @@ def test_device_walk_of_damaged_streams(ctx, monkeypatch):
             outcomes["same"] += 1
         d.free()
         res = []
-        for env in ({"DEXGPU_DEVICE_WALK_MIN": "0"}, {"DEXGPU_HOST_WALK": "1"}):
-            for kk, vv in env.items(): monkeypatch.setenv(kk, vv)
+        for env in ({"device_walk_min": "0"}, {"host_walk": "1"}):
+            for kk, vv in env.items(): set_flag(monkeypatch, kk, vv)
             try:
                 res.append(ctx.undexqv(bad))
             except L.DexGPUError as e:
                 res.append(e.code)
-            for kk in env: monkeypatch.delenv(kk)
+            for kk in env: set_flag(monkeypatch, kk, None)
         assert res[0] == res[1], (k, type(res[0]), type(res[1]))
     assert outcomes["same"] > 5 and outcomes["turned down"] > 5, outcomes
 
 
 def test_a_walk_that_cannot_allocate_leaves_the_host_walk_a_clean_slate(ctx, monkeypatch):
-    """The device walk's scratch does not fit (DEXGPU_FAIL_MALLOC_OVER: allocations beyond that size fail like a full device):
+    """The device walk's scratch does not fit (DEXGPU_TEST=fail_malloc_over=<bytes>: allocations beyond that size fail like a full device):
     dx_qv_walk_device reports it, and the file driver goes on with the host walk -- whose launches must not trip over the failed
     allocation's error (the runtime keeps it until it is read)."""
-    monkeypatch.setenv("DEXGPU_DEVICE_WALK_MIN", "0")
-    monkeypatch.setenv("DEXGPU_WALK_PIECE", "4096")
+    set_flag(monkeypatch, "device_walk_min", "0")
+    set_flag(monkeypatch, "walk_piece", "4096")
     c = synth.make_quiva(400, seed=81, mean=3000)
     img = O.dexqv(c.text)
     want = O.undexqv(img)
     coding, flip, prefix, used = api.qv_read_coding(img[2:])
     d = ctx.to_device(np.frombuffer(img, np.uint8))
-    monkeypatch.setenv("DEXGPU_FAIL_MALLOC_OVER", str(len(img) // 8))       # the records' scratch (0.44 of the image) fails, the tables do not
+    set_flag(monkeypatch, "fail_malloc_over", str(len(img) // 8))       # the records' scratch (0.44 of the image) fails, the tables do not
     with pytest.raises(L.DexGPUError) as e:
         ctx.qv_walk_device(d, len(img), 2 + used, coding, 1, flip)
     assert e.value.code in (-2, -6), e.value                                 # DX_E_NOMEM / DX_E_HIP
-    monkeypatch.delenv("DEXGPU_FAIL_MALLOC_OVER")
+    set_flag(monkeypatch, "fail_malloc_over", None)
     d.free()
     # through the file driver: the image goes up (it fits), the walk's scratch does not, the host plan takes over
-    monkeypatch.setenv("DEXGPU_FAIL_MALLOC_OVER", str(len(img) // 8))
-    monkeypatch.setenv("DEXGPU_FAIL_MALLOC_UNDER", str(len(img) // 2 + len(img) // 4))
+    set_flag(monkeypatch, "fail_malloc_over", str(len(img) // 8))
+    set_flag(monkeypatch, "fail_malloc_under", str(len(img) // 2 + len(img) // 4))
     ctx.profile(True)
     got = ctx.undexqv(img)
     assert "k_qv_walk" not in ctx.kernel_times()                             # (the device walk did not get as far as a kernel)
     ctx.profile(False)
-    monkeypatch.delenv("DEXGPU_FAIL_MALLOC_OVER")
-    monkeypatch.delenv("DEXGPU_FAIL_MALLOC_UNDER")
+    set_flag(monkeypatch, "fail_malloc_over", None)
+    set_flag(monkeypatch, "fail_malloc_under", None)
     assert got == want
-    monkeypatch.setenv("DEXGPU_FAIL_MALLOC_OVER", str(len(img) // 8))       # ... and when not even the image goes up
+    set_flag(monkeypatch, "fail_malloc_over", str(len(img) // 8))       # ... and when not even the image goes up
     with pytest.raises(L.DexGPUError):
         ctx.undexqv(img)
-    monkeypatch.delenv("DEXGPU_FAIL_MALLOC_OVER")
+    set_flag(monkeypatch, "fail_malloc_over", None)
     assert ctx.undexqv(img) == want                                          # nothing of it is left behind
 
 
@@ -246,7 +248,7 @@ def test_decode_with_the_groups_the_walk_notes(ctx, monkeypatch, n, mean, piece,
     k_qv_decode_runs takes them (dx_qv_use_dindex): the decode with them is the oracle's text (QV.c:604-691, 823-847), the wave-per-line
     kernel ran, and the lines that got no groups (runs with literals: a group's positions beyond 16 bits) still come out right."""
     if piece:
-        monkeypatch.setenv("DEXGPU_WALK_PIECE", str(piece))
+        set_flag(monkeypatch, "walk_piece", str(piece))
     kw = {"prof": synth.pacbio_profile(del_run_p=prof[0], sub_run_p=prof[1])} if prof else {}
     c = synth.make_quiva(n, seed=300 + n, mean=mean, **kw)
     img = O.dexqv(c.text)
@@ -286,10 +288,10 @@ def test_decode_with_the_groups_the_walk_notes(ctx, monkeypatch, n, mean, piece,
 def test_plain_lines_the_walk_leaves_without_words(ctx, monkeypatch):
     """An insertion line of one value nearly throughout codes to a bit a symbol: a burst of the walk's look-ups passes more than
     64 symbols, two marks of the index at once, and the line is left without its words (DXL_SYNC_NONE) -- k_qv_decode_plain takes
-    exactly those lines, k_qv_decode_sync the others; same text.  With DEXGPU_NO_SYNCINDEX / DEXGPU_NO_RUNINDEX the lane-per-line
+    exactly those lines, k_qv_decode_sync the others; same text.  With DEXGPU_TEST=no_syncindex / no_runindex the lane-per-line
     kernels take everything: same text again."""
     import dataclasses
-    monkeypatch.setenv("DEXGPU_WALK_PIECE", "8192")
+    set_flag(monkeypatch, "walk_piece", "8192")
     base = synth.pacbio_profile()
     flat = dataclasses.replace(base, ins_lut=synth.make_lut([ord("5"), ord("6"), ord("7")], [0.97, 0.02, 0.01]))
     c = synth.make_quiva(300, seed=91, mean=5000, prof=flat)
@@ -308,8 +310,8 @@ def test_plain_lines_the_walk_leaves_without_words(ctx, monkeypatch):
         d_oo = ctx.to_device(ooff)
         ctx.qv_set_coding(coding)
         wantb = np.frombuffer(want, np.uint8)
-        for env in ({}, {"DEXGPU_NO_SYNCINDEX": "1"}, {"DEXGPU_NO_RUNINDEX": "1"}):
-            for k_, v_ in env.items(): monkeypatch.setenv(k_, v_)
+        for env in ({}, {"no_syncindex": "1"}, {"no_runindex": "1"}):
+            for k_, v_ in env.items(): set_flag(monkeypatch, k_, v_)
             d_out = ctx.to_device(np.zeros(total + 64, np.uint8))
             x.use(d)
             ctx.profile(True)
@@ -324,7 +326,7 @@ def test_plain_lines_the_walk_leaves_without_words(ctx, monkeypatch):
             if not env:
                 assert "k_qv_decode_sub" in kt and "k_qv_decode_plain" in kt and "k_qv_decode_runs" in kt, kt
             d_out.free()
-            for k_ in env: monkeypatch.delenv(k_)
+            for k_ in env: set_flag(monkeypatch, k_, None)
         d_oo.free()
     finally:
         x.free()

@@ -8,6 +8,8 @@ import re
 import numpy as np
 import pytest
 
+from _flags import set_flag, test_env
+
 import _oracle as O
 from dextractor_amd import _lib as L
 from dextractor_amd import api, synth
@@ -269,12 +271,12 @@ def test_walk_on_several_threads_equals_front_to_back(monkeypatch):
     monkeypatch.setenv("DEXGPU_WALK_THREADS", "1")
     w1 = api.qv_walk(dx)
     monkeypatch.setenv("DEXGPU_WALK_THREADS", "7")
-    monkeypatch.setenv("DEXGPU_WALK_REQUIRE_PARALLEL", "1")
+    set_flag(monkeypatch, "walk_require_parallel", "1")
     w7 = api.qv_walk(dx)
     assert w7["n"] == w1["n"] == len(c.len)
     for k in ("rec_off", "hdr_off", "seg", "len", "hdr4"):
         assert (w7[k] == w1[k]).all()
-    monkeypatch.delenv("DEXGPU_WALK_REQUIRE_PARALLEL")
+    set_flag(monkeypatch, "walk_require_parallel", None)
     bad = bytearray(dx)
     bad[len(bad) // 2: len(bad) // 2 + 64] = bytes(64)        # a hole in the middle: no chain of walks survives it ...
     got = None
@@ -323,8 +325,8 @@ def test_out_bound_covers_the_encoded_size():
 def test_register_budgets_of_the_kernels_that_share_a_cu():
     """The build leaves every kernel's register / scratch / LDS use in dextractor_amd/kernel_resources.txt.  Four waves per
     SIMD (<= 128 VGPRs) for the kernels whose latency hiding was measured at four; no kernel may spill to scratch.  (Rounds 2
-    and 3 held the encoder to 112 so that the compaction's waves, <= 56 VGPRs, fit beside it: the product route has no
-    compaction any more -- records are written in place -- and the slot route behind DEXGPU_SLOTS=1 is a fallback.)"""
+    and 3 held the encoder to 112 so that the compaction's waves fit beside it; round 6 took the scratch slots and their
+    compaction kernel out: every route writes its records in place.)"""
     path = os.path.join(os.path.dirname(L.LIB_PATH), "kernel_resources.txt")
     if not os.path.isfile(path):
         pytest.skip("no kernel_resources.txt (library built without the Makefile)")
@@ -340,7 +342,7 @@ def test_register_budgets_of_the_kernels_that_share_a_cu():
     assert all(v["vgprs"] <= 128 for v in of("_Z16k_qv_encode_fastILb0EE"))    # the product encoder, no group index
     assert len(of("_Z16k_qv_encode_fast")) == 2                                 # with and without the group index, nothing else
     assert all(v["vgprs"] <= 128 for v in of("_Z11k_qv_encode7qv_args"))         # the generic encoder
-    assert all(v["vgprs"] <= 56 for v in of("_Z12k_qv_compact"))
+    assert not [k for k in res if "k_qv_compact" in k or "k_qv_bounds" in k]      # (the slot route is gone)
     assert all(v["waves_per_simd"] >= 4 for v in of("_Z9k_qv_hist") + of("_Z16k_qv_encode_fast") + of("_Z17k_qv_decode_plain"))
     assert all(v["waves_per_simd"] >= 6 for v in of("_Z15k_qv_decode_subILi2EE"))
 

@@ -11,8 +11,8 @@ P
 }
 for rep in 1 2; do
   run new_$rep X=1
-  run noguess_$rep DEXGPU_NO_SCAN_GUESS=1
-  run onegroup_$rep DEXGPU_ONEPASS_GROUPS=1
+  run noguess_$rep DEXGPU_TEST=no_scan_guess
+  run onegroup_$rep DEXGPU_TEST=onepass_groups=1
 done
 bash profiles/tools/timeline.sh --no-walk-index --no-verify > $O/s1_timeline.log 2>&1; cp $O/timeline.txt $O/s1_timeline.txt
 cd /tmp && export TMPDIR=/tmp

@@ -3,7 +3,7 @@
 for cfg in "16384 300" "65536 300" "262144 300" "65536 1000" "262144 1000"; do
   set -- $cfg
   for ns in 0 1; do
-    DEXGPU_NO_SHORT=$ns python bench.py --entries $1 --mean $2 --steps 20 --warmup 3 --only-main --no-cpu-baseline --no-walk-index --no-verify > gpurun_out/sn.json 2>/dev/null
+    DEXGPU_TEST=no_short=$ns python bench.py --entries $1 --mean $2 --steps 20 --warmup 3 --only-main --no-cpu-baseline --no-walk-index --no-verify > gpurun_out/sn.json 2>/dev/null
     python - $1 $2 $ns <<P
 import json,sys
 d=json.load(open("gpurun_out/sn.json"))

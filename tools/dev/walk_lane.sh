@@ -1,8 +1,8 @@
 #!/bin/bash
-# tools/dev/walk_lane.sh: pieces a lane (DEXGPU_WALK_PER_LANE) against the walk's time, fixed and lognormal lengths
+# tools/dev/walk_lane.sh: pieces a lane (DEXGPU_TEST=walk_per_lane=<n>) against the walk's time, fixed and lognormal lengths
 for dist in fixed lognormal; do
   for pl in 2 4 8; do
-    DEXGPU_WALK_PER_LANE=$pl DEXGPU_WALK_DEBUG=1 python bench.py --dist $dist --no-cpu-baseline --only-main --steps 2 --warmup 1 > gpurun_out/wl.json 2> gpurun_out/wl.err
+    DEXGPU_TEST=walk_per_lane=$pl,walk_debug python bench.py --dist $dist --no-cpu-baseline --only-main --steps 2 --warmup 1 > gpurun_out/wl.json 2> gpurun_out/wl.err
     python - $dist $pl <<P
 import json,sys,re
 d=json.loads([l for l in open("gpurun_out/wl.json") if l.startswith("{")][0]); w=d["device_walk"]

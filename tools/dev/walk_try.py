@@ -7,7 +7,7 @@ from dextractor_amd import api, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 mean = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 if len(sys.argv) > 3:
-    os.environ["DEXGPU_WALK_PIECE"] = sys.argv[3]
+    os.environ["DEXGPU_TEST"] = "walk_piece=" + sys.argv[3]
 with api.Context(0) as ctx:
     c = synth.make_quiva(n, seed=77, mean=mean)
     img = ctx.dexqv(c.text)
