@@ -68,6 +68,7 @@ class QVDIndex(C.Structure):                     # dx_qv_dindex
 # name -> (restype, argtypes); every symbol include/dexgpu.h declares
 _P = C.c_void_p
 SINK_FN = C.CFUNCTYPE(C.c_int, _P, C.POINTER(C.c_uint8), C.c_size_t, C.c_size_t)     # dx_sink_fn
+READ_FN = C.CFUNCTYPE(C.c_long, _P, _P, C.c_size_t)                                   # dx_read_fn
 SIGNATURES = {
     "dx_device_count": (C.c_int, []),
     "dx_open": (C.c_int, [C.c_int, C.POINTER(_P)]),
@@ -147,6 +148,9 @@ SIGNATURES = {
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "dx_file_undexqv": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "dx_qv_subindex": (C.c_int, [_P, C.c_int]),
+    "dx_file_pack2_stream": (C.c_int, [_P, C.c_int, READ_FN, _P, C.c_size_t, SINK_FN, _P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_int)]),
+    "dx_file_unpack2_stream": (C.c_int, [_P, C.c_int, READ_FN, _P, C.c_size_t, C.c_uint32, SINK_FN, _P, C.POINTER(C.c_size_t)]),
     "dx_file_unpack2_to": (C.c_int, [_P, C.c_int, _P, C.c_size_t, C.c_uint32, SINK_FN, _P, C.POINTER(C.c_size_t)]),
     "dx_file_dexqv_to": (C.c_int, [_P, _P, C.c_size_t, C.c_int, SINK_FN, _P, C.POINTER(C.c_size_t),
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),

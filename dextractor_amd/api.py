@@ -371,6 +371,48 @@ class Context:
         self._chk(rc)
         return total.value
 
+    def pack2_stream(self, read, sink, arrow=False, chunk=0) -> int:
+        """dx_file_pack2_stream: read(want: int) -> bytes (fewer than want only at the end); sink(data: bytes, at: int) -> falsy
+        to go on; returns the image's size."""
+        total, line, code = C.c_size_t(), C.c_uint64(), C.c_int()
+        cb, box = self._sink(sink)
+
+        def rd(user, buf, want):
+            try:
+                data = read(want)
+                C.memmove(buf, data, len(data))
+                return len(data)
+            except BaseException as e:                       # noqa: BLE001 -- re-raised by the caller
+                box.append(e)
+                return -1
+        rcb = L.READ_FN(rd)
+        rc = self.lib.dx_file_pack2_stream(self.h, int(arrow), rcb, None, int(chunk), cb, None, C.byref(total), C.byref(line), C.byref(code))
+        if box:
+            raise box[0]
+        if rc != 0:
+            raise L.DexGPUError(rc, f"line {line.value} (DX_IDX code {code.value}): " + (self.lib.dx_last_error(self.h) or b"").decode())
+        return total.value
+
+    def unpack2_pieces(self, read, sink, mode=L.DX_LETTERS_LOWER, width=80, chunk=0) -> int:
+        """dx_file_unpack2_stream: read(want: int) -> bytes of the image; sink(data: bytes, at: int); returns the text's size."""
+        total = C.c_size_t()
+        cb, box = self._sink(sink)
+
+        def rd(user, buf, want):
+            try:
+                data = read(want)
+                C.memmove(buf, data, len(data))
+                return len(data)
+            except BaseException as e:                       # noqa: BLE001 -- re-raised by the caller
+                box.append(e)
+                return -1
+        rcb = L.READ_FN(rd)
+        rc = self.lib.dx_file_unpack2_stream(self.h, int(mode), rcb, None, int(chunk), int(width), cb, None, C.byref(total))
+        if box:
+            raise box[0]
+        self._chk(rc)
+        return total.value
+
     def dexqv_stream(self, quiva: bytes, sink, lossy=False) -> int:
         """dx_file_dexqv_to: sink(data: bytes, at: int) -> falsy to go on; returns the image's size."""
         total, line, code = C.c_size_t(), C.c_uint64(), C.c_int()

@@ -251,6 +251,39 @@ static int sink_pwrite(void *user, uint8_t *data, size_t len, size_t at)
   return 0;
 }
 
+/* a pipe: the chunks come in file order (dx_file_pack2_stream) */
+static int sink_stream(void *user, uint8_t *data, size_t len, size_t at)
+{ (void) at;
+  return fwrite(data, 1, len, (FILE *) user) != len;
+}
+
+/* dx_read_fn over a descriptor: a pipe gives what it has, so ask until the want is met or the input ends */
+static long read_fd(void *user, void *buf, size_t want)
+{ const int fd = *(int *) user;
+  size_t got = 0;
+  while (got < want)
+    { const ssize_t k = read(fd, (uint8_t *) buf + got, want - got);
+      if (k < 0) return -1;
+      if (k == 0) break;
+      got += (size_t) k;
+    }
+  return (long) got;
+}
+
+/* ... with the input's first bytes looked at beforehand (an image's endian key, for the reference's words about a wrong one) */
+typedef struct { int fd; uint8_t pre[2]; size_t npre, given; } peek_fd;
+static long read_peeked(void *user, void *buf, size_t want)
+{ peek_fd *p = user;
+  size_t got = 0;
+  while (p->given < p->npre && got < want) ((uint8_t *) buf)[got++] = p->pre[p->given++];
+  if (got < want)
+    { const long k = read_fd(&p->fd, (uint8_t *) buf + got, want - got);
+      if (k < 0) return -1;
+      got += (size_t) k;
+    }
+  return (long) got;
+}
+
 static int sink_memory(void *user, uint8_t *data, size_t len, size_t at)
 { memcpy((uint8_t *) user + at, data, len);
   return 0;
@@ -545,6 +578,63 @@ int dex_tool_main(int tool, int argc, char *argv[])
               if (rc != DX_E_AGAIN)
                 leave(report_failure(ctx, tool, NULL, 0, rc, line, code));
             }                                              /* (DX_E_AGAIN: through memory, below) */
+        }
+      if ((tool == TOOL_DEXTA || tool == TOOL_DEXAR) && Nctx <= 1)
+        { /* dexta -i / dexar -i, and a file of 256 MB and more: the text goes through the device a chunk of whole records at a
+             time (dx_file_pack2_stream) -- as the reference reads record after record (dexta.c:104-205), with a chunk's memory
+             whatever the input's size, and no image of a large file in this process */
+          struct stat st;
+          const off_t least = (off_t) dx_test_num("fd_min", (long long) 256 << 20);
+          const int   isfile = fstat(fileno(input), &st) == 0 && S_ISREG(st.st_mode);
+          if (PIPE || (isfile && st.st_size >= least && file_is_ours(output)))
+            { uint64_t line = 0;
+              int      code = 0, rc, fdin = fileno(input), fdout = fileno(output);
+              if (Opening)
+                { pthread_join(Opener, NULL);
+                  Opening = 0;
+                }
+              ctx = Ctx0;
+              tmark("GPU context open");
+              if (PIPE || !file_is_ours(output))
+                rc = dx_file_pack2_stream(ctx, tool == TOOL_DEXAR, read_fd, &fdin, 0, sink_stream, output, &out_len, &line, &code);
+              else
+                { rc = dx_file_pack2_stream(ctx, tool == TOOL_DEXAR, read_fd, &fdin, 0, sink_pwrite, &fdout, &out_len, &line, &code);
+                  if (rc == DX_OK && lseek(fdout, (off_t) out_len, SEEK_SET) < 0) rc = DX_E_IO;
+                }
+              if (rc == DX_E_IO)
+                { fprintf(stderr, "%s: System error, write failed!\n", Prog);
+                  leave(2);
+                }
+              if (rc != DX_OK)
+                leave(report_failure(ctx, tool, NULL, 0, rc, line, code));
+              tmark("output written");
+              goto written;
+            }
+        }
+      if ((tool == TOOL_UNDEXTA || tool == TOOL_UNDEXAR) && PIPE)
+        { /* undexta -i / undexar -i: the image through the device a chunk of whole records at a time, their text out in order
+             (the reference reads and writes record after record, undexta.c:175-271) */
+          int     rc;
+          peek_fd pk = { fileno(input), { 0, 0 }, 0, 0 };
+          { const long k = read_fd(&pk.fd, pk.pre, 2);
+            pk.npre = k > 0 ? (size_t) k : 0;
+          }
+          if (Opening)
+            { pthread_join(Opener, NULL);
+              Opening = 0;
+            }
+          ctx = Ctx0;
+          tmark("GPU context open");
+          rc = dx_file_unpack2_stream(ctx, tool == TOOL_UNDEXAR ? DX_LETTERS_ARROW : (UPPER ? DX_LETTERS_UPPER : DX_LETTERS_LOWER),
+                                      read_peeked, &pk, 0, (uint32_t) width, sink_stream, output, &out_len);
+          if (rc == DX_E_IO)
+            { fprintf(stderr, "%s: System error, write failed!\n", Prog);
+              leave(2);
+            }
+          if (rc != DX_OK)
+            leave(report_failure(ctx, tool, pk.pre, pk.npre, rc, 0, 0));
+          tmark("output written");
+          goto written;
         }
       in = slurp(input, &n, &mapped);
       tmark("input read");

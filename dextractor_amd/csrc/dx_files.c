@@ -96,12 +96,15 @@ static size_t pack2_cap(dx_ctx *ctx, size_t n)
   return 1.35 * (double) n > 0.9 * (double) fr ? (size_t) (0.6 * (double) fr) : 0;
 }
 
-int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
-                  uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
+/* One piece of a .fasta / .arrow text -- whole records, the first of them the file's first (`first`: the image then begins with the
+   key and the name prefix, dexta.c:124-129) or a later one; *well: the last record's well before and after (the record framing
+   codes differences, dexta.c:187-193). */
+static int pack2_piece(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n, int first, int32_t *well,
+                       uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
 { dpool     pool = { {0}, 0, ctx };
   uint64_t  cnt = 0, i, *off = NULL, *hoff = NULL, *ooff = NULL;
   uint32_t *tlen = NULL, *nsym = NULL;
-  int32_t  *hdr4 = NULL, lwell = 0;
+  int32_t  *hdr4 = NULL, lwell = *well;
   uint16_t *cnr4 = NULL;
   uint8_t  *blob = NULL, *img = NULL;
   size_t    plen = 0, at, total;
@@ -156,7 +159,8 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
   if (!blob) { rc = DX_E_NOMEM; goto done; }
   TRY(dx_frame_headers(hdr4, cnr4, cnt, arrow, &lwell, blob, hoff));
 
-  at = 2 + 4 + plen;                                   /* key, prefix length, prefix: dexta.c:124-129 */
+  if (!first) plen = 0;
+  at = first ? 2 + 4 + plen : 0;                       /* key, prefix length, prefix: dexta.c:124-129 */
   for (i = 0; i < cnt; i++)
     { ooff[i] = at;
       at += (size_t) (hoff[i+1] - hoff[i]) + (((size_t) nsym[i] + 3) >> 2);
@@ -165,12 +169,13 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
 
   img = malloc(total + 16);
   if (!img) { rc = DX_E_NOMEM; goto done; }
-  { uint16_t key = 0x55aa;
-    int32_t  pl  = (int32_t) plen;
-    memcpy(img, &key, 2);
-    memcpy(img + 2, &pl, 4);
-    memcpy(img + 6, text, plen);
-  }
+  if (first)
+    { uint16_t key = 0x55aa;
+      int32_t  pl  = (int32_t) plen;
+      memcpy(img, &key, 2);
+      memcpy(img + 2, &pl, 4);
+      memcpy(img + 6, text, plen);
+    }
 
   if (cnt > 0 && sliced)
     { uint64_t *rel = NULL, i0, i1, most = 0;
@@ -225,11 +230,92 @@ int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
       TRY(dx_d2h(ctx, img + ooff[0], (uint8_t *) d_out + ooff[0], total - (size_t) ooff[0]));
     }
   *out = img; *out_len = total; img = NULL;
+  *well = lwell;
   rc = DX_OK;
 
 done:
   dfree_all(&pool);
   free(off); free(hoff); free(ooff); free(tlen); free(nsym); free(hdr4); free(cnr4); free(blob); free(img);
+  return rc;
+}
+
+int dx_file_pack2(dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
+                  uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode)
+{ int32_t well = 0;
+  if (ctx == NULL || out == NULL || out_len == NULL) return DX_E_ARG;
+  return pack2_piece(ctx, arrow, text, n, 1, &well, out, out_len, errline, errcode);
+}
+
+/* dexta / dexar of a text that arrives in pieces -- a pipe, or a file too large to hold: the reference reads record after record
+   (dexta.c:104-205, dexar.c:103-211) and never holds more than one.  Here: `chunk` bytes at a time from rd(); a piece is cut in
+   front of the buffer's last header but one (so that what stays behind begins with a header and holds another: the last piece,
+   which the end of the input makes, then tells a lone last header -- the reference's "too long" -- from a file of one header), the
+   piece's records packed on the device like a whole file's, its bytes handed to the sink in file order, the rest moved to the
+   buffer's front.  Memory: the buffer (chunk + a record or two) and a piece's image. */
+int dx_file_pack2_stream(dx_ctx *ctx, int arrow, dx_read_fn rd, void *ruser, size_t chunk,
+                         dx_sink_fn sink, void *suser, size_t *out_len, uint64_t *errline, int *errcode)
+{ uint8_t *buf = NULL;
+  size_t   cap, have = 0, total = 0;
+  uint64_t lines = 0;
+  int32_t  well = 0;
+  int      eof = 0, first = 1, rc = DX_OK;
+
+  if (ctx == NULL || rd == NULL || sink == NULL) return DX_E_ARG;
+  if (chunk == 0) chunk = (size_t) dx_test_num("stream_chunk", (long long) 256 << 20);
+  if (chunk < 4096) chunk = 4096;
+  cap = chunk + 65536;
+  buf = malloc(cap);
+  if (buf == NULL) return DX_E_NOMEM;
+  if (out_len) *out_len = 0;
+  for (;;)
+    { size_t cut, k, heads = 0;
+      while (!eof && have < chunk)
+        { const long got = rd(ruser, buf + have, chunk - have);
+          if (got < 0) { rc = DX_E_IO; goto done; }
+          if (got == 0) eof = 1;
+          have += (size_t) got;
+        }
+      cut = have;
+      if (!eof)                                        /* the last header line but one that is not the buffer's first line -- nor stands */
+        { int good = 0;                                /* behind another header line: a piece that ENDS in a header reads like a file that does */
+          for (k = have; k > 1 && !good; k--)
+            if (buf[k - 1] == '>' && buf[k - 2] == '\n')
+              { size_t q = k - 2;                       /* the line in front of this header begins at q */
+                while (q > 0 && buf[q - 1] != '\n') q--;
+                heads++;
+                if (heads >= 2 && buf[q] != '>') { cut = k - 1; good = 1; }
+              }
+          if (!good)                                   /* a record (or two) larger than the chunk: more of it */
+            { uint8_t *nb;
+              chunk += chunk;
+              nb = realloc(buf, chunk + 65536);
+              if (nb == NULL) { rc = DX_E_NOMEM; goto done; }
+              buf = nb; cap = chunk + 65536;
+              continue;
+            }
+        }
+      if (cut > 0 || first)
+        { uint8_t *img = NULL;
+          size_t   il = 0;
+          uint64_t el = 0;
+          rc = pack2_piece(ctx, arrow, buf, cut, first, &well, &img, &il, &el, errcode);
+          if (rc != DX_OK)
+            { if (errline) *errline = el ? lines + el : 0;
+              goto done;
+            }
+          if (il > 0 && sink(suser, img, il, total)) { free(img); rc = DX_E_IO; goto done; }
+          free(img);
+          total += il;
+          for (k = 0; k < cut; k++) lines += buf[k] == '\n';
+          first = 0;
+        }
+      memmove(buf, buf + cut, have - cut);
+      have -= cut;
+      if (eof && have == 0) break;
+    }
+  if (out_len) *out_len = total;
+done:
+  free(buf);
   return rc;
 }
 
@@ -437,10 +523,14 @@ static size_t out_cap(dx_ctx *ctx, size_t n, size_t total, uint64_t units)
   }
 }
 
+/* an image that arrives in pieces (dx_file_unpack2_stream): what the file's head said, the well the last record stood at, and
+   how far into this piece the whole records reached (a piece may end inside a record: `more` says that more is coming) */
+typedef struct { int started, flip, newv, well, more; int32_t plen; char *name; size_t consumed; } u2_state;
+
 /* mode: DX_LETTERS_LOWER / _UPPER (dexta images) or _ARROW (dexar images); out != NULL: the text in memory,
    else through the sink */
 static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
-                        uint8_t **out, dx_sink_fn sink, void *user, size_t *out_len)
+                        uint8_t **out, dx_sink_fn sink, void *user, size_t *out_len, u2_state *st)
 { dpool     pool = { {0}, 0, ctx };
   rsrc      r = { img, n, 0, 0 };
   tbuf      hd = { NULL, 0, 0 };               /* all header lines, concatenated */
@@ -459,20 +549,38 @@ static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uin
   if (out) *out = NULL;
   *out_len = 0;
 
-  rd(&r, &key, 2);                                        /* undexta.c:138-159, undexar.c:136-145 */
-  if (r.bad) return DX_E_FORMAT;
-  if (key == 0x55aa)               { flip = 0; newv = 1; }
-  else if (key == 0xaa55)          { flip = 1; newv = 1; }
-  else if (!arrow && key == 0x33cc) { flip = 0; newv = 0; }
-  else if (!arrow && key == 0xcc33) { flip = 1; newv = 0; }
-  else return DX_E_FORMAT;
+  if (st != NULL) st->consumed = 0;
+  if (st != NULL && st->started)                          /* a later piece: records from its first byte on */
+    { flip = st->flip; newv = st->newv; plen = st->plen; well = st->well;
+      name = malloc((size_t) plen + 1);
+      if (!name) return DX_E_NOMEM;
+      memcpy(name, st->name, (size_t) plen + 1);
+    }
+  else
+    { rd(&r, &key, 2);                                    /* undexta.c:138-159, undexar.c:136-145 */
+      if (r.bad) return st != NULL && st->more ? DX_OK : DX_E_FORMAT;
+      if (key == 0x55aa)               { flip = 0; newv = 1; }
+      else if (key == 0xaa55)          { flip = 1; newv = 1; }
+      else if (!arrow && key == 0x33cc) { flip = 0; newv = 0; }
+      else if (!arrow && key == 0xcc33) { flip = 1; newv = 0; }
+      else return DX_E_FORMAT;
 
-  plen = rd_i32(&r, flip);                                /* undexta.c:161-169 */
-  if (r.bad || plen < 0 || (size_t) plen > n) return DX_E_FORMAT;
-  name = malloc((size_t) plen + 1);
-  if (!name) return DX_E_NOMEM;
-  rd(&r, name, (size_t) plen);
-  name[plen] = '\0';
+      plen = rd_i32(&r, flip);                            /* undexta.c:161-169 */
+      if (r.bad) return st != NULL && st->more ? DX_OK : DX_E_FORMAT;            /* (DX_OK, nothing consumed: the head is not all here yet) */
+      if (plen < 0) return DX_E_FORMAT;
+      if ((size_t) plen > n - r.at) return st != NULL && st->more && plen < (1 << 24) ? DX_OK : DX_E_FORMAT;
+      name = malloc((size_t) plen + 1);
+      if (!name) return DX_E_NOMEM;
+      rd(&r, name, (size_t) plen);
+      name[plen] = '\0';
+      if (st != NULL)
+        { st->name = malloc((size_t) plen + 1);
+          if (st->name == NULL) { free(name); return DX_E_NOMEM; }
+          memcpy(st->name, name, (size_t) plen + 1);
+          st->started = 1; st->flip = flip; st->newv = newv; st->plen = plen;
+          st->consumed = r.at;
+        }
+    }
 
   while (r.at < r.n)                                      /* undexta.c:175-271: walk the records */
     { uint8_t  byte;
@@ -480,6 +588,8 @@ static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uin
       uint16_t cnr[4] = { 0, 0, 0, 0 };
       uint32_t rlen;
       size_t   clen;
+      const size_t rec_at = r.at;
+      const int    well_was = well;
 
       rd(&r, &byte, 1);
       while (byte == 255 && !r.bad)
@@ -495,11 +605,16 @@ static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uin
         }
       else
         { beg = rd_u16(&r, flip); end = rd_u16(&r, flip); qv = rd_u16(&r, flip); }
+      if (r.bad && st != NULL && st->more)                /* the piece ends inside this record's head: the next piece has it whole */
+        { r.at = rec_at; r.bad = 0; well = well_was; break; }
       if (r.bad || end < beg || (int64_t) end - (int64_t) beg > 0x7fffffff)   /* (hostile headers: no int overflow) */
         { rc = DX_E_FORMAT; goto done; }
       rlen = (uint32_t) ((int64_t) end - (int64_t) beg);
       clen = ((size_t) rlen + 3) >> 2;
-      if (r.at + clen > r.n) { rc = DX_E_FORMAT; goto done; }
+      if (r.at + clen > r.n)
+        { if (st != NULL && st->more) { r.at = rec_at; well = well_was; break; }     /* ... or inside its bases */
+          rc = DX_E_FORMAT; goto done;
+        }
 
       if (cnt == cap)
         { void *t;                                        /* a failed realloc leaves the old block to `done` */
@@ -607,6 +722,7 @@ static int unpack2_core(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uin
     }
   if (out) { *out = res; res = NULL; }
   *out_len = total;
+  if (st != NULL) { st->well = well; st->consumed = r.at; }
   rc = DX_OK;
 
 done:
@@ -617,13 +733,68 @@ done:
 
 int dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width, uint8_t **out, size_t *out_len)
 { if (out == NULL) return DX_E_ARG;
-  return unpack2_core(ctx, mode, img, n, width, out, NULL, NULL, out_len);
+  return unpack2_core(ctx, mode, img, n, width, out, NULL, NULL, out_len, NULL);
 }
 
 int dx_file_unpack2_to(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
                        dx_sink_fn sink, void *user, size_t *out_len)
 { if (sink == NULL) return DX_E_ARG;
-  return unpack2_core(ctx, mode, img, n, width, NULL, sink, user, out_len);
+  return unpack2_core(ctx, mode, img, n, width, NULL, sink, user, out_len, NULL);
+}
+
+/* undexta / undexar of an image that arrives in pieces (a pipe: undexta -i, undexta.c:175-271 reads record after record): `chunk`
+   bytes at a time from rd(), the whole records among them unpacked on the device, their text handed to the sink in file order, the
+   rest (a record the chunk cuts) moved to the buffer's front.  The same bytes as dx_file_unpack2 of the whole image. */
+typedef struct { dx_sink_fn sink; void *user; size_t shift; } u2_shift;
+static int u2_pass(void *arg, uint8_t *data, size_t len, size_t at)
+{ u2_shift *h = arg;
+  return h->sink(h->user, data, len, at + h->shift);
+}
+
+int dx_file_unpack2_stream(dx_ctx *ctx, int mode, dx_read_fn rd_, void *ruser, size_t chunk, uint32_t width,
+                           dx_sink_fn sink, void *suser, size_t *out_len)
+{ uint8_t *buf = NULL;
+  size_t   have = 0, total = 0;
+  u2_state st;
+  int      eof = 0, rc = DX_OK;
+
+  if (ctx == NULL || rd_ == NULL || sink == NULL || width == 0) return DX_E_ARG;
+  memset(&st, 0, sizeof(st));
+  if (chunk == 0) chunk = (size_t) dx_test_num("stream_chunk", (long long) 128 << 20);
+  if (chunk < 4096) chunk = 4096;
+  buf = malloc(chunk + 16);
+  if (buf == NULL) return DX_E_NOMEM;
+  if (out_len) *out_len = 0;
+  for (;;)
+    { size_t piece = 0;
+      u2_shift h = { sink, suser, total };
+      while (!eof && have < chunk)
+        { const long got = rd_(ruser, buf + have, chunk - have);
+          if (got < 0) { rc = DX_E_IO; goto done; }
+          if (got == 0) eof = 1;
+          have += (size_t) got;
+        }
+      st.more = !eof;
+      rc = unpack2_core(ctx, mode, buf, have, width, NULL, u2_pass, &h, &piece, &st);
+      if (rc != DX_OK) goto done;
+      total += piece;
+      if (eof) break;                                    /* (the last piece: whole, or the core has said DX_E_FORMAT) */
+      if (st.consumed == 0)                              /* not one whole record in the buffer: a larger one */
+        { uint8_t *nb;
+          chunk += chunk;
+          nb = realloc(buf, chunk + 16);
+          if (nb == NULL) { rc = DX_E_NOMEM; goto done; }
+          buf = nb;
+          continue;
+        }
+      memmove(buf, buf + st.consumed, have - st.consumed);
+      have -= st.consumed;
+    }
+  if (out_len) *out_len = total;
+done:
+  free(st.name);
+  free(buf);
+  return rc;
 }
 
 /* ==========================================================================================

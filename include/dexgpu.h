@@ -454,6 +454,17 @@ int  dx_qv_subindex(dx_ctx *ctx, int on);
  *   dx_file_dexqv    dexqv.c:79-143                                                             */
 int  dx_file_pack2  (dx_ctx *ctx, int arrow, const uint8_t *text, size_t n,
                      uint8_t **out, size_t *out_len, uint64_t *errline, int *errcode);
+/* The same for a text that arrives in pieces (a pipe: dexta -i, dexta.c:55-58; a file too large to hold): rd(user, buf, want)
+ * returns the bytes it put into buf (fewer than want only at the end, 0 at the end, < 0: an error); `chunk` bytes are read at a time
+ * (0: 256 MiB), whole records of them packed, the image's bytes handed to the sink in file order (at = their place in the
+ * image).  The same bytes as dx_file_pack2 of the whole text; memory: about 1.3 x chunk whatever the text's size.           */
+typedef long (*dx_read_fn)(void *user, void *buf, size_t want);
+int  dx_file_pack2_stream(dx_ctx *ctx, int arrow, dx_read_fn rd, void *ruser, size_t chunk,
+                          dx_sink_fn sink, void *suser, size_t *out_len, uint64_t *errline, int *errcode);
+/* ... and the other way (undexta -i / undexar -i, undexta.c:175-271): the image in pieces of `chunk` bytes (0: 128 MiB), the text of
+ * the whole records among them to the sink in file order; mode and width as for dx_file_unpack2.                              */
+int  dx_file_unpack2_stream(dx_ctx *ctx, int mode, dx_read_fn rd, void *ruser, size_t chunk, uint32_t width,
+                            dx_sink_fn sink, void *suser, size_t *out_len);
 int  dx_file_unpack2(dx_ctx *ctx, int mode, const uint8_t *img, size_t n, uint32_t width,
                      uint8_t **out, size_t *out_len);
 int  dx_file_dexqv  (dx_ctx *ctx, const uint8_t *text, size_t n, int lossy,

@@ -18,9 +18,9 @@ TOOLS = ["dexta", "undexta", "dexar", "undexar", "dexqv", "undexqv"]
 needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref (compiled reference) not present")
 
 
-def run(tool, args, cwd, ref=False, stdin=None):
+def run(tool, args, cwd, ref=False, stdin=None, env=None):
     exe = os.path.join(O.REF_BIN if ref else BIN, tool)
-    return subprocess.run([exe, *args], cwd=str(cwd), capture_output=True, input=stdin)
+    return subprocess.run([exe, *args], cwd=str(cwd), capture_output=True, input=stdin, env=env)
 
 
 def test_tools_are_built():
@@ -82,6 +82,32 @@ def test_cli_round_trips_equal_reference(tmp_path):
     for nme in names:
         assert _read(mine / nme) == _read(ref / nme), nme
     assert _read(mine / "c.quiva") == qv                            # dexqv | undexqv -U round trip
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("tool,kind", [("dexta", "fasta"), ("dexar", "arrow")])
+def test_cli_pipe_and_large_file_go_through_in_pieces(tmp_path, tool, kind):
+    """dexta -i / dexar -i and a "large" file (DEXGPU_TEST=fd_min=1) are packed a chunk of whole records at a time
+    (stream_chunk=20000: many pieces): the reference's bytes, the source file removed as the reference removes it."""
+    f = synth.make_seqfile(kind, 400, seed=21, mean=900, width=60)
+    env = dict(os.environ, DEXGPU_TEST=test_env(stream_chunk=20000, fd_min=1))
+    a, b = run(tool, ["-i"], tmp_path, stdin=f.text, env=env), run(tool, ["-i"], tmp_path, ref=True, stdin=f.text)
+    assert a.returncode == 0 and a.stdout == b.stdout
+    for sub in ("mine", "ref"):
+        (tmp_path / sub).mkdir()
+        _write(tmp_path / sub / ("x." + kind), f.text)
+    un = "un" + tool
+    a2 = run(un, ["-i"] + (["-U"] if tool == "dexta" else []), tmp_path, stdin=a.stdout, env=env)
+    b2 = run(un, ["-i"] + (["-U"] if tool == "dexta" else []), tmp_path, ref=True, stdin=b.stdout)
+    assert a2.returncode == 0 and a2.stdout == b2.stdout
+    a3, b3 = run(un, ["-i"], tmp_path, stdin=b"xy" + a.stdout[2:], env=env), run(un, ["-i"], tmp_path, ref=True, stdin=b"xy" + b.stdout[2:])
+    assert (a3.returncode, a3.stderr) == (b3.returncode, b3.stderr)                  # no endian key: the reference's words
+    a = run(tool, ["x"], tmp_path / "mine", env=env)
+    b = run(tool, ["x"], tmp_path / "ref", ref=True)
+    assert a.returncode == b.returncode == 0
+    assert sorted(os.listdir(tmp_path / "mine")) == sorted(os.listdir(tmp_path / "ref"))
+    assert _read(tmp_path / "mine" / ("x.dex" + ("ta" if kind == "fasta" else "ar"))) == _read(tmp_path / "ref" / ("x.dex" + ("ta" if kind == "fasta" else "ar")))
 
 
 @pytest.mark.gpu

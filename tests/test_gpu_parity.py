@@ -914,6 +914,73 @@ def test_gpu_index_rejects_like_host(ctx, bad):
     assert (e.value.line, e.value.idx_code) == (line.value, ec.value)
 
 
+@pytest.mark.parametrize("kind", ["fasta", "arrow"])
+def test_pack2_of_a_text_that_arrives_in_pieces(ctx, kind):
+    """dx_file_pack2_stream (dexta -i / dexar -i, files of 256 MB and more): chunks of whole records through the device, the bytes of
+    dx_file_pack2 of the whole text whatever the chunk -- records longer than a chunk, empty reads at a piece's end, a read source
+    that hands over a few bytes at a time -- and a malformed text's line number counted from the file's first line."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    lens = np.concatenate([rng.integers(0, 3000, 150), [0, 0, 40000, 0, 7, 0], rng.integers(1, 900, 60)]).astype(np.uint32)
+    f = synth.make_seqfile(kind, len(lens), seed=12, lens=lens, width=70)
+    want = O.dexta(f.text) if kind == "fasta" else O.dexar(f.text)
+
+    def run(text, chunk, dribble=0):
+        pos, parts = [0], {}
+
+        def read(n):
+            k = min(n, dribble) if dribble else n
+            out = text[pos[0]: pos[0] + k]
+            pos[0] += len(out)
+            return out
+        total = ctx.pack2_stream(read, lambda data, at: parts.__setitem__(at, data) and None, arrow=kind == "arrow", chunk=chunk)
+        img = b"".join(parts[a] for a in sorted(parts))
+        assert len(img) == total and sorted(parts)[0] == 0
+        return img
+
+    for chunk in (4096, 30000, 1 << 20, 1 << 26):
+        assert run(f.text, chunk) == want, chunk
+    assert run(f.text, 9000, dribble=777) == want
+    one = synth.make_seqfile(kind, 1, seed=2, mean=50000, width=80)           # one record, many chunks' worth
+    assert run(one.text, 4096) == (O.dexta(one.text) if kind == "fasta" else O.dexar(one.text))
+    # a line that is no header where one must be, far into the text: the same refusal, the line counted from the top
+    lines_ = f.text.split(b"\n")
+    hdrs = [i for i, ln in enumerate(lines_) if ln.startswith(b">")]
+    bad = b"\n".join(lines_[:hdrs[150]] + [lines_[hdrs[150]].replace(b"/", b"_")] + lines_[hdrs[150] + 1:])
+    with pytest.raises(L.DexGPUError) as e1:
+        ctx.dexta(bad) if kind == "fasta" else ctx.dexar(bad)
+    with pytest.raises(L.DexGPUError) as e2:
+        run(bad, 8192)
+    assert e1.value.code == e2.value.code
+    def outcome(fn):
+        try:
+            return fn()
+        except L.DexGPUError as e:
+            return e.code
+    assert outcome(lambda: run(b"", 4096)) == outcome(lambda: ctx.dexta(b"") if kind == "fasta" else ctx.dexar(b""))      # an empty text: as a whole file
+
+    # ... and the other way: the image in pieces, a record cut anywhere (its head, its bases), the text of the whole image
+    mode = L.DX_LETTERS_UPPER if kind == "fasta" else L.DX_LETTERS_ARROW
+    text = ctx.undexta(want, upper=True, width=70) if kind == "fasta" else ctx.undexar(want, width=70)
+
+    def back(img, chunk, dribble=0):
+        pos, parts = [0], {}
+
+        def read(n):
+            k = min(n, dribble) if dribble else n
+            out = img[pos[0]: pos[0] + k]
+            pos[0] += len(out)
+            return out
+        total = ctx.unpack2_pieces(read, lambda data, at: parts.__setitem__(at, data) and None, mode=mode, width=70, chunk=chunk)
+        got = b"".join(parts[a] for a in sorted(parts))
+        assert len(got) == total
+        return got
+    for chunk in (4096, 5000, 1 << 20):
+        assert back(want, chunk) == text, chunk
+    assert back(want, 4096, dribble=333) == text
+    assert outcome(lambda: back(want[:-3], 4096)) == outcome(lambda: ctx.undexta(want[:-3], upper=True, width=70) if kind == "fasta" else ctx.undexar(want[:-3], width=70))
+    assert outcome(lambda: back(b"\x00\x01" + want[2:], 4096)) == -3                    # (no endian key: DX_E_FORMAT)
+
+
 def test_dexqv_large_file_uses_gpu_index_and_still_matches(ctx, monkeypatch):
     c = synth.make_quiva(120, seed=17, mean=9000)                  # > 1 MiB: GPU-indexed in dx_file_dexqv
     assert len(c.text) > (1 << 20)
