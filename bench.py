@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--entries", type=int, default=None,
                     help=f"entries per GPU (default {ENTRIES_1GPU} at N=1, {ENTRIES_SHARD} per rank at N>1)")
     ap.add_argument("--mean", type=int, default=10_000)
-    ap.add_argument("--dist", default="fixed", choices=["fixed", "lognormal"])
+    ap.add_argument("--dist", default="fixed", choices=["fixed", "lognormal", "mixed", "short_u", "mixed_tail"])
     ap.add_argument("--pipeline", action="store_true",
                     help="dexqv: the timed steps as consecutive batches of one job (dx_qv_encode_onepass_begin / _end: a step's "
                          "last compaction runs beside the next step's scan) instead of every step ending its own encode")
@@ -200,6 +200,27 @@ def main():
             except Exception as e:
                 shapes[f"{entries}x{mean}"] = {"error": repr(e)}
         extra["dexqv_entry_length"] = shapes
+        # a batch of short entries with long ones among them (nine in ten U[100, 600], one in ten lognormal around 10 kb: three quarters
+        # of the bytes in the long ones) -- the lanes take the short ones, the wave-per-entry kernels the long ones as a batch of their
+        # own -- beside its two parts alone, and the length-weighted mean of their rates (what the mix could reach at best)
+        mixed = {}
+        for name, dist_, entries in (("mixed", "mixed", 2_000_000), ("short_part", "short_u", 1_800_000), ("long_part", "lognormal", 200_000)):
+            a6 = argparse.Namespace(**vars(args))
+            a6.dist, a6.mean, a6.entries, a6.steps, a6.warmup, a6.no_walk_index = dist_, 10_000, entries, 3, 1, True
+            trace(f"extra: dexqv, {name}")
+            try:
+                l6 = dexqv_bench(a6, 0, 1, local, cpu=False, front=False, index_decode=False)
+                mixed[name] = {"value": l6["value"], "unit": "GB/s", "ms_per_step": l6["ms_per_step"], "roundtrip_bit_exact": l6["roundtrip_bit_exact"],
+                               "GB_per_step": round(l6["value"] * l6["ms_per_step"] / 1e3, 3), "route": l6["encoder_route"].get("direct"),
+                               "kernels": {k: round(v["ms_avg"], 3) for k, v in l6["kernels"].items()}}
+            except Exception as e:
+                mixed[name] = {"error": repr(e)}
+        if all("value" in v for v in mixed.values()):
+            gs, gl = mixed["short_part"]["GB_per_step"], mixed["long_part"]["GB_per_step"]
+            best = (gs + gl) / (gs / mixed["short_part"]["value"] + gl / mixed["long_part"]["value"])
+            mixed["weighted_mean_of_the_parts_GBps"] = round(best, 1)
+            mixed["mixed_over_that"] = round(mixed["mixed"]["value"] / best, 3)
+        extra["dexqv_mixed_lengths"] = mixed
         # BASELINE configs[4]: the slice ONE GPU of the 8-GPU job holds (2.5 M entries, 125 GB of QV bytes), under the scratch
         # budget every rank of that job runs with -- so that the per-GPU work of configs[4] is timed wherever this line is
         if args.entries == ENTRIES_1GPU and args.mean == 10_000:

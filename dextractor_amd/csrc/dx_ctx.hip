@@ -168,7 +168,8 @@ extern "C" void dx_close(dx_ctx *ctx)
   if (ctx->h_pin) (void) hipHostFree(ctx->h_pin);
   (void) hipFree(ctx->tk.del); (void) hipFree(ctx->tk.sub); (void) hipFree(ctx->tk.off); (void) hipFree(ctx->tk.info); (void) hipFree(ctx->tk.count);
   (void) hipFree(ctx->tk.eh);
-  (void) hipFree(ctx->qs.perm);
+  (void) hipFree(ctx->qs.perm); (void) hipFree(ctx->qs.list); (void) hipFree(ctx->qs.off2); (void) hipFree(ctx->qs.len2);
+  (void) hipFree(ctx->qs.order); (void) hipFree(ctx->qs.rmax); (void) hipFree(ctx->qs.aux);
   (void) hipStreamDestroy(ctx->own);
   (void) hipStreamDestroy(ctx->side);
   for (int k = 0; k < 19; k++) (void) hipEventDestroy(ctx->ev[k]);
@@ -204,6 +205,8 @@ extern "C" int dx_trim(dx_ctx *ctx, int what)
       (void) hipFree(ctx->tk.count); (void) hipFree(ctx->tk.eh);
       memset(&ctx->tk, 0, sizeof(ctx->tk));
       (void) hipFree(ctx->qs.perm);                      /* the short-entry survey's dealing of the batch (k_qs_survey) */
+      (void) hipFree(ctx->qs.list); (void) hipFree(ctx->qs.off2); (void) hipFree(ctx->qs.len2);
+      (void) hipFree(ctx->qs.order); (void) hipFree(ctx->qs.rmax); (void) hipFree(ctx->qs.aux);
       memset(&ctx->qs, 0, sizeof(ctx->qs));
     }
   if (what & DX_TRIM_INDEX)

@@ -51,6 +51,16 @@ struct dx_ctx
       uint64_t  cap, n, text_bytes;
       const void *off, *len;
       int       valid, brief, ordered;
+      // a batch of short entries with long ones among them: the long ones' indices (k_qs_survey), and their offsets and lengths side by
+      // side -- the batch of their own as which the wave-per-entry kernels take them
+      int       mixed;
+      uint64_t  nl;            // how many
+      uint32_t *list;          // cap of them
+      uint64_t *off2;
+      uint32_t *len2;
+      uint32_t  cut;           // entries longer than this are the long ones (chosen per batch: the longest short entry's lane must be done when the lanes are)
+      uint32_t *order, *rmax;  // the rounds, longest entries first, and each round's longest (cap / 256 + 1 of them)
+      unsigned long long *aux; // 256 words of counters for the survey (length histogram, round buckets)
     } qs;
   uint32_t  pair_lo[2];        // ins, mrg: lowest coded byte value when the coded values span <= 64 (pair tables), else ~0
   int       onepass_min_groups;// dx_qv_encode_onepass: fewest groups whose scratch regions have fitted the device so far

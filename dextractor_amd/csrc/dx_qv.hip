@@ -732,7 +732,8 @@ template <bool FAST, bool OWNTOK>
 __global__ __launch_bounds__(HIST_BLOCK, (HIST_NWAVE * HIST_PER_CU + 3) / 4)
 void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_first,
                unsigned long long *g_hist /* 6*256 */, unsigned long long *g_tot, uint32_t *ticket, tok_sink ts, uint32_t *eh /* n x EH_WORDS (FAST) */,
-               const scan_dev *sd /* dx_qv_scan: the scan state, and the verdict on the host's guesses */, uint64_t tok_cap /* tokens the buffers hold */)
+               const scan_dev *sd /* dx_qv_scan: the scan state, and the verdict on the host's guesses */, uint64_t tok_cap /* tokens the buffers hold */,
+               const uint32_t *orig /* NULL, or: entry r of this batch is entry orig[r] of the file's batch (the long entries of a mixed batch) */)
 { __shared__ __attribute__((aligned(16))) hist_smem<FAST, OWNTOK> S;
   if (sd != NULL)
     { if (sd->inst != (FAST ? (OWNTOK ? SCAN_A : SCAN_B) : SCAN_G) || ts.off[a.n] > tok_cap)
@@ -775,7 +776,7 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   { nxt = next_unit(ticket, a.units);                  // drawn early: the atomic's latency hides behind these entries
     for (uint64_t r = r0; r < r0 + a.units && r < a.n; r++)
     { const uint32_t  L = a.len[r];
-      const long long g = (long long) (entry0 + r);
+      const long long g = (long long) (entry0 + (orig ? (uint64_t) orig[r] : r));
       const bool drun = FAST || (a.delChar >= 0 && (toks || g >= del_first));      // tokenised (and, from del_first on, run-histogrammed)
       const bool srun = FAST || (a.subChar >= 0 && (toks || g >= sub_first));
       const uint32_t dinc = (a.delChar >= 0 && g >= del_first) ? 1u : 0u, sinc = (a.subChar >= 0 && g >= sub_first) ? 1u : 0u;
@@ -2005,6 +2006,7 @@ static qv_args make_args(const dx_qv_batch *b, int delChar, int subChar, int los
 }
 
 int dx_scan_u32(dx_ctx *ctx, const uint32_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *total);
+static int fast_grid(dx_ctx *ctx, uint64_t entries);
 #include "dx_qv_short.hpp"
 
 extern "C" int dx_qv_prescan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx_qv_params *p)
@@ -2163,60 +2165,67 @@ extern "C" int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, co
   unsigned long long *d_hist = (unsigned long long *) scr;
   DX_HIP(ctx, hipMemsetAsync(d_hist, 0, (6 * 256 + 2) * 8, ctx->stream));
   qv_args a = make_args(b, p->delChar, p->subChar, 0);
-  bool brief = false;
-  const uint8_t *perm = NULL;
-  if ((e = qs_short(ctx, b, true, &brief, &perm))) return e;
-  if (brief)                                             // short entries: a lane each (dx_qv_short.hpp); no tokens, no counters per entry
+  qs_verdict qv;
+  if ((e = qs_short(ctx, b, true, &qv))) return e;
+  if (qv.brief)                                          // short entries: a lane each (dx_qv_short.hpp); no tokens, no counters per entry
     { ctx->tk.valid = 0; ctx->tk.eh_valid = 0;
-      DX_LAUNCH(ctx, DX_K_QV_HIST, k_qs_hist, qs_grid(ctx, n), QS_BLOCK, a, perm, entry0, (long long) p->del_first, (long long) p->sub_first,
+      DX_LAUNCH(ctx, DX_K_QV_HIST, k_qs_hist, qs_grid(ctx, n), QS_BLOCK, a, qv.deal, entry0, (long long) p->del_first, (long long) p->sub_first,
                 d_hist, d_hist + 6 * 256);
-      uint64_t host[6 * 256 + 1];
-      DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
-      DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      for (int s = 0; s < 6; s++)
-        for (int k = 0; k < 256; k++)
-          hist[s][k] += host[s * 256 + k];
-      *totChar += host[6 * 256];
-      return DX_OK;
+      if (!qv.mixed)
+        { uint64_t host[6 * 256 + 1];
+          DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+          DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+          for (int s = 0; s < 6; s++)
+            for (int k = 0; k < 256; k++)
+              hist[s][k] += host[s * 256 + k];
+          *totChar += host[6 * 256];
+          return DX_OK;
+        }
+      // ... and the long ones among them (the lanes have skipped them): a batch of their own for the kernels below, which add to the
+      // same counters; their tokens, and their own histograms, are that batch's (dx_qv_encode_onepass finds them under its arrays)
+      b = &qv.sub;
+      a = make_args(b, p->delChar, p->subChar, 0);
     }
+  const uint32_t *orig = qv.mixed ? qv.list : (const uint32_t *) NULL;
+  const uint64_t  nw   = b->n;                           // the entries the wave-per-entry kernels take
   tok_sink ts = { NULL, NULL, NULL, NULL, d_hist + 6 * 256 + 1, NULL };
   if (tokens_prepare(ctx, b, p, scr, hbytes))
     { ts.del = ctx->tk.del; ts.sub = ctx->tk.sub; ts.off = ctx->tk.off; ts.info = ctx->tk.info; ts.list = ctx->tk.list; }
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 17);
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
-  const uint64_t hist_blocks = (b->n + HIST_NWAVE - 1) / HIST_NWAVE, hist_room = (uint64_t) ctx->num_cu * HIST_PER_CU;   // HIST_PER_CU workgroups per CU
+  const uint64_t hist_blocks = (nw + HIST_NWAVE - 1) / HIST_NWAVE, hist_room = (uint64_t) ctx->num_cu * HIST_PER_CU;   // HIST_PER_CU workgroups per CU
   // the FAST instance also leaves every entry's own histograms (for k_qv_sizes_hist): 1.5 KB per entry
   bool fast_hist = ts.del != NULL && p->delChar >= 0 && p->subChar >= 0;
   ctx->tk.eh_valid = 0;
-  if (fast_hist && ctx->tk.cap_eh < n)
+  if (fast_hist && ctx->tk.cap_eh < nw)
     { (void) hipFree(ctx->tk.eh);
       ctx->tk.eh = NULL; ctx->tk.cap_eh = 0;
-      if (hipMalloc((void **) &ctx->tk.eh, n * EH_WORDS * 4 + 64) != hipSuccess)
+      if (hipMalloc((void **) &ctx->tk.eh, nw * EH_WORDS * 4 + 64) != hipSuccess)
         { (void) hipGetLastError();                        // (no memory for them: the instance without, and the slot encoder after it)
           fast_hist = false;
         }
       else
-        ctx->tk.cap_eh = n;
+        ctx->tk.cap_eh = nw;
     }
   uint32_t inst = SCAN_G;
   if (fast_hist && ctx->tk.share8 <= HIST_SHARE_A && !dx_test_on("hist_shared_tokens"))   // (tokens at most ~28 % of the denser line: run densities from ~0.72 up)
     { inst = SCAN_A;
       DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, true>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
                 a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh,
-                (const scan_dev *) NULL, (uint64_t) 0);
+                (const scan_dev *) NULL, (uint64_t) 0, orig);
     }
   else if (fast_hist)
     { inst = SCAN_B;
       DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, false>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
                 a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, ctx->tk.eh,
-                (const scan_dev *) NULL, (uint64_t) 0);
+                (const scan_dev *) NULL, (uint64_t) 0, orig);
     }
   else
     DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<false, false>), (int) (hist_blocks < hist_room ? hist_blocks : hist_room), HIST_BLOCK,
               a, entry0, (long long) p->del_first, (long long) p->sub_first, d_hist, d_hist + 6 * 256, d_ticket, ts, (uint32_t *) NULL,
-              (const scan_dev *) NULL, (uint64_t) 0);
+              (const scan_dev *) NULL, (uint64_t) 0, orig);
   // what dx_qv_scan may guess for this context's next batch (only instances that leave tokens are guessed)
-  ctx->scan.valid = ts.del != NULL && (inst != SCAN_G || (p->delChar >= 0) != (p->subChar >= 0));
+  ctx->scan.valid = !qv.mixed && ts.del != NULL && (inst != SCAN_G || (p->delChar >= 0) != (p->subChar >= 0));
   ctx->scan.inst  = inst;
   uint64_t host[6 * 256 + 2];
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
@@ -2263,7 +2272,7 @@ extern "C" int dx_qv_scan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx
   bool spec = n > 0 && ctx->scan.valid && !tokens_off() && !dx_test_on("no_scan_guess") &&
               ctx->tk.cap_entries >= n && ctx->tk.cap_tokens > 0 && ctx->tk.del != NULL && ctx->tk.sub != NULL &&
               (guess == SCAN_G || ctx->tk.cap_eh >= n) && want <= ctx->hscr_bytes && scan_pin(ctx) != NULL;
-  if (spec && n >= 4096 && b->text_bytes && b->text_bytes / n <= 5ull * (QS_MEAN + 1u) + 64u && !dx_test_on("no_short"))
+  if (spec && n >= 4096 && b->text_bytes && b->text_bytes / n <= 5ull * (QS_MAXLEN + 1u) + 64u && !dx_test_on("no_short"))
     spec = false;                                        // (qs_short's to look at)
   if (!spec)
     { if ((e = dx_qv_prescan(ctx, b, entry0, p))) return e;
@@ -2299,13 +2308,13 @@ extern "C" int dx_qv_scan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx
   const int      grid = (int) (hist_blocks < hist_room ? hist_blocks : hist_room);
   if (guess == SCAN_A)
     DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, true>), grid, HIST_BLOCK, a, entry0, 0ll, 0ll, d_hist, d_hist + 6 * 256, d_ticket, ts,
-              ctx->tk.eh, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens);
+              ctx->tk.eh, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens, (const uint32_t *) NULL);
   else if (guess == SCAN_B)
     DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<true, false>), grid, HIST_BLOCK, a, entry0, 0ll, 0ll, d_hist, d_hist + 6 * 256, d_ticket, ts,
-              ctx->tk.eh, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens);
+              ctx->tk.eh, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens, (const uint32_t *) NULL);
   else
     DX_LAUNCH(ctx, DX_K_QV_HIST, (k_qv_hist<false, false>), grid, HIST_BLOCK, a, entry0, 0ll, 0ll, d_hist, d_hist + 6 * 256, d_ticket, ts,
-              (uint32_t *) NULL, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens);
+              (uint32_t *) NULL, (const scan_dev *) sd, (uint64_t) ctx->tk.cap_tokens, (const uint32_t *) NULL);
   uint64_t *host = ctx->h_pin;                           // [0, 1538): histograms, total, unusable; [1600): scan_dev; [1610): tokens the slots want
   DX_HIP(ctx, hipMemcpyAsync(host, d_hist, (6 * 256 + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
   DX_HIP(ctx, hipMemcpyAsync(host + 1600, sd, sizeof(scan_dev), hipMemcpyDeviceToHost, ctx->stream));
@@ -2509,9 +2518,10 @@ extern "C" int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_
     }
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 18);
-  bool brief = false;
-  const uint8_t *perm = NULL;
-  if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
+  qs_verdict qv;
+  if ((e = qs_short(ctx, b, false, &qv))) return e;
+  const bool brief = qv.brief && !qv.mixed;              // (a mixed batch through this two-pass API: the wave-per-entry kernel for all of it)
+  const qs_deal perm = qv.deal;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   if (brief)
     DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
@@ -2539,10 +2549,10 @@ static int encode_text(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, 
   DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
   qv_args a = make_args(b, ctx->delChar, ctx->subChar, ctx->lossy);
   uint32_t *d_ticket = (uint32_t *) (ctx->d_u64 + 19);
-  bool brief = false;
-  const uint8_t *perm = NULL;
-  if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
-  if (sx_idx != NULL) brief = false;                     // (the lane-per-entry kernels leave no index)
+  qs_verdict qv;
+  if ((e = qs_short(ctx, b, false, &qv))) return e;
+  const bool brief = qv.brief && !qv.mixed && sx_idx == NULL;      // (the lane-per-entry kernels leave no index, and a mixed batch's long entries are not theirs)
+  const qs_deal perm = qv.deal;
   DX_HIP(ctx, hipMemsetAsync(d_ticket, 0, 4, ctx->stream));
   if (brief && ctx->tok_wide)
     DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, b->n), QS_BLOCK, a, perm, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
@@ -2831,12 +2841,12 @@ static int onepass_impl(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr,
   // (dx_qv_short.hpp).  A batch whose tokens this context's histogram pass has left: k_qv_encode_fast, its sizes from the
   // entries' own histograms (k_qv_sizes_hist: a dot product) or, where there are none (DEXGPU_TEST=sizes_from_tokens; one
   // run character only), from tokens and plain lines (k_qv_sizes_fast).  Anything else: sizes and records from the text.
-  { bool brief = false;
-    const uint8_t *perm = NULL;
-  if ((e = qs_short(ctx, b, false, &brief, &perm))) return e;
-    if (brief)
+  { qs_verdict qv;
+    if ((e = qs_short(ctx, b, false, &qv))) return e;
+    if (qv.brief)
       { uint64_t t = 0;
-        const int rc = onepass_short(ctx, b, perm, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
+        const int rc = qv.mixed ? onepass_mixed(ctx, b, &qv, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t)
+                                : onepass_short(ctx, b, qv.deal, d_hdr, d_hdr_off, d_seg, d_rec_off, d_out, out_cap, &t);
         if (total) *total = t;
         if (!wait) { ctx->op.pending = 1; ctx->op.direct = 1; ctx->op.rc = rc; ctx->op.total = t; return DX_OK; }   // (this route does not pipeline)
         return rc;

@@ -154,20 +154,165 @@ __device__ __forceinline__ uint32_t qs_order(qs_lds *s_key /* [QS_BLOCK] */, con
 // instead of sorting again -- and without the sort's code they keep the registers of their fifth wave a SIMD), and what the batch
 // would cost these kernels: work[0] = its longest entry, work[1] = its shortest, work[2..3] = the sum over the waves of the wave's
 // longest entry (a wave's 64 lanes go through their entries in step): x 64 / n it is the length an entry costs.
+// How the lanes are dealt a batch: perm (a byte an entry: its place among the 256 of its round when they are taken by length), order (the
+// rounds, those with the longest entries first: a lane is alone with its entry, and the longest entry's lane should be the first to
+// start, not the last), cut (entries longer than that are not the lanes': the wave-per-entry kernels take them as a batch of their own).
+struct qs_deal { const uint8_t *perm; const uint32_t *order; uint32_t cut; };
+
+// entries and symbols by length: bucket len / 64 (64 buckets up to QS_MAXLEN, one for everything longer): cnt[0..64], sym[0..64] (units of 64 symbols)
+// (every `every`-th entry, counted `every` times: an estimate is all the cut wants)
 __global__ __launch_bounds__(QS_BLOCK)
-void k_qs_survey(const uint32_t *len, uint64_t n, uint8_t *perm, uint32_t every /* one round in `every` counts for the sum, `every` times */, uint32_t *work)
+void k_qs_lenhist(const uint32_t *len, uint64_t n, unsigned long long *cnt /* 65 + 65 */, uint32_t every)
+{ __shared__ uint32_t s_c[65], s_s[65];
+  if (threadIdx.x < 65) { s_c[threadIdx.x] = 0; s_s[threadIdx.x] = 0; }
+  __syncthreads();
+  for (uint64_t i = ((uint64_t) blockIdx.x * QS_BLOCK + threadIdx.x) * every; i < n; i += (uint64_t) gridDim.x * QS_BLOCK * every)
+    { const uint32_t L = len[i], k = L > QS_MAXLEN ? 64u : (L ? (L - 1u) >> 6 : 0u);
+      atomicAdd(&s_c[k], every);
+      atomicAdd(&s_s[k], every * ((L + 63u) >> 6));
+    }
+  __syncthreads();
+  if (threadIdx.x < 65)
+    { if (s_c[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long) s_c[threadIdx.x]);
+      if (s_s[threadIdx.x]) atomicAdd(&cnt[65 + threadIdx.x], (unsigned long long) s_s[threadIdx.x]);
+    }
+}
+
+// Where the lanes stop: the longest entry they take is one lane's work from its first symbol to its last (~1.1 us a symbol when that lane
+// is alone on its SIMD), and it must not outlast what all the lanes together take for the entries up to that length (the text at
+// 2.5 TB/s in the fastest of the three kernels; the rounds with the longest entries go first) -- the largest multiple of 64 that does not.
+__host__ __device__ static uint32_t qs_cut(const unsigned long long *cnt /* 65 entries + 65 x 64 symbols, by length / 64 */, uint64_t *entries_le)
+{ uint64_t S = 0, N = 0;                                  // symbols and entries of the entries of at most 64 k symbols
+  for (int k = 0; k < 64; k++) { N += cnt[k]; S += 64ull * cnt[65 + k]; }
+  for (int k = 64; k >= 1; k--)
+    { const double lanes_s = 5.0 * (double) S / 2.5e12, lone_s = 64.0 * k * 1.1e-6;
+      if (N >= 4096 && lone_s <= (lanes_s > 1e-3 ? lanes_s : 1e-3)) { *entries_le = N; return 64u * (uint32_t) k; }      // (a millisecond at least: batches that small take no time either way)
+      N -= cnt[k - 1]; S -= 64ull * cnt[65 + k - 1];
+    }
+  *entries_le = 0;
+  return 0;
+}
+
+// ... decided where the counts are: *cut = the cut (forced: that value instead, the tests' way)
+__global__ void k_qs_cut(const unsigned long long *cnt, uint32_t forced, uint32_t *cut)
+{ if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint64_t le;
+  const uint32_t c = forced ? forced : qs_cut(cnt, &le);
+  *cut = c > QS_MAXLEN ? QS_MAXLEN : c;
+}
+
+// Entries of more than `cut` symbols are none of these kernels' (a lane is alone with its entry): they go on a list -- work[4] counts
+// them, list[] holds their indices, in no order -- and the wave-per-entry kernels take them as a batch of their own (a batch of short
+// entries with some long ones among them: what real subread sets look like); the lanes they fall to stand idle, and none of the figures
+// above counts them (work[0], the longest, is the longest SHORT entry; work[5] = their symbols in all, in units of 1024).
+// rmax[round] = the round's longest short entry, work[6..7] their sum (k_qs_round_order).
+__global__ __launch_bounds__(QS_BLOCK)
+void k_qs_survey(const uint32_t *len, uint64_t n, uint8_t *perm, uint32_t every /* one round in `every` counts for the sum, `every` times */, uint32_t *work,
+                 uint32_t *list, uint32_t list_cap, const uint32_t *cut_at, uint32_t *rmax)
 { __shared__ uint32_t s_key[QS_BLOCK];
+  const uint32_t cut = *cut_at;                            // (k_qs_cut's; 0: none of these entries is the lanes')
+  if (cut == 0) return;
+  __shared__ uint32_t s_max;
+  if (threadIdx.x == 0) s_max = 0;
   const uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK;
   const uint32_t place = qs_order(QS_LDS(s_key), len, base, n);      // (the t-th shortest of the round is this thread's)
   const bool     have  = place != 0xffffffffu;
-  const uint32_t L = have ? len[base + place] : 0u;
+  const uint32_t Lall  = have ? len[base + place] : 0u;
+  const bool     big   = Lall > cut;
+  const uint32_t L     = big ? 0u : Lall;
   if (have) perm[base + threadIdx.x] = (uint8_t) place;
-  if (blockIdx.x % every == 0u && ((threadIdx.x & 63u) == 63u || base + threadIdx.x + 1 == n))     // the last lane of a wave that has entries holds its longest
-    atomicAdd((unsigned long long *) (work + 2), (unsigned long long) L * every);      // (62 500 atomics on one word are 0.6 ms: an estimate from a sixteenth)
-  if ((threadIdx.x == QS_BLOCK - 1u || base + threadIdx.x + 1 == n) && L > __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    atomicMax(work, L);                                    // (checked first: 15 625 atomics on one word are 0.15 ms)
-  if (threadIdx.x == 0u && L < __hip_atomic_load(work + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+  { const uint64_t m = __ballot(big);                      // (one draw a wave: atomics on one word are 10 ns each, whoever asks)
+    if (m)
+      { const uint32_t kib = wave_sum(big ? (Lall + 1023u) >> 10 : 0u);
+        uint32_t at0 = 0;
+        if (lane_id() == 0)
+          { at0 = atomicAdd(work + 4, (uint32_t) __popcll(m));
+            atomicAdd(work + 5, kib);
+          }
+        at0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) at0);
+        const uint32_t at = at0 + (uint32_t) __popcll(m & ((1ull << lane_id()) - 1ull));
+        if (big && at < list_cap) list[at] = (uint32_t) (base + place);
+      }
+  }
+  const uint32_t wmax = wave_total(wave_incl_max(L));      // the wave's longest short entry: what its 64 lanes take
+  if (blockIdx.x % every == 0u && (threadIdx.x & 63u) == 0u && wmax)
+    atomicAdd((unsigned long long *) (work + 2), (unsigned long long) wmax * every);   // (62 500 atomics on one word are 0.6 ms: an estimate from a sixteenth)
+  if ((threadIdx.x & 63u) == 0u && wmax > __hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(work, wmax);                                 // (checked first: atomics on one word are 10 ns each)
+  if (threadIdx.x == 0u && have && !big && L < __hip_atomic_load(work + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMin(work + 1, L);
+  if ((threadIdx.x & 63u) == 0u && wmax) atomicMax(&s_max, wmax);
+  __syncthreads();
+  if (threadIdx.x == 0u)
+    { rmax[blockIdx.x] = s_max;
+      if (blockIdx.x % every == 0u && s_max) atomicAdd((unsigned long long *) (work + 6), (unsigned long long) s_max * every);
+    }
+}
+
+// The rounds as the lanes take them: those whose longest entry is well beyond the usual (more than one and a half times the rounds'
+// average: work[6..7] holds their sum) first, the others behind them in the file's order (a lane is alone with its entry: the longest
+// ones must be among the first to start; everything else reads the file front to back).  One workgroup.
+__global__ __launch_bounds__(QS_BLOCK)
+void k_qs_round_order(const uint32_t *rmax, uint64_t nblk, const uint32_t *work, uint32_t *order)
+{ __shared__ uint32_t s_heavy, s_wave[QS_BLOCK / 64];
+  const unsigned long long sum = ((unsigned long long) work[7] << 32) | work[6];
+  const uint32_t thr = (uint32_t) (3ull * sum / (2ull * (nblk ? nblk : 1)));
+  if (threadIdx.x == 0) s_heavy = 0;
+  __syncthreads();
+  for (uint64_t k = threadIdx.x; k < nblk; k += QS_BLOCK)
+    if (rmax[k] > thr) order[atomicAdd(&s_heavy, 1u)] = (uint32_t) k;
+  __syncthreads();
+  uint32_t running = s_heavy;
+  for (uint64_t c0 = 0; c0 < nblk; c0 += QS_BLOCK)
+    { const uint64_t k = c0 + threadIdx.x;
+      const bool light = k < nblk && rmax[k] <= thr;
+      const uint64_t m = __ballot(light);
+      if (lane_id() == 0) s_wave[threadIdx.x >> 6] = (uint32_t) __popcll(m);
+      __syncthreads();
+      uint32_t before = 0, all = 0;
+      for (uint32_t w = 0; w < QS_BLOCK / 64; w++) { if (w < (threadIdx.x >> 6)) before += s_wave[w]; all += s_wave[w]; }
+      if (light) order[running + before + (uint32_t) __popcll(m & ((1ull << lane_id()) - 1ull))] = (uint32_t) k;
+      running += all;
+      __syncthreads();
+    }
+}
+
+// the long entries as a batch of their own: their offsets and lengths side by side (the wave-per-entry kernels index a batch by r)
+__global__ __launch_bounds__(QS_BLOCK)
+void k_qs_sub_batch(const uint64_t *off, const uint32_t *len, const uint32_t *list, uint64_t nl, uint64_t *off2, uint32_t *len2)
+{ const uint64_t j = (uint64_t) blockIdx.x * QS_BLOCK + threadIdx.x;
+  if (j < nl)
+    { const uint32_t r = list[j];
+      off2[j] = off[r]; len2[j] = len[r];
+    }
+}
+
+// what the long entries' own kernels found, to the whole batch's arrays: the five segment sizes, and the record's size with its framing
+__global__ __launch_bounds__(QS_BLOCK)
+void k_qs_scatter_sizes(const uint32_t *list, uint64_t nl, const uint32_t *seg2, const uint32_t *size2, const uint64_t *hdr_off,
+                        uint32_t *seg, uint32_t *rec_size)
+{ const uint64_t j = (uint64_t) blockIdx.x * QS_BLOCK + threadIdx.x;
+  if (j >= nl) return;
+  const uint32_t r = list[j];
+  for (int k = 0; k < 5; k++) seg[5ull * r + k] = seg2[5 * j + k];
+  rec_size[r] = size2[j] + (hdr_off ? (uint32_t) (hdr_off[r + 1] - hdr_off[r]) : 0u);
+}
+
+// ... and back: where each long entry's payload goes (behind its framing bytes, which are written here)
+__global__ __launch_bounds__(QS_BLOCK)
+void k_qs_gather_places(const uint32_t *list, uint64_t nl, const uint64_t *rec_off, const uint8_t *hdr, const uint64_t *hdr_off,
+                        uint8_t *out, uint64_t *rec2 /* nl + 1 */)
+{ const uint64_t j = (uint64_t) blockIdx.x * QS_BLOCK + threadIdx.x;
+  if (j > nl) return;
+  if (j == nl) { rec2[j] = 0; return; }                  // (read by the encoder's bound test only, which is off: out_cap = ~0)
+  const uint32_t r = list[j];
+  uint64_t at = rec_off[r];
+  if (hdr != NULL)
+    { const uint64_t h0 = hdr_off[r], hl = hdr_off[r + 1] - h0;
+      for (uint64_t k = 0; k < hl; k++) out[at + k] = hdr[h0 + k];
+      at += hl;
+    }
+  rec2[j] = at;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -204,7 +349,7 @@ __device__ __forceinline__ void qs_count_runs(const uint8_t *p, uint32_t L, cons
 }
 
 __global__ __launch_bounds__(QS_BLOCK)
-void k_qs_hist(qv_args a, const uint8_t *perm, uint64_t entry0, long long del_first, long long sub_first, unsigned long long *hist,
+void k_qs_hist(qv_args a, qs_deal deal, uint64_t entry0, long long del_first, long long sub_first, unsigned long long *hist,
                unsigned long long *tot)
 { __shared__ uint32_t s_h[6][256][QS_COPIES];             // 24 KB
   __shared__ uint32_t s_key[QS_BLOCK];
@@ -213,10 +358,12 @@ void k_qs_hist(qv_args a, const uint8_t *perm, uint64_t entry0, long long del_fi
   const uint32_t cp = threadIdx.x & (QS_COPIES - 1u);
   #define H(s) (QS_LDS(&s_h[s][0][0]) + cp)
   uint64_t chars = 0;
-  for (uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK; base < a.n; base += (uint64_t) gridDim.x * QS_BLOCK)
-    { if (base + threadIdx.x >= a.n) continue;
-      const uint64_t r = base + (perm ? (uint32_t) perm[base + threadIdx.x] : threadIdx.x);   // (by length within the round: k_qs_survey)
+  for (uint64_t rk = blockIdx.x; rk * QS_BLOCK < a.n; rk += gridDim.x)
+    { const uint64_t base = (deal.order ? (uint64_t) deal.order[rk] : rk) * QS_BLOCK;        // (the rounds with the longest entries first)
+      if (base + threadIdx.x >= a.n) continue;
+      const uint64_t r = base + (deal.perm ? (uint32_t) deal.perm[base + threadIdx.x] : threadIdx.x);   // (by length within the round: k_qs_survey)
       const uint32_t L = a.len[r];
+      if (L > deal.cut) continue;                          // (on the long entries' list: the wave-per-entry kernels')
       const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2), *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
       const uint8_t *end16 = a.text + a.text_bytes - 16u;    // (text_bytes known and large: qs_short)
       chars += L;
@@ -458,7 +605,7 @@ __device__ __forceinline__ void qs_tags_all(const uint8_t *ptag, uint32_t L, con
 #endif
 template <bool EMIT, bool WIDE>
 __global__ __launch_bounds__(QS_BLOCK) QS_WAVES
-void k_qs_entries(qv_args a, const uint8_t *perm, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off, const uint64_t *rec_off,
+void k_qs_entries(qv_args a, qs_deal deal, const uint32_t *g_tok, const uint8_t *hdr, const uint64_t *hdr_off, const uint64_t *rec_off,
                   uint32_t *seg, uint32_t *rec_size, uint8_t *out, uint32_t *status)
 { __shared__ uint32_t s_tok[6][256];
   __shared__ uint32_t s_ring[EMIT ? QS_RING : 1u][QS_BLOCK];
@@ -466,10 +613,12 @@ void k_qs_entries(qv_args a, const uint8_t *perm, const uint32_t *g_tok, const u
   qs_lds *ring = QS_LDS(&s_ring[0][threadIdx.x]);
   const uint32_t imask = a.lossy ? 0xfefefefeu : ~0u, mmask = a.lossy ? 0xfcfcfcfcu : ~0u;
   uint32_t differ = 0;
-  for (uint64_t base = (uint64_t) blockIdx.x * QS_BLOCK; base < a.n; base += (uint64_t) gridDim.x * QS_BLOCK)
-    { if (base + threadIdx.x >= a.n) continue;
-      const uint64_t r = base + (perm ? (uint32_t) perm[base + threadIdx.x] : threadIdx.x);   // (by length within the round: k_qs_survey)
+  for (uint64_t rk = blockIdx.x; rk * QS_BLOCK < a.n; rk += gridDim.x)
+    { const uint64_t base = (deal.order ? (uint64_t) deal.order[rk] : rk) * QS_BLOCK;        // (the rounds with the longest entries first)
+      if (base + threadIdx.x >= a.n) continue;
+      const uint64_t r = base + (deal.perm ? (uint32_t) deal.perm[base + threadIdx.x] : threadIdx.x);   // (by length within the round: k_qs_survey)
       const uint32_t L = a.len[r];
+      if (L > deal.cut) continue;                          // (on the long entries' list: the wave-per-entry kernels')
       const uint8_t *p0 = line_ptr(a, r, L, 0);              // (the other lines' addresses where they are wanted: five pointers held are ten registers)
 #define p1 (p0 + ((uint64_t) L + a.pad))
 #define p2 (p0 + 2u * ((uint64_t) L + a.pad))
@@ -530,54 +679,95 @@ static int qs_grid(const dx_ctx *ctx, uint64_t n)
 // Is this a batch for the lane-per-entry kernels?  What an entry costs them is the length of the longest entry of its wave
 // (k_qs_survey): a batch is theirs when that, averaged over the entries, is at most QS_MEAN -- fixed lengths: the mean itself,
 // 1100 symbols being where the wave-per-entry kernels take over; lognormal lengths (sigma 0.35): 1.45 x the mean, and measured
-// (2 M entries, GB/s with / without): mean 600: 493 / 431, mean 800: 497 / 533 -- and no entry is longer than QS_MAXLEN (a lane
-// takes ~2.4 us a symbol through the three kernels: one entry of 4096 is 10 ms of one lane).
+// (2 M entries, GB/s with / without): mean 600: 493 / 431, mean 800: 497 / 533.  Entries of more than QS_MAXLEN symbols (a lane
+// takes ~2.4 us a symbol through the three kernels: one entry of 4096 is 10 ms of one lane) are not the lanes': a batch that has
+// some -- `mixed` -- is dealt, the short entries to the lanes (which skip the long ones), the long ones as a batch of their own
+// (sub) to the wave-per-entry kernels, when at least 4096 short ones are left and they cost what a batch of short ones may.
 // fresh (dx_qv_hist, the first to see a batch): looked at anew; the others take what the context remembers of a batch of these
 // arrays and sizes -- were the arrays' contents changed in between, the verdict is the old contents': slow at worst, not wrong.
-static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, bool *yes, const uint8_t **perm)
-{ *yes = false; *perm = NULL;
+struct qs_verdict { bool brief, mixed; qs_deal deal; dx_qv_batch sub; const uint32_t *list; };
+
+static void qs_free(dx_ctx *ctx)
+{ (void) hipFree(ctx->qs.perm); (void) hipFree(ctx->qs.list); (void) hipFree(ctx->qs.off2); (void) hipFree(ctx->qs.len2);
+  (void) hipFree(ctx->qs.order); (void) hipFree(ctx->qs.rmax); (void) hipFree(ctx->qs.aux);
+  ctx->qs.perm = NULL; ctx->qs.list = NULL; ctx->qs.off2 = NULL; ctx->qs.len2 = NULL; ctx->qs.order = NULL; ctx->qs.rmax = NULL; ctx->qs.aux = NULL;
+  ctx->qs.cap = 0;
+}
+
+static int qs_short(dx_ctx *ctx, const dx_qv_batch *b, bool fresh, qs_verdict *v)
+{ v->brief = v->mixed = false; v->deal = qs_deal{ NULL, NULL, QS_MAXLEN }; v->list = NULL;
+  memset(&v->sub, 0, sizeof(v->sub));
   if (dx_test_on("no_short") || b->n < 4096 || b->text_bytes == 0) return DX_OK;
-  if (b->text_bytes / b->n > 5ull * (QS_MEAN + 1u) + 64u) return DX_OK;
-  if (!fresh && ctx->qs.valid && ctx->qs.off == (const void *) b->d_off && ctx->qs.len == (const void *) b->d_len && ctx->qs.n == b->n &&
-      ctx->qs.text_bytes == b->text_bytes)
-    { *yes = ctx->qs.brief != 0; *perm = *yes && ctx->qs.ordered ? ctx->qs.perm : NULL;
-      return DX_OK;
-    }
-  ctx->qs.valid = 0;
-  if (ctx->qs.cap < b->n)
-    { (void) hipFree(ctx->qs.perm);
-      ctx->qs.perm = NULL; ctx->qs.cap = 0;
-      if (hipMalloc((void **) &ctx->qs.perm, b->n + 256) != hipSuccess)
-        { (void) hipGetLastError();
-          return DX_OK;                                    // (no memory for a byte an entry: the wave-per-entry kernels)
+  if (b->text_bytes / b->n > 5ull * (QS_MAXLEN + 1u) + 64u) return DX_OK;          // (a mean beyond what a lane takes at all: nothing to look at)
+  if (!(!fresh && ctx->qs.valid && ctx->qs.off == (const void *) b->d_off && ctx->qs.len == (const void *) b->d_len && ctx->qs.n == b->n &&
+        ctx->qs.text_bytes == b->text_bytes))
+    { ctx->qs.valid = 0;
+      const uint64_t nblk = (b->n + QS_BLOCK - 1) / QS_BLOCK;
+      if (ctx->qs.cap < b->n)
+        { qs_free(ctx);
+          if (hipMalloc((void **) &ctx->qs.perm, b->n + 256) != hipSuccess || hipMalloc((void **) &ctx->qs.list, b->n * 4 + 64) != hipSuccess ||
+              hipMalloc((void **) &ctx->qs.off2, b->n * 8 + 64) != hipSuccess || hipMalloc((void **) &ctx->qs.len2, b->n * 4 + 64) != hipSuccess ||
+              hipMalloc((void **) &ctx->qs.order, nblk * 4 + 64) != hipSuccess || hipMalloc((void **) &ctx->qs.rmax, nblk * 4 + 64) != hipSuccess ||
+              hipMalloc((void **) &ctx->qs.aux, 256 * 8) != hipSuccess)
+            { (void) hipGetLastError();
+              qs_free(ctx);
+              return DX_OK;                                // (no memory for a few bytes an entry: the wave-per-entry kernels)
+            }
+          ctx->qs.cap = b->n;
         }
-      ctx->qs.cap = b->n;
+      // the lengths first (a sample of them): where the lanes stop -- decided on the device, read back with the survey's figures
+      uint32_t *d_work = (uint32_t *) (ctx->d_u64 + 40), *d_cut = (uint32_t *) (ctx->qs.aux + 200);
+      uint32_t  work[8] = { 0u, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0u }, cut = 0;
+      const uint32_t every = b->n >= (1u << 18) ? 16u : 1u;
+      const uint64_t hb = (b->n / every + QS_BLOCK - 1) / QS_BLOCK;
+      DX_HIP(ctx, hipMemsetAsync(ctx->qs.aux, 0, 256 * 8, ctx->stream));
+      DX_HIP(ctx, hipMemcpyAsync(d_work, work, 32, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_qs_lenhist, dim3((unsigned) (hb < 1024 ? (hb ? hb : 1) : 1024)), dim3(QS_BLOCK), 0, ctx->stream, (const uint32_t *) b->d_len, b->n, ctx->qs.aux, every);
+      hipLaunchKernelGGL(k_qs_cut, dim3(1), dim3(64), 0, ctx->stream, (const unsigned long long *) ctx->qs.aux,
+                         dx_test_on("short_force") ? (uint32_t) dx_test_num("short_cut", QS_MAXLEN) : 0u, d_cut);
+      hipLaunchKernelGGL(k_qs_survey, dim3((unsigned) nblk), dim3(QS_BLOCK), 0, ctx->stream, (const uint32_t *) b->d_len, b->n,
+                         ctx->qs.perm, nblk >= 1024 ? 16u : 1u, d_work, ctx->qs.list, (uint32_t) b->n, (const uint32_t *) d_cut, ctx->qs.rmax);
+      hipLaunchKernelGGL(k_qs_round_order, dim3(1), dim3(QS_BLOCK), 0, ctx->stream, (const uint32_t *) ctx->qs.rmax, nblk, (const uint32_t *) d_work, ctx->qs.order);
+      DX_HIP(ctx, hipMemcpyAsync(work, d_work, 24, hipMemcpyDeviceToHost, ctx->stream));
+      DX_HIP(ctx, hipMemcpyAsync(&cut, d_cut, 4, hipMemcpyDeviceToHost, ctx->stream));
+      DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->qs.off = b->d_off; ctx->qs.len = b->d_len; ctx->qs.n = b->n; ctx->qs.text_bytes = b->text_bytes;
+      ctx->qs.brief = 0; ctx->qs.mixed = 0; ctx->qs.nl = 0; ctx->qs.cut = cut;
+      if (cut > 0)
+        {
+          const uint64_t cost = ((uint64_t) work[3] << 32) | work[2], nl = work[4], ns = b->n - nl;
+          const uint64_t long_bytes = 5ull * 1024u * work[5];                            // (the long entries' share of the text, rounded up)
+          const uint64_t short_bytes = b->text_bytes > long_bytes ? b->text_bytes - long_bytes : 0;
+          // theirs when what an entry costs them -- the longest entry of its wave, averaged -- is at most QS_MEAN symbols
+          bool yes = ns >= 4096 && 64u * cost <= (uint64_t) QS_MEAN * ns && short_bytes / ns <= 5ull * (QS_MEAN + 1u) + 64u;
+          if (dx_test_on("short_force")) yes = ns >= 1;
+          if (dx_test_on("no_mixed") && nl) yes = false;
+          ctx->qs.ordered = work[0] != work[1] && !dx_test_on("short_file_order");  // (entries of one length: as they come)
+          ctx->qs.brief = yes ? 1 : 0;
+          ctx->qs.mixed = yes && nl ? 1 : 0;
+          ctx->qs.nl = nl;
+          if (ctx->qs.mixed)
+            { hipLaunchKernelGGL(k_qs_sub_batch, dim3((unsigned) ((nl + QS_BLOCK - 1) / QS_BLOCK)), dim3(QS_BLOCK), 0, ctx->stream,
+                                 (const uint64_t *) b->d_off, (const uint32_t *) b->d_len, (const uint32_t *) ctx->qs.list, nl, ctx->qs.off2, ctx->qs.len2);
+              DX_HIP(ctx, hipGetLastError());
+            }
+        }
+      ctx->qs.valid = 1;
     }
-  uint32_t *d_work = (uint32_t *) (ctx->d_u64 + 40);
-  uint32_t  work[4] = { 0u, 0xffffffffu, 0u, 0u };
-  DX_HIP(ctx, hipMemcpyAsync(d_work, work, 16, hipMemcpyHostToDevice, ctx->stream));
-  const uint64_t nblk = (b->n + QS_BLOCK - 1) / QS_BLOCK;
-  hipLaunchKernelGGL(k_qs_survey, dim3((unsigned) nblk), dim3(QS_BLOCK), 0, ctx->stream, (const uint32_t *) b->d_len, b->n,
-                     ctx->qs.perm, nblk >= 1024 ? 16u : 1u, d_work);
-  DX_HIP(ctx, hipMemcpyAsync(work, d_work, 16, hipMemcpyDeviceToHost, ctx->stream));
-  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint64_t cost = ((uint64_t) work[3] << 32) | work[2];
-  // ... and the longest entry's lane (1.35 us a symbol through the three kernels when it is the last one running) is done when the batch is:
-  // no longer than the batch takes (0.6 TB/s), a millisecond at least -- one entry of 4096 symbols in a batch of 16 k x 300 would be
-  // 5.5 ms of a 0.9 ms step
-  const double room_s = (double) b->text_bytes / 6e11 > 1e-3 ? (double) b->text_bytes / 6e11 : 1e-3;
-  *yes = work[0] <= QS_MAXLEN && (double) work[0] * 1.35e-6 <= room_s && 64u * cost <= (uint64_t) QS_MEAN * b->n;
-  if (dx_test_on("short_force")) *yes = work[0] <= QS_MAXLEN;       // (tests: whatever the lengths cost)
-  ctx->qs.ordered = work[0] != work[1] && !dx_test_on("short_file_order");      // (entries of one length: as they come)
-  *perm = *yes && ctx->qs.ordered ? ctx->qs.perm : NULL;
-  ctx->qs.off = b->d_off; ctx->qs.len = b->d_len; ctx->qs.n = b->n; ctx->qs.text_bytes = b->text_bytes;
-  ctx->qs.brief = *yes ? 1 : 0;
-  ctx->qs.valid = 1;
+  v->brief = ctx->qs.brief != 0;
+  v->mixed = ctx->qs.mixed != 0;
+  v->deal  = qs_deal{ v->brief && ctx->qs.ordered ? ctx->qs.perm : (const uint8_t *) NULL,
+                      v->brief && ctx->qs.ordered ? ctx->qs.order : (const uint32_t *) NULL, ctx->qs.cut };
+  if (v->mixed)
+    { v->sub = *b;
+      v->sub.d_off = ctx->qs.off2; v->sub.d_len = ctx->qs.len2; v->sub.n = ctx->qs.nl;
+      v->list = ctx->qs.list;
+    }
   return DX_OK;
 }
 
 // sizes, offsets, records: dx_qv_encode_onepass's contract
-static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *perm, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, qs_deal perm, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total)
 { const uint64_t n = b->n;
   int e;
@@ -611,3 +801,91 @@ static int onepass_short(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *perm,
     return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an encoded segment differs in size from what the size kernel computed");
   return DX_OK;
 }
+
+// A batch of short entries with long ones among them (qs_verdict.mixed): the short ones as above (the lanes skip the long ones), the
+// long ones -- a batch of their own under the arrays k_qs_sub_batch made, with the tokens and histograms dx_qv_hist left for THAT batch --
+// through the wave-per-entry kernels; between sizes and records the long entries' sizes go to their places among all, one scan lays the
+// records out, and the long ones' places (behind their framing bytes, written on the way) come back to their own batch.
+static bool onepass_tokens_ok(const dx_ctx *ctx, const dx_qv_batch *b);
+static int onepass_mixed(dx_ctx *ctx, const dx_qv_batch *b, const qs_verdict *qv, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
+                         uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total)
+{ const uint64_t n = b->n, nl = qv->sub.n;
+  const dx_qv_batch *b2 = &qv->sub;
+  int e;
+  uint8_t *scr;
+  const size_t a4 = (n * 4 + 255) & ~(size_t) 255, s4 = (nl * 4 + 255) & ~(size_t) 255, s20 = (nl * 20 + 255) & ~(size_t) 255;
+  if ((e = dx_scratch(ctx, a4 + s4 + s20 + (nl + 1) * 8 + 512, (void **) &scr))) return e;
+  uint32_t *d_size = (uint32_t *) scr, *size2 = (uint32_t *) (scr + a4), *seg2 = (uint32_t *) (scr + a4 + s4);
+  uint64_t *rec2 = (uint64_t *) (scr + a4 + s4 + s20);
+  dx_sx_drop_external(ctx);
+  ctx->sx.valid = 0;                                     // (no group index from this route)
+  const qv_args a  = make_args(b,  ctx->delChar, ctx->subChar, ctx->lossy);
+  const qv_args a2 = make_args(b2, ctx->delChar, ctx->subChar, ctx->lossy);
+  const bool toks = onepass_tokens_ok(ctx, b2);          // the long entries' tokens (k_qv_hist over the batch of their own) ...
+  const bool by_hist = toks && ctx->tk.eh_valid && !dx_test_on("sizes_from_tokens");
+  const bool odd  = toks && ctx->tk.unusable > 0;        // ... some of which may be unusable: those entries from the text
+  const tok_src tg = { ctx->tk.del, ctx->tk.sub, ctx->tk.off, ctx->tk.info };
+  uint32_t *d_tick = (uint32_t *) (ctx->d_u64 + 19), *d_tick2 = (uint32_t *) (ctx->d_u64 + 22);
+  const unsigned lb = (unsigned) ((nl + QS_BLOCK - 1) / QS_BLOCK), lb1 = (unsigned) ((nl + 1 + QS_BLOCK - 1) / QS_BLOCK);
+  DX_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 4, ctx->stream));
+  // sizes: the short entries' by the lanes, the long ones' by their own kernels
+  DX_LAUNCH(ctx, DX_K_QV_SIZES, (k_qs_entries<false, false>), qs_grid(ctx, n), QS_BLOCK, a, qv->deal, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, d_hdr_off,
+            (const uint64_t *) NULL, d_seg, d_size, (uint8_t *) NULL, ctx->d_status);
+  DX_HIP(ctx, hipMemsetAsync(d_tick2, 0, 4, ctx->stream));
+  if (by_hist)
+    DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes_hist, dx_grid_waves(ctx, (nl + 7) / 8, 32), DX_BLOCK, a2, (const uint32_t *) ctx->d_tok, (const uint64_t *) NULL,
+              seg2, size2, tg, (const uint32_t *) ctx->tk.eh, ctx->tk.subChar);
+  else if (toks)
+    DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes_fast, fast_grid(ctx, (nl + TICKET_BATCH - 1) / TICKET_BATCH), FAST_BLOCK, a2, (const uint32_t *) ctx->d_tok,
+              (const uint64_t *) NULL, seg2, size2, d_tick2, tg);
+  if (!toks || odd)
+    { if (toks) DX_HIP(ctx, hipMemsetAsync(d_tick2, 0, 4, ctx->stream));
+      DX_LAUNCH(ctx, DX_K_QV_SIZES, k_qv_sizes, dx_grid_waves(ctx, toks ? (ctx->tk.unusable < nl ? ctx->tk.unusable : nl) : nl, 4 * SIZES_WAVES), DX_BLOCK,
+                a2, (const uint32_t *) ctx->d_tok, (const uint64_t *) NULL, seg2, size2, d_tick2,
+                toks ? (const uint32_t *) ctx->tk.list : (const uint32_t *) NULL, toks ? (const unsigned long long *) ctx->tk.count : (const unsigned long long *) NULL,
+                (uint64_t) 0, toks ? (const uint32_t *) ctx->tk.info : (const uint32_t *) NULL);
+    }
+  hipLaunchKernelGGL(k_qs_scatter_sizes, dim3(lb), dim3(QS_BLOCK), 0, ctx->stream, qv->list, nl, (const uint32_t *) seg2, (const uint32_t *) size2,
+                     d_hdr_off, d_seg, d_size);
+  DX_HIP(ctx, hipGetLastError());
+  uint64_t tot = 0;
+  if ((e = dx_scan_u32(ctx, d_size, n, d_rec_off, &tot))) return e;
+  if (total) *total = tot;
+  ctx->route.groups = 0; ctx->route.direct = 5; ctx->route.tokens = toks ? 1 : 0; ctx->route.region_bytes = 0;
+  ctx->route.scratch_bytes = ctx->scratch_bytes; ctx->route.token_bytes = toks ? 4ull * ctx->tk.cap_tokens : 0;
+  ctx->route.text_entries = n - nl + (toks ? ctx->tk.unusable : nl);
+  if (tot > out_cap)
+    return dx_fail(ctx, DX_E_SPACE, "dx_qv_encode_onepass: the record stream needs %llu bytes, d_out holds %llu",
+                   (unsigned long long) tot, (unsigned long long) out_cap);
+  // records: the long entries' places and framing bytes, the short entries by the lanes, the long ones by their own kernels
+  hipLaunchKernelGGL(k_qs_gather_places, dim3(lb1), dim3(QS_BLOCK), 0, ctx->stream, qv->list, nl, (const uint64_t *) d_rec_off, d_hdr, d_hdr_off, d_out, rec2);
+  DX_HIP(ctx, hipGetLastError());
+  if (ctx->tok_wide)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, true>), qs_grid(ctx, n), QS_BLOCK, a, qv->deal, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+              (const uint64_t *) d_rec_off, d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
+  else
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, (k_qs_entries<true, false>), qs_grid(ctx, n), QS_BLOCK, a, qv->deal, (const uint32_t *) ctx->d_tok, d_hdr, d_hdr_off,
+              (const uint64_t *) d_rec_off, d_seg, (uint32_t *) NULL, d_out, ctx->d_status);
+  DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, ctx->stream));
+  if (toks)
+    DX_LAUNCH(ctx, DX_K_QV_ENCODE, FAST_K, fast_grid(ctx, nl), FAST_BLOCK, a2, (const uint32_t *) ctx->d_tok, (const uint64_t *) NULL, ctx->d_status, d_tick, tg,
+              ctx->pair_lo[0], ctx->pair_lo[1], (const uint8_t *) NULL, (const uint64_t *) rec2, (const uint32_t *) seg2, d_out, ~(uint64_t) 0,
+              sub_sink{ NULL, NULL, NULL });
+  if (!toks || odd)
+    { if (toks) DX_HIP(ctx, hipMemsetAsync(d_tick, 0, 4, ctx->stream));
+      DX_LAUNCH(ctx, DX_K_QV_ENCODE_TEXT, k_qv_encode, dx_grid_waves(ctx, toks ? (ctx->tk.unusable < nl ? ctx->tk.unusable : nl) : nl, 4 * ENC_WAVES), DX_BLOCK,
+                a2, (const uint32_t *) ctx->d_tok, (const uint8_t *) NULL, (const uint64_t *) NULL, (const uint64_t *) rec2, (const uint32_t *) seg2, d_out,
+                ctx->d_status, d_tick, toks ? (const uint32_t *) ctx->tk.list : (const uint32_t *) NULL,
+                toks ? (const unsigned long long *) ctx->tk.count : (const unsigned long long *) NULL, (uint64_t) 0,
+                toks ? (const uint32_t *) ctx->tk.info : (const uint32_t *) NULL, ~(uint64_t) 0, sub_sink{ NULL, NULL, NULL });
+    }
+  uint32_t st = 0;
+  DX_HIP(ctx, hipMemcpyAsync(&st, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (st & DX_ST_INDEX)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an entry's offset and length reach beyond text_bytes");
+  if (st & 2u)
+    return dx_fail(ctx, DX_E_MISMATCH, "dx_qv_encode_onepass: an encoded segment differs in size from what the size kernel computed");
+  return DX_OK;
+}
+

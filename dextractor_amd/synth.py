@@ -107,6 +107,16 @@ def lengths(n: int, seed: int, dist: str = "lognormal", mean: int = 10000, sigma
     if dist == "fixed":
         return np.full(n, mean, dtype=np.uint32)
     rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+    if dist == "short_u":                        # the short part of "mixed" alone: uniform in [100, 600]
+        return rng.integers(100, 601, n).astype(np.uint32)
+    if dist == "mixed":                          # what a subread set looks like: nine entries in ten short (U[100, 600]), one in ten lognormal around `mean`
+        short = rng.integers(100, 601, n).astype(np.int64)
+        mu = np.log(mean) - 0.5 * sigma * sigma
+        long_ = np.clip(np.rint(rng.lognormal(mu, sigma, n)).astype(np.int64), lo, 20 * mean)
+        return np.where(rng.random(n) < 0.1, long_, short).astype(np.uint32)
+    if dist == "mixed_tail":                     # (experiments: the same entries, the long ones behind the short ones)
+        x = lengths(n, seed, "mixed", mean, sigma, lo)
+        return np.concatenate([x[x <= 4096], x[x > 4096]]).astype(np.uint32)
     mu = np.log(mean) - 0.5 * sigma * sigma
     ln = np.rint(rng.lognormal(mu, sigma, n)).astype(np.int64)
     return np.clip(ln, lo, 20 * mean).astype(np.uint32)

@@ -180,19 +180,71 @@ def test_long_entry_or_few_entries_keep_the_wave_per_entry_kernels(ctx, monkeypa
     assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
 
 
-def test_mixed_lengths_1_to_20000(ctx):
-    """a batch of entries of 1 ... 20 000 symbols, most of them short (the wave-per-entry kernels: an entry is longer than a lane
-    takes), the same batch with the long ones cut down to 4096 (still theirs: a wave's longest entry sets what its 64 cost, and the longest
-    entry's lane would still be running when the rest of so small a batch is done) and to 700 (the lane-per-entry kernels): all against the oracle"""
+def _took_mixed(ctx):
+    return ctx.qv_onepass_info()["direct"] == 5
+
+
+def test_mixed_lengths_1_to_20000(ctx, monkeypatch):
+    """a batch of entries of 1 ... 20 000 symbols, most of them short: the lanes take the short ones, the entries of more than 4096 symbols
+    go -- a batch of their own -- to the wave-per-entry kernels (direct == 5; round 5 sent the whole batch there for ONE long entry); the
+    same batch with the long ones cut down to 4096 (the longest entry's lane would still be running when the rest of so small a batch is
+    done: the wave-per-entry kernels) and to 700 (the lane-per-entry kernels alone): all against the oracle"""
     rng = np.random.Generator(np.random.PCG64(20))
     lens = np.concatenate([rng.integers(1, 400, 4000), rng.integers(400, 3000, 700), rng.integers(3000, 20001, 60),
-                           [1, 2, 3, 15, 16, 17, 20000]]).astype(np.uint32)
+                           [1, 2, 3, 15, 16, 17, 20000, 4096, 4097]]).astype(np.uint32)
     rng.shuffle(lens)
     c = synth.make_quiva(len(lens), seed=21, lens=lens)
-    assert ctx.dexqv(c.text) == O.dexqv(c.text) and not _took_short(ctx)
+    want = O.dexqv(c.text)
+    set_flag(monkeypatch, "short_force", "1")                  # (so small a batch: the lanes whatever the longest short entry's lane costs)
+    assert ctx.dexqv(c.text) == want and _took_mixed(ctx)
+    assert ctx.undexqv(want, upper=True) == O.undexqv(want, upper=True)
+    assert ctx.dexqv(c.text, True) == O.dexqv(c.text, True) and _took_mixed(ctx)
+    set_flag(monkeypatch, "no_mixed", "1")                     # the switch: one long entry sends the batch to the wave-per-entry kernels
+    assert ctx.dexqv(c.text) == want and not _took_mixed(ctx) and not _took_short(ctx)
+    set_flag(monkeypatch, "no_mixed", None)
+    set_flag(monkeypatch, "short_force", None)
+    assert ctx.dexqv(c.text) == want and not _took_short(ctx)   # unforced: a 4096-symbol entry's lane outlasts so small a batch
     c = synth.make_quiva(len(lens), seed=21, lens=np.minimum(lens, 4096).astype(np.uint32))
     assert ctx.dexqv(c.text) == O.dexqv(c.text)
     c = synth.make_quiva(len(lens), seed=21, lens=np.minimum(lens, 700).astype(np.uint32))
     want = O.dexqv(c.text)
     assert ctx.dexqv(c.text) == want and _took_short(ctx)
     assert ctx.undexqv(want, upper=True) == O.undexqv(want, upper=True)
+
+
+@pytest.mark.parametrize("case", ["usual", "dense_tokens", "no_deletion_run_character", "sizes_from_tokens", "no_tokens", "late_delchar"])
+def test_short_entries_with_long_ones_among_them(ctx, monkeypatch, case):
+    """The mixed route chosen by itself (20 000 short entries, a few hundred long ones carrying most of the bytes -- what a subread set looks
+    like): scan state and histograms (the long entries counted under their own indices: the run histograms start at the entry the run
+    character was found in), the oracle's bytes, through every way the long entries' batch can go -- its own histograms, sizes from
+    tokens, one run character only, no tokens at all."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    lens = np.concatenate([rng.integers(100, 600, 20000), np.clip(rng.lognormal(np.log(9000), 0.4, 300), 4097, 60000)]).astype(np.uint32)
+    rng.shuffle(lens)
+    prof = synth.pacbio_profile(0.4, 0.35) if case == "dense_tokens" else None
+    c = synth.make_quiva(len(lens), seed=33, lens=lens, prof=prof)
+    if case in ("no_deletion_run_character", "late_delchar"):
+        t = bytearray(c.text)
+        first = 0 if case == "no_deletion_run_character" else int(np.nonzero(lens > 4096)[0][5]) + 1   # no 'N' tag before that entry: delChar found late
+        stop = len(lens) if case == "no_deletion_run_character" else first
+        for i in range(stop):
+            L_, o = int(c.len[i]), int(c.off[i])
+            t[o + L_ + 1: o + 2 * L_ + 1] = bytes(t[o + L_ + 1: o + 2 * L_ + 1]).replace(b"N", b"A").replace(b"n", b"a")
+        c.text = bytes(t)
+    if case == "sizes_from_tokens":
+        set_flag(monkeypatch, "sizes_from_tokens", "1")
+    if case == "no_tokens":
+        set_flag(monkeypatch, "no_tokens", "1")
+    st = O.qv_scan(c.text)
+    d_text = ctx.to_device(np.frombuffer(c.text, np.uint8))
+    d_off, d_len = ctx.to_device(c.off), ctx.to_device(c.len)
+    b = ctx.qv_batch(d_text, d_off, d_len, len(c.len), text_bytes=len(c.text))
+    p, hist, tot = ctx.qv_scan(b)
+    want = O.hist_array(st)
+    want[4:6] -= 1
+    assert (p.delChar, p.subChar, p.del_first, p.sub_first) == (st.delChar, st.subChar, st.del_first, st.sub_first)
+    assert tot == st.totChar and (hist == want).all()
+    for x in (d_text, d_off, d_len): x.free()
+    img = ctx.dexqv(c.text)
+    assert img == O.dexqv(c.text) and _took_mixed(ctx)
+    assert ctx.undexqv(img, upper=True).split(b"\n")[1::6] == c.text.split(b"\n")[1::6]
