@@ -247,6 +247,30 @@ def main():
             except Exception as e:
                 extra[w] = {"error": repr(e)}
         line["other_workloads"] = extra
+    if rank == 0:
+        # what a reader of the line's top level (scalars only) should see of the secondary figures
+        def dig(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d if isinstance(d, (int, float, bool)) else None
+        flat = {"walk_and_decode_ms": dig(line, "device_walk", "walk_and_decode_ms"), "walk_kernel_ms": dig(line, "device_walk", "kernel_ms"),
+                "walk_decode_bit_exact": dig(line, "device_walk", "decode_bit_exact"),
+                "decode_indexed_ms": dig(line, "decode_indexed", "ms"),
+                "lognormal_GBps": dig(line, "other_workloads", "dexqv_lognormal", "value"),
+                "entries_2Mx2000_GBps": dig(line, "other_workloads", "dexqv_entry_length", "2000000x2000", "value"),
+                "entries_4Mx300_GBps": dig(line, "other_workloads", "dexqv_entry_length", "4000000x300", "value"),
+                "mixed_lengths_GBps": dig(line, "other_workloads", "dexqv_mixed_lengths", "mixed", "value"),
+                "mixed_over_weighted_mean_of_parts": dig(line, "other_workloads", "dexqv_mixed_lengths", "mixed_over_that"),
+                "run_density_0.5_GBps": dig(line, "other_workloads", "dexqv_run_density", "0.5", "value"),
+                "run_density_0.99_GBps": dig(line, "other_workloads", "dexqv_run_density", "0.99", "value"),
+                "config4_slice_GBps": dig(line, "other_workloads", "config4_slice", "value"),
+                "dexta_encode_frac": dig(line, "other_workloads", "dexta", "roofline", "frac"),
+                "dexta_decode_frac": dig(line, "other_workloads", "dexta", "decode", "frac"),
+                "cli_dexqv_20GB_s": dig(line, "cpu_baseline", "cli_end_to_end_large", "dexqv", "s"),
+                "cli_undexqv_20GB_s": dig(line, "cpu_baseline", "cli_end_to_end_large", "undexqv", "s")}
+        for k, v in flat.items():
+            if v is not None:
+                line["x_" + k] = v
     print(json.dumps(line))
 
 

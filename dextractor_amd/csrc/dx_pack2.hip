@@ -55,6 +55,9 @@
                                          // loads and the letters of one wave do not run beside the stores of another.  Loads issued three steps ahead
                                          // (three stores in flight per wave, vmcnt(5)): 31.7-32.4 against 32.1-33.6, and 73 registers -- not kept.
 #endif
+#ifndef P2D_ALIGN
+#define P2D_ALIGN     1                  // k_pack2_decode: a read's text as if it began (its address mod 16) bytes earlier, so that every 16-byte store of the
+#endif                                   // wave stands on a 16-byte boundary (stores 4 bytes off one: 3.5 TB/s against 5.3, profiles/r05e_copy_rate.txt: what the kernel ran at)
 #ifndef P2D_NT
 #define P2D_NT        0                  // k_pack2_decode: non-temporal stores for the text
 #endif
@@ -217,9 +220,9 @@ __device__ __forceinline__ uint32_t sym_letter(uint32_t code)
 // 16 text bytes of the generic case: any width, chunks at the end of the text
 template <int LETTERS>
 __device__ __forceinline__ void decode_chunk_generic(const uint8_t *src, uint8_t *dst, uint32_t q0, uint32_t T,
-                                                     uint32_t clen, uint32_t width)
+                                                     uint32_t clen, uint32_t width, uint32_t limit = 16u)
 { const uint32_t W1    = width + 1u;
-  const int      valid = (T - q0 >= 16u) ? 16 : (int) (T - q0);
+  const int      valid = (T - q0 >= limit) ? (int) limit : (int) (T - q0);
   const uint32_t line  = q0 / W1;
   uint32_t       col   = q0 - line * W1;
   const uint32_t i0    = q0 - line;                              // symbol index of text byte q0 (if a letter)
@@ -282,7 +285,15 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
       const uint32_t L    = nsym[r];
       const uint32_t clen = (L + 3u) >> 2;
       const uint32_t T    = L + (L + width - 1u) / width;        // letters + newlines
-      uint32_t line = line0, col = col0;
+      // The text as if it began adj bytes in front of dst (dstS, a 16-byte boundary): chunk q of that frame is text byte q - adj,
+      // every lane's 16-byte store is aligned, and only the frame's first chunk (lane 0 of the first step: the text's first
+      // 16 - adj bytes) is not whole.  (line, col) are the text position's: 16 lane - adj, one borrow at most (width >= 16).
+      const uint32_t adj  = P2D_ALIGN && !narrow ? (uint32_t) ((uintptr_t) dst & 15u) : 0u;
+      uint8_t       *dstS = dst - adj;
+      const uint32_t TS   = T + adj;
+      (void) dstS;
+      uint32_t line = line0, col = col0 - adj;
+      if (col0 < adj) { col += W1; line -= 1u; }                 // (lane 0: position -adj, as line -1: the advances below stay consistent)
 
       // Main loop: the steps in which every lane takes the fast path (16 letters from one 8-byte load; all but a read's
       // last one or two), software-pipelined by hand.  A wave's loads and stores are counted together (vmcnt) and retire
@@ -293,11 +304,14 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
       // own (a copy of a requested register would wait for it).
       uint32_t base = 0;
 #if P2D_PIPE
-#define P2D_ALLFAST(B) (!narrow && (B) + DX_STEP < T && (((B) + DX_STEP - 16u) >> 2) + 8u <= clen)
+#define P2D_ALLFAST(B) (!narrow && (B) + DX_STEP < TS && (((B) + DX_STEP - 16u) >> 2) + 8u <= clen)
 #define P2D_ADVANCE(LN, CL) { LN += dline; CL += dcol; if (CL >= W1) { CL -= W1; LN += 1u; } }
-#define P2D_LOAD(B, LN) (*(const u64_u *) (src + (((B) + 16u * (uint32_t) lane - (LN)) >> 2)))
+#define P2D_PRE(B) ((B) + 16u * (uint32_t) lane < adj)        /* the frame's first chunk (lane 0 of the first step): the text's first 16 bytes instead, */ \
+                                                              /* stored where they stand -- the one store of the read off a boundary; lane 1's writes the bytes they share again */
+#define P2D_LOAD(B, LN) (*(const u64_u *) (src + ((P2D_PRE(B) ? 0u : (B) + 16u * (uint32_t) lane - adj - (LN)) >> 2)))
 #define P2D_STEP_FAST(RAW, B, LN, CL)                                                                        \
-          { const uint32_t q0 = (B) + 16u * (uint32_t) lane, i0 = q0 - (LN), nlpos = width - (CL);           \
+          { const bool     pre = P2D_PRE(B);                                                                 \
+            const uint32_t q0 = pre ? 0u : (B) + 16u * (uint32_t) lane - adj, i0 = pre ? 0u : q0 - (LN), nlpos = pre ? width : width - (CL); \
             const uint64_t be = ((uint64_t) __builtin_bswap32((uint32_t) (RAW)) << 32) | __builtin_bswap32((uint32_t) ((RAW) >> 32)); \
             uint32_t cw = (uint32_t) ((be << (2u * (i0 & 3u))) >> 32);                                       \
             if (nlpos < 16u)                                                                                 \
@@ -352,17 +366,19 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
 #undef P2D_ALLFAST
 #endif
       // the rest (and everything, for narrow lines): P2D_UNROLL steps of 1 KiB per iteration, checked lane by lane
-      for (; base < T; base += P2D_UNROLL * DX_STEP)
+      for (; base < TS; base += P2D_UNROLL * DX_STEP)
         { uint64_t raw[P2D_UNROLL];
           uint32_t i0k[P2D_UNROLL], nlk[P2D_UNROLL];
           bool     fastk[P2D_UNROLL];
           #pragma unroll
           for (int k = 0; k < (int) P2D_UNROLL; k++)
-            { const uint32_t q0 = base + (uint32_t) k * DX_STEP + 16u * lane;
-              const uint32_t i0 = q0 - line;                     // symbols before text byte q0
+            { const uint32_t qs = base + (uint32_t) k * DX_STEP + 16u * lane;
+              const bool     pre = qs < adj;                     // the frame's first chunk (lane 0 of the first step): the text's first 16 bytes instead
+              const uint32_t q0 = pre ? 0u : qs - adj;           // the text byte the chunk begins with
+              const uint32_t i0 = pre ? 0u : q0 - line;          // symbols before text byte q0
               const uint32_t b0 = i0 >> 2;
               i0k[k]   = i0;
-              nlk[k]   = width - col;                            // offset of the line end in this chunk (>= 16: none)
+              nlk[k]   = pre ? width : width - col;              // offset of the line end in this chunk (>= 16: none)
               // every chunk of the text but those of narrow lines and of reads shorter than 8 packed bytes: the read's last
               // chunks too (P2D_ENDS) -- their 8 bytes taken from the last 8 of the read and shifted when they would reach
               // past its end, a second hole for the text's last line end, a byte-wise store when the chunk is not whole
@@ -382,7 +398,8 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
             }
           #pragma unroll
           for (int k = 0; k < (int) P2D_UNROLL; k++)
-            { const uint32_t q0 = base + (uint32_t) k * DX_STEP + 16u * lane;
+            { const uint32_t qs = base + (uint32_t) k * DX_STEP + 16u * lane;
+              const uint32_t q0 = qs < adj ? 0u : qs - adj;
               if (fastk[k])
                 { // 16 (or 15 + line end) letters from 8 packed bytes: symbol j of the chunk in bits 31-2j, 30-2j
                   const uint64_t be = ((uint64_t) __builtin_bswap32((uint32_t) raw[k]) << 32) | __builtin_bswap32((uint32_t) (raw[k] >> 32));

@@ -39,7 +39,9 @@ ACCESS = {"k_qv_hist": "stream", "k_qv_encode_fast": "stream", "k_qv_encode": "s
           "k_qv_decode_tags": "stream",
           "k_add_one": "lanes", "k_gather_headers": "lanes", "k_gather_lines": "lanes", "k_tok_rooms": "stream",
           "k_walk_find": "stream", "k_walk_pieces": "lanes", "k_walk_gather": "lanes", "k_walk_rooms": "lanes", "k_walk_index": "lanes",
-          "k_qs_survey": "lanes", "k_qs_hist": "lanes", "k_qs_entries": "lanes"}
+          "k_qs_survey": "lanes", "k_qs_hist": "lanes", "k_qs_entries": "lanes", "k_qs_lenhist": "lanes", "k_qs_cut": "lanes",
+          "k_qs_round_order": "lanes", "k_qs_sub_batch": "lanes", "k_qs_scatter_sizes": "lanes", "k_qs_gather_places": "lanes",
+          "k_scan_state": "lanes"}
 
 
 def kname(full):
