@@ -1528,6 +1528,28 @@ __device__ __forceinline__ void load_shift_tables(uint32_t (*s_stok)[256], uint8
     w0 = __builtin_amdgcn_alignbit(w0, (t), (t));                                               \
   }
 
+// ... and to a 96-bit string w2:w0, for the steps in which no lane of the wave has more (nearly all: sixteen symbols of a plain line are
+// 70 bits on average, eight tokens 64): three funnel shifts a token instead of four, four words placed instead of five
+#define STOK_APPEND3(t)                                                                         \
+  { w2 = __builtin_amdgcn_alignbit(w2, w1, (t));                                                \
+    w1 = __builtin_amdgcn_alignbit(w1, w0, (t));                                                \
+    w0 = __builtin_amdgcn_alignbit(w0, (t), (t));                                               \
+  }
+#ifndef FAST_CHAIN96
+#define FAST_CHAIN96 1
+#endif
+__device__ __forceinline__ void place_bits96(uint32_t *win, uint32_t bit, uint32_t nb, uint32_t w0, uint32_t w1, uint32_t w2)
+{ const uint32_t e  = bit + nb;
+  const uint32_t sl = (32u - (e & 31u)) & 31u, sr = 32u - sl;
+  const uint32_t we = (e - 1u) >> 5;
+  const uint32_t x0 = w0 << sl;
+  const uint32_t x1 = fsr(w1, w0, sr), x2 = fsr(w2, w1, sr), x3 = fsr(0u, w2, sr);
+  atomicOr(&win[we], x0);
+  atomicOr(&win[(int) we - 1], x1);
+  atomicOr(&win[(int) we - 2], x2);
+  atomicOr(&win[(int) we - 3], x3);
+}
+
 // OR the nb (1..128) bits right-aligned in w3:w0 into the window at bit offset `bit`
 __device__ __forceinline__ void place_bits128(uint32_t *win, uint32_t bit, uint32_t nb,
                                               uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)

@@ -84,6 +84,7 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
                 if ((uint32_t) k == xk) rt[k] = e;
             }
         }
+      // the lengths first: a wave none of whose lanes has more than 96 bits (and no run with a literal) chains into three words, not four
       uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, nb = 0, zor = 0, tacc = 0, span = 0;
       #pragma unroll
       for (int k = 0; k < (int) TOK_TP; k++)
@@ -91,19 +92,37 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
             const uint32_t run = XC && (uint32_t) k == xk ? xr : t16 >> 9;
             span += run + 1u;
-            STOK_APPEND(rt[k])
-            if (rt[k] & 0x80u)                                     // escaped run: its 16-bit literal follows (QV.c:486-487)
-              { const uint32_t lit = (run << 16) | 16u;
-                STOK_APPEND(lit)
-                w0 |= run & 0xffff0000u;                           // OCODE(16, run) with run >= 2^16 (QV.c:411, 420)
-                nb += 16u;
-              }
-            STOK_APPEND(st[k])
-            nb  += 64u - (rt[k] & 0x3fu) - (st[k] & 0xffu);
-            zor |= rt[k] | st[k];
+            nb   += 64u - (rt[k] & 0x3fu) - (st[k] & 0xffu) + ((rt[k] & 0x80u) ? 16u : 0u);
+            zor  |= rt[k] | st[k];
             if (TAGS)
               tacc = (tacc << 2) | (t16 & 3u);
           }
+      const bool narrow96 = FAST_CHAIN96 && !__any((int) ((zor & 0x80u) | (nb > 96u)));
+      if (narrow96)
+        {
+          #pragma unroll
+          for (int k = 0; k < (int) TOK_TP; k++)
+            if ((uint32_t) k < c)
+              { STOK_APPEND3(rt[k])
+                STOK_APPEND3(st[k])
+              }
+        }
+      else
+        {
+          #pragma unroll
+          for (int k = 0; k < (int) TOK_TP; k++)
+            if ((uint32_t) k < c)
+              { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
+                const uint32_t run = XC && (uint32_t) k == xk ? xr : t16 >> 9;
+                STOK_APPEND(rt[k])
+                if (rt[k] & 0x80u)                                 // escaped run: its 16-bit literal follows (QV.c:486-487)
+                  { const uint32_t lit = (run << 16) | 16u;
+                    STOK_APPEND(lit)
+                    w0 |= run & 0xffff0000u;                       // OCODE(16, run) with run >= 2^16 (QV.c:411, 420)
+                  }
+                STOK_APPEND(st[k])
+              }
+        }
       if (XC && xn > 1u)                                           // two exception tokens in one lane: its bits counted token by token
         { nb = 0; span = 0; zor |= 64u;                            // (and the pass placed token by token, below; bit 6 is free in every
                                                                    //  token: unlike bit 5 -- something has no code -- it leaves the line its index)
@@ -123,8 +142,14 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           wide |= ((zor & 32u) || span > 0xffffu || wave_total(incl) > RUN_PASSBITS) ? 1u : 0u;
         }
       if (!__any((int) ((zor & 96u) | (nb > 128u))))
-        { FOR_ONE_ROUND(o, incl, nb,
-            { place_bits128(o.win, bit_, nb, w0, w1, w2, w3); })
+        { if (narrow96)
+            { FOR_ONE_ROUND(o, incl, nb,
+                { place_bits96(o.win, bit_, nb, w0, w1, w2); })
+            }
+          else
+            { FOR_ONE_ROUND(o, incl, nb,
+                { place_bits128(o.win, bit_, nb, w0, w1, w2, w3); })
+            }
         }
       else                                    // a symbol or run without a code, or a string > 128 bits
         { FOR_EACH_ROUND_LATE(o, incl, nb,
@@ -235,6 +260,16 @@ __device__ __forceinline__ bool encode_plain_step_pair(wave_out &o, const u32x4 
     return false;
   const uint32_t incl = wave_incl_scan(nb);
   sub_step(sm, nb, 16u, false);
+  if (FAST_CHAIN96 && !__any((int) (nb > 96u)))
+    { FOR_ONE_ROUND(o, incl, nb,
+        { uint32_t w0 = 0, w1 = 0, w2 = 0;
+          _Pragma("unroll")
+          for (int k = 0; k < 8; k++)
+            STOK_APPEND3(tok[k])
+          place_bits96(o.win, bit_, nb, w0, w1, w2);
+        })
+      return true;
+    }
   FOR_ONE_ROUND(o, incl, nb,
     { uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
       _Pragma("unroll")

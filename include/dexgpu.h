@@ -237,7 +237,7 @@ int dx_qv_hist(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, const dx_qv_p
  * between the kernels; the two things the host has to decide before it knows that state (which of its histogram kernels
  * fits the batch's run density, whether the token buffers it holds are large enough) it takes from the context's last
  * scan, and the device checks them: a context's first batch, or a batch unlike the last one, simply goes through the
- * two calls.  Nothing of one batch's RESULTS is carried to the next.  DEXGPU_NO_SCAN_GUESS=1: always the two calls.      */
+ * two calls.  Nothing of one batch's RESULTS is carried to the next.  DEXGPU_TEST=no_scan_guess: always the two calls.   */
 int dx_qv_scan(dx_ctx *ctx, const dx_qv_batch *b, uint64_t entry0, dx_qv_params *p,
                uint64_t hist[6][256], uint64_t *totChar);
 
@@ -284,51 +284,45 @@ int dx_qv_sizes(dx_ctx *ctx, const dx_qv_batch *b, const uint64_t *d_hdr_off,
 int dx_qv_encode(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                  const uint64_t *d_rec_off, const uint32_t *d_seg, uint8_t *d_out);
 
-/* Compress_Next_QVentry x n WITHOUT a size pass: every entry is first encoded into a scratch slot whose
- * size is bounded from the code tables, its five segment sizes are recorded (d_seg, n x 5: the same index
- * dx_qv_sizes produces), a scan turns them into d_rec_off (n + 1), and a copy kernel moves header +
- * segments to d_out.  *total receives the stream's size; DX_E_SPACE if it exceeds out_cap (nothing
- * useful is in d_out then).  The bytes are those of dx_qv_sizes + dx_qv_encode (QV.c:1381-1426).  The
- * entries are worked through in groups; the copy of one group runs on a second stream of the context
- * beside the encode of the next.  Scratch (two group-sized regions, about 1 x the output for large
- * batches) is owned by the context and kept for the next call.                                      */
+/* Compress_Next_QVentry x n (QV.c:1381-1426) in one call: the five segment sizes of every entry (d_seg, n x 5: the same index
+ * dx_qv_sizes produces), a scan that turns them into d_rec_off (n + 1), and every record -- framing bytes and segments -- written
+ * where it belongs in d_out.  *total receives the stream's size; DX_E_SPACE if it exceeds out_cap (nothing useful is in d_out
+ * then).  The bytes are those of dx_qv_sizes + dx_qv_encode.  Which kernels run depends on what this context's dx_qv_hist (or
+ * dx_qv_scan) of the same batch has left: tokens and every entry's own histograms (the usual case: sizes by a dot product,
+ * k_qv_encode_fast), tokens alone (sizes from tokens and plain lines), nothing (sizes and records from the text); a batch of
+ * short entries goes a lane an entry, one with long entries among the short ones is dealt between the two kinds of kernel
+ * (dx_qv_onepass_info tells).  No scratch beyond O(n) bookkeeping: rounds 2-3's slots and their compaction are gone (round 6). */
 int dx_qv_encode_onepass(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                          uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap, uint64_t *total);
-/* The same in two halves, for a caller with more batches to come: _begin queues everything and returns while the
- * last group's compaction is still running on the context's second stream; _end makes the context's stream wait
- * for it and hands back the stream's size and the verdict (DX_E_SPACE, ...).  Between the two, the NEXT batch's
- * dx_qv_prescan, dx_qv_hist, dx_qv_build and dx_qv_set_coding may run (in that order: they touch nothing the
- * compaction reads) -- the compaction then hides behind the histogram pass, 3 ms of a 31 ms step.  Of the other calls,
- * dx_sync, dx_d2h and dx_d2h_stream first make the context's stream wait for the compaction; dx_qv_sizes,
- * dx_qv_encode, dx_qv_decode and a second dx_qv_encode_onepass[_begin] are refused (DX_E_ARG) until _end has been
- * called.  A dx_qv_set_coding in between leaves the group index (dx_qv_subindex) of the ended encode unarmed.  One
- * encode at a time per context.  d_out, d_seg, d_rec_off are complete once _end has returned.                   */
+/* The same in two halves (kept from the rounds in which a compaction ran behind the encoder: a caller written for them works
+ * unchanged): _begin does the encode and keeps the answer, _end hands back the stream's size and the verdict (DX_E_SPACE, ...).
+ * Between the two, the NEXT batch's dx_qv_prescan, dx_qv_hist, dx_qv_build and dx_qv_set_coding may run; dx_qv_sizes,
+ * dx_qv_encode, dx_qv_decode and a second dx_qv_encode_onepass[_begin] are refused (DX_E_ARG) until _end has been called.  A
+ * dx_qv_set_coding in between leaves the group index (dx_qv_subindex) of the ended encode unarmed.  One encode at a time per
+ * context.                                                                                                              */
 int dx_qv_encode_onepass_begin(dx_ctx *ctx, const dx_qv_batch *b, const uint8_t *d_hdr, const uint64_t *d_hdr_off,
                                uint32_t *d_seg, uint64_t *d_rec_off, uint8_t *d_out, uint64_t out_cap);
 int dx_qv_encode_onepass_end(dx_ctx *ctx, uint64_t *total);
 
-/* Which way the last dx_qv_encode_onepass / _begin of this context took (it depends on the memory left on the
- * device), for logs and benchmarks: groups = scratch regions the batch was worked through in (0: none, see direct),
- * direct = 2 when the histogram pass left every entry's own counters and the sizes came from them (records written in place:
- * the usual case), 1 when no scratch slots could be had and the sizes-first route with k_qv_sizes_fast ran, tokens = 1 when the histogram pass's tokens fed the encoder; region_bytes = one scratch region,
- * scratch_bytes = the context's scratch allocation after the call, avail_bytes = the memory the choice was made
- * against (free device memory + the scratch that exists, or the budget below), token_bytes = the token slots,
- * text_entries = entries the text-reading encoder took because their tokens could not be used (a byte >= 128 in a
- * run-coded line, more tokens than the slot holds).                                                              */
+/* Which way the last dx_qv_encode_onepass / _begin of this context took, for logs and benchmarks: direct (below), tokens = 1 when
+ * the histogram pass's tokens fed the encoder, scratch_bytes = the context's scratch allocation after the call, token_bytes =
+ * the token slots, text_entries = entries the text-reading kernels took (no tokens, or tokens that could not be used: a byte
+ * >= 128 in a run-coded line, more tokens than the slot or the list holds; the short entries of routes 3 and 5).  groups,
+ * region_bytes and avail_bytes are of the scratch-slot route, which is gone: always 0 (kept for the layout).            */
 typedef struct
-  { int32_t  groups, direct, tokens, reserved;        /* direct: 0 slots + compaction, 1 sizes first by k_qv_sizes_fast (tokens and plain lines read
-                                                         again), 2 sizes from the entries' own histograms (k_qv_sizes_hist): the product route,
-                                                         3 a batch of short entries: a lane per entry (k_qs_entries: sizes, then records) */
+  { int32_t  groups, direct, tokens, reserved;        /* direct: 1 sizes by k_qv_sizes_fast (tokens and plain lines read again), 2 sizes from the
+                                                         entries' own histograms (k_qv_sizes_hist): the product route, 3 a batch of short entries: a
+                                                         lane per entry (k_qs_entries: sizes, then records), 4 no tokens of this batch: sizes and records
+                                                         from the text, 5 short entries by the lanes and the long ones among them as a batch of their
+                                                         own through the wave-per-entry kernels */
     uint64_t region_bytes, scratch_bytes, avail_bytes, token_bytes, text_entries;
     uint64_t chain_waits[3];                          /* always 0 (the routes that reported here are gone; kept for the layout) */
   } dx_onepass_info;
 int dx_qv_onepass_info(const dx_ctx *ctx, dx_onepass_info *out);
 
-/* Memory the context may take for the scratch of dx_qv_encode_onepass (0, the default: whatever hipMemGetInfo
- * reports free when the call is made -- which depends on what else holds memory in the process, e.g. a caching
- * allocator).  With a budget the route a batch takes is a function of the batch and the budget alone: a job
- * sharded over several GPUs gives every rank the same one.  The environment variable DEXGPU_SCRATCH_BUDGET (bytes)
- * overrides both.                                                                                              */
+/* An upper bound on one scratch request of the context (0, the default: none; requests of up to 64 MB always pass).  Rounds
+ * 2-3's encoder sized its scratch regions by it; since round 6 no route needs scratch beyond O(n) bookkeeping, and the call
+ * only bounds that.  The environment variable DEXGPU_SCRATCH_BUDGET (bytes) overrides it.                              */
 int dx_set_scratch_budget(dx_ctx *ctx, uint64_t bytes);
 
 /* Device memory free / in all on the context's GPU right now (hipMemGetInfo). */

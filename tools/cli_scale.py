@@ -109,18 +109,17 @@ for kind, pack, unpack, ext, px, uflags in (("quiva", "dexqv", "undexqv", ".quiv
         log(pack, dt)
     if kind == "fasta":
         # ... and through a pipe (dexta -i: dx_file_pack2_stream, a chunk of whole records at a time): the same bytes, a chunk's memory
-        import resource
-        before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
         t1 = time.perf_counter()
         with open(os.path.join(D, "s" + ext), "rb") as fi, open(os.path.join(D, "piped" + px), "wb") as fo:
             cat = subprocess.Popen(["cat"], stdin=fi, stdout=subprocess.PIPE)
-            r = subprocess.run([os.path.join(BIN, pack), "-i"], stdin=cat.stdout, stdout=fo, stderr=subprocess.PIPE)
+            child = subprocess.Popen([os.path.join(BIN, pack), "-i"], stdin=cat.stdout, stdout=fo, stderr=subprocess.DEVNULL)
+            _, status, ru = os.wait4(child.pid, 0)             # (this child's own resource usage: its peak resident set)
+            child.returncode = os.waitstatus_to_exitcode(status)
             cat.wait()
         dt = time.perf_counter() - t1
-        res["runs"][pack + "_pipe"] = [{"s": round(dt, 3), "GBps": round(size / dt / 1e9, 2), "exit": r.returncode,
-                                        "same_bytes_as_the_file_mode": r.returncode == 0 and same("piped" + px, "s" + px),
-                                        "max_rss_MB_of_any_child_so_far": round(max(before, resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss) / 1024, 1),
-                                        "marks_ms": []}]
+        res["runs"][pack + "_pipe"] = [{"s": round(dt, 3), "GBps": round(size / dt / 1e9, 2), "exit": child.returncode,
+                                        "same_bytes_as_the_file_mode": child.returncode == 0 and same("piped" + px, "s" + px),
+                                        "max_rss_MB": round(ru.ru_maxrss / 1024, 1), "marks_ms": []}]
         log(pack, "-i", res["runs"][pack + "_pipe"])
         os.unlink(os.path.join(D, "piped" + px))
     os.unlink(os.path.join(D, "s" + ext))
