@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /*
  * cli_common.c -- command-line surface of the reference's six codec tools, on top of libdexgpu.
  *
@@ -508,6 +509,9 @@ int dex_tool_main(int tool, int argc, char *argv[])
     }
 
   tmark("start");
+#ifdef F_SETPIPE_SZ
+  if (PIPE) (void) fcntl(0, F_SETPIPE_SZ, 1 << 20);        /* (a pipe's 64 KB are 2 GB/s at best; no harm where stdin is none or the size is refused) */
+#endif
   Opening = pthread_create(&Opener, NULL, open_contexts, NULL) == 0;
   if (!Opening) open_contexts(NULL);
   for (i = 1; i < argc; i++)
@@ -597,7 +601,8 @@ int dex_tool_main(int tool, int argc, char *argv[])
               ctx = Ctx0;
               tmark("GPU context open");
               if (PIPE || !file_is_ours(output))
-                rc = dx_file_pack2_stream(ctx, tool == TOOL_DEXAR, read_fd, &fdin, 0, sink_stream, output, &out_len, &line, &code);
+                rc = dx_file_pack2_stream(ctx, tool == TOOL_DEXAR, read_fd, &fdin, (size_t) dx_test_num("stream_chunk", (long long) 64 << 20),
+                                          sink_stream, output, &out_len, &line, &code);          /* (a pipe: 64 MiB at a time -- the memory stays small, the pipe sets the pace) */
               else
                 { rc = dx_file_pack2_stream(ctx, tool == TOOL_DEXAR, read_fd, &fdin, 0, sink_pwrite, &fdout, &out_len, &line, &code);
                   if (rc == DX_OK && lseek(fdout, (off_t) out_len, SEEK_SET) < 0) rc = DX_E_IO;

@@ -267,20 +267,118 @@ static uint64_t count_newlines(const uint8_t *p, size_t n)
   return c;
 }
 
-int dx_file_pack2_stream(dx_ctx *ctx, int arrow, dx_read_fn rd, void *ruser, size_t chunk,
+/* Reading ahead: a helper thread takes the next block from the caller's read function while the last one is on the device -- a pipe
+   hands over 2 GB/s at best, and a chunk's packing is no faster than that: one after the other they add up (dexta -i of 4 GB: 3.1 s),
+   side by side the slower one counts.  Two blocks of RA_BLOCK bytes; ra_read() gives their bytes out in order. */
+#define RA_BLOCK ((size_t) 32 << 20)
+typedef struct
+  { dx_read_fn      rd;
+    void           *user;
+    uint8_t        *blk[2];
+    size_t          len[2], pos;
+    int             full[2], cur, eof, err, stop, threaded;
+    pthread_mutex_t mx;
+    pthread_cond_t  cv;
+    pthread_t       th;
+  } readahead;
+
+static void *ra_main(void *arg)
+{ readahead *r = arg;
+  int slot = 0;
+  for (;;)
+    { size_t n = 0;
+      pthread_mutex_lock(&r->mx);
+      while (r->full[slot] && !r->stop) pthread_cond_wait(&r->cv, &r->mx);
+      if (r->stop) { pthread_mutex_unlock(&r->mx); break; }
+      pthread_mutex_unlock(&r->mx);
+      while (n < RA_BLOCK)
+        { const long k = r->rd(r->user, r->blk[slot] + n, RA_BLOCK - n);
+          if (k < 0) { r->err = 1; break; }
+          if (k == 0) break;
+          n += (size_t) k;
+        }
+      pthread_mutex_lock(&r->mx);
+      r->len[slot] = n; r->full[slot] = 1;
+      if (n < RA_BLOCK) r->eof = 1;
+      pthread_cond_broadcast(&r->cv);
+      pthread_mutex_unlock(&r->mx);
+      if (n < RA_BLOCK) break;
+      slot ^= 1;
+    }
+  return NULL;
+}
+
+static void ra_begin(readahead *r, dx_read_fn rd, void *user)
+{ memset(r, 0, sizeof(*r));
+  r->rd = rd; r->user = user;
+  r->blk[0] = malloc(RA_BLOCK); r->blk[1] = malloc(RA_BLOCK);
+  if (r->blk[0] != NULL && r->blk[1] != NULL && !dx_test_on("no_readahead"))
+    { pthread_mutex_init(&r->mx, NULL);
+      pthread_cond_init(&r->cv, NULL);
+      r->threaded = pthread_create(&r->th, NULL, ra_main, r) == 0;
+    }
+}
+
+static long ra_read(void *arg, void *buf, size_t want)
+{ readahead *r = arg;
+  size_t got = 0;
+  if (!r->threaded) return r->rd(r->user, buf, want);
+  while (got < want)
+    { int have;
+      pthread_mutex_lock(&r->mx);
+      while (!r->full[r->cur] && !r->eof && !r->err) pthread_cond_wait(&r->cv, &r->mx);
+      have = r->full[r->cur];
+      pthread_mutex_unlock(&r->mx);
+      if (r->err) return -1;
+      if (!have) break;                                /* the input's end, and nothing left in this block (blocks come in turn) */
+      { const size_t k = r->len[r->cur] - r->pos < want - got ? r->len[r->cur] - r->pos : want - got;
+        memcpy((uint8_t *) buf + got, r->blk[r->cur] + r->pos, k);
+        got += k; r->pos += k;
+      }
+      if (r->pos == r->len[r->cur])
+        { const int last = r->len[r->cur] < RA_BLOCK;
+          pthread_mutex_lock(&r->mx);
+          r->full[r->cur] = 0;
+          pthread_cond_broadcast(&r->cv);
+          pthread_mutex_unlock(&r->mx);
+          r->cur ^= 1; r->pos = 0;
+          if (last) break;
+        }
+    }
+  return (long) got;
+}
+
+static void ra_end(readahead *r)
+{ if (r->threaded)
+    { pthread_mutex_lock(&r->mx);
+      r->stop = 1;
+      pthread_cond_broadcast(&r->cv);
+      pthread_mutex_unlock(&r->mx);
+      pthread_join(r->th, NULL);
+      pthread_cond_destroy(&r->cv);
+      pthread_mutex_destroy(&r->mx);
+    }
+  free(r->blk[0]); free(r->blk[1]);
+}
+
+int dx_file_pack2_stream(dx_ctx *ctx, int arrow, dx_read_fn rd_, void *ruser_, size_t chunk,
                          dx_sink_fn sink, void *suser, size_t *out_len, uint64_t *errline, int *errcode)
 { uint8_t *buf = NULL;
+  readahead ra;
+  dx_read_fn rd = ra_read;
+  void      *ruser = &ra;
   size_t   cap, have = 0, total = 0;
   uint64_t lines = 0;
   int32_t  well = 0;
   int      eof = 0, first = 1, rc = DX_OK;
 
-  if (ctx == NULL || rd == NULL || sink == NULL) return DX_E_ARG;
+  if (ctx == NULL || rd_ == NULL || sink == NULL) return DX_E_ARG;
   if (chunk == 0) chunk = (size_t) dx_test_num("stream_chunk", (long long) 256 << 20);
   if (chunk < 4096) chunk = 4096;
   cap = chunk + 65536;
   buf = malloc(cap);
   if (buf == NULL) return DX_E_NOMEM;
+  ra_begin(&ra, rd_, ruser_);
   if (out_len) *out_len = 0;
   for (;;)
     { size_t cut, k, heads = 0;
@@ -330,6 +428,7 @@ int dx_file_pack2_stream(dx_ctx *ctx, int arrow, dx_read_fn rd, void *ruser, siz
     }
   if (out_len) *out_len = total;
 done:
+  ra_end(&ra);
   free(buf);
   return rc;
 }
