@@ -375,14 +375,16 @@ __host__ __device__ __forceinline__ uint32_t tok_room(uint32_t L, uint32_t fr8)
 { return (((uint32_t) (((uint64_t) L * fr8) >> 8) + 64u + TOK_XMARGIN) + 7u) & ~7u; }
 
 // run length of exception token `idx` of a line: bisection over its nx records (ascending token index)
-__device__ __forceinline__ uint32_t tok_exception(const uint32_t *slot_end, uint32_t nx, uint32_t idx)
+__device__ __forceinline__ uint32_t tok_exception_at(const uint32_t *slot_end, uint32_t nx, uint32_t idx)      // which record
 { uint32_t lo = 0, hi = nx;
   while (lo < hi)
     { const uint32_t mid = (lo + hi) >> 1;
       if (*(slot_end - 2 * (int) mid - 2) < idx) lo = mid + 1; else hi = mid;
     }
-  return *(slot_end - 2 * (int) lo - 1);
+  return lo;
 }
+__device__ __forceinline__ uint32_t tok_exception(const uint32_t *slot_end, uint32_t nx, uint32_t idx)
+{ return *(slot_end - 2 * (int) tok_exception_at(slot_end, nx, idx) - 1); }
 
 // does this entry have to be encoded from the text (generic kernel)?  info: the n x 4 words k_qv_hist left
 __device__ __forceinline__ bool tok_unusable(const uint32_t *info, uint64_t r, int delChar, int subChar)
@@ -689,6 +691,27 @@ __device__ __forceinline__ uint32_t hist_copies_of(uint32_t k)
 { return k < HIST_W_PLAIN ? HC_PLAIN : (k < HIST_W_PLAIN + HIST_W_RSYM ? HC_RSYM : HC_RUN); }
 
 // ---------------------------------------------------------------------------------------------
+//  an entry's words, asked for in one go and an entry ahead
+// ---------------------------------------------------------------------------------------------
+// What a wave has to know of an entry before it can ask for a byte of it (its length, where its text and its tokens lie, ...) sits
+// in half a dozen arrays.  Asked for one after the other where they are needed, those words are a chain of dependent waits at every
+// entry's start (see k_qv_encode_fast); instead lane k asks for word k -- ONE load instruction, the arrays' bases and strides from a
+// small table in LDS -- and asks an entry ahead; each word is read where it is needed by v_readlane.
+struct meta_row { const uint8_t *base; uint32_t stride, pad; };
+
+__device__ __forceinline__ uint32_t meta_load(const meta_row *s_meta, uint32_t words, uint64_t r)
+{ uint32_t v = 0;
+  const uint32_t lane = (uint32_t) lane_id();
+  if (lane < words)
+    { const meta_row m = s_meta[lane];
+      v = *(const uint32_t *) (m.base + r * m.stride);
+    }
+  return v;
+}
+#define META(m, k)   ((uint32_t) __builtin_amdgcn_readlane((int) (m), (int) (k)))
+#define META64(m, k) ((uint64_t) META(m, k) | ((uint64_t) META(m, (k) + 1) << 32))
+
+// ---------------------------------------------------------------------------------------------
 //  the scan state on the device (dx_qv_scan)
 // ---------------------------------------------------------------------------------------------
 // dx_qv_prescan hands delChar / subChar to the host, which hands them to dx_qv_hist's kernels as arguments: a round trip,
@@ -768,29 +791,50 @@ void k_qv_hist(qv_args a, uint64_t entry0, long long del_first, long long sub_fi
   uint32_t *const hr4 = OT ? &Wo->pr[1][0][(uint32_t) lane & (PRC - 1)] : &runp[1][0][(uint32_t) lane & (HC_RUN - 1)];
   const uint32_t  rc0 = (uint32_t) (a.delChar & 0xff) * 0x01010101u, rc4 = (uint32_t) (a.subChar & 0xff) * 0x01010101u;
 
+  // the entry's words (meta_load): 0 its length, 1 2 its text's offset, 3 .. 6 its token slot's start and end, 7 its index in the file's batch
+#define HM_WORDS 8u
+  __shared__ __attribute__((aligned(16))) meta_row s_meta[HM_WORDS];
+  if (tid < (int) HM_WORDS)
+    { meta_row m;
+      if      (tid == 0) { m.base = (const uint8_t *) a.len;                   m.stride = 4u; }
+      else if (tid < 3)  { m.base = (const uint8_t *) a.off + 4 * (tid - 1);   m.stride = 8u; }
+      else if (tid < 7)  { m.base = (const uint8_t *) ts.off + 4 * (tid - 3);  m.stride = 8u; }
+      else               { m.base = (const uint8_t *) orig;                    m.stride = 4u; }
+      if ((tid >= 3 && tid < 7 && !(FAST || ts.del != NULL)) || (tid == 7 && orig == NULL))
+        { m.base = (const uint8_t *) a.len; m.stride = 0u; }      // (no such array in this launch: any word)
+      m.pad = 0;
+      s_meta[tid] = m;
+    }
   for (uint32_t k = tid; k < nwords; k += HIST_BLOCK) words[k] = 0;
   __syncthreads();
 
   uint64_t tot = 0, since = 0;
+  uint32_t mpre = 0;                                   // the words of entry mfor
+  uint64_t mfor = ~0ull;
   for (uint64_t r0 = next_unit(ticket, a.units), nxt; r0 < a.n; r0 = nxt)
   { nxt = next_unit(ticket, a.units);                  // drawn early: the atomic's latency hides behind these entries
     for (uint64_t r = r0; r < r0 + a.units && r < a.n; r++)
-    { const uint32_t  L = a.len[r];
-      const long long g = (long long) (entry0 + (orig ? (uint64_t) orig[r] : r));
+    { const uint32_t mw = mfor == r ? mpre : meta_load(s_meta, HM_WORDS, r);      // (not asked for ahead: a wave's first entry)
+      { const uint64_t rn = r + 1 < r0 + a.units && r + 1 < a.n ? r + 1 : nxt;
+        mfor = rn;
+        if (rn < a.n) mpre = meta_load(s_meta, HM_WORDS, rn);
+      }
+      const uint32_t  L = META(mw, 0);
+      const long long g = (long long) (entry0 + (orig ? (uint64_t) META(mw, 7) : r));
       const bool drun = FAST || (a.delChar >= 0 && (toks || g >= del_first));      // tokenised (and, from del_first on, run-histogrammed)
       const bool srun = FAST || (a.subChar >= 0 && (toks || g >= sub_first));
       const uint32_t dinc = (a.delChar >= 0 && g >= del_first) ? 1u : 0u, sinc = (a.subChar >= 0 && g >= sub_first) ? 1u : 0u;
-      const uint8_t *p0 = line_ptr(a, r, L, 0), *p2 = line_ptr(a, r, L, 2);
-      const uint8_t *p3 = line_ptr(a, r, L, 3), *p4 = line_ptr(a, r, L, 4);
-      const uint8_t *p1 = line_ptr(a, r, L, 1);
+      const uint8_t *p0 = a.text + META64(mw, 1);     // line_ptr(a, r, L, 0 .. 4)
+      const uint64_t pitch = (uint64_t) L + a.pad;
+      const uint8_t *p1 = p0 + pitch, *p2 = p1 + pitch, *p3 = p2 + pitch, *p4 = p3 + pitch;
       const bool over = can_overread(a, p4, L);       // p4 is the last line of the entry
       uint32_t C0 = 0, C4 = 0, n0 = 0, n4 = 0;
       uint16_t *tk0 = NULL, *tk4 = NULL;
       uint32_t  nt0 = 0, nt4 = 0, room = 0, bad0 = 0, bad4 = 0, nx0 = 0, nx4 = 0;
       tok_pend  pd0 = { 0ull, 0u, 0u }, pd4 = { 0ull, 0u, 0u };
       if (toks)
-        { const uint64_t t0 = ts.off[r];
-          room = (uint32_t) (ts.off[r + 1] - t0) - TOK_XMARGIN;
+        { const uint64_t t0 = META64(mw, 3);
+          room = (uint32_t) (META64(mw, 5) - t0) - TOK_XMARGIN;
           if (drun) tk0 = ts.del + t0;
           if (srun) tk4 = ts.sub + t0;
         }

@@ -29,34 +29,39 @@ struct tok_src
 // the window; with TAGS the lanes' 2-bit tag fields go into the tag window the same way.
 // gix (group index, dx_qv_subindex): the line's header word; groups: one word per lane and pass.
 // xend / nx: the line's exception list (runs of 127 and more: see "token hand-over"); XC = the line has exceptions
-// (nx is wave-uniform: a line without any runs the instance without a single instruction for them).  With exceptions a lane looks up the run of
-// its (one) exception token by bisection and swaps it in for the field's 127; a lane with two of them among its
-// tokens -- two runs of >= 127 within 8 tokens -- sends the pass to the token-by-token path.
+// (nx is wave-uniform: a line without any runs the instance without a single instruction for them).  With exceptions a lane finds the
+// record of its first exception token by counting the exception tokens in front of it (the list is in token order); the records of the
+// others among its tokens follow it in the list, and each run is swapped in for its field's 127.  (Round 5 sent a pass with two exceptions in one lane to the
+// token-by-token path: rare at a run density of 0.85, three passes in four at 0.99, where 28 % of the tokens have a run of >= 127
+// in front -- that batch's encoder took 15.7 ms instead of 10.)
+// per: the tokens of a pass -- 64 * TOK_TP, or fewer (a multiple of 64) for a line whose codes are long: a lane's string has to
+// fit 128 bits or the whole pass is placed token by token, and at 13 bits a token eight of them do not, in one lane of 64 or another.
 template <bool TAGS, bool XC>
 __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, const uint16_t *tok, uint32_t cnt,
                                                   const uint32_t *ntab, const uint32_t *rtab,
                                                   const uint32_t *nstab, const uint32_t *rstab, uint32_t *gix, uint32_t *groups,
-                                                  uint32_t *none_count, const uint32_t *xend, uint32_t nx)
+                                                  uint32_t *none_count, const uint32_t *xend, uint32_t nx, uint32_t per)
 { const uint32_t lane = (uint32_t) lane_id();
   uint32_t *g16 = gix ? groups + lane : (uint32_t *) NULL;
   uint32_t  wide = 0;                                              // a group that does not fit its 16 bits
   // a pass's tokens are requested a pass ahead, and the windows are drained at the start of a pass behind that request
   // (see FOR_EACH_ROUND_LATE): loads and stores then have a pass to complete in
 #define TOK_PASS(K0, M_, T_, FIRST_, C_)                                                                   \
-      const uint32_t M_     = cnt - (K0) < 64u * TOK_TP ? cnt - (K0) : 64u * TOK_TP;                        \
+      const uint32_t M_     = cnt - (K0) < per ? cnt - (K0) : per;                                          \
       const uint32_t T_     = (M_ + 63u) >> 6;                     /* tokens per lane in this pass (wave-uniform) */ \
       const uint32_t FIRST_ = (K0) + lane * T_;                                                             \
       const uint32_t C_     = FIRST_ < (K0) + M_ ? ((K0) + M_ - FIRST_ < T_ ? (K0) + M_ - FIRST_ : T_) : 0u;
   u32x4 tw = { 0u, 0u, 0u, 0u };
+  uint32_t xbase = 0;                                              // exception tokens of the passes before
   if (cnt)
     { TOK_PASS(0u, m0, T0, first0, c0)
       if (c0) tw = *(const u32x4_u *) (tok + first0);              // (may read up to 7 tokens past the count: inside the padded buffer)
     }
-  for (uint32_t k0 = 0; k0 < cnt; k0 += 64u * TOK_TP)
+  for (uint32_t k0 = 0; k0 < cnt; k0 += per)
     { TOK_PASS(k0, m, T, first, c)
       u32x4 twn = { 0u, 0u, 0u, 0u };
-      if (k0 + 64u * TOK_TP < cnt)
-        { TOK_PASS(k0 + 64u * TOK_TP, mn, Tn, firstn, cn)
+      if (k0 + per < cnt)
+        { TOK_PASS(k0 + per, mn, Tn, firstn, cn)
           if (cn) twn = *(const u32x4_u *) (tok + firstn);
         }
       if (o.winbits >= QV_FLUSH_BITS) flush_quads(o, false);
@@ -68,20 +73,30 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           rt[k] = rstab[t16 >> 9];                                 // QV.c:479-487 (runs below TOK_RUN_MAX: no clamp needed)
           st[k] = *(const uint32_t *) ((const uint8_t *) nstab + (t16 & 0x1fcu));
         }
-      uint32_t xk = TOK_TP, xr = 0, xn = 0;                        // this lane's exception token: which, its run; how many it has
+      uint32_t xmask = 0, xi0 = 0, xtra = 0;                       // this lane's exception tokens: which; the first one's record; their runs beyond 127
+#define TOK_XRUN(k) (*(xend - 2 * (int) (xi0 + (uint32_t) __builtin_popcount(xmask & ((1u << (k)) - 1u)) < nx ? xi0 + (uint32_t) __builtin_popcount(xmask & ((1u << (k)) - 1u)) : nx - 1u) - 1))
       if (XC)
         {
           #pragma unroll
           for (int k = 0; k < (int) TOK_TP; k++)
             { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
-              if ((uint32_t) k < c && (t16 >> 9) == TOK_RUN_MAX) { xk = (uint32_t) k; xn += 1u; }
+              if ((uint32_t) k < c && (t16 >> 9) == TOK_RUN_MAX) xmask |= 1u << k;
             }
-          if (xn)
-            { xr = tok_exception(xend, nx, first + xk);
-              const uint32_t e = rstab[xr > 255u ? 255u : xr];     // QV.c:479-482
+          // (the list is in token order and so are the lanes: a lane's first record is the number of exception tokens in front of it --
+          //  a prefix sum over the wave, not a bisection's seven dependent loads)
+          { const uint32_t xc = (uint32_t) __builtin_popcount(xmask), xin = wave_incl_scan(xc);
+            xi0 = xbase + xin - xc;
+            xbase += wave_total(xin);
+          }
+          if (xmask)
+            {
               #pragma unroll
               for (int k = 0; k < (int) TOK_TP; k++)
-                if ((uint32_t) k == xk) rt[k] = e;
+                if ((xmask >> k) & 1u)
+                  { const uint32_t xr = TOK_XRUN(k);
+                    rt[k] = rstab[xr > 255u ? 255u : xr];          // QV.c:479-482
+                    xtra += xr - TOK_RUN_MAX;
+                  }
             }
         }
       // the lengths first: a wave none of whose lanes has more than 96 bits (and no run with a literal) chains into three words, not four
@@ -90,13 +105,13 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
       for (int k = 0; k < (int) TOK_TP; k++)
         if ((uint32_t) k < c)
           { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
-            const uint32_t run = XC && (uint32_t) k == xk ? xr : t16 >> 9;
-            span += run + 1u;
+            span += (t16 >> 9) + 1u;
             nb   += 64u - (rt[k] & 0x3fu) - (st[k] & 0xffu) + ((rt[k] & 0x80u) ? 16u : 0u);
             zor  |= rt[k] | st[k];
             if (TAGS)
               tacc = (tacc << 2) | (t16 & 3u);
           }
+      span += xtra;
       const bool narrow96 = FAST_CHAIN96 && !__any((int) ((zor & 0x80u) | (nb > 96u)));
       if (narrow96)
         {
@@ -113,27 +128,15 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
           for (int k = 0; k < (int) TOK_TP; k++)
             if ((uint32_t) k < c)
               { const uint32_t t16 = (k & 1) ? chunk_word(tw, k >> 1) >> 16 : chunk_word(tw, k >> 1) & 0xffffu;
-                const uint32_t run = XC && (uint32_t) k == xk ? xr : t16 >> 9;
                 STOK_APPEND(rt[k])
                 if (rt[k] & 0x80u)                                 // escaped run: its 16-bit literal follows (QV.c:486-487)
-                  { const uint32_t lit = (run << 16) | 16u;
+                  { const uint32_t run = XC && ((xmask >> k) & 1u) ? TOK_XRUN(k) : t16 >> 9;
+                    const uint32_t lit = (run << 16) | 16u;
                     STOK_APPEND(lit)
                     w0 |= run & 0xffff0000u;                       // OCODE(16, run) with run >= 2^16 (QV.c:411, 420)
                   }
                 STOK_APPEND(st[k])
               }
-        }
-      if (XC && xn > 1u)                                           // two exception tokens in one lane: its bits counted token by token
-        { nb = 0; span = 0; zor |= 64u;                            // (and the pass placed token by token, below; bit 6 is free in every
-                                                                   //  token: unlike bit 5 -- something has no code -- it leaves the line its index)
-          for (uint32_t j = 0; j < c; j++)
-            { const uint32_t t16 = tok[first + j];
-              uint32_t run = t16 >> 9;
-              if (run == TOK_RUN_MAX) run = tok_exception(xend, nx, first + j);
-              const uint32_t re = rtab[run > 255u ? 255u : run], se = ntab[(t16 >> 2) & 0x7fu];
-              nb   += TOK_LEN(re) + (TOK_ESC(re) ? 16u : 0u) + TOK_LEN(se);
-              span += run + 1u;
-            }
         }
       const uint32_t incl = wave_incl_scan(nb);
       if (g16)
@@ -183,6 +186,7 @@ __device__ __forceinline__ void encode_token_line(wave_out &o, wave_out &ot, con
       tw = twn;
     }
 #undef TOK_PASS
+#undef TOK_XRUN
   if (gix)
     { const bool none = __any((int) wide) != 0;
       if (lane == 0)
@@ -446,6 +450,21 @@ __device__ __forceinline__ void entry_sizes_fast(const qv_args &a, uint64_t r, u
 #ifndef FAST_VGPR_CAP
 #define FAST_VGPR_CAP __attribute__((amdgpu_num_vgpr(112)))
 #endif
+// What the encoder has to know of an entry before it can ask for a byte of it -- its length, where its text, its tokens, its record,
+// its header lie, its five sizes, the hist pass's six words about its tokens: 26 words from six arrays.  Asked
+// for one after the other where they are needed they were a chain of six dependent waits at every entry's start (tokens usable? ->
+// record inside the output? -> length and offsets -> header offsets -> header bytes ...), 3 us of an entry's 11 (1 M entries of 10 kb:
+// 2.7 of the kernel's 11.2 ms; 2 M of 2 kb: 5.4 of 9.5).  Now lane k < 26 asks for word k -- ONE load instruction, the arrays' bases
+// and strides from a table in LDS -- and asks an entry ahead: by the time the wave gets there the words have long arrived, and each is
+// read where it is needed by v_readlane.
+#define META_INFO  0      // .. 5: the info words 0 .. 5
+#define META_LEN   6
+#define META_OFF   7      // 7, 8: a.off[r]
+#define META_TOFF  9      // 9 .. 12: tk.off[r], tk.off[r + 1]
+#define META_SEG  13      // .. 17
+#define META_REC  18      // 18 .. 21: rec_off[r], rec_off[r + 1]
+#define META_HDR  22      // 22 .. 25: hdr_off[r], hdr_off[r + 1]
+#define META_WORDS 26
 template <bool SUB>
 __global__ __launch_bounds__(FAST_BLOCK, FAST_WAVES) FAST_VGPR_CAP
 void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off, uint32_t *status, uint32_t *ticket,
@@ -458,6 +477,22 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   __shared__ uint8_t  s_tagcode[256];
   __shared__ __attribute__((aligned(16))) uint32_t s_win[FAST_NWAVE][QV_WIN_PAD + QV_WIN_WORDS];   // (the pad: see place_bits128)
   __shared__ __attribute__((aligned(16))) uint32_t s_tag[FAST_NWAVE][TAG_WIN_WORDS];
+  __shared__ __attribute__((aligned(16))) meta_row s_meta[META_WORDS];
+  if (threadIdx.x < META_WORDS)
+    { const uint32_t k = threadIdx.x;
+      meta_row m;
+      if      (k < META_LEN)  { m.base = (const uint8_t *) tk.info + 4u * k;               m.stride = 4u * TOK_INFO; }
+      else if (k == META_LEN) { m.base = (const uint8_t *) a.len;                         m.stride = 4u; }
+      else if (k < META_TOFF) { m.base = (const uint8_t *) a.off + 4u * (k - META_OFF);   m.stride = 8u; }
+      else if (k < META_SEG)  { m.base = (const uint8_t *) tk.off + 4u * (k - META_TOFF); m.stride = 8u; }
+      else if (k < META_REC)  { m.base = (const uint8_t *) seg + 4u * (k - META_SEG);     m.stride = 20u; }
+      else if (k < META_HDR)  { m.base = (const uint8_t *) rec_off + 4u * (k - META_REC); m.stride = 8u; }
+      else                    { m.base = (const uint8_t *) hdr_off + 4u * (k - META_HDR); m.stride = 8u; }
+      if (k >= META_HDR && (hdr == NULL || hdr_off == NULL))
+        { m.base = (const uint8_t *) a.len; m.stride = 0u; }          // (no such array in this launch: any word)
+      m.pad = 0;
+      s_meta[k] = m;
+    }
   load_tables(s_tok, g_tok);
   load_shift_tables(s_stok, s_tagcode, g_tok);
   build_pair_tables(s_pair, s_stok, pair_lo_ins, pair_lo_mrg);
@@ -475,48 +510,60 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
   // (a kernel doing nothing but drawing its 500 k tickets takes 5.8 ms), so a million single draws are 11 ms of the
   // counter's time inside a 13.7 ms kernel.
   const uint32_t TB = a.units;
+  uint32_t mpre = 0;                                     // the words of entry mfor (see meta_load)
+  uint64_t mfor = ~0ull;
   for (uint64_t r0 = next_unit(ticket, TB), nxt = 0; r0 < a.n; r0 = nxt)
   { nxt = next_unit(ticket, TB);
   for (uint64_t r = r0; r < r0 + TB && r < a.n; r++)
-    {
-      if (tok_unusable(tk.info, r, a.delChar, a.subChar))
+    { // (SUB, the instance that also writes the group index, has no register left for any of this: it asks as it goes, as before)
+      uint32_t mw = 0;
+      if (!SUB)
+        { mw = mfor == r ? mpre : meta_load(s_meta, META_WORDS, r);   // (not asked for ahead: a wave's first entry)
+          const uint64_t rn = r + 1 < r0 + TB && r + 1 < a.n ? r + 1 : nxt;
+          mfor = rn;
+          if (rn < a.n) mpre = meta_load(s_meta, META_WORDS, rn);
+        }
+#define INF(k)  (SUB ? tk.info[TOK_INFO * r + (k)] : META(mw, META_INFO + (k)))
+#define SG(k)   (SUB ? seg[5u * r + (k)] : META(mw, META_SEG + (k)))
+      if ((a.delChar >= 0 && (INF(0) & TOK_BAD)) || (a.subChar >= 0 && (INF(1) & TOK_BAD)))       // tok_unusable
         continue;                                        // the generic kernel encodes this entry from the text
       // The sizes are known (k_qv_sizes_hist, k_qv_sizes_fast): the record is written where it belongs -- framing bytes, del
       // words, tag bytes, ins, mrg, sub words (QV.c:1393-1423) -- and every size is checked.
-      const uint32_t  L      = a.len[r];
-      const uint32_t *inf    = tk.info + TOK_INFO * r;
-      const uint64_t  toff   = tk.off[r];
+      const uint32_t  L      = SUB ? a.len[r] : META(mw, META_LEN);
+      const uint64_t  toff   = SUB ? tk.off[r] : META64(mw, META_TOFF);
+      const uint8_t  *ebase  = a.text + (SUB ? a.off[r] : META64(mw, META_OFF));
+#define tend (SUB ? tk.off[r + 1] : META64(mw, META_TOFF + 2))
+#define ELINE(k) (ebase + (uint64_t) (k) * ((uint64_t) L + a.pad))            /* line_ptr(a, r, L, k) */
 #if FAST_GUARDS
       { // the entry inside the text, its token slot as k_tok_rooms laid it out, the counts inside the slot: else report and
         // skip (see entry_sane).  Off by default: the branch makes the wave wait for ALL of an entry's index words before its
         // first data load goes out -- one more memory round trip per entry, 0.6 ms of the 13.7 a 1 M-entry batch takes
         // (measured); the generic kernel (the odd entries) has them
-        const uint64_t room = tk.off[r + 1] - toff;
+        const uint64_t room = tend - toff;
         const bool ok = entry_sane(a, r, L) && room >= 64u + TOK_XMARGIN &&
-                        (inf[0] & ~TOK_BAD) <= room && (inf[1] & ~TOK_BAD) <= room && inf[4] <= room / 4u && inf[5] <= room / 4u;
+                        (INF(0) & ~TOK_BAD) <= room && (INF(1) & ~TOK_BAD) <= room && INF(4) <= room / 4u && INF(5) <= room / 4u;
         if (!ok)
           { if (lane == 0) atomicOr(status, DX_ST_INDEX);
             continue;
           }
       }
 #endif
-      const uint32_t *sg     = seg + 5 * r;
       uint8_t        *dst, *tag_at;
-      if (rec_off[r + 1] > out_cap)                      // d_out is too small: report, never overrun
+      if ((SUB ? rec_off[r + 1] : META64(mw, META_REC + 2)) > out_cap)            // d_out is too small: report, never overrun
         { if (lane == 0) atomicOr(status, 8u);
           continue;
         }
-      dst = out + rec_off[r];
+      dst = out + (SUB ? rec_off[r] : META64(mw, META_REC));
       if (hdr != NULL)                                   // record framing (dexqv.c:128-139)
-        { const uint64_t h0 = hdr_off[r];
-          const uint32_t hl = (uint32_t) (hdr_off[r + 1] - h0);
+        { const uint64_t h0 = SUB ? hdr_off[r] : META64(mw, META_HDR);
+          const uint32_t hl = (uint32_t) ((SUB ? hdr_off[r + 1] : META64(mw, META_HDR + 2)) - h0);
           for (uint32_t k = (uint32_t) lane; k < hl; k += 64)
             dst[k] = hdr[h0 + k];
           dst += hl;
         }
-      tag_at = dst + sg[0];
-      const uint8_t  *p1     = line_ptr(a, r, L, 1);
-      const bool      over   = can_overread(a, line_ptr(a, r, L, 4), L);
+      tag_at = dst + SG(0);
+      const uint8_t  *p1     = ELINE(1);
+      const bool      over   = can_overread(a, ELINE(4), L);
       uint32_t        bad    = 0;
 
       // The four QV streams in file order: del (its tag segment goes to the slot's end), ins, mrg, sub
@@ -528,7 +575,6 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
           const uint32_t *tab  = s_tok[q];
           o.seg = dst; o.wordbase = 0; o.winbits = 0;
           uint32_t got;
-
           if ((FAST_SKIP & 1) && rci >= 0) { got = 0; }
           else if ((FAST_SKIP & 2) && rci < 0) { got = 0; }
           else
@@ -536,26 +582,30 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
             { const int       rs   = q == 0 ? DX_DRUN : DX_SRUN;
               const uint32_t *rtab = s_tok[rs];
               const uint16_t *tok  = (q == 0 ? tk.del : tk.sub) + toff;
-              const uint32_t  cnt  = inf[q == 0 ? 0 : 1] & ~TOK_BAD;
-              const uint32_t  C    = inf[q == 0 ? 2 : 3];           // run left open at the line's end
+              const uint32_t  cnt  = INF(q == 0 ? 0 : 1) & ~TOK_BAD;
+              const uint32_t  C    = INF(q == 0 ? 2 : 3);           // run left open at the line's end
               ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
               uint32_t *gix = NULL, *grp = NULL;           // group index: header word and group words of this line
               if (SUB && sx.idx)
                 { uint32_t *base = sx.idx + sx.off[r] + run_base(L);
-                  const uint32_t pd = (inf[0] & TOK_BAD) ? 0u : run_passes(inf[0]);     // (as k_sub_rooms laid it out)
+                  const uint32_t pd = (INF(0) & TOK_BAD) ? 0u : run_passes(INF(0));     // (as k_sub_rooms laid it out)
                   gix = base + (q == 0 ? 0u : 1u);
                   grp = base + 3u + (q == 0 ? 0u : 64u * pd);
                   if (lane == 0) base[2] = pd;
                 }
-              const uint32_t *xend = (const uint32_t *) ((q == 0 ? tk.del : tk.sub) + tk.off[r + 1]);      // the slot's end
-              const uint32_t  nx   = inf[q == 0 ? 4 : 5];
+              const uint32_t *xend = (const uint32_t *) ((q == 0 ? tk.del : tk.sub) + tend);      // the slot's end
+              const uint32_t  nx   = INF(q == 0 ? 4 : 5);
+              // tokens a pass: eight a lane while the line's codes average <= 10 bits a token (its size is known), four up to 20, else
+              // two (see encode_token_line); the group index is laid out for eight
+              const uint32_t  lb   = SG(line);
+              const uint32_t  per  = gix != NULL || 4u * lb <= 5u * cnt ? 64u * TOK_TP : (2u * lb <= 5u * cnt ? 32u * TOK_TP : 16u * TOK_TP);
               if (nx == 0)
-                { if (q == 0) encode_token_line<true,  false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, 0u);
-                  else        encode_token_line<false, false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, 0u);
+                { if (q == 0) encode_token_line<true,  false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, 0u, per);
+                  else        encode_token_line<false, false>(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, 0u, per);
                 }
               else
-                { if (q == 0) encode_token_line<true,  true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx);
-                  else        encode_token_line<false, true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx);
+                { if (q == 0) encode_token_line<true,  true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx, per);
+                  else        encode_token_line<false, true >(o, ot, tok, cnt, tab, rtab, s_stok[q], s_stok[rs], gix, grp, sx.none, xend, nx, per);
                 }
               uint32_t last;
               if (C > 0)
@@ -569,12 +619,12 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               got = finish_words(o, last);
               if (q == 0)
                 { const uint32_t tb = finish_tags(ot);
-                  const uint32_t w1 = sg[1];
+                  const uint32_t w1 = SG(1);
                   bad |= tb ^ w1; dst += w1;
                 }
             }
           else                                           // Encode
-            { const uint8_t *p    = line_ptr(a, r, L, line);
+            { const uint8_t *p    = ELINE(line);
               const uint32_t mask = !a.lossy ? 0xffu : (q == 1 ? 0xfeu : (q == 2 ? 0xfcu : 0xffu));   // QV.c:1406-1415
               const uint32_t m4   = mask * 0x01010101u;
               uint32_t pos = 16u * lane;
@@ -622,15 +672,19 @@ void k_qv_encode_fast(qv_args a, const uint32_t *g_tok, const uint64_t *hdr_off,
               if (q == 0)                                // no delChar: the whole tag line is packed
                 { ot.seg = tag_at; ot.wordbase = 0; ot.winbits = 0;
                   const uint32_t tb = encode_all_tags(ot, p1, L, over);
-                  const uint32_t w1 = sg[1];
+                  const uint32_t w1 = SG(1);
                   bad |= tb ^ w1; dst += w1;
                 }
             }
-          bad |= got ^ sg[line];
+          bad |= got ^ SG(line);
           dst += got;
         }
       if (bad && lane == 0 && !FAST_SKIP)
         atomicOr(status, 2u);                            // a size differs from what the size kernel computed
+#undef SG
+#undef ELINE
+#undef INF
+#undef tend
     }
   }
 }

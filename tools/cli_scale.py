@@ -113,13 +113,22 @@ for kind, pack, unpack, ext, px, uflags in (("quiva", "dexqv", "undexqv", ".quiv
         with open(os.path.join(D, "s" + ext), "rb") as fi, open(os.path.join(D, "piped" + px), "wb") as fo:
             cat = subprocess.Popen(["cat"], stdin=fi, stdout=subprocess.PIPE)
             child = subprocess.Popen([os.path.join(BIN, pack), "-i"], stdin=cat.stdout, stdout=fo, stderr=subprocess.DEVNULL)
-            _, status, ru = os.wait4(child.pid, 0)             # (this child's own resource usage: its peak resident set)
-            child.returncode = os.waitstatus_to_exitcode(status)
+            # the tool's peak resident set: VmHWM of ITS address space, polled while it runs (wait4's ru_maxrss will not do: a child's
+            # figure starts from what it held between fork and exec -- this Python process's gigabytes of torch, copy on write)
+            hwm = 0
+            while child.poll() is None:
+                try:
+                    with open("/proc/%d/status" % child.pid) as st:
+                        for l in st:
+                            if l.startswith("VmHWM"): hwm = max(hwm, int(l.split()[1]))
+                except OSError:
+                    pass
+                time.sleep(0.02)
             cat.wait()
         dt = time.perf_counter() - t1
         res["runs"][pack + "_pipe"] = [{"s": round(dt, 3), "GBps": round(size / dt / 1e9, 2), "exit": child.returncode,
                                         "same_bytes_as_the_file_mode": child.returncode == 0 and same("piped" + px, "s" + px),
-                                        "max_rss_MB": round(ru.ru_maxrss / 1024, 1), "marks_ms": []}]
+                                        "max_rss_MB": round(hwm / 1024, 1), "marks_ms": []}]
         log(pack, "-i", res["runs"][pack + "_pipe"])
         os.unlink(os.path.join(D, "piped" + px))
     os.unlink(os.path.join(D, "s" + ext))
