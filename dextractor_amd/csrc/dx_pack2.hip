@@ -41,7 +41,7 @@
                                          // profiles/r03_ab_pack2.txt; more stores in flight per wave do not help this write-bound kernel)
 #endif
 #ifndef P2D_PIPE
-#define P2D_PIPE      1                  // k_pack2_decode: hand-pipelined main loop (0: every step through the checked loop)
+#define P2D_PIPE      3                  // k_pack2_decode: hand-pipelined main loop, the requests this many steps ahead (0: every step through the checked loop)
 #endif
 #ifndef P2E_OVER
 #define P2E_OVER      1                  // k_pack2_encode: a read's last, partial chunk by one 16-byte load when text follows it in the buffer
@@ -54,6 +54,9 @@
                                          // 10 M x 10 kb (profiles/r03d_perturb_pack2_decode.txt): 32.3 ms; 1: 15.2; 2: 29.0; 3: 9.5 -- the parts ADD UP: the
                                          // loads and the letters of one wave do not run beside the stores of another.  Loads issued three steps ahead
                                          // (three stores in flight per wave, vmcnt(5)): 31.7-32.4 against 32.1-33.6, and 73 registers -- not kept.
+#endif
+#if P2D_PIPE >= 2 && (P2D_SKIP & 1)
+#error "the pipelined loops count their memory operations by hand (one load, one store a step): no P2D_SKIP & 1 with P2D_PIPE >= 2"
 #endif
 #ifndef P2D_ALIGN
 #define P2D_ALIGN     1                  // k_pack2_decode: a read's text as if it began (its address mod 16) bytes earlier, so that every 16-byte store of the
@@ -335,6 +338,113 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
             if (!(P2D_SKIP & 1)) *(u32x4_u *) (dst + q0) = v;                                                \
             else if (v.x == 0x12345678u) dst[q0] = 1;                                                        \
           }
+#if P2D_PIPE == 3
+      // Three steps ahead (see the two-steps-ahead loop below for the scheme): what a wave may have in flight is what bounds it -- a wait
+      // for a load is a wait for every older store as well (one counter, in order), and the stores of a kernel that writes 100 GB take
+      // 4 us to be acknowledged: d steps ahead is d stores in flight.  A turn waits for all but the 2 d youngest operations.
+      if (P2D_ALLFAST(0u) && P2D_ALLFAST(DX_STEP) && P2D_ALLFAST(2u * DX_STEP))
+        { uint32_t lineA = line, colA = col, lineB = line, colB = col, lineC, colC, lineD, colD;
+          P2D_ADVANCE(lineB, colB)
+          lineC = lineB; colC = colB;
+          P2D_ADVANCE(lineC, colC)
+#define P2D_ASK(R, B, LN) { const uint8_t *a_ = src + ((P2D_PRE(B) ? 0u : (B) + 16u * (uint32_t) lane - adj - (LN)) >> 2); \
+                            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(R) : "v"(a_) : "memory"); }
+#define P2D_ARRIVED(R)    asm volatile("" : "+v"(R) : : "memory");
+          uint64_t rawA, rawB, rawC, rawD = 0;
+          P2D_ASK(rawA, 0u, lineA)
+          P2D_ASK(rawB, DX_STEP, lineB)
+          P2D_ASK(rawC, 2u * DX_STEP, lineC)
+          int      left = 0;
+          // (X: the step at base; Y: the newest requested, base + 2 steps; Z: takes the request for base + 3 steps)
+#define P2D_TURN(X, Y, Z, WAIT, OUT)                                                                              \
+          { const bool ok = P2D_ALLFAST(base + 3u * DX_STEP);        /* wave-uniform */                          \
+            line##Z = line##Y; col##Z = col##Y;                                                                 \
+            P2D_ADVANCE(line##Z, col##Z)                                                                        \
+            if (!ok) { left = OUT; break; }                                                                     \
+            P2D_ASK(raw##Z, base + 3u * DX_STEP, line##Z)                                                       \
+            __builtin_amdgcn_s_waitcnt(WAIT);                                                                   \
+            P2D_ARRIVED(raw##X)                                                                                 \
+            P2D_STEP_FAST(raw##X, base, line##X, col##X)                                                        \
+            base += DX_STEP;                                                                                    \
+          }
+          do
+            { P2D_TURN(A, C, D, 0x0F73, 0)                   // vmcnt(3): younger than A's load are B's, C's and D's
+              P2D_TURN(B, D, A, 0x0F74, 1)                   // vmcnt(4): ... and A's store
+              P2D_TURN(C, A, B, 0x0F75, 2)
+              for (;;)
+                { P2D_TURN(D, B, C, 0x0F76, 3)               // vmcnt(6): three loads and three stores
+                  P2D_TURN(A, C, D, 0x0F76, 0)
+                  P2D_TURN(B, D, A, 0x0F76, 1)
+                  P2D_TURN(C, A, B, 0x0F76, 2)
+                }
+            }
+          while (0);
+#undef P2D_TURN
+#undef P2D_ASK
+          // three steps are in flight or back: the one at base and the two behind it
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          P2D_ARRIVED(rawA) P2D_ARRIVED(rawB) P2D_ARRIVED(rawC) P2D_ARRIVED(rawD)
+#define P2D_DRAIN(X, Y, Z, W) { P2D_STEP_FAST(raw##X, base, line##X, col##X) base += DX_STEP; P2D_STEP_FAST(raw##Y, base, line##Y, col##Y) base += DX_STEP; \
+                                P2D_STEP_FAST(raw##Z, base, line##Z, col##Z) base += DX_STEP; line = line##W; col = col##W; }
+          if (left == 0)      P2D_DRAIN(A, B, C, D)
+          else if (left == 1) P2D_DRAIN(B, C, D, A)
+          else if (left == 2) P2D_DRAIN(C, D, A, B)
+          else                P2D_DRAIN(D, A, B, C)
+#undef P2D_DRAIN
+#undef P2D_ARRIVED
+        }
+#elif P2D_PIPE == 2
+      // Two steps ahead: a wave's step is as long as a request's way to memory and back under this kernel's load (2 us), so with the
+      // next step's request alone in flight every step ends in a wait.  Three registers in turn; a turn: [request step k + 2] [wait
+      // until all but the four youngest memory operations are back -- the store of step k - 2, the load of k + 1, the store of k - 1,
+      // the load of k + 2: the load of step k is the fifth] [16 letters] [store].  The first two turns have fewer stores in front
+      // (vmcnt 2, 3); when the steps that all lanes take the fast way run out, what is in flight is finished with plain waits.
+      if (P2D_ALLFAST(0u) && P2D_ALLFAST(DX_STEP))
+        { uint32_t lineA = line, colA = col, lineB = line, colB = col, lineC, colC;
+          P2D_ADVANCE(lineB, colB)
+          // (The requests are written in assembly: left to count them, the compiler loses the order where the loop's paths meet and
+          //  puts a wait for all but two in front of every wait written here -- one step ahead again.  It cannot see these loads, so it
+          //  waits for nothing; P2D_ARRIVED ties the register to the wait in front of it, so that nothing that reads it moves above.)
+#define P2D_ASK(R, B, LN) { const uint8_t *a_ = src + ((P2D_PRE(B) ? 0u : (B) + 16u * (uint32_t) lane - adj - (LN)) >> 2); \
+                            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(R) : "v"(a_) : "memory"); }
+#define P2D_ARRIVED(R)    asm volatile("" : "+v"(R) : : "memory");
+          uint64_t rawA, rawB, rawC = 0;
+          P2D_ASK(rawA, 0u, lineA)
+          P2D_ASK(rawB, DX_STEP, lineB)
+          int      left = 0;                                 // how the loop was left: which register holds the step at `base`
+          // (X: the step at base; Y: the one behind it; Z: takes the request for base + 2 steps)
+#define P2D_TURN(X, Y, Z, WAIT, OUT)                                                                              \
+          { const bool ok = P2D_ALLFAST(base + 2u * DX_STEP);        /* wave-uniform */                          \
+            line##Z = line##Y; col##Z = col##Y;                                                                 \
+            P2D_ADVANCE(line##Z, col##Z)                                                                        \
+            if (!ok) { left = OUT; break; }                                                                     \
+            P2D_ASK(raw##Z, base + 2u * DX_STEP, line##Z)                                                       \
+            __builtin_amdgcn_s_waitcnt(WAIT);                                                                   \
+            P2D_ARRIVED(raw##X)                                                                                 \
+            P2D_STEP_FAST(raw##X, base, line##X, col##X)                                                        \
+            base += DX_STEP;                                                                                    \
+          }
+          do
+            { P2D_TURN(A, B, C, 0x0F72, 0)                   // vmcnt(2): younger than A's load are B's and C's
+              P2D_TURN(B, C, A, 0x0F73, 1)                   // vmcnt(3): C's load, A's store, A's new load
+              for (;;)
+                { P2D_TURN(C, A, B, 0x0F74, 2)
+                  P2D_TURN(A, B, C, 0x0F74, 0)
+                  P2D_TURN(B, C, A, 0x0F74, 1)
+                }
+            }
+          while (0);
+#undef P2D_TURN
+#undef P2D_ASK
+          // two steps are in flight or back: the one at base and the one behind it
+          __builtin_amdgcn_s_waitcnt(0x0F70);
+          P2D_ARRIVED(rawA) P2D_ARRIVED(rawB) P2D_ARRIVED(rawC)
+          if (left == 0)      { P2D_STEP_FAST(rawA, base, lineA, colA) base += DX_STEP; P2D_STEP_FAST(rawB, base, lineB, colB) base += DX_STEP; line = lineC; col = colC; }
+          else if (left == 1) { P2D_STEP_FAST(rawB, base, lineB, colB) base += DX_STEP; P2D_STEP_FAST(rawC, base, lineC, colC) base += DX_STEP; line = lineA; col = colA; }
+          else                { P2D_STEP_FAST(rawC, base, lineC, colC) base += DX_STEP; P2D_STEP_FAST(rawA, base, lineA, colA) base += DX_STEP; line = lineB; col = colB; }
+#undef P2D_ARRIVED
+        }
+#else
       if (P2D_ALLFAST(0u))
         { uint32_t lineA = line, colA = col, lineB = line, colB = col;
           uint64_t rawA = P2D_LOAD(0u, lineA), rawB = 0;
@@ -360,6 +470,7 @@ void k_pack2_decode(const uint8_t *__restrict__ in, const uint64_t *__restrict__
               if (!ok) { line = lineA; col = colA; break; }
             }
         }
+#endif
 #undef P2D_STEP_FAST
 #undef P2D_LOAD
 #undef P2D_ADVANCE
