@@ -238,6 +238,28 @@ def test_dense_stretches_in_a_sparse_batch(ctx):
     assert ctx.undexqv(ctx.dexqv(c.text), upper=True).split(b"\n")[1::6] == c.text.split(b"\n")[1::6]
 
 
+def test_an_entry_of_a_million_symbols_with_one_insertion_value(ctx):
+    """An entry of 1.3 million symbols whose insertion and merge lines hold one value each: the wave's own counters (eight and four
+    copies a symbol, 64 additions a copy and step at most) take all of it, its 16-bit counters in memory are not used (the entry is
+    the text-reading kernels'), the workgroup's tables get the full counts.  Histogram and file as the oracle's."""
+    lens = np.array([1_300_000, 700, 70_000, 5], np.uint32)
+    c = synth.make_quiva(len(lens), seed=77, lens=lens)
+    txt = bytearray(c.text)
+    L, o = int(c.len[0]), int(c.off[0])
+    txt[o + 2 * (L + 1): o + 2 * (L + 1) + L] = b"7" * L            # the insertion line: one value
+    txt[o + 3 * (L + 1): o + 3 * (L + 1) + L] = b"9" * L            # ... and the merge line
+    c.text = bytes(txt)
+    st = O.qv_scan(c.text)
+    b, keep = _upload_quiva(ctx, c)
+    p = ctx.qv_prescan(b)
+    hist, tot = ctx.qv_hist(b, p)
+    want = O.hist_array(st)
+    want[4:6] -= 1
+    assert tot == st.totChar and (hist == want).all()
+    assert hist[1, ord("7")] >= L
+    assert ctx.dexqv(c.text) == O.dexqv(c.text)
+
+
 def test_qv_scan_wide_bytes_and_long_runs(ctx):
     """Bytes >= 128 and runs >= 64 leave the conflict-free 32-copy bins of k_qv_hist for its plain
     tables; the file still encodes byte-identically."""
